@@ -1,0 +1,166 @@
+/*
+ * vdetr_hip.h — C-ABI of libvdetr_hip.so, the MI355X (gfx950) hot-path library.
+ *
+ * This is the drop-in boundary for the three native surfaces of the V-DETR hot path:
+ *   (iii) the pointnet2 extension  (reference: third_party/pointnet2/_ext_src/src/bindings.cpp:9-22),
+ *   (i)   the 3D-vertex-RPE cross attention (reference: models/vdetr_transformer.py:701-758),
+ *   (ii)  the query self attention  (reference: models/vdetr_transformer.py:468,541-542 and :609-653).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + explicit sizes; no torch / ATen types;
+ *   - all tensors are contiguous, float32 or int32, laid out exactly as the reference op lays them out;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every launch goes on it;
+ *   - the library never allocates, frees or synchronises; scratch comes from the caller
+ *     (see the *_workspace_bytes queries);
+ *   - return value: 0 = ok, non-zero = error; vdetr_last_error() returns a thread-local message.
+ *     (the reference prints and calls exit(-1) on a launch failure: include/cuda_utils.h:32-41;
+ *      argument errors there are AT_ASSERT exceptions: include/utils.h:8-28);
+ *   - outputs that kernels ACCUMULATE into (all *_grad outputs) and the ball_query index tensor
+ *     must be zero-filled by the caller, as the reference's torch::zeros allocations do
+ *     (sampling.cpp:27-29, ball_query.cpp:23-25, group_points.cpp:50-52, interpolate.cpp:87-89).
+ */
+#ifndef VDETR_HIP_H
+#define VDETR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDETR_OK 0
+#define VDETR_ERR_ARG 1
+#define VDETR_ERR_LAUNCH 2
+#define VDETR_ERR_WORKSPACE 3
+
+typedef void* vdetr_stream_t; /* hipStream_t */
+
+/* library / diagnostics */
+int vdetr_abi_version(void);
+const char* vdetr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (iii) pointnet2 ops.  One symbol per function of bindings.cpp:9-22.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* furthest_point_sampling(points, nsamples)  — sampling.cpp:67-88, sampling_gpu.cu:73-232.
+ *   xyz (b,n,3) f32 -> idx (b,m) i32.  Bit-exact with the reference kernel's result, including
+ *   its origin-skip rule (x²+y²+z² <= 1e-3 points are never candidates) and its tie order
+ *   (block size opt_n_threads(n), strided scan, tree reduction).
+ *   The reference's `temp` (b,n) buffer (sampling.cpp:75-77) lives inside `workspace` here. */
+size_t vdetr_fps_workspace_bytes(int b, int n);
+int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n, int m, int32_t* idx,
+                                      void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
+
+/* gather_points(points, idx) — sampling.cpp:17-42, sampling_gpu.cu:11-33.
+ *   points (b,c,n) f32, idx (b,m) i32 -> out (b,c,m) f32 */
+int vdetr_gather_points_f32(const float* points, const int32_t* idx, float* out, int b, int c, int n,
+                            int m, vdetr_stream_t stream);
+/* gather_points_grad(grad_out, idx, n) — sampling.cpp:44-66, sampling_gpu.cu:37-60.
+ *   grad_out (b,c,m), idx (b,m) -> grad_points (b,c,n) (+=, caller zero-fills) */
+int vdetr_gather_points_grad_f32(const float* grad_out, const int32_t* idx, float* grad_points, int b,
+                                 int c, int n, int m, vdetr_stream_t stream);
+
+/* ball_query(new_xyz, xyz, radius, nsample) — ball_query.cpp:11-35, ball_query_gpu.cu:12-57.
+ *   new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample) i32 (caller zero-fills; rows with no
+ *   neighbour stay 0; first hit pre-fills the row; ascending point index; strict d² < r²). */
+int vdetr_ball_query_f32(const float* new_xyz, const float* xyz, int32_t* idx, int b, int n, int m,
+                         float radius, int nsample, vdetr_stream_t stream);
+
+/* group_points(points, idx) — group_points.cpp:14-38, group_points_gpu.cu:11-42.
+ *   points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
+int vdetr_group_points_f32(const float* points, const int32_t* idx, float* out, int b, int c, int n,
+                           int npoints, int nsample, vdetr_stream_t stream);
+/* group_points_grad(grad_out, idx, n) — group_points.cpp:40-63, group_points_gpu.cu:46-78. */
+int vdetr_group_points_grad_f32(const float* grad_out, const int32_t* idx, float* grad_points, int b,
+                                int c, int n, int npoints, int nsample, vdetr_stream_t stream);
+
+/* three_nn(unknowns, knows) — interpolate.cpp:17-44, interpolate_gpu.cu:12-73.
+ *   unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32 (SQUARED), idx (b,n,3) i32.
+ *   m<3: trailing idx stay 0 and dist2 = +inf (double 1e40 stored to float). */
+int vdetr_three_nn_f32(const float* unknown, const float* known, float* dist2, int32_t* idx, int b,
+                       int n, int m, vdetr_stream_t stream);
+/* three_interpolate(points, idx, weight) — interpolate.cpp:46-74, interpolate_gpu.cu:75-114.
+ *   points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n) */
+int vdetr_three_interpolate_f32(const float* points, const int32_t* idx, const float* weight,
+                                float* out, int b, int c, int m, int n, vdetr_stream_t stream);
+/* three_interpolate_grad(grad_out, idx, weight, m) — interpolate.cpp:75-101, interpolate_gpu.cu:119-157. */
+int vdetr_three_interpolate_grad_f32(const float* grad_out, const int32_t* idx, const float* weight,
+                                     float* grad_points, int b, int c, int n, int m,
+                                     vdetr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (i)+(ii) attention.  Row-major, batch-first device tensors; head_dim is fixed at 64.
+ *
+ * Kinds:
+ *   VDETR_ATTN_SHARED_KV  K,V are [B,nK,64] shared by all heads (GlobalShareCrossAttention
+ *                         vdetr_transformer.py:733-735, ShareSelfAttention :638-639)
+ *   VDETR_ATTN_PER_HEAD   K,V are [B,nK,H*64] (nn.MultiheadAttention, :468)
+ * ---------------------------------------------------------------------------------------------- */
+#define VDETR_ATTN_SHARED_KV 0
+#define VDETR_ATTN_PER_HEAD 1
+
+#define VDETR_MASK_NONE 0
+#define VDETR_MASK_BOOL 1  /* uint8 [B,nQ,nK]; non-zero -> score := -100 (vdetr_transformer.py:746-747) */
+#define VDETR_MASK_FLOAT 2 /* f32   [B,nQ,nK]; added to the score        (vdetr_transformer.py:748-749) */
+
+typedef struct vdetr_attn_desc {
+  int32_t kind;        /* VDETR_ATTN_* */
+  int32_t B, H, nQ, nK;
+  float scale;         /* applied to q (head_dim^-0.5, vdetr_transformer.py:670,738) */
+  /* --- 3DV-RPE (NULL table = no positional bias).  vdetr_transformer.py:710-731,741 --- */
+  const float* table;    /* [8, T, T, T, H] cpb_mlps[i](relative_coords_table), T = table_size */
+  int32_t table_size;    /* 10 for rpe_quant "bilinear_4_10" */
+  float log_scale;       /* 512 */
+  float inv_log_norm;    /* 1 / (log2(8) * max_value) = 1/12 */
+  const float* vertices; /* [B, nQ, 8, 3] reference_point */
+  const float* xyz;      /* [B, nK, 3] */
+  const float* cos_sin;  /* [B, nQ, 2] (cos, sin of reference_angle) or NULL (angle_type != object_coords) */
+  /* --- additive / boolean mask --- */
+  const void* mask;
+  int32_t mask_kind;     /* VDETR_MASK_* */
+  /* --- dropout on the attention probabilities (attn_drop, :752 / MHA dropout) --- */
+  float dropout_p;       /* 0 = off */
+  uint64_t seed, offset; /* Philox4x32-10 key / counter offset */
+} vdetr_attn_desc;
+
+/* Scratch needed by fwd (key-split partials). */
+size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d);
+
+/* Fused forward: out = dropout(softmax(scale*q k^T + rpe + mask)) v.
+ *   q      [B,nQ,H*64]
+ *   k, v   [B,nK,64] (shared) or [B,nK,H*64] (per head)
+ *   out    [B,nQ,H*64]                 (heads concatenated, vdetr_transformer.py:755)
+ *   lse    [B,nQ,H]                    log-sum-exp of the biased scores (saved for backward)
+ *   scores [B,nQ,H,nK] or NULL         biased, pre-softmax scores (saved for backward) */
+int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
+                       float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
+                       vdetr_stream_t stream);
+
+/* Backward, score stage.  In place:
+ *   scores [B,nQ,H,nK]  in: saved scores            out: P_drop = dropout(softmax)   (feeds dV = P_drop^T dO)
+ *   dprob  [B,nQ,H,nK]  in: dO V^T                  out: dS                          (feeds dQ = dS K, dK = dS^T Q)
+ *   lse    [B,nQ,H], delta [B,nQ,H] = rowsum(dO * O)
+ *   dtable [8,T,T,T,H] or NULL: += gradient of the RPE table (caller zero-fills)
+ * With dprob == NULL and delta == NULL only P_drop is produced (the `attn` return value,
+ * vdetr_transformer.py:758). */
+size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d);
+int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, float* scores, float* dprob, const float* lse,
+                              const float* delta, float* dtable, void* workspace,
+                              size_t workspace_bytes, vdetr_stream_t stream);
+
+/* Test hook: writes the dropout keep-mask (1/0 as uint8) [B,nQ,H,nK] the kernels above use. */
+int vdetr_attn_dropout_mask_u8(const vdetr_attn_desc* d, uint8_t* keep, vdetr_stream_t stream);
+
+/* Stand-alone RPE bias (no attention): rpe [B,nQ,H,nK].  Debug / parity hook for
+ * vdetr_transformer.py:710-731. */
+int vdetr_rpe_bias_f32(const vdetr_attn_desc* d, float* rpe, vdetr_stream_t stream);
+
+/* MFMA layout self-test: C[16,16] = A[16,64] * B[16,64]^T through v_mfma_f32_16x16x4_f32. */
+int vdetr_selftest_mfma_f32(const float* a, const float* b, float* c, vdetr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDETR_HIP_H */

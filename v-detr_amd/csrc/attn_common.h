@@ -1,0 +1,150 @@
+// attn_common.h — device helpers shared by the attention forward / backward kernels.
+#pragma once
+#include "common.h"
+#include "wave.h"
+
+namespace vdetr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDh = 64;          // head dim (reference: dec_dim 256 / dec_nhead 4, main.py:73,76)
+constexpr int kRpeHeads = 4;     // the RPE lane layout carries the heads of one (query,key) pair in 4 registers
+constexpr int kRpeVerts = 8;     // 8 box vertices (vdetr_transformer.py:710)
+constexpr float kNegBig = -1e30f;
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct AttnParams {
+  int kind, B, H, nQ, nK;
+  float scale;
+  const float* q;
+  const float* k;
+  const float* v;
+  float* out;
+  float* lse;
+  float* scores;
+  // rpe
+  const float* table;
+  int T;             // table edge
+  float log_scale;   // 512
+  float pix_mul;     // inv_log_norm * T / 2
+  float pix_add;     // (T - 1) / 2
+  const float* vertices;
+  const float* xyz;
+  const float* cos_sin;
+  const void* mask;
+  int mask_kind;
+  // dropout
+  unsigned drop_thresh;  // keep iff rand >= thresh
+  float drop_scale;      // 1 / (1 - p)
+  unsigned seed_lo, seed_hi, off_lo, off_hi;
+  // key split (forward)
+  int ksplit, tiles_per_split;
+  float* part_o;    // [ksplit][rows][64]
+  float* part_lse;  // [ksplit][rows]
+  // backward
+  float* dprob;
+  const float* delta;
+  float* dtable_part;  // [gridDim.x][8*T^3*H]
+};
+
+// ---- Philox4x32-10 (Salmon et al. 2011): counter-based, so forward and backward regenerate the same
+// keep-mask from (seed, offset, b, q, k, head) with no stored state.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+  constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    const unsigned hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += W0;
+    k.y += W1;
+  }
+  return c;
+}
+// Random words of attention element (b, q, key) for heads 4*hgroup .. 4*hgroup+3.
+__device__ __forceinline__ uint4 attn_rand4(const AttnParams& P, int b, int q, int key, int hgroup) {
+  return philox4x32_10(make_uint4((unsigned)key, (unsigned)q, (unsigned)b * 64u + (unsigned)hgroup, P.off_lo),
+                       make_uint2(P.seed_lo, P.seed_hi ^ P.off_hi));
+}
+__device__ __forceinline__ unsigned pick4(const uint4& r, int i) {
+  return i == 0 ? r.x : (i == 1 ? r.y : (i == 2 ? r.z : r.w));
+}
+
+// ---- 3DV-RPE lookup geometry ----------------------------------------------------------------------
+// Reference (vdetr_transformer.py:711-731 + F.grid_sample, bilinear/zeros/align_corners=False):
+//   g   = sign(d) * log2(|d|*log_scale + 1) / log2(8) / max_value
+//   pix = ((g + 1) * T - 1) / 2
+//   trilinear over floor(pix), floor(pix)+1 with out-of-range corners contributing 0.
+// Per axis this is the hat function sum_c T[c] * max(0, 1 - |pix - c|): with base = clamp(floor(pix),0,T-2)
+// the two cells base, base+1 carry wa = sat(1-|pix-base|), wb = sat(1-|pix-base-1|) and every
+// zero-padding case (pix<0, pix>T-1, far outside) falls out of the saturation — no bounds branches.
+struct AxisTap {
+  int base;
+  float wa, wb;
+};
+__device__ __forceinline__ AxisTap rpe_axis(float d, const AttnParams& P) {
+  const float L = __log2f(__builtin_fmaf(fabsf(d), P.log_scale, 1.0f));
+  const float pix = __builtin_fmaf(copysignf(L, d), P.pix_mul, P.pix_add);
+  const float bf = fminf(fmaxf(floorf(pix), 0.f), (float)(P.T - 2));
+  const float t = pix - bf;
+  AxisTap a;
+  a.base = (int)bf;
+  a.wa = __saturatef(1.f - fabsf(t));
+  a.wb = __saturatef(1.f - fabsf(t - 1.f));
+  return a;
+}
+
+// x -> LAST table axis, y -> middle, z -> FIRST (grid_sample: x=W, y=H, z=D)
+__device__ __forceinline__ int rpe_cell(const AxisTap& ax, const AxisTap& ay, const AxisTap& az, int T) {
+  return (az.base * T + ay.base) * T + ax.base;
+}
+
+// rotation used by angle_type == "object_coords" (vdetr_transformer.py:712-720 reduces to a yaw
+// rotation of (dx,dy): x' = dx*c - dy*s, y' = dx*s + dy*c, z' = dz)
+__device__ __forceinline__ void rpe_rotate(float& dx, float& dy, float c, float s) {
+  const float nx = dx * c - dy * s;
+  const float ny = dx * s + dy * c;
+  dx = nx;
+  dy = ny;
+}
+
+// bias of one (query, key) pair for the 4 heads; tab = LDS image [8][T^3] of float4 (heads)
+__device__ __forceinline__ void rpe_pair_bias(const AttnParams& P, const f32x4* tab, const float (&vx)[8],
+                                              const float (&vy)[8], const float (&vz)[8], float kx, float ky,
+                                              float kz, bool rot, float rc, float rs, float (&acc)[4]) {
+  const int T = P.T, TT = T * T, T3 = TT * T;
+#pragma unroll
+  for (int i = 0; i < kRpeVerts; ++i) {
+    float dx = vx[i] - kx, dy = vy[i] - ky, dz = vz[i] - kz;
+    if (rot) rpe_rotate(dx, dy, rc, rs);
+    const AxisTap ax = rpe_axis(dx, P), ay = rpe_axis(dy, P), az = rpe_axis(dz, P);
+    const f32x4* t = tab + i * T3 + rpe_cell(ax, ay, az, T);
+    const float w00 = az.wa * ay.wa, w01 = az.wa * ay.wb, w10 = az.wb * ay.wa, w11 = az.wb * ay.wb;
+    const f32x4 c000 = t[0], c001 = t[1], c010 = t[T], c011 = t[T + 1];
+    const f32x4 c100 = t[TT], c101 = t[TT + 1], c110 = t[TT + T], c111 = t[TT + T + 1];
+    const float w000 = w00 * ax.wa, w001 = w00 * ax.wb, w010 = w01 * ax.wa, w011 = w01 * ax.wb;
+    const float w100 = w10 * ax.wa, w101 = w10 * ax.wb, w110 = w11 * ax.wa, w111 = w11 * ax.wb;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float s = acc[h];
+      s = __builtin_fmaf(w000, c000[h], s);
+      s = __builtin_fmaf(w001, c001[h], s);
+      s = __builtin_fmaf(w010, c010[h], s);
+      s = __builtin_fmaf(w011, c011[h], s);
+      s = __builtin_fmaf(w100, c100[h], s);
+      s = __builtin_fmaf(w101, c101[h], s);
+      s = __builtin_fmaf(w110, c110[h], s);
+      s = __builtin_fmaf(w111, c111[h], s);
+      acc[h] = s;
+    }
+  }
+}
+
+// cooperative copy of the [8][T^3][4] table into LDS
+__device__ __forceinline__ void rpe_stage_table(const AttnParams& P, f32x4* tab, int tid, int nthreads) {
+  const int cells = kRpeVerts * P.T * P.T * P.T;
+  const f32x4* src = reinterpret_cast<const f32x4*>(P.table);
+  for (int c = tid; c < cells; c += nthreads) tab[c] = src[c];
+}
+
+}  // namespace vdetr

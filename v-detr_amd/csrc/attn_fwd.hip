@@ -1,0 +1,432 @@
+// attn_fwd.hip — fused attention forward for gfx950:  out = dropout(softmax(scale*q k^T + rpe + mask)) v
+//
+// Replaces the ~30 ATen kernels of GlobalShareCrossAttention.forward (vdetr_transformer.py:701-758: eight
+// grid_sample passes over a [B,nQ,nK,3] tensor, a [B,H,nQ,nK] bias tensor, softmax, two matmuls) and the
+// matmul/softmax/matmul of nn.MultiheadAttention / ShareSelfAttention (:468, :633-653) with ONE kernel.
+//
+// Tiling.  One MFMA tile is v_mfma_f32_16x16x4_f32: 16 score rows x 16 keys, exact fp32.
+//   shared-KV kinds (the 3DV-RPE cross attention): K and V are shared by the 4 heads, so the 4 heads of a
+//   query are 4 ROWS of the same tile: rows = 4 queries x 4 heads.  In the accumulator layout
+//   (col = lane&15, row = 4*(lane>>4)+reg) lane (g,c) then owns exactly ONE (query g, key c) pair and its
+//   4 registers are the 4 heads — which is the shape of the RPE lookup: the per-pair geometry (24 log2,
+//   floor/frac, trilinear weights) is computed once per lane and the table cell read from LDS is one
+//   16-byte float4 = the 4 heads.  No shuffles between the MFMA result and the bias.
+//   per-head kind (nn.MultiheadAttention): rows = 16 queries of one head.
+// A workgroup = 8 waves owns one row tile and a key range; wave w takes key tiles w, w+8, ... with a
+// private online-softmax state, the 8 partial states are merged through LDS at the end.  256 workgroups
+// for nQ=1024 (B=1): one per CU, which is also what the 128 KB LDS table image allows.
+//   LDS: [8][T^3] float4 RPE table (128,000 B for T=10) + 8 x 1,280 B P-transpose pads.
+// Contraction index order inside a tile is permuted (d = 16*(lane>>4)+s for QK^T, key = 4*(lane>>4)+s and
+// d = 4*(lane&15)+t for PV) so that every operand fetch is a contiguous float4 per lane.
+#include "attn_common.h"
+
+namespace vdetr {
+
+constexpr int kFwdThreads = 512;
+constexpr int kFwdWaves = kFwdThreads / kWave;
+constexpr int kPPad = 20;  // floats per row of the P transpose pad (16 + 4: keeps float4 alignment)
+
+template <bool PERHEAD, bool RPE>
+__global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.z;
+  const int head = PERHEAD ? blockIdx.y : 0;
+  const int split = PERHEAD ? 0 : blockIdx.y;  // key split uses grid.y only for the shared kinds
+  const int H = P.H, nQ = P.nQ, nK = P.nK;
+  const int rows_per_tile_q = PERHEAD ? 16 : 4;  // queries per workgroup
+  const int q0 = blockIdx.x * rows_per_tile_q;
+  const int qstride = H * kDh;                 // floats per query row of q / out
+  const int kvstride = PERHEAD ? H * kDh : kDh;
+  const int kvoff = PERHEAD ? head * kDh : 0;
+
+  const int table_floats = RPE ? kRpeVerts * P.T * P.T * P.T * 4 : 0;
+  f32x4* tab = reinterpret_cast<f32x4*>(smem);
+  float* ppad = smem + table_floats + w * (16 * kPPad);
+  if (RPE) rpe_stage_table(P, tab, tid, kFwdThreads);
+
+  // ---- A operand of QK^T: row i = c ---------------------------------------------------------------
+  float qa[16];
+  {
+    const int qi = PERHEAD ? min(q0 + c, nQ - 1) : min(q0 + (c >> 2), nQ - 1);
+    const int hoff = PERHEAD ? head * kDh : (c & 3) * kDh;
+    const f32x4* src = reinterpret_cast<const f32x4*>(P.q + ((size_t)b * nQ + qi) * qstride + hoff + 16 * g);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const f32x4 v = src[s4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
+    }
+  }
+  // ---- per-lane pair geometry (RPE): query g of the tile -------------------------------------------
+  float vx[8], vy[8], vz[8], rc = 1.f, rs = 0.f;
+  const bool rot = RPE && P.cos_sin != nullptr;
+  const int q_pair = min(q0 + g, nQ - 1);
+  if (RPE) {
+    const float* vp = P.vertices + ((size_t)b * nQ + q_pair) * 24;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
+    if (rot) { rc = P.cos_sin[((size_t)b * nQ + q_pair) * 2]; rs = P.cos_sin[((size_t)b * nQ + q_pair) * 2 + 1]; }
+  }
+  // query index of accumulator register r
+  int qrow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qrow[r] = PERHEAD ? (q0 + 4 * g + r) : (q0 + g);
+
+  f32x4 o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[4] = {kNegBig, kNegBig, kNegBig, kNegBig}, l[4] = {0.f, 0.f, 0.f, 0.f};
+
+  if (RPE) __syncthreads();  // table staged
+
+  const int ntiles = (nK + 15) >> 4;
+  const int tile_begin = split * P.tiles_per_split;
+  const int tile_end = min(ntiles, tile_begin + P.tiles_per_split);
+
+  for (int tile = tile_begin + w; tile < tile_end; tile += kFwdWaves) {
+    const int key0 = tile << 4;
+    const int key = key0 + c;
+    const bool kvalid = key < nK;
+    const int keyc = min(key, nK - 1);
+    // ---- S = Q K^T --------------------------------------------------------------------------------
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+      const f32x4* kp = reinterpret_cast<const f32x4*>(P.k + ((size_t)b * nK + keyc) * kvstride + kvoff + 16 * g);
+      f32x4 kb[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) kb[s4] = kp[s4];
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kb[s >> 2][s & 3], acc, 0, 0, 0);
+    }
+    float sc[4] = {acc[0], acc[1], acc[2], acc[3]};
+    // ---- + RPE bias -------------------------------------------------------------------------------
+    if (RPE) {
+      const float* xp = P.xyz + ((size_t)b * nK + keyc) * 3;
+      rpe_pair_bias(P, tab, vx, vy, vz, xp[0], xp[1], xp[2], rot, rc, rs, sc);
+    }
+    // ---- mask, tail ------------------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (P.mask_kind != VDETR_MASK_NONE) {
+        const size_t mi = ((size_t)b * nQ + min(qrow[r], nQ - 1)) * nK + keyc;
+        if (P.mask_kind == VDETR_MASK_BOOL) {
+          if (reinterpret_cast<const unsigned char*>(P.mask)[mi]) sc[r] = -100.f;
+        } else {
+          sc[r] += reinterpret_cast<const float*>(P.mask)[mi];
+        }
+      }
+      if (!kvalid) sc[r] = kNegBig;
+    }
+    if (P.scores && kvalid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (qrow[r] < nQ) {
+          const size_t row = PERHEAD ? (((size_t)b * H + head) * nQ + qrow[r]) : (((size_t)b * nQ + qrow[r]) * H + r);
+          P.scores[row * nK + key] = sc[r];
+        }
+      }
+    }
+    // ---- online softmax (rows live across the 16 lanes of a DPP row) --------------------------------
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float tmax = row_allmax_f32(sc[r]);
+      const float mn = fmaxf(m[r], tmax);
+      const float alpha = __expf(m[r] - mn);
+      const float e = kvalid ? __expf(sc[r] - mn) : 0.f;
+      l[r] = l[r] * alpha + row_allsum_f32(e);
+      m[r] = mn;
+      p[r] = e;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t][r] *= alpha;
+    }
+    // ---- dropout on the probabilities (normaliser l uses the undropped p) ---------------------------
+    if (P.drop_thresh) {
+      if (PERHEAD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint4 rnd = attn_rand4(P, b, qrow[r], key, head >> 2);
+          p[r] = pick4(rnd, head & 3) >= P.drop_thresh ? p[r] * P.drop_scale : 0.f;
+        }
+      } else {
+        const uint4 rnd = attn_rand4(P, b, qrow[0], key, 0);
+        p[0] = rnd.x >= P.drop_thresh ? p[0] * P.drop_scale : 0.f;
+        p[1] = rnd.y >= P.drop_thresh ? p[1] * P.drop_scale : 0.f;
+        p[2] = rnd.z >= P.drop_thresh ? p[2] * P.drop_scale : 0.f;
+        p[3] = rnd.w >= P.drop_thresh ? p[3] * P.drop_scale : 0.f;
+      }
+    }
+    // ---- P: accumulator layout -> A-operand layout through the wave-private LDS pad -------------------
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ppad[(4 * g + r) * kPPad + c] = p[r];
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(ppad + c * kPPad + 4 * g);
+    __builtin_amdgcn_wave_barrier();
+    // ---- O += P V ------------------------------------------------------------------------------------
+    {
+      f32x4 vb[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = min(key0 + 4 * g + s, nK - 1);
+        vb[s] = *reinterpret_cast<const f32x4*>(P.v + ((size_t)b * nK + kk) * kvstride + kvoff + 4 * c);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], vb[s][t], o[t], 0, 0, 0);
+    }
+  }
+
+  // ---- merge the 8 wave states -------------------------------------------------------------------------
+  __syncthreads();  // every wave is done with the table image: reuse it
+  float* red = smem;  // [w][lane][24]: 16 o + 4 m + 4 l
+  {
+    float* mine = red + ((size_t)w * kWave + lane) * 24;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[t * 4 + r] = o[t][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mine[16 + r] = m[r]; mine[20 + r] = l[r]; }
+  }
+  __syncthreads();
+  // wave w finishes d-tile t = w>>1 for registers r in {2*(w&1), 2*(w&1)+1}
+  {
+    const int t = w >> 1;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * (w & 1) + rr;
+      float M = kNegBig;
+#pragma unroll
+      for (int ww = 0; ww < kFwdWaves; ++ww) M = fmaxf(M, red[((size_t)ww * kWave + lane) * 24 + 16 + r]);
+      float L = 0.f, val = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < kFwdWaves; ++ww) {
+        const float* src = red + ((size_t)ww * kWave + lane) * 24;
+        const float f = __expf(src[16 + r] - M);
+        L += src[20 + r] * f;
+        val += src[t * 4 + r] * f;
+      }
+      const int qi = qrow[r];
+      if (qi < nQ) {
+        const float inv = L > 0.f ? 1.f / L : 0.f;
+        const float lse = L > 0.f ? M + __logf(L) : kNegBig;
+        const int hh = PERHEAD ? head : r;
+        const int d = 4 * c + t;
+        if (P.ksplit == 1) {
+          P.out[((size_t)b * nQ + qi) * qstride + hh * kDh + d] = val * inv;
+          if (t == 0 && c == 0) {
+            const size_t row = PERHEAD ? (((size_t)b * H + hh) * nQ + qi) : (((size_t)b * nQ + qi) * H + hh);
+            P.lse[row] = lse;
+          }
+        } else {
+          const size_t row = ((size_t)b * nQ + qi) * H + hh;
+          const size_t rows = (size_t)P.B * nQ * H;
+          P.part_o[((size_t)split * rows + row) * kDh + d] = val * inv;
+          if (t == 0 && c == 0) P.part_lse[(size_t)split * rows + row] = lse;
+        }
+      }
+    }
+  }
+}
+
+// merge of key-split partials: out = sum_s exp(lse_s - LSE) * o_s
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(AttnParams P) {
+  const size_t rows = (size_t)P.B * P.nQ * P.H;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;  // element of [rows][64]
+  if (e >= rows * kDh) return;
+  const size_t row = e / kDh;
+  const int d = (int)(e % kDh);
+  float M = kNegBig;
+  for (int s = 0; s < P.ksplit; ++s) M = fmaxf(M, P.part_lse[(size_t)s * rows + row]);
+  float L = 0.f, val = 0.f;
+  for (int s = 0; s < P.ksplit; ++s) {
+    const float f = __expf(P.part_lse[(size_t)s * rows + row] - M);
+    L += f;
+    val += f * P.part_o[((size_t)s * rows + row) * kDh + d];
+  }
+  // row = (b*nQ + q)*H + h  ->  out[(b*nQ+q)*H*64 + h*64 + d] is the same flat offset
+  P.out[row * kDh + d] = L > 0.f ? val / L : 0.f;
+  if (d == 0) P.lse[row] = L > 0.f ? M + __logf(L) : kNegBig;
+}
+
+// ---- stand-alone RPE bias (parity hook for vdetr_transformer.py:710-731) ------------------------------
+__global__ __launch_bounds__(256) void rpe_bias_kernel(AttnParams P, float* rpe) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4* tab = reinterpret_cast<f32x4*>(smem);
+  rpe_stage_table(P, tab, threadIdx.x, 256);
+  __syncthreads();
+  const int b = blockIdx.z, q = blockIdx.y;
+  const float* vp = P.vertices + ((size_t)b * P.nQ + q) * 24;
+  float vx[8], vy[8], vz[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
+  const bool rot = P.cos_sin != nullptr;
+  const float rc = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2] : 1.f;
+  const float rs = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1] : 0.f;
+  for (int key = blockIdx.x * 256 + threadIdx.x; key < P.nK; key += gridDim.x * 256) {
+    const float* xp = P.xyz + ((size_t)b * P.nK + key) * 3;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    rpe_pair_bias(P, tab, vx, vy, vz, xp[0], xp[1], xp[2], rot, rc, rs, acc);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) rpe[(((size_t)b * P.nQ + q) * 4 + h) * P.nK + key] = acc[h];
+  }
+}
+
+// ---- MFMA layout self test: C[16][16] = A[16][64] * B[16][64]^T with the operand mapping used above ----
+__global__ void mfma_selftest_kernel(const float* a, const float* b, float* cmat) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < 16; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c * 64 + 16 * g + s], b[c * 64 + 16 * g + s], acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) cmat[(4 * g + r) * 16 + c] = acc[r];
+}
+
+}  // namespace vdetr
+
+using namespace vdetr;
+
+namespace vdetr {
+int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
+  VDETR_REQUIRE(d != nullptr, "%s: null descriptor", op);
+  VDETR_REQUIRE(d->kind == VDETR_ATTN_SHARED_KV || d->kind == VDETR_ATTN_PER_HEAD, "%s: bad kind %d", op, d->kind);
+  VDETR_REQUIRE(d->B > 0 && d->H > 0 && d->nQ > 0 && d->nK > 0, "%s: empty dimension B=%d H=%d nQ=%d nK=%d", op,
+                d->B, d->H, d->nQ, d->nK);
+  VDETR_REQUIRE(d->B <= 65535, "%s: B=%d > 65535", op, d->B);
+  VDETR_REQUIRE(d->kind == VDETR_ATTN_PER_HEAD || d->H == kRpeHeads,
+                "%s: shared-KV attention is built for %d heads (got %d)", op, kRpeHeads, d->H);
+  VDETR_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "%s: dropout_p %f outside [0,1)", op, d->dropout_p);
+  VDETR_REQUIRE(d->mask_kind == VDETR_MASK_NONE || d->mask != nullptr, "%s: mask_kind set but mask is null", op);
+  *P = AttnParams{};
+  P->kind = d->kind; P->B = d->B; P->H = d->H; P->nQ = d->nQ; P->nK = d->nK; P->scale = d->scale;
+  P->table = d->table;
+  if (d->table) {
+    VDETR_REQUIRE(d->kind == VDETR_ATTN_SHARED_KV, "%s: RPE needs the shared-KV kind", op);
+    VDETR_REQUIRE(d->vertices && d->xyz, "%s: RPE table given without vertices/xyz", op);
+    VDETR_REQUIRE(d->table_size >= 2, "%s: table_size %d < 2", op, d->table_size);
+    const size_t bytes = (size_t)kRpeVerts * d->table_size * d->table_size * d->table_size * 16 + kFwdWaves * 16 * kPPad * 4;
+    VDETR_REQUIRE(bytes <= 160 * 1024, "%s: RPE table of edge %d does not fit the 160 KB LDS", op, d->table_size);
+    P->T = d->table_size;
+    P->log_scale = d->log_scale;
+    P->pix_mul = d->inv_log_norm * 0.5f * (float)d->table_size;
+    P->pix_add = 0.5f * (float)(d->table_size - 1);
+    P->vertices = d->vertices; P->xyz = d->xyz; P->cos_sin = d->cos_sin;
+  }
+  P->mask = d->mask; P->mask_kind = d->mask ? d->mask_kind : VDETR_MASK_NONE;
+  if (d->dropout_p > 0.f) {
+    double t = (double)d->dropout_p * 4294967296.0;
+    P->drop_thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (P->drop_thresh == 0) P->drop_thresh = 1;
+    P->drop_scale = 1.f / (1.f - d->dropout_p);
+  } else {
+    P->drop_thresh = 0; P->drop_scale = 1.f;
+  }
+  P->seed_lo = (unsigned)d->seed; P->seed_hi = (unsigned)(d->seed >> 32);
+  P->off_lo = (unsigned)d->offset; P->off_hi = (unsigned)(d->offset >> 32);
+  P->ksplit = 1; P->tiles_per_split = (d->nK + 15) / 16;
+  return VDETR_OK;
+}
+
+// key split so that small query counts still fill the chip (shared kinds only)
+static int choose_ksplit(const vdetr_attn_desc* d) {
+  if (d->kind != VDETR_ATTN_SHARED_KV) return 1;
+  const long wgs = (long)d->B * ((d->nQ + 3) / 4);
+  const int ntiles = (d->nK + 15) / 16;
+  int ks = 1;
+  while (wgs * ks < 256 && ks * 2 * kFwdWaves <= ntiles && ks < 16) ks *= 2;
+  return ks;
+}
+}  // namespace vdetr
+
+extern "C" size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d) {
+  if (!d) return 0;
+  const int ks = choose_ksplit(d);
+  if (ks == 1) return 0;
+  const size_t rows = (size_t)d->B * d->nQ * d->H;
+  return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes, const char* op) {
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      set_error("%s: cannot reserve %zu B of LDS: %s", op, bytes, hipGetErrorString(e));
+      return VDETR_ERR_LAUNCH;
+    }
+  }
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
+                                  float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
+                                  vdetr_stream_t stream) {
+  AttnParams P;
+  if (int e = attn_fill_params(d, &P, "attn_fwd")) return e;
+  VDETR_REQUIRE(q && k && v && out && lse, "attn_fwd: null pointer");
+  P.q = q; P.k = k; P.v = v; P.out = out; P.lse = lse; P.scores = scores;
+  const bool perhead = d->kind == VDETR_ATTN_PER_HEAD;
+  const bool rpe = d->table != nullptr;
+  const int ks = choose_ksplit(d);
+  if (ks > 1) {
+    const size_t need = vdetr_attn_fwd_workspace_bytes(d);
+    if (!workspace || workspace_bytes < need) {
+      set_error("attn_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
+      return VDETR_ERR_WORKSPACE;
+    }
+    const size_t rows = (size_t)d->B * d->nQ * d->H;
+    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    P.part_o = (float*)base;
+    P.part_lse = P.part_o + (size_t)ks * rows * kDh;
+    P.ksplit = ks;
+    const int ntiles = (d->nK + 15) / 16;
+    P.tiles_per_split = (ntiles + ks - 1) / ks;
+  }
+  const size_t lds_table = rpe ? (size_t)kRpeVerts * P.T * P.T * P.T * 16 : 0;
+  const size_t lds = lds_table + (size_t)kFwdWaves * 16 * kPPad * 4 > (size_t)kFwdWaves * kWave * 24 * 4
+                         ? lds_table + (size_t)kFwdWaves * 16 * kPPad * 4
+                         : (size_t)kFwdWaves * kWave * 24 * 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (perhead) {
+    dim3 grid((d->nQ + 15) / 16, d->H, d->B);
+    if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(kFwdThreads), lds, st, P);
+  } else {
+    dim3 grid((d->nQ + 3) / 4, ks, d->B);
+    if (rpe) {
+      if (int e = set_lds(attn_fwd_kernel<false, true>, lds, "attn_fwd")) return e;
+      hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(kFwdThreads), lds, st, P);
+    } else {
+      if (int e = set_lds(attn_fwd_kernel<false, false>, lds, "attn_fwd")) return e;
+      hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(kFwdThreads), lds, st, P);
+    }
+  }
+  if (int e = check_launch("attn_fwd")) return e;
+  if (ks > 1) {
+    const size_t elems = (size_t)d->B * d->nQ * d->H * kDh;
+    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, P);
+    return check_launch("attn_fwd_combine");
+  }
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_rpe_bias_f32(const vdetr_attn_desc* d, float* rpe, vdetr_stream_t stream) {
+  AttnParams P;
+  if (int e = attn_fill_params(d, &P, "rpe_bias")) return e;
+  VDETR_REQUIRE(d->table && rpe, "rpe_bias: null pointer");
+  VDETR_REQUIRE(d->nQ <= 65535, "rpe_bias: nQ=%d > 65535", d->nQ);
+  const size_t lds = (size_t)kRpeVerts * P.T * P.T * P.T * 16;
+  if (int e = set_lds(rpe_bias_kernel, lds, "rpe_bias")) return e;
+  dim3 grid(min(ceil_div(d->nK, 256), 64), d->nQ, d->B);
+  hipLaunchKernelGGL(rpe_bias_kernel, grid, dim3(256), lds, (hipStream_t)stream, P, rpe);
+  return check_launch("rpe_bias");
+}
+
+extern "C" int vdetr_selftest_mfma_f32(const float* a, const float* b, float* c, vdetr_stream_t stream) {
+  VDETR_REQUIRE(a && b && c, "selftest_mfma: null pointer");
+  hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);
+  return check_launch("selftest_mfma");
+}

@@ -1,0 +1,45 @@
+// common.h — shared host/device helpers for libvdetr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/vdetr_hip.h"
+
+namespace vdetr {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+void set_error(const char* fmt, ...);
+
+// Records the launch status instead of exiting (reference: cuda_utils.h:32-41 exits the process).
+inline int check_launch(const char* what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(err));
+    return VDETR_ERR_LAUNCH;
+  }
+  return VDETR_OK;
+}
+
+#define VDETR_REQUIRE(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      vdetr::set_error(__VA_ARGS__);  \
+      return VDETR_ERR_ARG;           \
+    }                                 \
+  } while (0)
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Squared distance in the contraction order LLVM emits for
+//   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
+// (sampling_gpu.cu:106-107, ball_query_gpu.cu:34-35, interpolate_gpu.cu:36): t = dy*dy; t = fma(dx,dx,t);
+// t = fma(dz,dz,t).  The oracle (oracle/pointnet2_oracle.c) pins the same order.
+__device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+  return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+}
+
+}  // namespace vdetr

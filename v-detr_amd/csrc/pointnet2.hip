@@ -1,0 +1,335 @@
+// pointnet2.hip — gather / group / three_nn / three_interpolate / ball_query for gfx950.
+//
+// MI355X-native re-design of the indexing ops behind the reference's `pointnet2._ext` module
+// (third_party/pointnet2/_ext_src/src/bindings.cpp:9-22).  The reference launches ONE block per batch
+// element for most of these (group_points_gpu.cu:37, interpolate_gpu.cu:69,110, ball_query_gpu.cu:53),
+// which leaves 255 of 256 CUs idle at batch 1.  Here every op is a flat, coalesced, chip-filling grid:
+// consecutive lanes own consecutive OUTPUT elements (64 x 4 B = one 256-B line per wave store), the
+// index / weight rows are read once per thread and reused across a channel strip, and the scans
+// (ball query, three_nn) are wave-cooperative.  All of them are HBM/L2-bound integer/byte work.
+#include "common.h"
+
+namespace vdetr {
+
+constexpr int kThreads = 256;
+constexpr int kChanStrip = 8;  // channels handled per thread: amortises the idx/weight loads
+
+// ---------------------------------------------------------------------------------------------
+// gather_points: out[b,c,j] = points[b,c,idx[b,j]]                      (sampling_gpu.cu:11-23)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void gather_points_kernel(const float* __restrict__ points,
+                                                                 const int32_t* __restrict__ idx,
+                                                                 float* __restrict__ out, int c, int n,
+                                                                 int m) {
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= m) return;
+  const int a = idx[(size_t)bi * m + j];
+  const int l0 = blockIdx.y * kChanStrip;
+#pragma unroll
+  for (int dl = 0; dl < kChanStrip; ++dl) {
+    const int l = l0 + dl;
+    if (l < c) out[((size_t)bi * c + l) * m + j] = points[((size_t)bi * c + l) * n + a];
+  }
+}
+
+// gather_points_grad: grad_points[b,c,idx[b,j]] += grad_out[b,c,j]       (sampling_gpu.cu:37-50)
+__global__ __launch_bounds__(kThreads) void gather_points_grad_kernel(
+    const float* __restrict__ grad_out, const int32_t* __restrict__ idx, float* __restrict__ grad_points,
+    int c, int n, int m) {
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= m) return;
+  const int a = idx[(size_t)bi * m + j];
+  const int l0 = blockIdx.y * kChanStrip;
+#pragma unroll
+  for (int dl = 0; dl < kChanStrip; ++dl) {
+    const int l = l0 + dl;
+    if (l < c)
+      unsafeAtomicAdd(grad_points + ((size_t)bi * c + l) * n + a, grad_out[((size_t)bi * c + l) * m + j]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// group_points: out[b,c,j,k] = points[b,c,idx[b,j,k]]                 (group_points_gpu.cu:11-31)
+// flat element e = j*nsample + k, so the (b,npoints,nsample) index tensor is read coalesced.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void group_points_kernel(const float* __restrict__ points,
+                                                                const int32_t* __restrict__ idx,
+                                                                float* __restrict__ out, int c, int n,
+                                                                long ne) {
+  const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (e >= ne) return;
+  const int a = idx[(size_t)bi * ne + e];
+  const int l0 = blockIdx.y * kChanStrip;
+#pragma unroll
+  for (int dl = 0; dl < kChanStrip; ++dl) {
+    const int l = l0 + dl;
+    if (l < c) out[((size_t)bi * c + l) * ne + e] = points[((size_t)bi * c + l) * n + a];
+  }
+}
+
+// group_points_grad: grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k] (group_points_gpu.cu:46-67)
+__global__ __launch_bounds__(kThreads) void group_points_grad_kernel(
+    const float* __restrict__ grad_out, const int32_t* __restrict__ idx, float* __restrict__ grad_points,
+    int c, int n, long ne) {
+  const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (e >= ne) return;
+  const int a = idx[(size_t)bi * ne + e];
+  const int l0 = blockIdx.y * kChanStrip;
+#pragma unroll
+  for (int dl = 0; dl < kChanStrip; ++dl) {
+    const int l = l0 + dl;
+    if (l < c)
+      unsafeAtomicAdd(grad_points + ((size_t)bi * c + l) * n + a, grad_out[((size_t)bi * c + l) * ne + e]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// three_interpolate: out[b,c,j] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3      (interpolate_gpu.cu:75-104)
+// Contraction order pinned as t = p2*w2; t = fma(p1,w1,t); t = fma(p3,w3,t) (see common.h).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void three_interpolate_kernel(
+    const float* __restrict__ points, const int32_t* __restrict__ idx, const float* __restrict__ weight,
+    float* __restrict__ out, int c, int m, int n) {
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= n) return;
+  const size_t r = ((size_t)bi * n + j) * 3;
+  const int i1 = idx[r], i2 = idx[r + 1], i3 = idx[r + 2];
+  const float w1 = weight[r], w2 = weight[r + 1], w3 = weight[r + 2];
+  const int l0 = blockIdx.y * kChanStrip;
+#pragma unroll
+  for (int dl = 0; dl < kChanStrip; ++dl) {
+    const int l = l0 + dl;
+    if (l < c) {
+      const float* p = points + ((size_t)bi * c + l) * m;
+      float t = __fmul_rn(p[i2], w2);
+      t = __fmaf_rn(p[i1], w1, t);
+      t = __fmaf_rn(p[i3], w3, t);
+      out[((size_t)bi * c + l) * n + j] = t;
+    }
+  }
+}
+
+// three_interpolate_grad: grad_points[b,c,i_t] += grad_out[b,c,j]*w_t (interpolate_gpu.cu:119-146)
+__global__ __launch_bounds__(kThreads) void three_interpolate_grad_kernel(
+    const float* __restrict__ grad_out, const int32_t* __restrict__ idx, const float* __restrict__ weight,
+    float* __restrict__ grad_points, int c, int n, int m) {
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= n) return;
+  const size_t r = ((size_t)bi * n + j) * 3;
+  const int i1 = idx[r], i2 = idx[r + 1], i3 = idx[r + 2];
+  const float w1 = weight[r], w2 = weight[r + 1], w3 = weight[r + 2];
+  const int l0 = blockIdx.y * kChanStrip;
+#pragma unroll
+  for (int dl = 0; dl < kChanStrip; ++dl) {
+    const int l = l0 + dl;
+    if (l < c) {
+      const float g = grad_out[((size_t)bi * c + l) * n + j];
+      float* gp = grad_points + ((size_t)bi * c + l) * m;
+      unsafeAtomicAdd(gp + i1, __fmul_rn(g, w1));
+      unsafeAtomicAdd(gp + i2, __fmul_rn(g, w2));
+      unsafeAtomicAdd(gp + i3, __fmul_rn(g, w3));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// three_nn: 3 nearest `known` points of every `unknown` point         (interpolate_gpu.cu:12-62)
+// One thread per unknown point keeps the reference's sequential insertion order (strict '<', so the
+// earliest index wins ties); the known cloud is streamed through LDS in 1024-point tiles that every
+// lane reads at the same address (LDS broadcast, conflict-free).
+// The reference's `double bestN = 1e40` only ever holds float values or the sentinel, and is stored
+// to float (-> +inf); float +inf reproduces every comparison and the stored value.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNNTile = 1024;
+__global__ __launch_bounds__(kThreads) void three_nn_kernel(const float* __restrict__ unknown,
+                                                            const float* __restrict__ known,
+                                                            float* __restrict__ dist2,
+                                                            int32_t* __restrict__ idx, int n, int m) {
+  __shared__ float tile[kNNTile * 3];
+  const int bi = blockIdx.z;
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  const bool live = j < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (live) {
+    const float* u = unknown + ((size_t)bi * n + j) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = 0, i2 = 0, i3 = 0;
+  const float* kb = known + (size_t)bi * m * 3;
+  for (int k0 = 0; k0 < m; k0 += kNNTile) {
+    const int cnt = min(kNNTile, m - k0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 3; t += kThreads) tile[t] = kb[(size_t)k0 * 3 + t];
+    __syncthreads();
+    if (live) {
+      for (int t = 0; t < cnt; ++t) {
+        const float d = sqdist3(ux - tile[t * 3], uy - tile[t * 3 + 1], uz - tile[t * 3 + 2]);
+        const int k = k0 + t;
+        if (d < b1) {
+          b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
+        } else if (d < b2) {
+          b3 = b2; i3 = i2; b2 = d; i2 = k;
+        } else if (d < b3) {
+          b3 = d; i3 = k;
+        }
+      }
+    }
+  }
+  if (live) {
+    const size_t r = ((size_t)bi * n + j) * 3;
+    dist2[r] = b1; dist2[r + 1] = b2; dist2[r + 2] = b3;
+    idx[r] = i1; idx[r + 1] = i2; idx[r + 2] = i3;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ball_query: first `nsample` indices (ascending) with d² < r²          (ball_query_gpu.cu:12-47)
+// One WAVE per query: each step tests 64 consecutive points, a 64-bit ballot + prefix popcount
+// compacts the hits in ascending index order, and the scan stops (wave-uniform) as soon as nsample
+// hits are found.  Unfilled slots are set to the first hit afterwards, which is what the reference's
+// "first hit pre-fills the row" produces; rows with no hit are left untouched (zero from the caller).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void ball_query_kernel(const float* __restrict__ new_xyz,
+                                                              const float* __restrict__ xyz,
+                                                              int32_t* __restrict__ idx, int n, int m,
+                                                              float radius2, int nsample) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+  const int bi = blockIdx.z;
+  if (j >= m) return;  // wave-uniform
+  const float* q = new_xyz + ((size_t)bi * m + j) * 3;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  const float* pts = xyz + (size_t)bi * n * 3;
+  int32_t* row = idx + ((size_t)bi * m + j) * nsample;
+  int cnt = 0, first = -1;
+  for (int k0 = 0; k0 < n && cnt < nsample; k0 += kWave) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < n) {
+      const float d2 = sqdist3(qx - pts[k * 3], qy - pts[k * 3 + 1], qz - pts[k * 3 + 2]);
+      hit = d2 < radius2;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0) continue;
+    if (first < 0) first = k0 + __ffsll((long long)mask) - 1;
+    const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+    if (hit && pos < nsample) row[pos] = k;
+    cnt += __popcll(mask);
+  }
+  if (first >= 0)
+    for (int l = min(cnt, nsample) + lane; l < nsample; l += kWave) row[l] = first;
+}
+
+}  // namespace vdetr
+
+using namespace vdetr;
+
+static int check_bcnm(const char* op, int b, int c, int n, int m) {
+  VDETR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 0, "%s: negative dimension", op);
+  VDETR_REQUIRE(b <= 65535, "%s: batch %d > 65535", op, b);
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_gather_points_f32(const float* points, const int32_t* idx, float* out, int b, int c,
+                                       int n, int m, vdetr_stream_t stream) {
+  if (int e = check_bcnm("gather_points", b, c, n, m)) return e;
+  if (b == 0 || c == 0 || m == 0) return VDETR_OK;
+  VDETR_REQUIRE(points && idx && out, "gather_points: null pointer");
+  dim3 grid(ceil_div(m, kThreads), ceil_div(c, kChanStrip), b);
+  hipLaunchKernelGGL(gather_points_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, points, idx, out,
+                     c, n, m);
+  return check_launch("gather_points");
+}
+
+extern "C" int vdetr_gather_points_grad_f32(const float* grad_out, const int32_t* idx, float* grad_points,
+                                            int b, int c, int n, int m, vdetr_stream_t stream) {
+  if (int e = check_bcnm("gather_points_grad", b, c, n, m)) return e;
+  if (b == 0 || c == 0 || m == 0) return VDETR_OK;
+  VDETR_REQUIRE(grad_out && idx && grad_points, "gather_points_grad: null pointer");
+  dim3 grid(ceil_div(m, kThreads), ceil_div(c, kChanStrip), b);
+  hipLaunchKernelGGL(gather_points_grad_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out,
+                     idx, grad_points, c, n, m);
+  return check_launch("gather_points_grad");
+}
+
+extern "C" int vdetr_group_points_f32(const float* points, const int32_t* idx, float* out, int b, int c,
+                                      int n, int npoints, int nsample, vdetr_stream_t stream) {
+  if (int e = check_bcnm("group_points", b, c, n, npoints)) return e;
+  VDETR_REQUIRE(nsample >= 0, "group_points: negative nsample");
+  const long ne = (long)npoints * nsample;
+  if (b == 0 || c == 0 || ne == 0) return VDETR_OK;
+  VDETR_REQUIRE(points && idx && out, "group_points: null pointer");
+  dim3 grid(ceil_div(ne, kThreads), ceil_div(c, kChanStrip), b);
+  hipLaunchKernelGGL(group_points_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, points, idx, out, c,
+                     n, ne);
+  return check_launch("group_points");
+}
+
+extern "C" int vdetr_group_points_grad_f32(const float* grad_out, const int32_t* idx, float* grad_points,
+                                           int b, int c, int n, int npoints, int nsample,
+                                           vdetr_stream_t stream) {
+  if (int e = check_bcnm("group_points_grad", b, c, n, npoints)) return e;
+  VDETR_REQUIRE(nsample >= 0, "group_points_grad: negative nsample");
+  const long ne = (long)npoints * nsample;
+  if (b == 0 || c == 0 || ne == 0) return VDETR_OK;
+  VDETR_REQUIRE(grad_out && idx && grad_points, "group_points_grad: null pointer");
+  dim3 grid(ceil_div(ne, kThreads), ceil_div(c, kChanStrip), b);
+  hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out, idx,
+                     grad_points, c, n, ne);
+  return check_launch("group_points_grad");
+}
+
+extern "C" int vdetr_three_nn_f32(const float* unknown, const float* known, float* dist2, int32_t* idx,
+                                  int b, int n, int m, vdetr_stream_t stream) {
+  if (int e = check_bcnm("three_nn", b, 0, n, m)) return e;
+  if (b == 0 || n == 0) return VDETR_OK;
+  VDETR_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
+  dim3 grid(ceil_div(n, kThreads), 1, b);
+  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, unknown, known, dist2,
+                     idx, n, m);
+  return check_launch("three_nn");
+}
+
+extern "C" int vdetr_three_interpolate_f32(const float* points, const int32_t* idx, const float* weight,
+                                           float* out, int b, int c, int m, int n, vdetr_stream_t stream) {
+  if (int e = check_bcnm("three_interpolate", b, c, n, m)) return e;
+  if (b == 0 || c == 0 || n == 0) return VDETR_OK;
+  VDETR_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
+  dim3 grid(ceil_div(n, kThreads), ceil_div(c, kChanStrip), b);
+  hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, points, idx,
+                     weight, out, c, m, n);
+  return check_launch("three_interpolate");
+}
+
+extern "C" int vdetr_three_interpolate_grad_f32(const float* grad_out, const int32_t* idx,
+                                                const float* weight, float* grad_points, int b, int c,
+                                                int n, int m, vdetr_stream_t stream) {
+  if (int e = check_bcnm("three_interpolate_grad", b, c, n, m)) return e;
+  if (b == 0 || c == 0 || n == 0) return VDETR_OK;
+  VDETR_REQUIRE(grad_out && idx && weight && grad_points, "three_interpolate_grad: null pointer");
+  dim3 grid(ceil_div(n, kThreads), ceil_div(c, kChanStrip), b);
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out,
+                     idx, weight, grad_points, c, n, m);
+  return check_launch("three_interpolate_grad");
+}
+
+extern "C" int vdetr_ball_query_f32(const float* new_xyz, const float* xyz, int32_t* idx, int b, int n,
+                                    int m, float radius, int nsample, vdetr_stream_t stream) {
+  if (int e = check_bcnm("ball_query", b, 0, n, m)) return e;
+  VDETR_REQUIRE(nsample >= 0, "ball_query: negative nsample");
+  if (b == 0 || m == 0 || nsample == 0 || n == 0) return VDETR_OK;
+  VDETR_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");
+  dim3 grid(ceil_div(m, kThreads / kWave), 1, b);
+  // radius2 is formed in float like the reference (ball_query_gpu.cu:25)
+  const float radius2 = radius * radius;
+  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, new_xyz, xyz, idx, n,
+                     m, radius2, nsample);
+  return check_launch("ball_query");
+}

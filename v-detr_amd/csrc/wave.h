@@ -1,0 +1,104 @@
+// wave.h — 64-lane wavefront primitives (DPP / permlane-swap based; no LDS traffic).
+#pragma once
+#include "common.h"
+
+namespace vdetr {
+
+// DPP control words (LLVM AMDGPU DppCtrl encoding)
+constexpr int kDppQuadXor1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = dpp_u32<CTRL>((unsigned)v), hi = dpp_u32<CTRL>((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Cross-row / cross-half exchange.  permlane16_swap(vdst, src) swaps the odd 16-lane rows of vdst with
+// the even rows of src; permlane32_swap swaps lanes 32-63 of vdst with lanes 0-31 of src.  Called with
+// vdst = src = v the two results are A' = [r0,r0,r2,r2] / [lo,lo] and B' = [r1,r1,r3,r3] / [hi,hi], so
+// op(A', B') is the all-reduce over the row pair / the two halves for any commutative op.
+struct pair_u32 { unsigned a, b; };
+__device__ __forceinline__ pair_u32 xrow16(unsigned v) {
+  auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return {r[0], r[1]};
+}
+__device__ __forceinline__ pair_u32 xhalf32(unsigned v) {
+  auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return {r[0], r[1]};
+}
+
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) {
+  return a > b ? a : b;
+}
+
+// all-reduce max over the 16 lanes of a DPP row
+__device__ __forceinline__ unsigned long long row_allmax_u64(unsigned long long v) {
+  v = umax64(v, dpp_u64<kDppQuadXor1>(v));
+  v = umax64(v, dpp_u64<kDppQuadXor2>(v));
+  v = umax64(v, dpp_u64<kDppRowHalfMirror>(v));
+  v = umax64(v, dpp_u64<kDppRowMirror>(v));
+  return v;
+}
+// all-reduce max over the whole wave
+__device__ __forceinline__ unsigned long long wave_allmax_u64(unsigned long long v) {
+  v = row_allmax_u64(v);
+  {
+    const pair_u32 lo = xrow16((unsigned)v), hi = xrow16((unsigned)(v >> 32));
+    v = umax64(((unsigned long long)hi.a << 32) | lo.a, ((unsigned long long)hi.b << 32) | lo.b);
+  }
+  {
+    const pair_u32 lo = xhalf32((unsigned)v), hi = xhalf32((unsigned)(v >> 32));
+    v = umax64(((unsigned long long)hi.a << 32) | lo.a, ((unsigned long long)hi.b << 32) | lo.b);
+  }
+  return v;
+}
+
+__device__ __forceinline__ float row_allmax_f32(float v) {
+  v = fmaxf(v, dpp_f32<kDppQuadXor1>(v));
+  v = fmaxf(v, dpp_f32<kDppQuadXor2>(v));
+  v = fmaxf(v, dpp_f32<kDppRowHalfMirror>(v));
+  v = fmaxf(v, dpp_f32<kDppRowMirror>(v));
+  return v;
+}
+__device__ __forceinline__ float row_allsum_f32(float v) {
+  v += dpp_f32<kDppQuadXor1>(v);
+  v += dpp_f32<kDppQuadXor2>(v);
+  v += dpp_f32<kDppRowHalfMirror>(v);
+  v += dpp_f32<kDppRowMirror>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_allmax_f32(float v) {
+  v = row_allmax_f32(v);
+  pair_u32 p = xrow16(__float_as_uint(v));
+  v = fmaxf(__uint_as_float(p.a), __uint_as_float(p.b));
+  p = xhalf32(__float_as_uint(v));
+  return fmaxf(__uint_as_float(p.a), __uint_as_float(p.b));
+}
+__device__ __forceinline__ float wave_allmin_f32(float v) { return -wave_allmax_f32(-v); }
+__device__ __forceinline__ float wave_allsum_f32(float v) {
+  v = row_allsum_f32(v);
+  pair_u32 p = xrow16(__float_as_uint(v));
+  v = __uint_as_float(p.a) + __uint_as_float(p.b);
+  p = xhalf32(__float_as_uint(v));
+  return __uint_as_float(p.a) + __uint_as_float(p.b);
+}
+
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+__device__ __forceinline__ unsigned readlane_u32(unsigned v, int lane) {
+  return (unsigned)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+}  // namespace vdetr
