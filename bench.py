@@ -1,0 +1,350 @@
+#!/usr/bin/env python3
+"""Benchmark of the V-DETR hot path on MI355X:  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one TRAINING step of the post-backbone path on one synthetic scene per GPU:
+  FPS + gather (40k voxels -> 4096 tokens) -> projection -> decoder (FFN stage, top-1024 proposals, 8 x [self-attn,
+  3DV-RPE cross-attn, FFN], 9 head stages) -> scalar loss -> backward -> (N>1) gradient all-reduce over RCCL ->
+  gradient clipping + AdamW.
+Workload = BASELINE.json configs[1] ("ScanNet 40k-point scene, full V-DETR config, bs=1, 1xMI355X"); N>1 is
+configs[2] (one scene per GPU, weak scaling).  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (points, batch per GPU, preenc_npoints, nqueries, dec_nlayers, angle_type, description)
+    "c1": (4000, 1, 4096, 64, 3, "", "C1: synthetic 4k-point scene, 64 queries, 2 RPE decoder layers"),
+    "c2": (40000, 1, 4096, 1024, 9, "", "C2: synthetic 40k-point ScanNet-like scene, full V-DETR decoder config "
+           "(4096 keys, 1024 queries, 8 RPE layers, 9 head stages), bs=1 per GPU"),
+    "c4": (80000, 1, 4096, 1024, 9, "", "C4: synthetic 80k-point dense scene, 1024 queries (fp32)"),
+    "c5": (20000, 4, 4096, 1024, 9, "object_coords", "C5: synthetic 20k-point rotated-box scenes, bs=4 per GPU"),
+}
+
+
+def make_scene(npoints, seed, device):
+    """N points uniform in an 8x6x3 m room offset by +1 m, quantised to the 4 cm grid and de-duplicated (what the
+    backbone's out.C * voxel_size looks like), + 256-channel random features (the backbone's out.F)."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform([0, 0, 0], [8, 6, 3], (npoints, 3)) + 1.0
+    vox = np.unique(np.round(pts / 0.04).astype(np.int64), axis=0)
+    rng.shuffle(vox)
+    xyz = torch.from_numpy((vox * 0.04).astype(np.float32)).to(device)
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn((xyz.shape[0], 256), generator=g).to(device)
+    return xyz, feats
+
+
+def build_model(cfg_name, device, seed=0):
+    from vdetr_amd.dataset_config import RotatedBoxDatasetConfig, ScannetDatasetConfig
+    from vdetr_amd.model_vdetr import build_vdetr, default_args
+    npts, bs, npre, nq, nl, angle_type, _ = CONFIGS[cfg_name]
+    torch.manual_seed(seed)
+    args = default_args(dec_nlayers=nl, nqueries=nq, preenc_npoints=npre, angle_type=angle_type)
+    ds = RotatedBoxDatasetConfig() if angle_type else ScannetDatasetConfig()
+    model = build_vdetr(args, ds)
+    with torch.no_grad():  # centre/size regressors are zero-initialised (vdetr_transformer.py:169-173): perturb them
+        for h in model.decoder.mlp_heads:  # so boxes (and the RPE vertices) differ between stages
+            for k in ("center_head", "size_head"):
+                h[k].layers[-1].weight.add_(0.01 * torch.randn_like(h[k].layers[-1].weight))
+    return model.to(device).train()
+
+
+def make_inputs(cfg_name, device, rank):
+    npts, bs, *_ = CONFIGS[cfg_name]
+    xyzs, feats = [], []
+    for i in range(bs):
+        x, f = make_scene(npts, rank * 1000 + i, device)
+        xyzs.append(x)
+        feats.append(f.requires_grad_(True))  # gradient flows back into the (out-of-scope) backbone
+    n = min(x.shape[0] for x in xyzs)          # equal token counts -> one batched FPS launch
+    xyzs = [x[:n].contiguous() for x in xyzs]
+    feats = [f.detach()[:n].contiguous().requires_grad_(True) for f in feats]
+    stacked = torch.stack(xyzs)
+    return {"backbone_xyz": xyzs, "backbone_features": feats,
+            "point_cloud_dims_min": stacked.min(1)[0], "point_cloud_dims_max": stacked.max(1)[0]}
+
+
+def loss_fn(out):
+    """synthetic scalar loss of SURVEY.md §8d: sum over the 9 stages of sem_cls_logits + centre + size"""
+    return sum(o["sem_cls_logits"].sum() + o["center_normalized"].sum() + o["size_normalized"].sum()
+               for o in out["aux_outputs"] + [out["outputs"]])
+
+
+class Trainer:
+    """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
+
+    def __init__(self, model, inputs, world, use_graph, overlap):
+        from vdetr_amd.dist import GradientReducer
+        self.model, self.inputs, self.world = model, inputs, world
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.reducer = GradientReducer(self.params, bucket_mb=25.0, overlap=overlap and not use_graph)
+        self.opt = torch.optim.AdamW(self.params, lr=7e-4, weight_decay=0.1, capturable=True, foreach=True)
+        self.use_graph = use_graph
+        self.g_main = self.g_opt = None
+        self.loss = None
+
+    def _fwd_bwd(self):
+        self.reducer.zero_grad()
+        for f in self.inputs["backbone_features"]:
+            f.grad = None
+        self.loss = loss_fn(self.model(self.inputs))
+        self.loss.backward()
+
+    def _update(self):
+        torch.nn.utils.clip_grad_norm_(self.params, 0.1, foreach=True)  # engine.py:105-106
+        self.opt.step()
+
+    def capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):  # warm allocator, lazy inits, LDS attribute grants
+                self._fwd_bwd()
+                self._update()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_main = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_main):
+            self._fwd_bwd()
+            if self.world == 1:
+                self._update()
+        if self.world > 1:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                self._update()
+
+    def step(self):
+        if self.g_main is not None:
+            self.g_main.replay()
+            if self.world > 1:
+                self.reducer.reduce_all()
+                self.g_opt.replay()
+        else:
+            self._fwd_bwd()
+            self.reducer.finish()
+            self._update()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernels, measured live with HIP events on the launch stream
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_rooflines(cfg_name, device, reps=20):
+    import ctypes
+    from vdetr_amd import _lib as L
+    from vdetr_amd import attention as A
+    _, bs, nK, nQ, *_ = CONFIGS[cfg_name]
+    B, H = bs, 4
+    g = torch.Generator().manual_seed(0)
+    xyz, _ = make_scene(40000, 0, device)
+    kxyz = xyz[torch.randperm(xyz.shape[0], generator=g)[:nK].to(device)][None].repeat(B, 1, 1).contiguous()
+    center = kxyz[:, torch.randperm(nK, generator=g)[:nQ].to(device)]
+    half = (0.1 + torch.rand((B, nQ, 1, 3), generator=g)).to(device)
+    signs = torch.tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]],
+                         dtype=torch.float32, device=device)
+    verts = (center[:, :, None, :] + half * signs).contiguous()
+    q = torch.randn((B, nQ, 256), generator=g).to(device)
+    k = torch.randn((B, nK, 64), generator=g).to(device)
+    v = torch.randn((B, nK, 64), generator=g).to(device)
+    table = torch.randn((8, 10, 10, 10, 4), generator=g).to(device)
+    rng = A.begin_step(device)
+    d = A._desc(L.VDETR_ATTN_SHARED_KV, B, H, nQ, nK, 0.125, table, A.RPEConfig(), verts, kxyz, None, None, 0.1, rng, 1)
+    lib = L.lib()
+    out = torch.empty_like(q)
+    lse = torch.empty((B, nQ, H), device=device)
+    scores = torch.empty((B, nQ, H, nK), device=device)
+    dprob = torch.randn((B, nQ, H, nK), generator=g).to(device) * 1e-3
+    delta = torch.zeros((B, nQ, H), device=device)
+    dtable = torch.zeros_like(table)
+    wsf = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
+    wsb = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
+    ws = L.workspace(max(wsf, wsb), device)
+    st = L.stream_ptr()
+
+    def fwd():
+        L.check(lib.vdetr_attn_fwd_f32(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse),
+                                       L.ptr(scores), L.ptr(ws), wsf, st), "attn_fwd")
+
+    def bwd():
+        L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), L.ptr(dprob), L.ptr(lse), L.ptr(delta),
+                                              L.ptr(dtable), L.ptr(ws), wsb, st), "attn_bwd")
+
+    def timeit(fn, prep=None):
+        ts = []
+        for i in range(reps + 3):
+            if prep is not None:
+                prep()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            if i >= 3:
+                ts.append(e0.elapsed_time(e1) * 1e-3)
+        return float(np.mean(ts))
+
+    t_fwd = timeit(fwd)
+    t_bwd = timeit(bwd, prep=fwd)  # bwd consumes the saved scores in place
+    pairs = B * nQ * nK
+    flops = 4.0 * H * pairs * 64                       # QK^T + PV (MFMA-eligible), SURVEY.md §8d
+    bytes_bwd = 4.0 * 4 * H * pairs                    # S, dP~ read + P~, dS written (fp32)
+    fwd_obj = {"kernel": "attn_fwd_kernel<shared_kv,rpe> (3DV-RPE cross-attention forward)", "bound": "mfma",
+               "achieved": flops / t_fwd / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+               "frac": flops / t_fwd / 1e12 / 157.3, "traffic": None, "launch_us": t_fwd * 1e6,
+               "rpe_lookups_per_s": 8.0 * pairs / t_fwd}
+    bwd_obj = {"kernel": "attn_bwd_scores_rpe_kernel (softmax backward + RPE table gradient)", "bound": "hbm",
+               "achieved": bytes_bwd / t_bwd / 1e9, "peak": 8000.0, "unit": "GB/s",
+               "frac": bytes_bwd / t_bwd / 1e9 / 8000.0, "traffic": None, "launch_us": t_bwd * 1e6,
+               "rpe_scatter_per_s": 8.0 * pairs / t_bwd}
+    return fwd_obj, bwd_obj
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a port: this repo's host modules with the attention / pointnet2 entry points routed to
+# the CPU restatement), on a bounded sample of the same workload
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg_name):
+    import vdetr_amd.attention as A
+    from oracle import pointnet2_oracle as O
+    from functools import partial
+    from oracle.attention_oracle import fused_attention_reference as _ref
+    from vdetr_amd.dataset_config import ScannetDatasetConfig
+    from vdetr_amd.model_vdetr import build_decoder, default_args
+    # the bias through eight F.grid_sample passes, i.e. the ops the reference itself runs on CPU
+    fused_attention_reference = partial(_ref, rpe_impl="grid_sample")
+    npts, bs, npre, nq, nl, angle_type, _ = CONFIGS[cfg_name]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    xyz, _ = make_scene(npts, 0, "cpu")
+    t0 = time.perf_counter()
+    idx = O.furthest_point_sampling(xyz[None].numpy(), npre)
+    t_fps = time.perf_counter() - t0
+    kxyz = xyz[torch.from_numpy(idx[0]).long()][None]
+    saved = (A.fused_attention, A.begin_step, A.current_rng)
+    A.fused_attention, A.begin_step, A.current_rng = fused_attention_reference, (lambda dev: None), (lambda dev: None)
+    try:
+        times = {}
+        for layers in (2, 3):  # FFN stage + 1 resp. 2 RPE layers; per-layer cost = difference
+            torch.manual_seed(0)
+            dec = build_decoder(default_args(dec_nlayers=layers, nqueries=nq), ScannetDatasetConfig()).train()
+            feats = torch.randn((kxyz.shape[1], 1, 256), requires_grad=True)
+            dims = [kxyz.min(1)[0], kxyz.max(1)[0]]
+            scene = dims[1] - dims[0]
+            enc = {"center_normalized": (kxyz - dims[0][:, None]) / scene[:, None],
+                   "size_normalized": torch.ones_like(kxyz) / scene[:, None]}
+            t0 = time.perf_counter()
+            out, _ = dec(None, feats, kxyz, kxyz, dims, query_pos=kxyz, enc_box_predictions=enc, enc_box_features=feats)
+            loss_fn(out).backward()
+            times[layers] = time.perf_counter() - t0
+    finally:
+        A.fused_attention, A.begin_step, A.current_rng = saved
+    per_layer = max(times[3] - times[2], 1e-9)
+    full = t_fps + times[2] + (nl - 2) * per_layer
+    return {"value": bs / (full * bs), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"FPS {npts}->{npre} pts with the C oracle on 1 thread ({t_fps:.2f} s) + decoder fwd+bwd with 1 and 2 of "
+                      f"{nl - 1} RPE layers at full nQ={nq}/nK={npre} through the torch CPU oracle (RPE via F.grid_sample, as the reference) on {cores} threads "
+                      f"({times[2]:.1f} s, {times[3]:.1f} s), extrapolated linearly to {nl - 1} layers = {full:.1f} s/scene"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
+    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm as in main.py:512-514 (implies --no-graph)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    from vdetr_amd.dist import broadcast_parameters, init_distributed
+    rank, local, world = init_distributed("nccl")
+    assert world == a.gpus or (world == 1 and a.gpus == 1), f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    model = build_model(a.config, device)
+    use_graph = not (a.no_graph or a.sync_bn)
+    if world > 1:
+        broadcast_parameters(model)
+        if a.sync_bn:
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    inputs = make_inputs(a.config, device, rank)
+    trainer = Trainer(model, inputs, world, use_graph, overlap=True)
+    graph_ok = False
+    if use_graph:
+        try:
+            trainer.capture()
+            graph_ok = True
+        except Exception as e:  # capture is an optimisation: report and fall back to eager launches
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            trainer.g_main = trainer.g_opt = None
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(a.warmup):
+        trainer.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(trainer.loss.item())
+    assert np.isfinite(loss), "non-finite loss"
+
+    npts, bs, npre, nq, nl, _, desc = CONFIGS[a.config]
+    result = {
+        "metric": "scenes/sec (train fwd+bwd) 40k-pt ScanNet", "value": world * bs * a.steps / dt, "unit": "scenes/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "global_batch": world * bs, "voxels_per_scene": int(inputs["backbone_xyz"][0].shape[0]),
+                   "keys": npre, "queries": nq, "rpe_layers": nl - 1, "parallelism": f"dp{world}",
+                   "step": "FPS+gather, projection, decoder fwd, loss, backward, grad all-reduce (N>1), clip, AdamW",
+                   "hip_graph": graph_ok, "sync_bn": bool(a.sync_bn),
+                   "grad_allreduce_bytes": trainer.reducer.grad_bytes()},
+        "loss": loss,
+    }
+    if rank == 0 and world == 1:
+        if not a.no_roofline:
+            fwd_obj, bwd_obj = kernel_rooflines(a.config, device)
+            layers = nl - 1
+            dom, other = (bwd_obj, fwd_obj) if bwd_obj["launch_us"] >= fwd_obj["launch_us"] else (fwd_obj, bwd_obj)
+            dom["share_of_step"] = layers * dom["launch_us"] * 1e-3 / result["ms_per_step"]
+            other["share_of_step"] = layers * other["launch_us"] * 1e-3 / result["ms_per_step"]
+            result["roofline"] = dom
+            result["roofline_secondary"] = other
+        if not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(a.config)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

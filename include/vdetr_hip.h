@@ -123,6 +123,10 @@ typedef struct vdetr_attn_desc {
   /* --- dropout on the attention probabilities (attn_drop, :752 / MHA dropout) --- */
   float dropout_p;       /* 0 = off */
   uint64_t seed, offset; /* Philox4x32-10 key / counter offset */
+  const uint64_t* rng_state; /* optional DEVICE pointer to {seed, offset}, folded into the two fields above
+                                (seed ^= state[0], offset += state[1]): a captured hipGraph can advance the
+                                device offset between replays, and modules sharing one state stay independent
+                                through their by-value seed */
 } vdetr_attn_desc;
 
 /* Scratch needed by fwd (key-split partials). */
@@ -132,16 +136,18 @@ size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d);
  *   q      [B,nQ,H*64]
  *   k, v   [B,nK,64] (shared) or [B,nK,H*64] (per head)
  *   out    [B,nQ,H*64]                 (heads concatenated, vdetr_transformer.py:755)
- *   lse    [B,nQ,H]                    log-sum-exp of the biased scores (saved for backward)
- *   scores [B,nQ,H,nK] or NULL         biased, pre-softmax scores (saved for backward) */
+ *   lse    row log-sum-exp of the biased scores (saved for backward)
+ *   scores biased, pre-softmax scores (saved for backward), or NULL
+ * Row order of lse / scores / delta / dprob: shared-KV kind [B,nQ,H](,nK); per-head kind [B,H,nQ](,nK)
+ * (so that the library GEMMs of the backward are plain batched GEMMs in both cases). */
 int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
                        float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
                        vdetr_stream_t stream);
 
-/* Backward, score stage.  In place:
- *   scores [B,nQ,H,nK]  in: saved scores            out: P_drop = dropout(softmax)   (feeds dV = P_drop^T dO)
- *   dprob  [B,nQ,H,nK]  in: dO V^T                  out: dS                          (feeds dQ = dS K, dK = dS^T Q)
- *   lse    [B,nQ,H], delta [B,nQ,H] = rowsum(dO * O)
+/* Backward, score stage.  In place (row order as above):
+ *   scores  in: saved scores            out: P_drop = dropout(softmax)   (feeds dV = P_drop^T dO)
+ *   dprob   in: dO V^T                  out: dS                          (feeds dQ = dS K, dK = dS^T Q)
+ *   lse, delta = rowsum(dO * O)
  *   dtable [8,T,T,T,H] or NULL: += gradient of the RPE table (caller zero-fills)
  * With dprob == NULL and delta == NULL only P_drop is produced (the `attn` return value,
  * vdetr_transformer.py:758). */

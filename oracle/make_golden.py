@@ -1,0 +1,217 @@
+"""Generates tests/golden/*.npz by importing the REFERENCE's Python (read-only, /root/reference) on CPU.
+
+Run in the build container only:  python oracle/make_golden.py
+The reference cannot travel to the GPU box, so its inputs / outputs / gradients are committed as small fixtures
+(weights are NOT stored: both sides fill their modules with oracle/param_fill.py, keyed by parameter name).
+
+Import recipe: `models/__init__.py` pulls MinkowskiEngine, and pc_util / scannet / the transformer
+import plyfile, trimesh and mmcv at module import time; none is installed, none is used on this path.  They are
+replaced by empty stub modules, and `models` is registered as a namespace package so its __init__ is skipped.
+"""
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.param_fill import fill_module  # noqa: E402
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    for name, attrs in {"mmcv": [], "mmcv.ops": ["points_in_boxes_all"], "mmcv.ops.furthest_point_sample": [],
+                        "plyfile": ["PlyData", "PlyElement"], "trimesh": []}.items():
+        m = types.ModuleType(name)
+        for a in attrs:
+            setattr(m, a, None)
+        sys.modules[name] = m
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules["models"] = pkg
+    sys.path.insert(0, REF)
+    import models.vdetr_transformer as T  # noqa
+    import models.position_embedding as PE  # noqa
+    from datasets.scannet import ScannetDatasetConfig  # noqa
+    return T, PE, ScannetDatasetConfig
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KB")
+
+
+def args_ns(**kw):
+    a = dict(log_scale=512.0, rpe_quant="bilinear_4_10", angle_type="", rpe_dim=128, share_selfattn=False)
+    a.update(kw)
+    return Namespace(**a)
+
+
+def scene(g, B, nQ, nK, edge_cases=False):
+    """Random boxes + key cloud in a 8x6x3 m room offset by +1 m."""
+    lo, ext = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([8.0, 6.0, 3.0])
+    xyz = lo + torch.rand((B, nK, 3), generator=g) * ext
+    center = lo + torch.rand((B, nQ, 3), generator=g) * ext
+    size = 0.2 + torch.rand((B, nQ, 3), generator=g) * 1.8
+    if edge_cases:
+        xyz[:, 0] = center[:, 0] + 0.5 * size[:, 0] * torch.tensor([1.0, 1.0, -1.0])  # delta == 0 for one vertex
+        xyz[:, 1] = torch.tensor([30.0, -25.0, 12.0])   # |delta| > 8 m on every axis: all corners out of range
+        xyz[:, 2] = center[:, 1] + torch.tensor([9.5, 0.0, -9.5])  # g slightly above 1: half of the corners padded
+    return xyz, center, size
+
+
+def cross_attention_cases(T, Cfg):
+    cfg = Cfg()
+    for name, B, nQ, nK, angle_type, grads in [("cross_attn_small", 2, 5, 7, "", "all"),
+                                                ("cross_attn_rot", 2, 6, 9, "object_coords", "all"),
+                                                ("cross_attn_mid", 1, 64, 512, "", "some")]:
+        g = torch.Generator().manual_seed(hash(name) & 0xFFFF if False else sum(map(ord, name)))
+        mod = T.GlobalShareCrossAttention(256, 4, attn_drop=0.1, proj_drop=0.1, args=args_ns(angle_type=angle_type))
+        fill_module(mod)
+        # cpb MLPs: larger weights so that the bias is O(1) and the table has structure
+        with torch.no_grad():
+            for m in mod.cpb_mlps:
+                m[0].weight.mul_(2.0)
+                m[2].weight.mul_(1.5)
+        mod.eval()
+        xyz, center, size = scene(g, B, nQ, nK, edge_cases=(name == "cross_attn_small"))
+        angle = (torch.rand((B, nQ), generator=g) * 2 - 1) * 3.1 if angle_type else torch.zeros((B, nQ))
+        corners = cfg.box_parametrization_to_corners(center, size, angle)
+        ref_pts = T.convert_corners_camera2lidar(corners.clone())
+        query = torch.randn((nQ, B, 256), generator=g).requires_grad_(True)
+        key = torch.randn((nK, B, 256), generator=g).requires_grad_(True)
+        wout = torch.randn((nQ, B, 256), generator=g)
+        x, attn = mod(query, key, ref_pts, angle if angle_type else None, xyz)
+        (x * wout).sum().backward()
+        arrays = dict(query=np_(query), key=np_(key), reference_point=np_(ref_pts), reference_angle=np_(angle),
+                      xyz=np_(xyz), wout=np_(wout), x=np_(x), attn=np_(attn), grad_query=np_(query.grad),
+                      grad_key=np_(key.grad), angle_type=np.array(angle_type))
+        for pname, p in mod.named_parameters():
+            if grads == "all" or pname.startswith("cpb_mlps") or pname in ("q.weight", "k.weight", "v.bias"):
+                arrays["grad_param:" + pname] = np_(p.grad)
+        if name == "cross_attn_small":  # the bias alone, for the stand-alone RPE check
+            tables = torch.stack([m(mod.relative_coords_table)[0] for m in mod.cpb_mlps])
+            arrays["tables"] = np_(tables)
+        save(name, **arrays)
+
+
+def share_self_attention_case(T):
+    g = torch.Generator().manual_seed(11)
+    mod = T.ShareSelfAttention(256, 4, dropout=0.1)
+    fill_module(mod)
+    mod.eval()
+    N, B = 9, 2
+    tgt = torch.randn((N, B, 256), generator=g).requires_grad_(True)
+    pos = torch.randn((N, B, 256), generator=g)
+    wout = torch.randn((N, B, 256), generator=g)
+    x, _ = mod(tgt + pos, tgt + pos, value=tgt)
+    (x * wout).sum().backward()
+    arrays = dict(tgt=np_(tgt), pos=np_(pos), wout=np_(wout), x=np_(x), grad_tgt=np_(tgt.grad))
+    for pname, p in mod.named_parameters():
+        arrays["grad_param:" + pname] = np_(p.grad)
+    save("share_self_attn", **arrays)
+
+
+def decoder_cases(T, Cfg):
+    from models.helpers import GenericMLP  # noqa: F401  (import check)
+    cfg = Cfg()
+    for name, dec_nlayers, share in [("decoder_c1_l2", 2, False), ("decoder_c1_l3", 3, False),
+                                     ("decoder_c1_l3_share", 3, True)]:
+        a = args_ns(share_selfattn=share)
+        first = T.FFNLayer(d_model=256, dim_feedforward=256, dropout=0.1)
+        layer = T.GlobalDecoderLayer(d_model=256, nhead=4, dim_feedforward=256, dropout=0.1, pos_for_key=False, args=a)
+        dec = T.TransformerDecoder(first, layer, cfg, num_layers=dec_nlayers - 1, decoder_dim=256, mlp_dropout=0.3,
+                                   mlp_norm="bn1d", mlp_act="relu", mlp_sep=True, pos_for_key=False, num_queries=64,
+                                   cls_loss="focalloss_0.25", is_bilable=True, q_content="random",
+                                   return_intermediate=True, args=a)
+        fill_module(dec)
+        with torch.no_grad():
+            for l in dec.layers:
+                for m in l.multihead_attn.cpb_mlps:
+                    m[0].weight.mul_(2.0)
+                    m[2].weight.mul_(1.5)
+            for h in dec.mlp_heads:  # keep box regressions small: size = exp(reg) * prior
+                for k in ("center_head", "size_head"):
+                    h[k].layers[-1].weight.mul_(0.2)
+        dec.eval()
+        g = torch.Generator().manual_seed(100 + dec_nlayers)
+        B, nK = 1, 512
+        xyz, _, _ = scene(g, B, 1, nK)
+        dims = [xyz.min(1)[0], xyz.max(1)[0]]
+        feats = torch.randn((nK, B, 256), generator=g).requires_grad_(True)
+        size_un = torch.tensor(cfg.mean_size_arr, dtype=torch.float32)[torch.randint(0, 18, (B, nK), generator=g)]
+        scene_size = dims[1] - dims[0]
+        enc = {"center_normalized": (xyz - dims[0][:, None]) / scene_size[:, None],
+               "size_normalized": size_un / scene_size[:, None]}
+        out, _ = dec(None, feats, xyz, xyz, dims, query_pos=xyz, enc_box_predictions=enc, enc_box_features=feats)
+        stages = out["aux_outputs"] + [out["outputs"]]
+        loss = 0
+        arrays = dict(feats=np_(feats), xyz=np_(xyz), dims_min=np_(dims[0]), dims_max=np_(dims[1]),
+                      center_normalized=np_(enc["center_normalized"]), size_normalized=np_(enc["size_normalized"]),
+                      nstages=np.array(len(stages)))
+        for s, st in enumerate(stages):
+            for k in ("sem_cls_logits", "center_unnormalized", "size_unnormalized", "box_corners", "center_normalized",
+                      "size_normalized", "angle_continuous", "objectness_prob"):
+                arrays[f"s{s}:{k}"] = np_(st[k])
+            w = torch.randn(st["sem_cls_logits"].shape, generator=g)
+            loss = loss + (st["sem_cls_logits"] * w).sum() + st["center_normalized"].sum() + st["size_normalized"].sum()
+            arrays[f"s{s}:w"] = np_(w)
+        loss.backward()
+        arrays["loss"] = np_(loss)
+        arrays["grad_feats"] = np_(feats.grad)
+        keep = ["query_embed.weight", "layers.0.multihead_attn.q.weight", "layers.0.multihead_attn.k.weight",
+                "layers.0.multihead_attn.v.weight", "layers.0.multihead_attn.proj.bias", "first_layer.linear1.weight",
+                "layers.0.linear2.weight", "norm.weight", "mlp_heads.1.center_head.layers.8.weight",
+                "query_pos_projection.0.position_embedding_head.0.weight"]
+        keep += ["layers.0.self_attn.k.weight", "layers.0.self_attn.q.bias"] if share else \
+            ["layers.0.self_attn.in_proj_weight", "layers.0.self_attn.out_proj.weight"]
+        for pname, p in dec.named_parameters():
+            if pname in keep or "cpb_mlps" in pname:
+                arrays["grad_param:" + pname] = np_(p.grad)
+        arrays["param_names"] = np.array(sorted(n for n, _ in dec.named_parameters()))
+        arrays["buffer_names"] = np.array(sorted(n for n, _ in dec.named_buffers()))
+        save(name, **arrays)
+
+
+def misc_cases(T, PE, Cfg):
+    g = torch.Generator().manual_seed(5)
+    cfg = Cfg()
+    center = torch.randn((3, 11, 3), generator=g) * 2
+    size = 0.1 + torch.rand((3, 11, 3), generator=g) * 2
+    angle = (torch.rand((3, 11), generator=g) * 2 - 1) * 3.1
+    corners = cfg.box_parametrization_to_corners(center, size, angle)
+    corners0 = cfg.box_parametrization_to_corners(center, size, torch.zeros_like(angle))
+    save("box_corners", center=np_(center), size=np_(size), angle=np_(angle), corners=np_(corners),
+         corners_zero_angle=np_(corners0), lidar=np_(T.convert_corners_camera2lidar(corners.clone())))
+    xyz = torch.rand((2, 13, 3), generator=g) * 5 + 1
+    rng = [xyz.min(1)[0] - 0.1, xyz.max(1)[0] + 0.1]
+    four = fill_module(PE.PositionEmbeddingCoordsSine(d_pos=256, pos_type="fourier", normalize=True))
+    sine = PE.PositionEmbeddingCoordsSine(pos_type="sine", normalize=True)
+    save("pos_embed", xyz=np_(xyz), rmin=np_(rng[0]), rmax=np_(rng[1]), fourier=np_(four(xyz, input_range=rng)),
+         fourier_64=np_(four(xyz, num_channels=64, input_range=rng)),
+         sine_256=np_(sine(xyz, num_channels=256, input_range=rng)),
+         sine_100=np_(sine(xyz, num_channels=100, input_range=rng)))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    T, PE, Cfg = import_reference()
+    cross_attention_cases(T, Cfg)
+    share_self_attention_case(T)
+    decoder_cases(T, Cfg)
+    misc_cases(T, PE, Cfg)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a CPU-only machine and exports every symbol include/vdetr_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "vdetr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vdetr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from vdetr_amd import _lib
+    assert header_symbols() == _lib.exported_symbols()
+
+
+def test_library_exports_every_symbol():
+    from vdetr_amd import _lib
+    handle = _lib.lib()
+    for sym in header_symbols():
+        assert hasattr(handle, sym), sym
+    assert handle.vdetr_abi_version() == 1
+
+
+def test_descriptor_layout():
+    from vdetr_amd import _lib
+    # 6x4 | ptr | 3x4 + pad | 3 ptr | ptr | 2x4 | 2x8 | ptr
+    assert ctypes.sizeof(_lib.AttnDesc) == 112
+    assert _lib.AttnDesc.table.offset == 24 and _lib.AttnDesc.vertices.offset == 48
+    assert _lib.AttnDesc.seed.offset == 88 and _lib.AttnDesc.rng_state.offset == 104
+
+
+def test_argument_errors_do_not_exit():
+    """status codes + vdetr_last_error instead of the reference's exit(-1) (cuda_utils.h:32-41)."""
+    from vdetr_amd import _lib
+    lib = _lib.lib()
+    assert lib.vdetr_gather_points_f32(None, None, None, -1, 1, 1, 1, None) == 1
+    assert b"negative" in lib.vdetr_last_error()
+    assert lib.vdetr_furthest_point_sampling_f32(None, 1, 0, 4, None, None, 0, None) == 1
+    assert lib.vdetr_furthest_point_sampling_f32(None, 1, 10, 0, None, None, 0, None) == 0  # m <= 0: no-op
+    assert lib.vdetr_fps_workspace_bytes(1, 40000) == 40000 * 20 + 256
+    d = _lib.AttnDesc()
+    d.kind, d.B, d.H, d.nQ, d.nK = 0, 1, 3, 4, 4
+    assert lib.vdetr_attn_fwd_f32(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == 1
+    assert b"4 heads" in lib.vdetr_last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: the reference asserts "CPU not supported" (sampling.cpp:36,62,84)."""
+    from vdetr_amd import pointnet2_utils as PU
+    from vdetr_amd import attention as A
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        PU.furthest_point_sample(torch.rand(1, 16, 3), 4)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        PU.gather_operation(torch.rand(1, 4, 16), torch.zeros(1, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        A.fused_attention(torch.rand(1, 4, 256), torch.rand(1, 8, 64), torch.rand(1, 8, 64), num_heads=4, scale=0.125,
+                          shared_kv=True)

@@ -1,0 +1,82 @@
+"""N>1 path on CPU: two gloo ranks, scene-sharded gradients averaged by GradientReducer (the RCCL path on GPUs)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vdetr_amd.dist import GradientReducer, broadcast_parameters, init_distributed
+    r, _, w = init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)  # different init per rank: broadcast must fix it
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+    for p in model[3].parameters():
+        p.requires_grad_(True)
+    broadcast_parameters(model)
+    red = GradientReducer(model.parameters(), bucket_mb=0.0003, overlap=overlap)  # several tiny buckets
+    assert len(red.buckets) > 1
+    torch.manual_seed(rank)        # each rank sees its own "scene"
+    x = torch.randn(5, 8)
+    for step in range(2):
+        red.zero_grad()
+        out = model[2](model[1](model[0](x)))  # model[3] is unused: its gradient stays zero, bucket flushed by finish()
+        out.square().sum().backward()
+        if overlap:
+            red.finish()
+        else:
+            red.reduce_all()
+    q.put((rank, [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()], x))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, w0, x0), (_, g1, w1, x1) = res
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)            # broadcast made the replicas identical
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, atol=1e-7)   # both ranks hold the same averaged gradient
+    # and it IS the average of the two local gradients
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+    with torch.no_grad():
+        for p, w in zip(model.parameters(), w0):
+            p.copy_(w)
+    exp = None
+    for x in (x0, x1):
+        model.zero_grad()
+        model[2](model[1](model[0](x))).square().sum().backward()
+        gs = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in model.parameters()]
+        exp = gs if exp is None else [a + b for a, b in zip(exp, gs)]
+    for a, e in zip(g0, exp):
+        assert torch.allclose(a, e / 2, atol=1e-6)
+
+
+def test_gradient_reducer_overlap_hooks():
+    _run(True)
+
+
+def test_gradient_reducer_after_backward():
+    _run(False)

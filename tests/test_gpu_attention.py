@@ -1,0 +1,211 @@
+"""Fused attention kernels (HIP, through the C-ABI) vs the CPU oracle and the reference's golden vectors.
+
+Tolerance (BASELINE.json north_star): box/logit tensors within 1e-3 relative fp32.  Forward outputs are checked at
+1e-4 relative (+1e-5 abs), gradients at 1e-3 relative to the tensor's max (fp32 sums in a different order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import (assert_close, build_cross_attention, build_decoder, build_share_self_attention,
+                     run_cross_attention_case, run_decoder_case, t)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_mfma_layout_selftest():
+    """A[16,64] x B[16,64]^T through v_mfma_f32_16x16x4_f32 with the operand mapping the kernels use; asymmetric
+    operands so a transposed result cannot pass."""
+    import ctypes
+    from vdetr_amd import _lib as L
+    a = torch.randn(16, 64, device=DEV)
+    b = torch.randn(16, 64, device=DEV) + torch.arange(16, device=DEV)[:, None]
+    c = torch.zeros(16, 16, device=DEV)
+    L.check(L.lib().vdetr_selftest_mfma_f32(L.ptr(a), L.ptr(b), L.ptr(c), L.stream_ptr()), "selftest")
+    assert_close(c, (a.double() @ b.double().T).cpu().numpy(), 1e-5, 1e-4, "mfma")
+
+
+def _scene(B, nQ, nK, seed, rot=False):
+    g = torch.Generator().manual_seed(seed)
+    lo, ext = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([8.0, 6.0, 3.0])
+    xyz = lo + torch.rand((B, nK, 3), generator=g) * ext
+    center = lo + torch.rand((B, nQ, 3), generator=g) * ext
+    half = 0.1 + torch.rand((B, nQ, 3), generator=g)
+    signs = torch.tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]],
+                         dtype=torch.float32)
+    verts = center[:, :, None, :] + half[:, :, None, :] * signs
+    tables = torch.randn((8, 10, 10, 10, 4), generator=g)
+    cs = None
+    if rot:
+        ang = (torch.rand((B, nQ), generator=g) * 2 - 1) * 3.1
+        cs = torch.stack((torch.cos(ang), torch.sin(ang)), -1)
+    return xyz, verts, tables, cs
+
+
+@pytest.mark.parametrize("B,nQ,nK,rot", [(2, 5, 7, False), (1, 33, 100, True), (1, 64, 1000, False)])
+def test_rpe_bias_kernel(B, nQ, nK, rot):
+    from oracle.attention_oracle import rpe_bias_reference
+    from vdetr_amd import attention as A
+    xyz, verts, tables, cs = _scene(B, nQ, nK, 3, rot)
+    xyz[:, 1] = torch.tensor([30.0, -25.0, 12.0])  # all-padding key
+    xyz[:, 0] = verts[:, 0, 0]                     # delta == 0
+    ref = rpe_bias_reference(tables.double(), verts.double(), xyz.double(), cos_sin=None if cs is None else cs.double())
+    got = A.rpe_bias(tables.to(DEV), verts.to(DEV).contiguous(), xyz.to(DEV), A.RPEConfig(), None if cs is None else cs.to(DEV))
+    assert_close(got, ref.numpy(), 1e-4, 2e-5 * float(ref.abs().max()), "rpe")
+    assert float(got[:, :, :, 1].abs().max()) == 0.0
+
+
+CASES = [  # B, nQ, nK, shared, rpe, rot, mask
+    (2, 5, 7, True, True, False, None),
+    (1, 64, 512, True, True, True, None),
+    (1, 37, 301, True, True, False, "bool"),
+    (2, 16, 96, True, True, False, "float"),
+    (1, 4, 4096, True, True, False, None),      # few queries -> key-split path
+    (2, 9, 9, True, False, False, None),        # ShareSelfAttention core
+    (1, 50, 50, False, False, False, None),     # nn.MultiheadAttention core
+    (2, 130, 77, False, False, False, "float"),
+]
+
+
+@pytest.mark.parametrize("B,nQ,nK,shared,rpe,rot,mask", CASES)
+def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
+    from oracle.attention_oracle import fused_attention_reference
+    from vdetr_amd import attention as A
+    H = 4
+    g = torch.Generator().manual_seed(B * 1000 + nQ + nK)
+    xyz, verts, tables, cs = _scene(B, nQ, nK, 7, rot)
+    q = torch.randn((B, nQ, 256), generator=g)
+    kd = 64 if shared else 256
+    k = torch.randn((B, nK, kd), generator=g)
+    v = torch.randn((B, nK, kd), generator=g)
+    wout = torch.randn((B, nQ, 256), generator=g)
+    m = None
+    if mask == "bool":
+        m = torch.rand((B, nQ, nK), generator=g) < 0.2
+    elif mask == "float":
+        m = torch.randn((B, nQ, nK), generator=g)
+    cfg = A.RPEConfig()
+    kw = dict(num_heads=H, scale=0.125, shared_kv=shared)
+
+    def run(fn, dev, dtype):
+        args = [x.to(dev, dtype).requires_grad_(True) for x in (q, k, v)]
+        tb = tables.to(dev, dtype).requires_grad_(True) if rpe else None
+        extra = dict(table=tb, rpe=cfg, vertices=verts.to(dev, dtype).contiguous(), xyz=xyz.to(dev, dtype),
+                     cos_sin=None if cs is None else cs.to(dev, dtype)) if rpe else {}
+        mm = None if m is None else (m.to(dev) if m.dtype == torch.bool else m.to(dev, dtype))
+        out = fn(*args, attn_mask=mm, **kw, **extra)
+        (out * wout.to(dev, dtype)).sum().backward()
+        return [out] + [a.grad for a in args] + ([tb.grad] if rpe else [])
+
+    ref = run(fused_attention_reference, "cpu", torch.float64)
+    got = run(A.fused_attention, DEV, torch.float32)
+    names = ["out", "dq", "dk", "dv", "dtable"]
+    for name, r, o in zip(names, ref, got):
+        scale = float(r.abs().max())
+        if name == "out":
+            assert_close(o, r.numpy(), 1e-4, 1e-5 * max(scale, 1.0), name)
+        else:
+            assert_close(o, r.numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
+
+
+def test_attention_probabilities_and_dropout_statistics():
+    from oracle.attention_oracle import fused_attention_reference
+    from vdetr_amd import attention as A
+    B, nQ, nK, H = 1, 32, 256, 4
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 9)
+    g = torch.Generator().manual_seed(1)
+    q, k, v = torch.randn((B, nQ, 256), generator=g), torch.randn((B, nK, 64), generator=g), torch.randn((B, nK, 64), generator=g)
+    cfg = A.RPEConfig()
+    common = dict(num_heads=H, scale=0.125, shared_kv=True, rpe=cfg)
+    dev = dict(table=tables.to(DEV), vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV))
+    _, probs = fused_attention_reference(q.double(), k.double(), v.double(), table=tables.double(), vertices=verts.double(),
+                                         xyz=xyz.double(), return_probs=True, **common)
+    got = A.attention_probabilities(q.to(DEV), k.to(DEV), **common, **dev)
+    assert_close(got, probs.numpy(), 1e-4, 1e-7, "probs")
+    # dropout: the kernels' keep mask has the right rate, differs per salt / step, and fwd+bwd are consistent with it
+    p = 0.1
+    rng = A.begin_step(DEV)
+    keep = A.dropout_keep_mask(B, H, nQ, nK, True, p, rng, salt=5)
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - p) < 0.01, rate
+    assert not torch.equal(keep, A.dropout_keep_mask(B, H, nQ, nK, True, p, rng, salt=6))
+    assert not torch.equal(keep, A.dropout_keep_mask(B, H, nQ, nK, True, p, A.begin_step(DEV), salt=5))
+    qd, kd, vd, td = (x.to(DEV).requires_grad_(True) for x in (q, k, v, tables))
+    out = A.fused_attention(qd, kd, vd, **common, table=td, vertices=dev["vertices"], xyz=dev["xyz"], dropout_p=p,
+                            rng_state=rng, salt=5)
+    out.sum().backward()
+    qr, kr, vr, tr = (x.double().requires_grad_(True) for x in (q, k, v, tables))
+    ref = fused_attention_reference(qr, kr, vr, table=tr, vertices=verts.double(), xyz=xyz.double(), dropout_p=p,
+                                    keep_mask=keep.cpu(), **common)
+    ref.sum().backward()
+    assert_close(out, ref.detach().numpy(), 1e-4, 1e-5, "dropout out")
+    for name, a, b in [("dq", qd, qr), ("dk", kd, kr), ("dv", vd, vr), ("dtable", td, tr)]:
+        assert_close(a.grad, b.grad.numpy(), 1e-3, 1e-4 * float(b.grad.abs().max()), "dropout " + name)
+
+
+def test_multihead_self_attention_matches_torch():
+    """MultiheadSelfAttention (HIP core) vs torch.nn.MultiheadAttention with the same parameters."""
+    from vdetr_amd.vdetr_transformer import MultiheadSelfAttention
+    torch.manual_seed(0)
+    ref = torch.nn.MultiheadAttention(256, 4, dropout=0.1).eval()
+    mine = MultiheadSelfAttention(256, 4, dropout=0.1).eval()
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    L_, B = 70, 2
+    tgt, pos = torch.randn(L_, B, 256), torch.randn(L_, B, 256)
+    a = tgt.clone().requires_grad_(True)
+    out_ref = ref(a + pos, a + pos, value=a)[0]
+    out_ref.square().sum().backward()
+    b = tgt.clone().to(DEV).requires_grad_(True)
+    qk = b + pos.to(DEV)
+    out = mine(qk, qk, value=b)[0]
+    out.square().sum().backward()
+    assert_close(out, out_ref.detach().numpy(), 1e-4, 1e-5, "mha out")
+    assert_close(b.grad, a.grad.numpy(), 1e-3, 1e-4 * float(a.grad.abs().max()), "mha dgrad")
+    for (n1, p1), (n2, p2) in zip(sorted(ref.named_parameters()), sorted(mine.named_parameters())):
+        assert n1 == n2
+        assert_close(p2.grad, p1.grad.numpy(), 1e-3, 1e-4 * float(p1.grad.abs().max()) + 1e-7, n1)
+
+
+@pytest.mark.parametrize("case", ["cross_attn_small", "cross_attn_rot", "cross_attn_mid"])
+def test_cross_attention_module_vs_reference_vectors(case):
+    g = load_golden(case)
+    mod = build_cross_attention(str(g["angle_type"]), DEV)
+    res = run_cross_attention_case(g, mod, DEV)
+    assert_close(res["x"], g["x"], 1e-3, 1e-5, "x")
+    assert_close(res["attn"], g["attn"], 1e-3, 1e-7, "attn")
+    for k in g.files:
+        if k.startswith("grad_"):
+            assert_close(res[k], g[k], 1e-3, max(2e-4 * np.abs(g[k]).max(), 2e-6), k)
+
+
+def test_share_self_attention_module_vs_reference_vectors():
+    g = load_golden("share_self_attn")
+    mod = build_share_self_attention(DEV)
+    tgt, pos = t(g["tgt"], DEV, grad=True), t(g["pos"], DEV)
+    x, _ = mod(tgt + pos, tgt + pos, value=tgt)
+    (x * t(g["wout"], DEV)).sum().backward()
+    assert_close(x, g["x"], 1e-3, 1e-5, "x")
+    assert_close(tgt.grad, g["grad_tgt"], 1e-3, 1e-6, "grad_tgt")
+    for pname, p in mod.named_parameters():
+        assert_close(p.grad, g["grad_param:" + pname], 1e-3, max(2e-4 * np.abs(g["grad_param:" + pname]).max(), 2e-6), pname)
+
+
+@pytest.mark.parametrize("case,nl,share", [("decoder_c1_l2", 2, False), ("decoder_c1_l3", 3, False),
+                                           ("decoder_c1_l3_share", 3, True)])
+def test_decoder_vs_reference_vectors(case, nl, share):
+    """BASELINE config 1: the whole decoder (HIP attention cores) against the reference's outputs + gradients."""
+    g = load_golden(case)
+    dec = build_decoder(nl, share, DEV)
+    stages, loss, gfeats = run_decoder_case(g, dec, DEV)
+    for s, st in enumerate(stages):
+        for k in ("sem_cls_logits", "center_unnormalized", "size_unnormalized", "box_corners"):
+            assert_close(st[k], g[f"s{s}:{k}"], 1e-3, 2e-4, f"stage {s} {k}")   # 1e-3 relative (north_star)
+    assert_close(loss, g["loss"], 1e-3, 1e-2, "loss")
+    assert_close(gfeats, g["grad_feats"], 5e-3, 2e-4 * np.abs(g["grad_feats"]).max(), "grad_feats")
+    params = dict(dec.named_parameters())
+    for k in g.files:
+        if k.startswith("grad_param:"):
+            assert_close(params[k[11:]].grad, g[k], 5e-3, max(5e-4 * np.abs(g[k]).max(), 2e-6), k)

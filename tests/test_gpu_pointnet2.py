@@ -1,0 +1,146 @@
+"""HIP pointnet2 ops vs the CPU oracle, through the Python API that mirrors pointnet2_utils.py (which calls the
+C-ABI).  Indices: bit-exact.  Floats: bit-exact too where the summation order is fixed (gather, group,
+three_interpolate, three_nn distances); atomically accumulated gradients within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointnet2_oracle as O
+from test_oracle_pointnet2 import grid_cloud
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def cu(a, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("n,m,seed", [(3000, 128, 0), (6000, 1024, 1), (700, 700, 2), (65, 40, 3), (512, 100, 4),
+                                      (1, 1, 5), (63, 63, 6), (20000, 2048, 7)])
+def test_fps_grid_clouds_bit_exact(n, m, seed):
+    from vdetr_amd import pointnet2_utils as PU
+    x = grid_cloud(n, seed)
+    ref = O.furthest_point_sampling(x[None], m)
+    got = PU.furthest_point_sample(cu(x[None]), m).cpu().numpy()
+    assert got.dtype == np.int32
+    bad = np.nonzero(ref != got)[1]
+    assert bad.size == 0, f"first mismatch at sample {bad[:1]} of {m}: ref {ref[0, bad[:3]]} got {got[0, bad[:3]]}"
+
+
+def test_fps_batch_random_and_skip_rule():
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(3, 5000, 3)).astype(np.float32) * 2
+    x[1, :40] *= 0.004            # a cluster inside the origin-skip ball
+    x[2, 0] = 0                   # index 0 itself is skipped but still emitted first
+    ref = O.furthest_point_sampling(x, 600)
+    got = PU.furthest_point_sample(cu(x), 600).cpu().numpy()
+    assert np.array_equal(ref, got)
+    z = torch.zeros((1, 100, 3), device=DEV)
+    assert PU.furthest_point_sample(z, 5).cpu().tolist() == [[0, 0, 0, 0, 0]]
+
+
+def test_fps_full_size_scene():
+    """BASELINE config 2 size: 40k-point voxelised scene -> 4096 samples, against the oracle."""
+    from vdetr_amd import pointnet2_utils as PU
+    x = grid_cloud(40000, 11)
+    ref = O.furthest_point_sampling(x[None], 4096)
+    got = PU.furthest_point_sample(cu(x[None]), 4096).cpu().numpy()
+    assert np.array_equal(ref, got)
+    assert len(set(got[0].tolist())) == 4096  # size-independent property: samples are distinct
+
+
+def test_fps_large_property():
+    """n beyond one bucket per lane-slot (bucket size > 64): distinct samples, first index 0, and the min pairwise
+    distance of the sample set is non-increasing in sampling order (the defining FPS property)."""
+    from vdetr_amd import pointnet2_utils as PU
+    x = np.random.default_rng(3).uniform(1, 9, size=(1, 300000, 3)).astype(np.float32)
+    got = PU.furthest_point_sample(cu(x), 512).cpu().numpy()[0]
+    assert got[0] == 0 and len(set(got.tolist())) == 512
+    p = x[0, got].astype(np.float64)
+    d = ((p[:, None] - p[None]) ** 2).sum(-1)
+    radii = [d[j, :j].min() for j in range(1, 512)]
+    assert all(radii[i] >= radii[i + 1] - 1e-9 for i in range(len(radii) - 1))
+
+
+def test_gather_group_interpolate_and_grads():
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(1)
+    b, c, n, m = 2, 37, 1000, 300
+    pts = rng.normal(size=(b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    f = cu(pts).requires_grad_(True)
+    out = PU.gather_operation(f, cu(idx))
+    assert np.array_equal(out.detach().cpu().numpy(), O.gather_points(pts, idx))
+    g = rng.normal(size=(b, c, m)).astype(np.float32)
+    out.backward(cu(g))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.gather_points_grad(g, idx, n), rtol=1e-5, atol=1e-5)
+
+    gidx = rng.integers(0, n, size=(b, 50, 7)).astype(np.int32)
+    f = cu(pts).requires_grad_(True)
+    out = PU.grouping_operation(f, cu(gidx))
+    assert np.array_equal(out.detach().cpu().numpy(), O.group_points(pts, gidx))
+    g = rng.normal(size=(b, c, 50, 7)).astype(np.float32)
+    out.backward(cu(g))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.group_points_grad(g, gidx, n), rtol=1e-5, atol=1e-5)
+
+    iidx = rng.integers(0, n, size=(b, 400, 3)).astype(np.int32)
+    w = rng.random(size=(b, 400, 3)).astype(np.float32)
+    f = cu(pts).requires_grad_(True)
+    out = PU.three_interpolate(f, cu(iidx), cu(w))
+    assert np.array_equal(out.detach().cpu().numpy(), O.three_interpolate(pts, iidx, w))
+    g = rng.normal(size=(b, c, 400)).astype(np.float32)
+    out.backward(cu(g))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.three_interpolate_grad(g, iidx, w, n), rtol=1e-5, atol=1e-5)
+
+
+def test_reference_interpolation_test_vector():
+    """pointnet2_test.py:15-27 (gradcheck of three_interpolate, atol=rtol=1e-1) on the HIP kernels"""
+    from torch.autograd import gradcheck
+    from vdetr_amd import pointnet2_utils as PU
+    feats = torch.randn(1, 2, 4, device=DEV, requires_grad=True)
+
+    def interpolate_func(inputs):
+        idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32, device=DEV)
+        weight = torch.tensor([[[1, 1, 1], [2, 2, 2]]], dtype=torch.float32, device=DEV)
+        return PU.three_interpolate(inputs, idx, weight)
+
+    assert gradcheck(interpolate_func, feats, atol=1e-1, rtol=1e-1, eps=1e-2)
+
+
+def test_three_nn_and_ball_query():
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(2)
+    known = grid_cloud(1500, 3)[None][:, :1024]
+    unk = grid_cloud(3000, 4)[None][:, :2048]
+    d2, idx = O.three_nn(unk, known)
+    dist, gi = PU.three_nn(cu(unk), cu(known))
+    assert np.array_equal(gi.cpu().numpy(), idx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    # m < 3
+    dist, gi = PU.three_nn(cu(unk[:, :10]), cu(known[:, :2]))
+    assert gi[0, :, 2].cpu().tolist() == [0] * 10 and torch.isinf(dist[0, :, 2]).all()
+
+    xyz = grid_cloud(20000, 5)[None]
+    new_xyz = xyz[:, :700].copy()
+    new_xyz[0, 5] = [100, 100, 100]  # no neighbour
+    for radius, ns in [(0.2, 64), (0.05, 16), (1.0, 3)]:
+        ref = O.ball_query(new_xyz, xyz, radius, ns)
+        got = PU.ball_query(radius, ns, cu(xyz), cu(new_xyz)).cpu().numpy()
+        assert np.array_equal(ref, got), (radius, ns)
+    assert got[0, 5].tolist() == [0, 0, 0]
+
+
+def test_query_and_group_module():
+    from vdetr_amd import pointnet2_utils as PU
+    xyz = cu(grid_cloud(4000, 6)[None])
+    new_xyz = xyz[:, :128].contiguous()
+    feats = torch.randn(1, 5, xyz.shape[1], device=DEV)
+    out = PU.QueryAndGroup(0.3, 8, use_xyz=True)(xyz, new_xyz, feats)
+    assert out.shape == (1, 8, 128, 8)
+    idx = PU.ball_query(0.3, 8, xyz, new_xyz).long()
+    exp = torch.gather(feats[0], 1, idx[0].reshape(1, -1).expand(5, -1)).view(5, 128, 8)
+    assert torch.equal(out[0, 3:], exp)
+    assert PU.GroupAll()(xyz, None, feats).shape == (1, 8, 1, xyz.shape[1])

@@ -1,0 +1,142 @@
+"""Known-answer tests that pin the CPU oracle of the pointnet2 ops (oracle/pointnet2_oracle.c).
+
+The reference pins only three_interpolate (third_party/pointnet2/pointnet2_test.py:15-27, CUDA-only gradcheck
+with idx [[0,1,2],[1,2,3]] and weights [[1,1,1],[2,2,2]]); everything else here is hand-computed from the kernels'
+definition (parity unpinned by the reference).
+"""
+import numpy as np
+
+from oracle import pointnet2_oracle as O
+
+
+def grid_cloud(n, seed=0, voxel=0.04):
+    rng = np.random.default_rng(seed)
+    p = rng.uniform([0, 0, 0], [8, 6, 3], (n, 3)) + 1.0
+    q = np.unique(np.round(p / voxel).astype(np.int64), axis=0)
+    rng.shuffle(q)
+    return (q * voxel).astype(np.float32)
+
+
+def morton_order(x):
+    lo = x.min(0)
+    ext = np.maximum(x.max(0) - lo, 1e-9)
+    c = np.minimum((x - lo) * (16 / ext), 15).astype(np.int64)
+    sp = lambda v: (v & 1) | ((v & 2) << 2) | ((v & 4) << 4) | ((v & 8) << 6)
+    return np.argsort(sp(c[:, 0]) | (sp(c[:, 1]) << 1) | (sp(c[:, 2]) << 2), kind="stable").astype(np.int32)
+
+
+def test_fps_line():
+    xyz = np.array([[[1, 1, 1], [2, 1, 1], [5, 1, 1], [9, 1, 1]]], np.float32)
+    assert O.furthest_point_sampling(xyz, 4).tolist() == [[0, 3, 2, 1]]
+    assert O.furthest_point_sampling(xyz, 1).tolist() == [[0]]
+    assert O.furthest_point_sampling(xyz, 0).shape == (1, 0)
+
+
+def test_fps_tie_order_is_not_first_index():
+    """n=3 -> block of 2 virtual threads: thread 0 scans k=0,2, thread 1 scans k=1.  Points 1 and 2 are both at
+    distance 1 from point 0; the tree keeps the LOWER slot on ties, i.e. thread 0's candidate k=2."""
+    xyz = np.array([[[2, 2, 2], [3, 2, 2], [1, 2, 2]]], np.float32)
+    assert O.furthest_point_sampling(xyz, 2).tolist() == [[0, 2]]
+    assert O.furthest_point_sampling(xyz, 2, "keyed").tolist() == [[0, 2]]
+
+
+def test_fps_origin_skip():
+    """points with x²+y²+z² <= 1e-3 are never candidates (sampling_gpu.cu:103-104) but index 0 is always emitted"""
+    xyz = np.array([[[0.01, 0.01, 0.01], [1, 0, 0], [0, 0.02, 0.01], [3, 0, 0], [-50, 0, 0.001 * 0]]], np.float32)
+    xyz[0, 4] = [0.0, 0.0, 0.03]  # mag 9e-4: skipped although it is far from nothing
+    idx = O.furthest_point_sampling(xyz, 4)[0].tolist()
+    assert idx[0] == 0 and 2 not in idx and 4 not in idx
+    assert idx == [0, 3, 1, 3] or idx[:3] == [0, 3, 1]
+    # all points skipped: the reduction returns besti = 0
+    z = np.zeros((1, 5, 3), np.float32)
+    assert O.furthest_point_sampling(z, 3).tolist() == [[0, 0, 0]]
+
+
+def test_fps_three_formulations_agree_on_tie_heavy_grid():
+    for n, m, seed in [(3000, 128, 0), (6000, 512, 1), (700, 700, 2), (65, 40, 3), (512, 100, 4)]:
+        x = grid_cloud(n, seed)
+        a = O.furthest_point_sampling(x[None], m, "literal")
+        b = O.furthest_point_sampling(x[None], m, "keyed")
+        c, evals = O.furthest_point_sampling_bucketed(x, m, morton_order(x))
+        assert np.array_equal(a, b), (n, m)
+        assert np.array_equal(a[0], c), (n, m)
+        assert evals <= x.shape[0] * (m - 1)
+    # random (tie-free) floats too
+    x = np.random.default_rng(5).normal(size=(2, 2000, 3)).astype(np.float32) + 3
+    assert np.array_equal(O.furthest_point_sampling(x, 300), O.furthest_point_sampling(x, 300, "keyed"))
+
+
+def test_fps_bucket_skipping_saves_work():
+    x = grid_cloud(20000, 7)
+    idx, evals = O.furthest_point_sampling_bucketed(x, 1024, morton_order(x))
+    assert np.array_equal(idx, O.furthest_point_sampling(x[None], 1024)[0])
+    assert evals < 0.2 * x.shape[0] * 1023
+
+
+def test_fps_differs_from_plain_argmax_on_grid_ties():
+    """documents WHY the tie order matters: first-index arg-max diverges on voxel-grid coordinates"""
+    x = grid_cloud(3000, 0)
+    ref = O.furthest_point_sampling(x[None], 256)[0]
+    t = np.full(x.shape[0], 1e10, np.float32)
+    naive, old = [0], 0
+    for _ in range(255):
+        d = ((x - x[old]) ** 2).sum(1, dtype=np.float32)
+        t = np.minimum(t, d)
+        old = int(np.argmax(t))
+        naive.append(old)
+    assert naive[0] == ref[0] and not np.array_equal(np.array(naive), ref)
+
+
+def test_gather_and_grad():
+    pts = np.arange(2 * 3 * 5, dtype=np.float32).reshape(2, 3, 5)
+    idx = np.array([[4, 0, 0], [1, 3, 2]], np.int32)
+    out = O.gather_points(pts, idx)
+    assert out[0, 1].tolist() == [9, 5, 5] and out[1, 2].tolist() == [26, 28, 27]
+    g = O.gather_points_grad(np.ones((2, 3, 3), np.float32), idx, 5)
+    assert g[0, 0].tolist() == [2, 0, 0, 0, 1] and g[1, 0].tolist() == [0, 1, 1, 1, 0]
+
+
+def test_ball_query():
+    xyz = np.array([[[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0], [1.5, 0, 0]]], np.float32)
+    q = np.array([[[1.2, 0, 0], [10, 10, 10], [3, 0, 0]]], np.float32)
+    idx = O.ball_query(q, xyz, 1.0, 4)
+    # query 0: d² < 1 -> points 1 (0.04), 2 (0.64), 4 (0.09): ascending index, then padded with the first hit
+    assert idx[0, 0].tolist() == [1, 2, 4, 1]
+    assert idx[0, 1].tolist() == [0, 0, 0, 0]            # no neighbour: row stays zero
+    assert idx[0, 2].tolist() == [3, 3, 3, 3]            # d² = 1.0 to point 2 is NOT < 1 (strict)
+    assert O.ball_query(q, xyz, 1.0, 2)[0, 0].tolist() == [1, 2]  # stops at nsample
+
+
+def test_group_and_grad():
+    pts = np.arange(2 * 4, dtype=np.float32).reshape(1, 2, 4)
+    idx = np.array([[[0, 0, 3], [2, 1, 1]]], np.int32)
+    out = O.group_points(pts, idx)
+    assert out.shape == (1, 2, 2, 3) and out[0, 1].tolist() == [[4, 4, 7], [6, 5, 5]]
+    g = O.group_points_grad(np.ones((1, 2, 2, 3), np.float32), idx, 4)
+    assert g[0, 0].tolist() == [2, 2, 1, 1]
+
+
+def test_three_nn():
+    known = np.array([[[0, 0, 0], [1, 0, 0], [2, 0, 0], [0.5, 0, 0]]], np.float32)
+    unk = np.array([[[0.4, 0, 0], [5, 0, 0]]], np.float32)
+    d2, idx = O.three_nn(unk, known)
+    assert idx[0, 0].tolist() == [3, 0, 1] and np.allclose(d2[0, 0], [0.01, 0.16, 0.36], atol=1e-6)
+    assert idx[0, 1].tolist() == [2, 1, 3]
+    # tie: equidistant known points -> the earlier index wins (strict '<')
+    d2, idx = O.three_nn(np.array([[[0.5, 0, 0]]], np.float32), known[:, :2])
+    assert idx[0, 0].tolist() == [0, 1, 0] and np.isinf(d2[0, 0, 2])   # m < 3: trailing slot stays (inf, 0)
+
+
+def test_three_interpolate_reference_vector():
+    """the reference's own test inputs (pointnet2_test.py:21-24)"""
+    feats = np.random.default_rng(0).normal(size=(1, 2, 4)).astype(np.float32)
+    idx = np.array([[[0, 1, 2], [1, 2, 3]]], np.int32)
+    w = np.array([[[1, 1, 1], [2, 2, 2]]], np.float32)
+    out = O.three_interpolate(feats, idx, w)
+    exp = np.stack([feats[0, :, 0] + feats[0, :, 1] + feats[0, :, 2], 2 * (feats[0, :, 1] + feats[0, :, 2] + feats[0, :, 3])], -1)
+    assert np.allclose(out[0], exp, rtol=1e-6)
+    # gradient = transpose of the (linear) forward map: <out, g> == <feats, grad(g)>   (the gradcheck of :26)
+    g = np.random.default_rng(1).normal(size=out.shape).astype(np.float32)
+    gf = O.three_interpolate_grad(g, idx, w, 4)
+    assert np.isclose((out * g).sum(), (feats * gf).sum(), rtol=1e-5)
+    assert np.allclose(gf[0, 0], [g[0, 0, 0], g[0, 0, 0] + 2 * g[0, 0, 1], g[0, 0, 0] + 2 * g[0, 0, 1], 2 * g[0, 0, 1]], rtol=1e-6)

@@ -1,0 +1,118 @@
+"""ctypes binding of lib/libvdetr_hip.so (the C-ABI declared in include/vdetr_hip.h).
+
+The binding is deliberately thin: raw device pointers, explicit sizes, the caller's current HIP stream.
+It fails loudly — there is no CPU path behind any of these calls.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvdetr_hip.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+VDETR_ATTN_SHARED_KV, VDETR_ATTN_PER_HEAD = 0, 1
+VDETR_MASK_NONE, VDETR_MASK_BOOL, VDETR_MASK_FLOAT = 0, 1, 2
+
+
+class AttnDesc(ctypes.Structure):
+    """Mirror of ``vdetr_attn_desc`` (include/vdetr_hip.h)."""
+
+    _fields_ = [
+        ("kind", ctypes.c_int32), ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("nQ", ctypes.c_int32),
+        ("nK", ctypes.c_int32), ("scale", c_float),
+        ("table", c_void_p), ("table_size", ctypes.c_int32), ("log_scale", c_float), ("inv_log_norm", c_float),
+        ("vertices", c_void_p), ("xyz", c_void_p), ("cos_sin", c_void_p),
+        ("mask", c_void_p), ("mask_kind", ctypes.c_int32),
+        ("dropout_p", c_float), ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
+        ("rng_state", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
+_SIGNATURES = {
+    "vdetr_abi_version": (c_int, []),
+    "vdetr_last_error": (ctypes.c_char_p, []),
+    "vdetr_fps_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vdetr_furthest_point_sampling_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_gather_points_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vdetr_gather_points_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vdetr_ball_query_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "vdetr_group_points_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vdetr_group_points_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vdetr_three_nn_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vdetr_three_interpolate_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vdetr_three_interpolate_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vdetr_attn_fwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
+    "vdetr_attn_fwd_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_attn_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
+    "vdetr_attn_bwd_scores_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_attn_dropout_mask_u8": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
+    "vdetr_rpe_bias_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
+    "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load (once) the HIP library.  Raises if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  vdetr_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError = ABI mismatch: fail loudly
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(status, op):
+    if status != 0:
+        msg = lib().vdetr_last_error().decode(errors="replace")
+        raise RuntimeError(f"vdetr_hip {op} failed (status {status}): {msg}")
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+# ---- argument checks mirroring the reference's CHECK_* macros (_ext_src/include/utils.h:8-28) ------------
+def require_gpu(t, name):
+    if not t.is_cuda:
+        # reference: AT_ASSERT(false, "CPU not supported") (sampling.cpp:36,62,84 ...)
+        raise RuntimeError(f"{name}: CPU not supported (tensor is on {t.device})")
+
+
+def require_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def require_float(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")
+
+
+def require_int(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

@@ -1,0 +1,263 @@
+"""Autograd bindings of the fused attention kernels (lib/libvdetr_hip.so: vdetr_attn_fwd_f32 /
+vdetr_attn_bwd_scores_f32).
+
+One ``torch.autograd.Function`` covers the three attention flavours of the decoder:
+  * 3DV-RPE cross attention  (GlobalShareCrossAttention core, vdetr_transformer.py:710-753): shared K/V + RPE table
+  * ShareSelfAttention core  (:644-648): shared K/V, no bias
+  * nn.MultiheadAttention core (:468): per-head K/V
+Everything outside the core (q/k/v/out projections, the cpb MLP that produces the table) stays in PyTorch so
+that parameters, their names and their gradients flow exactly as in the reference modules.
+
+Forward saves the biased scores S [rows, nK] and the row log-sum-exp; backward is
+  dP~ = dO V^T (GEMM) -> kernel: P~, dS, dTable -> dV = P~^T dO, dK = dS^T q, dQ = dS K (GEMMs).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+HEAD_DIM = 64
+
+
+class RPEConfig:
+    """Static parameters of the 3DV-RPE lookup (vdetr_transformer.py:671-683,722-723)."""
+
+    def __init__(self, table_size=10, log_scale=512.0, max_value=4.0):
+        self.table_size = int(table_size)
+        self.log_scale = float(log_scale)
+        self.max_value = float(max_value)
+
+    @property
+    def inv_log_norm(self):
+        # deltas / np.log2(8) / max_value
+        return 1.0 / (3.0 * self.max_value)
+
+
+def new_rng_state(device, seed=None):
+    """Device-resident Philox {seed, offset}."""
+    if seed is None:
+        seed = torch.initial_seed()
+    return torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+
+
+# Per-device master state + the snapshot of the current step.  ``begin_step`` takes a snapshot (a NEW tensor that
+# is never written again, so autograd can keep it by reference) and bumps the master offset with a device op:
+# the same captured hipGraph therefore draws fresh dropout masks on every replay.  Modules that share a snapshot
+# stay independent through their per-module ``salt`` (the by-value seed of the descriptor).
+_master = {}
+_current = {}
+
+
+def begin_step(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _master:
+        _master[key] = new_rng_state(device)
+    snap = _master[key].clone()
+    _master[key][1] += 1
+    _current[key] = snap
+    return snap
+
+
+def current_rng(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    return _current.get(key)
+
+
+def reset_rng(seed=None):
+    """Forget every per-device state (e.g. after torch.manual_seed)."""
+    _master.clear()
+    _current.clear()
+
+
+def _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng_state, salt=0):
+    d = L.AttnDesc()
+    d.kind, d.B, d.H, d.nQ, d.nK, d.scale = kind, B, H, nQ, nK, float(scale)
+    if table is not None:
+        d.table = table.data_ptr()
+        d.table_size, d.log_scale, d.inv_log_norm = rpe.table_size, rpe.log_scale, rpe.inv_log_norm
+        d.vertices, d.xyz = vertices.data_ptr(), xyz.data_ptr()
+        d.cos_sin = cos_sin.data_ptr() if cos_sin is not None else None
+    if mask is not None:
+        d.mask = mask.data_ptr()
+        d.mask_kind = L.VDETR_MASK_BOOL if mask.dtype == torch.uint8 else L.VDETR_MASK_FLOAT
+    d.dropout_p = float(dropout_p)
+    d.seed = int(salt) & 0xFFFFFFFFFFFFFFFF
+    if rng_state is not None:
+        d.rng_state = rng_state.data_ptr()
+    return d
+
+
+def _prep_mask(mask, B, nQ, nK):
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        mask = mask.to(torch.uint8)
+    elif mask.dtype != torch.float32:
+        mask = mask.float()
+    return mask.expand(B, nQ, nK).contiguous()
+
+
+def _check_inputs(**tensors):
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        L.require_gpu(t, name)
+        L.require_contiguous(t, name)
+        L.require_float(t, name)
+
+
+class _FusedAttention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, table, vertices, xyz, cos_sin, mask, kind, H, scale, rpe, dropout_p, rng_state,
+                need_grad, salt):
+        B, nQ, C = q.shape
+        nK = k.shape[1]
+        assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
+        _check_inputs(q=q, k=k, v=v, table=table, vertices=vertices, xyz=xyz, cos_sin=cos_sin)
+        lib = L.lib()
+        use_drop = dropout_p > 0.0
+        rng = rng_state if use_drop else None  # a per-step snapshot nobody writes again (begin_step)
+        d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p if use_drop else 0.0, rng,
+                  salt)
+        out = torch.empty_like(q)
+        rows = (B, nQ, H) if kind == L.VDETR_ATTN_SHARED_KV else (B, H, nQ)
+        lse = torch.empty(rows, dtype=torch.float32, device=q.device)
+        scores = torch.empty(rows + (nK,), dtype=torch.float32, device=q.device) if need_grad else None
+        nbytes = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
+        ws = L.workspace(nbytes, q.device) if nbytes else None
+        L.check(lib.vdetr_attn_fwd_f32(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse),
+                                       L.ptr(scores), L.ptr(ws), nbytes, L.stream_ptr()), "attn_fwd")
+        if need_grad:
+            ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
+            ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng = ctx.saved_tensors
+        kind, H, scale, rpe, dropout_p, salt = ctx.cfg
+        B, nQ, C = q.shape
+        nK = k.shape[1]
+        lib = L.lib()
+        dout = dout.contiguous()
+        shared = kind == L.VDETR_ATTN_SHARED_KV
+        if shared:
+            # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
+            do_r = dout.view(B, nQ * H, HEAD_DIM)
+            delta = (dout * out).view(B, nQ, H, HEAD_DIM).sum(-1)
+            dprob = torch.bmm(do_r, v.transpose(1, 2))  # [B, nQ*H, nK]
+        else:
+            # rows (b, h, q): [B*H, nQ, 64]; K/V [B*H, nK, 64]
+            do_r = dout.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
+            o_r = out.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
+            delta = (do_r * o_r).sum(-1).view(B, H, nQ)
+            v_r = v.view(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
+            dprob = torch.bmm(do_r, v_r.transpose(1, 2))  # [B*H, nQ, nK]
+        delta = delta.contiguous()
+        d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt)
+        want_table = table is not None and ctx.needs_input_grad[3]
+        dtable = torch.zeros_like(table) if want_table else None
+        nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d)) if want_table else 0
+        ws = L.workspace(nbytes, q.device) if nbytes else None
+        # in place: scores -> P~ (dropped probabilities), dprob -> dS.  `scores` is dead after this call.
+        L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), L.ptr(dprob), L.ptr(lse), L.ptr(delta),
+                                              L.ptr(dtable), L.ptr(ws), nbytes, L.stream_ptr()), "attn_bwd_scores")
+        if shared:
+            p_r = scores.view(B, nQ * H, nK)
+            ds_r = dprob
+            q_r = q.view(B, nQ * H, HEAD_DIM)
+            dv = torch.bmm(p_r.transpose(1, 2), do_r)
+            dk = torch.bmm(ds_r.transpose(1, 2), q_r) * scale
+            dq = (torch.bmm(ds_r, k) * scale).view(B, nQ, C)
+        else:
+            p_r = scores.view(B * H, nQ, nK)
+            ds_r = dprob
+            q_r = q.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
+            k_r = k.view(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
+            dv = torch.bmm(p_r.transpose(1, 2), do_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
+            dk = (torch.bmm(ds_r.transpose(1, 2), q_r) * scale).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
+            dq = (torch.bmm(ds_r, k_r) * scale).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
+        return (dq, dk, dv, dtable) + (None,) * 12
+
+
+def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
+                    cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0):
+    """out[B,nQ,H*64] = dropout(softmax(scale * q k^T + rpe + mask)) v.
+
+    q [B,nQ,H*64]; k,v [B,nK,64] (shared_kv) or [B,nK,H*64]; table [8,T,T,T,H]; vertices [B,nQ,8,3];
+    xyz [B,nK,3]; cos_sin [B,nQ,2] or None; attn_mask [B,nQ,nK] bool (-100 fill) / float (additive) or None.
+    """
+    B, nQ, _ = q.shape
+    nK = k.shape[1]
+    kind = L.VDETR_ATTN_SHARED_KV if shared_kv else L.VDETR_ATTN_PER_HEAD
+    if dropout_p > 0.0 and rng_state is None:
+        rng_state = current_rng(q.device)
+        if rng_state is None:
+            rng_state = begin_step(q.device)
+    mask = _prep_mask(attn_mask, B, nQ, nK)
+    need_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (q, k, v, table))
+    if table is not None:
+        table = table.contiguous()
+        vertices = vertices.detach().contiguous()
+        xyz = xyz.detach().contiguous()
+        if cos_sin is not None:
+            cos_sin = cos_sin.detach().contiguous()
+    return _FusedAttention.apply(q.contiguous(), k.contiguous(), v.contiguous(), table, vertices, xyz, cos_sin, mask,
+                                 kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt))
+
+
+def attention_probabilities(q, k, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
+                            cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0):
+    """The ``attn`` tensor the reference modules return next to the output (vdetr_transformer.py:751-752,758):
+    dropout(softmax(scores)) as [B,H,nQ,nK].  Only materialised on request (it is 64 MB per layer at full size).
+    ``rng_state`` must be the state the matching forward call used."""
+    B, nQ, C = q.shape
+    nK = k.shape[1]
+    kind = L.VDETR_ATTN_SHARED_KV if shared_kv else L.VDETR_ATTN_PER_HEAD
+    mask = _prep_mask(attn_mask, B, nQ, nK)
+    lib = L.lib()
+    with torch.no_grad():
+        q, k = q.detach().contiguous(), k.detach().contiguous()
+        if table is not None:
+            table, vertices, xyz = table.detach().contiguous(), vertices.detach().contiguous(), xyz.detach().contiguous()
+            cos_sin = cos_sin.detach().contiguous() if cos_sin is not None else None
+        d = _desc(kind, B, num_heads, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng_state, salt)
+        out = torch.empty_like(q)
+        rows = (B, nQ, num_heads) if shared_kv else (B, num_heads, nQ)
+        lse = torch.empty(rows, dtype=torch.float32, device=q.device)
+        scores = torch.empty(rows + (nK,), dtype=torch.float32, device=q.device)
+        # V is irrelevant for the probabilities; K doubles as V to keep the call well-formed
+        nbytes = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
+        ws = L.workspace(nbytes, q.device) if nbytes else None
+        L.check(lib.vdetr_attn_fwd_f32(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(k), L.ptr(out), L.ptr(lse),
+                                       L.ptr(scores), L.ptr(ws), nbytes, L.stream_ptr()), "attn_fwd")
+        L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), None, L.ptr(lse), None, None, None, 0,
+                                              L.stream_ptr()), "attn_probs")
+    return scores.permute(0, 2, 1, 3) if shared_kv else scores
+
+
+def rpe_bias(table, vertices, xyz, rpe, cos_sin=None):
+    """rpe[B,H,nQ,nK] of vdetr_transformer.py:710-731 alone (parity hook; the fused kernel never stores it)."""
+    _check_inputs(table=table, vertices=vertices, xyz=xyz, cos_sin=cos_sin)
+    B, nQ = vertices.shape[:2]
+    nK = xyz.shape[1]
+    H = table.shape[-1]
+    d = _desc(L.VDETR_ATTN_SHARED_KV, B, H, nQ, nK, 1.0, table, rpe, vertices, xyz, cos_sin, None, 0.0, None)
+    out = torch.empty((B, nQ, H, nK), dtype=torch.float32, device=table.device)
+    L.check(L.lib().vdetr_rpe_bias_f32(ctypes.byref(d), L.ptr(out), L.stream_ptr()), "rpe_bias")
+    return out.permute(0, 2, 1, 3)
+
+
+def dropout_keep_mask(B, H, nQ, nK, shared_kv, dropout_p, rng_state, salt=0):
+    """uint8 keep-mask the kernels draw for (dropout_p, rng_state): [B,H,nQ,nK].  Test hook."""
+    kind = L.VDETR_ATTN_SHARED_KV if shared_kv else L.VDETR_ATTN_PER_HEAD
+    d = _desc(kind, B, H, nQ, nK, 1.0, None, None, None, None, None, None, dropout_p, rng_state, salt)
+    rows = (B, nQ, H) if shared_kv else (B, H, nQ)
+    keep = torch.empty(rows + (nK,), dtype=torch.uint8, device=rng_state.device)
+    L.check(L.lib().vdetr_attn_dropout_mask_u8(ctypes.byref(d), L.ptr(keep), L.stream_ptr()), "dropout_mask")
+    return keep.permute(0, 2, 1, 3) if shared_kv else keep

@@ -42,6 +42,7 @@ __device__ __forceinline__ ScoreGrad score_grad(float s, float lse, bool keep, f
 
 // ---- generic kernel (no RPE): one thread per score element ----------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(AttnParams P) {
+  attn_load_rng(P);
   const size_t total = (size_t)P.B * P.H * P.nQ * P.nK;
   const bool perhead = P.kind == VDETR_ATTN_PER_HEAD;
   const bool have_grad = P.dprob != nullptr;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(AttnParams P) {
 template <int VARIANT>
 __global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // dTable copy [8][T^3][4]
+  attn_load_rng(P);
   const int tid = threadIdx.x;
   const int T = P.T, TT = T * T, T3 = TT * T;
   const int table_floats = kRpeVerts * T3 * 4;
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(256) void attn_bwd_table_reduce_kernel(const float*
 
 // keep-mask dump (test hook)
 __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, uint8_t* keep) {
+  attn_load_rng(P);
   const size_t total = (size_t)P.B * P.H * P.nQ * P.nK;
   const bool perhead = P.kind == VDETR_ATTN_PER_HEAD;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -212,12 +215,7 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, float* scores
     }
     P.dtable_part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     lds = (size_t)table_floats * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_scores_rpe_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("attn_bwd_scores: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      return VDETR_ERR_LAUNCH;
-    }
+    if (int e = set_lds(attn_bwd_scores_rpe_kernel<0>, lds, "attn_bwd_scores")) return e;
   }
   hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<0>), dim3(grid), dim3(kBwdThreads), lds, st, P);
   if (int e = check_launch("attn_bwd_scores_rpe")) return e;

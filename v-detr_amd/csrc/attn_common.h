@@ -37,6 +37,7 @@ struct AttnParams {
   unsigned drop_thresh;  // keep iff rand >= thresh
   float drop_scale;      // 1 / (1 - p)
   unsigned seed_lo, seed_hi, off_lo, off_hi;
+  const unsigned long long* rng;  // optional device {seed, offset}
   // key split (forward)
   int ksplit, tiles_per_split;
   float* part_o;    // [ksplit][rows][64]
@@ -60,6 +61,17 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
     k.y += W1;
   }
   return c;
+}
+// kernels call this first: fold the device-resident {seed, offset} pair into the by-value one
+__device__ __forceinline__ void attn_load_rng(AttnParams& P) {
+  if (P.rng) {
+    // device state is COMBINED with the by-value pair: seed ^= state.seed, offset += state.offset, so that
+    // many attention modules can share one per-step device state and still draw independent masks
+    const unsigned long long s = P.rng[0] ^ (((unsigned long long)P.seed_hi << 32) | P.seed_lo);
+    const unsigned long long o = P.rng[1] + (((unsigned long long)P.off_hi << 32) | P.off_lo);
+    P.seed_lo = (unsigned)s; P.seed_hi = (unsigned)(s >> 32);
+    P.off_lo = (unsigned)o; P.off_hi = (unsigned)(o >> 32);
+  }
 }
 // Random words of attention element (b, q, key) for heads 4*hgroup .. 4*hgroup+3.
 __device__ __forceinline__ uint4 attn_rand4(const AttnParams& P, int b, int q, int key, int hgroup) {

@@ -29,6 +29,7 @@ constexpr int kPPad = 20;  // floats per row of the P transpose pad (16 + 4: kee
 template <bool PERHEAD, bool RPE>
 __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  attn_load_rng(P);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int b = blockIdx.z;
@@ -326,6 +327,7 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   }
   P->seed_lo = (unsigned)d->seed; P->seed_hi = (unsigned)(d->seed >> 32);
   P->off_lo = (unsigned)d->offset; P->off_hi = (unsigned)(d->offset >> 32);
+  P->rng = reinterpret_cast<const unsigned long long*>(d->rng_state);
   P->ksplit = 1; P->tiles_per_split = (d->nK + 15) / 16;
   return VDETR_OK;
 }
@@ -347,18 +349,6 @@ extern "C" size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (ks == 1) return 0;
   const size_t rows = (size_t)d->B * d->nQ * d->H;
   return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256;
-}
-
-template <typename K>
-static int set_lds(K kernel, size_t bytes, const char* op) {
-  if (bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) {
-      set_error("%s: cannot reserve %zu B of LDS: %s", op, bytes, hipGetErrorString(e));
-      return VDETR_ERR_LAUNCH;
-    }
-  }
-  return VDETR_OK;
 }
 
 extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,

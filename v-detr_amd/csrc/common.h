@@ -34,6 +34,14 @@ inline int check_launch(const char* what) {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Raises a kernel's dynamic-LDS limit (needed above 64 KB) once per high-water mark, so that after the first
+// launches no runtime API call is left on the launch path (safe inside hipGraph capture).  core.hip.
+int reserve_lds(const void* kernel, size_t bytes, const char* op);
+template <typename K>
+inline int set_lds(K kernel, size_t bytes, const char* op) {
+  return reserve_lds(reinterpret_cast<const void*>(kernel), bytes, op);
+}
+
 // Squared distance in the contraction order LLVM emits for
 //   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
 // (sampling_gpu.cu:106-107, ball_query_gpu.cu:34-35, interpolate_gpu.cu:36): t = dy*dy; t = fma(dx,dx,t);

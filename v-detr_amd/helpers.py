@@ -1,0 +1,92 @@
+"""Small building blocks of the decoder with the reference's state-dict layout (models/helpers.py).
+
+Kept in plain PyTorch on purpose: these are 1x1 convolutions / linears + norms, i.e. library GEMMs; only their
+parameter NAMES and numerics matter for checkpoint compatibility:
+  GenericMLP.layers.{0,1,4,5,8}.*                (helpers.py:74-141, Conv1d-BN-ReLU-Dropout x2 -> Conv1d)
+  PositionEmbeddingLearned.position_embedding_head.{0,1,3}.*   (helpers.py:17-33)
+"""
+import copy
+from functools import partial
+
+import torch.nn as nn
+
+
+class BatchNormDim1Swap(nn.BatchNorm1d):
+    """BatchNorm over the channel axis of a sequence-first (L, N, C) tensor (helpers.py:36-53)."""
+
+    def forward(self, x):
+        return super().forward(x.permute(1, 2, 0)).permute(2, 0, 1)
+
+
+NORM_DICT = {"bn": BatchNormDim1Swap, "bn1d": nn.BatchNorm1d, "id": nn.Identity, "ln": nn.LayerNorm}
+ACTIVATION_DICT = {"relu": nn.ReLU, "gelu": nn.GELU, "leakyrelu": partial(nn.LeakyReLU, negative_slope=0.1)}
+WEIGHT_INIT_DICT = {"xavier_uniform": nn.init.xavier_uniform_}
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """(B, N, C_in) coordinates -> (B, num_pos_feats, N) learned embedding (helpers.py:17-33)."""
+
+    def __init__(self, input_channel, num_pos_feats=288):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            nn.BatchNorm1d(num_pos_feats),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1),
+        )
+
+    def forward(self, xyz):
+        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+
+class GenericMLP(nn.Module):
+    """Stack of (Conv1d|Linear) -> norm -> activation -> dropout blocks followed by an output layer.
+
+    Constructor arguments, defaults and the order of sub-modules inside ``self.layers`` follow helpers.py:74-141,
+    so ``state_dict()`` keys line up with reference checkpoints.
+    """
+
+    def __init__(self, input_dim, hidden_dims, output_dim, norm_fn_name=None, activation="relu", use_conv=False,
+                 dropout=None, hidden_use_bias=False, output_use_bias=True, output_use_activation=False,
+                 output_use_norm=False, weight_init_name=None):
+        super().__init__()
+        act = ACTIVATION_DICT[activation]
+        norm = NORM_DICT[norm_fn_name] if norm_fn_name is not None else None
+        if norm_fn_name == "ln" and use_conv:
+            norm = lambda ch: nn.GroupNorm(1, ch)  # LayerNorm over channels for (B, C, N) tensors
+        if dropout is not None and not isinstance(dropout, list):
+            dropout = [dropout] * len(hidden_dims)
+
+        def affine(cin, cout, bias):
+            return nn.Conv1d(cin, cout, 1, bias=bias) if use_conv else nn.Linear(cin, cout, bias=bias)
+
+        mods, cin = [], input_dim
+        for i, width in enumerate(hidden_dims):
+            mods.append(affine(cin, width, hidden_use_bias))
+            if norm:
+                mods.append(norm(width))
+            mods.append(act())
+            if dropout is not None:
+                mods.append(nn.Dropout(p=dropout[i]))
+            cin = width
+        mods.append(affine(cin, output_dim, output_use_bias))
+        if output_use_norm:
+            mods.append(norm(output_dim))
+        if output_use_activation:
+            mods.append(act())
+        self.layers = nn.Sequential(*mods)
+        if weight_init_name is not None:
+            self.do_weight_init(weight_init_name)
+
+    def do_weight_init(self, weight_init_name):
+        init = WEIGHT_INIT_DICT[weight_init_name]
+        for _, p in self.named_parameters():
+            if p.dim() > 1:
+                init(p)
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+def get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])

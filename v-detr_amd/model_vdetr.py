@@ -1,0 +1,174 @@
+"""Post-backbone part of the reference's ``models/model_vdetr.py``: FPS + gather of the backbone's voxel
+features, projection, first-stage anchors and the decoder call, with the same ``forward(inputs)`` contract and the
+same state-dict keys (``encoder_to_decoder_projection.layers.{0,1}``, ``decoder.*``).
+
+The sparse-convolution backbone (MinkowskiEngine ResNet34 + FPN, model_vdetr.py:139-185,250-280) is OUT OF SCOPE:
+``pre_encoder`` here is any callable that returns what the reference takes from it at model_vdetr.py:279-280 —
+per scene, the voxel coordinates ``xyz [n,3]`` (= out.C[:,1:] * voxel_size) and features ``feats [n,C]`` (= out.F).
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import pointnet2_utils
+from .helpers import GenericMLP
+from .position_embedding import PositionEmbeddingCoordsSine
+from .vdetr_transformer import FFNLayer, GlobalDecoderLayer, TransformerDecoder
+
+
+class FPSModule(nn.Module):
+    """Farthest point sampling + gather of coordinates and features (model_vdetr.py:18-34)."""
+
+    def forward(self, xyz, features, num_proposal):
+        """xyz (B,K,3), features (B,C,K) -> new_xyz (B,M,3), new_features (B,C,M), sample_inds (B,M) int32"""
+        sample_inds = pointnet2_utils.furthest_point_sample(xyz, num_proposal)
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sample_inds).transpose(1, 2).contiguous()
+        new_features = pointnet2_utils.gather_operation(features, sample_inds).contiguous()
+        return new_xyz, new_features, sample_inds
+
+
+class TensorBackbone(nn.Module):
+    """Backbone provider that hands back tensors stored in the batch itself: ``inputs["backbone_xyz"]`` /
+    ``inputs["backbone_features"]`` are lists with one ``[n_i,3]`` / ``[n_i,C]`` tensor per scene.  Used by the
+    benchmarks and tests in place of the sparse-conv backbone."""
+
+    def forward(self, inputs):
+        return list(zip(inputs["backbone_xyz"], inputs["backbone_features"]))
+
+
+def convert_unnorm2norm(xyz_unnorm, point_cloud_dims, with_offset=True):
+    """model_vdetr.py:383-390"""
+    scene_size = point_cloud_dims[1] - point_cloud_dims[0]
+    offset = point_cloud_dims[0].unsqueeze(1) if with_offset else 0
+    return (xyz_unnorm - offset) / scene_size.unsqueeze(1)
+
+
+class ModelVDETR(nn.Module):
+    """forward(inputs) with inputs = {"point_clouds": ..., "point_cloud_dims_min": [B,3], "point_cloud_dims_max":
+    [B,3]} -> {"outputs", "aux_outputs", "seed_inds", "seed_xyz", "enc_outputs"} (model_vdetr.py:328-381)."""
+
+    def __init__(self, pre_encoder, encoder, decoder, dataset_config, encoder_dim=256, decoder_dim=256,
+                 num_queries=1024, querypos_mlp=False, minkowski=False, inplane=64, num_stages=4, voxel_size=0.01,
+                 npoint=2048, use_fpn=False, layer_idx=-1, proj_nohid=False, woexpand_conv=False, args=None):
+        super().__init__()
+        self.pre_encoder = pre_encoder
+        self.encoder = encoder  # always None: V-DETR removed the 3DETR encoder (model_vdetr.py:452)
+        self.querypos_mlp = querypos_mlp
+        self.voxel_size = voxel_size
+        self.npoint = npoint
+        # reads args.random_fps with a default: the reference never defines the flag
+        self.random_fps = bool(getattr(args, "random_fps", False))
+        self.fps_module = FPSModule()
+        hidden_dims = [] if (encoder is None and proj_nohid) else [encoder_dim]
+        self.encoder_to_decoder_projection = GenericMLP(
+            input_dim=encoder_dim, hidden_dims=hidden_dims, output_dim=decoder_dim, norm_fn_name="bn1d",
+            activation="relu", use_conv=True, output_use_activation=True, output_use_norm=True,
+            output_use_bias=False)
+        if not self.querypos_mlp:
+            self.pos_embedding = PositionEmbeddingCoordsSine(d_pos=decoder_dim, pos_type="fourier", normalize=True)
+            self.query_projection = GenericMLP(input_dim=decoder_dim, hidden_dims=[decoder_dim],
+                                               output_dim=decoder_dim, use_conv=True, output_use_activation=True,
+                                               hidden_use_bias=True)
+        self.decoder = decoder
+        self.num_queries = num_queries
+        self.dataset_config = dataset_config
+        self.hard_anchor = bool(getattr(args, "hard_anchor", False))
+
+    def _anchor_sizes(self, ref):
+        """per-class anchor sizes on ref's device (model_vdetr.py:348-352), cached so the forward has no H2D copy"""
+        key = (ref.device, ref.dtype, self.hard_anchor)
+        cache = self.__dict__.setdefault("_anchor_cache", {})
+        if key not in cache:
+            sizes = self.dataset_config.mean_size_arr_hard_anchor if self.hard_anchor else self.dataset_config.mean_size_arr
+            cache[key] = torch.as_tensor(sizes, dtype=ref.dtype, device=ref.device)
+        return cache[key]
+
+    def get_query_embeddings(self, encoder_xyz, enc_features, point_cloud_dims):
+        if self.querypos_mlp:
+            return encoder_xyz, encoder_xyz, None
+        pos_embed = self.pos_embedding(encoder_xyz, input_range=point_cloud_dims)
+        return encoder_xyz, self.query_projection(pos_embed).permute(2, 0, 1), None
+
+    def run_encoder(self, inputs):
+        """Backbone output -> FPS to ``npoint`` tokens per scene (model_vdetr.py:279-326)."""
+        scenes = self.pre_encoder(inputs)
+        same_n = len({s[0].shape[0] for s in scenes}) == 1
+        if same_n and not self.random_fps:
+            xyz = torch.stack([s[0] for s in scenes]).contiguous()                   # B,n,3
+            feats = torch.stack([s[1] for s in scenes]).transpose(1, 2).contiguous()  # B,C,n
+            enc_xyz, enc_features, enc_inds = self.fps_module(xyz, feats, self.npoint)  # one launch, B workgroups
+        else:
+            out = []
+            for xyz_i, feats_i in scenes:
+                if self.random_fps:
+                    perm = torch.randperm(xyz_i.shape[0], device=xyz_i.device)
+                    xyz_i, feats_i = xyz_i[perm], feats_i[perm]
+                out.append(self.fps_module(xyz_i.unsqueeze(0).contiguous(),
+                                           feats_i.transpose(0, 1).unsqueeze(0).contiguous(), self.npoint))
+            enc_xyz = torch.cat([o[0] for o in out])
+            enc_features = torch.cat([o[1] for o in out])
+            enc_inds = torch.cat([o[2] for o in out])
+        return enc_xyz, enc_features.permute(2, 0, 1), enc_inds  # features: npoints x batch x channel
+
+    def forward(self, inputs, encoder_only=False):
+        point_cloud_dims = [inputs["point_cloud_dims_min"], inputs["point_cloud_dims_max"]]
+        enc_xyz, enc_features, enc_inds = self.run_encoder(inputs)
+        bs, npoints, _ = enc_xyz.shape
+        enc_features = self.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
+
+        point_cls_logits = self.decoder.pointcls_heads(enc_features.permute(1, 2, 0).contiguous()) \
+            .transpose(1, 2).reshape((bs, npoints, -1)).contiguous()
+        class_idx = point_cls_logits.sigmoid().max(dim=-1)[1]
+        size_unnormalized = self._anchor_sizes(enc_features)[class_idx]
+        query_xyz, query_embed, _ = self.get_query_embeddings(enc_xyz, enc_features, point_cloud_dims)
+        enc_box_predictions = {
+            "point_cls_logits": point_cls_logits,
+            "center_unnormalized": query_xyz,
+            "center_normalized": convert_unnorm2norm(query_xyz, point_cloud_dims),
+            "size_unnormalized": size_unnormalized,
+            "size_normalized": convert_unnorm2norm(size_unnormalized, point_cloud_dims, with_offset=False),
+        }
+        enc_box_predictions["box_corners"] = self.decoder.box_processor.box_parametrization_to_corners(
+            query_xyz, size_unnormalized, query_xyz.new_zeros((bs, npoints)))
+        tgt = None if self.querypos_mlp else torch.zeros_like(query_embed)
+        box_predictions = self.decoder(tgt, enc_features, query_xyz, enc_xyz, point_cloud_dims, query_pos=query_embed,
+                                       enc_box_predictions=enc_box_predictions, enc_box_features=enc_features)[0]
+        box_predictions["seed_inds"] = enc_inds
+        box_predictions["seed_xyz"] = enc_xyz
+        box_predictions["enc_outputs"] = enc_box_predictions
+        return box_predictions
+
+
+def default_args(**overrides):
+    """The hot-path flags of main.py:30-216 with their defaults."""
+    a = dict(enc_dim=256, dec_nlayers=9, dec_dim=256, dec_ffn_dim=256, dec_dropout=0.1, dec_nhead=4, rpe_dim=128,
+             rpe_quant="bilinear_4_10", log_scale=512.0, pos_for_key=False, querypos_mlp=True, q_content="random",
+             proj_nohid=True, share_selfattn=False, mlp_dropout=0.3, mlp_norm="bn1d", mlp_act="relu", mlp_sep=True,
+             preenc_npoints=4096, nqueries=1024, is_bilable=True, angle_type="", hard_anchor=False,
+             cls_loss="focalloss_0.25", voxel_size=0.01, random_fps=False)
+    a.update(overrides)
+    return SimpleNamespace(**a)
+
+
+def build_decoder(args, dataset_config):
+    """model_vdetr.py:413-447"""
+    first_layer = FFNLayer(d_model=args.dec_dim, dim_feedforward=args.dec_ffn_dim, dropout=args.dec_dropout)
+    decoder_layer = GlobalDecoderLayer(d_model=args.dec_dim, nhead=args.dec_nhead,
+                                       dim_feedforward=args.dec_ffn_dim, dropout=args.dec_dropout,
+                                       pos_for_key=args.pos_for_key, args=args)
+    return TransformerDecoder(first_layer, decoder_layer, dataset_config, num_layers=args.dec_nlayers - 1,
+                              decoder_dim=args.dec_dim, mlp_dropout=args.mlp_dropout, mlp_norm=args.mlp_norm,
+                              mlp_act=args.mlp_act, mlp_sep=args.mlp_sep, pos_for_key=args.pos_for_key,
+                              num_queries=args.nqueries, cls_loss=args.cls_loss, is_bilable=args.is_bilable,
+                              q_content=args.q_content, return_intermediate=True, args=args)
+
+
+def build_vdetr(args, dataset_config, pre_encoder=None):
+    """model_vdetr.py:450-474, with the backbone replaced by a provider (default: TensorBackbone)."""
+    return ModelVDETR(pre_encoder if pre_encoder is not None else TensorBackbone(), None,
+                      build_decoder(args, dataset_config), dataset_config, encoder_dim=args.enc_dim,
+                      decoder_dim=args.dec_dim, num_queries=args.nqueries, querypos_mlp=args.querypos_mlp,
+                      minkowski=True, voxel_size=args.voxel_size, npoint=args.preenc_npoints,
+                      proj_nohid=args.proj_nohid, args=args)

@@ -1,0 +1,66 @@
+"""Point / box coordinate helpers the decoder needs (subset of the reference's utils/pc_util.py:38-73 and
+utils/box_util.py:294-358, without their import-time plyfile/trimesh dependencies)."""
+import torch
+
+
+def shift_scale_points(pred_xyz, src_range, dst_range=None):
+    """Affine map of (B,N,3) points from src_range=[min (B,3), max (B,3)] to dst_range (default [0,1]^3)
+    (pc_util.py:38-66; same operation order: ((x - smin) * ddiff) / sdiff + dmin)."""
+    if dst_range is None:
+        dst_range = [torch.zeros_like(src_range[0]), torch.ones_like(src_range[0])]
+    if pred_xyz.ndim == 4:
+        src_range = [x[:, None] for x in src_range]
+        dst_range = [x[:, None] for x in dst_range]
+    assert src_range[0].shape[0] == pred_xyz.shape[0] and dst_range[0].shape[0] == pred_xyz.shape[0]
+    assert src_range[0].shape[-1] == pred_xyz.shape[-1]
+    src_diff = src_range[1][:, None, :] - src_range[0][:, None, :]
+    dst_diff = dst_range[1][:, None, :] - dst_range[0][:, None, :]
+    return ((pred_xyz - src_range[0][:, None, :]) * dst_diff) / src_diff + dst_range[0][:, None, :]
+
+
+def scale_points(pred_xyz, mult_factor):
+    """pc_util.py:69-73"""
+    if pred_xyz.ndim == 4:
+        mult_factor = mult_factor[:, None]
+    return pred_xyz * mult_factor[:, None, :]
+
+
+def flip_axis_to_camera_tensor(pc):
+    """depth (x right, y forward, z up) -> camera (x, -z, y)   (box_util.py:294-301)"""
+    return torch.stack((pc[..., 0], -pc[..., 2], pc[..., 1]), dim=-1)
+
+
+def roty_batch_tensor(t):
+    """Rotation about the camera y axis, [..., 3, 3] (box_util.py:304-316)."""
+    c, s = torch.cos(t), torch.sin(t)
+    zero, one = torch.zeros_like(c), torch.ones_like(c)
+    return torch.stack((torch.stack((c, zero, s), -1), torch.stack((zero, one, zero), -1),
+                        torch.stack((-s, zero, c), -1)), -2)
+
+
+# corner sign pattern of get_3d_box_batch_tensor (box_util.py:338-346): x=+-l/2, y=+-h/2, z=+-w/2 (camera frame)
+_SX = (1, 1, -1, -1, 1, 1, -1, -1)
+_SY = (1, 1, 1, 1, -1, -1, -1, -1)
+_SZ = (1, -1, -1, 1, 1, -1, -1, 1)
+
+
+_sign_cache = {}
+
+
+def _corner_signs(ref):
+    """(3, 8) half-extent sign table on ref's device/dtype, cached: no host->device copy per call (and none
+    inside a captured hipGraph)."""
+    key = (ref.device, ref.dtype)
+    if key not in _sign_cache:
+        _sign_cache[key] = torch.tensor([_SX, _SY, _SZ], dtype=ref.dtype, device=ref.device) * 0.5
+    return _sign_cache[key]
+
+
+def get_3d_box_batch_tensor(box_size, angle, center):
+    """(.., 3) size (l,w,h), (..) yaw, (.., 3) camera-frame centre -> (.., 8, 3) corners (box_util.py:319-352)."""
+    sx, sy, sz = _corner_signs(box_size)
+    l, w, h = box_size[..., 0:1], box_size[..., 1:2], box_size[..., 2:3]
+    local = torch.stack((l * sx, h * sy, w * sz), dim=-1)  # (.., 8, 3)
+    R = roty_batch_tensor(angle)                            # (.., 3, 3)
+    corners = torch.matmul(local, R.transpose(-1, -2))
+    return corners + center.unsqueeze(-2)

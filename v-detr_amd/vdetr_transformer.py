@@ -1,0 +1,583 @@
+"""V-DETR decoder on the MI355X kernels — module / argument / state-dict compatible with the reference's
+``models/vdetr_transformer.py``.
+
+Only the attention cores differ from a plain PyTorch module: ``GlobalShareCrossAttention`` (3DV-RPE cross
+attention, reference :656-758), ``ShareSelfAttention`` (:609-653) and ``MultiheadSelfAttention`` (the
+``nn.MultiheadAttention(256, 4)`` of :468) call ``attention.fused_attention`` (HIP).  Projections, norms, FFNs and
+the box heads are library GEMMs / element-wise ops and stay in PyTorch with the reference's parameter names:
+
+  decoder.first_layer.{linear1,linear2,norm}            decoder.layers.N.self_attn.{in_proj_weight,in_proj_bias,out_proj}
+  decoder.layers.N.multihead_attn.{relative_coords_table,cpb_mlps.I.{0,2},q,k,v,proj}
+  decoder.layers.N.{norm1,norm2,norm3,linear1,linear2}  decoder.norm   decoder.query_embed
+  decoder.query_pos_projection.N.position_embedding_head.{0,1,3}
+  decoder.mlp_heads.S.{sem_cls_head,center_head,size_head,angle_cls_head,angle_residual_head}.layers.{0,1,4,5,8}
+  decoder.pointcls_heads.layers.*
+"""
+import copy
+import itertools
+import math
+from functools import partial
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import attention as A
+from .helpers import ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PositionEmbeddingLearned, get_clones
+from .pc_util import scale_points, shift_scale_points
+
+_salt_counter = itertools.count(1)
+
+
+class BoxProcessor(object):
+    """MLP head outputs -> box parameters (reference :20-90)."""
+
+    def __init__(self, dataset_config, cls_loss="celoss"):
+        self.dataset_config = dataset_config
+        self.cls_loss = cls_loss
+
+    def compute_predicted_center(self, center_offset, query_xyz, point_cloud_dims):
+        center_unnormalized = query_xyz + center_offset
+        return shift_scale_points(center_unnormalized, src_range=point_cloud_dims), center_unnormalized
+
+    def compute_predicted_class_size(self, size_normalized_offset, logits):
+        class_idx = logits.sigmoid().max(dim=-1)[1]
+        size_per_class = torch.tensor(self.dataset_config.mean_size_arr, device=logits.device).float()
+        class_size = size_per_class[class_idx]
+        return class_size + size_normalized_offset * class_size, size_normalized_offset * class_size
+
+    def compute_predicted_size(self, size_normalized, point_cloud_dims):
+        scene_scale = torch.clamp(point_cloud_dims[1] - point_cloud_dims[0], min=1e-1)
+        return scale_points(size_normalized, mult_factor=scene_scale)
+
+    def compute_predicted_angle(self, angle_logits, angle_residual, zero_angle=False):
+        """:48-71.  Datasets without rotation (one angle bin) still route the head outputs into the result (x0) so
+        that every parameter receives a gradient, as the reference does for DDP."""
+        nbin = angle_logits.shape[-1]
+        if nbin == 1 or zero_angle:
+            if nbin == 1:
+                angle = (angle_logits * 0 + angle_residual * 0).squeeze(-1).clamp(min=0)
+            else:
+                angle = (angle_logits.sum(-1) * 0 + angle_residual.sum(-1) * 0).squeeze(-1).clamp(min=0)
+            return angle, angle
+        angle_per_cls = 2 * np.pi / self.dataset_config.num_angle_bin
+        angle_prob, pred_angle_class = F.softmax(angle_logits, dim=-1).max(dim=-1)
+        pred_angle_class = pred_angle_class.detach()
+        angle = angle_per_cls * pred_angle_class + angle_residual.gather(2, pred_angle_class.unsqueeze(-1)).squeeze(-1)
+        angle = torch.where(angle > np.pi, angle - 2 * np.pi, angle)
+        return angle, angle_prob
+
+    def compute_objectness_and_cls_prob(self, cls_logits):
+        if self.cls_loss.split("_")[0] == "focalloss":
+            return cls_logits, cls_logits.sigmoid().max(dim=-1)[0]
+        assert cls_logits.shape[-1] == self.dataset_config.num_semcls + 1
+        cls_prob = F.softmax(cls_logits, dim=-1)
+        return cls_prob[..., :-1], 1 - cls_prob[..., -1]
+
+    def box_parametrization_to_corners(self, box_center_unnorm, box_size_unnorm, box_angle):
+        return self.dataset_config.box_parametrization_to_corners(box_center_unnorm, box_size_unnorm, box_angle)
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def convert_corners_camera2lidar(corners_camera):
+    """camera (x, y, z) -> lidar (x, z, -y)   (reference :98-102, without mutating the argument)"""
+    return torch.stack((corners_camera[..., 0], corners_camera[..., 2], -corners_camera[..., 1]), dim=-1)
+
+
+def roty_batch_tensor(t):
+    c, s = torch.cos(t), torch.sin(t)
+    zero, one = torch.zeros_like(c), torch.ones_like(c)
+    return torch.stack((torch.stack((c, zero, s), -1), torch.stack((zero, one, zero), -1),
+                        torch.stack((-s, zero, c), -1)), -2)
+
+
+def rotz_batch_tensor(t):
+    c, s = torch.cos(t), torch.sin(t)
+    zero, one = torch.zeros_like(c), torch.ones_like(c)
+    return torch.stack((torch.stack((c, -s, zero), -1), torch.stack((s, c, zero), -1),
+                        torch.stack((zero, zero, one), -1)), -2)
+
+
+# =====================================================================================================
+# attention modules
+# =====================================================================================================
+class GlobalShareCrossAttention(nn.Module):
+    """3D-vertex-RPE cross attention (reference :656-758).
+
+    forward(query [nQ,B,C], key [nK,B,C], reference_point [B,nQ,8,3], reference_angle [B,nQ], xyz [B,nK,3],
+            attn_mask=None, key_padding_mask=None) -> (x [nQ,B,C], attn or None)
+
+    K and V are 64-wide and shared by the heads.  The bias rpe[b,h,q,k] = sum_i trilinear(T_i, g(P_i[q] - X[k])) is
+    evaluated inside the fused HIP kernel from the eight tables T_i = cpb_mlps[i](relative_coords_table); the
+    [B,H,nQ,nK] bias / probability tensors of the reference never exist.  ``attn`` (post-dropout probabilities,
+    :751-752) is only produced when ``self.return_attn`` is set.  ``key_padding_mask`` is accepted and ignored,
+    exactly as in the reference.
+    """
+
+    def __init__(self, dim, num_heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0, args=None):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.log_scale = args.log_scale
+        self.rpe_quant = args.rpe_quant
+        self.angle_type = args.angle_type
+        self.interp_method, max_value, num_points = self.rpe_quant.split("_")
+        max_value, num_points = float(max_value), int(num_points)
+        if self.interp_method != "bilinear":
+            raise NotImplementedError(f"rpe_quant interpolation '{self.interp_method}' (only 'bilinear' is built)")
+        lin = torch.linspace(-max_value, max_value, num_points, dtype=torch.float32)
+        table = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), dim=-1).unsqueeze(0)
+        self.register_buffer("relative_coords_table", table)  # [1,T,T,T,3]
+        self.max_value = max_value
+        self.cpb_mlps = get_clones(self.build_cpb_mlp(3, args.rpe_dim, num_heads), 8)
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k = nn.Linear(dim, dim // num_heads, bias=qkv_bias)
+        self.v = nn.Linear(dim, dim // num_heads, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)  # p is read by the fused kernel
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.rpe_cfg = A.RPEConfig(num_points, self.log_scale, max_value)
+        self.return_attn = False
+        self._salt = next(_salt_counter)
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, copy.deepcopy(v, memo))
+        new._salt = next(_salt_counter)  # every clone draws its own dropout stream
+        return new
+
+    def build_cpb_mlp(self, in_dim, hidden_dim, out_dim):
+        return nn.Sequential(nn.Linear(in_dim, hidden_dim, bias=True), nn.ReLU(inplace=False),
+                             nn.Linear(hidden_dim, out_dim, bias=False))
+
+    def rpe_tables(self):
+        """[8,T,T,T,H]: the eight cpb MLPs evaluated on the coordinate grid (reference :725), as two batched GEMMs."""
+        w1 = torch.stack([m[0].weight for m in self.cpb_mlps])  # [8,hid,3]
+        b1 = torch.stack([m[0].bias for m in self.cpb_mlps])    # [8,hid]
+        w2 = torch.stack([m[2].weight for m in self.cpb_mlps])  # [8,H,hid]
+        T = self.relative_coords_table.shape[1]
+        coords = self.relative_coords_table.reshape(1, -1, 3).expand(8, -1, -1)
+        hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
+        return torch.bmm(hid, w2.transpose(1, 2)).view(8, T, T, T, self.num_heads)
+
+    def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None):
+        key_b, query_b = key.permute(1, 0, 2), query.permute(1, 0, 2)
+        q = self.q(query_b)   # [B,nQ,C]
+        k = self.k(key_b)     # [B,nK,C/H]
+        v = self.v(key_b)
+        cos_sin = None
+        if self.angle_type == "object_coords" and reference_angle is not None:
+            ang = reference_angle.detach()
+            cos_sin = torch.stack((torch.cos(ang), torch.sin(ang)), dim=-1)
+        p = self.attn_drop.p if self.training else 0.0
+        rng = A.current_rng(q.device) if p > 0 else None
+        if p > 0 and rng is None:
+            rng = A.begin_step(q.device)
+        tables = self.rpe_tables()
+        x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, table=tables,
+                              rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
+                              attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt)
+        attn = None
+        if self.return_attn:
+            attn = A.attention_probabilities(q, k, num_heads=self.num_heads, scale=self.scale, shared_kv=True,
+                                             table=tables, rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz,
+                                             cos_sin=cos_sin, attn_mask=attn_mask, dropout_p=p, rng_state=rng,
+                                             salt=self._salt)
+        x = self.proj_drop(self.proj(x)).permute(1, 0, 2)
+        return x, attn
+
+
+class ShareSelfAttention(nn.Module):
+    """Self attention with head-shared 64-wide K/V (reference :609-653), enabled by --share_selfattn."""
+
+    def __init__(self, dim, num_heads, qkv_bias=True, dropout=0.0, args=None):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k = nn.Linear(dim, dim // num_heads, bias=qkv_bias)
+        self.v = nn.Linear(dim, dim // num_heads, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(dropout)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(dropout)
+        self._salt = next(_salt_counter)
+
+    __deepcopy__ = GlobalShareCrossAttention.__deepcopy__
+
+    def forward(self, query, key, value=None, attn_mask=None, key_padding_mask=None):
+        assert attn_mask is None and key_padding_mask is None
+        key_b, query_b = key.permute(1, 0, 2), query.permute(1, 0, 2)
+        k = self.k(key_b)
+        # The reference projects `value` WITHOUT the (1,0,2) permute and then reshapes the sequence-first
+        # [N,B,64] result as (B,N,64) (:639).  Identical for B == 1, a batch/sequence mix-up for B > 1; kept as
+        # is so that outputs match the reference on the same inputs.
+        v = self.v(value).reshape(key_b.shape[0], key_b.shape[1], -1)
+        q = self.q(query_b)
+        p = self.attn_drop.p if self.training else 0.0
+        x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, dropout_p=p,
+                              salt=self._salt)
+        return self.proj_drop(self.proj(x)).permute(1, 0, 2), None
+
+
+class _OutProj(nn.Linear):
+    """Plain Linear under the name ``out_proj`` (nn.MultiheadAttention's NonDynamicallyQuantizableLinear)."""
+
+
+class MultiheadSelfAttention(nn.Module):
+    """Drop-in for the ``nn.MultiheadAttention(d_model, nhead, dropout)`` the reference builds at :468: same
+    parameters (in_proj_weight [3E,E], in_proj_bias [3E], out_proj.{weight,bias}), same call
+    ``(query, key, value=..., attn_mask=..., key_padding_mask=...) -> (out, None)`` on sequence-first tensors."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = _OutProj(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.in_proj_bias, 0.0)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+        self._salt = next(_salt_counter)
+
+    __deepcopy__ = GlobalShareCrossAttention.__deepcopy__
+
+    def forward(self, query, key, value=None, attn_mask=None, key_padding_mask=None, need_weights=False):
+        E = self.embed_dim
+        value = key if value is None else value
+        w, b = self.in_proj_weight, self.in_proj_bias
+        if query is key:
+            qk = F.linear(query, w[: 2 * E], b[: 2 * E])  # one GEMM for q and k (they share the input)
+            q, k = qk[..., :E], qk[..., E:]
+        else:
+            q, k = F.linear(query, w[:E], b[:E]), F.linear(key, w[E: 2 * E], b[E: 2 * E])
+        v = F.linear(value, w[2 * E:], b[2 * E:])
+        L_, B = query.shape[0], query.shape[1]
+        S = key.shape[0]
+        mask = None
+        if attn_mask is not None or key_padding_mask is not None:
+            mask = torch.zeros((B, L_, S), dtype=torch.float32, device=query.device)
+            if attn_mask is not None:
+                am = attn_mask
+                am = torch.zeros_like(am, dtype=torch.float32).masked_fill_(am, -1e30) if am.dtype == torch.bool else am.float()
+                mask = mask + (am if am.dim() == 3 else am.unsqueeze(0))
+            if key_padding_mask is not None:
+                mask = mask.masked_fill(key_padding_mask.view(B, 1, S).bool(), -1e30)
+        p = self.dropout if self.training else 0.0
+        x = A.fused_attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), num_heads=self.num_heads,
+                              scale=self.head_dim ** -0.5, shared_kv=False, attn_mask=mask, dropout_p=p,
+                              salt=self._salt)
+        return self.out_proj(x).transpose(0, 1), None
+
+
+# =====================================================================================================
+# decoder layers
+# =====================================================================================================
+class GlobalDecoderLayer(nn.Module):
+    """self-attn -> 3DV-RPE cross-attn -> FFN with residuals (reference :455-582; pre-norm by default)."""
+
+    def __init__(self, d_model, nhead=4, dim_feedforward=256, dropout=0.1, dropout_attn=None, activation="relu",
+                 normalize_before=True, norm_fn_name="ln", pos_for_key=False, args=None):
+        super().__init__()
+        if dropout_attn is None:
+            dropout_attn = dropout
+        self.pos_for_key = pos_for_key
+        if args.share_selfattn:
+            self.self_attn = ShareSelfAttention(d_model, nhead, dropout=dropout)
+        else:
+            self.self_attn = MultiheadSelfAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = GlobalShareCrossAttention(d_model, nhead, attn_drop=dropout, proj_drop=dropout, args=args)
+        self.norm1 = NORM_DICT[norm_fn_name](d_model)
+        self.norm2 = NORM_DICT[norm_fn_name](d_model)
+        self.norm3 = NORM_DICT[norm_fn_name](d_model)
+        self.dropout1 = nn.Dropout(dropout, inplace=False)
+        self.dropout2 = nn.Dropout(dropout, inplace=False)
+        self.dropout3 = nn.Dropout(dropout, inplace=False)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout, inplace=False)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.activation = ACTIVATION_DICT[activation]()
+        self.normalize_before = normalize_before
+
+    @staticmethod
+    def with_pos_embed(tensor, pos: Optional[Tensor]):
+        return tensor if pos is None else tensor + pos
+
+    def _cross(self, tgt_in, memory, reference_point, reference_angle, enc_xyz, memory_mask,
+               memory_key_padding_mask, pos, query_pos):
+        key = self.with_pos_embed(memory, pos) if self.pos_for_key else memory
+        return self.multihead_attn(query=self.with_pos_embed(tgt_in, query_pos), key=key,
+                                   reference_point=reference_point, reference_angle=reference_angle, xyz=enc_xyz,
+                                   attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)
+
+    def forward_pre(self, tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask=None,
+                    memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None,
+                    query_pos=None, return_attn_weights=False):
+        tgt2 = self.norm1(tgt)
+        q = k = self.with_pos_embed(tgt2, query_pos)
+        tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        tgt = tgt + self.dropout1(tgt2)
+        tgt2, attn = self._cross(self.norm2(tgt), memory, reference_point, reference_angle, enc_xyz, memory_mask,
+                                 memory_key_padding_mask, pos, query_pos)
+        tgt = tgt + self.dropout2(tgt2)
+        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(self.norm3(tgt)))))
+        tgt = tgt + self.dropout3(tgt2)
+        return tgt, (attn if return_attn_weights else None)
+
+    def forward_post(self, tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask=None,
+                     memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None,
+                     query_pos=None, return_attn_weights=False):
+        q = k = self.with_pos_embed(tgt, query_pos)
+        tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        tgt2, attn = self._cross(tgt, memory, reference_point, reference_angle, enc_xyz, memory_mask,
+                                 memory_key_padding_mask, pos, query_pos)
+        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
+        tgt = self.norm3(tgt + self.dropout3(tgt2))
+        return tgt, (attn if return_attn_weights else None)
+
+    def forward(self, tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask=None,
+                memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
+                return_attn_weights=False):
+        self.multihead_attn.return_attn = bool(return_attn_weights)
+        fn = self.forward_pre if self.normalize_before else self.forward_post
+        return fn(tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask, memory_mask,
+                  tgt_key_padding_mask, memory_key_padding_mask, pos, query_pos, return_attn_weights)
+
+
+class FFNLayer(nn.Module):
+    """The light first 'decoder layer' applied to all encoder tokens (reference :585-606)."""
+
+    def __init__(self, d_model, dim_feedforward=256, dropout=0.1, norm_fn_name="ln", activation="relu",
+                 normalize_before=True):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout, inplace=False)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = NORM_DICT[norm_fn_name](d_model)
+        self.activation = ACTIVATION_DICT[activation]()
+        self.normalize_before = normalize_before
+
+    def forward_pre(self, memory):
+        memory = self.norm(memory)
+        return memory + self.dropout(self.linear2(self.dropout(self.activation(self.linear1(memory)))))
+
+    def forward(self, memory):
+        return self.forward_pre(memory)
+
+
+# =====================================================================================================
+# decoder
+# =====================================================================================================
+class TransformerDecoder(nn.Module):
+    """FFN stage on all tokens -> top-k proposals -> num_layers x GlobalDecoderLayer with per-stage box heads and
+    iterative box refinement (reference :105-452).  Constructor arguments as in the reference."""
+
+    def __init__(self, first_layer, decoder_layer, dataset_config, num_layers, decoder_dim=256, mlp_dropout=0.3,
+                 mlp_norm="bn1d", mlp_act="relu", mlp_sep=False, pos_for_key=False, num_queries=256,
+                 cls_loss="celoss", norm_fn_name="ln", is_bilable=False, q_content="sample",
+                 return_intermediate=False, weight_init_name="xavier_uniform", args=None):
+        super().__init__()
+        self.first_layer = first_layer
+        self.layers = get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.dec_output_dim = self.layers[0].linear2.out_features
+        self.norm = NORM_DICT[norm_fn_name](self.dec_output_dim) if norm_fn_name is not None else None
+        self.is_bilable = is_bilable
+        self.pos_for_key = pos_for_key
+        self.num_queries = num_queries
+        self.q_content = q_content
+        self.query_pos_projection = nn.ModuleList(
+            PositionEmbeddingLearned(6, self.dec_output_dim) for _ in range(num_layers))
+        if pos_for_key:
+            self.key_pos_projection = nn.ModuleList(
+                PositionEmbeddingLearned(3, self.dec_output_dim) for _ in range(num_layers))
+        if q_content in ("random", "random_add"):
+            self.query_embed = nn.Embedding(num_queries, self.dec_output_dim)
+        self.return_intermediate = return_intermediate
+        self._reset_parameters(weight_init_name)  # before the heads are built, as in the reference (:151-159)
+
+        self.mlp_norm, self.mlp_act, self.mlp_sep, self.cls_loss = mlp_norm, mlp_act, mlp_sep, cls_loss
+        self.build_mlp_heads(dataset_config, decoder_dim, mlp_dropout)
+        self.build_pointcls_heads(dataset_config, decoder_dim, mlp_dropout)
+
+        heads = self.mlp_heads if mlp_sep else [self.mlp_heads] * (num_layers + 1)
+        if cls_loss.split("_")[0] == "focalloss":  # focal prior: p = 0.01 (:161-167)
+            bias_value = -math.log((1 - 0.01) / 0.01)
+            for h in heads:
+                last = h["sem_cls_head"].layers[-1]
+                last.bias.data = torch.ones(last.bias.shape[0]) * bias_value
+        for h in heads:  # centre / size regressors start at zero offset (:169-173)
+            for name in ("center_head", "size_head"):
+                nn.init.constant_(h[name].layers[-1].weight.data, 0.0)
+                nn.init.constant_(h[name].layers[-1].bias.data, 0.0)
+        self.box_processor = BoxProcessor(dataset_config, cls_loss=cls_loss)
+
+    def _mlp(self, decoder_dim, mlp_dropout, output_dim):
+        return GenericMLP(input_dim=decoder_dim, hidden_dims=[decoder_dim, decoder_dim], output_dim=output_dim,
+                          norm_fn_name=self.mlp_norm, activation=self.mlp_act, use_conv=True, dropout=mlp_dropout)
+
+    def build_pointcls_heads(self, dataset_config, decoder_dim, mlp_dropout):
+        ncls = dataset_config.num_semcls + (0 if self.cls_loss.split("_")[0] == "focalloss" else 1)
+        self.pointcls_heads = self._mlp(decoder_dim, mlp_dropout, ncls)
+
+    def build_mlp_heads(self, dataset_config, decoder_dim, mlp_dropout):
+        mk = partial(self._mlp, decoder_dim, mlp_dropout)
+        ncls = dataset_config.num_semcls + (0 if self.cls_loss.split("_")[0] == "focalloss" else 1)
+        heads = [("sem_cls_head", mk(ncls)), ("center_head", mk(3)), ("size_head", mk(3)),
+                 ("angle_cls_head", mk(dataset_config.num_angle_bin)),
+                 ("angle_residual_head", mk(dataset_config.num_angle_bin))]
+        if not self.mlp_sep:
+            self.mlp_heads = nn.ModuleDict(heads)
+        elif self.is_bilable:  # stage 0 is a binary objectness head (:226-230)
+            self.mlp_heads = get_clones(nn.ModuleDict(heads), self.num_layers)
+            first = copy.deepcopy(heads)
+            first[0] = ("sem_cls_head", mk(1))
+            self.mlp_heads.insert(0, nn.ModuleDict(first))
+        else:
+            self.mlp_heads = get_clones(nn.ModuleDict(heads), self.num_layers + 1)
+
+    def _reset_parameters(self, weight_init_name):
+        init = WEIGHT_INIT_DICT[weight_init_name]
+        for _, p in self.named_parameters():
+            if p.dim() > 1:
+                init(p)
+
+    def get_proposal_box_predictions_refine(self, idx, query_xyz, point_cloud_dims, box_features,
+                                            pre_center_normalized=None, pre_size_normalized=None):
+        """Stage-`idx` heads on box_features [nQ,B,C]; boxes are decoded RELATIVE to the given (normalised) prior
+        centre / size: centre = reg * size_prior + centre_prior, size = exp(reg) * size_prior (reference :244-333)."""
+        assert pre_center_normalized is not None and pre_size_normalized is not None
+        feats = box_features.permute(1, 2, 0)  # B x C x nQ
+        batch, _, nq = feats.shape
+        heads = self.mlp_heads[idx] if self.mlp_sep else self.mlp_heads
+        dmin = point_cloud_dims[0].unsqueeze(1)
+        scene_size = (point_cloud_dims[1] - point_cloud_dims[0]).unsqueeze(1)
+        pre_center_unnormalized = pre_center_normalized * scene_size + dmin
+        pre_size_unnormalized = pre_size_normalized * scene_size
+
+        cls_logits = heads["sem_cls_head"](feats).transpose(1, 2)
+        center_reg = heads["center_head"](feats).transpose(1, 2).contiguous().view(batch, nq, 3)
+        center_unnormalized = center_reg * pre_size_unnormalized + pre_center_unnormalized
+        center_normalized = (center_unnormalized - dmin) / scene_size
+        size_reg = heads["size_head"](feats).transpose(1, 2).contiguous().view(batch, nq, 3)
+        size_unnormalized = torch.exp(size_reg) * pre_size_unnormalized
+        size_normalized = size_unnormalized / scene_size
+        angle_logits = heads["angle_cls_head"](feats).transpose(1, 2)
+        angle_residual_normalized = heads["angle_residual_head"](feats).transpose(1, 2)
+        angle_residual = angle_residual_normalized * (np.pi / angle_residual_normalized.shape[-1])
+        angle_continuous, angle_prob = self.box_processor.compute_predicted_angle(angle_logits, angle_residual)
+        box_corners = self.box_processor.box_parametrization_to_corners(center_unnormalized, size_unnormalized,
+                                                                        angle_continuous)
+        angle_zero, _ = self.box_processor.compute_predicted_angle(angle_logits, angle_residual, zero_angle=True)
+        box_corners_axis_align = self.box_processor.box_parametrization_to_corners(center_unnormalized,
+                                                                                   size_unnormalized, angle_zero)
+        with torch.no_grad():
+            semcls_prob, objectness_prob = self.box_processor.compute_objectness_and_cls_prob(cls_logits)
+        return {
+            "sem_cls_logits": cls_logits,
+            "center_normalized": center_normalized.contiguous(),
+            "center_unnormalized": center_unnormalized,
+            "size_normalized": size_normalized,
+            "size_unnormalized": size_unnormalized,
+            "angle_logits": angle_logits,
+            "angle_prob": angle_prob,
+            "angle_residual": angle_residual,
+            "angle_residual_normalized": angle_residual_normalized,
+            "angle_continuous": angle_continuous,
+            "objectness_prob": objectness_prob,
+            "sem_cls_prob": semcls_prob,
+            "box_corners": box_corners,
+            "box_corners_axis_align": box_corners_axis_align,
+            "pre_box_center_unnormalized": pre_center_unnormalized,
+            "center_reg": center_reg,
+            "pre_box_size_unnormalized": pre_size_unnormalized,
+            "size_reg": size_reg,
+        }
+
+    def forward(self, tgt, memory, query_xyz, enc_xyz, point_cloud_dims, tgt_mask=None, memory_mask=None,
+                tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
+                transpose_swap=False, return_attn_weights=False, enc_box_predictions=None, enc_box_features=None):
+        A.begin_step(memory.device)  # one dropout-RNG snapshot per forward, shared by all attention modules
+        intermediate, attns = [], []
+        output = self.first_layer(enc_box_features)
+        box_prediction = self.get_proposal_box_predictions_refine(
+            0, query_xyz, point_cloud_dims, self.norm(output),
+            pre_center_normalized=enc_box_predictions["center_normalized"],
+            pre_size_normalized=enc_box_predictions["size_normalized"])
+        if self.return_intermediate:
+            intermediate.append(box_prediction)
+
+        # ---- top-k proposals by objectness (:364-398) ----------------------------------------------------
+        objectness = box_prediction["objectness_prob"].detach()
+        ntok = objectness.shape[1]
+        if ntok >= self.num_queries:
+            topk = torch.topk(objectness, self.num_queries, dim=1)[1]
+        else:
+            topk = torch.arange(ntok, device=objectness.device).unsqueeze(0).repeat(objectness.shape[0], 1)
+
+        def take(t):
+            t = t.detach()
+            index = topk.view(topk.shape + (1,) * (t.dim() - 2)).expand(topk.shape + t.shape[2:])
+            return torch.gather(t, 1, index)
+
+        reference_point = convert_corners_camera2lidar(take(box_prediction["box_corners"]))
+        reference_center = take(box_prediction["center_unnormalized"])
+        query_xyz = reference_center
+        reference_size = take(box_prediction["size_unnormalized"])
+        reference_angle = take(box_prediction["angle_continuous"])
+        proposal_center_normalized = take(box_prediction["center_normalized"])
+        proposal_size_normalized = take(box_prediction["size_normalized"])
+        batch = output.shape[1]
+        if self.q_content == "zero":
+            output = output.new_zeros((topk.shape[1], batch, output.shape[-1]))
+        elif self.q_content == "random":  # query content is a learned embedding; first-stage features are dropped
+            output = self.query_embed.weight.unsqueeze(1).repeat(1, batch, 1)
+        else:
+            gathered = torch.gather(output.permute(1, 0, 2), 1,
+                                    topk.unsqueeze(-1).expand(-1, -1, output.shape[-1])).permute(1, 0, 2).contiguous()
+            output = gathered + self.query_embed.weight.unsqueeze(1) if self.q_content == "random_add" else gathered
+
+        # ---- decoder layers with box feedback (:407-436) ---------------------------------------------------
+        for idx, layer in enumerate(self.layers):
+            if idx > 0:
+                reference_point = convert_corners_camera2lidar(box_prediction["box_corners"].detach())
+                reference_center = box_prediction["center_unnormalized"].detach()
+                reference_size = box_prediction["size_unnormalized"].detach()
+                reference_angle = box_prediction["angle_continuous"].detach()
+            query_reference = torch.cat([reference_center, reference_size], dim=-1)
+            query_pos = self.query_pos_projection[idx](query_reference).permute(2, 0, 1)
+            if self.pos_for_key:
+                pos = self.key_pos_projection[idx](enc_xyz).permute(2, 0, 1)
+            output, attn = layer(output, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims,
+                                 tgt_mask=tgt_mask, memory_mask=memory_mask,
+                                 tgt_key_padding_mask=tgt_key_padding_mask,
+                                 memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos,
+                                 return_attn_weights=return_attn_weights)
+            # stages >= 1 decode relative to the FIXED stage-0 proposal centre / size (:427-431)
+            box_prediction = self.get_proposal_box_predictions_refine(
+                idx + 1, query_xyz, point_cloud_dims, self.norm(output),
+                pre_center_normalized=proposal_center_normalized, pre_size_normalized=proposal_size_normalized)
+            if self.return_intermediate:
+                intermediate.append(box_prediction)
+            if return_attn_weights:
+                attns.append(attn)
+
+        if return_attn_weights:
+            attns = torch.stack(attns)
+        if self.return_intermediate:
+            return {"outputs": intermediate[-1], "aux_outputs": intermediate[:-1]}, attns
+        return {"outputs": box_prediction}, attns
