@@ -38,7 +38,9 @@ def _worker(rank, world, port, overlap, q):
             red.finish()
         else:
             red.reduce_all()
-    q.put((rank, [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()], x))
+    # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with the worker
+    q.put((rank, [p.grad.numpy().copy() for p in model.parameters()],
+           [p.detach().numpy().copy() for p in model.parameters()], x.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,7 +56,8 @@ def _run(overlap):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, g0, w0, x0), (_, g1, w1, x1) = res
+    conv = lambda r: (r[0], [torch.from_numpy(a) for a in r[1]], [torch.from_numpy(a) for a in r[2]], torch.from_numpy(r[3]))
+    (_, g0, w0, x0), (_, g1, w1, x1) = conv(res[0]), conv(res[1])
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)            # broadcast made the replicas identical
     for a, b in zip(g0, g1):
