@@ -105,9 +105,9 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
     for name, r, o in zip(names, ref, got):
         scale = float(r.abs().max())
         if name == "out":
-            assert_close(o, r.numpy(), 1e-4, 1e-5 * max(scale, 1.0), name)
+            assert_close(o, r.detach().numpy(), 1e-4, 1e-5 * max(scale, 1.0), name)
         else:
-            assert_close(o, r.numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
+            assert_close(o, r.detach().numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
 def test_attention_probabilities_and_dropout_statistics():

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarises a rocprofv3 --kernel-trace run (rocpd .db or *_kernel_trace.csv) into the per-kernel table that is
+committed under profiles/:  python tools/rocprof_summary.py <results.db|kernel_trace.csv> [steps] > profiles/xxx.txt"""
+import csv
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def rows_from_db(path):
+    cur = sqlite3.connect(path).cursor()
+    return [(n, (e - s) / 1e3) for n, s, e in cur.execute("select name, start, end from kernels")]
+
+
+def rows_from_csv(path):
+    out = []
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            out.append((r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    return out
+
+
+def main():
+    path = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rows = rows_from_db(path) if path.endswith(".db") else rows_from_csv(path)
+    agg = defaultdict(list)
+    for n, d in rows:
+        agg[n].append(d)
+    tot = sum(d for _, d in rows)
+    print(f"# source: {path}")
+    print(f"# kernels: {len(rows)} dispatches, {tot / 1e3:.2f} ms total GPU kernel time" +
+          (f", {steps} steps -> {tot / 1e3 / steps:.2f} ms/step, {len(rows) // steps} dispatches/step" if steps else ""))
+    print(f"{'%':>6} {'calls':>7} {'total_us':>11} {'avg_us':>10} {'min_us':>9} {'max_us':>9}  kernel")
+    for n, ds in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:45]:
+        print(f"{sum(ds) / tot * 100:6.2f} {len(ds):7d} {sum(ds):11.1f} {sum(ds) / len(ds):10.2f} {min(ds):9.2f} {max(ds):9.2f}  {n[:110]}")
+
+
+if __name__ == "__main__":
+    main()
