@@ -147,7 +147,9 @@ def kernel_rooflines(cfg_name, device, reps=20):
     B, H = bs, 4
     g = torch.Generator().manual_seed(0)
     xyz, _ = make_scene(40000, 0, device)
+    from vdetr_amd.pc_util import morton_argsort
     kxyz = xyz[torch.randperm(xyz.shape[0], generator=g)[:nK].to(device)][None].repeat(B, 1, 1).contiguous()
+    kxyz = torch.gather(kxyz, 1, morton_argsort(kxyz).unsqueeze(-1).expand(-1, -1, 3)).contiguous()  # as the decoder does
     center = kxyz[:, torch.randperm(nK, generator=g)[:nQ].to(device)]
     half = (0.1 + torch.rand((B, nQ, 1, 3), generator=g)).to(device)
     signs = torch.tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]],

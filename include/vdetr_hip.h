@@ -122,7 +122,7 @@ typedef struct vdetr_attn_desc {
   int32_t mask_kind;     /* VDETR_MASK_* */
   /* --- dropout on the attention probabilities (attn_drop, :752 / MHA dropout) --- */
   float dropout_p;       /* 0 = off */
-  uint64_t seed, offset; /* Philox4x32-10 key / counter offset */
+  uint64_t seed, offset; /* key / counter offset of the counter-based dropout generator */
   const uint64_t* rng_state; /* optional DEVICE pointer to {seed, offset}, folded into the two fields above
                                 (seed ^= state[0], offset += state[1]): a captured hipGraph can advance the
                                 device offset between replays, and modules sharing one state stay independent

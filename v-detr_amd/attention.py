@@ -36,7 +36,7 @@ class RPEConfig:
 
 
 def new_rng_state(device, seed=None):
-    """Device-resident Philox {seed, offset}."""
+    """Device-resident {seed, offset} of the counter-based dropout generator."""
     if seed is None:
         seed = torch.initial_seed()
     return torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)

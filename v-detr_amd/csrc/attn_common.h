@@ -34,8 +34,8 @@ struct AttnParams {
   const void* mask;
   int mask_kind;
   // dropout
-  unsigned drop_thresh;  // keep iff rand >= thresh
-  float drop_scale;      // 1 / (1 - p)
+  unsigned drop_thresh;  // keep iff rand16 >= thresh (thresh = p * 65536)
+  float drop_scale;      // 65536 / (65536 - thresh): unbiased for the quantised rate
   unsigned seed_lo, seed_hi, off_lo, off_hi;
   const unsigned long long* rng;  // optional device {seed, offset}
   // key split (forward)
@@ -48,19 +48,18 @@ struct AttnParams {
   float* dtable_part;  // [gridDim.x][8*T^3*H]
 };
 
-// ---- Philox4x32-10 (Salmon et al. 2011): counter-based, so forward and backward regenerate the same
-// keep-mask from (seed, offset, b, q, k, head) with no stored state.
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-  constexpr unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    const unsigned hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += W0;
-    k.y += W1;
-  }
-  return c;
+// ---- dropout random numbers: counter-based (stateless), so forward and backward regenerate the same keep-mask
+// from (seed, offset, b, head group, q, key).  A chain of murmur3 finalisers (fmix32: a bijection of 32 bits with
+// full avalanche) keyed by the counter words; the (seed, offset, b, q) prefix is lane-invariant in the kernels and
+// is hoisted out of the key loop, leaving two fmix32 (~16 VALU ops) per (query, key) pair for its 4 heads —
+// a Philox4x32-10 here cost ~100 ops, a seventh of the whole forward tile step.
+__device__ __forceinline__ unsigned fmix32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
 }
 // kernels call this first: fold the device-resident {seed, offset} pair into the by-value one
 __device__ __forceinline__ void attn_load_rng(AttnParams& P) {
@@ -73,10 +72,13 @@ __device__ __forceinline__ void attn_load_rng(AttnParams& P) {
     P.off_lo = (unsigned)o; P.off_hi = (unsigned)(o >> 32);
   }
 }
-// Random words of attention element (b, q, key) for heads 4*hgroup .. 4*hgroup+3.
+// Four 16-bit uniform values of attention element (b, q, key) for heads 4*hgroup .. 4*hgroup+3.
 __device__ __forceinline__ uint4 attn_rand4(const AttnParams& P, int b, int q, int key, int hgroup) {
-  return philox4x32_10(make_uint4((unsigned)key, (unsigned)q, (unsigned)b * 64u + (unsigned)hgroup, P.off_lo),
-                       make_uint2(P.seed_lo, P.seed_hi ^ P.off_hi));
+  unsigned x = fmix32(((unsigned)q * 0x9E3779B1u + P.off_lo) ^ P.seed_lo);
+  x = fmix32(x ^ (((unsigned)b * 64u + (unsigned)hgroup) * 0x27D4EB2Fu + P.off_hi) ^ P.seed_hi);
+  x = fmix32(x ^ ((unsigned)key * 0x165667B1u));
+  const unsigned y = fmix32(x + 0x9E3779B9u);
+  return make_uint4(x & 0xFFFFu, x >> 16, y & 0xFFFFu, y >> 16);
 }
 __device__ __forceinline__ unsigned pick4(const uint4& r, int i) {
   return i == 0 ? r.x : (i == 1 ? r.y : (i == 2 ? r.z : r.w));

@@ -318,10 +318,10 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   }
   P->mask = d->mask; P->mask_kind = d->mask ? d->mask_kind : VDETR_MASK_NONE;
   if (d->dropout_p > 0.f) {
-    double t = (double)d->dropout_p * 4294967296.0;
-    P->drop_thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
-    if (P->drop_thresh == 0) P->drop_thresh = 1;
-    P->drop_scale = 1.f / (1.f - d->dropout_p);
+    int t = (int)((double)d->dropout_p * 65536.0 + 0.5);
+    t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
+    P->drop_thresh = (unsigned)t;
+    P->drop_scale = 65536.f / (float)(65536 - t);
   } else {
     P->drop_thresh = 0; P->drop_scale = 1.f;
   }

@@ -53,17 +53,29 @@ __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return bits ?
 __device__ __forceinline__ unsigned spread3(unsigned v) {  // 4 bits -> every third bit
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
-// (t, key) -> one 64-bit word whose unsigned max is "largest t, then smallest key".  t is >= 0 for every
-// candidate point; non-candidates (origin-skip, padding) carry t = -inf and map to 0.
-__device__ __forceinline__ unsigned long long pack_cand(float t, unsigned key) {
-  return t >= 0.f ? (((unsigned long long)(__float_as_uint(t) + 1u) << 32) | (unsigned)(~key)) : 0ull;
+// Candidate order: largest running distance t, then smallest tie key.  t >= 0 for every candidate, so its bit
+// pattern is monotone as an unsigned; non-candidates (origin-skip, padding: t = -inf) rank as 0.
+__device__ __forceinline__ unsigned rank_of(float t) { return t >= 0.f ? __float_as_uint(t) + 1u : 0u; }
+__device__ __forceinline__ float t_of_rank(unsigned r) { return r ? __uint_as_float(r - 1u) : -INFINITY; }
+
+// wave arg-max of (rank desc, key asc): two 32-bit all-reduces; returns the winning lane
+struct WaveBest {
+  unsigned rank, key;
+  int lane;
+};
+__device__ __forceinline__ WaveBest wave_argbest(unsigned rank, unsigned key) {
+  WaveBest r;
+  r.rank = wave_allmax_u32(rank);
+  r.key = wave_allmin_u32(rank == r.rank ? key : 0xFFFFFFFFu);
+  r.lane = __ffsll((long long)__ballot(rank == r.rank && key == r.key)) - 1;
+  return r;
 }
 
 __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
   __shared__ int s_hist[kCells];
   __shared__ int s_wsum[kFpsWaves];
   __shared__ float s_red[kFpsWaves][6];
-  __shared__ unsigned long long s_best[2][kFpsWaves];
+  __shared__ unsigned s_rank[2][kFpsWaves], s_key[2][kFpsWaves];
   __shared__ float s_bxyz[2][kFpsWaves][3];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -192,6 +204,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
   }
 
   // ---- rounds ---------------------------------------------------------------------------------------
+  constexpr int kBatch = 4;  // buckets in flight per wave: their loads are issued together, their reductions interleave
   float cx = p0x, cy = p0y, cz = p0z;  // the reference starts from index 0 unconditionally (:89-90)
   if (tid == 0) out[0] = 0;
   for (int j = 1; j < P.m; ++j) {
@@ -204,56 +217,90 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
       const bool active = sqdist3(dx, dy, dz) < bmax[s];
       unsigned long long todo = __ballot(active);
       while (todo) {
-        const int li = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int g = w + kFpsWaves * (li + kWave * s);
-        float4* bp = pts + (size_t)g * P.bucket_pts;
-        const uint32_t* bk = keys + (size_t)g * P.bucket_pts;
-        unsigned long long cand = 0ull;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        for (int r = 0; r < R; ++r) {
-          const float4 p = bp[r * kWave + lane];
-          const unsigned key = bk[r * kWave + lane];
-          const float d = sqdist3(p.x - cx, p.y - cy, p.z - cz);
-          const float t = fminf(d, p.w);  // p.w = -inf for non-candidates: stays -inf
-          if (t < p.w) bp[r * kWave + lane].w = t;
-          const unsigned long long c = pack_cand(t, key);
-          if (c > cand) { cand = c; qx = p.x; qy = p.y; qz = p.z; }
+        int li[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          li[u] = todo ? __ffsll((long long)todo) - 1 : -1;
+          todo &= todo - 1;  // 0 stays 0
         }
-        const unsigned long long best = wave_allmax_u64(cand);
-        const int src = __ffsll((long long)__ballot(cand == best)) - 1;
-        const float wx = readlane_f32(qx, src), wy = readlane_f32(qy, src), wz = readlane_f32(qz, src);
-        if (lane == li) {
-          bmax[s] = best ? __uint_as_float((unsigned)(best >> 32) - 1u) : -INFINITY;
-          bkey[s] = ~(unsigned)best;
-          bpx[s] = wx; bpy[s] = wy; bpz[s] = wz;
+        unsigned rk[kBatch], ky[kBatch];
+        float qx[kBatch], qy[kBatch], qz[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          rk[u] = 0u; ky[u] = 0xFFFFFFFFu; qx[u] = qy[u] = qz[u] = 0.f;
         }
+        if (R == 1) {
+          float4 pt[kBatch];
+          unsigned kk[kBatch];
+#pragma unroll
+          for (int u = 0; u < kBatch; ++u)
+            if (li[u] >= 0) {  // wave-uniform
+              const size_t base = (size_t)(w + kFpsWaves * (li[u] + kWave * s)) * kWave + lane;
+              pt[u] = pts[base];
+              kk[u] = keys[base];
+            }
+#pragma unroll
+          for (int u = 0; u < kBatch; ++u)
+            if (li[u] >= 0) {
+              const size_t base = (size_t)(w + kFpsWaves * (li[u] + kWave * s)) * kWave + lane;
+              const float d = sqdist3(pt[u].x - cx, pt[u].y - cy, pt[u].z - cz);
+              const float t = fminf(d, pt[u].w);  // -inf (non-candidate) stays -inf
+              if (t < pt[u].w) pts[base].w = t;
+              rk[u] = rank_of(t); ky[u] = kk[u]; qx[u] = pt[u].x; qy[u] = pt[u].y; qz[u] = pt[u].z;
+            }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kBatch; ++u)
+            if (li[u] >= 0) {
+              const size_t base = (size_t)(w + kFpsWaves * (li[u] + kWave * s)) * P.bucket_pts + lane;
+              for (int r = 0; r < R; ++r) {
+                const float4 p = pts[base + r * kWave];
+                const unsigned key = keys[base + r * kWave];
+                const float d = sqdist3(p.x - cx, p.y - cy, p.z - cz);
+                const float t = fminf(d, p.w);
+                if (t < p.w) pts[base + r * kWave].w = t;
+                const unsigned rr = rank_of(t);
+                if (rr > rk[u] || (rr == rk[u] && key < ky[u])) { rk[u] = rr; ky[u] = key; qx[u] = p.x; qy[u] = p.y; qz[u] = p.z; }
+              }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+          if (li[u] >= 0) {
+            const WaveBest wb = wave_argbest(rk[u], ky[u]);
+            const float wx = readlane_f32(qx[u], wb.lane), wy = readlane_f32(qy[u], wb.lane), wz = readlane_f32(qz[u], wb.lane);
+            if (lane == li[u]) {
+              bmax[s] = t_of_rank(wb.rank);
+              bkey[s] = wb.key;
+              bpx[s] = wx; bpy[s] = wy; bpz[s] = wz;
+            }
+          }
       }
     }
     // arg-max over this wave's buckets, then over the 16 waves through LDS (double-buffered: 1 barrier)
-    unsigned long long mine = 0ull;
+    unsigned mrank = 0u, mkey = 0xFFFFFFFFu;
     float mx = 0.f, my = 0.f, mz = 0.f;
 #pragma unroll
     for (int s = 0; s < kFpsSlots; ++s) {
-      const unsigned long long c = pack_cand(bmax[s], bkey[s]);
-      if (c > mine) { mine = c; mx = bpx[s]; my = bpy[s]; mz = bpz[s]; }
+      const unsigned rr = rank_of(bmax[s]);
+      if (rr > mrank || (rr == mrank && bkey[s] < mkey)) { mrank = rr; mkey = bkey[s]; mx = bpx[s]; my = bpy[s]; mz = bpz[s]; }
     }
-    const unsigned long long wbest = wave_allmax_u64(mine);
-    const int src = __ffsll((long long)__ballot(mine == wbest)) - 1;
-    const float wx = readlane_f32(mx, src), wy = readlane_f32(my, src), wz = readlane_f32(mz, src);
+    const WaveBest wb = wave_argbest(mrank, mkey);
+    const float wx = readlane_f32(mx, wb.lane), wy = readlane_f32(my, wb.lane), wz = readlane_f32(mz, wb.lane);
     const int par = j & 1;
     if (lane == 0) {
-      s_best[par][w] = wbest;
+      s_rank[par][w] = wb.rank; s_key[par][w] = wb.key;
       s_bxyz[par][w][0] = wx; s_bxyz[par][w][1] = wy; s_bxyz[par][w][2] = wz;
     }
     __syncthreads();
-    const unsigned long long slot = s_best[par][lane & (kFpsWaves - 1)];
-    const unsigned long long gbest = row_allmax_u64(slot);  // every 16-lane row holds all 16 slots
-    const int ws = (__ffsll((long long)__ballot(slot == gbest)) - 1) & (kFpsWaves - 1);
+    const int sl = lane & (kFpsWaves - 1);  // every 16-lane row reads all 16 slots
+    const unsigned srank = s_rank[par][sl], skey = s_key[par][sl];
+    const unsigned grank = row_allmax_u32(srank);
+    const unsigned gkey = row_allmin_u32(srank == grank ? skey : 0xFFFFFFFFu);
+    const int ws = (__ffsll((long long)__ballot(srank == grank && skey == gkey)) - 1) & (kFpsWaves - 1);
     int winner = 0;
-    if (gbest) {
-      const unsigned key = ~(unsigned)gbest;
-      winner = (int)((key & 0x3FFFFFu) * rb + bitrev(key >> 22, P.ref_log2));
+    if (grank) {
+      winner = (int)((gkey & 0x3FFFFFu) * rb + bitrev(gkey >> 22, P.ref_log2));
       cx = s_bxyz[par][ws][0]; cy = s_bxyz[par][ws][1]; cz = s_bxyz[par][ws][2];
     } else {  // no candidate at all: the reference's reduction returns besti = 0 (:93-94)
       cx = p0x; cy = p0y; cz = p0z;

@@ -94,6 +94,36 @@ __device__ __forceinline__ float wave_allsum_f32(float v) {
   return __uint_as_float(p.a) + __uint_as_float(p.b);
 }
 
+// 32-bit unsigned all-reduces: one DPP-fused VALU op per stage
+__device__ __forceinline__ unsigned row_allmax_u32(unsigned v) {
+  v = max(v, dpp_u32<kDppQuadXor1>(v));
+  v = max(v, dpp_u32<kDppQuadXor2>(v));
+  v = max(v, dpp_u32<kDppRowHalfMirror>(v));
+  v = max(v, dpp_u32<kDppRowMirror>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned row_allmin_u32(unsigned v) {
+  v = min(v, dpp_u32<kDppQuadXor1>(v));
+  v = min(v, dpp_u32<kDppQuadXor2>(v));
+  v = min(v, dpp_u32<kDppRowHalfMirror>(v));
+  v = min(v, dpp_u32<kDppRowMirror>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned wave_allmax_u32(unsigned v) {
+  v = row_allmax_u32(v);
+  pair_u32 p = xrow16(v);
+  v = max(p.a, p.b);
+  p = xhalf32(v);
+  return max(p.a, p.b);
+}
+__device__ __forceinline__ unsigned wave_allmin_u32(unsigned v) {
+  v = row_allmin_u32(v);
+  pair_u32 p = xrow16(v);
+  v = min(p.a, p.b);
+  p = xhalf32(v);
+  return min(p.a, p.b);
+}
+
 __device__ __forceinline__ float readlane_f32(float v, int lane) {
   return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
 }

@@ -64,3 +64,22 @@ def get_3d_box_batch_tensor(box_size, angle, center):
     R = roty_batch_tensor(angle)                            # (.., 3, 3)
     corners = torch.matmul(local, R.transpose(-1, -2))
     return corners + center.unsqueeze(-2)
+
+
+def morton_argsort(xyz):
+    """[B,N,3] -> [B,N] permutation that orders the points along a 30-bit Morton (Z-order) curve of their bounding
+    box.  Attention is invariant to the order of its keys; the HIP kernels are not indifferent to it: neighbouring
+    lanes = neighbouring keys = the same RPE table cell (LDS broadcast in the forward, wave-level aggregation of
+    the table gradient in the backward)."""
+    lo = xyz.min(dim=1, keepdim=True)[0]
+    ext = (xyz.max(dim=1, keepdim=True)[0] - lo).clamp(min=1e-6)
+    q = ((xyz - lo) / ext * 1023.0).long().clamp_(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+
+    code = spread(q[..., 0]) | (spread(q[..., 1]) << 1) | (spread(q[..., 2]) << 2)
+    return torch.argsort(code, dim=1)

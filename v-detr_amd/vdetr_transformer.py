@@ -26,7 +26,7 @@ from torch import Tensor, nn
 
 from . import attention as A
 from .helpers import ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PositionEmbeddingLearned, get_clones
-from .pc_util import scale_points, shift_scale_points
+from .pc_util import morton_argsort, scale_points, shift_scale_points
 
 _salt_counter = itertools.count(1)
 
@@ -408,6 +408,8 @@ class TransformerDecoder(nn.Module):
         if q_content in ("random", "random_add"):
             self.query_embed = nn.Embedding(num_queries, self.dec_output_dim)
         self.return_intermediate = return_intermediate
+        # keys of the cross attention are visited in Morton order (performance only: attention is invariant to it)
+        self.sort_keys = True
         self._reset_parameters(weight_init_name)  # before the heads are built, as in the reference (:151-159)
 
         self.mlp_norm, self.mlp_act, self.mlp_sep, self.cls_loss = mlp_norm, mlp_act, mlp_sep, cls_loss
@@ -551,6 +553,13 @@ class TransformerDecoder(nn.Module):
                                     topk.unsqueeze(-1).expand(-1, -1, output.shape[-1])).permute(1, 0, 2).contiguous()
             output = gathered + self.query_embed.weight.unsqueeze(1) if self.q_content == "random_add" else gathered
 
+        # ---- keys in Morton order for the RPE kernels (memory / enc_xyz feed only the cross attention) -----------
+        key_order = None
+        if self.sort_keys and memory_mask is None and memory_key_padding_mask is None and pos is None:
+            key_order = morton_argsort(enc_xyz.detach())                                   # B,nK
+            enc_xyz = torch.gather(enc_xyz, 1, key_order.unsqueeze(-1).expand(-1, -1, 3))
+            memory = torch.gather(memory, 0, key_order.t().unsqueeze(-1).expand(-1, -1, memory.shape[-1]))
+
         # ---- decoder layers with box feedback (:407-436) ---------------------------------------------------
         for idx, layer in enumerate(self.layers):
             if idx > 0:
@@ -574,6 +583,9 @@ class TransformerDecoder(nn.Module):
             if self.return_intermediate:
                 intermediate.append(box_prediction)
             if return_attn_weights:
+                if key_order is not None:  # back to the caller's key order
+                    inv = torch.argsort(key_order, dim=1)[:, None, None, :].expand_as(attn)
+                    attn = torch.gather(attn, 3, inv)
                 attns.append(attn)
 
         if return_attn_weights:
