@@ -222,6 +222,129 @@ __global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnPa
   }
 }
 
+// ---- RPE kernel, producer/consumer variant (default) -------------------------------------------------------------
+// The table gradient needs, per (pair, vertex), 8 corners x 4 heads = 32 products added into 32 histogram bins.
+// Aggregating them ACROSS lanes (variant 1) costs a masked 6-stage reduce-scatter per distinct cell (measured: 7.9
+// distinct cells per 64 Morton-consecutive keys).  This variant turns the problem by 90 degrees:
+//   producer  lane = pair, as before: per vertex it computes only the lookup RECORD (cell id + the 3 sub-cell
+//             coordinates, 16 B) and parks it, with the pair's dS[4], in a wave-private LDS strip;
+//   consumer  lane = BIN: lane (half, j) owns corner j>>2 / head j&3 of one vertex per half-wave and walks the 64
+//             records of the strip in order.  All 32 lanes of a half read the same record (LDS broadcast), build
+//             their own corner weight with 6 VALU ops, and add weight*dS[h] into ONE register.  Because every
+//             lane of the half sees the same cell sequence, the run-length accumulation is uniform: when the cell
+//             changes (34 % of the steps on Morton-ordered keys) the half flushes with a single ds_add_f32 whose 32
+//             addresses are distinct — no same-address serialisation, no cross-lane reduction at all.
+// ~13 VALU + 2 LDS reads per (pair, vertex) for 32 bins, against ~150 VALU per distinct cell before.
+constexpr int kPcThreads = 512;
+constexpr int kPcWaves = kPcThreads / kWave;
+constexpr int kPcStripFloats = 3 * kWave * 4;  // 2 vertex records + dS, float4 each, per lane
+
+__global__ __launch_bounds__(kPcThreads) void attn_bwd_scores_rpe_pc_kernel(AttnParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy 8*T^3*4][8 strips]
+  attn_load_rng(P);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = P.T, TT = T * T, T3 = TT * T;
+  const int table_floats = kRpeVerts * T3 * 4;
+  for (int i = tid; i < table_floats; i += kPcThreads) smem[i] = 0.f;
+  __syncthreads();
+  f32x4* strip = reinterpret_cast<f32x4*>(smem + table_floats + w * kPcStripFloats);  // [3][64]
+  const bool rot = P.cos_sin != nullptr;
+  const int items = P.B * P.nQ;
+  const int nchunks = (P.nK + kWave - 1) / kWave;
+  // consumer role of this lane
+  const int half = lane >> 5, jv = lane & 31;
+  const float czf = (float)((jv >> 4) & 1), cyf = (float)((jv >> 3) & 1), cxf = (float)((jv >> 2) & 1);
+  const int hsel = jv & 3;
+  const int my_off = (((jv >> 4) & 1) * TT + ((jv >> 3) & 1) * T + ((jv >> 2) & 1)) * 4 + hsel;
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int b = item / P.nQ, q = item - b * P.nQ;
+    const size_t row0 = ((size_t)b * P.nQ + q) * 4;
+    float lse[4], delta[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { lse[h] = P.lse[row0 + h]; delta[h] = P.delta[row0 + h]; }
+    float vx[8], vy[8], vz[8];
+    const float* vp = P.vertices + ((size_t)b * P.nQ + q) * 24;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
+    const float rc = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2] : 1.f;
+    const float rs = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1] : 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // one running bin per vertex group (this half's vertex 2*g + half)
+    int cur[4] = {-1, -1, -1, -1};
+
+    for (int chunk = w; chunk < nchunks; chunk += kPcWaves) {
+      // ---- producer: element-wise softmax backward for this lane's pair ------------------------------------
+      const int key = chunk * kWave + lane;
+      const bool valid = key < P.nK;
+      const int keyc = valid ? key : P.nK - 1;
+      f32x4 ds = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+        if (P.drop_thresh) rnd = attn_rand4(P, b, q, key, 0);
+        const bool masked = P.mask_kind == VDETR_MASK_BOOL &&
+                            reinterpret_cast<const unsigned char*>(P.mask)[((size_t)b * P.nQ + q) * P.nK + key];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const size_t e = (row0 + h) * P.nK + key;
+          const bool keep = pick4(rnd, h) >= P.drop_thresh;
+          const ScoreGrad g = score_grad(P.scores[e], lse[h], keep, P.drop_scale, true, P.dprob[e], delta[h], masked);
+          P.scores[e] = g.p_drop;
+          P.dprob[e] = g.ds;
+          ds[h] = g.ds;
+        }
+      }
+      const float* xp = P.xyz + ((size_t)b * P.nK + keyc) * 3;
+      const float kx = xp[0], ky = xp[1], kz = xp[2];
+      __builtin_amdgcn_wave_barrier();
+      strip[2 * kWave + lane] = ds;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // ---- producer: lookup records of vertices 2g, 2g+1 ------------------------------------------------
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv) {
+          const int i = 2 * g + hv;
+          float dx = vx[i] - kx, dy = vy[i] - ky, dz = vz[i] - kz;
+          if (rot) rpe_rotate(dx, dy, rc, rs);
+          float tx, ty, tz;
+          const int bx = rpe_axis_base(dx, P, tx), by = rpe_axis_base(dy, P, ty), bz = rpe_axis_base(dz, P, tz);
+          const int cell = i * T3 + (bz * T + by) * T + bx;
+          strip[hv * kWave + lane] = f32x4{__int_as_float(cell), tz, ty, tx};
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- consumer: walk the 64 records of this half's vertex ---------------------------------------------
+        const f32x4* rec = strip + half * kWave;
+        const float* dsr = reinterpret_cast<const float*>(strip + 2 * kWave) + hsel;
+        float a = acc[g];
+        int c = cur[g];
+#pragma unroll 4
+        for (int p = 0; p < kWave; ++p) {
+          const f32x4 r = rec[p];
+          const float d = dsr[p * 4];
+          const int cell = __float_as_int(r[0]);
+          const float wz = __saturatef(1.f - fabsf(r[1] - czf));
+          const float wy = __saturatef(1.f - fabsf(r[2] - cyf));
+          const float wx = __saturatef(1.f - fabsf(r[3] - cxf));
+          if (cell != c) {
+            if (c >= 0) atomicAdd(smem + (size_t)c * 4 + my_off, a);
+            a = 0.f;
+            c = cell;
+          }
+          a = __builtin_fmaf(wz * wy * wx, d, a);
+        }
+        acc[g] = a;
+        cur[g] = c;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (cur[g] >= 0) atomicAdd(smem + (size_t)cur[g] * 4 + my_off, acc[g]);
+  }
+  __syncthreads();
+  float* dst = P.dtable_part + (size_t)blockIdx.x * table_floats;
+  for (int i = tid; i < table_floats; i += kPcThreads) dst[i] = smem[i];
+}
+
 // ---- RPE kernel, run-length variant (default) ---------------------------------------------------------------
 // Lanes own QUERIES and walk the (Morton-ordered) keys one by one: lane l = (query l>>1 of a 32-query group,
 // vertex half l&1 -> 4 of the 8 vertices).  A (query, vertex) sees its lookup cell change only when the key
@@ -403,7 +526,7 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, ui
 using namespace vdetr;
 
 static int bwd_variant() {
-  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 2; }();
+  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 3; }();
   return variant;
 }
 // run-length variant: grid (query groups, key splits, B); splits chosen to give >= ~256 workgroups
@@ -460,7 +583,11 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, float* scores
     lds = (size_t)table_floats * sizeof(float);
   }
   const int variant = bwd_variant();
-  if (variant == 2 && dtable) {
+  if (variant == 3 && dtable) {
+    lds += (size_t)kPcWaves * kPcStripFloats * sizeof(float);
+    if (int e = set_lds(attn_bwd_scores_rpe_pc_kernel, lds, "attn_bwd_scores")) return e;
+    hipLaunchKernelGGL(attn_bwd_scores_rpe_pc_kernel, dim3(grid), dim3(kPcThreads), lds, st, P);
+  } else if (variant == 2 && dtable) {
     int qg, sp, per;
     rl_geometry(d, &qg, &sp, &per);
     if (int e = set_lds(attn_bwd_scores_rpe_rl_kernel, lds, "attn_bwd_scores")) return e;

@@ -86,28 +86,46 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   const int tile_begin = split * P.tiles_per_split;
   const int tile_end = min(ntiles, tile_begin + P.tiles_per_split);
 
+  // Operands of a key tile: fetched one tile AHEAD (software pipelining).  With loads issued right before their
+  // use every tile step exposed 2-3 full memory latencies (vmcnt is in-order on gfx950, so a V load also waits
+  // for the score stores issued before it).
+  struct TileOps {
+    f32x4 kb[4], vb[4];
+    float kx, ky, kz;
+  };
+  auto fetch = [&](int tile, TileOps& t) {
+    const int key0 = tile << 4;
+    const int keyc = min(key0 + c, nK - 1);
+    const f32x4* kp = reinterpret_cast<const f32x4*>(P.k + ((size_t)b * nK + keyc) * kvstride + kvoff + 16 * g);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = min(key0 + 4 * g + s, nK - 1);
+      t.vb[s] = *reinterpret_cast<const f32x4*>(P.v + ((size_t)b * nK + kk) * kvstride + kvoff + 4 * c);
+    }
+    if (RPE) {
+      const float* xp = P.xyz + ((size_t)b * nK + keyc) * 3;
+      t.kx = xp[0]; t.ky = xp[1]; t.kz = xp[2];
+    }
+  };
+  TileOps ops, nxt;
+  if (tile_begin + w < tile_end) fetch(tile_begin + w, ops);
+
   for (int tile = tile_begin + w; tile < tile_end; tile += kFwdWaves) {
     const int key0 = tile << 4;
     const int key = key0 + c;
     const bool kvalid = key < nK;
     const int keyc = min(key, nK - 1);
+    if (tile + kFwdWaves < tile_end) fetch(tile + kFwdWaves, nxt);
     // ---- S = Q K^T --------------------------------------------------------------------------------
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    {
-      const f32x4* kp = reinterpret_cast<const f32x4*>(P.k + ((size_t)b * nK + keyc) * kvstride + kvoff + 16 * g);
-      f32x4 kb[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) kb[s4] = kp[s4];
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kb[s >> 2][s & 3], acc, 0, 0, 0);
-    }
+    for (int s = 0; s < 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
     float sc[4] = {acc[0], acc[1], acc[2], acc[3]};
     // ---- + RPE bias -------------------------------------------------------------------------------
-    if (RPE) {
-      const float* xp = P.xyz + ((size_t)b * nK + keyc) * 3;
-      rpe_pair_bias(P, tab, vx, vy, vz, xp[0], xp[1], xp[2], rot, rc, rs, sc);
-    }
+    if (RPE) rpe_pair_bias(P, tab, vx, vy, vz, ops.kx, ops.ky, ops.kz, rot, rc, rs, sc);
     // ---- mask, tail ------------------------------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -167,18 +185,11 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
     const f32x4 pa = *reinterpret_cast<const f32x4*>(ppad + c * kPPad + 4 * g);
     __builtin_amdgcn_wave_barrier();
     // ---- O += P V ------------------------------------------------------------------------------------
-    {
-      f32x4 vb[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kk = min(key0 + 4 * g + s, nK - 1);
-        vb[s] = *reinterpret_cast<const f32x4*>(P.v + ((size_t)b * nK + kk) * kvstride + kvoff + 4 * c);
-      }
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], vb[s][t], o[t], 0, 0, 0);
-    }
+      for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], ops.vb[s][t], o[t], 0, 0, 0);
+    ops = nxt;
   }
 
   // ---- merge the 8 wave states -------------------------------------------------------------------------

@@ -292,7 +292,10 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
       s_rank[par][w] = wb.rank; s_key[par][w] = wb.key;
       s_bxyz[par][w][0] = wx; s_bxyz[par][w][1] = wy; s_bxyz[par][w][2] = wz;
     }
-    __syncthreads();
+    // LDS-only barrier.  __syncthreads() would also drain vmcnt, i.e. make every wave wait for the L2
+    // acknowledgement of the running-distance stores it issued this round — stores that only the SAME lane
+    // reads back in a later round, so nobody needs them visible here.  That wait was most of the round time.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int sl = lane & (kFpsWaves - 1);  // every 16-lane row reads all 16 slots
     const unsigned srank = s_rank[par][sl], skey = s_key[par][sl];
     const unsigned grank = row_allmax_u32(srank);
