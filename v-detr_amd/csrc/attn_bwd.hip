@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, ui
 using namespace vdetr;
 
 static int bwd_variant() {
-  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 3; }();
+  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 1; }();
   return variant;
 }
 // run-length variant: grid (query groups, key splits, B); splits chosen to give >= ~256 workgroups
