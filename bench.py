@@ -84,22 +84,41 @@ def loss_fn(out):
 class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
-    def __init__(self, model, inputs, world, use_graph, overlap):
+    def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True):
         from vdetr_amd.dist import GradientReducer
         self.model, self.inputs, self.world = model, inputs, world
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.reducer = GradientReducer(self.params, bucket_mb=25.0, overlap=overlap and not use_graph)
+        # hooks + bucket views only pay off when they overlap communication with an EAGER backward; otherwise
+        # gradients stay ordinary tensors and are packed with one multi-tensor copy before the all-reduce
+        self.hooked = world > 1 and overlap and not use_graph
+        self.reducer = GradientReducer(self.params, bucket_mb=25.0, overlap=self.hooked, bucket_views=self.hooked)
         self.opt = torch.optim.AdamW(self.params, lr=7e-4, weight_decay=0.1, capturable=True, foreach=True)
         self.use_graph = use_graph
         self.g_main = self.g_opt = None
         self.loss = None
+        # FPS of the NEXT scene runs on a side stream while this scene is in the decoder (the sampling depends on
+        # voxel coordinates only).  Every step still runs one full FPS kernel; it just no longer serialises a
+        # one-CU kernel in front of a 256-CU step.
+        self.fps_prefetch = fps_prefetch
+        if fps_prefetch:
+            self.side = torch.cuda.Stream()
+            self.cur_inds = model.sample_indices(inputs)
 
     def _fwd_bwd(self):
         self.reducer.zero_grad()
         for f in self.inputs["backbone_features"]:
             f.grad = None
+        if self.fps_prefetch:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                next_inds = self.model.sample_indices(self.inputs)  # (the synthetic bench feeds the same scene again)
+            self.inputs["fps_inds"] = self.cur_inds
         self.loss = loss_fn(self.model(self.inputs))
         self.loss.backward()
+        if self.fps_prefetch:
+            main.wait_stream(self.side)
+            self.cur_inds.copy_(next_inds)
 
     def _update(self):
         torch.nn.utils.clip_grad_norm_(self.params, 0.1, foreach=True)  # engine.py:105-106
@@ -120,6 +139,8 @@ class Trainer:
             if self.world == 1:
                 self._update()
         if self.world > 1:
+            self.graph_grads = [p.grad for p in self.params]  # static buffers of the captured backward
+            self.reducer.pack_and_reduce(self.graph_grads)    # p.grad -> bucket views, which the update graph reads
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt):
                 self._update()
@@ -128,11 +149,14 @@ class Trainer:
         if self.g_main is not None:
             self.g_main.replay()
             if self.world > 1:
-                self.reducer.reduce_all()
+                self.reducer.pack_and_reduce(self.graph_grads)
                 self.g_opt.replay()
         else:
             self._fwd_bwd()
-            self.reducer.finish()
+            if self.hooked:
+                self.reducer.finish()
+            elif self.world > 1:
+                self.reducer.pack_and_reduce()
             self._update()
 
 
@@ -268,6 +292,7 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm as in main.py:512-514 (implies --no-graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
     a = ap.parse_args()
 
     from vdetr_amd.dist import broadcast_parameters, init_distributed
@@ -284,7 +309,7 @@ def main():
         if a.sync_bn:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     inputs = make_inputs(a.config, device, rank)
-    trainer = Trainer(model, inputs, world, use_graph, overlap=True)
+    trainer = Trainer(model, inputs, world, use_graph, overlap=True, fps_prefetch=not a.no_fps_prefetch)
     graph_ok = False
     if use_graph:
         try:
@@ -327,7 +352,7 @@ def main():
         "config": {"workload": desc, "global_batch": world * bs, "voxels_per_scene": int(inputs["backbone_xyz"][0].shape[0]),
                    "keys": npre, "queries": nq, "rpe_layers": nl - 1, "parallelism": f"dp{world}",
                    "step": "FPS+gather, projection, decoder fwd, loss, backward, grad all-reduce (N>1), clip, AdamW",
-                   "hip_graph": graph_ok, "sync_bn": bool(a.sync_bn),
+                   "hip_graph": graph_ok, "sync_bn": bool(a.sync_bn), "fps_prefetch": not a.no_fps_prefetch,
                    "grad_allreduce_bytes": trainer.reducer.grad_bytes()},
         "loss": loss,
     }

@@ -15,7 +15,8 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, mode, q):
+    overlap = mode == "hooks"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from vdetr_amd.dist import GradientReducer, broadcast_parameters, init_distributed
@@ -26,7 +27,8 @@ def _worker(rank, world, port, overlap, q):
     for p in model[3].parameters():
         p.requires_grad_(True)
     broadcast_parameters(model)
-    red = GradientReducer(model.parameters(), bucket_mb=0.0003, overlap=overlap)  # several tiny buckets
+    red = GradientReducer(model.parameters(), bucket_mb=0.0003, overlap=overlap,  # several tiny buckets
+                          bucket_views=mode != "pack")
     assert len(red.buckets) > 1
     torch.manual_seed(rank)        # each rank sees its own "scene"
     x = torch.randn(5, 8)
@@ -34,22 +36,24 @@ def _worker(rank, world, port, overlap, q):
         red.zero_grad()
         out = model[2](model[1](model[0](x)))  # model[3] is unused: its gradient stays zero, bucket flushed by finish()
         out.square().sum().backward()
-        if overlap:
+        if mode == "hooks":
             red.finish()
-        else:
+        elif mode == "after":
             red.reduce_all()
+        else:
+            red.pack_and_reduce()
     # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with the worker
-    q.put((rank, [p.grad.numpy().copy() for p in model.parameters()],
+    q.put((rank, [(torch.zeros_like(p) if p.grad is None else p.grad).numpy().copy() for p in model.parameters()],
            [p.detach().numpy().copy() for p in model.parameters()], x.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(overlap):
+def _run(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -78,8 +82,13 @@ def _run(overlap):
 
 
 def test_gradient_reducer_overlap_hooks():
-    _run(True)
+    _run("hooks")
 
 
 def test_gradient_reducer_after_backward():
-    _run(False)
+    _run("after")
+
+
+def test_gradient_reducer_pack_after_backward():
+    """gradients stay ordinary tensors and are packed into the buckets with one multi-tensor copy"""
+    _run("pack")

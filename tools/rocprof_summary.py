@@ -33,7 +33,7 @@ def main():
           (f", {steps} steps -> {tot / 1e3 / steps:.2f} ms/step, {len(rows) // steps} dispatches/step" if steps else ""))
     print(f"{'%':>6} {'calls':>7} {'total_us':>11} {'avg_us':>10} {'min_us':>9} {'max_us':>9}  kernel")
     for n, ds in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:45]:
-        print(f"{sum(ds) / tot * 100:6.2f} {len(ds):7d} {sum(ds):11.1f} {sum(ds) / len(ds):10.2f} {min(ds):9.2f} {max(ds):9.2f}  {n[:110]}")
+        print(f"{sum(ds) / tot * 100:6.2f} {len(ds):7d} {sum(ds):11.1f} {sum(ds) / len(ds):10.2f} {min(ds):9.2f} {max(ds):9.2f}  {n[:260]}")
 
 
 if __name__ == "__main__":

@@ -13,6 +13,10 @@ main.py:531-532), so the only data-path collective is the gradient average:
     (the reference needs find_unused_parameters for those);
   * graph mode: forward+backward run as one captured hipGraph (no hooks fire inside a replay), so
     ``reduce_all()`` is called after the replay.
+``bucket_views=False`` keeps ``p.grad`` ordinary tensors (autograd then hands its gradient buffers over without
+the per-parameter accumulate kernel that writing into a pre-existing ``.grad`` costs — ~1100 launches per step
+for this model) and packs them into the buckets with one multi-tensor copy before the all-reduce
+(``pack_and_reduce()``), pointing ``p.grad`` at the reduced views afterwards.
 On CPU tensors (gloo, used by the tests) the same code runs without streams.
 """
 import os
@@ -39,7 +43,7 @@ def init_distributed(backend=None):
 
 
 class GradientReducer:
-    def __init__(self, params, bucket_mb=25.0, overlap=True, process_group=None):
+    def __init__(self, params, bucket_mb=25.0, overlap=True, process_group=None, bucket_views=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -59,11 +63,16 @@ class GradientReducer:
         if cur:
             groups.append(cur)
         self.buckets, self._bucket_of, self._pending, self._launched = [], {}, [], []
+        self.bucket_views = bucket_views
+        self._views = []  # (param, view) in bucket order
         for gi, g in enumerate(groups):
             flat = torch.zeros(sum(p.numel() for p in g), dtype=dtype, device=dev)
             off = 0
             for p in g:
-                p.grad = flat[off:off + p.numel()].view_as(p)  # gradients accumulate straight into the bucket
+                view = flat[off:off + p.numel()].view_as(p)
+                if bucket_views:
+                    p.grad = view  # gradients accumulate straight into the bucket
+                self._views.append((p, view))
                 off += p.numel()
                 self._bucket_of[id(p)] = gi
             self.buckets.append(flat)
@@ -72,7 +81,7 @@ class GradientReducer:
         self._counts = list(self._pending)
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._handles = []
-        if overlap and self.world > 1:
+        if overlap and self.world > 1 and bucket_views:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
@@ -98,8 +107,28 @@ class GradientReducer:
 
     # ---- public -------------------------------------------------------------------------------------
     def zero_grad(self):
-        for b in self.buckets:
-            b.zero_()
+        if self.bucket_views:
+            for b in self.buckets:
+                b.zero_()
+        else:
+            for p in self.params:
+                p.grad = None
+
+    def pack_and_reduce(self, grads=None):
+        """bucket_views=False: one multi-tensor copy of the fresh gradients into the buckets, all-reduce, and
+        ``p.grad`` -> reduced bucket views (parameters without a gradient contribute zeros).  ``grads`` (one
+        tensor or None per parameter, in ``self.params`` order) overrides ``p.grad`` as the source — the static
+        gradient buffers of a captured hipGraph."""
+        src = {id(p): (p.grad if grads is None else g) for p, g in zip(self.params, grads or self.params)}
+        have = [(src[id(p)], v) for p, v in self._views if src[id(p)] is not None]
+        missing = [v for p, v in self._views if src[id(p)] is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if have:
+            torch._foreach_copy_([v for _, v in have], [g for g, _ in have])
+        self.reduce_all()
+        for p, v in self._views:
+            p.grad = v
 
     def finish(self):
         """End of backward: flush buckets that never completed (unused parameters), join the side stream."""

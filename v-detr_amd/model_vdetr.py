@@ -20,9 +20,11 @@ from .vdetr_transformer import FFNLayer, GlobalDecoderLayer, TransformerDecoder
 class FPSModule(nn.Module):
     """Farthest point sampling + gather of coordinates and features (model_vdetr.py:18-34)."""
 
-    def forward(self, xyz, features, num_proposal):
-        """xyz (B,K,3), features (B,C,K) -> new_xyz (B,M,3), new_features (B,C,M), sample_inds (B,M) int32"""
-        sample_inds = pointnet2_utils.furthest_point_sample(xyz, num_proposal)
+    def forward(self, xyz, features, num_proposal, sample_inds=None):
+        """xyz (B,K,3), features (B,C,K) -> new_xyz (B,M,3), new_features (B,C,M), sample_inds (B,M) int32.
+        ``sample_inds`` may be handed in when it was computed ahead of time (``ModelVDETR.sample_indices``)."""
+        if sample_inds is None:
+            sample_inds = pointnet2_utils.furthest_point_sample(xyz, num_proposal)
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sample_inds).transpose(1, 2).contiguous()
         new_features = pointnet2_utils.gather_operation(features, sample_inds).contiguous()
@@ -91,6 +93,15 @@ class ModelVDETR(nn.Module):
         pos_embed = self.pos_embedding(encoder_xyz, input_range=point_cloud_dims)
         return encoder_xyz, self.query_projection(pos_embed).permute(2, 0, 1), None
 
+    @torch.no_grad()
+    def sample_indices(self, inputs):
+        """FPS indices [B, npoint] (int32) of a batch whose scenes have equal voxel counts.  The sampling only
+        depends on the voxel COORDINATES, so a training loop can run it ahead of time — e.g. for the next batch on a
+        side stream while the current batch is in the decoder — and pass the result as ``inputs["fps_inds"]``."""
+        scenes = self.pre_encoder(inputs)
+        xyz = torch.stack([s[0] for s in scenes]).contiguous()
+        return pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+
     def run_encoder(self, inputs):
         """Backbone output -> FPS to ``npoint`` tokens per scene (model_vdetr.py:279-326)."""
         scenes = self.pre_encoder(inputs)
@@ -98,7 +109,8 @@ class ModelVDETR(nn.Module):
         if same_n and not self.random_fps:
             xyz = torch.stack([s[0] for s in scenes]).contiguous()                   # B,n,3
             feats = torch.stack([s[1] for s in scenes]).transpose(1, 2).contiguous()  # B,C,n
-            enc_xyz, enc_features, enc_inds = self.fps_module(xyz, feats, self.npoint)  # one launch, B workgroups
+            enc_xyz, enc_features, enc_inds = self.fps_module(xyz, feats, self.npoint,  # one launch, B workgroups
+                                                              sample_inds=inputs.get("fps_inds"))
         else:
             out = []
             for xyz_i, feats_i in scenes:
