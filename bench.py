@@ -92,7 +92,7 @@ class Trainer:
         # gradients stay ordinary tensors and are packed with one multi-tensor copy before the all-reduce
         self.hooked = world > 1 and overlap and not use_graph
         self.reducer = GradientReducer(self.params, bucket_mb=25.0, overlap=self.hooked, bucket_views=self.hooked)
-        self.opt = torch.optim.AdamW(self.params, lr=7e-4, weight_decay=0.1, capturable=True, foreach=True)
+        self.opt = torch.optim.AdamW(self.params, lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
         self.use_graph = use_graph
         self.g_main = self.g_opt = None
         self.loss = None
