@@ -222,6 +222,148 @@ __global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnPa
   }
 }
 
+// ---- RPE kernel, matrix-core variant (default) --------------------------------------------------------------------
+// The wave-level aggregation of the table gradient IS a small matrix product:
+//     G[group][value] = sum over the 64 lanes  M[group][lane] * V[lane][value]
+// with M the 0/1 membership of a lane (pair) in a group (= distinct lookup cell among the wave's lanes, <= 16 per
+// round) and V the lane's 32 products weight(corner) * dS(head).  Variant 1 evaluates it group by group with a
+// masked 6-stage shuffle reduction (~125 VALU ops per group, 7.9 groups per wave step measured); here it is 16
+// v_mfma_f32_16x16x4_f32 per 16 values for ALL groups at once — exact fp32 (products with 0/1, fp32 accumulation
+// in a fixed order, so the result is also run-to-run deterministic up to the final LDS adds).
+//   lane l as A operand: row = group l&15, k-slot l>>4 -> membership of pair 4s + (l>>4)   (cells via an LDS strip)
+//   lane l as B operand: k-slot l>>4, column = value l&15        -> V[pair 4s + (l>>4)][l&15] (values via an LDS strip)
+//   result: lane l holds value l&15 of groups 4*(l>>4)+r -> 4 ds_add_f32 with distinct addresses.
+constexpr int kMmThreads = 512;
+constexpr int kMmWaves = kMmThreads / kWave;
+constexpr int kMmStripFloats = kWave + kWave * 16;  // cell ids + 64 x 16 values
+
+__global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(AttnParams P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy 8*T^3*4][8 strips]
+  attn_load_rng(P);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = P.T, TT = T * T, T3 = TT * T;
+  const int table_floats = kRpeVerts * T3 * 4;
+  for (int i = tid; i < table_floats; i += kMmThreads) smem[i] = 0.f;
+  __syncthreads();
+  int* cellbuf = reinterpret_cast<int*>(smem + table_floats + w * kMmStripFloats);
+  float* vbuf = smem + table_floats + w * kMmStripFloats + kWave;
+  const bool rot = P.cos_sin != nullptr;
+  const int items = P.B * P.nQ;
+  const int nchunks = (P.nK + kWave - 1) / kWave;
+  const int kk = lane >> 4, c15 = lane & 15;
+  // bin offsets of this lane's output column for the two 16-value tiles (tile jt = corners 4jt..4jt+3)
+  int off[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int corner = jt * 4 + (c15 >> 2);
+    off[jt] = (((corner >> 2) & 1) * TT + ((corner >> 1) & 1) * T + (corner & 1)) * 4 + (c15 & 3);
+  }
+  // swizzled strip columns (bank-conflict-free 16-B writes AND 4-B reads)
+  const int wr_sw = lane >> 1;
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int b = item / P.nQ, q = item - b * P.nQ;
+    const size_t row0 = ((size_t)b * P.nQ + q) * 4;
+    float lse[4], delta[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { lse[h] = P.lse[row0 + h]; delta[h] = P.delta[row0 + h]; }
+    float vx[8], vy[8], vz[8];
+    const float* vp = P.vertices + ((size_t)b * P.nQ + q) * 24;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
+    const float rc = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2] : 1.f;
+    const float rs = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1] : 0.f;
+
+    for (int chunk = w; chunk < nchunks; chunk += kMmWaves) {
+      const int key = chunk * kWave + lane;
+      const bool valid = key < P.nK;
+      const int keyc = valid ? key : P.nK - 1;
+      float ds[4] = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+        if (P.drop_thresh) rnd = attn_rand4(P, b, q, key, 0);
+        const bool masked = P.mask_kind == VDETR_MASK_BOOL &&
+                            reinterpret_cast<const unsigned char*>(P.mask)[((size_t)b * P.nQ + q) * P.nK + key];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const size_t e = (row0 + h) * P.nK + key;
+          const bool keep = pick4(rnd, h) >= P.drop_thresh;
+          const ScoreGrad g = score_grad(P.scores[e], lse[h], keep, P.drop_scale, true, P.dprob[e], delta[h], masked);
+          P.scores[e] = g.p_drop;
+          P.dprob[e] = g.ds;
+          ds[h] = g.ds;
+        }
+      }
+      const float* xp = P.xyz + ((size_t)b * P.nK + keyc) * 3;
+      const float kx = xp[0], ky = xp[1], kz = xp[2];
+#pragma unroll 1
+      for (int i = 0; i < kRpeVerts; ++i) {
+        float dx = vx[i] - kx, dy = vy[i] - ky, dz = vz[i] - kz;
+        if (rot) rpe_rotate(dx, dy, rc, rs);
+        const AxisTap ax = rpe_axis(dx, P), ay = rpe_axis(dy, P), az = rpe_axis(dz, P);
+        const int cell = i * T3 + rpe_cell(ax, ay, az, T);
+        const float w00 = az.wa * ay.wa, w01 = az.wa * ay.wb, w10 = az.wb * ay.wa, w11 = az.wb * ay.wb;
+        const float wgt[8] = {w00 * ax.wa, w00 * ax.wb, w01 * ax.wa, w01 * ax.wb,
+                              w10 * ax.wa, w10 * ax.wb, w11 * ax.wa, w11 * ax.wb};
+        // cells of all 64 pairs, laid out so that k-slot kk reads pairs kk, 4+kk, 8+kk, ... as 4 float4
+        __builtin_amdgcn_wave_barrier();
+        cellbuf[(lane & 3) * 16 + (lane >> 2)] = cell;
+        __builtin_amdgcn_wave_barrier();
+        int cr[16];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int4 v4 = *reinterpret_cast<const int4*>(cellbuf + kk * 16 + t4 * 4);
+          cr[t4 * 4] = v4.x; cr[t4 * 4 + 1] = v4.y; cr[t4 * 4 + 2] = v4.z; cr[t4 * 4 + 3] = v4.w;
+        }
+        unsigned long long todo = ~0ull;
+        while (todo) {
+          // up to 16 distinct cells of this round: lane g keeps the cell of group g
+          int mygcell = -1, ng = 0;
+          while (todo && ng < 16) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int c0 = __builtin_amdgcn_readlane(cell, leader);
+            todo &= ~__ballot(cell == c0);
+            if (lane == ng) mygcell = c0;
+            ++ng;
+          }
+          const int rowcell = __shfl(mygcell, c15);
+          float am[16];
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) am[s2] = cr[s2] == rowcell ? 1.f : 0.f;
+          int gc[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gc[r] = __shfl(mygcell, 4 * kk + r);
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            // V strip: my 16 values (4 corners x 4 heads), 16-B blocks rotated by lane>>1
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float wc = wgt[jt * 4 + cc];
+              *reinterpret_cast<f32x4*>(vbuf + lane * 16 + ((cc + wr_sw) & 3) * 4) =
+                  f32x4{wc * ds[0], wc * ds[1], wc * ds[2], wc * ds[3]};
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+              const int p = 4 * s2 + kk;
+              const float bv = vbuf[p * 16 + (((c15 >> 2) + (p >> 1)) & 3) * 4 + (c15 & 3)];
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s2], bv, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (gc[r] >= 0) atomicAdd(smem + (size_t)gc[r] * 4 + off[jt], acc[r]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = P.dtable_part + (size_t)blockIdx.x * table_floats;
+  for (int i = tid; i < table_floats; i += kMmThreads) dst[i] = smem[i];
+}
+
 // ---- RPE kernel, producer/consumer variant (default) -------------------------------------------------------------
 // The table gradient needs, per (pair, vertex), 8 corners x 4 heads = 32 products added into 32 histogram bins.
 // Aggregating them ACROSS lanes (variant 1) costs a masked 6-stage reduce-scatter per distinct cell (measured: 7.9
@@ -526,7 +668,7 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, ui
 using namespace vdetr;
 
 static int bwd_variant() {
-  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 1; }();
+  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 4; }();
   return variant;
 }
 // run-length variant: grid (query groups, key splits, B); splits chosen to give >= ~256 workgroups
@@ -583,7 +725,11 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, float* scores
     lds = (size_t)table_floats * sizeof(float);
   }
   const int variant = bwd_variant();
-  if (variant == 3 && dtable) {
+  if (variant == 4 && dtable) {
+    lds += (size_t)kMmWaves * kMmStripFloats * sizeof(float);
+    if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel, lds, "attn_bwd_scores")) return e;
+    hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel, dim3(grid), dim3(kMmThreads), lds, st, P);
+  } else if (variant == 3 && dtable) {
     lds += (size_t)kPcWaves * kPcStripFloats * sizeof(float);
     if (int e = set_lds(attn_bwd_scores_rpe_pc_kernel, lds, "attn_bwd_scores")) return e;
     hipLaunchKernelGGL(attn_bwd_scores_rpe_pc_kernel, dim3(grid), dim3(kPcThreads), lds, st, P);
