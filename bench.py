@@ -192,6 +192,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
     dprob = torch.randn((B, nQ, H, nK), generator=g).to(device) * 1e-3
     delta = torch.zeros((B, nQ, H), device=device)
     dtable = torch.zeros_like(table)
+    probs, dscore = torch.empty_like(scores), torch.empty_like(dprob)
     wsf = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
     wsb = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
     ws = L.workspace(max(wsf, wsb), device)
@@ -203,7 +204,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
 
     def bwd():
         L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), L.ptr(dprob), L.ptr(lse), L.ptr(delta),
-                                              L.ptr(dtable), L.ptr(ws), wsb, st), "attn_bwd")
+                                              L.ptr(probs), L.ptr(dscore), L.ptr(dtable), L.ptr(ws), wsb, st), "attn_bwd")
 
     def timeit(fn, prep=None):
         ts = []
@@ -220,7 +221,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
         return float(np.mean(ts))
 
     t_fwd = timeit(fwd)
-    t_bwd = timeit(bwd, prep=fwd)  # bwd consumes the saved scores in place
+    t_bwd = timeit(bwd)
     pairs = B * nQ * nK
     flops = 4.0 * H * pairs * 64                       # QK^T + PV (MFMA-eligible), SURVEY.md §8d
     bytes_bwd = 4.0 * 4 * H * pairs                    # S, dP~ read + P~, dS written (fp32)

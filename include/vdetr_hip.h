@@ -144,16 +144,17 @@ int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k,
                        float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
                        vdetr_stream_t stream);
 
-/* Backward, score stage.  In place (row order as above):
- *   scores  in: saved scores            out: P_drop = dropout(softmax)   (feeds dV = P_drop^T dO)
- *   dprob   in: dO V^T                  out: dS                          (feeds dQ = dS K, dK = dS^T Q)
+/* Backward, score stage (row order as above):
+ *   scores  in : saved scores                         probs_out : P_drop = dropout(softmax)  (feeds dV = P_drop^T dO)
+ *   dprob   in : dO V^T                               ds_out    : dS                         (feeds dQ = dS K, dK = dS^T Q)
  *   lse, delta = rowsum(dO * O)
  *   dtable [8,T,T,T,H] or NULL: += gradient of the RPE table (caller zero-fills)
- * With dprob == NULL and delta == NULL only P_drop is produced (the `attn` return value,
- * vdetr_transformer.py:758). */
+ * probs_out / ds_out may alias scores / dprob (element-wise in place) EXCEPT when dtable is requested: the table
+ * gradient kernel lets several waves re-read the inputs, so its outputs must be separate tensors.
+ * With dprob == delta == ds_out == NULL only P_drop is produced (the `attn` return value, vdetr_transformer.py:758). */
 size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d);
-int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, float* scores, float* dprob, const float* lse,
-                              const float* delta, float* dtable, void* workspace,
+int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, const float* dprob, const float* lse,
+                              const float* delta, float* probs_out, float* ds_out, float* dtable, void* workspace,
                               size_t workspace_bytes, vdetr_stream_t stream);
 
 /* Test hook: writes the dropout keep-mask (1/0 as uint8) [B,nQ,H,nK] the kernels above use. */

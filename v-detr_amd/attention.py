@@ -163,9 +163,14 @@ class _FusedAttention(Function):
         dtable = torch.zeros_like(table) if want_table else None
         nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d)) if want_table else 0
         ws = L.workspace(nbytes, q.device) if nbytes else None
-        # in place: scores -> P~ (dropped probabilities), dprob -> dS.  `scores` is dead after this call.
+        # scores -> P~ (dropped probabilities), dprob -> dS.  In place where allowed; the table-gradient kernel
+        # re-reads its inputs from several waves and needs separate outputs.
+        probs = torch.empty_like(scores) if want_table else scores
+        dscore = torch.empty_like(dprob) if want_table else dprob
         L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), L.ptr(dprob), L.ptr(lse), L.ptr(delta),
-                                              L.ptr(dtable), L.ptr(ws), nbytes, L.stream_ptr()), "attn_bwd_scores")
+                                              L.ptr(probs), L.ptr(dscore), L.ptr(dtable), L.ptr(ws), nbytes,
+                                              L.stream_ptr()), "attn_bwd_scores")
+        scores, dprob = probs, dscore
         if shared:
             p_r = scores.view(B, nQ * H, nK)
             ds_r = dprob
@@ -236,8 +241,8 @@ def attention_probabilities(q, k, *, num_heads, scale, shared_kv, table=None, rp
         ws = L.workspace(nbytes, q.device) if nbytes else None
         L.check(lib.vdetr_attn_fwd_f32(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(k), L.ptr(out), L.ptr(lse),
                                        L.ptr(scores), L.ptr(ws), nbytes, L.stream_ptr()), "attn_fwd")
-        L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), None, L.ptr(lse), None, None, None, 0,
-                                              L.stream_ptr()), "attn_probs")
+        L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), None, L.ptr(lse), None, L.ptr(scores),
+                                              None, None, None, 0, L.stream_ptr()), "attn_probs")
     return scores.permute(0, 2, 1, 3) if shared_kv else scores
 
 

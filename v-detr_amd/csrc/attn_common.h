@@ -45,6 +45,8 @@ struct AttnParams {
   // backward
   float* dprob;
   const float* delta;
+  float* probs_out;
+  float* ds_out;
   float* dtable_part;  // [gridDim.x][8*T^3*H]
 };
 
