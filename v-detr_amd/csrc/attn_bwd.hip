@@ -228,7 +228,9 @@ __global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnPa
 // plain per-lane atomics 6.5 ms, wave-aggregated (variant 1) 1.29 ms — no matter how cheap the aggregation itself is.
 // This variant therefore removes the atomics altogether:
 //   * wave w of the workgroup owns VERTEX w: it is the only writer of table i = w in the workgroup's LDS histogram,
-//     so its updates are plain ds_read / add / ds_write (the lanes of one update hit distinct bins by construction);
+//     and the lanes of one update hit distinct bins by construction, so the ds_add_f32 it issues never serialise on
+//     an address (template ATOMIC=false swaps them for plain read/add/write: 0.80 vs 1.17 ms, but it did NOT
+//     reproduce the atomic result on hardware although a census found no colliding bins — kept off until understood);
 //   * the wave-level aggregation is a small matrix product on the matrix cores,
 //         G[group][value] = sum over the 64 lanes  M[group][lane] * V[lane][value]
 //     with M the 0/1 membership of a lane (pair) in a group (= distinct lookup cell among the wave's 64 pairs, <= 16
@@ -245,6 +247,7 @@ constexpr int kMmWaves = kMmThreads / kWave;
 constexpr int kMmStripFloats = kWave + kWave * 16;  // cell ids + 64 x 16 values
 static_assert(kMmWaves == kRpeVerts, "one wave per vertex table");
 
+template <bool ATOMIC>
 __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy 8*T^3*4][8 strips]
   attn_load_rng(P);
@@ -254,8 +257,11 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
   const int table_floats = kRpeVerts * T3 * 4;
   for (int i = tid; i < table_floats; i += kMmThreads) smem[i] = 0.f;
   __syncthreads();
-  int* cellbuf = reinterpret_cast<int*>(smem + table_floats + w * kMmStripFloats);
-  float* vbuf = smem + table_floats + w * kMmStripFloats + kWave;
+  // wave-private strip, accessed as int throughout (values are bit-cast) so that the scoreboard and the value
+  // tile, which share memory, are never seen through two different types by the compiler's alias analysis
+  int* cellbuf = reinterpret_cast<int*>(smem + table_floats + w * kMmStripFloats);  // 64 ints
+  int* vbuf = cellbuf + kWave;                                                       // 64 x 16 values
+  int* scoreboard = vbuf;                                                            // T^3 <= 1024 ints, aliases vbuf
   float* mytab = smem + (size_t)w * T3 * 4;
   const bool rot = P.cos_sin != nullptr;
   const int items = P.B * P.nQ;
@@ -269,6 +275,25 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
   }
   const int wr_sw = lane >> 1;  // 16-B blocks of a strip row are rotated by lane>>1: conflict-free b128 writes AND b32 reads
 
+  // operands of one chunk (64 consecutive keys, one per lane); fetched one chunk ahead
+  struct ChunkOps {
+    float s[4], d[4], kx, ky, kz;
+    unsigned char masked;
+  };
+  auto fetch = [&](int b, size_t row0, int q, int chunk, ChunkOps& o) {
+    const int key = min(chunk * kWave + lane, P.nK - 1);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const size_t e = (row0 + h) * P.nK + key;
+      o.s[h] = P.scores[e];
+      o.d[h] = P.dprob[e];
+    }
+    const float* xp = P.xyz + ((size_t)b * P.nK + key) * 3;
+    o.kx = xp[0]; o.ky = xp[1]; o.kz = xp[2];
+    o.masked = P.mask_kind == VDETR_MASK_BOOL
+                   ? reinterpret_cast<const unsigned char*>(P.mask)[((size_t)b * P.nQ + q) * P.nK + key] : 0;
+  };
+
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int b = item / P.nQ, q = item - b * P.nQ;
     const size_t row0 = ((size_t)b * P.nQ + q) * 4;
@@ -279,40 +304,50 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
     const float vx = vp[0], vy = vp[1], vz = vp[2];
     const float rc = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2] : 1.f;
     const float rs = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1] : 0.f;
+    ChunkOps ops, nxt;
+    fetch(b, row0, q, 0, ops);
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
+      if (chunk + 1 < nchunks) fetch(b, row0, q, chunk + 1, nxt);
+      // ---- element-wise softmax backward of this lane's pair (recomputed by every wave; wave 0 stores) ----------
       const int key = chunk * kWave + lane;
       const bool valid = key < P.nK;
-      const int keyc = valid ? key : P.nK - 1;
-      float ds[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid) {
+      float ds[4];
+      {
         uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
         if (P.drop_thresh) rnd = attn_rand4(P, b, q, key, 0);
-        const bool masked = P.mask_kind == VDETR_MASK_BOOL &&
-                            reinterpret_cast<const unsigned char*>(P.mask)[((size_t)b * P.nQ + q) * P.nK + key];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const size_t e = (row0 + h) * P.nK + key;
           const bool keep = pick4(rnd, h) >= P.drop_thresh;
-          const ScoreGrad g = score_grad(P.scores[e], lse[h], keep, P.drop_scale, true, P.dprob[e], delta[h], masked);
-          if (w == 0) {
+          const ScoreGrad g = score_grad(ops.s[h], lse[h], keep, P.drop_scale, true, ops.d[h], delta[h], ops.masked != 0);
+          if (w == 0 && valid) {
+            const size_t e = (row0 + h) * P.nK + key;
             P.probs_out[e] = g.p_drop;
             P.ds_out[e] = g.ds;
           }
-          ds[h] = g.ds;
+          ds[h] = valid ? g.ds : 0.f;
         }
       }
-      const float* xp = P.xyz + ((size_t)b * P.nK + keyc) * 3;
-      float dx = vx - xp[0], dy = vy - xp[1], dz = vz - xp[2];
+      // ---- lookup geometry of (pair, vertex w) ---------------------------------------------------------------------
+      float dx = vx - ops.kx, dy = vy - ops.ky, dz = vz - ops.kz;
       if (rot) rpe_rotate(dx, dy, rc, rs);
       const AxisTap ax = rpe_axis(dx, P), ay = rpe_axis(dy, P), az = rpe_axis(dz, P);
       const int cell = rpe_cell(ax, ay, az, T);
       const float w00 = az.wa * ay.wa, w01 = az.wa * ay.wb, w10 = az.wb * ay.wa, w11 = az.wb * ay.wb;
       const float wgt[8] = {w00 * ax.wa, w00 * ax.wb, w01 * ax.wa, w01 * ax.wb,
                             w10 * ax.wa, w10 * ax.wb, w11 * ax.wa, w11 * ax.wb};
-      // cells of all 64 pairs, laid out so that k-slot kk reads pairs kk, 4+kk, 8+kk, ... as 4 x 16 bytes
+      // ---- groups = distinct cells among the 64 pairs, without a serial loop: every lane posts its id on a
+      // scoreboard slot indexed by its cell; whoever is read back is the group's leader, and a group's index is the
+      // rank of its leader among the leaders.
       __builtin_amdgcn_wave_barrier();
-      cellbuf[(lane & 3) * 16 + (lane >> 2)] = cell;
+      scoreboard[cell] = lane;
+      __builtin_amdgcn_wave_barrier();
+      const int leader = scoreboard[cell];
+      const unsigned long long lmask = __ballot(leader == lane);
+      const int ngroups = __popcll(lmask);
+      const int gidx = __popcll(lmask & ((1ull << leader) - 1ull));
+      // group index of all 64 pairs, laid out so that k-slot kk reads pairs kk, 4+kk, 8+kk, ... as 4 x 16 bytes
+      cellbuf[(lane & 3) * 16 + (lane >> 2)] = gidx;
       __builtin_amdgcn_wave_barrier();
       int cr[16];
 #pragma unroll
@@ -320,52 +355,55 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
         const int4 v4 = *reinterpret_cast<const int4*>(cellbuf + kk * 16 + t4 * 4);
         cr[t4 * 4] = v4.x; cr[t4 * 4 + 1] = v4.y; cr[t4 * 4 + 2] = v4.z; cr[t4 * 4 + 3] = v4.w;
       }
-      unsigned long long todo = ~0ull;
-      while (todo) {
-        // up to 16 distinct cells per round: lane g keeps the cell of group g
-        int mygcell = -1, ng = 0;
-        while (todo && ng < 16) {
-          const int leader = __ffsll((long long)todo) - 1;
-          const int c0 = __builtin_amdgcn_readlane(cell, leader);
-          todo &= ~__ballot(cell == c0);
-          if (lane == ng) mygcell = c0;
-          ++ng;
-        }
-        const int rowcell = __shfl(mygcell, c15);
+      __builtin_amdgcn_wave_barrier();
+      if (leader == lane) cellbuf[gidx] = cell;  // the strip now holds cell-of-group
+      __builtin_amdgcn_wave_barrier();
+
+      for (int g0 = 0; g0 < ngroups; g0 += 16) {  // 16 groups per round (one round in 95 % of the chunks)
         float am[16];
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) am[s2] = cr[s2] == rowcell ? 1.f : 0.f;
+        for (int s2 = 0; s2 < 16; ++s2) am[s2] = cr[s2] == g0 + c15 ? 1.f : 0.f;
         int gc[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gc[r] = __shfl(mygcell, 4 * kk + r);
+        for (int r = 0; r < 4; ++r) {
+          const int g = g0 + 4 * kk + r;
+          gc[r] = g < ngroups ? cellbuf[g] : -1;
+        }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const float wc = wgt[jt * 4 + cc];
-            *reinterpret_cast<f32x4*>(vbuf + lane * 16 + ((cc + wr_sw) & 3) * 4) =
-                f32x4{wc * ds[0], wc * ds[1], wc * ds[2], wc * ds[3]};
+            *reinterpret_cast<int4*>(vbuf + lane * 16 + ((cc + wr_sw) & 3) * 4) =
+                make_int4(__float_as_int(wc * ds[0]), __float_as_int(wc * ds[1]), __float_as_int(wc * ds[2]),
+                          __float_as_int(wc * ds[3]));
           }
           __builtin_amdgcn_wave_barrier();
-          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: MFMA issue-, not latency-bound
+          float bv[16];
 #pragma unroll
-          for (int s2 = 0; s2 < 16; s2 += 2) {
-            const int p0 = 4 * s2 + kk, p1 = p0 + 4;
-            const float b0 = vbuf[p0 * 16 + (((c15 >> 2) + (p0 >> 1)) & 3) * 4 + (c15 & 3)];
-            const float b1 = vbuf[p1 * 16 + (((c15 >> 2) + (p1 >> 1)) & 3) * 4 + (c15 & 3)];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s2], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s2 + 1], b1, acc1, 0, 0, 0);
+          for (int s2 = 0; s2 < 16; ++s2) {
+            const int p = 4 * s2 + kk;
+            bv[s2] = __int_as_float(vbuf[p * 16 + (((c15 >> 2) + (p >> 1)) & 3) * 4 + (c15 & 3)]);
           }
-          __builtin_amdgcn_wave_barrier();
-          // this wave is the only writer of table w; (group, value) pairs of one update are distinct bins
+          f32x4 acc[4];  // four independent chains: the MFMAs are issue-, not latency-bound
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch) acc[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2)
+            acc[s2 & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s2], bv[s2], acc[s2 & 3], 0, 0, 0);
+          // wave w is the only writer of table w in this workgroup; the (group, value) bins of one update are distinct
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (gc[r] >= 0) {
               float* bin = mytab + (size_t)gc[r] * 4 + off[jt];
-              *bin += acc0[r] + acc1[r];
+              const float tot = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+              if (ATOMIC) atomicAdd(bin, tot);
+              else *bin += tot;
             }
         }
       }
+      ops = nxt;
     }
   }
   __syncthreads();
@@ -459,10 +497,15 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     lds = (size_t)table_floats * sizeof(float);
   }
   const int variant = bwd_variant();
-  if (dtable && variant != 0 && variant != 1) {
+  if (dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16) {
     lds += (size_t)kMmWaves * kMmStripFloats * sizeof(float);
-    if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel, lds, "attn_bwd_scores")) return e;
-    hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel, dim3(grid), dim3(kMmThreads), lds, st, P);
+    if (variant == 5) {  // plain (non-atomic) LDS updates: faster but NOT parity-green, see the kernel header
+      if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<false>, lds, "attn_bwd_scores")) return e;
+      hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel<false>, dim3(grid), dim3(kMmThreads), lds, st, P);
+    } else {
+      if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<true>, lds, "attn_bwd_scores")) return e;
+      hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel<true>, dim3(grid), dim3(kMmThreads), lds, st, P);
+    }
   } else if (variant == 0) {
     if (int e = set_lds(attn_bwd_scores_rpe_kernel<0>, lds, "attn_bwd_scores")) return e;
     hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<0>), dim3(grid), dim3(kBwdThreads), lds, st, P);
