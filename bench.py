@@ -250,7 +250,9 @@ def cpu_baseline(cfg_name):
     # the bias through eight F.grid_sample passes, i.e. the ops the reference itself runs on CPU
     fused_attention_reference = partial(_ref, rpe_impl="grid_sample")
     npts, bs, npre, nq, nl, angle_type, _ = CONFIGS[cfg_name]
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling on these small tensors well before a 256-thread host is full (measured on
+    # the GPU box's 2 x EPYC 9575F: 1 RPE layer fwd+bwd 4.2 s @8, 4.0 s @16/32, 4.5 s @64, 100 s @256 threads)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     xyz, _ = make_scene(npts, 0, "cpu")
     t0 = time.perf_counter()
