@@ -1,0 +1,184 @@
+"""End-to-end and full-size checks of the hot path on the GPU: ModelVDETR (HIP) vs the same model on CPU with the
+native entry points routed to the oracle; size-independent properties at BASELINE's full attention size; the captured
+(hipGraph) step."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from test_oracle_pointnet2 import grid_cloud
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _make_model(nq=64, npre=512, nl=3, angle_type="", seed=0):
+    from oracle.param_fill import fill_module
+    from vdetr_amd.dataset_config import RotatedBoxDatasetConfig, ScannetDatasetConfig
+    from vdetr_amd.model_vdetr import build_vdetr, default_args
+    torch.manual_seed(seed)
+    args = default_args(dec_nlayers=nl, nqueries=nq, preenc_npoints=npre, angle_type=angle_type)
+    ds = RotatedBoxDatasetConfig() if angle_type else ScannetDatasetConfig()
+    model = build_vdetr(args, ds)
+    fill_module(model)
+    with torch.no_grad():
+        for l in model.decoder.layers:
+            for m in l.multihead_attn.cpb_mlps:
+                m[0].weight.mul_(2.0)
+                m[2].weight.mul_(1.5)
+        for h in model.decoder.mlp_heads:
+            for k in ("center_head", "size_head"):
+                h[k].layers[-1].weight.mul_(0.2)
+    return model
+
+
+def _inputs(n_points, seed, device, batch=1):
+    xyzs, feats = [], []
+    for i in range(batch):
+        x = torch.from_numpy(grid_cloud(n_points, seed + i))
+        xyzs.append(x)
+    n = min(x.shape[0] for x in xyzs)
+    g = torch.Generator().manual_seed(seed)
+    xyzs = [x[:n].contiguous().to(device) for x in xyzs]
+    feats = [torch.randn((n, 256), generator=g).to(device).requires_grad_(True) for _ in range(batch)]
+    st = torch.stack(xyzs)
+    return {"backbone_xyz": xyzs, "backbone_features": feats, "point_cloud_dims_min": st.min(1)[0],
+            "point_cloud_dims_max": st.max(1)[0]}
+
+
+def _loss(out):
+    return sum(o["sem_cls_logits"].sum() + o["center_normalized"].sum() + o["size_normalized"].sum()
+               for o in out["aux_outputs"] + [out["outputs"]])
+
+
+@pytest.mark.parametrize("angle_type,batch", [("", 1), ("", 2), ("object_coords", 2)])
+def test_model_forward_backward_vs_cpu_oracle(angle_type, batch, monkeypatch):
+    """BASELINE config 1 shape (4k-point scene, 64 queries, 2 RPE layers): whole post-backbone path, HIP vs the CPU
+    oracle on identical weights and inputs; seed indices bit-exact, boxes / logits within 1e-3 relative."""
+    model = _make_model(angle_type=angle_type).eval()
+    inp_cpu = _inputs(4000, 3, "cpu", batch)
+    ref_model = model
+    # ---- GPU (HIP kernels) first, before anything is patched
+    import copy
+    gpu_model = copy.deepcopy(model).to(DEV)
+    inp_gpu = {k: ([t.detach().to(DEV).requires_grad_(t.requires_grad) for t in v] if isinstance(v, list) else v.to(DEV))
+               for k, v in inp_cpu.items()}
+    out_gpu = gpu_model(inp_gpu)
+    _loss(out_gpu).backward()
+    # ---- CPU with the oracle behind the two native entry points (test fixture only)
+    import vdetr_amd.attention as A
+    import vdetr_amd.pointnet2_utils as PU
+    from conftest import _OracleExt
+    from oracle.attention_oracle import fused_attention_reference
+    monkeypatch.setattr(A, "fused_attention", fused_attention_reference)
+    monkeypatch.setattr(A, "begin_step", lambda device: None)
+    monkeypatch.setattr(A, "current_rng", lambda device: None)
+    monkeypatch.setattr(PU, "_ext", _OracleExt())
+    out_cpu = ref_model(inp_cpu)
+    _loss(out_cpu).backward()
+    assert torch.equal(out_gpu["seed_inds"].cpu(), out_cpu["seed_inds"])          # FPS: bit-exact
+    assert torch.equal(out_gpu["seed_xyz"].cpu(), out_cpu["seed_xyz"])            # gather: bit-exact
+    stages_g = out_gpu["aux_outputs"] + [out_gpu["outputs"]]
+    stages_c = out_cpu["aux_outputs"] + [out_cpu["outputs"]]
+    for s, (a, b) in enumerate(zip(stages_g, stages_c)):
+        for k in ("sem_cls_logits", "center_unnormalized", "size_unnormalized", "box_corners", "angle_continuous"):
+            assert_close(a[k], b[k].detach().numpy(), 1e-3, 2e-4, f"stage {s} {k}")
+    for fg, fc in zip(inp_gpu["backbone_features"], inp_cpu["backbone_features"]):
+        assert_close(fg.grad, fc.grad.numpy(), 5e-3, 2e-4 * float(fc.grad.abs().max()), "d loss / d backbone features")
+
+
+def test_precomputed_fps_indices_equal_inline_sampling():
+    model = _make_model().to(DEV).eval()
+    inp = _inputs(6000, 5, DEV)
+    with torch.no_grad():
+        a = model(inp)
+        inp2 = dict(inp)
+        inp2["fps_inds"] = model.sample_indices(inp)
+        b = model(inp2)
+    assert torch.equal(a["seed_inds"], b["seed_inds"])
+    assert torch.equal(a["outputs"]["sem_cls_logits"], b["outputs"]["sem_cls_logits"])
+
+
+def test_full_size_attention_properties():
+    """nQ=1024, nK=4096 (BASELINE config 2 layer size): properties that do not need a full-size oracle run."""
+    from oracle.attention_oracle import fused_attention_reference
+    from vdetr_amd import attention as A
+    B, nQ, nK, H = 1, 1024, 4096, 4
+    g = torch.Generator().manual_seed(0)
+    xyz = (1 + torch.rand((B, nK, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0])).to(DEV)
+    center = xyz[:, torch.randperm(nK, generator=g)[:nQ].to(DEV)]
+    half = (0.1 + torch.rand((B, nQ, 1, 3), generator=g)).to(DEV)
+    signs = torch.tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]],
+                         dtype=torch.float32, device=DEV)
+    verts = (center[:, :, None, :] + half * signs).contiguous()
+    q = torch.randn((B, nQ, 256), generator=g).to(DEV)
+    k = torch.randn((B, nK, 64), generator=g).to(DEV)
+    v1 = torch.randn((B, nK, 64), generator=g).to(DEV)
+    v2 = torch.randn((B, nK, 64), generator=g).to(DEV)
+    tables = torch.randn((8, 10, 10, 10, 4), generator=g).to(DEV)
+    kw = dict(num_heads=H, scale=0.125, shared_kv=True, table=tables, rpe=A.RPEConfig(), vertices=verts)
+    o1 = A.fused_attention(q, k, v1, xyz=xyz, **kw)
+    o2 = A.fused_attention(q, k, v2, xyz=xyz, **kw)
+    o12 = A.fused_attention(q, k, v1 + 2 * v2, xyz=xyz, **kw)
+    assert_close(o12, (o1 + 2 * o2).cpu().numpy(), 1e-4, 1e-5, "linearity in V")
+    perm = torch.randperm(nK, generator=g).to(DEV)
+    op = A.fused_attention(q, k[:, perm].contiguous(), v1[:, perm].contiguous(), xyz=xyz[:, perm].contiguous(), **kw)
+    assert_close(op, o1.cpu().numpy(), 1e-4, 1e-5, "invariance to key order")
+    ones = A.fused_attention(q, k, torch.ones_like(v1), xyz=xyz, **kw)
+    assert_close(ones, np.ones((B, nQ, 256)), 1e-5, 1e-5, "probabilities sum to one")
+    # a slice of the queries against the oracle at full key count
+    sl = slice(500, 516)
+    ref = fused_attention_reference(q[:, sl].cpu().double(), k.cpu().double(), v1.cpu().double(), num_heads=H, scale=0.125,
+                                    shared_kv=True, table=tables.cpu().double(), rpe=A.RPEConfig(),
+                                    vertices=verts[:, sl].cpu().double(), xyz=xyz.cpu().double())
+    assert_close(o1[:, sl], ref.numpy(), 1e-4, 1e-5, "16 queries x 4096 keys vs oracle")
+    # table gradient: linear in the upstream gradient, and equal to the oracle's on the query slice
+    tb = tables.clone().requires_grad_(True)
+    kw2 = dict(kw, table=tb, vertices=verts[:, sl].contiguous())
+    out = A.fused_attention(q[:, sl].contiguous(), k, v1, xyz=xyz, **kw2)
+    w = torch.randn(out.shape, generator=g).to(DEV)
+    (out * w).sum().backward()
+    tr = tables.cpu().double().requires_grad_(True)
+    ref = fused_attention_reference(q[:, sl].cpu().double(), k.cpu().double(), v1.cpu().double(), num_heads=H, scale=0.125,
+                                    shared_kv=True, table=tr, rpe=A.RPEConfig(), vertices=verts[:, sl].cpu().double(),
+                                    xyz=xyz.cpu().double())
+    (ref * w.cpu().double()).sum().backward()
+    assert_close(tb.grad, tr.grad.numpy(), 1e-3, 1e-4 * float(tr.grad.abs().max()), "table gradient, 4096 keys")
+
+
+def test_captured_step_replays_with_fresh_dropout():
+    """The whole train step as one hipGraph: replays run, stay finite, and draw a new dropout mask each time."""
+    from vdetr_amd import attention as A
+    model = _make_model(nq=64, npre=512, nl=2).to(DEV).train()
+    inp = _inputs(3000, 9, DEV)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, capturable=True, fused=True)
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = _loss(model(inp))
+        loss.backward()
+        opt.step()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    state = A._master[("cuda", torch.cuda.current_device())]
+    losses, offsets = [], []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        losses.append(float(loss))
+        offsets.append(int(state[1]))
+    assert all(np.isfinite(losses))
+    assert offsets[1] == offsets[0] + 1 and offsets[2] == offsets[1] + 1   # device-side RNG offset advances per replay
+    assert len(set(losses)) == 3                                            # different masks / updated weights
