@@ -27,8 +27,64 @@ def time_fps(npts, m, reps=5):
     return {"kernel": "fps", "n": int(x.shape[1]), "m": m, "ms": sum(ts) / len(ts), "us_per_round": sum(ts) / len(ts) * 1e3 / (m - 1)}
 
 
+def _time(fn, reps=10):
+    ts = []
+    for i in range(reps + 2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        if i >= 2:
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+    return sum(ts) / len(ts)
+
+
+def indexing_ops():
+    """Stand-alone pointnet2 ops at the VoteNet-like shapes of SURVEY.md §8a (a11/a12); bytes = the algorithmic
+    formulas of SURVEY.md §8d."""
+    from vdetr_amd import pointnet2_utils as PU
+    dev = "cuda"
+    out = []
+    xyz, _ = bench.make_scene(40000, 0, dev)
+    xyz = xyz[None].contiguous()
+    n = xyz.shape[1]
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn((1, 256, n), generator=g).to(dev)
+    idx = PU.furthest_point_sample(xyz, 4096)
+    t = _time(lambda: PU._ext.gather_points(feats, idx))
+    out.append(("gather_points c=256 n=40k m=4096", t, 2 * 4 * 256 * 4096 + 4 * 4096))
+    go = torch.randn((1, 256, 4096), generator=g).to(dev)
+    t = _time(lambda: PU._ext.gather_points_grad(go, idx, n))
+    out.append(("gather_points_grad (incl. 41 MB zero-fill)", t, 4 * 256 * (n + 4096) + 4 * 256 * n))
+    new_xyz = xyz[:, :2048].contiguous()
+    t = _time(lambda: PU._ext.ball_query(new_xyz, xyz, 0.2, 64))
+    out.append(("ball_query n=40k m=2048 r=0.2 nsample=64 (worst-case scan bytes 12nm)", t, 12.0 * n * 2048))
+    bidx = PU._ext.ball_query(new_xyz, xyz, 0.2, 64)
+    f128 = feats[:, :128].contiguous()
+    t = _time(lambda: PU._ext.group_points(f128, bidx))
+    out.append(("group_points c=128 np=2048 ns=64", t, 2 * 4 * 128 * 2048 * 64 + 4 * 2048 * 64))
+    gg = torch.randn((1, 128, 2048, 64), generator=g).to(dev)
+    t = _time(lambda: PU._ext.group_points_grad(gg, bidx, n))
+    out.append(("group_points_grad", t, 2 * 4 * 128 * 2048 * 64 + 4 * 2048 * 64 + 4 * 128 * n))
+    unk, kn = xyz[:, :2048].contiguous(), xyz[:, 5000:6024].contiguous()
+    t = _time(lambda: PU._ext.three_nn(unk, kn))
+    out.append(("three_nn n=2048 m=1024 (12nm scan bytes)", t, 12.0 * 2048 * 1024))
+    d2, tidx = PU._ext.three_nn(unk, kn)
+    w = torch.rand((1, 2048, 3), generator=g).to(dev)
+    fk = torch.randn((1, 256, 1024), generator=g).to(dev)
+    t = _time(lambda: PU._ext.three_interpolate(fk, tidx, w))
+    out.append(("three_interpolate c=256 n=2048", t, 4 * 256 * 2048 * 4 + 2048 * 24))
+    for name, t, nbytes in out:
+        print(json.dumps({"kernel": name, "us": t * 1e6, "algorithmic_GB_s": nbytes / t / 1e9, "frac_of_8TBs": nbytes / t / 8e12}))
+
+
 if __name__ == "__main__":
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
     f, b = bench.kernel_rooflines(cfg, torch.device("cuda"))
     print(json.dumps({"variant": os.environ.get("VDETR_BWD_VARIANT", "default"), "fwd_us": f["launch_us"], "bwd_us": b["launch_us"]}))
     print(json.dumps(time_fps(bench.CONFIGS[cfg][0], 4096)))
+    if "--indexing" in sys.argv:
+        indexing_ops()
+        print(json.dumps(time_fps(80000, 4096)))
+        print(json.dumps(time_fps(4000, 1024)))

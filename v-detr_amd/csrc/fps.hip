@@ -28,6 +28,8 @@
 #include "common.h"
 #include "wave.h"
 
+#include <stdlib.h>
+
 namespace vdetr {
 
 constexpr int kFpsThreads = 1024;
@@ -71,6 +73,17 @@ __device__ __forceinline__ WaveBest wave_argbest(unsigned rank, unsigned key) {
   return r;
 }
 
+__device__ unsigned long long g_fps_cyc[8];
+__device__ __forceinline__ unsigned long long fps_clock() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t = clock64();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+template <bool DEBUG>
 __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
   __shared__ int s_hist[kCells];
   __shared__ int s_wsum[kFpsWaves];
@@ -208,6 +221,8 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
   float cx = p0x, cy = p0y, cz = p0z;  // the reference starts from index 0 unconditionally (:89-90)
   if (tid == 0) out[0] = 0;
   for (int j = 1; j < P.m; ++j) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (DEBUG) t0 = fps_clock();
 #pragma unroll
     for (int s = 0; s < kFpsSlots; ++s) {
       // distance of p to the bucket box, same arithmetic as a point distance
@@ -277,6 +292,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
           }
       }
     }
+    if (DEBUG) t1 = fps_clock();
     // arg-max over this wave's buckets, then over the 16 waves through LDS (double-buffered: 1 barrier)
     unsigned mrank = 0u, mkey = 0xFFFFFFFFu;
     float mx = 0.f, my = 0.f, mz = 0.f;
@@ -295,7 +311,9 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
     // LDS-only barrier.  __syncthreads() would also drain vmcnt, i.e. make every wave wait for the L2
     // acknowledgement of the running-distance stores it issued this round — stores that only the SAME lane
     // reads back in a later round, so nobody needs them visible here.  That wait was most of the round time.
+    if (DEBUG) t2 = fps_clock();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (DEBUG) t3 = fps_clock();
     const int sl = lane & (kFpsWaves - 1);  // every 16-lane row reads all 16 slots
     const unsigned srank = s_rank[par][sl], skey = s_key[par][sl];
     const unsigned grank = row_allmax_u32(srank);
@@ -309,6 +327,13 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
       cx = p0x; cy = p0y; cz = p0z;
     }
     if (tid == 0) out[j] = winner;
+    if (DEBUG && lane == 0) {
+      const unsigned long long t4 = fps_clock();
+      if (w == 0 || w == 7) {
+        unsigned long long* c = g_fps_cyc + (w ? 4 : 0);
+        c[0] += t1 - t0; c[1] += t2 - t1; c[2] += t3 - t2; c[3] += t4 - t3;
+      }
+    }
   }
 }
 
@@ -356,6 +381,18 @@ extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n,
   while ((2L << lg) <= (long)n) ++lg;
   if (lg > 9) lg = 9;
   P.ref_log2 = lg; P.ref_block = 1 << lg;
-  hipLaunchKernelGGL(fps_kernel, dim3(b), dim3(kFpsThreads), 0, (hipStream_t)stream, P);
+  static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
+  if (debug) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_fps_cyc), z, sizeof(z));
+    hipLaunchKernelGGL(fps_kernel<true>, dim3(b), dim3(kFpsThreads), 0, (hipStream_t)stream, P);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fps_cyc), sizeof(z));
+    for (int i = 0; i < 2; ++i)
+      fprintf(stderr, "[fps debug] wave %d cycles/round: buckets %llu, wave-argmax+lds %llu, barrier wait %llu, decode %llu\n",
+              i ? 7 : 0, z[i * 4] / (m - 1), z[i * 4 + 1] / (m - 1), z[i * 4 + 2] / (m - 1), z[i * 4 + 3] / (m - 1));
+    return check_launch("furthest_point_sampling");
+  }
+  hipLaunchKernelGGL(fps_kernel<false>, dim3(b), dim3(kFpsThreads), 0, (hipStream_t)stream, P);
   return check_launch("furthest_point_sampling");
 }

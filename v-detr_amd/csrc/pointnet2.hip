@@ -8,6 +8,7 @@
 // index / weight rows are read once per thread and reused across a channel strip, and the scans
 // (ball query, three_nn) are wave-cooperative.  All of them are HBM/L2-bound integer/byte work.
 #include "common.h"
+#include "wave.h"
 
 namespace vdetr {
 
@@ -71,19 +72,34 @@ __global__ __launch_bounds__(kThreads) void group_points_kernel(const float* __r
 }
 
 // group_points_grad: grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k] (group_points_gpu.cu:46-67)
+// Duplicates are the norm here (ball_query pads a row with its first hit), and equal addresses inside one atomic
+// instruction serialise.  One thread walks the nsample entries of a (channel, point) row and only issues an atomic
+// when the index changes: a padded row costs 2 atomics instead of nsample.  Lanes run along the points j.
 __global__ __launch_bounds__(kThreads) void group_points_grad_kernel(
     const float* __restrict__ grad_out, const int32_t* __restrict__ idx, float* __restrict__ grad_points,
-    int c, int n, long ne) {
-  const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+    int c, int n, int npoints, int nsample) {
+  const int j = blockIdx.x * kThreads + threadIdx.x;
   const int bi = blockIdx.z;
-  if (e >= ne) return;
-  const int a = idx[(size_t)bi * ne + e];
+  if (j >= npoints) return;
+  const int32_t* row = idx + ((size_t)bi * npoints + j) * nsample;
   const int l0 = blockIdx.y * kChanStrip;
-#pragma unroll
   for (int dl = 0; dl < kChanStrip; ++dl) {
     const int l = l0 + dl;
-    if (l < c)
-      unsafeAtomicAdd(grad_points + ((size_t)bi * c + l) * n + a, grad_out[((size_t)bi * c + l) * ne + e]);
+    if (l >= c) break;
+    const float* g = grad_out + (((size_t)bi * c + l) * npoints + j) * nsample;
+    float* gp = grad_points + ((size_t)bi * c + l) * n;
+    int cur = row[0];
+    float acc = 0.f;
+    for (int k = 0; k < nsample; ++k) {
+      const int a = row[k];
+      if (a != cur) {
+        unsafeAtomicAdd(gp + cur, acc);
+        acc = 0.f;
+        cur = a;
+      }
+      acc += g[k];
+    }
+    unsafeAtomicAdd(gp + cur, acc);
   }
 }
 
@@ -140,52 +156,55 @@ __global__ __launch_bounds__(kThreads) void three_interpolate_grad_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // three_nn: 3 nearest `known` points of every `unknown` point         (interpolate_gpu.cu:12-62)
-// One thread per unknown point keeps the reference's sequential insertion order (strict '<', so the
-// earliest index wins ties); the known cloud is streamed through LDS in 1024-point tiles that every
-// lane reads at the same address (LDS broadcast, conflict-free).
-// The reference's `double bestN = 1e40` only ever holds float values or the sentinel, and is stored
-// to float (-> +inf); float +inf reproduces every comparison and the stored value.
+// The reference's sequential insertion with strict '<' returns the three smallest entries under the order
+// (distance, index) — the earlier index wins ties — so the scan can be split: one WAVE per unknown point, lane l scans
+// known points l, l+64, ... keeping its own top-3, then three rounds of "wave arg-min, winner pops its head" merge the
+// 64 lists.  64x the parallelism of the reference's one-thread-per-point scan at identical results.
+// `double bestN = 1e40` sentinels (-> +inf when stored to float, index 0) are float +inf here: a real distance of
+// +inf or NaN is never inserted by the reference ('<' against 1e40 / NaN is false) and is skipped here too.
 // ---------------------------------------------------------------------------------------------
-constexpr int kNNTile = 1024;
 __global__ __launch_bounds__(kThreads) void three_nn_kernel(const float* __restrict__ unknown,
                                                             const float* __restrict__ known,
                                                             float* __restrict__ dist2,
                                                             int32_t* __restrict__ idx, int n, int m) {
-  __shared__ float tile[kNNTile * 3];
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
   const int bi = blockIdx.z;
-  const int j = blockIdx.x * kThreads + threadIdx.x;
-  const bool live = j < n;
-  float ux = 0.f, uy = 0.f, uz = 0.f;
-  if (live) {
-    const float* u = unknown + ((size_t)bi * n + j) * 3;
-    ux = u[0]; uy = u[1]; uz = u[2];
-  }
-  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-  int i1 = 0, i2 = 0, i3 = 0;
+  if (j >= n) return;  // wave-uniform
+  const float* u = unknown + ((size_t)bi * n + j) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
   const float* kb = known + (size_t)bi * m * 3;
-  for (int k0 = 0; k0 < m; k0 += kNNTile) {
-    const int cnt = min(kNNTile, m - k0);
-    __syncthreads();
-    for (int t = threadIdx.x; t < cnt * 3; t += kThreads) tile[t] = kb[(size_t)k0 * 3 + t];
-    __syncthreads();
-    if (live) {
-      for (int t = 0; t < cnt; ++t) {
-        const float d = sqdist3(ux - tile[t * 3], uy - tile[t * 3 + 1], uz - tile[t * 3 + 2]);
-        const int k = k0 + t;
-        if (d < b1) {
-          b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
-        } else if (d < b2) {
-          b3 = b2; i3 = i2; b2 = d; i2 = k;
-        } else if (d < b3) {
-          b3 = d; i3 = k;
-        }
-      }
+  float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+  int i1 = 0x7FFFFFFF, i2 = 0x7FFFFFFF, i3 = 0x7FFFFFFF;
+  for (int k = lane; k < m; k += kWave) {
+    const float d = sqdist3(ux - kb[k * 3], uy - kb[k * 3 + 1], uz - kb[k * 3 + 2]);
+    if (d < b1) {
+      b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
+    } else if (d < b2) {
+      b3 = b2; i3 = i2; b2 = d; i2 = k;
+    } else if (d < b3) {
+      b3 = d; i3 = k;
     }
   }
-  if (live) {
+  float od[3];
+  int oi[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    // wave arg-min of (b1, i1): distance bits are monotone for d >= 0; +inf heads (empty lists) never win over a finite one
+    const unsigned db = __float_as_uint(b1);
+    const unsigned dmin = ~wave_allmax_u32(~db);
+    const unsigned imin = ~wave_allmax_u32(db == dmin ? ~(unsigned)i1 : 0u);
+    const bool none = dmin >= 0x7F800000u;  // every list is exhausted (m < 3)
+    od[t] = none ? INFINITY : __uint_as_float(dmin);
+    oi[t] = none ? 0 : (int)imin;
+    if (!none && db == dmin && (unsigned)i1 == imin) {  // the winner pops its head
+      b1 = b2; i1 = i2; b2 = b3; i2 = i3; b3 = INFINITY; i3 = 0x7FFFFFFF;
+    }
+  }
+  if (lane == 0) {
     const size_t r = ((size_t)bi * n + j) * 3;
-    dist2[r] = b1; dist2[r + 1] = b2; dist2[r + 2] = b3;
-    idx[r] = i1; idx[r + 1] = i2; idx[r + 2] = i3;
+    dist2[r] = od[0]; dist2[r + 1] = od[1]; dist2[r + 2] = od[2];
+    idx[r] = oi[0]; idx[r + 1] = oi[1]; idx[r + 2] = oi[2];
   }
 }
 
@@ -280,9 +299,9 @@ extern "C" int vdetr_group_points_grad_f32(const float* grad_out, const int32_t*
   const long ne = (long)npoints * nsample;
   if (b == 0 || c == 0 || ne == 0) return VDETR_OK;
   VDETR_REQUIRE(grad_out && idx && grad_points, "group_points_grad: null pointer");
-  dim3 grid(ceil_div(ne, kThreads), ceil_div(c, kChanStrip), b);
+  dim3 grid(ceil_div(npoints, kThreads), ceil_div(c, kChanStrip), b);
   hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out, idx,
-                     grad_points, c, n, ne);
+                     grad_points, c, n, npoints, nsample);
   return check_launch("group_points_grad");
 }
 
@@ -291,7 +310,7 @@ extern "C" int vdetr_three_nn_f32(const float* unknown, const float* known, floa
   if (int e = check_bcnm("three_nn", b, 0, n, m)) return e;
   if (b == 0 || n == 0) return VDETR_OK;
   VDETR_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
-  dim3 grid(ceil_div(n, kThreads), 1, b);
+  dim3 grid(ceil_div(n, kThreads / kWave), 1, b);
   hipLaunchKernelGGL(three_nn_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, unknown, known, dist2,
                      idx, n, m);
   return check_launch("three_nn");
