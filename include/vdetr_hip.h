@@ -164,6 +164,10 @@ int vdetr_attn_dropout_mask_u8(const vdetr_attn_desc* d, uint8_t* keep, vdetr_st
  * vdetr_transformer.py:710-731. */
 int vdetr_rpe_bias_f32(const vdetr_attn_desc* d, float* rpe, vdetr_stream_t stream);
 
+/* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
+ * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
+int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);
+
 /* MFMA layout self-test: C[16,16] = A[16,64] * B[16,64]^T through v_mfma_f32_16x16x4_f32. */
 int vdetr_selftest_mfma_f32(const float* a, const float* b, float* c, vdetr_stream_t stream);
 

@@ -79,11 +79,23 @@ def indexing_ops():
         print(json.dumps({"kernel": name, "us": t * 1e6, "algorithmic_GB_s": nbytes / t / 1e9, "frac_of_8TBs": nbytes / t / 8e12}))
 
 
+def lds_probe():
+    from vdetr_amd import _lib as L
+    sink = torch.zeros(4, device="cuda")
+    iters = 2000
+    for mode, name in [(0, "ds_add_f32 scattered"), (1, "ds_add_u32 scattered"), (2, "plain read-add-write"), (3, "ds_add_f32, 8 hot bins")]:
+        t = _time(lambda: L.check(L.lib().vdetr_selftest_lds_atomics(mode, iters, L.ptr(sink), L.stream_ptr()), "probe"), reps=5)
+        lane_ops = 256 * 512 * iters
+        print(json.dumps({"lds_probe": name, "us": t * 1e6, "lane_ops_per_clk_per_CU": lane_ops / 256 / (t * 2.1e9)}))
+
+
 if __name__ == "__main__":
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
     f, b = bench.kernel_rooflines(cfg, torch.device("cuda"))
     print(json.dumps({"variant": os.environ.get("VDETR_BWD_VARIANT", "default"), "fwd_us": f["launch_us"], "bwd_us": b["launch_us"]}))
     print(json.dumps(time_fps(bench.CONFIGS[cfg][0], 4096)))
+    if "--lds" in sys.argv:
+        lds_probe()
     if "--indexing" in sys.argv:
         indexing_ops()
         print(json.dumps(time_fps(80000, 4096)))

@@ -228,9 +228,8 @@ __global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnPa
 // plain per-lane atomics 6.5 ms, wave-aggregated (variant 1) 1.29 ms — no matter how cheap the aggregation itself is.
 // This variant therefore removes the atomics altogether:
 //   * wave w of the workgroup owns VERTEX w: it is the only writer of table i = w in the workgroup's LDS histogram,
-//     and the lanes of one update hit distinct bins by construction, so the ds_add_f32 it issues never serialise on
-//     an address (template ATOMIC=false swaps them for plain read/add/write: 0.80 vs 1.17 ms, but it did NOT
-//     reproduce the atomic result on hardware although a census found no colliding bins — kept off until understood);
+//     (plain read/add/write instead of atomics is NOT possible: neighbouring cells' 8-corner footprints overlap, so two
+//     groups of one update can hit the same bin);
 //   * the wave-level aggregation is a small matrix product on the matrix cores,
 //         G[group][value] = sum over the 64 lanes  M[group][lane] * V[lane][value]
 //     with M the 0/1 membership of a lane (pair) in a group (= distinct lookup cell among the wave's 64 pairs, <= 16
@@ -247,10 +246,42 @@ constexpr int kMmWaves = kMmThreads / kWave;
 constexpr int kMmStripFloats = kWave + kWave * 16;  // cell ids + 64 x 16 values
 static_assert(kMmWaves == kRpeVerts, "one wave per vertex table");
 
-template <bool ATOMIC>
+// |dP~| maximum of the launch (bit pattern of a non-negative float, atomicMax on unsigned)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const size_t n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(x[i]));
+  m = wave_allmax_f32(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// FIXED: the LDS histogram is int32 fixed point.  Measured on MI355X (tools/kernel_bench.py --lds): ds_add_f32 runs
+// at 0.37 lane-updates/clk/CU regardless of address conflicts, ds_add_u32 at 2.3 — the float atomics alone were
+// ~0.5 ms of this kernel.  The scale is exact-safe: per bin, sum |contribution| <= sum over the workgroup's queries of
+// sum_k P(q,k) * |dP - delta| <= queries_per_wg * 2 * drop_scale * max|dP~|  (weights <= 1, softmax rows sum to 1),
+// so with S = 2^floor(log2(2^30 / bound)) no partial sum can overflow, and the resolution (bound * 2^-30) is ~1e-5
+// of a typical group sum.  Integer adds also make the histogram independent of the order of the updates.
+template <bool FIXED>
 __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy 8*T^3*4][8 strips]
   attn_load_rng(P);
+  float fix_scale = 1.f, fix_inv = 1.f;
+  if (FIXED) {
+    const float dmax = __uint_as_float(*P.absmax);
+    const int per_wg = (P.B * P.nQ + (int)gridDim.x - 1) / (int)gridDim.x;
+    const float bound = 2.f * P.drop_scale * dmax * (float)per_wg;
+    if (bound > 0.f && bound < INFINITY) {
+      const int e = 30 - (int)ceilf(__log2f(bound) + 1e-3f);  // 2^e * bound <= 2^30
+      fix_scale = ldexpf(1.f, e);
+      fix_inv = ldexpf(1.f, -e);
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // = vertex index
   const int T = P.T, TT = T * T, T3 = TT * T;
@@ -398,8 +429,8 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
             if (gc[r] >= 0) {
               float* bin = mytab + (size_t)gc[r] * 4 + off[jt];
               const float tot = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-              if (ATOMIC) atomicAdd(bin, tot);
-              else *bin += tot;
+              if (FIXED) atomicAdd(reinterpret_cast<int*>(bin), __float2int_rn(tot * fix_scale));
+              else atomicAdd(bin, tot);
             }
         }
       }
@@ -408,7 +439,8 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
   }
   __syncthreads();
   float* dst = P.dtable_part + (size_t)blockIdx.x * table_floats;
-  for (int i = tid; i < table_floats; i += kMmThreads) dst[i] = smem[i];
+  for (int i = tid; i < table_floats; i += kMmThreads)
+    dst[i] = FIXED ? (float)reinterpret_cast<const int*>(smem)[i] * fix_inv : smem[i];
 }
 
 // dtable[e] += sum over workgroup copies; blockIdx.y takes a slice of the copies so that the 32 MB of partials are
@@ -421,6 +453,26 @@ __global__ __launch_bounds__(256) void attn_bwd_table_reduce_kernel(const float*
   float s = 0.f;
   for (int p = p0; p < p1; ++p) s += part[(size_t)p * n + e];
   unsafeAtomicAdd(dtable + e, s);
+}
+
+// LDS atomic-rate probe (tools/kernel_bench.py --lds): mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write,
+// 3 ds_add_f32 with all lanes on 8 addresses; 512-thread workgroups, `iters` updates per lane to scattered bins
+__global__ __launch_bounds__(512) void lds_atomic_probe_kernel(int mode, int iters, float* sink) {
+  __shared__ float tab[32768];
+  for (int i = threadIdx.x; i < 32768; i += 512) tab[i] = 0.f;
+  __syncthreads();
+  unsigned a = threadIdx.x * 2654435761u;
+  float acc = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    a = a * 1664525u + 1013904223u;
+    const unsigned slot = mode == 3 ? ((a >> 10) & 7u) * 4u : ((a >> 10) & 8191u) * 4u + (threadIdx.x & 3);
+    if (mode == 0 || mode == 3) atomicAdd(&tab[slot], 1.0f);
+    else if (mode == 1) atomicAdd(reinterpret_cast<unsigned*>(&tab[slot]), 1u);
+    else tab[slot] += 1.0f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32768; i += 512) acc += tab[i];
+  if (acc == -1.f) sink[0] = acc;
 }
 
 // keep-mask dump (test hook)
@@ -458,7 +510,7 @@ static int bwd_grid(const vdetr_attn_desc* d) {
 extern "C" size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d || !d->table) return 0;
   const size_t table_floats = (size_t)kRpeVerts * d->table_size * d->table_size * d->table_size * 4;
-  return (size_t)bwd_grid(d) * table_floats * sizeof(float) + 256;
+  return (size_t)bwd_grid(d) * table_floats * sizeof(float) + 512;  // partial tables + |dP~| max scalar + alignment
 }
 
 extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, const float* dprob,
@@ -499,10 +551,19 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
   const int variant = bwd_variant();
   if (dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16) {
     lds += (size_t)kMmWaves * kMmStripFloats * sizeof(float);
-    if (variant == 5) {  // plain (non-atomic) LDS updates: faster but NOT parity-green, see the kernel header
+    if (variant == 5) {  // float LDS atomics (A/B reference for the fixed-point histogram)
       if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<false>, lds, "attn_bwd_scores")) return e;
       hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel<false>, dim3(grid), dim3(kMmThreads), lds, st, P);
     } else {
+      // max |dP~| of the launch -> scale of the fixed-point histogram (scalar lives at the end of the workspace)
+      unsigned* absmax = reinterpret_cast<unsigned*>(P.dtable_part + (size_t)grid * table_floats);
+      P.absmax = absmax;
+      if (hipMemsetAsync(absmax, 0, sizeof(unsigned), st) != hipSuccess) {
+        set_error("attn_bwd_scores: memset failed");
+        return VDETR_ERR_LAUNCH;
+      }
+      const size_t total = (size_t)d->B * d->H * d->nQ * d->nK;
+      hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, dprob, total, absmax);
       if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<true>, lds, "attn_bwd_scores")) return e;
       hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel<true>, dim3(grid), dim3(kMmThreads), lds, st, P);
     }
@@ -520,6 +581,11 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     return check_launch("attn_bwd_table_reduce");
   }
   return VDETR_OK;
+}
+
+extern "C" int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream) {
+  hipLaunchKernelGGL(lds_atomic_probe_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, mode, iters, sink);
+  return check_launch("lds_atomic_probe");
 }
 
 extern "C" int vdetr_attn_dropout_mask_u8(const vdetr_attn_desc* d, uint8_t* keep, vdetr_stream_t stream) {

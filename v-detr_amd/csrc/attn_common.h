@@ -47,6 +47,7 @@ struct AttnParams {
   const float* delta;
   float* probs_out;
   float* ds_out;
+  const unsigned* absmax;  // bits of max |dprob| (fixed-point histogram scale)
   float* dtable_part;  // [gridDim.x][8*T^3*H]
 };
 
