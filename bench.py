@@ -305,13 +305,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
+                    "the N>1 code path with several ranks on one GPU)")
     a = ap.parse_args()
 
     from vdetr_amd.dist import broadcast_parameters, init_distributed
-    rank, local, world = init_distributed("nccl")
-    assert world == a.gpus or (world == 1 and a.gpus == 1), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    if a.backend != "nccl":
+        os.environ["LOCAL_RANK"] = str(local)
+    rank, local, world = init_distributed(a.backend)
+    assert world == a.gpus or (world == 1 and a.gpus == 1), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local)
 
     model = build_model(a.config, device)

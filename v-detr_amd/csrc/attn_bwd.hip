@@ -248,16 +248,19 @@ static_assert(kMmWaves == kRpeVerts, "one wave per vertex table");
 
 // |dP~| maximum of the launch (bit pattern of a non-negative float, atomicMax on unsigned)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
-  float m = 0.f;
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
   const size_t n4 = n >> 2;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const f32x4 v = x4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  auto amax4 = [](const f32x4& v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); };
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-B loads in flight per lane
+    const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    m0 = fmaxf(m0, amax4(a)); m1 = fmaxf(m1, amax4(b)); m2 = fmaxf(m2, amax4(c)); m3 = fmaxf(m3, amax4(d));
   }
-  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    m = fmaxf(m, fabsf(x[i]));
-  m = wave_allmax_f32(m);
+  for (; i < n4; i += stride) m0 = fmaxf(m0, amax4(x4[i]));
+  for (size_t t = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride) m0 = fmaxf(m0, fabsf(x[t]));
+  const float m = wave_allmax_f32(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
@@ -563,7 +566,7 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
         return VDETR_ERR_LAUNCH;
       }
       const size_t total = (size_t)d->B * d->H * d->nQ * d->nK;
-      hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, dprob, total, absmax);
+      hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, dprob, total, absmax);
       if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<true>, lds, "attn_bwd_scores")) return e;
       hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel<true>, dim3(grid), dim3(kMmThreads), lds, st, P);
     }

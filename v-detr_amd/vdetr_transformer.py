@@ -257,13 +257,11 @@ class MultiheadSelfAttention(nn.Module):
     def forward(self, query, key, value=None, attn_mask=None, key_padding_mask=None, need_weights=False):
         E = self.embed_dim
         value = key if value is None else value
-        w, b = self.in_proj_weight, self.in_proj_bias
-        if query is key:
-            qk = F.linear(query, w[: 2 * E], b[: 2 * E])  # one GEMM for q and k (they share the input)
-            q, k = qk[..., :E], qk[..., E:]
-        else:
-            q, k = F.linear(query, w[:E], b[:E]), F.linear(key, w[E: 2 * E], b[E: 2 * E])
-        v = F.linear(value, w[2 * E:], b[2 * E:])
+        # three projections from the packed weight.  unbind (backward = one stack) instead of slicing the parameter
+        # or a joint q/k output (each slice's backward is a zero-filled full-size buffer + copy)
+        wq, wk, wv = self.in_proj_weight.view(3, E, E).unbind(0)
+        bq, bk, bv = self.in_proj_bias.view(3, E).unbind(0)
+        q, k, v = F.linear(query, wq, bq), F.linear(key, wk, bk), F.linear(value, wv, bv)
         L_, B = query.shape[0], query.shape[1]
         S = key.shape[0]
         mask = None
