@@ -89,7 +89,22 @@ def lds_probe():
         print(json.dumps({"lds_probe": name, "us": t * 1e6, "lane_ops_per_clk_per_CU": lane_ops / 256 / (t * 2.1e9)}))
 
 
+def issue_probe():
+    """Can a SIMD overlap MFMA with VALU / LDS issue?  (cycles per round per wave at an assumed 2.4 GHz)"""
+    from vdetr_amd import _lib as L
+    sink = torch.zeros(4, device="cuda")
+    iters = 4000
+    for mode, name in [(10, "16 mfma_f32_16x16x4"), (11, "128 v_fma_f32"), (12, "both, same wave"),
+                       (13, "waves 0-3 mfma / waves 4-7 valu"), (14, "128 v_fma_f32 + 16 ds_read_b128"), (15, "16 mfma_f32_16x16x32_bf16"),
+                       (16, "waves 0-3 bf16 mfma / waves 4-7 valu"), (17, "bf16 mfma + valu, same wave")]:
+        t = _time(lambda: L.check(L.lib().vdetr_selftest_lds_atomics(mode, iters, L.ptr(sink), L.stream_ptr()), "probe"), reps=5)
+        print(json.dumps({"issue_probe": name, "us": t * 1e6, "cycles_per_round_at_2.4GHz": t * 2.4e9 / iters}))
+
+
 if __name__ == "__main__":
+    if "--issue" in sys.argv:
+        issue_probe()
+        sys.exit(0)
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
     f, b = bench.kernel_rooflines(cfg, torch.device("cuda"))
     print(json.dumps({"variant": os.environ.get("VDETR_BWD_VARIANT", "default"), "fwd_us": f["launch_us"], "bwd_us": b["launch_us"]}))

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel trace of the eager step, the hot kernels' micro-bench, and the HBM-traffic
+# PMC passes.  Raw rocprofv3 output stays in /tmp (too large to copy back); summaries go to gpurun_out/prof_$1/.
+tag=${1:-x}
+out=$PWD/gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline > $out/bench_eager.log 2>&1
+db=$(find /tmp/rp_eager -name '*.db' | head -1); csv=$(find /tmp/rp_eager -name '*kernel_trace.csv' | head -1)
+python3 tools/rocprof_summary.py ${db:-$csv} 5 3 > $out/eager_kernel_summary.txt 2>&1
+python3 tools/kernel_bench.py c2 > $out/kernel_bench_c2.txt 2>&1
+python3 tools/kernel_bench.py c2 --indexing > $out/kernel_bench_indexing.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$c -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_$c.log 2>&1
+  f=$(find /tmp/rp_$c -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python3 - "$f" $c > $out/pmc_$c.txt <<'PY'
+import csv, sys
+from collections import defaultdict
+agg = defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if r["Counter_Name"] == sys.argv[2]:
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+print(f"# {sys.argv[2]} per launch (KB as reported by rocprofv3), mean over launches")
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:25]:
+    print(f"{sum(v)/len(v):14.1f} {len(v):5d}  {k[:200]}")
+PY
+done
+python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
+tail -1 $out/bench_n1.json | cut -c1-400

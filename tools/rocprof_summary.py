@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Summarises a rocprofv3 --kernel-trace run (rocpd .db or *_kernel_trace.csv) into the per-kernel table that is
-committed under profiles/:  python tools/rocprof_summary.py <results.db|kernel_trace.csv> [steps] > profiles/xxx.txt"""
+committed under profiles/:  python tools/rocprof_summary.py <results.db|kernel_trace.csv> [steps [warmup]] > profiles/xxx.txt
+With `warmup`, the first `warmup` of the `steps + warmup` traced steps are dropped (library auto-tuning runs every
+candidate solver once during the first steps); step boundaries are the optimizer's kernels."""
 import csv
 import sqlite3
 import sys
@@ -9,21 +11,30 @@ from collections import defaultdict
 
 def rows_from_db(path):
     cur = sqlite3.connect(path).cursor()
-    return [(n, (e - s) / 1e3) for n, s, e in cur.execute("select name, start, end from kernels")]
+    return [(n, (e - s) / 1e3, s, e) for n, s, e in cur.execute("select name, start, end from kernels")]
 
 
 def rows_from_csv(path):
     out = []
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            out.append((r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            out.append((r["Kernel_Name"], (e - s) / 1e3, s, e))
     return out
 
 
 def main():
     path = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rows = rows_from_db(path) if path.endswith(".db") else rows_from_csv(path)
+    if warmup:
+        marks = sorted(e for n, _, _, e in rows if "FusedOptimizerTensorListMetadata" in n)
+        per_step = len(marks) // (steps + warmup)
+        t0 = marks[warmup * per_step - 1]
+        rows = [r for r in rows if r[2] > t0]
+        print(f"# first {warmup} steps dropped (auto-tuning), {steps} steady-state steps summarised")
+    rows = [(n, d) for n, d, _, _ in rows]
     agg = defaultdict(list)
     for n, d in rows:
         agg[n].append(d)

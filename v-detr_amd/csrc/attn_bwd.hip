@@ -241,43 +241,67 @@ __global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnPa
 //   * every wave recomputes the cheap element-wise softmax backward of the 64 pairs it looks at (8x redundant, ~100
 //     VALU ops against ~600 + 32 MFMA of vertex work); wave 0 writes P~ / dS.  Because the waves of a workgroup
 //     drift apart, P~ / dS go to SEPARATE output tensors (in-place would let a slow wave read overwritten scores).
-constexpr int kMmThreads = 512;
-constexpr int kMmWaves = kMmThreads / kWave;
 constexpr int kMmStripFloats = kWave + kWave * 16;  // cell ids + 64 x 16 values
-static_assert(kMmWaves == kRpeVerts, "one wave per vertex table");
 
-// |dP~| maximum of the launch (bit pattern of a non-negative float, atomicMax on unsigned)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
-  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-  const size_t n4 = n >> 2;
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  auto amax4 = [](const f32x4& v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); };
-  for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-B loads in flight per lane
-    const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
-    m0 = fmaxf(m0, amax4(a)); m1 = fmaxf(m1, amax4(b)); m2 = fmaxf(m2, amax4(c)); m3 = fmaxf(m3, amax4(d));
-  }
-  for (; i < n4; i += stride) m0 = fmaxf(m0, amax4(x4[i]));
-  for (size_t t = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride) m0 = fmaxf(m0, fabsf(x[t]));
-  const float m = wave_allmax_f32(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
-}
-
+// Workgroup shapes (VERTS vertex tables in the LDS histogram, WPV waves per vertex):
+//   <8,1>  512 threads, 128 KB histogram + 8 strips: one wave per vertex, 2 waves per SIMD;
+//   <4,4> 1024 threads,  64 KB histogram + 16 strips: a query is covered by TWO workgroups (vertices 0-3 / 4-7), the four
+//         waves of a vertex take every fourth 64-key chunk and share the table through the (integer) atomics.  Same LDS
+//         budget, twice the waves per SIMD to hide the LDS / MFMA latency chain of a chunk, half the partial-table bytes.
 // FIXED: the LDS histogram is int32 fixed point.  Measured on MI355X (tools/kernel_bench.py --lds): ds_add_f32 runs
 // at 0.37 lane-updates/clk/CU regardless of address conflicts, ds_add_u32 at 2.3 — the float atomics alone were
 // ~0.5 ms of this kernel.  The scale is exact-safe: per bin, sum |contribution| <= sum over the workgroup's queries of
-// sum_k P(q,k) * |dP - delta| <= queries_per_wg * 2 * drop_scale * max|dP~|  (weights <= 1, softmax rows sum to 1),
-// so with S = 2^floor(log2(2^30 / bound)) no partial sum can overflow, and the resolution (bound * 2^-30) is ~1e-5
-// of a typical group sum.  Integer adds also make the histogram independent of the order of the updates.
-template <bool FIXED>
-__global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(AttnParams P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy 8*T^3*4][8 strips]
+// sum_k P(q,k) * |dP - delta| <= queries_per_wg * 2 * drop_scale * max|dP~|  (weights <= 1, softmax rows sum to 1,
+// max taken over the workgroup's own rows in a prologue pass), so with S = 2^floor(log2(2^30 / bound)) no partial sum
+// can overflow, and the resolution (bound * 2^-30) is ~1e-5 of a typical group sum.  Integer adds also make the
+// histogram independent of the order of the updates.
+// SPLIT16: the product runs on the bf16 matrix pipe instead of v_mfma_f32_16x16x4_f32.  Measured on MI355X
+// (tools/kernel_bench.py --issue): an fp32 MFMA occupies its SIMD for 32 cycles and VALU instructions of other waves do
+// NOT issue underneath it, so the 32 fp32 MFMAs of a chunk cost as much as ~290 VALU instructions.  The 0/1 membership
+// is exact in bf16; a value v is sent as hi = v & 0xFFFF0000 and lo = bf16(v - hi) packed in one 32-bit word (relative
+// error <= 2^-16, far inside the 1e-3 gradient budget), and G = M*hi + M*lo takes 8 v_mfma_f32_16x16x32_bf16 (16 cycles
+// each) with fp32 accumulation; hi and lo ride in the same MFMA as two k-entries of one pair.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <bool FIXED, int VERTS, int WPV, bool SPLIT16>
+__global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_kernel(AttnParams P) {
+  constexpr int kThreads = VERTS * WPV * kWave;
+  constexpr int kSplit = kRpeVerts / VERTS;  // workgroups per query
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy VERTS*T^3*4][strips]
   attn_load_rng(P);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vloc = wv % VERTS, cslot = wv / VERTS;
+  const int part = blockIdx.x % kSplit, wg = blockIdx.x / kSplit, nwg = gridDim.x / kSplit;
+  const int w = part * VERTS + vloc;  // vertex index
+  const int T = P.T, TT = T * T, T3 = TT * T;
+  const int table_floats = VERTS * T3 * 4;
+  const int items = P.B * P.nQ;
+  for (int i = tid; i < table_floats; i += kThreads) smem[i] = 0.f;
   float fix_scale = 1.f, fix_inv = 1.f;
   if (FIXED) {
-    const float dmax = __uint_as_float(*P.absmax);
-    const int per_wg = (P.B * P.nQ + (int)gridDim.x - 1) / (int)gridDim.x;
+    // max |dP~| over this workgroup's rows (the 4 head rows of a query are contiguous: one 16-B aligned run)
+    float m = 0.f;
+    for (int item = wg; item < items; item += nwg) {
+      const float* base = P.dprob + (size_t)item * 4 * P.nK;
+      if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(base);
+        for (int i = tid; i < P.nK; i += kThreads) {
+          const f32x4 v = b4[i];
+          m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+      } else {
+        for (int i = tid; i < 4 * P.nK; i += kThreads) m = fmaxf(m, fabsf(base[i]));
+      }
+    }
+    m = wave_allmax_f32(m);
+    float* red = smem + table_floats;  // strip memory, not yet in use
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    float dmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < VERTS * WPV; ++i) dmax = fmaxf(dmax, red[i]);
+    const int per_wg = (items + nwg - 1) / nwg;
     const float bound = 2.f * P.drop_scale * dmax * (float)per_wg;
     if (bound > 0.f && bound < INFINITY) {
       const int e = 30 - (int)ceilf(__log2f(bound) + 1e-3f);  // 2^e * bound <= 2^30
@@ -285,20 +309,15 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
       fix_inv = ldexpf(1.f, -e);
     }
   }
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // = vertex index
-  const int T = P.T, TT = T * T, T3 = TT * T;
-  const int table_floats = kRpeVerts * T3 * 4;
-  for (int i = tid; i < table_floats; i += kMmThreads) smem[i] = 0.f;
   __syncthreads();
   // wave-private strip, accessed as int throughout (values are bit-cast) so that the scoreboard and the value
   // tile, which share memory, are never seen through two different types by the compiler's alias analysis
-  int* cellbuf = reinterpret_cast<int*>(smem + table_floats + w * kMmStripFloats);  // 64 ints
-  int* vbuf = cellbuf + kWave;                                                       // 64 x 16 values
-  int* scoreboard = vbuf;                                                            // T^3 <= 1024 ints, aliases vbuf
-  float* mytab = smem + (size_t)w * T3 * 4;
+  int* cellbuf = reinterpret_cast<int*>(smem + table_floats + wv * kMmStripFloats);  // 64 ints
+  int* vbuf = cellbuf + kWave;                                                        // 64 x 16 values
+  int* scoreboard = vbuf;                                                             // T^3 <= 1024 ints, aliases vbuf
+  float* mytab = smem + (size_t)vloc * T3 * 4;
   const bool rot = P.cos_sin != nullptr;
-  const int items = P.B * P.nQ;
+  const bool writer = w == 0;  // the waves of vertex 0 store P~ / dS of the chunks they visit
   const int nchunks = (P.nK + kWave - 1) / kWave;
   const int kk = lane >> 4, c15 = lane & 15;
   int off[2];  // bin offsets of this lane's output column for the two 16-value tiles (tile jt = corners 4jt..4jt+3)
@@ -309,26 +328,34 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
   }
   const int wr_sw = lane >> 1;  // 16-B blocks of a strip row are rotated by lane>>1: conflict-free b128 writes AND b32 reads
 
-  // operands of one chunk (64 consecutive keys, one per lane); fetched one chunk ahead
+  // operands of one chunk (64 consecutive keys, one per lane); fetched one visit ahead
   struct ChunkOps {
     float s[4], d[4], kx, ky, kz;
     unsigned char masked;
   };
-  auto fetch = [&](int b, size_t row0, int q, int chunk, ChunkOps& o) {
-    const int key = min(chunk * kWave + lane, P.nK - 1);
+  // Buffer addressing: a wave-uniform resource descriptor per row block (SGPRs) + one 32-bit lane offset.  With flat
+  // pointers the compiler keeps a 64-bit per-lane address for each of the 16 streams (32 VGPRs, spilled under the
+  // 128-VGPR budget of the 16-wave shape); reads past the end of a block return 0.
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  auto make_rsrc = [](const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+  };
+  auto ldf = [](rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
+  const int rowbytes = P.nK * 4;
+  auto fetch = [&](rsrc_t rs, rsrc_t rd, rsrc_t rx, rsrc_t rm, bool has_mask, int chunk, ChunkOps& o) {
+    const int key = chunk * kWave + lane;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const size_t e = (row0 + h) * P.nK + key;
-      o.s[h] = P.scores[e];
-      o.d[h] = P.dprob[e];
+      o.s[h] = ldf(rs, key * 4, h * rowbytes);
+      o.d[h] = ldf(rd, key * 4, h * rowbytes);
     }
-    const float* xp = P.xyz + ((size_t)b * P.nK + key) * 3;
-    o.kx = xp[0]; o.ky = xp[1]; o.kz = xp[2];
-    o.masked = P.mask_kind == VDETR_MASK_BOOL
-                   ? reinterpret_cast<const unsigned char*>(P.mask)[((size_t)b * P.nQ + q) * P.nK + key] : 0;
+    o.kx = ldf(rx, key * 12, 0); o.ky = ldf(rx, key * 12 + 4, 0); o.kz = ldf(rx, key * 12 + 8, 0);
+    o.masked = has_mask ? __builtin_amdgcn_raw_buffer_load_b8(rm, key, 0, 0) : 0;
   };
 
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+  for (int item = wg; item < items; item += nwg) {
     const int b = item / P.nQ, q = item - b * P.nQ;
     const size_t row0 = ((size_t)b * P.nQ + q) * 4;
     float lse[4], delta[4];
@@ -338,12 +365,18 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
     const float vx = vp[0], vy = vp[1], vz = vp[2];
     const float rc = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2] : 1.f;
     const float rs = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1] : 0.f;
+    const rsrc_t rsc = make_rsrc(P.scores + row0 * P.nK, 4u * rowbytes), rd = make_rsrc(P.dprob + row0 * P.nK, 4u * rowbytes);
+    const rsrc_t rp = make_rsrc(P.probs_out + row0 * P.nK, 4u * rowbytes), rg = make_rsrc(P.ds_out + row0 * P.nK, 4u * rowbytes);
+    const rsrc_t rx = make_rsrc(P.xyz + (size_t)b * P.nK * 3, 3u * rowbytes);
+    const bool has_mask = P.mask_kind == VDETR_MASK_BOOL;
+    const rsrc_t rm = make_rsrc(has_mask ? reinterpret_cast<const unsigned char*>(P.mask) + ((size_t)b * P.nQ + q) * P.nK
+                                         : reinterpret_cast<const unsigned char*>(P.xyz), has_mask ? (unsigned)P.nK : 0u);
     ChunkOps ops, nxt;
-    fetch(b, row0, q, 0, ops);
+    fetch(rsc, rd, rx, rm, has_mask, cslot, ops);
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      if (chunk + 1 < nchunks) fetch(b, row0, q, chunk + 1, nxt);
-      // ---- element-wise softmax backward of this lane's pair (recomputed by every wave; wave 0 stores) ----------
+    for (int chunk = cslot; chunk < nchunks; chunk += WPV) {
+      if (chunk + WPV < nchunks) fetch(rsc, rd, rx, rm, has_mask, chunk + WPV, nxt);
+      // ---- element-wise softmax backward of this lane's pair (recomputed by every wave; vertex 0's waves store) ---
       const int key = chunk * kWave + lane;
       const bool valid = key < P.nK;
       float ds[4];
@@ -354,10 +387,9 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
         for (int h = 0; h < 4; ++h) {
           const bool keep = pick4(rnd, h) >= P.drop_thresh;
           const ScoreGrad g = score_grad(ops.s[h], lse[h], keep, P.drop_scale, true, ops.d[h], delta[h], ops.masked != 0);
-          if (w == 0 && valid) {
-            const size_t e = (row0 + h) * P.nK + key;
-            P.probs_out[e] = g.p_drop;
-            P.ds_out[e] = g.ds;
+          if (writer && valid) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(g.p_drop), rp, key * 4, h * rowbytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(g.ds), rg, key * 4, h * rowbytes, 0);
           }
           ds[h] = valid ? g.ds : 0.f;
         }
@@ -380,28 +412,40 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
       const unsigned long long lmask = __ballot(leader == lane);
       const int ngroups = __popcll(lmask);
       const int gidx = __popcll(lmask & ((1ull << leader) - 1ull));
-      // group index of all 64 pairs, laid out so that k-slot kk reads pairs kk, 4+kk, 8+kk, ... as 4 x 16 bytes
-      cellbuf[(lane & 3) * 16 + (lane >> 2)] = gidx;
       __builtin_amdgcn_wave_barrier();
-      int cr[16];
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        const int4 v4 = *reinterpret_cast<const int4*>(cellbuf + kk * 16 + t4 * 4);
-        cr[t4 * 4] = v4.x; cr[t4 * 4 + 1] = v4.y; cr[t4 * 4 + 2] = v4.z; cr[t4 * 4 + 3] = v4.w;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (leader == lane) cellbuf[gidx] = cell;  // the strip now holds cell-of-group
-      __builtin_amdgcn_wave_barrier();
+      if (leader == lane) cellbuf[gidx] = cell;  // cell of every group
 
       for (int g0 = 0; g0 < ngroups; g0 += 16) {  // 16 groups per round (one round in 95 % of the chunks)
-        float am[16];
+        // group index of all 64 pairs through the (currently free) value tile, laid out so that k-slot kk reads pairs
+        // kk, 4+kk, 8+kk, ... as 4 x 16 bytes; re-read per round so that the 16 registers are not live across the round
+        __builtin_amdgcn_wave_barrier();
+        vbuf[(lane & 3) * 16 + (lane >> 2)] = gidx;
+        __builtin_amdgcn_wave_barrier();
+        int cr[16];
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) am[s2] = cr[s2] == g0 + c15 ? 1.f : 0.f;
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int4 v4 = *reinterpret_cast<const int4*>(vbuf + kk * 16 + t4 * 4);
+          cr[t4 * 4] = v4.x; cr[t4 * 4 + 1] = v4.y; cr[t4 * 4 + 2] = v4.z; cr[t4 * 4 + 3] = v4.w;
+        }
         int gc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int g = g0 + 4 * kk + r;
           gc[r] = g < ngroups ? cellbuf[g] : -1;
+        }
+        // membership operand, built once per round.  k-slot (kk, s) of every MFMA = pair 4s + kk.
+        float am[16];
+        i32x4 am16[4];
+        if (SPLIT16) {
+          // a strip word carries (hi, lo) of one value = two consecutive bf16 k-entries, so the words feed the B operand
+          // as they are and the membership of a pair is simply duplicated into both halves of an A register
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) am16[t][m] = cr[4 * t + m] == g0 + c15 ? 0x3F803F80 : 0;  // bf16 (1.0, 1.0)
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) am[s2] = cr[s2] == g0 + c15 ? 1.f : 0.f;
         }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
@@ -409,31 +453,55 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) {
             const float wc = wgt[jt * 4 + cc];
-            *reinterpret_cast<int4*>(vbuf + lane * 16 + ((cc + wr_sw) & 3) * 4) =
-                make_int4(__float_as_int(wc * ds[0]), __float_as_int(wc * ds[1]), __float_as_int(wc * ds[2]),
-                          __float_as_int(wc * ds[3]));
+            int wd[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              const float v = wc * ds[h];
+              if (SPLIT16) {
+                const float hi = __int_as_float(__float_as_int(v) & 0xFFFF0000);
+                const float lo = v - hi;  // exact
+                wd[h] = (int)__builtin_amdgcn_perm((unsigned)__float_as_int(v), (unsigned)__float_as_int(lo), 0x07060302u);
+              } else {
+                wd[h] = __float_as_int(v);
+              }
+            }
+            *reinterpret_cast<int4*>(vbuf + lane * 16 + ((cc + wr_sw) & 3) * 4) = make_int4(wd[0], wd[1], wd[2], wd[3]);
           }
           __builtin_amdgcn_wave_barrier();
-          float bv[16];
+          int bw[16];
 #pragma unroll
           for (int s2 = 0; s2 < 16; ++s2) {
             const int p = 4 * s2 + kk;
-            bv[s2] = __int_as_float(vbuf[p * 16 + (((c15 >> 2) + (p >> 1)) & 3) * 4 + (c15 & 3)]);
+            bw[s2] = vbuf[p * 16 + (((c15 >> 2) + (p >> 1)) & 3) * 4 + (c15 & 3)];
           }
-          f32x4 acc[4];  // four independent chains: the MFMAs are issue-, not latency-bound
+          float tot[4];
+          if (SPLIT16) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-          for (int ch = 0; ch < 4; ++ch) acc[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) {  // 16 pairs x (hi, lo) per MFMA
+              const i32x4 b = {bw[4 * t], bw[4 * t + 1], bw[4 * t + 2], bw[4 * t + 3]};
+              acc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, am16[t]),
+                                                                   __builtin_bit_cast(bf16x8, b), acc[t & 1], 0, 0, 0);
+            }
 #pragma unroll
-          for (int s2 = 0; s2 < 16; ++s2)
-            acc[s2 & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s2], bv[s2], acc[s2 & 3], 0, 0, 0);
-          // wave w is the only writer of table w in this workgroup; the (group, value) bins of one update are distinct
+            for (int r = 0; r < 4; ++r) tot[r] = acc[0][r] + acc[1][r];
+          } else {
+            f32x4 acc[4];  // four independent chains
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) acc[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2)
+              acc[s2 & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[s2], __int_as_float(bw[s2]), acc[s2 & 3], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tot[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+          }
+          // the (group, value) bins of one update are distinct, but neighbouring cells' footprints overlap: atomics
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (gc[r] >= 0) {
-              float* bin = mytab + (size_t)gc[r] * 4 + off[jt];
-              const float tot = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-              if (FIXED) atomicAdd(reinterpret_cast<int*>(bin), __float2int_rn(tot * fix_scale));
-              else atomicAdd(bin, tot);
+              float* bin = mytab + gc[r] * 4 + off[jt];
+              if (FIXED) atomicAdd(reinterpret_cast<int*>(bin), __float2int_rn(tot[r] * fix_scale));
+              else atomicAdd(bin, tot[r]);
             }
         }
       }
@@ -442,19 +510,22 @@ __global__ __launch_bounds__(kMmThreads) void attn_bwd_scores_rpe_mm_kernel(Attn
   }
   __syncthreads();
   float* dst = P.dtable_part + (size_t)blockIdx.x * table_floats;
-  for (int i = tid; i < table_floats; i += kMmThreads)
+  for (int i = tid; i < table_floats; i += kThreads)
     dst[i] = FIXED ? (float)reinterpret_cast<const int*>(smem)[i] * fix_inv : smem[i];
 }
 
-// dtable[e] += sum over workgroup copies; blockIdx.y takes a slice of the copies so that the 32 MB of partials are
-// read by ~2000 blocks instead of 125
+// dtable[e] += sum over workgroup copies.  Workgroup p of the scores kernel wrote the `n / nsplit` floats of table
+// slice p % nsplit; blockIdx.y takes kRedSlice of the copies so that the partials are read by ~1000 blocks
 constexpr int kRedSlice = 16;
-__global__ __launch_bounds__(256) void attn_bwd_table_reduce_kernel(const float* part, int nparts, int n, float* dtable) {
+__global__ __launch_bounds__(256) void attn_bwd_table_reduce_kernel(const float* part, int nparts, int nsplit, int n,
+                                                                    float* dtable) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
-  const int p0 = blockIdx.y * kRedSlice, p1 = min(nparts, p0 + kRedSlice);
+  const int nsub = n / nsplit, sl = e / nsub, esub = e - sl * nsub;
+  const int copies = nparts / nsplit;
+  const int p0 = blockIdx.y * kRedSlice, p1 = min(copies, p0 + kRedSlice);
   float s = 0.f;
-  for (int p = p0; p < p1; ++p) s += part[(size_t)p * n + e];
+  for (int p = p0; p < p1; ++p) s += part[((size_t)p * nsplit + sl) * nsub + esub];
   unsafeAtomicAdd(dtable + e, s);
 }
 
@@ -476,6 +547,57 @@ __global__ __launch_bounds__(512) void lds_atomic_probe_kernel(int mode, int ite
   __syncthreads();
   for (int i = threadIdx.x; i < 32768; i += 512) acc += tab[i];
   if (acc == -1.f) sink[0] = acc;
+}
+
+// Issue-overlap probe (tools/kernel_bench.py --issue): 512-thread workgroups, one per CU, `iters` rounds of
+//   mode 10: 16 independent v_mfma_f32_16x16x4_f32        mode 11: 128 independent v_fma_f32
+//   mode 12: both, interleaved in every wave              mode 13: waves 0-3 MFMA only, waves 4-7 VALU only
+//   mode 14: 128 v_fma_f32 + 16 ds_read_b128
+//   mode 15: 16 v_mfma_f32_16x16x32_bf16                  mode 16: waves 0-3 bf16 MFMA, waves 4-7 VALU
+//   mode 17: bf16 MFMA + VALU interleaved in every wave
+__global__ __launch_bounds__(512) void issue_probe_kernel(int mode, int iters, float* sink) {
+  __shared__ f32x4 buf[1024];
+  for (int i = threadIdx.x; i < 1024; i += 512) buf[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+  __syncthreads();
+  const int wv = threadIdx.x >> 6;
+  const bool do_mfma = mode == 10 || mode == 12 || (mode == 13 && wv < 4);
+  const bool do_valu = mode == 11 || mode == 12 || mode == 14 || mode == 17 || ((mode == 13 || mode == 16) && wv >= 4);
+  const bool do_bf16 = mode == 15 || mode == 17 || (mode == 16 && wv < 4);
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  bf16x8 pa, pb;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { pa[i] = (__bf16)(1.0f + i); pb[i] = (__bf16)(0.5f * (threadIdx.x & 3)); }
+  f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = (float)(threadIdx.x + i);
+  const float a = 1.0001f, b = 0.5f;
+  f32x4 l = f32x4{0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+    if (do_mfma) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc[s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[s & 3], 0, 0, 0);
+    }
+    if (do_bf16) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc[s & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, pb, acc[s & 3], 0, 0, 0);
+    }
+    if (do_valu) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(v[i], a, b);
+    }
+    if (mode == 14) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) l += buf[(threadIdx.x * 7 + r * 64 + it) & 1023];
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += v[i];
+  t += acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + l[0] + l[3];
+  if (t == -1.f) sink[0] = t;
 }
 
 // keep-mask dump (test hook)
@@ -501,19 +623,29 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, ui
 using namespace vdetr;
 
 static int bwd_variant() {
-  // 0: per-lane ds_add_f32, 1: wave-aggregated + ds_add_f32, 4: matrix-core aggregation, no atomics (default)
-  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 4; }();
+  // 0: per-lane ds_add_f32, 1: wave-aggregated + ds_add_f32, 8 (default): matrix-core aggregation (split-bf16 product,
+  // fixed-point histogram, two 16-wave workgroups per query), 4: as 8 with one 8-wave workgroup per query,
+  // 5 / 7: fp32 MFMA with float / fixed-point histogram (8-wave workgroups)
+  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 8; }();
   return variant;
 }
-static int bwd_grid(const vdetr_attn_desc* d) {
-  const long items = (long)d->B * d->nQ;
-  return (int)(items < 256 ? items : 256);
+static int bwd_grid(const vdetr_attn_desc* d, int split) {
+  const long wgs = (long)d->B * d->nQ * split;
+  return (int)(wgs < 256 ? wgs : 256);
 }
 
 extern "C" size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d || !d->table) return 0;
   const size_t table_floats = (size_t)kRpeVerts * d->table_size * d->table_size * d->table_size * 4;
-  return (size_t)bwd_grid(d) * table_floats * sizeof(float) + 512;  // partial tables + |dP~| max scalar + alignment
+  return (size_t)bwd_grid(d, 1) * table_floats * sizeof(float) + 256;  // partial tables (any variant) + alignment
+}
+
+template <bool FIXED, int VERTS, int WPV, bool SPLIT16>
+static int launch_mm(const AttnParams& P, int grid, size_t lds, hipStream_t st) {
+  if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<FIXED, VERTS, WPV, SPLIT16>, lds, "attn_bwd_scores")) return e;
+  hipLaunchKernelGGL((attn_bwd_scores_rpe_mm_kernel<FIXED, VERTS, WPV, SPLIT16>), dim3(grid), dim3(VERTS * WPV * kWave), lds,
+                     st, P);
+  return VDETR_OK;
 }
 
 extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, const float* dprob,
@@ -539,9 +671,11 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     hipLaunchKernelGGL(attn_bwd_scores_kernel, dim3(grid), dim3(256), 0, st, P);
     return check_launch("attn_bwd_scores");
   }
-  const int grid = bwd_grid(d);
+  const int variant = bwd_variant();
   const int table_floats = kRpeVerts * P.T * P.T * P.T * 4;
-  size_t lds = 16;
+  const bool mm = dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16;
+  const int split = mm && variant == 8 ? 2 : 1;  // workgroups per query
+  const int grid = bwd_grid(d, split);
   if (dtable) {
     const size_t need = vdetr_attn_bwd_workspace_bytes(d);
     if (!workspace || workspace_bytes < need) {
@@ -549,45 +683,38 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
       return VDETR_ERR_WORKSPACE;
     }
     P.dtable_part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    lds = (size_t)table_floats * sizeof(float);
   }
-  const int variant = bwd_variant();
-  if (dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16) {
-    lds += (size_t)kMmWaves * kMmStripFloats * sizeof(float);
-    if (variant == 5) {  // float LDS atomics (A/B reference for the fixed-point histogram)
-      if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<false>, lds, "attn_bwd_scores")) return e;
-      hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel<false>, dim3(grid), dim3(kMmThreads), lds, st, P);
-    } else {
-      // max |dP~| of the launch -> scale of the fixed-point histogram (scalar lives at the end of the workspace)
-      unsigned* absmax = reinterpret_cast<unsigned*>(P.dtable_part + (size_t)grid * table_floats);
-      P.absmax = absmax;
-      if (hipMemsetAsync(absmax, 0, sizeof(unsigned), st) != hipSuccess) {
-        set_error("attn_bwd_scores: memset failed");
-        return VDETR_ERR_LAUNCH;
-      }
-      const size_t total = (size_t)d->B * d->H * d->nQ * d->nK;
-      hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, dprob, total, absmax);
-      if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<true>, lds, "attn_bwd_scores")) return e;
-      hipLaunchKernelGGL(attn_bwd_scores_rpe_mm_kernel<true>, dim3(grid), dim3(kMmThreads), lds, st, P);
-    }
-  } else if (variant == 0) {
-    if (int e = set_lds(attn_bwd_scores_rpe_kernel<0>, lds, "attn_bwd_scores")) return e;
-    hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<0>), dim3(grid), dim3(kBwdThreads), lds, st, P);
+  if (mm) {
+    const size_t lds = (size_t)table_floats / split * sizeof(float) + (size_t)8 * split * kMmStripFloats * sizeof(float);
+    int e;
+    if (variant == 5) e = launch_mm<false, 8, 1, false>(P, grid, lds, st);      // fp32 MFMA, float LDS atomics
+    else if (variant == 7) e = launch_mm<true, 8, 1, false>(P, grid, lds, st);  // fp32 MFMA, fixed-point histogram
+    else if (variant == 8) e = launch_mm<true, 4, 4, true>(P, grid, lds, st);   // as 4, two 16-wave workgroups per query
+    else e = launch_mm<true, 8, 1, true>(P, grid, lds, st);
+    if (e) return e;
   } else {
-    if (int e = set_lds(attn_bwd_scores_rpe_kernel<1>, lds, "attn_bwd_scores")) return e;
-    hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<1>), dim3(grid), dim3(kBwdThreads), lds, st, P);
+    const size_t lds = dtable ? (size_t)table_floats * sizeof(float) : 16;
+    if (variant == 0) {
+      if (int e = set_lds(attn_bwd_scores_rpe_kernel<0>, lds, "attn_bwd_scores")) return e;
+      hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<0>), dim3(grid), dim3(kBwdThreads), lds, st, P);
+    } else {
+      if (int e = set_lds(attn_bwd_scores_rpe_kernel<1>, lds, "attn_bwd_scores")) return e;
+      hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<1>), dim3(grid), dim3(kBwdThreads), lds, st, P);
+    }
   }
   if (int e = check_launch("attn_bwd_scores_rpe")) return e;
   if (dtable) {
-    hipLaunchKernelGGL(attn_bwd_table_reduce_kernel, dim3((table_floats + 255) / 256, (grid + kRedSlice - 1) / kRedSlice),
-                       dim3(256), 0, st, P.dtable_part, grid, table_floats, dtable);
+    hipLaunchKernelGGL(attn_bwd_table_reduce_kernel,
+                       dim3((table_floats + 255) / 256, (grid / split + kRedSlice - 1) / kRedSlice), dim3(256), 0, st,
+                       P.dtable_part, grid, split, table_floats, dtable);
     return check_launch("attn_bwd_table_reduce");
   }
   return VDETR_OK;
 }
 
 extern "C" int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream) {
-  hipLaunchKernelGGL(lds_atomic_probe_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, mode, iters, sink);
+  if (mode >= 10) hipLaunchKernelGGL(issue_probe_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, mode, iters, sink);
+  else hipLaunchKernelGGL(lds_atomic_probe_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, mode, iters, sink);
   return check_launch("lds_atomic_probe");
 }
 

@@ -47,7 +47,6 @@ struct AttnParams {
   const float* delta;
   float* probs_out;
   float* ds_out;
-  const unsigned* absmax;  // bits of max |dprob| (fixed-point histogram scale)
   float* dtable_part;  // [gridDim.x][8*T^3*H]
 };
 
@@ -99,15 +98,18 @@ struct AxisTap {
   int base;
   float wa, wb;
 };
+// v_med3_f32 clamps: __saturatef / fminf(fmaxf()) expand to compare+select pairs (4 instructions per weight, measured
+// 192 of the forward kernel's ~950 VALU instructions per 64 pairs)
+__device__ __forceinline__ float sat01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
 __device__ __forceinline__ AxisTap rpe_axis(float d, const AttnParams& P) {
   const float L = __log2f(__builtin_fmaf(fabsf(d), P.log_scale, 1.0f));
   const float pix = __builtin_fmaf(copysignf(L, d), P.pix_mul, P.pix_add);
-  const float bf = fminf(fmaxf(floorf(pix), 0.f), (float)(P.T - 2));
+  const float bf = __builtin_amdgcn_fmed3f(floorf(pix), 0.f, (float)(P.T - 2));
   const float t = pix - bf;
   AxisTap a;
   a.base = (int)bf;
-  a.wa = __saturatef(1.f - fabsf(t));
-  a.wb = __saturatef(1.f - fabsf(t - 1.f));
+  a.wa = sat01(1.f - fabsf(t));
+  a.wb = sat01(1.f - fabsf(t - 1.f));
   return a;
 }
 
@@ -115,7 +117,7 @@ __device__ __forceinline__ AxisTap rpe_axis(float d, const AttnParams& P) {
 __device__ __forceinline__ int rpe_axis_base(float d, const AttnParams& P, float& t) {
   const float L = __log2f(__builtin_fmaf(fabsf(d), P.log_scale, 1.0f));
   const float pix = __builtin_fmaf(copysignf(L, d), P.pix_mul, P.pix_add);
-  const float bf = fminf(fmaxf(floorf(pix), 0.f), (float)(P.T - 2));
+  const float bf = __builtin_amdgcn_fmed3f(floorf(pix), 0.f, (float)(P.T - 2));
   t = pix - bf;
   return (int)bf;
 }
