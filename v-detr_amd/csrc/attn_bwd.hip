@@ -263,17 +263,21 @@ constexpr int kMmStripFloats = kWave + kWave * 16;  // cell ids + 64 x 16 values
 // each) with fp32 accumulation; hi and lo ride in the same MFMA as two k-entries of one pair.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <bool FIXED, int VERTS, int WPV, bool SPLIT16>
+// VLOOP: a wave takes every (VERTS*WPV)-th chunk and walks ALL the workgroup's vertices for it, so the element-wise
+// softmax backward (loads, exp, dropout hash, stores: ~85 of ~385 VALU instructions per (chunk, vertex)) is done once
+// per chunk and workgroup instead of once per vertex.
+template <bool FIXED, int VERTS, int WPV, bool SPLIT16, bool VLOOP>
 __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_kernel(AttnParams P) {
   constexpr int kThreads = VERTS * WPV * kWave;
+  constexpr int kChunkStride = VLOOP ? VERTS * WPV : WPV;
   constexpr int kSplit = kRpeVerts / VERTS;  // workgroups per query
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy VERTS*T^3*4][strips]
   attn_load_rng(P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int vloc = wv % VERTS, cslot = wv / VERTS;
+  const int vloc = VLOOP ? 0 : wv % VERTS, cslot = VLOOP ? wv : wv / VERTS;
   const int part = blockIdx.x % kSplit, wg = blockIdx.x / kSplit, nwg = gridDim.x / kSplit;
-  const int w = part * VERTS + vloc;  // vertex index
+  const int w = part * VERTS + vloc;  // (first) vertex index
   const int T = P.T, TT = T * T, T3 = TT * T;
   const int table_floats = VERTS * T3 * 4;
   const int items = P.B * P.nQ;
@@ -315,9 +319,8 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
   int* cellbuf = reinterpret_cast<int*>(smem + table_floats + wv * kMmStripFloats);  // 64 ints
   int* vbuf = cellbuf + kWave;                                                        // 64 x 16 values
   int* scoreboard = vbuf;                                                             // T^3 <= 1024 ints, aliases vbuf
-  float* mytab = smem + (size_t)vloc * T3 * 4;
   const bool rot = P.cos_sin != nullptr;
-  const bool writer = w == 0;  // the waves of vertex 0 store P~ / dS of the chunks they visit
+  const bool writer = w == 0;  // the waves that look at vertex 0 store P~ / dS of the chunks they visit
   const int nchunks = (P.nK + kWave - 1) / kWave;
   const int kk = lane >> 4, c15 = lane & 15;
   int off[2];  // bin offsets of this lane's output column for the two 16-value tiles (tile jt = corners 4jt..4jt+3)
@@ -358,13 +361,18 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
   for (int item = wg; item < items; item += nwg) {
     const int b = item / P.nQ, q = item - b * P.nQ;
     const size_t row0 = ((size_t)b * P.nQ + q) * 4;
+    // per-item constants are wave-uniform: pin them to SGPRs (the loads are vector loads because the kernel also stores)
+    auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
     float lse[4], delta[4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lse[h] = P.lse[row0 + h]; delta[h] = P.delta[row0 + h]; }
+    for (int h = 0; h < 4; ++h) { lse[h] = uni(P.lse[row0 + h]); delta[h] = uni(P.delta[row0 + h]); }
+    constexpr int kVL = VLOOP ? VERTS : 1;
     const float* vp = P.vertices + ((size_t)b * P.nQ + q) * 24 + w * 3;
-    const float vx = vp[0], vy = vp[1], vz = vp[2];
-    const float rc = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2] : 1.f;
-    const float rs = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1] : 0.f;
+    float vxs[kVL], vys[kVL], vzs[kVL];
+#pragma unroll
+    for (int vl = 0; vl < kVL; ++vl) { vxs[vl] = uni(vp[vl * 3]); vys[vl] = uni(vp[vl * 3 + 1]); vzs[vl] = uni(vp[vl * 3 + 2]); }
+    const float rc = rot ? uni(P.cos_sin[((size_t)b * P.nQ + q) * 2]) : 1.f;
+    const float rs = rot ? uni(P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1]) : 0.f;
     const rsrc_t rsc = make_rsrc(P.scores + row0 * P.nK, 4u * rowbytes), rd = make_rsrc(P.dprob + row0 * P.nK, 4u * rowbytes);
     const rsrc_t rp = make_rsrc(P.probs_out + row0 * P.nK, 4u * rowbytes), rg = make_rsrc(P.ds_out + row0 * P.nK, 4u * rowbytes);
     const rsrc_t rx = make_rsrc(P.xyz + (size_t)b * P.nK * 3, 3u * rowbytes);
@@ -374,8 +382,8 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
     ChunkOps ops, nxt;
     fetch(rsc, rd, rx, rm, has_mask, cslot, ops);
 
-    for (int chunk = cslot; chunk < nchunks; chunk += WPV) {
-      if (chunk + WPV < nchunks) fetch(rsc, rd, rx, rm, has_mask, chunk + WPV, nxt);
+    for (int chunk = cslot; chunk < nchunks; chunk += kChunkStride) {
+      if (chunk + kChunkStride < nchunks) fetch(rsc, rd, rx, rm, has_mask, chunk + kChunkStride, nxt);
       // ---- element-wise softmax backward of this lane's pair (recomputed by every wave; vertex 0's waves store) ---
       const int key = chunk * kWave + lane;
       const bool valid = key < P.nK;
@@ -391,11 +399,15 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(g.p_drop), rp, key * 4, h * rowbytes, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(g.ds), rg, key * 4, h * rowbytes, 0);
           }
-          ds[h] = valid ? g.ds : 0.f;
+          ds[h] = valid ? g.ds * fix_scale : 0.f;  // fix_scale is a power of two (1 for the float histogram): exact
         }
       }
-      // ---- lookup geometry of (pair, vertex w) ---------------------------------------------------------------------
-      float dx = vx - ops.kx, dy = vy - ops.ky, dz = vz - ops.kz;
+#pragma unroll
+      for (int vl = 0; vl < kVL; ++vl) {
+      if (VLOOP) __builtin_amdgcn_sched_barrier(0);  // keep the vertices' geometry from being hoisted together (VGPRs)
+      float* mytab = smem + (size_t)(VLOOP ? vl : vloc) * T3 * 4;
+      // ---- lookup geometry of (pair, vertex) ------------------------------------------------------------------------
+      float dx = vxs[vl] - ops.kx, dy = vys[vl] - ops.ky, dz = vzs[vl] - ops.kz;
       if (rot) rpe_rotate(dx, dy, rc, rs);
       const AxisTap ax = rpe_axis(dx, P), ay = rpe_axis(dy, P), az = rpe_axis(dz, P);
       const int cell = rpe_cell(ax, ay, az, T);
@@ -454,16 +466,20 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
           for (int cc = 0; cc < 4; ++cc) {
             const float wc = wgt[jt * 4 + cc];
             int wd[4];
+            if (SPLIT16) {
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-              const float v = wc * ds[h];
-              if (SPLIT16) {
-                const float hi = __int_as_float(__float_as_int(v) & 0xFFFF0000);
-                const float lo = v - hi;  // exact
-                wd[h] = (int)__builtin_amdgcn_perm((unsigned)__float_as_int(v), (unsigned)__float_as_int(lo), 0x07060302u);
-              } else {
-                wd[h] = __float_as_int(v);
+              for (int hp = 0; hp < 2; ++hp) {  // packed fp32: two heads per v_pk_mul / v_pk_add
+                const f32x2 v = f32x2{wc, wc} * f32x2{ds[2 * hp], ds[2 * hp + 1]};
+                const f32x2 hi = {__int_as_float(__float_as_int(v[0]) & 0xFFFF0000), __int_as_float(__float_as_int(v[1]) & 0xFFFF0000)};
+                const f32x2 lo = v - hi;  // exact
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                  wd[2 * hp + e] = (int)__builtin_amdgcn_perm((unsigned)__float_as_int(v[e]), (unsigned)__float_as_int(lo[e]), 0x07060302u);
               }
+            } else {
+#pragma unroll
+              for (int h = 0; h < 4; ++h) wd[h] = __float_as_int(wc * ds[h]);
             }
             *reinterpret_cast<int4*>(vbuf + lane * 16 + ((cc + wr_sw) & 3) * 4) = make_int4(wd[0], wd[1], wd[2], wd[3]);
           }
@@ -500,11 +516,12 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
           for (int r = 0; r < 4; ++r)
             if (gc[r] >= 0) {
               float* bin = mytab + gc[r] * 4 + off[jt];
-              if (FIXED) atomicAdd(reinterpret_cast<int*>(bin), __float2int_rn(tot[r] * fix_scale));
+              if (FIXED) atomicAdd(reinterpret_cast<int*>(bin), __float2int_rn(tot[r]));
               else atomicAdd(bin, tot[r]);
             }
         }
       }
+      }  // vertex loop
       ops = nxt;
     }
   }
@@ -623,10 +640,11 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, ui
 using namespace vdetr;
 
 static int bwd_variant() {
-  // 0: per-lane ds_add_f32, 1: wave-aggregated + ds_add_f32, 8 (default): matrix-core aggregation (split-bf16 product,
-  // fixed-point histogram, two 16-wave workgroups per query), 4: as 8 with one 8-wave workgroup per query,
-  // 5 / 7: fp32 MFMA with float / fixed-point histogram (8-wave workgroups)
-  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 8; }();
+  // 0: per-lane ds_add_f32, 1: wave-aggregated + ds_add_f32; matrix-core aggregation: 9 (default) split-bf16 product,
+  // fixed-point histogram, two 16-wave workgroups per query, a wave walks the workgroup's 4 vertices per chunk;
+  // 8: as 9 with one vertex per wave; 10 / 4: one 8-wave workgroup per query with / without the vertex walk;
+  // 5 / 7: fp32 MFMA with float / fixed-point histogram (8-wave workgroups, one vertex per wave)
+  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 9; }();
   return variant;
 }
 static int bwd_grid(const vdetr_attn_desc* d, int split) {
@@ -640,11 +658,11 @@ extern "C" size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d) {
   return (size_t)bwd_grid(d, 1) * table_floats * sizeof(float) + 256;  // partial tables (any variant) + alignment
 }
 
-template <bool FIXED, int VERTS, int WPV, bool SPLIT16>
+template <bool FIXED, int VERTS, int WPV, bool SPLIT16, bool VLOOP>
 static int launch_mm(const AttnParams& P, int grid, size_t lds, hipStream_t st) {
-  if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<FIXED, VERTS, WPV, SPLIT16>, lds, "attn_bwd_scores")) return e;
-  hipLaunchKernelGGL((attn_bwd_scores_rpe_mm_kernel<FIXED, VERTS, WPV, SPLIT16>), dim3(grid), dim3(VERTS * WPV * kWave), lds,
-                     st, P);
+  if (int e = set_lds(attn_bwd_scores_rpe_mm_kernel<FIXED, VERTS, WPV, SPLIT16, VLOOP>, lds, "attn_bwd_scores")) return e;
+  hipLaunchKernelGGL((attn_bwd_scores_rpe_mm_kernel<FIXED, VERTS, WPV, SPLIT16, VLOOP>), dim3(grid),
+                     dim3(VERTS * WPV * kWave), lds, st, P);
   return VDETR_OK;
 }
 
@@ -674,7 +692,7 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
   const int variant = bwd_variant();
   const int table_floats = kRpeVerts * P.T * P.T * P.T * 4;
   const bool mm = dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16;
-  const int split = mm && variant == 8 ? 2 : 1;  // workgroups per query
+  const int split = mm && (variant == 8 || variant == 9) ? 2 : 1;  // workgroups per query
   const int grid = bwd_grid(d, split);
   if (dtable) {
     const size_t need = vdetr_attn_bwd_workspace_bytes(d);
@@ -687,10 +705,12 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
   if (mm) {
     const size_t lds = (size_t)table_floats / split * sizeof(float) + (size_t)8 * split * kMmStripFloats * sizeof(float);
     int e;
-    if (variant == 5) e = launch_mm<false, 8, 1, false>(P, grid, lds, st);      // fp32 MFMA, float LDS atomics
-    else if (variant == 7) e = launch_mm<true, 8, 1, false>(P, grid, lds, st);  // fp32 MFMA, fixed-point histogram
-    else if (variant == 8) e = launch_mm<true, 4, 4, true>(P, grid, lds, st);   // as 4, two 16-wave workgroups per query
-    else e = launch_mm<true, 8, 1, true>(P, grid, lds, st);
+    if (variant == 5) e = launch_mm<false, 8, 1, false, false>(P, grid, lds, st);      // fp32 MFMA, float LDS atomics
+    else if (variant == 7) e = launch_mm<true, 8, 1, false, false>(P, grid, lds, st);  // fp32 MFMA, fixed-point histogram
+    else if (variant == 4) e = launch_mm<true, 8, 1, true, false>(P, grid, lds, st);
+    else if (variant == 8) e = launch_mm<true, 4, 4, true, false>(P, grid, lds, st);
+    else if (variant == 10) e = launch_mm<true, 8, 1, true, true>(P, grid, lds, st);
+    else e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st);
     if (e) return e;
   } else {
     const size_t lds = dtable ? (size_t)table_floats * sizeof(float) : 16;
