@@ -268,8 +268,12 @@ def cpu_baseline(cfg_name):
     idx = O.furthest_point_sampling(xyz[None].numpy(), npre)
     t_fps = time.perf_counter() - t0
     kxyz = xyz[torch.from_numpy(idx[0]).long()][None]
+    import vdetr_amd.box_decode as BD
+    from oracle.box_oracle import decode_boxes_reference
     saved = (A.fused_attention, A.begin_step, A.current_rng)
+    saved_bd = BD.decode_boxes
     A.fused_attention, A.begin_step, A.current_rng = fused_attention_reference, (lambda dev: None), (lambda dev: None)
+    BD.decode_boxes = decode_boxes_reference
     try:
         times = {}
         for layers in (2, 3):  # FFN stage + 1 resp. 2 RPE layers; per-layer cost = difference
@@ -286,6 +290,7 @@ def cpu_baseline(cfg_name):
             times[layers] = time.perf_counter() - t0
     finally:
         A.fused_attention, A.begin_step, A.current_rng = saved
+        BD.decode_boxes = saved_bd
     per_layer = max(times[3] - times[2], 1e-9)
     full = t_fps + times[2] + (nl - 2) * per_layer
     return {"value": bs / (full * bs), "unit": "scenes/s", "cores": cores, "kind": "port",

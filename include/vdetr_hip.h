@@ -164,6 +164,53 @@ int vdetr_attn_dropout_mask_u8(const vdetr_attn_desc* d, uint8_t* keep, vdetr_st
  * vdetr_transformer.py:710-731. */
 int vdetr_rpe_bias_f32(const vdetr_attn_desc* d, float* rpe, vdetr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Box decode of one decoder stage: head outputs -> box parameters, corners, class probabilities.
+ * Replaces the ATen composition of TransformerDecoder.get_proposal_box_predictions_refine
+ * (models/vdetr_transformer.py:244-333: lines :286-318 after the five mlp heads), BoxProcessor (:20-90),
+ * datasets/scannet.py:168-171 and utils/box_util.py:294-352 (flip_axis_to_camera_tensor, roty_batch_tensor,
+ * get_3d_box_batch_tensor).  All tensors fp32 contiguous unless noted; nullable pointers say so.
+ * ---------------------------------------------------------------------------------------------- */
+#define VDETR_CLS_SOFTMAX 0 /* celoss: sem_cls_prob = softmax[..., :-1], objectness = 1 - softmax[..., -1]  (:80-86) */
+#define VDETR_CLS_SIGMOID 1 /* focalloss: objectness = max sigmoid(logits); sem_cls_prob is the logits tensor (:74-79) */
+
+typedef struct vdetr_box_decode_desc {
+  int32_t B, N;          /* scenes, queries */
+  int32_t A;             /* channels of the angle heads (= number of angle bins) */
+  int32_t C1;            /* channels of the class head */
+  int32_t num_angle_bin; /* dataset_config.num_angle_bin (angle_per_cls = 2 pi / num_angle_bin, :63) */
+  int32_t cls_kind;      /* VDETR_CLS_* */
+  /* inputs: head outputs in the Conv1d layout [B, channels, N] (:286-301 transposes views of these) */
+  const float *center, *size;         /* [B,3,N] */
+  const float *angle_cls, *angle_res; /* [B,A,N] */
+  const float* cls;                   /* [B,C1,N] */
+  const float *pre_center_norm, *pre_size_norm; /* [B,N,3] prior the stage refines (:278-284), no gradient */
+  const float *dims_min, *dims_max;   /* [B,3] point_cloud_dims */
+  /* outputs [B,N,3] */
+  float *center_reg, *size_reg, *center_unnorm, *center_norm, *size_unnorm, *size_norm, *pre_center_unnorm, *pre_size_unnorm;
+  float* angle_residual;            /* [B,N,A] = angle_res^T * pi / A (:303) */
+  float *angle_cont, *angle_prob;   /* [B,N] */
+  int32_t* angle_class;             /* [B,N] arg-max bin (saved for backward) */
+  float* corners;                   /* [B,N,8,3] camera frame */
+  float* corners_aa;                /* [B,N,8,3] zero-angle corners, or NULL (with A == 1 they equal `corners`) */
+  float* cls_prob;                  /* [B,N,C1-1] (VDETR_CLS_SOFTMAX) or NULL */
+  float* objectness;                /* [B,N] */
+} vdetr_box_decode_desc;
+
+/* Gradients w.r.t. the forward's outputs (each may be NULL = unused) and w.r.t. the head outputs (required). */
+typedef struct vdetr_box_decode_grads {
+  const float *center_reg, *size_reg, *center_unnorm, *center_norm, *size_unnorm, *size_norm; /* [B,N,3] */
+  const float* angle_residual;          /* [B,N,A] */
+  const float *angle_cont, *angle_prob; /* [B,N] */
+  const float *corners, *corners_aa;    /* [B,N,8,3] */
+  float *d_center, *d_size;             /* [B,3,N] */
+  float *d_angle_cls, *d_angle_res;     /* [B,A,N] */
+} vdetr_box_decode_grads;
+
+int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stream);
+/* `d` as passed to the forward (inputs + the saved outputs size_unnorm, pre_size_unnorm, angle_cont, angle_class). */
+int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

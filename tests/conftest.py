@@ -61,7 +61,7 @@ class _OracleExt:
 
 @pytest.fixture
 def cpu_oracle_backend(monkeypatch):
-    """Routes the two native entry points of the host modules to the CPU oracle so that the HOST logic (module wiring,
+    """Routes the native entry points of the host modules (attention, pointnet2 ops, box decode) to the CPU oracle so that the HOST logic (module wiring,
     box decode, top-k, state-dict layout) can be checked without a GPU.  The product never does this."""
     import vdetr_amd.attention as A
     import vdetr_amd.pointnet2_utils as PU
@@ -76,6 +76,9 @@ def cpu_oracle_backend(monkeypatch):
 
     monkeypatch.setattr(A, "attention_probabilities", probs)
     monkeypatch.setattr(PU, "_ext", _OracleExt())
+    import vdetr_amd.box_decode as BD
+    from oracle.box_oracle import decode_boxes_reference
+    monkeypatch.setattr(BD, "decode_boxes", decode_boxes_reference)
     yield
 
 

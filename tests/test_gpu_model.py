@@ -74,6 +74,9 @@ def test_model_forward_backward_vs_cpu_oracle(angle_type, batch, monkeypatch):
     monkeypatch.setattr(A, "begin_step", lambda device: None)
     monkeypatch.setattr(A, "current_rng", lambda device: None)
     monkeypatch.setattr(PU, "_ext", _OracleExt())
+    import vdetr_amd.box_decode as BD
+    from oracle.box_oracle import decode_boxes_reference
+    monkeypatch.setattr(BD, "decode_boxes", decode_boxes_reference)
     out_cpu = ref_model(inp_cpu)
     _loss(out_cpu).backward()
     assert torch.equal(out_gpu["seed_inds"].cpu(), out_cpu["seed_inds"])          # FPS: bit-exact

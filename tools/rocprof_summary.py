@@ -34,6 +34,17 @@ def main():
         t0 = marks[warmup * per_step - 1]
         rows = [r for r in rows if r[2] > t0]
         print(f"# first {warmup} steps dropped (auto-tuning), {steps} steady-state steps summarised")
+    if "--timeline" in sys.argv:  # dispatch sequence of the last traced step, in start order, with gaps
+        marks = sorted(e for n, _, _, e in rows if "FusedOptimizerTensorListMetadata" in n)
+        per_step = len(marks) // max(steps, 1)
+        t0 = marks[-per_step - 1] if len(marks) > per_step else 0
+        seq = sorted((r for r in rows if r[2] > t0), key=lambda r: r[2])
+        prev = None
+        for n, d, st, en in seq:
+            gap = (st - prev) / 1e3 if prev is not None else 0.0
+            print(f"{(st - seq[0][2]) / 1e3:10.1f} {d:8.2f} {gap:7.2f}  {n[:150]}")
+            prev = en
+        return
     rows = [(n, d) for n, d, _, _ in rows]
     agg = defaultdict(list)
     for n, d in rows:

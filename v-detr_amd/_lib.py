@@ -31,6 +31,32 @@ class AttnDesc(ctypes.Structure):
     ]
 
 
+VDETR_CLS_SOFTMAX, VDETR_CLS_SIGMOID = 0, 1
+
+_BOX_IN = ("center", "size", "angle_cls", "angle_res", "cls", "pre_center_norm", "pre_size_norm", "dims_min", "dims_max")
+_BOX_OUT = ("center_reg", "size_reg", "center_unnorm", "center_norm", "size_unnorm", "size_norm", "pre_center_unnorm",
+            "pre_size_unnorm", "angle_residual", "angle_cont", "angle_prob", "angle_class", "corners", "corners_aa",
+            "cls_prob", "objectness")
+
+
+class BoxDecodeDesc(ctypes.Structure):
+    """Mirror of ``vdetr_box_decode_desc`` (include/vdetr_hip.h)."""
+
+    _fields_ = ([(n, ctypes.c_int32) for n in ("B", "N", "A", "C1", "num_angle_bin", "cls_kind")] +
+                [(n, c_void_p) for n in _BOX_IN + _BOX_OUT])
+
+
+_BOX_GRAD_IN = ("center_reg", "size_reg", "center_unnorm", "center_norm", "size_unnorm", "size_norm", "angle_residual",
+                "angle_cont", "angle_prob", "corners", "corners_aa")
+_BOX_GRAD_OUT = ("d_center", "d_size", "d_angle_cls", "d_angle_res")
+
+
+class BoxDecodeGrads(ctypes.Structure):
+    """Mirror of ``vdetr_box_decode_grads``."""
+
+    _fields_ = [(n, c_void_p) for n in _BOX_GRAD_IN + _BOX_GRAD_OUT]
+
+
 # name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
 _SIGNATURES = {
     "vdetr_abi_version": (c_int, []),
@@ -51,6 +77,8 @@ _SIGNATURES = {
     "vdetr_attn_bwd_scores_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_dropout_mask_u8": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
     "vdetr_rpe_bias_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
+    "vdetr_box_decode_fwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), c_void_p]),
+    "vdetr_box_decode_bwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), ctypes.POINTER(BoxDecodeGrads), c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -1,0 +1,229 @@
+// box_decode.hip — head outputs -> box parameters, corners and class probabilities of one decoder stage, forward and
+// backward, as ONE launch each.
+//
+// Reference: TransformerDecoder.get_proposal_box_predictions_refine (models/vdetr_transformer.py:244-333) with
+// BoxProcessor (:20-90), ScannetDatasetConfig.box_parametrization_to_corners (datasets/scannet.py:168-171) and
+// get_3d_box_batch_tensor / flip_axis_to_camera_tensor / roty_batch_tensor (utils/box_util.py:294-352).  The reference
+// spends ~45 ATen kernels per stage on [B, nQ, <=24] tensors here (and as many again in backward); with 9 stages per
+// step that was ~800 of the step's 2,650 dispatches, each of which costs ~4.5 us on MI355X however little it does.
+// One thread per (scene, query): channel-major head outputs [B, ch, N] are read coalesced across the queries.
+#include "common.h"
+
+namespace vdetr {
+
+constexpr int kMaxAngleBins = 32;
+constexpr float kPi = 3.14159265358979323846f;
+// corner sign pattern of get_3d_box_batch_tensor (box_util.py:338-346): x = +-l/2, y = +-h/2, z = +-w/2
+__device__ __constant__ float kSX[8] = {0.5f, 0.5f, -0.5f, -0.5f, 0.5f, 0.5f, -0.5f, -0.5f};
+__device__ __constant__ float kSY[8] = {0.5f, 0.5f, 0.5f, 0.5f, -0.5f, -0.5f, -0.5f, -0.5f};
+__device__ __constant__ float kSZ[8] = {0.5f, -0.5f, -0.5f, 0.5f, 0.5f, -0.5f, -0.5f, 0.5f};
+
+// corners of a box: size (l, w, h), yaw (cos c, sin s), centre in the CAMERA frame (box_util.py:319-352)
+__device__ __forceinline__ void box_corners(float l, float w, float h, float c, float s, float cx, float cy, float cz,
+                                            float* out /* 8 x 3 */) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float lx = l * kSX[i], ly = h * kSY[i], lz = w * kSZ[i];
+    out[i * 3 + 0] = (lx * c + lz * s) + cx;  // local @ roty(angle)^T
+    out[i * 3 + 1] = ly + cy;
+    out[i * 3 + 2] = (lz * c - lx * s) + cz;
+  }
+}
+
+__global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_desc d) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= d.B * d.N) return;
+  const int b = t / d.N, n = t - b * d.N;
+  const size_t o3 = (size_t)t * 3;
+  float dmin[3], scene[3], pcu[3], psu[3], cu[3], su[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    dmin[a] = d.dims_min[b * 3 + a];
+    scene[a] = d.dims_max[b * 3 + a] - dmin[a];
+    pcu[a] = d.pre_center_norm[o3 + a] * scene[a] + dmin[a];
+    psu[a] = d.pre_size_norm[o3 + a] * scene[a];
+    const float creg = d.center[((size_t)b * 3 + a) * d.N + n];
+    const float sreg = d.size[((size_t)b * 3 + a) * d.N + n];
+    cu[a] = creg * psu[a] + pcu[a];
+    su[a] = expf(sreg) * psu[a];
+    d.center_reg[o3 + a] = creg;
+    d.size_reg[o3 + a] = sreg;
+    d.pre_center_unnorm[o3 + a] = pcu[a];
+    d.pre_size_unnorm[o3 + a] = psu[a];
+    d.center_unnorm[o3 + a] = cu[a];
+    d.center_norm[o3 + a] = (cu[a] - dmin[a]) / scene[a];
+    d.size_unnorm[o3 + a] = su[a];
+    d.size_norm[o3 + a] = su[a] / scene[a];
+  }
+  // ---- angle (BoxProcessor.compute_predicted_angle, :48-71) --------------------------------------------------------
+  const int A = d.A;
+  float angle = 0.f, prob = 0.f;
+  int cls = 0;
+  const float res_scale = kPi / (float)A;
+  if (A == 1) {
+    const float al = d.angle_cls[(size_t)b * d.N + n], ar = d.angle_res[(size_t)b * d.N + n] * res_scale;
+    d.angle_residual[t] = ar;
+    angle = fmaxf(al * 0.f + ar * 0.f, 0.f);  // (:53-55) the head outputs stay in the graph, multiplied by zero
+    prob = angle;
+  } else {
+    float mx = -INFINITY;
+    for (int a = 0; a < A; ++a) {
+      const float al = d.angle_cls[((size_t)b * A + a) * d.N + n];
+      if (al > mx) { mx = al; cls = a; }  // first maximum
+    }
+    float den = 0.f, rsel = 0.f;
+    for (int a = 0; a < A; ++a) {
+      den += expf(d.angle_cls[((size_t)b * A + a) * d.N + n] - mx);
+      const float ar = d.angle_res[((size_t)b * A + a) * d.N + n] * res_scale;
+      d.angle_residual[(size_t)t * A + a] = ar;
+      if (a == cls) rsel = ar;
+    }
+    prob = 1.f / den;
+    angle = (2.f * kPi / (float)d.num_angle_bin) * (float)cls + rsel;
+    if (angle > kPi) angle -= 2.f * kPi;
+  }
+  d.angle_cont[t] = angle;
+  d.angle_prob[t] = prob;
+  d.angle_class[t] = cls;
+  // ---- corners (camera frame: (x, -z, y), box_util.py:294-301) -----------------------------------------------------
+  float cor[24];
+  box_corners(su[0], su[1], su[2], cosf(angle), sinf(angle), cu[0], -cu[2], cu[1], cor);
+#pragma unroll
+  for (int i = 0; i < 24; ++i) d.corners[(size_t)t * 24 + i] = cor[i];
+  if (d.corners_aa) {  // zero-angle corners (:311-316); with one angle bin the caller reuses `corners`
+    box_corners(su[0], su[1], su[2], 1.f, 0.f, cu[0], -cu[2], cu[1], cor);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) d.corners_aa[(size_t)t * 24 + i] = cor[i];
+  }
+  // ---- class probabilities (BoxProcessor.compute_objectness_and_cls_prob, :73-86; no gradient) ---------------------
+  const int C1 = d.C1;
+  if (d.cls_kind == VDETR_CLS_SOFTMAX) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C1; ++c) mx = fmaxf(mx, d.cls[((size_t)b * C1 + c) * d.N + n]);
+    float den = 0.f;
+    for (int c = 0; c < C1; ++c) den += expf(d.cls[((size_t)b * C1 + c) * d.N + n] - mx);
+    const float inv = 1.f / den;
+    float last = 0.f;
+    for (int c = 0; c < C1; ++c) {
+      const float p = expf(d.cls[((size_t)b * C1 + c) * d.N + n] - mx) * inv;
+      if (c < C1 - 1) d.cls_prob[(size_t)t * (C1 - 1) + c] = p;
+      else last = p;
+    }
+    d.objectness[t] = 1.f - last;
+  } else {  // focal loss: sem_cls_prob IS the logits (a view on the caller's side); objectness = max sigmoid
+    float mx = -INFINITY;
+    for (int c = 0; c < C1; ++c) mx = fmaxf(mx, d.cls[((size_t)b * C1 + c) * d.N + n]);
+    d.objectness[t] = 1.f / (1.f + expf(-mx));
+  }
+}
+
+// Backward: every incoming gradient pointer may be NULL (that output was not used).
+__global__ __launch_bounds__(256) void box_decode_bwd_kernel(vdetr_box_decode_desc d, vdetr_box_decode_grads g) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= d.B * d.N) return;
+  const int b = t / d.N, n = t - b * d.N;
+  const size_t o3 = (size_t)t * 3;
+  auto ld = [](const float* p, size_t i) { return p ? p[i] : 0.f; };
+  float scene[3], psu[3], su[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    scene[a] = d.dims_max[b * 3 + a] - d.dims_min[b * 3 + a];
+    psu[a] = d.pre_size_unnorm[o3 + a];
+    su[a] = d.size_unnorm[o3 + a];
+  }
+  // gradients of the unnormalised centre / size / angle, starting with the direct uses
+  float gcu[3], gsu[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    gcu[a] = ld(g.center_unnorm, o3 + a) + ld(g.center_norm, o3 + a) / scene[a];
+    gsu[a] = ld(g.size_unnorm, o3 + a) + ld(g.size_norm, o3 + a) / scene[a];
+  }
+  float gang = ld(g.angle_cont, t);
+  const float angle = d.angle_cont[t];
+  // corners: x' = lx c + lz s + cx, y' = ly + cy, z' = lz c - lx s + cz, (lx, ly, lz) = (l sx, h sy, w sz)
+  auto corner_grads = [&](const float* gc, float c, float s, bool with_angle) {
+    if (!gc) return;
+    float gl = 0.f, gw = 0.f, gh = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, gth = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float gxi = gc[(size_t)t * 24 + i * 3], gyi = gc[(size_t)t * 24 + i * 3 + 1], gzi = gc[(size_t)t * 24 + i * 3 + 2];
+      gx += gxi; gy += gyi; gz += gzi;
+      gl += kSX[i] * (c * gxi - s * gzi);
+      gh += kSY[i] * gyi;
+      gw += kSZ[i] * (s * gxi + c * gzi);
+      const float lx = su[0] * kSX[i], lz = su[1] * kSZ[i];
+      gth += gxi * (lz * c - lx * s) + gzi * (-lz * s - lx * c);
+    }
+    gsu[0] += gl; gsu[1] += gw; gsu[2] += gh;
+    gcu[0] += gx; gcu[2] -= gy; gcu[1] += gz;  // camera (x, -z, y)
+    if (with_angle) gang += gth;
+  };
+  corner_grads(g.corners, cosf(angle), sinf(angle), true);
+  corner_grads(g.corners_aa, 1.f, 0.f, false);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    g.d_center[((size_t)b * 3 + a) * d.N + n] = ld(g.center_reg, o3 + a) + gcu[a] * psu[a];
+    g.d_size[((size_t)b * 3 + a) * d.N + n] = ld(g.size_reg, o3 + a) + gsu[a] * su[a];
+  }
+  const int A = d.A;
+  const float res_scale = kPi / (float)A;
+  if (A == 1) {
+    // angle = clamp(0*logit + 0*residual, 0): the head outputs only receive the direct residual gradient (x0 paths
+    // contribute exact zeros unless the incoming gradient is not finite, which the reference would also spread)
+    const float z = (gang + ld(g.angle_prob, t)) * 0.f;
+    g.d_angle_cls[(size_t)b * d.N + n] = z;
+    g.d_angle_res[(size_t)b * d.N + n] = ld(g.angle_residual, t) * res_scale + z * res_scale;
+  } else {
+    const int cls = d.angle_class[t];
+    const float gp = ld(g.angle_prob, t);
+    float mx = -INFINITY;
+    for (int a = 0; a < A; ++a) mx = fmaxf(mx, d.angle_cls[((size_t)b * A + a) * d.N + n]);
+    float den = 0.f;
+    for (int a = 0; a < A; ++a) den += expf(d.angle_cls[((size_t)b * A + a) * d.N + n] - mx);
+    const float pc = 1.f / den;  // = softmax at the arg-max
+    for (int a = 0; a < A; ++a) {
+      const float pa = expf(d.angle_cls[((size_t)b * A + a) * d.N + n] - mx) / den;
+      g.d_angle_cls[((size_t)b * A + a) * d.N + n] = gp * pc * ((a == cls ? 1.f : 0.f) - pa);
+      g.d_angle_res[((size_t)b * A + a) * d.N + n] =
+          (ld(g.angle_residual, (size_t)t * A + a) + (a == cls ? gang : 0.f)) * res_scale;
+    }
+  }
+}
+
+}  // namespace vdetr
+
+using namespace vdetr;
+
+static int box_check(const vdetr_box_decode_desc* d, const char* op) {
+  VDETR_REQUIRE(d != nullptr, "%s: null descriptor", op);
+  VDETR_REQUIRE(d->B > 0 && d->N > 0 && d->A > 0 && d->C1 > 0, "%s: empty dimension B=%d N=%d A=%d C1=%d", op, d->B,
+                d->N, d->A, d->C1);
+  VDETR_REQUIRE(d->A <= kMaxAngleBins, "%s: %d angle bins > %d", op, d->A, kMaxAngleBins);
+  VDETR_REQUIRE(d->num_angle_bin > 0, "%s: num_angle_bin must be positive", op);
+  VDETR_REQUIRE(d->cls_kind == VDETR_CLS_SOFTMAX || d->cls_kind == VDETR_CLS_SIGMOID, "%s: bad cls_kind %d", op, d->cls_kind);
+  VDETR_REQUIRE(d->center && d->size && d->angle_cls && d->angle_res && d->cls && d->pre_center_norm && d->pre_size_norm &&
+                    d->dims_min && d->dims_max, "%s: null input pointer", op);
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stream) {
+  if (int e = box_check(d, "box_decode_fwd")) return e;
+  VDETR_REQUIRE(d->center_reg && d->size_reg && d->center_unnorm && d->center_norm && d->size_unnorm && d->size_norm &&
+                    d->pre_center_unnorm && d->pre_size_unnorm && d->angle_residual && d->angle_cont && d->angle_prob &&
+                    d->angle_class && d->corners && d->objectness,
+                "box_decode_fwd: null output pointer");
+  VDETR_REQUIRE(d->cls_kind != VDETR_CLS_SOFTMAX || d->cls_prob, "box_decode_fwd: cls_prob is required for the softmax kind");
+  hipLaunchKernelGGL(box_decode_fwd_kernel, dim3(ceil_div((long)d->B * d->N, 256)), dim3(256), 0, (hipStream_t)stream, *d);
+  return check_launch("box_decode_fwd");
+}
+
+extern "C" int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g,
+                                        vdetr_stream_t stream) {
+  if (int e = box_check(d, "box_decode_bwd")) return e;
+  VDETR_REQUIRE(g != nullptr, "box_decode_bwd: null gradient block");
+  VDETR_REQUIRE(d->size_unnorm && d->pre_size_unnorm && d->angle_cont && d->angle_class,
+                "box_decode_bwd: the forward's size_unnorm / pre_size_unnorm / angle_cont / angle_class are required");
+  VDETR_REQUIRE(g->d_center && g->d_size && g->d_angle_cls && g->d_angle_res, "box_decode_bwd: null output pointer");
+  hipLaunchKernelGGL(box_decode_bwd_kernel, dim3(ceil_div((long)d->B * d->N, 256)), dim3(256), 0, (hipStream_t)stream, *d, *g);
+  return check_launch("box_decode_bwd");
+}

@@ -384,10 +384,10 @@ extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n,
   static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
   if (debug) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_fps_cyc), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_cyc), z, sizeof(z));
     hipLaunchKernelGGL(fps_kernel<true>, dim3(b), dim3(kFpsThreads), 0, (hipStream_t)stream, P);
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fps_cyc), sizeof(z));
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fps_cyc), sizeof(z));
     for (int i = 0; i < 2; ++i)
       fprintf(stderr, "[fps debug] wave %d cycles/round: buckets %llu, wave-argmax+lds %llu, barrier wait %llu, decode %llu\n",
               i ? 7 : 0, z[i * 4] / (m - 1), z[i * 4 + 1] / (m - 1), z[i * 4 + 2] / (m - 1), z[i * 4 + 3] / (m - 1));

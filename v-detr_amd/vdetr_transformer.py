@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import attention as A
+from . import box_decode
 from .helpers import ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PositionEmbeddingLearned, get_clones
 from .pc_util import morton_argsort, scale_points, shift_scale_points
 
@@ -514,57 +515,12 @@ class TransformerDecoder(nn.Module):
         centre / size: centre = reg * size_prior + centre_prior, size = exp(reg) * size_prior (reference :244-333)."""
         assert pre_center_normalized is not None and pre_size_normalized is not None
         feats = box_features.permute(1, 2, 0)  # B x C x nQ
-        batch, _, nq = feats.shape
         heads = self.mlp_heads[idx] if self.mlp_sep else self.mlp_heads
-        dmin = point_cloud_dims[0].unsqueeze(1)
-        scene_size = (point_cloud_dims[1] - point_cloud_dims[0]).unsqueeze(1)
-        pre_center_unnormalized = pre_center_normalized * scene_size + dmin
-        pre_size_unnormalized = pre_size_normalized * scene_size
-
         raw = self._run_heads(heads, feats)
-        cls_logits = raw["sem_cls_head"].transpose(1, 2)
-        center_reg = raw["center_head"].transpose(1, 2).contiguous().view(batch, nq, 3)
-        center_unnormalized = center_reg * pre_size_unnormalized + pre_center_unnormalized
-        center_normalized = (center_unnormalized - dmin) / scene_size
-        size_reg = raw["size_head"].transpose(1, 2).contiguous().view(batch, nq, 3)
-        size_unnormalized = torch.exp(size_reg) * pre_size_unnormalized
-        size_normalized = size_unnormalized / scene_size
-        angle_logits = raw["angle_cls_head"].transpose(1, 2)
-        angle_residual_normalized = raw["angle_residual_head"].transpose(1, 2)
-        angle_residual = angle_residual_normalized * (np.pi / angle_residual_normalized.shape[-1])
-        angle_continuous, angle_prob = self.box_processor.compute_predicted_angle(angle_logits, angle_residual)
-        box_corners = self.box_processor.box_parametrization_to_corners(center_unnormalized, size_unnormalized,
-                                                                        angle_continuous)
-        if angle_logits.shape[-1] == 1:
-            # one angle bin: angle_continuous IS the zero angle (:53-55), so the axis-aligned corners are the same
-            # tensor values; computed once instead of twice
-            box_corners_axis_align = box_corners
-        else:
-            angle_zero, _ = self.box_processor.compute_predicted_angle(angle_logits, angle_residual, zero_angle=True)
-            box_corners_axis_align = self.box_processor.box_parametrization_to_corners(center_unnormalized,
-                                                                                       size_unnormalized, angle_zero)
-        with torch.no_grad():
-            semcls_prob, objectness_prob = self.box_processor.compute_objectness_and_cls_prob(cls_logits)
-        return {
-            "sem_cls_logits": cls_logits,
-            "center_normalized": center_normalized.contiguous(),
-            "center_unnormalized": center_unnormalized,
-            "size_normalized": size_normalized,
-            "size_unnormalized": size_unnormalized,
-            "angle_logits": angle_logits,
-            "angle_prob": angle_prob,
-            "angle_residual": angle_residual,
-            "angle_residual_normalized": angle_residual_normalized,
-            "angle_continuous": angle_continuous,
-            "objectness_prob": objectness_prob,
-            "sem_cls_prob": semcls_prob,
-            "box_corners": box_corners,
-            "box_corners_axis_align": box_corners_axis_align,
-            "pre_box_center_unnormalized": pre_center_unnormalized,
-            "center_reg": center_reg,
-            "pre_box_size_unnormalized": pre_size_unnormalized,
-            "size_reg": size_reg,
-        }
+        # everything after the heads (:286-333: ~45 ATen launches on [B,nQ,<=24] tensors, as many again in backward)
+        # is one HIP launch forward and one backward
+        return box_decode.decode_boxes(raw, pre_center_normalized, pre_size_normalized, point_cloud_dims,
+                                       self.box_processor.dataset_config.num_angle_bin, self.box_processor.cls_loss)
 
     def forward(self, tgt, memory, query_xyz, enc_xyz, point_cloud_dims, tgt_mask=None, memory_mask=None,
                 tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
