@@ -8,7 +8,27 @@ parameter NAMES and numerics matter for checkpoint compatibility:
 import copy
 from functools import partial
 
+import torch
 import torch.nn as nn
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """``nn.Conv1d(cin, cout, kernel_size=1)`` (same parameters, same state-dict entries) evaluated as the GEMM it is.
+
+    MIOpen wraps every such convolution in layout transposes and spends ~4.5 launches on its backward; a [cout, cin] x
+    [cin, N] GEMM is one launch forward and two backward, and on MI355X the step pays ~4.5 us per launch whatever its
+    size (profiles/)."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__(in_channels, out_channels, 1, bias=bias)
+
+    def forward(self, x):
+        w = self.weight.squeeze(-1)
+        if x.shape[0] == 1:
+            y = torch.mm(w, x.reshape(x.shape[1], x.shape[2])).unsqueeze(0)  # view, not x[0]: SelectBackward is a fill + a copy
+        else:
+            y = torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
+        return y if self.bias is None else y + self.bias.view(1, -1, 1)
 
 
 class BatchNormDim1Swap(nn.BatchNorm1d):
@@ -29,10 +49,10 @@ class PositionEmbeddingLearned(nn.Module):
     def __init__(self, input_channel, num_pos_feats=288):
         super().__init__()
         self.position_embedding_head = nn.Sequential(
-            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            PointwiseConv1d(input_channel, num_pos_feats),
             nn.BatchNorm1d(num_pos_feats),
             nn.ReLU(inplace=True),
-            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1),
+            PointwiseConv1d(num_pos_feats, num_pos_feats),
         )
 
     def forward(self, xyz):
@@ -58,7 +78,7 @@ class GenericMLP(nn.Module):
             dropout = [dropout] * len(hidden_dims)
 
         def affine(cin, cout, bias):
-            return nn.Conv1d(cin, cout, 1, bias=bias) if use_conv else nn.Linear(cin, cout, bias=bias)
+            return PointwiseConv1d(cin, cout, bias=bias) if use_conv else nn.Linear(cin, cout, bias=bias)
 
         mods, cin = [], input_dim
         for i, width in enumerate(hidden_dims):

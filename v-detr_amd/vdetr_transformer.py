@@ -26,7 +26,8 @@ from torch import Tensor, nn
 
 from . import attention as A
 from . import box_decode
-from .helpers import ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PositionEmbeddingLearned, get_clones
+from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
+                      PositionEmbeddingLearned, get_clones)
 from .pc_util import morton_argsort, scale_points, shift_scale_points
 
 _salt_counter = itertools.count(1)
@@ -462,7 +463,8 @@ class TransformerDecoder(nn.Module):
             l = heads[n].layers
             if len(l) != 9:
                 return False
-            kinds = (nn.Conv1d, nn.BatchNorm1d, nn.ReLU, nn.Dropout, nn.Conv1d, nn.BatchNorm1d, nn.ReLU, nn.Dropout, nn.Conv1d)
+            kinds = (PointwiseConv1d, nn.BatchNorm1d, nn.ReLU, nn.Dropout, PointwiseConv1d, nn.BatchNorm1d, nn.ReLU,
+                     nn.Dropout, PointwiseConv1d)
             if any(type(m) is not k for m, k in zip(l, kinds)) or l[0].bias is not None or l[4].bias is not None:
                 return False
         return True
@@ -494,14 +496,15 @@ class TransformerDecoder(nn.Module):
         L = [heads[n].layers for n in names]
         G, C = len(L), feats.shape[1]
         Bsz, _, N = feats.shape
-        x = F.conv1d(feats, torch.cat([l[0].weight for l in L], 0))                       # [B, G*C, N]
+        w1 = torch.cat([l[0].weight for l in L], 0).squeeze(-1)                          # [G*C, C]
+        x = torch.mm(w1, feats.reshape(C, N)).unsqueeze(0) if Bsz == 1 else torch.matmul(w1, feats)  # [B, G*C, N]
         x = F.dropout(F.relu(self._bn_group(x, [l[1] for l in L], self.training)), L[0][3].p, self.training)
         w2 = torch.stack([l[4].weight.squeeze(-1) for l in L])                           # [G, C, C]
         x = torch.matmul(w2.unsqueeze(0), x.view(Bsz, G, C, N)).view(Bsz, G * C, N)
         x = F.dropout(F.relu(self._bn_group(x, [l[5] for l in L], self.training)), L[0][7].p, self.training)
         # unbind (one stack kernel in backward) rather than five slices (five zero-fills + copies + adds)
         xs = x.view(Bsz, G, C, N).unbind(1)
-        return {n: F.conv1d(xs[g], L[g][8].weight, L[g][8].bias) for g, n in enumerate(names)}
+        return {n: L[g][8](xs[g]) for g, n in enumerate(names)}
 
     def _reset_parameters(self, weight_init_name):
         init = WEIGHT_INIT_DICT[weight_init_name]
