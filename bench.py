@@ -119,8 +119,8 @@ class Trainer:
             self.inputs["fps_inds"] = self.cur_inds
         self.loss = loss_fn(self.model(self.inputs))
         self.loss.backward()
-        if self.world == 1:
-            self.flat.pack_grads()  # N>1: the reducer packs (and averages) them
+        if not self.hooked:
+            self.flat.pack_grads()  # one launch; (hooked eager mode accumulates straight into the flat buffer)
         if self.fps_prefetch:
             main.wait_stream(self.side)
             self.cur_inds.copy_(next_inds)
@@ -146,8 +146,7 @@ class Trainer:
             if self.world == 1:
                 self._update()
         if self.world > 1:
-            self.graph_grads = [p.grad for p in self.params]  # static buffers of the captured backward
-            self.reducer.pack_and_reduce(self.graph_grads)    # p.grad -> bucket views, which the update graph reads
+            self.reducer.reduce_all()  # the flat gradient buffer, in slices; not captured (RCCL outside the graph)
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt):
                 self._update()
@@ -156,14 +155,14 @@ class Trainer:
         if self.g_main is not None:
             self.g_main.replay()
             if self.world > 1:
-                self.reducer.pack_and_reduce(self.graph_grads)
+                self.reducer.reduce_all()
                 self.g_opt.replay()
         else:
             self._fwd_bwd()
             if self.hooked:
                 self.reducer.finish()
             elif self.world > 1:
-                self.reducer.pack_and_reduce()
+                self.reducer.reduce_all()
             self._update()
 
 

@@ -211,6 +211,22 @@ int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stre
 /* `d` as passed to the forward (inputs + the saved outputs size_unnorm, pre_size_unnorm, angle_cont, angle_class). */
 int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, vdetr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Gradient packing: n separate fp32 tensors -> slices of one flat buffer, one launch.  The role of the bucket copy in
+ * DistributedDataParallel's reducer (reference main.py:515-517).  All three tables are DEVICE arrays:
+ *   entries[e]      = {src (NULL = zero-fill), dst_offset (floats), numel}
+ *   block_entry[b], block_chunk[b]: workgroup b copies floats [chunk * C, (chunk+1) * C) of entry block_entry[b],
+ *   C = vdetr_pack_chunk_floats().
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vdetr_pack_entry {
+  const void* src;
+  uint64_t dst_offset;
+  uint64_t numel;
+} vdetr_pack_entry;
+int vdetr_pack_chunk_floats(void);
+int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk, int nblocks,
+                   float* dst, vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

@@ -185,3 +185,29 @@ def test_captured_step_replays_with_fresh_dropout():
     assert all(np.isfinite(losses))
     assert offsets[1] == offsets[0] + 1 and offsets[2] == offsets[1] + 1   # device-side RNG offset advances per replay
     assert len(set(losses)) == 3                                            # different masks / updated weights
+
+
+def test_flat_params_pack_one_launch():
+    """vdetr_pack_f32: scattered gradient tensors (odd sizes, a missing one, a non-contiguous one) -> flat buffer."""
+    from vdetr_amd.dist import FlatParams
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    shapes = [(3,), (257, 33), (1,), (40000,), (7, 5, 3), (8192,), (8193,), (64, 64)]
+    params = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    before = [p.detach().clone() for p in params]
+    flat = FlatParams(params)
+    for p, b in zip(params, before):
+        assert torch.equal(p.detach(), b)
+    for rep in range(2):
+        grads = [torch.randn(s, device=dev) for s in shapes]
+        grads[2] = None
+        grads[1] = torch.randn((33, 257), device=dev).t()  # non-contiguous
+        for p, g in zip(params, grads):
+            p.grad = g
+        flat.pack_grads()
+        torch.cuda.synchronize()
+        for p, g in zip(params, grads):
+            off = flat.offsets[id(p)]
+            got = flat.grad[off:off + p.numel()].view(p.shape)
+            want = torch.zeros_like(p) if g is None else g
+            assert torch.equal(got, want), p.shape

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "vdetr_rpe_bias_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
     "vdetr_box_decode_fwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), c_void_p]),
     "vdetr_box_decode_bwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), ctypes.POINTER(BoxDecodeGrads), c_void_p]),
+    "vdetr_pack_chunk_floats": (c_int, []),
+    "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

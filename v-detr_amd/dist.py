@@ -73,9 +73,13 @@ class FlatParams:
         self.param.grad = self.grad
 
     def pack_grads(self, grads=None):
-        """``p.grad`` (or the given tensors, in ``self.params`` order) -> the flat gradient buffer, with one
-        multi-tensor copy; parameters that received no gradient contribute zeros."""
+        """``p.grad`` (or the given tensors, in ``self.params`` order) -> the flat gradient buffer; parameters that
+        received no gradient contribute zeros.  GPU: ONE launch of ``vdetr_pack_f32`` (the source-pointer table goes up
+        through pinned memory; inside a hipGraph capture that upload is a captured copy node and the captured gradient
+        buffers are static).  CPU tensors (gloo tests of the host logic): multi-tensor copy."""
         src = [p.grad for p in self.params] if grads is None else list(grads)
+        if self.grad.is_cuda:
+            return self._pack_hip(src)
         have_v = [v for v, g in zip(self.grad_views, src) if g is not None]
         have_g = [g for g in src if g is not None]
         missing = [v for v, g in zip(self.grad_views, src) if g is None]
@@ -83,6 +87,57 @@ class FlatParams:
             torch._foreach_zero_(missing)
         if have_g:
             torch._foreach_copy_(have_v, have_g)
+
+    def _pack_tables(self):
+        from . import _lib as L
+        chunk = L.lib().vdetr_pack_chunk_floats()
+        n = len(self.params)
+        tab = torch.zeros((n, 3), dtype=torch.int64)
+        be, bc = [], []
+        for i, p in enumerate(self.params):
+            tab[i, 1], tab[i, 2] = self.offsets[id(p)], p.numel()
+            nch = (p.numel() + chunk - 1) // chunk
+            be += [i] * nch
+            bc += list(range(nch))
+        dev = self.grad.device
+        self._pack = {"static": tab, "block_entry": torch.tensor(be, dtype=torch.int32, device=dev),
+                      "block_chunk": torch.tensor(bc, dtype=torch.int32, device=dev), "nblocks": len(be),
+                      "dev": torch.empty((n, 3), dtype=torch.int64, device=dev), "host": tab.clone().pin_memory(),
+                      "event": None, "captured": [],
+                      # pinned tables for hipGraph captures, allocated up front (no host allocation while capturing)
+                      "spare": [tab.clone().pin_memory() for _ in range(4)]}
+
+    def _pack_hip(self, src):
+        from . import _lib as L
+        if not hasattr(self, "_pack"):
+            self._pack_tables()
+        P = self._pack
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:  # a captured upload reads ITS host table at every replay: never reuse it
+            assert P["spare"], "FlatParams: more than 4 graph captures of pack_grads (call it once eagerly first)"
+            host = P["spare"].pop()
+            P["captured"].append(host)
+        else:
+            host = P["host"]
+            if P["event"] is not None:
+                P["event"].synchronize()  # the previous upload has left the pinned table
+        keep = []
+        for i, g in enumerate(src):
+            if g is None:
+                host[i, 0] = 0
+                continue
+            if g.dtype != self.grad.dtype or not g.is_contiguous():
+                g = g.to(self.grad.dtype).contiguous()
+                keep.append(g)
+            host[i, 0] = g.data_ptr()
+        P["dev"].copy_(host, non_blocking=True)
+        L.check(L.lib().vdetr_pack_f32(L.ptr(P["dev"]), L.ptr(P["block_entry"]), L.ptr(P["block_chunk"]), P["nblocks"],
+                                       L.ptr(self.grad), L.stream_ptr()), "pack")
+        if not capturing:
+            P["event"] = torch.cuda.Event()
+            P["event"].record()
+        for g in keep:
+            g.record_stream(torch.cuda.current_stream())
 
     def clip_scale(self, max_norm, eps=1e-6):
         """1 / clip coefficient of ``clip_grad_norm_(params, max_norm)`` as a device scalar: max(||g|| / max_norm, 1).
@@ -175,6 +230,12 @@ class GradientReducer:
         tensor or None per parameter, in ``self.params`` order) overrides ``p.grad`` as the source — the static
         gradient buffers of a captured hipGraph."""
         src = {id(p): (p.grad if grads is None else g) for p, g in zip(self.params, grads or self.params)}
+        if self.flat is not None:
+            self.flat.pack_grads([src[id(p)] for p in self.flat.params])
+            self.reduce_all()
+            for p, v in self._views:
+                p.grad = v
+            return
         have = [(src[id(p)], v) for p, v in self._views if src[id(p)] is not None]
         missing = [v for p, v in self._views if src[id(p)] is None]
         if missing:
