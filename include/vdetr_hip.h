@@ -127,6 +127,11 @@ typedef struct vdetr_attn_desc {
                                 (seed ^= state[0], offset += state[1]): a captured hipGraph can advance the
                                 device offset between replays, and modules sharing one state stay independent
                                 through their by-value seed */
+  /* --- strided K / V (forward only): floats between consecutive key rows, 0 = dense (64 shared-KV, H*64 per head).
+         Element (b, key, d) lives at k[(b*nK + key) * k_row_stride + d]; multiples of 4, base 16-B aligned.  Lets the
+         K/V of all decoder layers come out of ONE projection GEMM over the layer-invariant encoder features
+         (vdetr_transformer.py:733-735 runs self.k / self.v per layer on the same `key`). --- */
+  int32_t k_row_stride, v_row_stride;
 } vdetr_attn_desc;
 
 /* Scratch needed by fwd (key-split partials). */

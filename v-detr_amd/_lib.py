@@ -28,6 +28,7 @@ class AttnDesc(ctypes.Structure):
         ("mask", c_void_p), ("mask_kind", ctypes.c_int32),
         ("dropout_p", c_float), ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
         ("rng_state", c_void_p),
+        ("k_row_stride", ctypes.c_int32), ("v_row_stride", ctypes.c_int32),
     ]
 
 

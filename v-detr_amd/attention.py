@@ -73,8 +73,10 @@ def reset_rng(seed=None):
     _current.clear()
 
 
-def _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng_state, salt=0):
+def _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng_state, salt=0,
+          k_stride=0, v_stride=0):
     d = L.AttnDesc()
+    d.k_row_stride, d.v_row_stride = int(k_stride), int(v_stride)
     d.kind, d.B, d.H, d.nQ, d.nK, d.scale = kind, B, H, nQ, nK, float(scale)
     if table is not None:
         d.table = table.data_ptr()
@@ -117,12 +119,16 @@ class _FusedAttention(Function):
         B, nQ, C = q.shape
         nK = k.shape[1]
         assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
-        _check_inputs(q=q, k=k, v=v, table=table, vertices=vertices, xyz=xyz, cos_sin=cos_sin)
+        _check_inputs(q=q, table=table, vertices=vertices, xyz=xyz, cos_sin=cos_sin)
+        for name, t in (("k", k), ("v", v)):  # row-strided views are fine (see _kv_layout)
+            L.require_gpu(t, name)
+            L.require_float(t, name)
+        ks, vs = k.stride(1), v.stride(1)
         lib = L.lib()
         use_drop = dropout_p > 0.0
         rng = rng_state if use_drop else None  # a per-step snapshot nobody writes again (begin_step)
         d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p if use_drop else 0.0, rng,
-                  salt)
+                  salt, ks, vs)
         out = torch.empty_like(q)
         rows = (B, nQ, H) if kind == L.VDETR_ATTN_SHARED_KV else (B, H, nQ)
         lse = torch.empty(rows, dtype=torch.float32, device=q.device)
@@ -155,7 +161,7 @@ class _FusedAttention(Function):
             do_r = dout.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
             o_r = out.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
             delta = (do_r * o_r).sum(-1).view(B, H, nQ)
-            v_r = v.view(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
+            v_r = v.reshape(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
             dprob = torch.bmm(do_r, v_r.transpose(1, 2))  # [B*H, nQ, nK]
         delta = delta.contiguous()
         d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt)
@@ -182,11 +188,20 @@ class _FusedAttention(Function):
             p_r = scores.view(B * H, nQ, nK)
             ds_r = dprob
             q_r = q.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
-            k_r = k.view(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
+            k_r = k.reshape(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
             dv = torch.bmm(p_r.transpose(1, 2), do_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
             dk = (torch.bmm(ds_r.transpose(1, 2), q_r) * scale).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
             dq = (torch.bmm(ds_r, k_r) * scale).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         return (dq, dk, dv, dtable) + (None,) * 12
+
+
+def _kv_layout(t, B, nK):
+    """K / V as the kernel can read them: rows of contiguous floats at a constant row stride (a multiple of 4 floats,
+    16-B aligned base, batches nK rows apart) — e.g. a 64-wide column block of a wider projection output.  Anything
+    else is made contiguous."""
+    ok = (t.dim() == 3 and t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(1) >= t.shape[2] and
+          t.data_ptr() % 16 == 0 and (B == 1 or t.stride(0) == nK * t.stride(1)))
+    return t if ok else t.contiguous()
 
 
 def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
@@ -212,7 +227,8 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
         xyz = xyz.detach().contiguous()
         if cos_sin is not None:
             cos_sin = cos_sin.detach().contiguous()
-    return _FusedAttention.apply(q.contiguous(), k.contiguous(), v.contiguous(), table, vertices, xyz, cos_sin, mask,
+    k, v = _kv_layout(k, B, nK), _kv_layout(v, B, nK)
+    return _FusedAttention.apply(q.contiguous(), k, v, table, vertices, xyz, cos_sin, mask,
                                  kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt))
 
 

@@ -19,6 +19,7 @@ struct AttnParams {
   const float* q;
   const float* k;
   const float* v;
+  int k_stride, v_stride;  // floats between consecutive key rows
   float* out;
   float* lse;
   float* scores;

@@ -39,7 +39,6 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   const int rows_per_tile_q = PERHEAD ? 16 : 4;  // queries per workgroup
   const int q0 = blockIdx.x * rows_per_tile_q;
   const int qstride = H * kDh;                 // floats per query row of q / out
-  const int kvstride = PERHEAD ? H * kDh : kDh;
   const int kvoff = PERHEAD ? head * kDh : 0;
 
   const int table_floats = RPE ? kRpeVerts * P.T * P.T * P.T * 4 : 0;
@@ -96,13 +95,13 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   auto fetch = [&](int tile, TileOps& t) {
     const int key0 = tile << 4;
     const int keyc = min(key0 + c, nK - 1);
-    const f32x4* kp = reinterpret_cast<const f32x4*>(P.k + ((size_t)b * nK + keyc) * kvstride + kvoff + 16 * g);
+    const f32x4* kp = reinterpret_cast<const f32x4*>(P.k + ((size_t)b * nK + keyc) * P.k_stride + kvoff + 16 * g);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int kk = min(key0 + 4 * g + s, nK - 1);
-      t.vb[s] = *reinterpret_cast<const f32x4*>(P.v + ((size_t)b * nK + kk) * kvstride + kvoff + 4 * c);
+      t.vb[s] = *reinterpret_cast<const f32x4*>(P.v + ((size_t)b * nK + kk) * P.v_stride + kvoff + 4 * c);
     }
     if (RPE) {
       const float* xp = P.xyz + ((size_t)b * nK + keyc) * 3;
@@ -314,6 +313,11 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   VDETR_REQUIRE(d->mask_kind == VDETR_MASK_NONE || d->mask != nullptr, "%s: mask_kind set but mask is null", op);
   *P = AttnParams{};
   P->kind = d->kind; P->B = d->B; P->H = d->H; P->nQ = d->nQ; P->nK = d->nK; P->scale = d->scale;
+  const int dense = d->kind == VDETR_ATTN_PER_HEAD ? d->H * 64 : 64;
+  P->k_stride = d->k_row_stride ? d->k_row_stride : dense;
+  P->v_stride = d->v_row_stride ? d->v_row_stride : dense;
+  VDETR_REQUIRE(P->k_stride >= dense && P->v_stride >= dense && P->k_stride % 4 == 0 && P->v_stride % 4 == 0,
+                "%s: K/V row strides %d / %d must be multiples of 4 and >= %d", op, P->k_stride, P->v_stride, dense);
   P->table = d->table;
   if (d->table) {
     VDETR_REQUIRE(d->kind == VDETR_ATTN_SHARED_KV, "%s: RPE needs the shared-KV kind", op);

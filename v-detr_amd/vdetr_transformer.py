@@ -172,11 +172,38 @@ class GlobalShareCrossAttention(nn.Module):
         hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
         return torch.bmm(hid, w2.transpose(1, 2)).view(8, T, T, T, self.num_heads)
 
-    def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None):
-        key_b, query_b = key.permute(1, 0, 2), query.permute(1, 0, 2)
+    @staticmethod
+    def precompute(mods, key):
+        """K, V and RPE tables of SEVERAL cross-attention modules that see the same ``key`` [nK,B,C] (the decoder layers
+        all attend to the same encoder features): one [C -> n*128] projection GEMM instead of 2n small ones, and the
+        8n cpb MLPs as two batched GEMMs.  Returns a list of (k, v, tables) for ``forward(..., cache=)``; k / v are
+        64-wide column blocks of the joint projection (row-strided views, read in place by the kernel)."""
+        n = len(mods)
+        key_b = key.permute(1, 0, 2)
+        w = torch.cat([t for m in mods for t in (m.k.weight, m.v.weight)], 0)
+        b = torch.cat([t for m in mods for t in (m.k.bias, m.v.bias)], 0) if mods[0].k.bias is not None else None
+        kv = F.linear(key_b, w, b)                                                   # [B,nK,n*128]
+        parts = kv.view(kv.shape[0], kv.shape[1], 2 * n, -1).unbind(2)
+        mlps = [mm for m in mods for mm in m.cpb_mlps]
+        w1 = torch.stack([mm[0].weight for mm in mlps])
+        b1 = torch.stack([mm[0].bias for mm in mlps])
+        w2 = torch.stack([mm[2].weight for mm in mlps])
+        T, H = mods[0].relative_coords_table.shape[1], mods[0].num_heads
+        coords = mods[0].relative_coords_table.reshape(1, -1, 3).expand(8 * n, -1, -1)
+        hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
+        tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H).unbind(0)
+        return [(parts[2 * i], parts[2 * i + 1], tables[i]) for i in range(n)]
+
+    def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None,
+                cache=None):
+        query_b = query.permute(1, 0, 2)
         q = self.q(query_b)   # [B,nQ,C]
-        k = self.k(key_b)     # [B,nK,C/H]
-        v = self.v(key_b)
+        if cache is None:
+            key_b = key.permute(1, 0, 2)
+            k = self.k(key_b)     # [B,nK,C/H]
+            v = self.v(key_b)
+        else:
+            k, v = cache[0], cache[1]
         cos_sin = None
         if self.angle_type == "object_coords" and reference_angle is not None:
             ang = reference_angle.detach()
@@ -185,7 +212,7 @@ class GlobalShareCrossAttention(nn.Module):
         rng = A.current_rng(q.device) if p > 0 else None
         if p > 0 and rng is None:
             rng = A.begin_step(q.device)
-        tables = self.rpe_tables()
+        tables = self.rpe_tables() if cache is None else cache[2]
         x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, table=tables,
                               rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
                               attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt)
@@ -294,6 +321,7 @@ class GlobalDecoderLayer(nn.Module):
         if dropout_attn is None:
             dropout_attn = dropout
         self.pos_for_key = pos_for_key
+        self.cross_cache = None  # (k, v, tables) handed over by TransformerDecoder for the current forward
         if args.share_selfattn:
             self.self_attn = ShareSelfAttention(d_model, nhead, dropout=dropout)
         else:
@@ -318,9 +346,10 @@ class GlobalDecoderLayer(nn.Module):
     def _cross(self, tgt_in, memory, reference_point, reference_angle, enc_xyz, memory_mask,
                memory_key_padding_mask, pos, query_pos):
         key = self.with_pos_embed(memory, pos) if self.pos_for_key else memory
+        extra = {"cache": self.cross_cache} if self.cross_cache is not None else {}
         return self.multihead_attn(query=self.with_pos_embed(tgt_in, query_pos), key=key,
                                    reference_point=reference_point, reference_angle=reference_angle, xyz=enc_xyz,
-                                   attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)
+                                   attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask, **extra)
 
     def forward_pre(self, tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask=None,
                     memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None,
@@ -575,8 +604,16 @@ class TransformerDecoder(nn.Module):
             enc_xyz = torch.gather(enc_xyz, 1, key_order.unsqueeze(-1).expand(-1, -1, 3))
             memory = torch.gather(memory, 0, key_order.t().unsqueeze(-1).expand(-1, -1, memory.shape[-1]))
 
+        # ---- K / V / RPE tables of all layers in one go: every layer projects the SAME encoder features ----------
+        cross = [l.multihead_attn for l in self.layers]
+        caches = [None] * len(self.layers)
+        if (not self.pos_for_key and all(type(m) is GlobalShareCrossAttention for m in cross) and
+                not any(l.pos_for_key for l in self.layers)):
+            caches = GlobalShareCrossAttention.precompute(cross, memory)
+
         # ---- decoder layers with box feedback (:407-436) ---------------------------------------------------
         for idx, layer in enumerate(self.layers):
+            layer.cross_cache = caches[idx]
             if idx > 0:
                 reference_point = convert_corners_camera2lidar(box_prediction["box_corners"].detach())
                 reference_center = box_prediction["center_unnormalized"].detach()
@@ -591,6 +628,7 @@ class TransformerDecoder(nn.Module):
                                  tgt_key_padding_mask=tgt_key_padding_mask,
                                  memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos,
                                  return_attn_weights=return_attn_weights)
+            layer.cross_cache = None
             # stages >= 1 decode relative to the FIXED stage-0 proposal centre / size (:427-431)
             box_prediction = self.get_proposal_box_predictions_refine(
                 idx + 1, query_xyz, point_cloud_dims, self.norm(output),
