@@ -151,7 +151,8 @@ int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k,
 
 /* Backward, score stage (row order as above):
  *   scores  in : saved scores                         probs_out : P_drop = dropout(softmax)  (feeds dV = P_drop^T dO)
- *   dprob   in : dO V^T                               ds_out    : dS                         (feeds dQ = dS K, dK = dS^T Q)
+ *   dprob   in : dO V^T                               ds_out    : scale * dS                 (feeds dQ = ds_out K, dK = ds_out^T Q;
+ *                                                                 the q-scale is folded in here, the table gradient uses dS)
  *   lse, delta = rowsum(dO * O)
  *   dtable [8,T,T,T,H] or NULL: += gradient of the RPE table (caller zero-fills)
  * probs_out / ds_out may alias scores / dprob (element-wise in place) EXCEPT when dtable is requested: the table
@@ -161,6 +162,11 @@ size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d);
 int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, const float* dprob, const float* lse,
                               const float* delta, float* probs_out, float* ds_out, float* dtable, void* workspace,
                               size_t workspace_bytes, vdetr_stream_t stream);
+
+/* delta = rowsum(dO * O) over the 64 channels of a head, in the row order of the kind (see vdetr_attn_fwd_f32);
+ * dout / out [B,nQ,H*64].  The softmax-backward term the score stage subtracts. */
+int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, float* delta,
+                         vdetr_stream_t stream);
 
 /* Test hook: writes the dropout keep-mask (1/0 as uint8) [B,nQ,H,nK] the kernels above use. */
 int vdetr_attn_dropout_mask_u8(const vdetr_attn_desc* d, uint8_t* keep, vdetr_stream_t stream);

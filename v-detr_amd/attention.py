@@ -151,20 +151,18 @@ class _FusedAttention(Function):
         lib = L.lib()
         dout = dout.contiguous()
         shared = kind == L.VDETR_ATTN_SHARED_KV
+        d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt)
+        delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
+        L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(delta), L.stream_ptr()), "attn_delta")
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)
-            delta = (dout * out).view(B, nQ, H, HEAD_DIM).sum(-1)
             dprob = torch.bmm(do_r, v.transpose(1, 2))  # [B, nQ*H, nK]
         else:
             # rows (b, h, q): [B*H, nQ, 64]; K/V [B*H, nK, 64]
             do_r = dout.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
-            o_r = out.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
-            delta = (do_r * o_r).sum(-1).view(B, H, nQ)
             v_r = v.reshape(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
             dprob = torch.bmm(do_r, v_r.transpose(1, 2))  # [B*H, nQ, nK]
-        delta = delta.contiguous()
-        d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt)
         want_table = table is not None and ctx.needs_input_grad[3]
         dtable = torch.zeros_like(table) if want_table else None
         nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d)) if want_table else 0
@@ -182,16 +180,16 @@ class _FusedAttention(Function):
             ds_r = dprob
             q_r = q.view(B, nQ * H, HEAD_DIM)
             dv = torch.bmm(p_r.transpose(1, 2), do_r)
-            dk = torch.bmm(ds_r.transpose(1, 2), q_r) * scale
-            dq = (torch.bmm(ds_r, k) * scale).view(B, nQ, C)
+            dk = torch.bmm(ds_r.transpose(1, 2), q_r)  # ds_out already carries the q-scale
+            dq = torch.bmm(ds_r, k).view(B, nQ, C)
         else:
             p_r = scores.view(B * H, nQ, nK)
             ds_r = dprob
             q_r = q.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
             k_r = k.reshape(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
             dv = torch.bmm(p_r.transpose(1, 2), do_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
-            dk = (torch.bmm(ds_r.transpose(1, 2), q_r) * scale).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
-            dq = (torch.bmm(ds_r, k_r) * scale).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
+            dk = torch.bmm(ds_r.transpose(1, 2), q_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
+            dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         return (dq, dk, dv, dtable) + (None,) * 12
 
 

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(AttnParams P) {
     const ScoreGrad g = score_grad(P.scores[e], P.lse[row], keep, P.drop_scale, have_grad,
                                    have_grad ? P.dprob[e] : 0.f, have_grad ? P.delta[row] : 0.f, masked);
     P.probs_out[e] = g.p_drop;
-    if (have_grad) P.ds_out[e] = g.ds;
+    if (have_grad) P.ds_out[e] = g.ds * P.scale;
   }
 }
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnPa
           const ScoreGrad g = score_grad(P.scores[e], lse[h], keep, P.drop_scale, have_grad,
                                          have_grad ? P.dprob[e] : 0.f, delta[h], masked);
           P.probs_out[e] = g.p_drop;
-          if (have_grad) P.ds_out[e] = g.ds;
+          if (have_grad) P.ds_out[e] = g.ds * P.scale;
           ds[h] = g.ds;
         }
       }
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
           const ScoreGrad g = score_grad(ops.s[h], lse[h], keep, P.drop_scale, true, ops.d[h], delta[h], ops.masked != 0);
           if (writer && valid) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(g.p_drop), rp, key * 4, h * rowbytes, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(g.ds), rg, key * 4, h * rowbytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(g.ds * P.scale), rg, key * 4, h * rowbytes, 0);
           }
           ds[h] = valid ? g.ds * fix_scale : 0.f;  // fix_scale is a power of two (1 for the float histogram): exact
         }
@@ -617,6 +617,19 @@ __global__ __launch_bounds__(512) void issue_probe_kernel(int mode, int iters, f
   if (t == -1.f) sink[0] = t;
 }
 
+// delta[row] = sum_d dO[b,q,h,d] * O[b,q,h,d]: one wave per (b, q), lane l holds element h*64 + l of the four heads
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                        float* __restrict__ delta, int B, int nQ, int H, int perhead) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * nQ) return;
+  const int b = row / nQ, q = row - b * nQ;
+  for (int h = 0; h < H; ++h) {
+    const size_t e = ((size_t)row * H + h) * 64 + lane;
+    const float s = wave_allsum_f32(dout[e] * out[e]);
+    if (lane == 0) delta[perhead ? ((size_t)b * H + h) * nQ + q : (size_t)row * H + h] = s;
+  }
+}
+
 // keep-mask dump (test hook)
 __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, uint8_t* keep) {
   attn_load_rng(P);
@@ -730,6 +743,15 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     return check_launch("attn_bwd_table_reduce");
   }
   return VDETR_OK;
+}
+
+extern "C" int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, float* delta,
+                                    vdetr_stream_t stream) {
+  VDETR_REQUIRE(d && dout && out && delta, "attn_delta: null pointer");
+  VDETR_REQUIRE(d->B > 0 && d->nQ > 0 && d->H > 0, "attn_delta: empty dimension");
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div((long)d->B * d->nQ, 4)), dim3(256), 0, (hipStream_t)stream, dout, out,
+                     delta, d->B, d->nQ, d->H, d->kind == VDETR_ATTN_PER_HEAD ? 1 : 0);
+  return check_launch("attn_delta");
 }
 
 extern "C" int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream) {
