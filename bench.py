@@ -280,6 +280,10 @@ def cpu_baseline(cfg_name):
     saved_bd = BD.decode_boxes
     A.fused_attention, A.begin_step, A.current_rng = fused_attention_reference, (lambda dev: None), (lambda dev: None)
     BD.decode_boxes = decode_boxes_reference
+    import vdetr_amd.add_ln as ALN
+    from oracle import add_ln_oracle
+    saved_ln = (ALN.layer_norm, ALN.add_dropout_layer_norm)
+    ALN.layer_norm, ALN.add_dropout_layer_norm = add_ln_oracle.layer_norm, add_ln_oracle.add_dropout_layer_norm
     try:
         times = {}
         for layers in (2, 3):  # FFN stage + 1 resp. 2 RPE layers; per-layer cost = difference
@@ -297,6 +301,7 @@ def cpu_baseline(cfg_name):
     finally:
         A.fused_attention, A.begin_step, A.current_rng = saved
         BD.decode_boxes = saved_bd
+        ALN.layer_norm, ALN.add_dropout_layer_norm = saved_ln
     per_layer = max(times[3] - times[2], 1e-9)
     full = t_fps + times[2] + (nl - 2) * per_layer
     return {"value": bs / (full * bs), "unit": "scenes/s", "cores": cores, "kind": "port",

@@ -223,6 +223,41 @@ int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stre
 int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Residual add + dropout + LayerNorm:  y = x + dropout(r);  out = LN(y; gamma, beta);  out2 = LN(y; gamma2, beta2).
+ * The pre-norm residual blocks of GlobalDecoderLayer.forward_pre (models/vdetr_transformer.py:531-568:
+ * `tgt = tgt + self.dropoutN(tgt2); tgt2 = self.norm(tgt)`) and the decoder's `self.norm(output)` next to the next
+ * layer's `norm1(output)` (:401,:433) as one launch forward, one backward.  r == NULL: plain LayerNorm of x.
+ * C must be a multiple of 256 (<= 1024); all tensors fp32 contiguous.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vdetr_addln_desc {
+  int32_t rows, C;
+  float eps;
+  float dropout_p;           /* on r; 0 = off */
+  uint64_t seed, offset;     /* counter-based generator, as in vdetr_attn_desc */
+  const uint64_t* rng_state; /* optional device {seed, offset}, folded in */
+  const float* x;            /* [rows, C] */
+  const float* r;            /* [rows, C] or NULL.  Backward only tests it for NULL (the data is not read). */
+  const float *gamma, *beta; /* [C] */
+  const float *gamma2, *beta2; /* [C] second affine map of the same statistics, or NULL */
+  float* y;                  /* [rows, C] = x + dropout(r); required iff r != NULL (backward reads it) */
+  float *out, *out2;         /* [rows, C]; out2 may be NULL */
+  float *mean, *rstd;        /* [rows] statistics (written by forward, read by backward) */
+} vdetr_addln_desc;
+
+typedef struct vdetr_addln_grads {
+  const float *d_out, *d_out2; /* [rows, C] gradients of out / out2 (each may be NULL) */
+  const float* d_y;            /* [rows, C] gradient reaching y (or x when r == NULL) from its other uses, or NULL */
+  float* d_x;                  /* [rows, C] total gradient of y = gradient of x */
+  float* d_r;                  /* [rows, C] gradient of r (d_x through the dropout mask), or NULL */
+  float *d_gamma, *d_beta, *d_gamma2, *d_beta2; /* [C]; the *2 pair only with d_out2 */
+  float* partials;             /* vdetr_add_ln_bwd_workspace_bytes() of scratch */
+} vdetr_addln_grads;
+
+int vdetr_add_ln_fwd_f32(const vdetr_addln_desc* d, vdetr_stream_t stream);
+size_t vdetr_add_ln_bwd_workspace_bytes(const vdetr_addln_desc* d);
+int vdetr_add_ln_bwd_f32(const vdetr_addln_desc* d, const vdetr_addln_grads* g, vdetr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Gradient packing: n separate fp32 tensors -> slices of one flat buffer, one launch.  The role of the bucket copy in
  * DistributedDataParallel's reducer (reference main.py:515-517).  All three tables are DEVICE arrays:
  *   entries[e]      = {src (NULL = zero-fill), dst_offset (floats), numel}

@@ -79,6 +79,10 @@ def cpu_oracle_backend(monkeypatch):
     import vdetr_amd.box_decode as BD
     from oracle.box_oracle import decode_boxes_reference
     monkeypatch.setattr(BD, "decode_boxes", decode_boxes_reference)
+    import vdetr_amd.add_ln as ALN
+    from oracle import add_ln_oracle
+    monkeypatch.setattr(ALN, "layer_norm", add_ln_oracle.layer_norm)
+    monkeypatch.setattr(ALN, "add_dropout_layer_norm", add_ln_oracle.add_dropout_layer_norm)
     yield
 
 

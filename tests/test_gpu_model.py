@@ -77,6 +77,10 @@ def test_model_forward_backward_vs_cpu_oracle(angle_type, batch, monkeypatch):
     import vdetr_amd.box_decode as BD
     from oracle.box_oracle import decode_boxes_reference
     monkeypatch.setattr(BD, "decode_boxes", decode_boxes_reference)
+    import vdetr_amd.add_ln as ALN
+    from oracle import add_ln_oracle
+    monkeypatch.setattr(ALN, "layer_norm", add_ln_oracle.layer_norm)
+    monkeypatch.setattr(ALN, "add_dropout_layer_norm", add_ln_oracle.add_dropout_layer_norm)
     out_cpu = ref_model(inp_cpu)
     _loss(out_cpu).backward()
     assert torch.equal(out_gpu["seed_inds"].cpu(), out_cpu["seed_inds"])          # FPS: bit-exact

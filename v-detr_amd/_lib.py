@@ -58,6 +58,21 @@ class BoxDecodeGrads(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in _BOX_GRAD_IN + _BOX_GRAD_OUT]
 
 
+class AddLnDesc(ctypes.Structure):
+    """Mirror of ``vdetr_addln_desc``."""
+
+    _fields_ = [("rows", ctypes.c_int32), ("C", ctypes.c_int32), ("eps", c_float), ("dropout_p", c_float),
+                ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("rng_state", c_void_p)] + [
+        (n, c_void_p) for n in ("x", "r", "gamma", "beta", "gamma2", "beta2", "y", "out", "out2", "mean", "rstd")]
+
+
+class AddLnGrads(ctypes.Structure):
+    """Mirror of ``vdetr_addln_grads``."""
+
+    _fields_ = [(n, c_void_p) for n in ("d_out", "d_out2", "d_y", "d_x", "d_r", "d_gamma", "d_beta", "d_gamma2", "d_beta2",
+                                        "partials")]
+
+
 # name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
 _SIGNATURES = {
     "vdetr_abi_version": (c_int, []),
@@ -81,6 +96,9 @@ _SIGNATURES = {
     "vdetr_rpe_bias_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
     "vdetr_box_decode_fwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), c_void_p]),
     "vdetr_box_decode_bwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), ctypes.POINTER(BoxDecodeGrads), c_void_p]),
+    "vdetr_add_ln_fwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), c_void_p]),
+    "vdetr_add_ln_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AddLnDesc)]),
+    "vdetr_add_ln_bwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), ctypes.POINTER(AddLnGrads), c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),

@@ -24,6 +24,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from . import add_ln as ALN
 from . import attention as A
 from . import box_decode
 from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
@@ -322,6 +323,11 @@ class GlobalDecoderLayer(nn.Module):
             dropout_attn = dropout
         self.pos_for_key = pos_for_key
         self.cross_cache = None  # (k, v, tables) handed over by TransformerDecoder for the current forward
+        # fused residual + dropout + LayerNorm plumbing, set by TransformerDecoder around a call:
+        self.pre_normed = None   # norm1(tgt), already computed by the previous block's launch
+        self.post_norms = None   # LayerNorm modules to apply to the layer output in the same launch as dropout3 + add
+        self.post_normed = None  # their results
+        self._aln_salts = None   # dropout streams of the three residual blocks (created on first use: clones differ)
         if args.share_selfattn:
             self.self_attn = ShareSelfAttention(d_model, nhead, dropout=dropout)
         else:
@@ -354,15 +360,33 @@ class GlobalDecoderLayer(nn.Module):
     def forward_pre(self, tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask=None,
                     memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None,
                     query_pos=None, return_attn_weights=False):
-        tgt2 = self.norm1(tgt)
+        if not ALN.supported(self.norm1, self.norm2, self.norm3):  # other norm types: the plain composition
+            tgt2 = self.norm1(tgt)
+            q = k = self.with_pos_embed(tgt2, query_pos)
+            tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+            tgt = tgt + self.dropout1(tgt2)
+            tgt2, attn = self._cross(self.norm2(tgt), memory, reference_point, reference_angle, enc_xyz, memory_mask,
+                                     memory_key_padding_mask, pos, query_pos)
+            tgt = tgt + self.dropout2(tgt2)
+            tgt2 = self.linear2(self.dropout(self.activation(self.linear1(self.norm3(tgt)))))
+            tgt = tgt + self.dropout3(tgt2)
+            return tgt, (attn if return_attn_weights else None)
+        # `tgt = tgt + dropoutN(branch); normed = norm(tgt)` (:541-560) is one launch per residual block
+        if self._aln_salts is None:
+            self._aln_salts = [ALN.new_salt() for _ in range(3)]
+        tgt2 = self.pre_normed if self.pre_normed is not None else ALN.layer_norm(tgt, self.norm1)
         q = k = self.with_pos_embed(tgt2, query_pos)
-        tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
-        tgt = tgt + self.dropout1(tgt2)
-        tgt2, attn = self._cross(self.norm2(tgt), memory, reference_point, reference_angle, enc_xyz, memory_mask,
-                                 memory_key_padding_mask, pos, query_pos)
-        tgt = tgt + self.dropout2(tgt2)
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(self.norm3(tgt)))))
-        tgt = tgt + self.dropout3(tgt2)
+        branch = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        tgt, tgt2 = ALN.add_dropout_layer_norm(tgt, branch, self.dropout1, self.norm2, salt=self._aln_salts[0])
+        branch, attn = self._cross(tgt2, memory, reference_point, reference_angle, enc_xyz, memory_mask,
+                                   memory_key_padding_mask, pos, query_pos)
+        tgt, tgt2 = ALN.add_dropout_layer_norm(tgt, branch, self.dropout2, self.norm3, salt=self._aln_salts[1])
+        branch = self.linear2(self.dropout(self.activation(self.linear1(tgt2))))
+        if self.post_norms:  # the decoder's output norm (+ the next layer's norm1) ride in the same launch
+            res = ALN.add_dropout_layer_norm(tgt, branch, self.dropout3, *self.post_norms, salt=self._aln_salts[2])
+            tgt, self.post_normed = res[0], res[1:]
+        else:
+            tgt = tgt + self.dropout3(branch)
         return tgt, (attn if return_attn_weights else None)
 
     def forward_post(self, tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask=None,
@@ -399,10 +423,23 @@ class FFNLayer(nn.Module):
         self.norm = NORM_DICT[norm_fn_name](d_model)
         self.activation = ACTIVATION_DICT[activation]()
         self.normalize_before = normalize_before
+        self.post_norm = None    # LayerNorm the caller applies to the output: fused into the residual launch
+        self.post_normed = None
+        self._aln_salt = None
 
     def forward_pre(self, memory):
-        memory = self.norm(memory)
-        return memory + self.dropout(self.linear2(self.dropout(self.activation(self.linear1(memory)))))
+        if not ALN.supported(self.norm):
+            memory = self.norm(memory)
+            return memory + self.dropout(self.linear2(self.dropout(self.activation(self.linear1(memory)))))
+        memory = ALN.layer_norm(memory, self.norm)
+        branch = self.linear2(self.dropout(self.activation(self.linear1(memory))))
+        if self.post_norm is not None:
+            if self._aln_salt is None:
+                self._aln_salt = ALN.new_salt()
+            memory, self.post_normed = ALN.add_dropout_layer_norm(memory, branch, self.dropout, self.post_norm,
+                                                                  salt=self._aln_salt)
+            return memory
+        return memory + self.dropout(branch)
 
     def forward(self, memory):
         return self.forward_pre(memory)
@@ -559,9 +596,14 @@ class TransformerDecoder(nn.Module):
                 transpose_swap=False, return_attn_weights=False, enc_box_predictions=None, enc_box_features=None):
         A.begin_step(memory.device)  # one dropout-RNG snapshot per forward, shared by all attention modules
         intermediate, attns = [], []
+        fuse_ln = ALN.supported(self.norm) and isinstance(self.first_layer, FFNLayer) and \
+            ALN.supported(self.first_layer.norm, self.norm)
+        self.first_layer.post_norm = self.norm if fuse_ln else None
         output = self.first_layer(enc_box_features)
+        normed = self.first_layer.post_normed if fuse_ln else self.norm(output)
+        self.first_layer.post_norm = self.first_layer.post_normed = None
         box_prediction = self.get_proposal_box_predictions_refine(
-            0, query_xyz, point_cloud_dims, self.norm(output),
+            0, query_xyz, point_cloud_dims, normed,
             pre_center_normalized=enc_box_predictions["center_normalized"],
             pre_size_normalized=enc_box_predictions["size_normalized"])
         if self.return_intermediate:
@@ -612,8 +654,16 @@ class TransformerDecoder(nn.Module):
             caches = GlobalShareCrossAttention.precompute(cross, memory)
 
         # ---- decoder layers with box feedback (:407-436) ---------------------------------------------------
+        fuse_ln = ALN.supported(self.norm) and all(
+            isinstance(l, GlobalDecoderLayer) and l.normalize_before and ALN.supported(self.norm, l.norm1, l.norm2, l.norm3)
+            for l in self.layers)
+        carried = None  # norm1 of the next layer, produced by the previous layer's last launch
         for idx, layer in enumerate(self.layers):
             layer.cross_cache = caches[idx]
+            if fuse_ln:
+                layer.pre_normed = carried
+                nxt = self.layers[idx + 1].norm1 if idx + 1 < len(self.layers) else None
+                layer.post_norms = (self.norm,) + ((nxt,) if nxt is not None else ())
             if idx > 0:
                 reference_point = convert_corners_camera2lidar(box_prediction["box_corners"].detach())
                 reference_center = box_prediction["center_unnormalized"].detach()
@@ -629,9 +679,15 @@ class TransformerDecoder(nn.Module):
                                  memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos,
                                  return_attn_weights=return_attn_weights)
             layer.cross_cache = None
+            if fuse_ln:
+                normed = layer.post_normed[0]
+                carried = layer.post_normed[1] if len(layer.post_normed) > 1 else None
+                layer.pre_normed = layer.post_norms = layer.post_normed = None
+            else:
+                normed = self.norm(output)
             # stages >= 1 decode relative to the FIXED stage-0 proposal centre / size (:427-431)
             box_prediction = self.get_proposal_box_predictions_refine(
-                idx + 1, query_xyz, point_cloud_dims, self.norm(output),
+                idx + 1, query_xyz, point_cloud_dims, normed,
                 pre_center_normalized=proposal_center_normalized, pre_size_normalized=proposal_size_normalized)
             if self.return_intermediate:
                 intermediate.append(box_prediction)
