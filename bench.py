@@ -89,7 +89,7 @@ class Trainer:
         self.model, self.inputs, self.world = model, inputs, world
         self.params = [p for p in model.parameters() if p.requires_grad]
         # parameters / gradients as views of two flat buffers: one AdamW launch, one norm, slice-shaped buckets
-        self.flat = FlatParams(self.params)
+        self.flat = FlatParams(self.params, groups=model.flat_param_groups())
         # hooks + bucket views only pay off when they overlap communication with an EAGER backward; otherwise
         # gradients stay ordinary tensors and are packed with one multi-tensor copy before the all-reduce
         self.hooked = world > 1 and overlap and not use_graph

@@ -215,3 +215,40 @@ def test_flat_params_pack_one_launch():
             got = flat.grad[off:off + p.numel()].view(p.shape)
             want = torch.zeros_like(p) if g is None else g
             assert torch.equal(got, want), p.shape
+
+
+def test_adjacent_parameter_aliases_match_cat_and_stack():
+    """helpers.cat_params / stack_params / slot_stack_params on parameters laid out by dist.FlatParams: same values and
+    gradients as torch.cat / torch.stack, without the copy; non-adjacent tensors fall back."""
+    from vdetr_amd.dist import FlatParams
+    from vdetr_amd.helpers import cat_params, slot_stack_params, stack_params
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    mk = lambda *s: torch.nn.Parameter(torch.randn(*s, device=dev))
+    a = [mk(8, 4, 1) for _ in range(3)]          # cat along dim 0
+    b = [mk(6, 6) for _ in range(4)]             # stack
+    c = [mk(r, 4, 1) for r in (5, 3, 1)]         # zero-padded slabs of 5 rows
+    other = [mk(7), mk(2, 2)]
+    assert cat_params(a).data_ptr() != a[0].data_ptr()  # separate storages: the copying path
+    assert slot_stack_params(c, 5) is None
+    ref = [p.detach().clone() for p in a + b + c]
+    flat = FlatParams(a + b + c + other, groups=[(a, None), (b, None), (c, 5 * 4)])
+    for p, r in zip(a + b + c, ref):
+        assert torch.equal(p.detach(), r)
+    ca, sb, sc = cat_params(a), stack_params(b), slot_stack_params(c, 5)
+    assert ca.data_ptr() == a[0].data_ptr() and sb.data_ptr() == b[0].data_ptr() and sc.data_ptr() == c[0].data_ptr()
+    assert torch.equal(ca, torch.cat(ref[:3], 0)) and torch.equal(sb, torch.stack(ref[3:7]))
+    assert sc.shape == (3, 5, 4, 1) and torch.equal(sc[1, :3], ref[8]) and sc[1, 3:].abs().max() == 0
+    wa, wb, wc = torch.randn_like(ca), torch.randn_like(sb), torch.randn_like(sc)
+    ((ca * wa).sum() + (sb * wb).sum() + (sc * wc).sum()).backward()
+    for i, p in enumerate(a):
+        assert torch.equal(p.grad, wa[8 * i:8 * i + 8])
+    for i, p in enumerate(b):
+        assert torch.equal(p.grad, wb[i])
+    for i, p in enumerate(c):
+        assert torch.equal(p.grad, wc[i, :p.shape[0]])
+    flat.pack_grads()
+    torch.cuda.synchronize()
+    off = flat.offsets[id(c[1])]
+    assert torch.equal(flat.grad[off:off + 12].view(3, 4, 1), wc[1, :3])
+    assert flat.grad[off + 12:off + 20].abs().max() == 0  # slab padding stays zero

@@ -50,25 +50,46 @@ class FlatParams:
     one tensor and rides into the optimizer launch as its ``grad_scale``, and the all-reduce buckets are plain slices of
     the gradient buffer.  ``p.data`` of every parameter is re-pointed at its slice (state_dict / load_state_dict keep
     working, they copy in place); calling ``module.to()`` afterwards would detach the views again.
-    Layout = REVERSE parameter order, so that slices complete roughly front-to-back during backward."""
+    Layout = the model's adjacency groups first, then REVERSE parameter order, so that slices complete roughly
+    front-to-back during backward."""
 
-    def __init__(self, params):
-        self.params = [p for p in reversed(list(params)) if p.requires_grad]
-        assert self.params, "no trainable parameters"
+    def __init__(self, params, groups=None):
+        """``groups``: optional list of (parameters, slot) — parameters a model wants ADJACENT in memory, in this order
+        (see helpers.cat_params).  slot = None packs them back to back; slot = n gives every parameter a zero-padded
+        slab of n elements (helpers.slot_stack_params).  Everything else follows in reverse parameter order."""
+        plist = [p for p in params if p.requires_grad]
+        assert plist, "no trainable parameters"
+        known = {id(p) for p in plist}
+        layout, placed, off = [], set(), 0  # (param, offset)
+        for plist_g, slot in (groups or []):
+            plist_g = [p for p in plist_g if id(p) in known and id(p) not in placed]
+            if not plist_g:
+                continue
+            off = (off + 63) // 64 * 64
+            for p in plist_g:
+                assert slot is None or p.numel() <= slot, "slot smaller than a parameter of its group"
+                layout.append((p, off))
+                placed.add(id(p))
+                off += slot if slot is not None else p.numel()
+        for p in reversed(plist):
+            if id(p) not in placed:
+                off = (off + 3) // 4 * 4  # 16-B aligned slices (vectorised pack / fused optimizer)
+                layout.append((p, off))
+                off += p.numel()
+        self.params = [p for p, _ in layout]
         dev, dtype = self.params[0].device, self.params[0].dtype
-        total = sum(p.numel() for p in self.params)
-        self.data = torch.empty(total, dtype=dtype, device=dev)
+        total = (off + 3) // 4 * 4
+        self.data = torch.zeros(total, dtype=dtype, device=dev)   # padding stays zero: zero gradient, zero decay
         self.grad = torch.zeros(total, dtype=dtype, device=dev)
-        self.grad_views, self.offsets, off = [], {}, 0
+        self.grad_views, self.offsets = [], {}
         with torch.no_grad():
-            for p in self.params:
+            for p, o in layout:
                 assert p.device == dev and p.dtype == dtype, "one device / dtype per flat buffer"
                 n = p.numel()
-                self.data[off:off + n].copy_(p.data.reshape(-1))
-                p.data = self.data[off:off + n].view(p.shape)
-                self.grad_views.append(self.grad[off:off + n].view(p.shape))
-                self.offsets[id(p)] = off
-                off += n
+                self.data[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.data[o:o + n].view(p.shape)
+                self.grad_views.append(self.grad[o:o + n].view(p.shape))
+                self.offsets[id(p)] = o
         self.param = torch.nn.Parameter(self.data)  # what the optimizer sees; shares the storage
         self.param.grad = self.grad
 
@@ -170,16 +191,18 @@ class GradientReducer:
         self.buckets, self._bucket_of, self._pending, self._launched = [], {}, [], []
         self.bucket_views = bucket_views
         self._views = []  # (param, view) in bucket order
+        gview = {id(p): v for p, v in zip(flat.params, flat.grad_views)} if flat is not None else None
         for gi, g in enumerate(groups):
             n_g = sum(p.numel() for p in g)
-            if self.flat is not None:
+            if self.flat is not None:  # a slice of the flat gradient buffer (alignment / slot padding included: zeros)
                 start = self.flat.offsets[id(g[0])]
-                flat = self.flat.grad[start:start + n_g]
+                end = self.flat.offsets[id(g[-1])] + g[-1].numel()
+                flat = self.flat.grad[start:end]
             else:
                 flat = torch.zeros(n_g, dtype=dtype, device=dev)
             off = 0
             for p in g:
-                view = flat[off:off + p.numel()].view_as(p)
+                view = gview[id(p)] if gview is not None else flat[off:off + p.numel()].view_as(p)
                 if bucket_views:
                     p.grad = view  # gradients accumulate straight into the bucket
                 self._views.append((p, view))

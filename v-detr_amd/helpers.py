@@ -31,6 +31,87 @@ class PointwiseConv1d(nn.Conv1d):
         return y if self.bias is None else y + self.bias.view(1, -1, 1)
 
 
+# ---- zero-copy concatenation of parameters that already sit next to each other in memory ---------------------------
+# Five heads per stage, eight layers, 64 cpb MLPs: the batched GEMMs want their weights as ONE tensor, and torch.cat /
+# torch.stack of the per-module parameters is a launch (~4.5 us on MI355X) per group and step.  dist.FlatParams lays
+# the groups a model names in ``flat_param_groups()`` out contiguously; these helpers then return an alias of that memory
+# (no launch) whose backward hands each parameter its slice of the joint gradient.  Parameters that are NOT adjacent
+# (a model used without FlatParams, after .to(), a loaded checkpoint with its own storages) fall back to cat / stack.
+def _adjacent(ts, slot=None):
+    t0 = ts[0]
+    esize = t0.element_size()
+    ptr = t0.data_ptr()
+    for t in ts:
+        if t.data_ptr() != ptr or not t.is_contiguous() or t.dtype != t0.dtype or t.device != t0.device:
+            return False
+        ptr += (slot if slot is not None else t.numel()) * esize
+    avail = t0.untyped_storage().nbytes() - t0.storage_offset() * esize
+    return ptr - t0.data_ptr() <= avail
+
+
+class _Alias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mode, shape, *ts):
+        ctx.mode, ctx.shapes = mode, [t.shape for t in ts]
+        t0 = ts[0]
+        out = torch.empty(0, dtype=t0.dtype, device=t0.device)
+        out.set_(t0.untyped_storage(), t0.storage_offset(), shape)  # contiguous alias of the parameters' memory
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if ctx.mode == "cat":
+            parts, off = [], 0
+            for sh in ctx.shapes:
+                parts.append(g.narrow(0, off, sh[0]))
+                off += sh[0]
+        elif ctx.mode == "stack":
+            parts = list(g.unbind(0))
+        else:  # "slot": [G, S, ...] with parameter i in rows [0, shape_i[0]) of slab i
+            parts = [g[i, :sh[0]] for i, sh in enumerate(ctx.shapes)]
+        return (None, None) + tuple(parts)
+
+
+def cat_params(ts):
+    """torch.cat(ts, 0), without a copy when the tensors are adjacent in memory."""
+    ts = list(ts)
+    if ts[0].is_cuda and _adjacent(ts):
+        return _Alias.apply("cat", (sum(t.shape[0] for t in ts),) + tuple(ts[0].shape[1:]), *ts)
+    return torch.cat(ts, 0)
+
+
+def stack_params(ts):
+    """torch.stack(ts), without a copy when the tensors are adjacent in memory."""
+    ts = list(ts)
+    if ts[0].is_cuda and _adjacent(ts):
+        return _Alias.apply("stack", (len(ts),) + tuple(ts[0].shape), *ts)
+    return torch.stack(ts)
+
+
+def slot_stack_params(ts, rows):
+    """[G, rows, ...] alias when parameter i (shape [r_i <= rows, ...]) starts slab i of a zero-padded slab array
+    (dist.FlatParams lays such groups out on request); None otherwise."""
+    ts = list(ts)
+    rest = tuple(ts[0].shape[1:])
+    per_row = 1
+    for d in rest:
+        per_row *= d
+    if ts[0].is_cuda and all(tuple(t.shape[1:]) == rest and t.shape[0] <= rows for t in ts) and _adjacent(ts, rows * per_row):
+        return _Alias.apply("slot", (len(ts), rows) + rest, *ts)
+    return None
+
+
+def buffers_alias(ts):
+    """Adjacent buffers (running statistics) as one tensor that shares their memory, or None."""
+    ts = list(ts)
+    if ts[0].is_cuda and _adjacent(ts):
+        t0 = ts[0]
+        out = torch.empty(0, dtype=t0.dtype, device=t0.device)
+        return out.set_(t0.untyped_storage(), t0.storage_offset(), (sum(t.shape[0] for t in ts),) + tuple(t0.shape[1:]))
+    return None
+
+
 class BatchNormDim1Swap(nn.BatchNorm1d):
     """BatchNorm over the channel axis of a sequence-first (L, N, C) tensor (helpers.py:36-53)."""
 

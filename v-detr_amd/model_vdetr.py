@@ -94,6 +94,10 @@ class ModelVDETR(nn.Module):
         return encoder_xyz, self.query_projection(pos_embed).permute(2, 0, 1), None
 
     @torch.no_grad()
+    def flat_param_groups(self):
+        """Adjacency wishes for dist.FlatParams (see TransformerDecoder.flat_param_groups)."""
+        return self.decoder.flat_param_groups() if hasattr(self.decoder, "flat_param_groups") else []
+
     def sample_indices(self, inputs):
         """FPS indices [B, npoint] (int32) of a batch whose scenes have equal voxel counts.  The sampling only
         depends on the voxel COORDINATES, so a training loop can run it ahead of time — e.g. for the next batch on a

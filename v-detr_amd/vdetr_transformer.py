@@ -28,7 +28,7 @@ from . import add_ln as ALN
 from . import attention as A
 from . import box_decode
 from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
-                      PositionEmbeddingLearned, get_clones)
+                      PositionEmbeddingLearned, buffers_alias, cat_params, get_clones, slot_stack_params, stack_params)
 from .pc_util import morton_argsort, scale_points, shift_scale_points
 
 _salt_counter = itertools.count(1)
@@ -181,14 +181,14 @@ class GlobalShareCrossAttention(nn.Module):
         64-wide column blocks of the joint projection (row-strided views, read in place by the kernel)."""
         n = len(mods)
         key_b = key.permute(1, 0, 2)
-        w = torch.cat([t for m in mods for t in (m.k.weight, m.v.weight)], 0)
-        b = torch.cat([t for m in mods for t in (m.k.bias, m.v.bias)], 0) if mods[0].k.bias is not None else None
+        w = cat_params([t for m in mods for t in (m.k.weight, m.v.weight)])
+        b = cat_params([t for m in mods for t in (m.k.bias, m.v.bias)]) if mods[0].k.bias is not None else None
         kv = F.linear(key_b, w, b)                                                   # [B,nK,n*128]
         parts = kv.view(kv.shape[0], kv.shape[1], 2 * n, -1).unbind(2)
         mlps = [mm for m in mods for mm in m.cpb_mlps]
-        w1 = torch.stack([mm[0].weight for mm in mlps])
-        b1 = torch.stack([mm[0].bias for mm in mlps])
-        w2 = torch.stack([mm[2].weight for mm in mlps])
+        w1 = stack_params([mm[0].weight for mm in mlps])
+        b1 = stack_params([mm[0].bias for mm in mlps])
+        w2 = stack_params([mm[2].weight for mm in mlps])
         T, H = mods[0].relative_coords_table.shape[1], mods[0].num_heads
         coords = mods[0].relative_coords_table.reshape(1, -1, 3).expand(8 * n, -1, -1)
         hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
@@ -537,37 +537,91 @@ class TransformerDecoder(nn.Module):
 
     @staticmethod
     def _bn_group(x, bns, training):
-        """BatchNorm1d of G side-by-side channel groups in one call (per-channel statistics: identical numbers)."""
-        w = torch.cat([b.weight for b in bns])
-        bias = torch.cat([b.bias for b in bns])
-        rm = torch.cat([b.running_mean for b in bns])
-        rv = torch.cat([b.running_var for b in bns])
+        """BatchNorm1d of G side-by-side channel groups in one call (per-channel statistics: identical numbers).
+        Parameters / running statistics that are adjacent in memory are used in place (no cat, no copy-back)."""
+        w = cat_params([b.weight for b in bns])
+        bias = cat_params([b.bias for b in bns])
+        rm, rv = buffers_alias([b.running_mean for b in bns]), buffers_alias([b.running_var for b in bns])
+        if rm is None or rv is None:
+            if training and x.is_cuda:  # first call on this device: put the statistics next to each other, once
+                with torch.no_grad():
+                    for name in ("running_mean", "running_var"):
+                        flat = torch.cat([getattr(b, name) for b in bns])
+                        c = bns[0].num_features
+                        for i, b in enumerate(bns):
+                            setattr(b, name, flat[i * c:(i + 1) * c])
+                rm, rv = buffers_alias([b.running_mean for b in bns]), buffers_alias([b.running_var for b in bns])
+        inplace = rm is not None and rv is not None
+        if not inplace:
+            rm = torch.cat([b.running_mean for b in bns])
+            rv = torch.cat([b.running_var for b in bns])
         y = F.batch_norm(x, rm, rv, w, bias, training, bns[0].momentum, bns[0].eps)
-        if training:  # hand the updated statistics back to the modules that own them
-            c = bns[0].num_features
+        if training:
             with torch.no_grad():
-                torch._foreach_copy_([b.running_mean for b in bns], list(rm.split(c)))
-                torch._foreach_copy_([b.running_var for b in bns], list(rv.split(c)))
+                if not inplace:  # hand the updated statistics back to the modules that own them
+                    c = bns[0].num_features
+                    torch._foreach_copy_([b.running_mean for b in bns], list(rm.split(c)))
+                    torch._foreach_copy_([b.running_var for b in bns], list(rv.split(c)))
                 torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
         return y
+
+    def _head_layers(self, stage):
+        heads = self.mlp_heads[stage] if self.mlp_sep else self.mlp_heads
+        return [heads[n].layers for n in self._HEAD_NAMES]
+
+    def flat_param_groups(self):
+        """Parameter groups the batched GEMMs read as ONE tensor (dist.FlatParams lays each group out contiguously,
+        helpers.cat_params / stack_params / slot_stack_params then alias the memory instead of copying it)."""
+        groups = []
+        stages = range(len(self.mlp_heads)) if self.mlp_sep else [0]
+        for st in stages:
+            heads = self.mlp_heads[st] if self.mlp_sep else self.mlp_heads
+            if not self._batchable(heads):
+                continue
+            L = self._head_layers(st)
+            C = L[0][0].weight.shape[1]
+            rows = max(l[8].weight.shape[0] for l in L)
+            groups += [([l[0].weight for l in L], None), ([l[1].weight for l in L], None), ([l[1].bias for l in L], None),
+                       ([l[4].weight for l in L], None), ([l[5].weight for l in L], None), ([l[5].bias for l in L], None),
+                       ([l[8].weight for l in L], rows * C), ([l[8].bias for l in L], rows)]
+        cross = [l.multihead_attn for l in self.layers]
+        if all(type(m) is GlobalShareCrossAttention for m in cross):
+            groups.append(([t for m in cross for t in (m.k.weight, m.v.weight)], None))
+            if cross[0].k.bias is not None:
+                groups.append(([t for m in cross for t in (m.k.bias, m.v.bias)], None))
+            mlps = [mm for m in cross for mm in m.cpb_mlps]
+            groups += [([mm[0].weight for mm in mlps], None), ([mm[0].bias for mm in mlps], None),
+                       ([mm[2].weight for mm in mlps], None)]
+        return groups
 
     def _run_heads(self, heads, feats):
         """{head name: [B, out, N]} for feats [B, C, N].  The reference runs five independent GenericMLPs on the
         same input (:261-285); their first layers are one [5C x C] GEMM, their second layers one batched GEMM, the
-        BatchNorms one call over 5C channels — a third of the launches and much better-shaped GEMMs, with the
-        parameters still living (and checkpointing) in the per-head modules."""
+        BatchNorms one call over 5C channels, the output layers one zero-padded batched GEMM when the parameters
+        are laid out for it — a fraction of the launches and better-shaped GEMMs, with the parameters still living (and
+        checkpointing) in the per-head modules."""
         names = self._HEAD_NAMES
         if not self._batchable(heads):
             return {n: heads[n](feats) for n in names}
         L = [heads[n].layers for n in names]
         G, C = len(L), feats.shape[1]
         Bsz, _, N = feats.shape
-        w1 = torch.cat([l[0].weight for l in L], 0).squeeze(-1)                          # [G*C, C]
+        w1 = cat_params([l[0].weight for l in L]).squeeze(-1)                            # [G*C, C]
         x = torch.mm(w1, feats.reshape(C, N)).unsqueeze(0) if Bsz == 1 else torch.matmul(w1, feats)  # [B, G*C, N]
         x = F.dropout(F.relu(self._bn_group(x, [l[1] for l in L], self.training)), L[0][3].p, self.training)
-        w2 = torch.stack([l[4].weight.squeeze(-1) for l in L])                           # [G, C, C]
+        w2 = stack_params([l[4].weight for l in L]).squeeze(-1)                          # [G, C, C]
         x = torch.matmul(w2.unsqueeze(0), x.view(Bsz, G, C, N)).view(Bsz, G * C, N)
         x = F.dropout(F.relu(self._bn_group(x, [l[5] for l in L], self.training)), L[0][7].p, self.training)
+        outs = [l[8].weight.shape[0] for l in L]
+        rows = max(outs)
+        w3 = slot_stack_params([l[8].weight for l in L], rows)                            # [G, rows, C, 1] or None
+        b3 = slot_stack_params([l[8].bias for l in L], rows) if w3 is not None and L[0][8].bias is not None else None
+        if w3 is not None and (b3 is not None or L[0][8].bias is None):
+            # output layers of the five heads as one batched GEMM over zero-padded [rows, C] weight slabs
+            y = torch.matmul(w3.squeeze(-1).unsqueeze(0), x.view(Bsz, G, C, N))           # [B, G, rows, N]
+            if b3 is not None:
+                y = y + b3.view(1, G, rows, 1)
+            return {n: y[:, g, :outs[g]] for g, n in enumerate(names)}
         # unbind (one stack kernel in backward) rather than five slices (five zero-fills + copies + adds)
         xs = x.view(Bsz, G, C, N).unbind(1)
         return {n: L[g][8](xs[g]) for g, n in enumerate(names)}
