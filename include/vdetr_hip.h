@@ -269,6 +269,9 @@ typedef struct vdetr_pack_entry {
   uint64_t dst_offset;
   uint64_t numel;
 } vdetr_pack_entry;
+/* out[c] = sum_r x[r * row_stride + c]: the bias gradient of nn.Linear / 1x1 Conv1d (the `sum` inside AddmmBackward of
+ * every projection in models/vdetr_transformer.py), one launch. */
+int vdetr_colsum_f32(const float* x, float* out, int rows, int cols, long row_stride, vdetr_stream_t stream);
 int vdetr_pack_chunk_floats(void);
 int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk, int nblocks,
                    float* dst, vdetr_stream_t stream);

@@ -252,3 +252,26 @@ def test_adjacent_parameter_aliases_match_cat_and_stack():
     off = flat.offsets[id(c[1])]
     assert torch.equal(flat.grad[off:off + 12].view(3, 4, 1), wc[1, :3])
     assert flat.grad[off + 12:off + 20].abs().max() == 0  # slab padding stays zero
+
+
+@pytest.mark.parametrize("rows,cols", [(1024, 256), (4096, 64), (1000, 1280), (3, 19)])
+def test_colsum_and_linear_backward(rows, cols):
+    """vdetr_colsum_f32 and helpers.linear (bias gradient in one launch) vs torch."""
+    from vdetr_amd.helpers import colsum, linear
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(dev)
+    torch.testing.assert_close(colsum(x), x.sum(0), rtol=1e-5, atol=1e-4)
+    wide = torch.randn(rows, cols + 8, generator=g).to(dev)
+    torch.testing.assert_close(colsum(wide[:, 3:3 + cols]), wide[:, 3:3 + cols].sum(0), rtol=1e-5, atol=1e-4)
+    lin = torch.nn.Linear(cols, 32).to(dev)
+    xin = torch.randn(2, rows // 2 if rows > 3 else 3, cols, generator=g).to(dev)
+    outs = []
+    for fn in (lambda t: linear(t, lin.weight, lin.bias), lambda t: torch.nn.functional.linear(t, lin.weight, lin.bias)):
+        t = xin.clone().requires_grad_(True)
+        lin.zero_grad()
+        y = fn(t)
+        (y * y).sum().backward()
+        outs.append((y.detach(), t.grad, lin.weight.grad.clone(), lin.bias.grad.clone()))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))

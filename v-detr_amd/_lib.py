@@ -99,6 +99,7 @@ _SIGNATURES = {
     "vdetr_add_ln_fwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), c_void_p]),
     "vdetr_add_ln_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AddLnDesc)]),
     "vdetr_add_ln_bwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), ctypes.POINTER(AddLnGrads), c_void_p]),
+    "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),

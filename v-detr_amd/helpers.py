@@ -12,6 +12,48 @@ import torch
 import torch.nn as nn
 
 
+def colsum(x2d):
+    """sum over the rows of a [rows, cols] fp32 CUDA matrix (row-strided is fine) in one launch (vdetr_colsum_f32)."""
+    import ctypes
+    from . import _lib as L
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    out = torch.empty(x2d.shape[1], dtype=x2d.dtype, device=x2d.device)
+    L.check(L.lib().vdetr_colsum_f32(L.ptr(x2d), L.ptr(out), x2d.shape[0], x2d.shape[1], ctypes.c_long(x2d.stride(0)),
+                                     L.stream_ptr()), "colsum")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b with the bias gradient as ONE launch (ATen: two-pass reduction, 2 launches / 14 us per layer)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(g2, w).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(g2.t(), x.reshape(-1, x.shape[-1]))
+        if ctx.needs_input_grad[2]:
+            g2c = g2 if g2.stride(1) == 1 else g2.contiguous()
+            db = colsum(g2c)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """F.linear; on the GPU with a bias, the backward computes the bias gradient with the one-launch column sum."""
+    if b is not None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and (
+            x.requires_grad or w.requires_grad or b.requires_grad):
+        return _Linear.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
+
+
 class PointwiseConv1d(nn.Conv1d):
     """``nn.Conv1d(cin, cout, kernel_size=1)`` (same parameters, same state-dict entries) evaluated as the GEMM it is.
 

@@ -28,7 +28,8 @@ from . import add_ln as ALN
 from . import attention as A
 from . import box_decode
 from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
-                      PositionEmbeddingLearned, buffers_alias, cat_params, get_clones, slot_stack_params, stack_params)
+                      PositionEmbeddingLearned, buffers_alias, cat_params, get_clones, linear, slot_stack_params,
+                      stack_params)
 from .pc_util import morton_argsort, scale_points, shift_scale_points
 
 _salt_counter = itertools.count(1)
@@ -183,7 +184,7 @@ class GlobalShareCrossAttention(nn.Module):
         key_b = key.permute(1, 0, 2)
         w = cat_params([t for m in mods for t in (m.k.weight, m.v.weight)])
         b = cat_params([t for m in mods for t in (m.k.bias, m.v.bias)]) if mods[0].k.bias is not None else None
-        kv = F.linear(key_b, w, b)                                                   # [B,nK,n*128]
+        kv = linear(key_b, w, b)                                                   # [B,nK,n*128]
         parts = kv.view(kv.shape[0], kv.shape[1], 2 * n, -1).unbind(2)
         mlps = [mm for m in mods for mm in m.cpb_mlps]
         w1 = stack_params([mm[0].weight for mm in mlps])
@@ -198,11 +199,11 @@ class GlobalShareCrossAttention(nn.Module):
     def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None,
                 cache=None):
         query_b = query.permute(1, 0, 2)
-        q = self.q(query_b)   # [B,nQ,C]
+        q = linear(query_b, self.q.weight, self.q.bias)   # [B,nQ,C]
         if cache is None:
             key_b = key.permute(1, 0, 2)
-            k = self.k(key_b)     # [B,nK,C/H]
-            v = self.v(key_b)
+            k = linear(key_b, self.k.weight, self.k.bias)     # [B,nK,C/H]
+            v = linear(key_b, self.v.weight, self.v.bias)
         else:
             k, v = cache[0], cache[1]
         cos_sin = None
@@ -223,7 +224,7 @@ class GlobalShareCrossAttention(nn.Module):
                                              table=tables, rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz,
                                              cos_sin=cos_sin, attn_mask=attn_mask, dropout_p=p, rng_state=rng,
                                              salt=self._salt)
-        x = self.proj_drop(self.proj(x)).permute(1, 0, 2)
+        x = self.proj_drop(linear(x, self.proj.weight, self.proj.bias)).permute(1, 0, 2)
         return x, attn
 
 
@@ -248,16 +249,16 @@ class ShareSelfAttention(nn.Module):
     def forward(self, query, key, value=None, attn_mask=None, key_padding_mask=None):
         assert attn_mask is None and key_padding_mask is None
         key_b, query_b = key.permute(1, 0, 2), query.permute(1, 0, 2)
-        k = self.k(key_b)
+        k = linear(key_b, self.k.weight, self.k.bias)
         # The reference projects `value` WITHOUT the (1,0,2) permute and then reshapes the sequence-first
         # [N,B,64] result as (B,N,64) (:639).  Identical for B == 1, a batch/sequence mix-up for B > 1; kept as
         # is so that outputs match the reference on the same inputs.
-        v = self.v(value).reshape(key_b.shape[0], key_b.shape[1], -1)
-        q = self.q(query_b)
+        v = linear(value, self.v.weight, self.v.bias).reshape(key_b.shape[0], key_b.shape[1], -1)
+        q = linear(query_b, self.q.weight, self.q.bias)
         p = self.attn_drop.p if self.training else 0.0
         x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, dropout_p=p,
                               salt=self._salt)
-        return self.proj_drop(self.proj(x)).permute(1, 0, 2), None
+        return self.proj_drop(linear(x, self.proj.weight, self.proj.bias)).permute(1, 0, 2), None
 
 
 class _OutProj(nn.Linear):
@@ -291,7 +292,7 @@ class MultiheadSelfAttention(nn.Module):
         # or a joint q/k output (each slice's backward is a zero-filled full-size buffer + copy)
         wq, wk, wv = self.in_proj_weight.view(3, E, E).unbind(0)
         bq, bk, bv = self.in_proj_bias.view(3, E).unbind(0)
-        q, k, v = F.linear(query, wq, bq), F.linear(key, wk, bk), F.linear(value, wv, bv)
+        q, k, v = linear(query, wq, bq), linear(key, wk, bk), linear(value, wv, bv)
         L_, B = query.shape[0], query.shape[1]
         S = key.shape[0]
         mask = None
@@ -307,7 +308,7 @@ class MultiheadSelfAttention(nn.Module):
         x = A.fused_attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), num_heads=self.num_heads,
                               scale=self.head_dim ** -0.5, shared_kv=False, attn_mask=mask, dropout_p=p,
                               salt=self._salt)
-        return self.out_proj(x).transpose(0, 1), None
+        return linear(x, self.out_proj.weight, self.out_proj.bias).transpose(0, 1), None
 
 
 # =====================================================================================================
@@ -368,7 +369,7 @@ class GlobalDecoderLayer(nn.Module):
             tgt2, attn = self._cross(self.norm2(tgt), memory, reference_point, reference_angle, enc_xyz, memory_mask,
                                      memory_key_padding_mask, pos, query_pos)
             tgt = tgt + self.dropout2(tgt2)
-            tgt2 = self.linear2(self.dropout(self.activation(self.linear1(self.norm3(tgt)))))
+            tgt2 = linear(self.dropout(self.activation(linear(self.norm3(tgt), self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias)
             tgt = tgt + self.dropout3(tgt2)
             return tgt, (attn if return_attn_weights else None)
         # `tgt = tgt + dropoutN(branch); normed = norm(tgt)` (:541-560) is one launch per residual block
@@ -381,7 +382,7 @@ class GlobalDecoderLayer(nn.Module):
         branch, attn = self._cross(tgt2, memory, reference_point, reference_angle, enc_xyz, memory_mask,
                                    memory_key_padding_mask, pos, query_pos)
         tgt, tgt2 = ALN.add_dropout_layer_norm(tgt, branch, self.dropout2, self.norm3, salt=self._aln_salts[1])
-        branch = self.linear2(self.dropout(self.activation(self.linear1(tgt2))))
+        branch = linear(self.dropout(self.activation(linear(tgt2, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias)
         if self.post_norms:  # the decoder's output norm (+ the next layer's norm1) ride in the same launch
             res = ALN.add_dropout_layer_norm(tgt, branch, self.dropout3, *self.post_norms, salt=self._aln_salts[2])
             tgt, self.post_normed = res[0], res[1:]
@@ -398,7 +399,7 @@ class GlobalDecoderLayer(nn.Module):
         tgt2, attn = self._cross(tgt, memory, reference_point, reference_angle, enc_xyz, memory_mask,
                                  memory_key_padding_mask, pos, query_pos)
         tgt = self.norm2(tgt + self.dropout2(tgt2))
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
+        tgt2 = linear(self.dropout(self.activation(linear(tgt, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias)
         tgt = self.norm3(tgt + self.dropout3(tgt2))
         return tgt, (attn if return_attn_weights else None)
 
@@ -430,9 +431,9 @@ class FFNLayer(nn.Module):
     def forward_pre(self, memory):
         if not ALN.supported(self.norm):
             memory = self.norm(memory)
-            return memory + self.dropout(self.linear2(self.dropout(self.activation(self.linear1(memory)))))
+            return memory + self.dropout(linear(self.dropout(self.activation(linear(memory, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias))
         memory = ALN.layer_norm(memory, self.norm)
-        branch = self.linear2(self.dropout(self.activation(self.linear1(memory))))
+        branch = linear(self.dropout(self.activation(linear(memory, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias)
         if self.post_norm is not None:
             if self._aln_salt is None:
                 self._aln_salt = ALN.new_salt()
