@@ -206,6 +206,11 @@ typedef struct vdetr_box_decode_desc {
   float* corners_aa;                /* [B,N,8,3] zero-angle corners, or NULL (with A == 1 they equal `corners`) */
   float* cls_prob;                  /* [B,N,C1-1] (VDETR_CLS_SOFTMAX) or NULL */
   float* objectness;                /* [B,N] */
+  /* --- the five head outputs as slabs of ONE tensor [B, 5, slab_rows, N] (they come out of one batched GEMM):
+         floats between scenes for every input pointer, 0 = each input dense [B,ch,N] --- */
+  int32_t in_batch_stride;
+  /* transposed copies [B,N,ch] of the logits the reference hands out as transposed views (:286,:300-301), or NULL */
+  float *cls_logits_t, *angle_logits_t, *angle_res_norm_t;
 } vdetr_box_decode_desc;
 
 /* Gradients w.r.t. the forward's outputs (each may be NULL = unused) and w.r.t. the head outputs (required). */
@@ -216,6 +221,12 @@ typedef struct vdetr_box_decode_grads {
   const float *corners, *corners_aa;    /* [B,N,8,3] */
   float *d_center, *d_size;             /* [B,3,N] */
   float *d_angle_cls, *d_angle_res;     /* [B,A,N] */
+  /* gradients of the transposed logit outputs [B,N,ch] (each may be NULL) and, if cls_logits_t was produced, the class
+     head's gradient buffer [B,C1,N] (NULL otherwise) */
+  const float *cls_logits_t, *angle_logits_t, *angle_res_norm_t;
+  float* d_cls;
+  /* slab mode: floats between scenes for every d_* pointer (0 = dense) and rows per slab (rows >= ch are zero-filled) */
+  int32_t out_batch_stride, slab_rows;
 } vdetr_box_decode_grads;
 
 int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stream);

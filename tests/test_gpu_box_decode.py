@@ -63,3 +63,38 @@ def test_box_decode_unused_outputs_and_cpu_error():
     assert torch.isfinite(r["center_head"].grad).all() and r["size_head"].grad.abs().max() == 0
     with pytest.raises(RuntimeError, match="CPU not supported"):
         decode_boxes({k: v.cpu() for k, v in raw.items()}, pre_c.cpu(), pre_s.cpu(), [d.cpu() for d in dims], 1)
+
+
+@pytest.mark.parametrize("B,N,A,C1,cls_loss", [(1, 1024, 1, 19, "celoss"), (2, 200, 12, 11, "celoss"), (2, 64, 12, 10, "focalloss_0.25")])
+def test_box_decode_joint_slabs_match_oracle(B, N, A, C1, cls_loss):
+    """The five head outputs as slabs of one [B,5,rows,N] tensor: same dictionary, and the backward delivers the whole
+    gradient of the joint tensor (zeros in the slab padding) in one launch."""
+    from oracle.box_oracle import decode_boxes_reference
+    from vdetr_amd.box_decode import decode_boxes_joint
+    dev = torch.device("cuda")
+    chans = (C1, 3, 3, A, A)
+    rows = max(chans) + 2
+    g = torch.Generator().manual_seed(N + A)
+    y0 = torch.randn(B, 5, rows, N, generator=g)
+    _, pre_c, pre_s, dims = _inputs(B, N, A, C1, 3, dev)
+    names = ("sem_cls_head", "center_head", "size_head", "angle_cls_head", "angle_residual_head")
+    res, grads = {}, {}
+    for name, where in (("hip", dev), ("ref", torch.device("cpu"))):
+        y = y0.to(where).requires_grad_(True)
+        if name == "hip":
+            out = decode_boxes_joint(y, chans, pre_c, pre_s, dims, A, cls_loss)
+        else:
+            raw = {n: y[:, i, :chans[i]] for i, n in enumerate(names)}
+            out = decode_boxes_reference(raw, pre_c.cpu(), pre_s.cpu(), [d.cpu() for d in dims], A, cls_loss)
+        gg = torch.Generator().manual_seed(5)
+        loss = 0
+        for k in DIFF_KEYS:
+            loss = loss + (out[k] * torch.randn(out[k].shape, generator=gg).to(where)).sum()
+        loss.backward()
+        res[name] = {k: v.detach().cpu().numpy() for k, v in out.items()}
+        grads[name] = y.grad.detach().cpu().numpy()
+    for k, ref in res["ref"].items():
+        np.testing.assert_allclose(res["hip"][k], ref, rtol=1e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(grads["hip"], grads["ref"], rtol=1e-3, atol=1e-4 * np.abs(grads["ref"]).max())
+    for i in range(5):
+        assert np.abs(grads["hip"][:, i, chans[i]:]).max() == 0

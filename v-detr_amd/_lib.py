@@ -44,7 +44,8 @@ class BoxDecodeDesc(ctypes.Structure):
     """Mirror of ``vdetr_box_decode_desc`` (include/vdetr_hip.h)."""
 
     _fields_ = ([(n, ctypes.c_int32) for n in ("B", "N", "A", "C1", "num_angle_bin", "cls_kind")] +
-                [(n, c_void_p) for n in _BOX_IN + _BOX_OUT])
+                [(n, c_void_p) for n in _BOX_IN + _BOX_OUT] + [("in_batch_stride", ctypes.c_int32)] +
+                [(n, c_void_p) for n in ("cls_logits_t", "angle_logits_t", "angle_res_norm_t")])
 
 
 _BOX_GRAD_IN = ("center_reg", "size_reg", "center_unnorm", "center_norm", "size_unnorm", "size_norm", "angle_residual",
@@ -55,7 +56,9 @@ _BOX_GRAD_OUT = ("d_center", "d_size", "d_angle_cls", "d_angle_res")
 class BoxDecodeGrads(ctypes.Structure):
     """Mirror of ``vdetr_box_decode_grads``."""
 
-    _fields_ = [(n, c_void_p) for n in _BOX_GRAD_IN + _BOX_GRAD_OUT]
+    _fields_ = ([(n, c_void_p) for n in _BOX_GRAD_IN + _BOX_GRAD_OUT] +
+                [(n, c_void_p) for n in ("cls_logits_t", "angle_logits_t", "angle_res_norm_t", "d_cls")] +
+                [("out_batch_stride", ctypes.c_int32), ("slab_rows", ctypes.c_int32)])
 
 
 class AddLnDesc(ctypes.Structure):

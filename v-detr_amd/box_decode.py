@@ -18,9 +18,10 @@ _OUT3 = ("center_reg", "size_reg", "center_unnorm", "center_norm", "size_unnorm"
 def _desc(B, N, A, C1, num_angle_bin, cls_kind, tensors):
     d = L.BoxDecodeDesc()
     d.B, d.N, d.A, d.C1, d.num_angle_bin, d.cls_kind = B, N, A, C1, num_angle_bin, cls_kind
-    for k in L._BOX_IN + L._BOX_OUT:
+    for k in L._BOX_IN + L._BOX_OUT + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t"):
         t = tensors.get(k)
-        setattr(d, k, t.data_ptr() if t is not None else None)
+        setattr(d, k, (t if isinstance(t, int) else t.data_ptr()) if t is not None else None)
+    d.in_batch_stride = int(tensors.get("in_batch_stride", 0))
     return d
 
 
@@ -91,26 +92,103 @@ class _BoxDecode(torch.autograd.Function):
         return d_center, d_size, d_acls, d_ares, None, None, None, None, None, None, None
 
 
-def decode_boxes(raw, pre_center_normalized, pre_size_normalized, point_cloud_dims, num_angle_bin, cls_loss="celoss"):
-    """raw: {"center_head", "size_head", "angle_cls_head", "angle_residual_head", "sem_cls_head"} -> [B, ch, N] head
-    outputs.  Returns the reference's box-prediction dictionary (vdetr_transformer.py:319-333)."""
-    assert not pre_center_normalized.requires_grad and not pre_size_normalized.requires_grad, \
-        "the prior boxes of a stage are detached in the reference (vdetr_transformer.py:385-394, 427-431)"
+_JOINT_ORDER = ("cls", "center", "size", "angle_cls", "angle_res")  # slab order = TransformerDecoder._HEAD_NAMES
+
+
+class _BoxDecodeJoint(torch.autograd.Function):
+    """The five head outputs as slabs of ONE tensor y [B, 5, rows, N] (the batched output GEMM of the heads).  The logits
+    the reference returns as transposed views are real (transposed) outputs here, so the whole backward is one launch
+    that writes the complete gradient of y (slab padding included)."""
+    OUTS = _BoxDecode.OUTS + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t")
+
+    @staticmethod
+    def forward(ctx, y, chans, pre_center_norm, pre_size_norm, dims_min, dims_max, num_angle_bin, cls_kind):
+        for k, t in (("y", y), ("pre_center_norm", pre_center_norm), ("pre_size_norm", pre_size_norm),
+                     ("dims_min", dims_min), ("dims_max", dims_max)):
+            L.require_gpu(t, k)
+            L.require_float(t, k)
+        y = y.contiguous()
+        pre_center_norm, pre_size_norm = pre_center_norm.contiguous(), pre_size_norm.contiguous()
+        dims_min, dims_max = dims_min.contiguous(), dims_max.contiguous()
+        B, G, rows, N = y.shape
+        C1, A = chans[0], chans[3]
+        assert G == 5 and chans[1] == 3 and chans[2] == 3 and chans[4] == A and max(chans) <= rows
+        slab = rows * N * 4
+        ins = {k: y.data_ptr() + i * slab for i, k in enumerate(_JOINT_ORDER)}
+        new = y.new_empty
+        outs = {k: new((B, N, 3)) for k in _OUT3}
+        outs["angle_residual"] = new((B, N, A))
+        outs["angle_cont"], outs["angle_prob"], outs["objectness"] = new((B, N)), new((B, N)), new((B, N))
+        outs["angle_class"] = torch.empty((B, N), dtype=torch.int32, device=y.device)
+        outs["corners"] = new((B, N, 8, 3))
+        outs["corners_aa"] = new((B, N, 8, 3)) if A > 1 else None
+        outs["cls_prob"] = new((B, N, C1 - 1)) if cls_kind == L.VDETR_CLS_SOFTMAX else None
+        outs["cls_logits_t"], outs["angle_logits_t"], outs["angle_res_norm_t"] = new((B, N, C1)), new((B, N, A)), new((B, N, A))
+        d = _desc(B, N, A, C1, num_angle_bin, cls_kind,
+                  {**ins, "pre_center_norm": pre_center_norm, "pre_size_norm": pre_size_norm, "dims_min": dims_min,
+                   "dims_max": dims_max, **outs, "in_batch_stride": G * rows * N})
+        L.check(L.lib().vdetr_box_decode_fwd_f32(ctypes.byref(d), L.stream_ptr()), "box_decode_fwd")
+        ctx.meta = (B, N, A, C1, num_angle_bin, cls_kind, G, rows)
+        ctx.save_for_backward(y, dims_min, dims_max, outs["size_unnorm"], outs["pre_size_unnorm"], outs["angle_cont"],
+                              outs["angle_class"])
+        ctx.set_materialize_grads(False)
+        nondiff = [outs[k] for k in ("pre_center_unnorm", "pre_size_unnorm", "objectness")]
+        if outs["cls_prob"] is not None:
+            nondiff.append(outs["cls_prob"])
+        ctx.mark_non_differentiable(*nondiff)
+        return tuple(outs[k] for k in _BoxDecodeJoint.OUTS)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, N, A, C1, num_angle_bin, cls_kind, G, rows = ctx.meta
+        y, dims_min, dims_max, size_unnorm, pre_size_unnorm, angle_cont, angle_class = ctx.saved_tensors
+        gin = dict(zip(_BoxDecodeJoint.OUTS, grads))
+        slab = rows * N * 4
+        d = _desc(B, N, A, C1, num_angle_bin, cls_kind,
+                  {**{k: y.data_ptr() + i * slab for i, k in enumerate(_JOINT_ORDER)},
+                   "dims_min": dims_min, "dims_max": dims_max, "size_unnorm": size_unnorm,
+                   "pre_size_unnorm": pre_size_unnorm, "angle_cont": angle_cont, "angle_class": angle_class,
+                   "pre_center_norm": size_unnorm, "pre_size_norm": size_unnorm, "in_batch_stride": G * rows * N})
+        g = L.BoxDecodeGrads()
+        keep = []
+        for k in L._BOX_GRAD_IN + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t"):
+            t = gin.get(k)
+            if t is not None:
+                t = t.contiguous()
+                keep.append(t)
+            setattr(g, k, t.data_ptr() if t is not None else None)
+        d_y = torch.empty_like(y)
+        base = d_y.data_ptr()
+        g.d_cls, g.d_center, g.d_size, g.d_angle_cls, g.d_angle_res = (base, base + slab, base + 2 * slab, base + 3 * slab,
+                                                                         base + 4 * slab)
+        g.out_batch_stride, g.slab_rows = G * rows * N, rows
+        L.check(L.lib().vdetr_box_decode_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "box_decode_bwd")
+        return d_y, None, None, None, None, None, None, None
+
+
+def decode_boxes_joint(y, chans, pre_center_normalized, pre_size_normalized, point_cloud_dims, num_angle_bin,
+                       cls_loss="celoss"):
+    """As decode_boxes, for the heads' outputs as slabs of y [B, 5, rows, N] in the order (sem_cls, center, size,
+    angle_cls, angle_residual) with ``chans`` used rows each."""
+    assert not pre_center_normalized.requires_grad and not pre_size_normalized.requires_grad
     cls_kind = L.VDETR_CLS_SIGMOID if cls_loss.split("_")[0] == "focalloss" else L.VDETR_CLS_SOFTMAX
-    o = dict(zip(_BoxDecode.OUTS, _BoxDecode.apply(
-        raw["center_head"], raw["size_head"], raw["angle_cls_head"], raw["angle_residual_head"], raw["sem_cls_head"],
-        pre_center_normalized, pre_size_normalized, point_cloud_dims[0], point_cloud_dims[1], int(num_angle_bin), cls_kind)))
-    cls_logits = raw["sem_cls_head"].transpose(1, 2)
+    o = dict(zip(_BoxDecodeJoint.OUTS, _BoxDecodeJoint.apply(
+        y, tuple(int(c) for c in chans), pre_center_normalized, pre_size_normalized, point_cloud_dims[0],
+        point_cloud_dims[1], int(num_angle_bin), cls_kind)))
+    return _result(o, o["cls_logits_t"], o["angle_logits_t"], o["angle_res_norm_t"])
+
+
+def _result(o, cls_logits, angle_logits, angle_residual_normalized):
     return {
         "sem_cls_logits": cls_logits,
         "center_normalized": o["center_norm"],
         "center_unnormalized": o["center_unnorm"],
         "size_normalized": o["size_norm"],
         "size_unnormalized": o["size_unnorm"],
-        "angle_logits": raw["angle_cls_head"].transpose(1, 2),
+        "angle_logits": angle_logits,
         "angle_prob": o["angle_prob"],
         "angle_residual": o["angle_residual"],
-        "angle_residual_normalized": raw["angle_residual_head"].transpose(1, 2),
+        "angle_residual_normalized": angle_residual_normalized,
         "angle_continuous": o["angle_cont"],
         "objectness_prob": o["objectness"],
         "sem_cls_prob": o["cls_prob"] if o["cls_prob"] is not None else cls_logits,
@@ -121,3 +199,16 @@ def decode_boxes(raw, pre_center_normalized, pre_size_normalized, point_cloud_di
         "pre_box_size_unnormalized": o["pre_size_unnorm"],
         "size_reg": o["size_reg"],
     }
+
+
+def decode_boxes(raw, pre_center_normalized, pre_size_normalized, point_cloud_dims, num_angle_bin, cls_loss="celoss"):
+    """raw: {"center_head", "size_head", "angle_cls_head", "angle_residual_head", "sem_cls_head"} -> [B, ch, N] head
+    outputs.  Returns the reference's box-prediction dictionary (vdetr_transformer.py:319-333)."""
+    assert not pre_center_normalized.requires_grad and not pre_size_normalized.requires_grad, \
+        "the prior boxes of a stage are detached in the reference (vdetr_transformer.py:385-394, 427-431)"
+    cls_kind = L.VDETR_CLS_SIGMOID if cls_loss.split("_")[0] == "focalloss" else L.VDETR_CLS_SOFTMAX
+    o = dict(zip(_BoxDecode.OUTS, _BoxDecode.apply(
+        raw["center_head"], raw["size_head"], raw["angle_cls_head"], raw["angle_residual_head"], raw["sem_cls_head"],
+        pre_center_normalized, pre_size_normalized, point_cloud_dims[0], point_cloud_dims[1], int(num_angle_bin), cls_kind)))
+    return _result(o, raw["sem_cls_head"].transpose(1, 2), raw["angle_cls_head"].transpose(1, 2),
+                   raw["angle_residual_head"].transpose(1, 2))

@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_de
   if (t >= d.B * d.N) return;
   const int b = t / d.N, n = t - b * d.N;
   const size_t o3 = (size_t)t * 3;
+  // element (b, channel a, n) of a head output with `ch` channels: dense [B,ch,N] or a slab of a joint tensor
+  auto in = [&](const float* p, int ch, int a) {
+    return p[(size_t)b * (d.in_batch_stride ? (size_t)d.in_batch_stride : (size_t)ch * d.N) + (size_t)a * d.N + n];
+  };
   float dmin[3], scene[3], pcu[3], psu[3], cu[3], su[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -42,8 +46,8 @@ __global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_de
     scene[a] = d.dims_max[b * 3 + a] - dmin[a];
     pcu[a] = d.pre_center_norm[o3 + a] * scene[a] + dmin[a];
     psu[a] = d.pre_size_norm[o3 + a] * scene[a];
-    const float creg = d.center[((size_t)b * 3 + a) * d.N + n];
-    const float sreg = d.size[((size_t)b * 3 + a) * d.N + n];
+    const float creg = in(d.center, 3, a);
+    const float sreg = in(d.size, 3, a);
     cu[a] = creg * psu[a] + pcu[a];
     su[a] = expf(sreg) * psu[a];
     d.center_reg[o3 + a] = creg;
@@ -61,21 +65,26 @@ __global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_de
   int cls = 0;
   const float res_scale = kPi / (float)A;
   if (A == 1) {
-    const float al = d.angle_cls[(size_t)b * d.N + n], ar = d.angle_res[(size_t)b * d.N + n] * res_scale;
+    const float al = in(d.angle_cls, 1, 0), arn = in(d.angle_res, 1, 0), ar = arn * res_scale;
     d.angle_residual[t] = ar;
+    if (d.angle_logits_t) d.angle_logits_t[t] = al;
+    if (d.angle_res_norm_t) d.angle_res_norm_t[t] = arn;
     angle = fmaxf(al * 0.f + ar * 0.f, 0.f);  // (:53-55) the head outputs stay in the graph, multiplied by zero
     prob = angle;
   } else {
     float mx = -INFINITY;
     for (int a = 0; a < A; ++a) {
-      const float al = d.angle_cls[((size_t)b * A + a) * d.N + n];
+      const float al = in(d.angle_cls, A, a);
       if (al > mx) { mx = al; cls = a; }  // first maximum
     }
     float den = 0.f, rsel = 0.f;
     for (int a = 0; a < A; ++a) {
-      den += expf(d.angle_cls[((size_t)b * A + a) * d.N + n] - mx);
-      const float ar = d.angle_res[((size_t)b * A + a) * d.N + n] * res_scale;
+      const float al = in(d.angle_cls, A, a), arn = in(d.angle_res, A, a);
+      den += expf(al - mx);
+      const float ar = arn * res_scale;
       d.angle_residual[(size_t)t * A + a] = ar;
+      if (d.angle_logits_t) d.angle_logits_t[(size_t)t * A + a] = al;
+      if (d.angle_res_norm_t) d.angle_res_norm_t[(size_t)t * A + a] = arn;
       if (a == cls) rsel = ar;
     }
     prob = 1.f / den;
@@ -97,22 +106,24 @@ __global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_de
   }
   // ---- class probabilities (BoxProcessor.compute_objectness_and_cls_prob, :73-86; no gradient) ---------------------
   const int C1 = d.C1;
+  if (d.cls_logits_t)
+    for (int c = 0; c < C1; ++c) d.cls_logits_t[(size_t)t * C1 + c] = in(d.cls, C1, c);
   if (d.cls_kind == VDETR_CLS_SOFTMAX) {
     float mx = -INFINITY;
-    for (int c = 0; c < C1; ++c) mx = fmaxf(mx, d.cls[((size_t)b * C1 + c) * d.N + n]);
+    for (int c = 0; c < C1; ++c) mx = fmaxf(mx, in(d.cls, C1, c));
     float den = 0.f;
-    for (int c = 0; c < C1; ++c) den += expf(d.cls[((size_t)b * C1 + c) * d.N + n] - mx);
+    for (int c = 0; c < C1; ++c) den += expf(in(d.cls, C1, c) - mx);
     const float inv = 1.f / den;
     float last = 0.f;
     for (int c = 0; c < C1; ++c) {
-      const float p = expf(d.cls[((size_t)b * C1 + c) * d.N + n] - mx) * inv;
+      const float p = expf(in(d.cls, C1, c) - mx) * inv;
       if (c < C1 - 1) d.cls_prob[(size_t)t * (C1 - 1) + c] = p;
       else last = p;
     }
     d.objectness[t] = 1.f - last;
   } else {  // focal loss: sem_cls_prob IS the logits (a view on the caller's side); objectness = max sigmoid
     float mx = -INFINITY;
-    for (int c = 0; c < C1; ++c) mx = fmaxf(mx, d.cls[((size_t)b * C1 + c) * d.N + n]);
+    for (int c = 0; c < C1; ++c) mx = fmaxf(mx, in(d.cls, C1, c));
     d.objectness[t] = 1.f / (1.f + expf(-mx));
   }
 }
@@ -124,6 +135,16 @@ __global__ __launch_bounds__(256) void box_decode_bwd_kernel(vdetr_box_decode_de
   const int b = t / d.N, n = t - b * d.N;
   const size_t o3 = (size_t)t * 3;
   auto ld = [](const float* p, size_t i) { return p ? p[i] : 0.f; };
+  auto in = [&](const float* p, int ch, int a) {
+    return p[(size_t)b * (d.in_batch_stride ? (size_t)d.in_batch_stride : (size_t)ch * d.N) + (size_t)a * d.N + n];
+  };
+  // gradient element (b, channel a, n) of a head output; with slabs (g.slab_rows > 0) the rows [ch, slab_rows) are padding
+  auto out = [&](float* p, int ch, int a) -> float& {
+    return p[(size_t)b * (g.out_batch_stride ? (size_t)g.out_batch_stride : (size_t)ch * d.N) + (size_t)a * d.N + n];
+  };
+  auto pad = [&](float* p, int ch) {
+    for (int a = ch; a < g.slab_rows; ++a) out(p, ch, a) = 0.f;
+  };
   float scene[3], psu[3], su[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -162,8 +183,14 @@ __global__ __launch_bounds__(256) void box_decode_bwd_kernel(vdetr_box_decode_de
   corner_grads(g.corners_aa, 1.f, 0.f, false);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    g.d_center[((size_t)b * 3 + a) * d.N + n] = ld(g.center_reg, o3 + a) + gcu[a] * psu[a];
-    g.d_size[((size_t)b * 3 + a) * d.N + n] = ld(g.size_reg, o3 + a) + gsu[a] * su[a];
+    out(g.d_center, 3, a) = ld(g.center_reg, o3 + a) + gcu[a] * psu[a];
+    out(g.d_size, 3, a) = ld(g.size_reg, o3 + a) + gsu[a] * su[a];
+  }
+  pad(g.d_center, 3);
+  pad(g.d_size, 3);
+  if (g.d_cls) {  // the class logits are handed out transposed ([B,N,C1]); their gradient comes back the same way
+    for (int c = 0; c < d.C1; ++c) out(g.d_cls, d.C1, c) = ld(g.cls_logits_t, (size_t)t * d.C1 + c);
+    pad(g.d_cls, d.C1);
   }
   const int A = d.A;
   const float res_scale = kPi / (float)A;
@@ -171,23 +198,25 @@ __global__ __launch_bounds__(256) void box_decode_bwd_kernel(vdetr_box_decode_de
     // angle = clamp(0*logit + 0*residual, 0): the head outputs only receive the direct residual gradient (x0 paths
     // contribute exact zeros unless the incoming gradient is not finite, which the reference would also spread)
     const float z = (gang + ld(g.angle_prob, t)) * 0.f;
-    g.d_angle_cls[(size_t)b * d.N + n] = z;
-    g.d_angle_res[(size_t)b * d.N + n] = ld(g.angle_residual, t) * res_scale + z * res_scale;
+    out(g.d_angle_cls, 1, 0) = z + ld(g.angle_logits_t, t);
+    out(g.d_angle_res, 1, 0) = ld(g.angle_residual, t) * res_scale + z * res_scale + ld(g.angle_res_norm_t, t);
   } else {
     const int cls = d.angle_class[t];
     const float gp = ld(g.angle_prob, t);
     float mx = -INFINITY;
-    for (int a = 0; a < A; ++a) mx = fmaxf(mx, d.angle_cls[((size_t)b * A + a) * d.N + n]);
+    for (int a = 0; a < A; ++a) mx = fmaxf(mx, in(d.angle_cls, A, a));
     float den = 0.f;
-    for (int a = 0; a < A; ++a) den += expf(d.angle_cls[((size_t)b * A + a) * d.N + n] - mx);
+    for (int a = 0; a < A; ++a) den += expf(in(d.angle_cls, A, a) - mx);
     const float pc = 1.f / den;  // = softmax at the arg-max
     for (int a = 0; a < A; ++a) {
-      const float pa = expf(d.angle_cls[((size_t)b * A + a) * d.N + n] - mx) / den;
-      g.d_angle_cls[((size_t)b * A + a) * d.N + n] = gp * pc * ((a == cls ? 1.f : 0.f) - pa);
-      g.d_angle_res[((size_t)b * A + a) * d.N + n] =
-          (ld(g.angle_residual, (size_t)t * A + a) + (a == cls ? gang : 0.f)) * res_scale;
+      const float pa = expf(in(d.angle_cls, A, a) - mx) / den;
+      out(g.d_angle_cls, A, a) = gp * pc * ((a == cls ? 1.f : 0.f) - pa) + ld(g.angle_logits_t, (size_t)t * A + a);
+      out(g.d_angle_res, A, a) = (ld(g.angle_residual, (size_t)t * A + a) + (a == cls ? gang : 0.f)) * res_scale +
+                                 ld(g.angle_res_norm_t, (size_t)t * A + a);
     }
   }
+  pad(g.d_angle_cls, A);
+  pad(g.d_angle_res, A);
 }
 
 }  // namespace vdetr

@@ -622,7 +622,7 @@ class TransformerDecoder(nn.Module):
             y = torch.matmul(w3.squeeze(-1).unsqueeze(0), x.view(Bsz, G, C, N))           # [B, G, rows, N]
             if b3 is not None:
                 y = y + b3.view(1, G, rows, 1)
-            return {n: y[:, g, :outs[g]] for g, n in enumerate(names)}
+            return {"_joint": (y, outs)}  # the box decode reads the slabs in place (and writes their gradient whole)
         # unbind (one stack kernel in backward) rather than five slices (five zero-fills + copies + adds)
         xs = x.view(Bsz, G, C, N).unbind(1)
         return {n: L[g][8](xs[g]) for g, n in enumerate(names)}
@@ -641,6 +641,11 @@ class TransformerDecoder(nn.Module):
         feats = box_features.permute(1, 2, 0)  # B x C x nQ
         heads = self.mlp_heads[idx] if self.mlp_sep else self.mlp_heads
         raw = self._run_heads(heads, feats)
+        if "_joint" in raw:
+            y, chans = raw["_joint"]
+            return box_decode.decode_boxes_joint(y, chans, pre_center_normalized, pre_size_normalized, point_cloud_dims,
+                                                 self.box_processor.dataset_config.num_angle_bin,
+                                                 self.box_processor.cls_loss)
         # everything after the heads (:286-333: ~45 ATen launches on [B,nQ,<=24] tensors, as many again in backward)
         # is one HIP launch forward and one backward
         return box_decode.decode_boxes(raw, pre_center_normalized, pre_size_normalized, point_cloud_dims,
