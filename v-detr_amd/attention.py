@@ -159,9 +159,12 @@ class _FusedAttention(Function):
             do_r = dout.view(B, nQ * H, HEAD_DIM)
             dprob = torch.bmm(do_r, v.transpose(1, 2))  # [B, nQ*H, nK]
         else:
-            # rows (b, h, q): [B*H, nQ, 64]; K/V [B*H, nK, 64]
-            do_r = dout.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
-            v_r = v.reshape(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
+            # rows (b, h, q): [B*H, nQ, 64]; K/V [B*H, nK, 64].  For one scene the per-head operands are plain strided
+            # views [H, L, 64] (row stride H*64) that the batched GEMM reads in place; B > 1 needs the copies.
+            def heads(t, n):
+                t4 = t.reshape(B, n, H, HEAD_DIM).permute(0, 2, 1, 3)
+                return t4[0] if B == 1 else t4.reshape(B * H, n, HEAD_DIM)
+            do_r, v_r = heads(dout, nQ), heads(v, nK)
             dprob = torch.bmm(do_r, v_r.transpose(1, 2))  # [B*H, nQ, nK]
         want_table = table is not None and ctx.needs_input_grad[3]
         dtable = torch.zeros_like(table) if want_table else None
@@ -185,8 +188,7 @@ class _FusedAttention(Function):
         else:
             p_r = scores.view(B * H, nQ, nK)
             ds_r = dprob
-            q_r = q.view(B, nQ, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nQ, HEAD_DIM)
-            k_r = k.reshape(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * H, nK, HEAD_DIM)
+            q_r, k_r = heads(q, nQ), heads(k, nK)
             dv = torch.bmm(p_r.transpose(1, 2), do_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
             dk = torch.bmm(ds_r.transpose(1, 2), q_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
             dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
