@@ -105,7 +105,17 @@ if __name__ == "__main__":
     if "--issue" in sys.argv:
         issue_probe()
         sys.exit(0)
-    cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    cfg = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "c2"
+    if "--with-fps" in sys.argv:  # one CU busy with the side-stream FPS, as in the training step
+        from vdetr_amd import pointnet2_utils as PU
+        pts = bench.make_scene(40000, 0, "cuda")[0][None].contiguous()
+        side = torch.cuda.Stream()
+        _orig = bench.kernel_rooflines.__globals__["torch"].cuda.Event
+        def keep_busy():
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    PU.furthest_point_sample(pts, 4096)
+        keep_busy()
     f, b = bench.kernel_rooflines(cfg, torch.device("cuda"))
     print(json.dumps({"variant": os.environ.get("VDETR_BWD_VARIANT", "default"), "fwd_us": f["launch_us"], "bwd_us": b["launch_us"]}))
     print(json.dumps(time_fps(bench.CONFIGS[cfg][0], 4096)))
