@@ -132,6 +132,11 @@ typedef struct vdetr_attn_desc {
          K/V of all decoder layers come out of ONE projection GEMM over the layer-invariant encoder features
          (vdetr_transformer.py:733-735 runs self.k / self.v per layer on the same `key`). --- */
   int32_t k_row_stride, v_row_stride;
+  /* --- backward only: four zero-initialised device words {max |dO row|^2, max |V row|^2, query counters of the two
+         vertex halves}.  vdetr_attn_delta_f32 fills the first two, vdetr_attn_bwd_scores_f32 then distributes the
+         queries dynamically over its workgroups (a CU busy with other work costs 1/8 of a round, not a whole one) and
+         takes the fixed-point scale from the Cauchy-Schwarz bound.  NULL: static distribution. --- */
+  uint32_t* bwd_aux;
 } vdetr_attn_desc;
 
 /* Scratch needed by fwd (key-split partials). */
@@ -164,8 +169,9 @@ int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, con
                               size_t workspace_bytes, vdetr_stream_t stream);
 
 /* delta = rowsum(dO * O) over the 64 channels of a head, in the row order of the kind (see vdetr_attn_fwd_f32);
- * dout / out [B,nQ,H*64].  The softmax-backward term the score stage subtracts. */
-int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, float* delta,
+ * dout / out [B,nQ,H*64].  The softmax-backward term the score stage subtracts.  With d->bwd_aux (shared-KV kind, `v` as
+ * passed to the forward) the launch also produces the two norm maxima described at vdetr_attn_desc.bwd_aux. */
+int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, const float* v, float* delta,
                          vdetr_stream_t stream);
 
 /* Test hook: writes the dropout keep-mask (1/0 as uint8) [B,nQ,H,nK] the kernels above use. */

@@ -31,7 +31,7 @@ def test_library_exports_every_symbol():
 def test_descriptor_layout():
     from vdetr_amd import _lib
     # 6x4 | ptr | 3x4 + pad | 3 ptr | ptr | 2x4 | 2x8 | ptr
-    assert ctypes.sizeof(_lib.AttnDesc) == 120
+    assert ctypes.sizeof(_lib.AttnDesc) == 128
     assert _lib.AttnDesc.table.offset == 24 and _lib.AttnDesc.vertices.offset == 48
     assert _lib.AttnDesc.seed.offset == 88 and _lib.AttnDesc.rng_state.offset == 104
 

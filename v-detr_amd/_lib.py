@@ -29,6 +29,7 @@ class AttnDesc(ctypes.Structure):
         ("dropout_p", c_float), ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
         ("rng_state", c_void_p),
         ("k_row_stride", ctypes.c_int32), ("v_row_stride", ctypes.c_int32),
+        ("bwd_aux", c_void_p),
     ]
 
 
@@ -94,7 +95,7 @@ _SIGNATURES = {
     "vdetr_attn_fwd_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
     "vdetr_attn_bwd_scores_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "vdetr_attn_delta_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vdetr_attn_delta_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vdetr_attn_dropout_mask_u8": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
     "vdetr_rpe_bias_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
     "vdetr_box_decode_fwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), c_void_p]),

@@ -12,6 +12,7 @@ Forward saves the biased scores S [rows, nK] and the row log-sum-exp; backward i
   dP~ = dO V^T (GEMM) -> kernel: P~, dS, dTable -> dV = P~^T dO, dK = dS^T q, dQ = dS K (GEMMs).
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -46,6 +47,7 @@ def new_rng_state(device, seed=None):
 # is never written again, so autograd can keep it by reference) and bumps the master offset with a device op:
 # the same captured hipGraph therefore draws fresh dropout masks on every replay.  Modules that share a snapshot
 # stay independent through their per-module ``salt`` (the by-value seed of the descriptor).
+DYNAMIC_BWD = os.environ.get("VDETR_BWD_DYNAMIC", "1") != "0"
 _master = {}
 _current = {}
 
@@ -151,9 +153,14 @@ class _FusedAttention(Function):
         lib = L.lib()
         dout = dout.contiguous()
         shared = kind == L.VDETR_ATTN_SHARED_KV
-        d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt)
+        want_table = table is not None and ctx.needs_input_grad[3]
+        d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt, 0, v.stride(1))
+        if want_table and DYNAMIC_BWD:  # norm maxima + query counters for the dynamic distribution (see vdetr_hip.h)
+            aux = torch.zeros(4, dtype=torch.int32, device=q.device)
+            d.bwd_aux = aux.data_ptr()
         delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
-        L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(delta), L.stream_ptr()), "attn_delta")
+        L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),
+                "attn_delta")
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)
@@ -166,7 +173,6 @@ class _FusedAttention(Function):
                 return t4[0] if B == 1 else t4.reshape(B * H, n, HEAD_DIM)
             do_r, v_r = heads(dout, nQ), heads(v, nK)
             dprob = torch.bmm(do_r, v_r.transpose(1, 2))  # [B*H, nQ, nK]
-        want_table = table is not None and ctx.needs_input_grad[3]
         dtable = torch.zeros_like(table) if want_table else None
         nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d)) if want_table else 0
         ws = L.workspace(nbytes, q.device) if nbytes else None

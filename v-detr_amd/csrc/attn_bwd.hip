@@ -283,7 +283,22 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
   const int items = P.B * P.nQ;
   for (int i = tid; i < table_floats; i += kThreads) smem[i] = 0.f;
   float fix_scale = 1.f, fix_inv = 1.f;
-  if (FIXED) {
+  // Dynamic query distribution (P.bwd_aux != NULL): the workgroups of a vertex half pull queries from a device counter,
+  // so a CU that is busy elsewhere (the side-stream FPS) costs 1/8 of a round instead of a whole one.  The histogram
+  // scale must then hold for ANY set of queries: |dP~| <= |dO row| * |V row| (Cauchy-Schwarz) with the two maxima left
+  // in aux[0..1] by vdetr_attn_delta_f32, and a workgroup stops after `cap` queries.
+  const bool dynamic = P.bwd_aux != nullptr;
+  const int per_wg = (items + nwg - 1) / nwg;
+  const int cap = dynamic ? 2 * per_wg : per_wg;
+  if (FIXED && dynamic) {
+    const float dmax = sqrtf(__uint_as_float(P.bwd_aux[0]) * __uint_as_float(P.bwd_aux[1]));
+    const float bound = 2.f * P.drop_scale * dmax * (float)cap;
+    if (bound > 0.f && bound < INFINITY) {
+      const int e = 30 - (int)ceilf(__log2f(bound) + 1e-3f);  // 2^e * bound <= 2^30
+      fix_scale = ldexpf(1.f, e);
+      fix_inv = ldexpf(1.f, -e);
+    }
+  } else if (FIXED) {
     // max |dP~| over this workgroup's rows (the 4 head rows of a query are contiguous: one 16-B aligned run)
     float m = 0.f;
     for (int item = wg; item < items; item += nwg) {
@@ -305,7 +320,6 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
     float dmax = 0.f;
 #pragma unroll
     for (int i = 0; i < VERTS * WPV; ++i) dmax = fmaxf(dmax, red[i]);
-    const int per_wg = (items + nwg - 1) / nwg;
     const float bound = 2.f * P.drop_scale * dmax * (float)per_wg;
     if (bound > 0.f && bound < INFINITY) {
       const int e = 30 - (int)ceilf(__log2f(bound) + 1e-3f);  // 2^e * bound <= 2^30
@@ -358,7 +372,16 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
     o.masked = has_mask ? __builtin_amdgcn_raw_buffer_load_b8(rm, key, 0, 0) : 0;
   };
 
-  for (int item = wg; item < items; item += nwg) {
+  __shared__ int next_item;
+  for (int it = 0; it < cap; ++it) {
+    int item = wg + it * nwg;
+    if (dynamic) {
+      if (tid == 0) next_item = (int)atomicAdd(const_cast<unsigned*>(P.bwd_aux) + 2 + part, 1u);
+      __syncthreads();
+      item = next_item;
+      __syncthreads();  // everyone holds the item before thread 0 fetches the next one
+    }
+    if (item >= items) break;
     const int b = item / P.nQ, q = item - b * P.nQ;
     const size_t row0 = ((size_t)b * P.nQ + q) * 4;
     // per-item constants are wave-uniform: pin them to SGPRs (the loads are vector loads because the kernel also stores)
@@ -617,17 +640,34 @@ __global__ __launch_bounds__(512) void issue_probe_kernel(int mode, int iters, f
   if (t == -1.f) sink[0] = t;
 }
 
-// delta[row] = sum_d dO[b,q,h,d] * O[b,q,h,d]: one wave per (b, q), lane l holds element h*64 + l of the four heads
+// delta[row] = sum_d dO[b,q,h,d] * O[b,q,h,d]: one wave per (b, q), lane l holds element h*64 + l of the four heads.
+// With `aux` (zeroed by the caller) the launch also leaves max_row |dO row|^2 in aux[0] and, from extra workgroups that
+// walk the key rows, max_key |V row|^2 in aux[1] (bit patterns of non-negative floats under atomicMax).
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                        float* __restrict__ delta, int B, int nQ, int H, int perhead) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                        float* __restrict__ delta, int B, int nQ, int H, int perhead,
+                                                        unsigned* aux, const float* __restrict__ v, int nK, int v_stride,
+                                                        int qblocks) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= qblocks) {  // |V row|^2 (shared-KV: 64 floats per key)
+    const int key = ((int)blockIdx.x - qblocks) * 4 + wv;
+    if (key >= B * nK) return;
+    const float x = v[(size_t)key * v_stride + lane];
+    const float s = wave_allsum_f32(x * x);
+    if (lane == 0) atomicMax(aux + 1, __float_as_uint(s));
+    return;
+  }
+  const int row = blockIdx.x * 4 + wv;
   if (row >= B * nQ) return;
   const int b = row / nQ, q = row - b * nQ;
+  float n2max = 0.f;
   for (int h = 0; h < H; ++h) {
     const size_t e = ((size_t)row * H + h) * 64 + lane;
-    const float s = wave_allsum_f32(dout[e] * out[e]);
+    const float g = dout[e];
+    const float s = wave_allsum_f32(g * out[e]);
+    if (aux) n2max = fmaxf(n2max, wave_allsum_f32(g * g));
     if (lane == 0) delta[perhead ? ((size_t)b * H + h) * nQ + q : (size_t)row * H + h] = s;
   }
+  if (aux && lane == 0) atomicMax(aux, __float_as_uint(n2max));
 }
 
 // keep-mask dump (test hook)
@@ -745,12 +785,17 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
   return VDETR_OK;
 }
 
-extern "C" int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, float* delta,
-                                    vdetr_stream_t stream) {
+extern "C" int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, const float* v,
+                                    float* delta, vdetr_stream_t stream) {
   VDETR_REQUIRE(d && dout && out && delta, "attn_delta: null pointer");
   VDETR_REQUIRE(d->B > 0 && d->nQ > 0 && d->H > 0, "attn_delta: empty dimension");
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div((long)d->B * d->nQ, 4)), dim3(256), 0, (hipStream_t)stream, dout, out,
-                     delta, d->B, d->nQ, d->H, d->kind == VDETR_ATTN_PER_HEAD ? 1 : 0);
+  const bool norms = d->bwd_aux != nullptr;
+  VDETR_REQUIRE(!norms || (v && d->kind == VDETR_ATTN_SHARED_KV), "attn_delta: bwd_aux needs v and the shared-KV kind");
+  const int qblocks = ceil_div((long)d->B * d->nQ, 4);
+  const int vblocks = norms ? ceil_div((long)d->B * d->nK, 4) : 0;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(qblocks + vblocks), dim3(256), 0, (hipStream_t)stream, dout, out, delta, d->B,
+                     d->nQ, d->H, d->kind == VDETR_ATTN_PER_HEAD ? 1 : 0, d->bwd_aux, v, d->nK,
+                     d->v_row_stride ? d->v_row_stride : 64, qblocks);
   return check_launch("attn_delta");
 }
 

@@ -20,6 +20,7 @@ struct AttnParams {
   const float* k;
   const float* v;
   int k_stride, v_stride;  // floats between consecutive key rows
+  const unsigned* bwd_aux; // {max |dO row|^2, max |V row|^2, query counter half 0, half 1} or NULL
   float* out;
   float* lse;
   float* scores;

@@ -318,6 +318,7 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   P->v_stride = d->v_row_stride ? d->v_row_stride : dense;
   VDETR_REQUIRE(P->k_stride >= dense && P->v_stride >= dense && P->k_stride % 4 == 0 && P->v_stride % 4 == 0,
                 "%s: K/V row strides %d / %d must be multiples of 4 and >= %d", op, P->k_stride, P->v_stride, dense);
+  P->bwd_aux = d->bwd_aux;
   P->table = d->table;
   if (d->table) {
     VDETR_REQUIRE(d->kind == VDETR_ATTN_SHARED_KV, "%s: RPE needs the shared-KV kind", op);
