@@ -195,8 +195,10 @@ def kernel_rooflines(cfg_name, device, reps=20):
     out = torch.empty_like(q)
     lse = torch.empty((B, nQ, H), device=device)
     scores = torch.empty((B, nQ, H, nK), device=device)
-    dprob = torch.randn((B, nQ, H, nK), generator=g).to(device) * 1e-3
+    dout = torch.randn((B, nQ, H * 64), generator=g).to(device) * 1e-3
+    dprob = torch.bmm(dout.view(B, nQ * H, 64), v.transpose(1, 2)).view(B, nQ, H, nK).contiguous()  # dP~ = dO V^T
     delta = torch.zeros((B, nQ, H), device=device)
+    aux = torch.zeros(4, dtype=torch.int32, device=device)  # norm maxima + query counters (dynamic distribution)
     dtable = torch.zeros_like(table)
     probs, dscore = torch.empty_like(scores), torch.empty_like(dprob)
     wsf = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
@@ -207,6 +209,11 @@ def kernel_rooflines(cfg_name, device, reps=20):
     def fwd():
         L.check(lib.vdetr_attn_fwd_f32(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse),
                                        L.ptr(scores), L.ptr(ws), wsf, st), "attn_fwd")
+
+    def bwd_prep():  # as attention.py's backward does before the score stage (not part of the timed launch)
+        aux.zero_()
+        d.bwd_aux = aux.data_ptr()
+        L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), st), "attn_delta")
 
     def bwd():
         L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), L.ptr(dprob), L.ptr(lse), L.ptr(delta),
@@ -227,7 +234,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
         return float(np.mean(ts))
 
     t_fwd = timeit(fwd)
-    t_bwd = timeit(bwd)
+    t_bwd = timeit(bwd, bwd_prep)
     pairs = B * nQ * nK
     flops = 4.0 * H * pairs * 64                       # QK^T + PV (MFMA-eligible), SURVEY.md §8d
     bytes_bwd = 4.0 * 4 * H * pairs                    # S, dP~ read + P~, dS written (fp32)
