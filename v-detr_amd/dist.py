@@ -231,12 +231,10 @@ class GradientReducer:
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream())  # gradients of this bucket are complete
             with torch.cuda.stream(self._side):
-                flat.div_(self.world)
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                self._allreduce_avg(flat)
             flat.record_stream(self._side)
         else:
-            flat.div_(self.world)
-            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._handles.append(self._allreduce_avg(flat, async_op=True))
 
     # ---- public -------------------------------------------------------------------------------------
     def zero_grad(self):
@@ -283,12 +281,18 @@ class GradientReducer:
         self._pending = list(self._counts)
         self._launched = [False] * len(self.buckets)
 
+    def _allreduce_avg(self, t, async_op=False):
+        """Average over the ranks.  RCCL averages inside the collective (ncclAvg); gloo (CPU tests) needs the division."""
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        t.div_(self.world)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
     def reduce_all(self):
         """Graph mode: average every bucket after the captured forward+backward has been replayed."""
         if self.world > 1:
             for b in self.buckets:
-                b.div_(self.world)
-                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                self._allreduce_avg(b)
 
     def grad_bytes(self):
         return sum(b.numel() * b.element_size() for b in self.buckets)
