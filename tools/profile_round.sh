@@ -25,5 +25,25 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:25]:
     print(f"{sum(v)/len(v):14.1f} {len(v):5d}  {k[:200]}")
 PY
 done
+# SQ counters of the hot kernels (what bounds them): two passes of 8 counters
+pass=1
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/rp_sq$pass -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_sq$pass.log 2>&1
+  f=$(find /tmp/rp_sq$pass -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python3 - "$f" > $out/pmc_sq_pass$pass.txt <<'PY'
+import csv, sys
+from collections import defaultdict
+agg = defaultdict(lambda: defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    if "vdetr" in r["Kernel_Name"]:
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in agg.items():
+    print(k[:150])
+    for c, v in sorted(cs.items()):
+        print(f"   {c:32s} n={len(v):4d} avg={sum(v)/len(v):16.1f}")
+PY
+  pass=$((pass+1))
+done
 python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400
