@@ -275,6 +275,35 @@ size_t vdetr_add_ln_bwd_workspace_bytes(const vdetr_addln_desc* d);
 int vdetr_add_ln_bwd_f32(const vdetr_addln_desc* d, const vdetr_addln_grads* g, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * y = dropout(relu(BatchNorm1d(x))) on [B, C, N]: the hidden blocks of GenericMLP (models/helpers.py:74-141,
+ * Conv1d -> BatchNorm1d -> ReLU -> Dropout; the box heads of models/vdetr_transformer.py:193-242 and
+ * PositionEmbeddingLearned, helpers.py:17-33).  One launch forward, one backward.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vdetr_bnact_desc {
+  int32_t B, C, N;
+  int32_t training;          /* 1: batch statistics (+ running-statistics update), 0: running statistics */
+  int32_t relu;              /* apply max(., 0) after the affine map */
+  float eps, momentum;
+  float dropout_p;           /* after the relu; training only */
+  uint64_t seed, offset;     /* counter-based generator, as in vdetr_attn_desc */
+  const uint64_t* rng_state;
+  const float* x;            /* [B, C, N] */
+  const float *gamma, *beta; /* [C] or both NULL */
+  float *running_mean, *running_var; /* [C], updated in place in training mode (may be NULL there) */
+  float* y;                  /* [B, C, N] */
+  float *save_mean, *save_invstd;    /* [C], written in training mode, read by backward */
+} vdetr_bnact_desc;
+
+typedef struct vdetr_bnact_grads {
+  const float* dy;            /* [B, C, N] */
+  float* dx;                  /* [B, C, N] or NULL */
+  float *d_gamma, *d_beta;    /* [C] or NULL */
+} vdetr_bnact_grads;
+
+int vdetr_bn_act_fwd_f32(const vdetr_bnact_desc* d, vdetr_stream_t stream);
+int vdetr_bn_act_bwd_f32(const vdetr_bnact_desc* d, const vdetr_bnact_grads* g, vdetr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Gradient packing: n separate fp32 tensors -> slices of one flat buffer, one launch.  The role of the bucket copy in
  * DistributedDataParallel's reducer (reference main.py:515-517).  All three tables are DEVICE arrays:
  *   entries[e]      = {src (NULL = zero-fill), dst_offset (floats), numel}

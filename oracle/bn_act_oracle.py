@@ -1,0 +1,13 @@
+"""TEST INFRASTRUCTURE — torch restatement of BatchNorm1d + ReLU + Dropout (reference models/helpers.py:74-141, the hidden
+blocks of GenericMLP) with the signature of v-detr_amd/bn_act.py:bn_act.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline import this module.  ``keep`` injects the kernel's own dropout keep-mask."""
+import torch.nn.functional as F
+
+
+def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, relu=True, dropout_p=0.0, salt=0, keep=None):
+    y = F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
+    if relu:
+        y = F.relu(y)
+    if training and dropout_p > 0.0:
+        y = y * keep / (1.0 - dropout_p) if keep is not None else F.dropout(y, dropout_p, True)
+    return y

@@ -77,6 +77,21 @@ class AddLnGrads(ctypes.Structure):
                                         "partials")]
 
 
+class BnActDesc(ctypes.Structure):
+    """Mirror of ``vdetr_bnact_desc``."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "N", "training", "relu")] + [
+        ("eps", c_float), ("momentum", c_float), ("dropout_p", c_float), ("seed", ctypes.c_uint64),
+        ("offset", ctypes.c_uint64), ("rng_state", c_void_p)] + [
+        (n, c_void_p) for n in ("x", "gamma", "beta", "running_mean", "running_var", "y", "save_mean", "save_invstd")]
+
+
+class BnActGrads(ctypes.Structure):
+    """Mirror of ``vdetr_bnact_grads``."""
+
+    _fields_ = [(n, c_void_p) for n in ("dy", "dx", "d_gamma", "d_beta")]
+
+
 # name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
 _SIGNATURES = {
     "vdetr_abi_version": (c_int, []),
@@ -103,6 +118,8 @@ _SIGNATURES = {
     "vdetr_add_ln_fwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), c_void_p]),
     "vdetr_add_ln_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AddLnDesc)]),
     "vdetr_add_ln_bwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), ctypes.POINTER(AddLnGrads), c_void_p]),
+    "vdetr_bn_act_fwd_f32": (c_int, [ctypes.POINTER(BnActDesc), c_void_p]),
+    "vdetr_bn_act_bwd_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_void_p]),
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

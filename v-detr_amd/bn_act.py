@@ -1,0 +1,78 @@
+"""BatchNorm1d + ReLU + Dropout on [B, C, N] as one HIP launch (and one for its backward).
+
+Host side of ``vdetr_bn_act_{fwd,bwd}_f32``: the hidden blocks of the reference's GenericMLP (models/helpers.py:74-141,
+``Conv1d -> BatchNorm1d -> ReLU -> Dropout``).  Running statistics are updated in place by the kernel (training mode), the
+dropout mask comes from the attention kernels' counter-based generator.  No CPU path: CPU tensors raise.
+"""
+import ctypes
+import itertools
+
+import torch
+
+from . import _lib as L
+from . import attention as A
+
+_salts = itertools.count(0xB0A70001)
+
+
+def new_salt():
+    return next(_salts)
+
+
+def _desc(x, gamma, beta, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng):
+    d = L.BnActDesc()
+    d.B, d.C, d.N = x.shape
+    d.training, d.relu, d.eps, d.momentum, d.dropout_p = int(training), int(relu), float(eps), float(momentum), float(p)
+    d.seed = int(salt) & 0xFFFFFFFFFFFFFFFF
+    d.rng_state = rng.data_ptr() if rng is not None else None
+    for k, t in (("x", x), ("gamma", gamma), ("beta", beta), ("running_mean", rm), ("running_var", rv), ("y", y),
+                 ("save_mean", smean), ("save_invstd", sinv)):
+        setattr(d, k, t.data_ptr() if t is not None else None)
+    return d
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, training, relu, eps, momentum, p, rng, salt):
+        L.require_gpu(x, "x")
+        L.require_float(x, "x")
+        x = x.contiguous()
+        gamma_c, beta_c = (gamma.contiguous(), beta.contiguous()) if gamma is not None else (None, None)
+        y = torch.empty_like(x)
+        C = x.shape[1]
+        smean = torch.empty(C, dtype=torch.float32, device=x.device) if training else None
+        sinv = torch.empty_like(smean) if training else None
+        p = p if training else 0.0
+        d = _desc(x, gamma_c, beta_c, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng if p > 0 else None)
+        L.check(L.lib().vdetr_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "bn_act_fwd")
+        ctx.cfg = (training, relu, eps, momentum, p, salt)
+        ctx.save_for_backward(x, gamma_c, beta_c, smean, sinv, rng if p > 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, relu, eps, momentum, p, salt = ctx.cfg
+        x, gamma, beta, smean, sinv, rng = ctx.saved_tensors
+        if not training:
+            raise RuntimeError("bn_act: backward through the eval-mode (running statistics) path is not built")
+        dy = dy.contiguous()
+        d = _desc(x, gamma, beta, None, None, None, smean, sinv, True, relu, eps, momentum, p, salt, rng)
+        g = L.BnActGrads()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dg = torch.empty_like(gamma) if gamma is not None and ctx.needs_input_grad[1] else None
+        db = torch.empty_like(beta) if beta is not None and ctx.needs_input_grad[2] else None
+        g.dy, g.dx = dy.data_ptr(), dx.data_ptr() if dx is not None else None
+        g.d_gamma, g.d_beta = (dg.data_ptr() if dg is not None else None), (db.data_ptr() if db is not None else None)
+        L.check(L.lib().vdetr_bn_act_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "bn_act_bwd")
+        return dx, dg, db, None, None, None, None, None, None, None, None, None
+
+
+def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, relu=True, dropout_p=0.0, salt=0):
+    """dropout(relu(batch_norm(x))) for x [B, C, N]; running statistics are updated in place when training."""
+    rng = None
+    if training and dropout_p > 0.0:
+        rng = A.current_rng(x.device)
+        if rng is None:
+            rng = A.begin_step(x.device)
+    return _BnAct.apply(x, weight, bias, running_mean, running_var, bool(training), bool(relu), float(eps), float(momentum),
+                        float(dropout_p), rng, int(salt))

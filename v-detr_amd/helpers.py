@@ -179,7 +179,17 @@ class PositionEmbeddingLearned(nn.Module):
         )
 
     def forward(self, xyz):
-        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+        head = self.position_embedding_head
+        x = xyz.transpose(1, 2)  # [B, C_in, N]; the 1x1 convolution reads the transposed operand in place
+        bn = head[1]
+        if not (self.training and x.is_cuda and bn.momentum is not None and bn.track_running_stats):
+            return head(x.contiguous())
+        from . import bn_act as BNA  # BatchNorm1d + ReLU as one launch (and one backward)
+        y = BNA.bn_act(head[0](x), bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, bn.momentum,
+                       relu=True, dropout_p=0.0)
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+        return head[3](y)
 
 
 class GenericMLP(nn.Module):

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import add_ln as ALN
+from . import bn_act as BNA
 from . import attention as A
 from . import box_decode
 from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
@@ -566,6 +567,23 @@ class TransformerDecoder(nn.Module):
                 torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
         return y
 
+    def _bn_relu_drop(self, x, bns, p, key):
+        """dropout(relu(batch_norm(x))) of G side-by-side channel groups: one HIP launch when training on the GPU with
+        the statistics laid out adjacently, the ATen composition otherwise."""
+        if not (self.training and x.is_cuda and bns[0].momentum is not None and bns[0].track_running_stats):
+            return F.dropout(F.relu(self._bn_group(x, bns, self.training)), p, self.training)
+        rm, rv = buffers_alias([b.running_mean for b in bns]), buffers_alias([b.running_var for b in bns])
+        if rm is None or rv is None:
+            return F.dropout(F.relu(self._bn_group(x, bns, self.training)), p, self.training)  # (lays them out, once)
+        if not hasattr(self, "_bn_salts"):
+            self._bn_salts = {}
+        salt = self._bn_salts.setdefault(key, BNA.new_salt())
+        y = BNA.bn_act(x, cat_params([b.weight for b in bns]), cat_params([b.bias for b in bns]), rm, rv, True,
+                       bns[0].eps, bns[0].momentum, relu=True, dropout_p=p, salt=salt)
+        with torch.no_grad():
+            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+        return y
+
     def _head_layers(self, stage):
         heads = self.mlp_heads[stage] if self.mlp_sep else self.mlp_heads
         return [heads[n].layers for n in self._HEAD_NAMES]
@@ -609,10 +627,10 @@ class TransformerDecoder(nn.Module):
         Bsz, _, N = feats.shape
         w1 = cat_params([l[0].weight for l in L]).squeeze(-1)                            # [G*C, C]
         x = torch.mm(w1, feats.reshape(C, N)).unsqueeze(0) if Bsz == 1 else torch.matmul(w1, feats)  # [B, G*C, N]
-        x = F.dropout(F.relu(self._bn_group(x, [l[1] for l in L], self.training)), L[0][3].p, self.training)
+        x = self._bn_relu_drop(x, [l[1] for l in L], L[0][3].p, (id(heads), 1))
         w2 = stack_params([l[4].weight for l in L]).squeeze(-1)                          # [G, C, C]
         x = torch.matmul(w2.unsqueeze(0), x.view(Bsz, G, C, N)).view(Bsz, G * C, N)
-        x = F.dropout(F.relu(self._bn_group(x, [l[5] for l in L], self.training)), L[0][7].p, self.training)
+        x = self._bn_relu_drop(x, [l[5] for l in L], L[0][7].p, (id(heads), 2))
         outs = [l[8].weight.shape[0] for l in L]
         rows = max(outs)
         w3 = slot_stack_params([l[8].weight for l in L], rows)                            # [G, rows, C, 1] or None
