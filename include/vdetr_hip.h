@@ -292,6 +292,10 @@ typedef struct vdetr_bnact_desc {
   float *running_mean, *running_var; /* [C], updated in place in training mode (may be NULL there) */
   float* y;                  /* [B, C, N] */
   float *save_mean, *save_invstd;    /* [C], written in training mode, read by backward */
+  const float* pre_bias;     /* [C] or NULL: bias of the convolution in front, left OUT of x (it cancels under batch
+                                statistics; the running mean is kept as that of conv(x) + bias) */
+  int64_t* counters[8];      /* num_batches_tracked of the modules that make up the channel group: += 1 (training) */
+  int32_t ncounters;
 } vdetr_bnact_desc;
 
 typedef struct vdetr_bnact_grads {

@@ -4,7 +4,13 @@ bench.py's cpu_baseline import this module.  ``keep`` injects the kernel's own d
 import torch.nn.functional as F
 
 
-def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, relu=True, dropout_p=0.0, salt=0, keep=None):
+def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, relu=True, dropout_p=0.0, salt=0,
+           pre_bias=None, counters=(), keep=None):
+    if pre_bias is not None:  # the reference adds the convolution bias before the BatchNorm
+        x = x + pre_bias.view(1, -1, 1)
+    for c in counters:
+        if training:
+            c.add_(1)
     y = F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
     if relu:
         y = F.relu(y)

@@ -54,3 +54,24 @@ def test_bn_act_eval_and_errors():
     torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-5)
     with pytest.raises(RuntimeError, match="CPU not supported"):
         bn_act(x.cpu(), w.cpu(), b.cpu(), rm.cpu(), rv.cpu(), True, 1e-5, 0.1)
+
+
+def test_bn_act_pre_bias_and_counters():
+    """A convolution bias in front of a batch-statistics BatchNorm is left out of x: same output, the running mean
+    accounts for it; num_batches_tracked counters are incremented by the launch."""
+    from oracle.bn_act_oracle import bn_act as ref_fn
+    from vdetr_amd.bn_act import bn_act
+    B, C, N = 1, 288, 1024
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, N, generator=g)
+    w, b, cb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(C, generator=g) * 3
+    rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    cnt = [torch.tensor(5, dtype=torch.int64, device=DEV), torch.tensor(0, dtype=torch.int64, device=DEV)]
+    rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    y = bn_act(x.to(DEV), w.to(DEV), b.to(DEV), rm, rv, True, 1e-5, 0.1, relu=True, pre_bias=cb.to(DEV), counters=cnt)
+    rm_r, rv_r = rm0.clone(), rv0.clone()
+    y_r = ref_fn(x, w, b, rm_r, rv_r, True, 1e-5, 0.1, relu=True, pre_bias=cb)
+    torch.testing.assert_close(y.cpu(), y_r, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm.cpu(), rm_r, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv.cpu(), rv_r, rtol=1e-4, atol=1e-5)
+    assert [int(c) for c in cnt] == [6, 1]

@@ -83,7 +83,8 @@ class BnActDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("B", "C", "N", "training", "relu")] + [
         ("eps", c_float), ("momentum", c_float), ("dropout_p", c_float), ("seed", ctypes.c_uint64),
         ("offset", ctypes.c_uint64), ("rng_state", c_void_p)] + [
-        (n, c_void_p) for n in ("x", "gamma", "beta", "running_mean", "running_var", "y", "save_mean", "save_invstd")]
+        (n, c_void_p) for n in ("x", "gamma", "beta", "running_mean", "running_var", "y", "save_mean", "save_invstd",
+                                "pre_bias")] + [("counters", c_void_p * 8), ("ncounters", ctypes.c_int32)]
 
 
 class BnActGrads(ctypes.Structure):

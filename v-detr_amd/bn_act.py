@@ -19,21 +19,26 @@ def new_salt():
     return next(_salts)
 
 
-def _desc(x, gamma, beta, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng):
+def _desc(x, gamma, beta, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng, pre_bias=None, counters=()):
     d = L.BnActDesc()
     d.B, d.C, d.N = x.shape
     d.training, d.relu, d.eps, d.momentum, d.dropout_p = int(training), int(relu), float(eps), float(momentum), float(p)
     d.seed = int(salt) & 0xFFFFFFFFFFFFFFFF
     d.rng_state = rng.data_ptr() if rng is not None else None
     for k, t in (("x", x), ("gamma", gamma), ("beta", beta), ("running_mean", rm), ("running_var", rv), ("y", y),
-                 ("save_mean", smean), ("save_invstd", sinv)):
+                 ("save_mean", smean), ("save_invstd", sinv), ("pre_bias", pre_bias)):
         setattr(d, k, t.data_ptr() if t is not None else None)
+    assert len(counters) <= 8
+    for i, t in enumerate(counters):
+        assert t.dtype == torch.int64 and t.is_cuda
+        d.counters[i] = t.data_ptr()
+    d.ncounters = len(counters)
     return d
 
 
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, training, relu, eps, momentum, p, rng, salt):
+    def forward(ctx, x, gamma, beta, rm, rv, training, relu, eps, momentum, p, rng, salt, pre_bias, counters):
         L.require_gpu(x, "x")
         L.require_float(x, "x")
         x = x.contiguous()
@@ -43,7 +48,8 @@ class _BnAct(torch.autograd.Function):
         smean = torch.empty(C, dtype=torch.float32, device=x.device) if training else None
         sinv = torch.empty_like(smean) if training else None
         p = p if training else 0.0
-        d = _desc(x, gamma_c, beta_c, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng if p > 0 else None)
+        d = _desc(x, gamma_c, beta_c, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng if p > 0 else None,
+                  pre_bias.detach().contiguous() if pre_bias is not None else None, counters)
         L.check(L.lib().vdetr_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "bn_act_fwd")
         ctx.cfg = (training, relu, eps, momentum, p, salt)
         ctx.save_for_backward(x, gamma_c, beta_c, smean, sinv, rng if p > 0 else None)
@@ -64,15 +70,18 @@ class _BnAct(torch.autograd.Function):
         g.dy, g.dx = dy.data_ptr(), dx.data_ptr() if dx is not None else None
         g.d_gamma, g.d_beta = (dg.data_ptr() if dg is not None else None), (db.data_ptr() if db is not None else None)
         L.check(L.lib().vdetr_bn_act_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "bn_act_bwd")
-        return dx, dg, db, None, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None, None, None, None
 
 
-def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, relu=True, dropout_p=0.0, salt=0):
-    """dropout(relu(batch_norm(x))) for x [B, C, N]; running statistics are updated in place when training."""
+def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, relu=True, dropout_p=0.0, salt=0,
+           pre_bias=None, counters=()):
+    """dropout(relu(batch_norm(x))) for x [B, C, N]; running statistics are updated in place when training.
+    ``pre_bias``: bias of the 1x1 convolution that produced x, NOT yet added (exactly cancelled by batch statistics; its
+    gradient is zero, the running mean accounts for it).  ``counters``: num_batches_tracked buffers to increment."""
     rng = None
     if training and dropout_p > 0.0:
         rng = A.current_rng(x.device)
         if rng is None:
             rng = A.begin_step(x.device)
     return _BnAct.apply(x, weight, bias, running_mean, running_var, bool(training), bool(relu), float(eps), float(momentum),
-                        float(dropout_p), rng, int(salt))
+                        float(dropout_p), rng, int(salt), pre_bias, tuple(counters))

@@ -44,7 +44,15 @@ __device__ __forceinline__ bool bn_keep(const BnRng& g, unsigned chankey, int e)
 
 constexpr int kBnThreads = 256;  // 4 channels per workgroup
 
+// bookkeeping nn.BatchNorm1d does next to the normalisation: num_batches_tracked += 1 (one counter per module of a
+// channel group), and the running mean of conv(x) + bias when the convolution's bias was left out of x (a bias in front
+// of a batch-statistics BatchNorm cancels exactly: only the running mean sees it)
+__device__ __forceinline__ void bn_bookkeeping(const vdetr_bnact_desc& d) {
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)d.ncounters && d.training) d.counters[threadIdx.x][0] += 1;
+}
+
 __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_kernel(vdetr_bnact_desc d) {
+  bn_bookkeeping(d);
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.C) return;
@@ -67,12 +75,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_kernel(vdetr_bnact_desc
       d.save_invstd[c] = invstd;
       if (d.running_mean) {
         const float m = d.momentum;
-        d.running_mean[c] = (1.f - m) * d.running_mean[c] + m * mean;
+        d.running_mean[c] = (1.f - m) * d.running_mean[c] + m * (mean + (d.pre_bias ? d.pre_bias[c] : 0.f));
         d.running_var[c] = (1.f - m) * d.running_var[c] + m * var * ((float)n / (float)(n > 1 ? n - 1 : 1));
       }
     }
   } else {
-    mean = d.running_mean[c];
+    mean = d.running_mean[c] - (d.pre_bias ? d.pre_bias[c] : 0.f);
     invstd = rsqrtf(d.running_var[c] + d.eps);
   }
   const float ga = d.gamma ? d.gamma[c] : 1.f, be = d.beta ? d.beta[c] : 0.f;
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_kernel(vdetr_bnact_desc
 // above took 17 / 20 us on the heads' [1, 1280, 1024] tensors: three resp. two dependent passes of scalar loads.)
 template <int NCH>
 __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_reg_kernel(vdetr_bnact_desc d) {
+  bn_bookkeeping(d);
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.C) return;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_reg_kernel(vdetr_bnact_
     d.save_invstd[c] = invstd;
     if (d.running_mean) {
       const float m = d.momentum;
-      d.running_mean[c] = (1.f - m) * d.running_mean[c] + m * mean;
+      d.running_mean[c] = (1.f - m) * d.running_mean[c] + m * (mean + (d.pre_bias ? d.pre_bias[c] : 0.f));
       d.running_var[c] = (1.f - m) * d.running_var[c] + m * var * ((float)N / (float)(N - 1));
     }
   }
@@ -242,6 +251,7 @@ static int bnact_check(const vdetr_bnact_desc* d, const char* op) {
   VDETR_REQUIRE((d->gamma == nullptr) == (d->beta == nullptr), "%s: gamma and beta go together", op);
   VDETR_REQUIRE((d->running_mean == nullptr) == (d->running_var == nullptr), "%s: running_mean and running_var go together", op);
   VDETR_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "%s: dropout_p %f outside [0,1)", op, d->dropout_p);
+  VDETR_REQUIRE(d->ncounters >= 0 && d->ncounters <= 8, "%s: ncounters %d outside [0,8]", op, d->ncounters);
   return VDETR_OK;
 }
 

@@ -64,6 +64,12 @@ class PointwiseConv1d(nn.Conv1d):
     def __init__(self, in_channels, out_channels, bias=True):
         super().__init__(in_channels, out_channels, 1, bias=bias)
 
+    def forward_no_bias(self, x):
+        w = self.weight.squeeze(-1)
+        if x.shape[0] == 1:
+            return torch.mm(w, x.reshape(x.shape[1], x.shape[2])).unsqueeze(0)
+        return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
+
     def forward(self, x):
         w = self.weight.squeeze(-1)
         if x.shape[0] == 1:
@@ -185,10 +191,11 @@ class PositionEmbeddingLearned(nn.Module):
         if not (self.training and x.is_cuda and bn.momentum is not None and bn.track_running_stats):
             return head(x.contiguous())
         from . import bn_act as BNA  # BatchNorm1d + ReLU as one launch (and one backward)
-        y = BNA.bn_act(head[0](x), bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, bn.momentum,
-                       relu=True, dropout_p=0.0)
-        with torch.no_grad():
-            bn.num_batches_tracked.add_(1)
+        conv = head[0]
+        # the convolution's bias cancels under batch statistics (zero gradient): it only enters the running mean
+        h = conv(x) if conv.bias is None else PointwiseConv1d.forward_no_bias(conv, x)
+        y = BNA.bn_act(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, bn.momentum, relu=True,
+                       dropout_p=0.0, pre_bias=conv.bias, counters=[bn.num_batches_tracked])
         return head[3](y)
 
 

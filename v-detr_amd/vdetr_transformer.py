@@ -578,11 +578,9 @@ class TransformerDecoder(nn.Module):
         if not hasattr(self, "_bn_salts"):
             self._bn_salts = {}
         salt = self._bn_salts.setdefault(key, BNA.new_salt())
-        y = BNA.bn_act(x, cat_params([b.weight for b in bns]), cat_params([b.bias for b in bns]), rm, rv, True,
-                       bns[0].eps, bns[0].momentum, relu=True, dropout_p=p, salt=salt)
-        with torch.no_grad():
-            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
-        return y
+        return BNA.bn_act(x, cat_params([b.weight for b in bns]), cat_params([b.bias for b in bns]), rm, rv, True,
+                          bns[0].eps, bns[0].momentum, relu=True, dropout_p=p, salt=salt,
+                          counters=[b.num_batches_tracked for b in bns])
 
     def _head_layers(self, stage):
         heads = self.mlp_heads[stage] if self.mlp_sep else self.mlp_heads
