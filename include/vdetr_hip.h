@@ -217,6 +217,9 @@ typedef struct vdetr_box_decode_desc {
   int32_t in_batch_stride;
   /* transposed copies [B,N,ch] of the logits the reference hands out as transposed views (:286,:300-301), or NULL */
   float *cls_logits_t, *angle_logits_t, *angle_res_norm_t;
+  /* what the NEXT decoder layer consumes (no gradient; :408-415): the corners in the lidar frame
+     (convert_corners_camera2lidar, :98-102) [B,N,8,3] and cat(center_unnorm, size_unnorm) [B,N,6]; each may be NULL */
+  float *corners_lidar, *center_size;
 } vdetr_box_decode_desc;
 
 /* Gradients w.r.t. the forward's outputs (each may be NULL = unused) and w.r.t. the head outputs (required). */
@@ -304,6 +307,11 @@ typedef struct vdetr_bnact_grads {
   float *d_gamma, *d_beta;    /* [C] or NULL */
 } vdetr_bnact_grads;
 
+/* y = dropout(relu(x)), element-wise over n floats (n % 4 == 0, 16-B aligned): the FFN's
+ * `self.dropout(self.activation(self.linear1(.)))` (models/vdetr_transformer.py:566,604).  The backward needs y only. */
+int vdetr_relu_dropout_fwd_f32(const float* x, float* y, long n, float dropout_p, uint64_t seed, uint64_t offset,
+                               const uint64_t* rng_state, vdetr_stream_t stream);
+int vdetr_relu_dropout_bwd_f32(const float* y, const float* dy, float* dx, long n, float dropout_p, vdetr_stream_t stream);
 int vdetr_bn_act_fwd_f32(const vdetr_bnact_desc* d, vdetr_stream_t stream);
 int vdetr_bn_act_bwd_f32(const vdetr_bnact_desc* d, const vdetr_bnact_grads* g, vdetr_stream_t stream);
 

@@ -17,3 +17,10 @@ def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, 
     if training and dropout_p > 0.0:
         y = y * keep / (1.0 - dropout_p) if keep is not None else F.dropout(y, dropout_p, True)
     return y
+
+
+def relu_dropout(x, drop, salt=0, keep=None):
+    y = F.relu(x)
+    if keep is not None:
+        return y * keep / (1.0 - drop.p)
+    return drop(y) if drop is not None else y

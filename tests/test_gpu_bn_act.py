@@ -75,3 +75,29 @@ def test_bn_act_pre_bias_and_counters():
     torch.testing.assert_close(rm.cpu(), rm_r, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rv.cpu(), rv_r, rtol=1e-4, atol=1e-5)
     assert [int(c) for c in cnt] == [6, 1]
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_relu_dropout_matches_oracle(p):
+    from oracle.bn_act_oracle import relu_dropout as ref_fn
+    from vdetr_amd import attention as A
+    from vdetr_amd.bn_act import relu_dropout
+    A.reset_rng()
+    A.begin_step(torch.device(DEV))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1024, 1, 256, generator=g)
+    wout = torch.randn(1024, 1, 256, generator=g)
+    drop = torch.nn.Dropout(p).train()
+    keep = None
+    if p > 0:
+        y0 = relu_dropout(torch.ones(1024, 1, 256, device=DEV), drop, salt=9)
+        keep = (y0 > 0).float().cpu()
+        assert abs(float(keep.mean()) - (1 - p)) < 0.02
+    res = []
+    for fn, dev, kw in ((relu_dropout, DEV, {}), (ref_fn, "cpu", {"keep": keep})):
+        xx = x.to(dev).requires_grad_(True)
+        y = fn(xx, drop, salt=9, **kw)
+        (y * wout.to(dev)).sum().backward()
+        res.append((y.detach().cpu(), xx.grad.cpu()))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)

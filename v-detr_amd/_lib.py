@@ -46,7 +46,7 @@ class BoxDecodeDesc(ctypes.Structure):
 
     _fields_ = ([(n, ctypes.c_int32) for n in ("B", "N", "A", "C1", "num_angle_bin", "cls_kind")] +
                 [(n, c_void_p) for n in _BOX_IN + _BOX_OUT] + [("in_batch_stride", ctypes.c_int32)] +
-                [(n, c_void_p) for n in ("cls_logits_t", "angle_logits_t", "angle_res_norm_t")])
+                [(n, c_void_p) for n in ("cls_logits_t", "angle_logits_t", "angle_res_norm_t", "corners_lidar", "center_size")])
 
 
 _BOX_GRAD_IN = ("center_reg", "size_reg", "center_unnorm", "center_norm", "size_unnorm", "size_norm", "angle_residual",
@@ -119,6 +119,9 @@ _SIGNATURES = {
     "vdetr_add_ln_fwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), c_void_p]),
     "vdetr_add_ln_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AddLnDesc)]),
     "vdetr_add_ln_bwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), ctypes.POINTER(AddLnGrads), c_void_p]),
+    "vdetr_relu_dropout_fwd_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_float, ctypes.c_uint64, ctypes.c_uint64, c_void_p,
+                                           c_void_p]),
+    "vdetr_relu_dropout_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p]),
     "vdetr_bn_act_fwd_f32": (c_int, [ctypes.POINTER(BnActDesc), c_void_p]),
     "vdetr_bn_act_bwd_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_void_p]),
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),

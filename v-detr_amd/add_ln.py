@@ -107,9 +107,13 @@ def layer_norm(x, ln, ln2=None):
     return out if ln2 is None else (out, out2)
 
 
-def add_dropout_layer_norm(x, r, drop, ln, ln2=None, salt=0):
-    """y = x + drop(r); returns (y, ln(y)) or (y, ln(y), ln2(y)).  ``drop`` is the nn.Dropout module of the block."""
+def add_dropout_layer_norm(x, r, drop, ln, ln2=None, salt=0, also_drop=None):
+    """y = x + drop(r); returns (y, ln(y)) or (y, ln(y), ln2(y)).  ``drop`` is the nn.Dropout module of the block.
+    ``also_drop``: a second nn.Dropout the branch output r still has to pass (e.g. the attention module's proj_drop):
+    two independent Bernoulli masks are one mask with keep probability (1-p1)(1-p2) and the product of the scales."""
     p = drop.p if (drop is not None and drop.training) else 0.0
+    if also_drop is not None and also_drop.training and also_drop.p > 0.0:
+        p = 1.0 - (1.0 - p) * (1.0 - also_drop.p)
     rng = None
     if p > 0.0:
         rng = A.current_rng(x.device)

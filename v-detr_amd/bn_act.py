@@ -85,3 +85,38 @@ def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, 
             rng = A.begin_step(x.device)
     return _BnAct.apply(x, weight, bias, running_mean, running_var, bool(training), bool(relu), float(eps), float(momentum),
                         float(dropout_p), rng, int(salt), pre_bias, tuple(counters))
+
+
+class _ReluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, rng, salt):
+        L.require_gpu(x, "x")
+        L.require_float(x, "x")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.lib().vdetr_relu_dropout_fwd_f32(L.ptr(x), L.ptr(y), x.numel(), float(p), int(salt) & 0xFFFFFFFFFFFFFFFF, 0,
+                                                   L.ptr(rng) if (rng is not None and p > 0) else None, L.stream_ptr()),
+                "relu_dropout_fwd")
+        ctx.p = p
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        L.check(L.lib().vdetr_relu_dropout_bwd_f32(L.ptr(y), L.ptr(dy), L.ptr(dx), y.numel(), float(ctx.p), L.stream_ptr()),
+                "relu_dropout_bwd")
+        return dx, None, None, None
+
+
+def relu_dropout(x, drop, salt=0):
+    """``drop(relu(x))`` (drop: the nn.Dropout module) as one launch; needs numel % 4 == 0."""
+    p = drop.p if (drop is not None and drop.training) else 0.0
+    rng = None
+    if p > 0.0:
+        rng = A.current_rng(x.device)
+        if rng is None:
+            rng = A.begin_step(x.device)
+    return _ReluDropout.apply(x, p, rng, salt)

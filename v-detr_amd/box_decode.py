@@ -18,7 +18,7 @@ _OUT3 = ("center_reg", "size_reg", "center_unnorm", "center_norm", "size_unnorm"
 def _desc(B, N, A, C1, num_angle_bin, cls_kind, tensors):
     d = L.BoxDecodeDesc()
     d.B, d.N, d.A, d.C1, d.num_angle_bin, d.cls_kind = B, N, A, C1, num_angle_bin, cls_kind
-    for k in L._BOX_IN + L._BOX_OUT + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t"):
+    for k in L._BOX_IN + L._BOX_OUT + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t", "corners_lidar", "center_size"):
         t = tensors.get(k)
         setattr(d, k, (t if isinstance(t, int) else t.data_ptr()) if t is not None else None)
     d.in_batch_stride = int(tensors.get("in_batch_stride", 0))
@@ -99,7 +99,7 @@ class _BoxDecodeJoint(torch.autograd.Function):
     """The five head outputs as slabs of ONE tensor y [B, 5, rows, N] (the batched output GEMM of the heads).  The logits
     the reference returns as transposed views are real (transposed) outputs here, so the whole backward is one launch
     that writes the complete gradient of y (slab padding included)."""
-    OUTS = _BoxDecode.OUTS + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t")
+    OUTS = _BoxDecode.OUTS + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t", "corners_lidar", "center_size")
 
     @staticmethod
     def forward(ctx, y, chans, pre_center_norm, pre_size_norm, dims_min, dims_max, num_angle_bin, cls_kind):
@@ -124,6 +124,7 @@ class _BoxDecodeJoint(torch.autograd.Function):
         outs["corners_aa"] = new((B, N, 8, 3)) if A > 1 else None
         outs["cls_prob"] = new((B, N, C1 - 1)) if cls_kind == L.VDETR_CLS_SOFTMAX else None
         outs["cls_logits_t"], outs["angle_logits_t"], outs["angle_res_norm_t"] = new((B, N, C1)), new((B, N, A)), new((B, N, A))
+        outs["corners_lidar"], outs["center_size"] = new((B, N, 8, 3)), new((B, N, 6))
         d = _desc(B, N, A, C1, num_angle_bin, cls_kind,
                   {**ins, "pre_center_norm": pre_center_norm, "pre_size_norm": pre_size_norm, "dims_min": dims_min,
                    "dims_max": dims_max, **outs, "in_batch_stride": G * rows * N})
@@ -132,7 +133,7 @@ class _BoxDecodeJoint(torch.autograd.Function):
         ctx.save_for_backward(y, dims_min, dims_max, outs["size_unnorm"], outs["pre_size_unnorm"], outs["angle_cont"],
                               outs["angle_class"])
         ctx.set_materialize_grads(False)
-        nondiff = [outs[k] for k in ("pre_center_unnorm", "pre_size_unnorm", "objectness")]
+        nondiff = [outs[k] for k in ("pre_center_unnorm", "pre_size_unnorm", "objectness", "corners_lidar", "center_size")]
         if outs["cls_prob"] is not None:
             nondiff.append(outs["cls_prob"])
         ctx.mark_non_differentiable(*nondiff)
@@ -175,7 +176,10 @@ def decode_boxes_joint(y, chans, pre_center_normalized, pre_size_normalized, poi
     o = dict(zip(_BoxDecodeJoint.OUTS, _BoxDecodeJoint.apply(
         y, tuple(int(c) for c in chans), pre_center_normalized, pre_size_normalized, point_cloud_dims[0],
         point_cloud_dims[1], int(num_angle_bin), cls_kind)))
-    return _result(o, o["cls_logits_t"], o["angle_logits_t"], o["angle_res_norm_t"])
+    res = _result(o, o["cls_logits_t"], o["angle_logits_t"], o["angle_res_norm_t"])
+    # extras for the decoder loop (not part of the reference dictionary): the next layer's RPE vertices and query-pos input
+    res["_reference_point_lidar"], res["_query_reference"] = o["corners_lidar"], o["center_size"]
+    return res
 
 
 def _result(o, cls_logits, angle_logits, angle_residual_normalized):

@@ -240,6 +240,37 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reg_kernel(vdetr_bnact_
   }
 }
 
+// ---- y = dropout(relu(x)) element-wise (the FFN's `self.dropout(self.activation(self.linear1(.)))`,
+// models/vdetr_transformer.py:566,604): one launch instead of clamp + dropout; the backward needs only y
+// (y > 0 <=> the element passed the relu AND was kept): dx = y > 0 ? dy * scale : 0.
+__global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n4,
+                                                              vdetr_bnact_desc d) {
+  const BnRng rg = bn_rng(d);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    unsigned r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+    if (rg.thresh) {
+      r0 = fmix32(((unsigned)i * 0x9E3779B1u + rg.off_lo) ^ rg.seed_lo ^ ((unsigned)(i >> 32) * 0x27D4EB2Fu));
+      r0 = fmix32(r0 ^ rg.seed_hi ^ rg.off_hi);
+      r1 = fmix32(r0 + 0x9E3779B9u);
+    }
+    const unsigned k[4] = {r0 & 0xFFFFu, r0 >> 16, r1 & 0xFFFFu, r1 >> 16};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f && k[e] >= rg.thresh) ? v[e] * rg.scale : 0.f;
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, long n4, float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] * scale : 0.f;
+    reinterpret_cast<f32x4*>(dx)[i] = g;
+  }
+}
+
 }  // namespace vdetr
 
 using namespace vdetr;
@@ -293,4 +324,30 @@ extern "C" int vdetr_bn_act_bwd_f32(const vdetr_bnact_desc* d, const vdetr_bnact
     default: hipLaunchKernelGGL(bn_act_bwd_kernel, grid, block, 0, st, *d, *g); break;
   }
   return check_launch("bn_act_bwd");
+}
+
+extern "C" int vdetr_relu_dropout_fwd_f32(const float* x, float* y, long n, float dropout_p, uint64_t seed, uint64_t offset,
+                                          const uint64_t* rng_state, vdetr_stream_t stream) {
+  VDETR_REQUIRE(x && y && n > 0 && n % 4 == 0, "relu_dropout_fwd: needs non-null tensors with a multiple of 4 elements");
+  VDETR_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "relu_dropout_fwd: dropout_p %f outside [0,1)", dropout_p);
+  VDETR_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "relu_dropout_fwd: tensors must be 16-B aligned");
+  vdetr_bnact_desc d = {};
+  d.dropout_p = dropout_p; d.seed = seed; d.offset = offset; d.rng_state = rng_state;
+  const long n4 = n / 4;
+  const int grid = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+  hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, n4, d);
+  return check_launch("relu_dropout_fwd");
+}
+
+extern "C" int vdetr_relu_dropout_bwd_f32(const float* y, const float* dy, float* dx, long n, float dropout_p,
+                                          vdetr_stream_t stream) {
+  VDETR_REQUIRE(y && dy && dx && n > 0 && n % 4 == 0, "relu_dropout_bwd: needs non-null tensors with a multiple of 4 elements");
+  VDETR_REQUIRE((((uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "relu_dropout_bwd: tensors must be 16-B aligned");
+  vdetr_bnact_desc d = {};
+  d.dropout_p = dropout_p;
+  const BnRng rg = [&] { BnRng r; r.thresh = 0; r.scale = 1.f; if (dropout_p > 0.f) { int t = (int)((double)dropout_p * 65536.0 + 0.5); t = t < 1 ? 1 : (t > 65535 ? 65535 : t); r.scale = 65536.f / (float)(65536 - t); } return r; }();
+  const long n4 = n / 4;
+  const int grid = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n4, rg.scale);
+  return check_launch("relu_dropout_bwd");
 }

@@ -99,6 +99,18 @@ __global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_de
   box_corners(su[0], su[1], su[2], cosf(angle), sinf(angle), cu[0], -cu[2], cu[1], cor);
 #pragma unroll
   for (int i = 0; i < 24; ++i) d.corners[(size_t)t * 24 + i] = cor[i];
+  if (d.corners_lidar) {  // convert_corners_camera2lidar (:98-102): (x, y, z) -> (x, z, -y); what the next layer's RPE reads
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      d.corners_lidar[(size_t)t * 24 + i * 3] = cor[i * 3];
+      d.corners_lidar[(size_t)t * 24 + i * 3 + 1] = cor[i * 3 + 2];
+      d.corners_lidar[(size_t)t * 24 + i * 3 + 2] = -cor[i * 3 + 1];
+    }
+  }
+  if (d.center_size) {  // torch.cat([center_unnormalized, size_unnormalized], -1) (:415): input of the query-pos MLP
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { d.center_size[(size_t)t * 6 + a] = cu[a]; d.center_size[(size_t)t * 6 + 3 + a] = su[a]; }
+  }
   if (d.corners_aa) {  // zero-angle corners (:311-316); with one angle bin the caller reuses `corners`
     box_corners(su[0], su[1], su[2], 1.f, 0.f, cu[0], -cu[2], cu[1], cor);
 #pragma unroll

@@ -151,6 +151,7 @@ class GlobalShareCrossAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.rpe_cfg = A.RPEConfig(num_points, self.log_scale, max_value)
         self.return_attn = False
+        self.defer_proj_drop = False
         self._salt = next(_salt_counter)
 
     def __deepcopy__(self, memo):
@@ -225,8 +226,10 @@ class GlobalShareCrossAttention(nn.Module):
                                              table=tables, rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz,
                                              cos_sin=cos_sin, attn_mask=attn_mask, dropout_p=p, rng_state=rng,
                                              salt=self._salt)
-        x = self.proj_drop(linear(x, self.proj.weight, self.proj.bias)).permute(1, 0, 2)
-        return x, attn
+        x = linear(x, self.proj.weight, self.proj.bias)
+        if not self.defer_proj_drop:  # (the caller applies it together with its own residual dropout: one mask)
+            x = self.proj_drop(x)
+        return x.permute(1, 0, 2), attn
 
 
 class ShareSelfAttention(nn.Module):
@@ -315,6 +318,15 @@ class MultiheadSelfAttention(nn.Module):
 # =====================================================================================================
 # decoder layers
 # =====================================================================================================
+def _act_drop(mod, h):
+    """``mod.dropout(mod.activation(h))`` of an FFN block (:566, :604): one launch for relu + dropout on the GPU."""
+    if type(mod.activation) is nn.ReLU and h.is_cuda and h.dtype == torch.float32 and h.numel() % 4 == 0:
+        if getattr(mod, "_act_salt", None) is None:
+            mod._act_salt = BNA.new_salt()
+        return BNA.relu_dropout(h, mod.dropout, salt=mod._act_salt)
+    return mod.dropout(mod.activation(h))
+
+
 class GlobalDecoderLayer(nn.Module):
     """self-attn -> 3DV-RPE cross-attn -> FFN with residuals (reference :455-582; pre-norm by default)."""
 
@@ -380,10 +392,17 @@ class GlobalDecoderLayer(nn.Module):
         q = k = self.with_pos_embed(tgt2, query_pos)
         branch = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
         tgt, tgt2 = ALN.add_dropout_layer_norm(tgt, branch, self.dropout1, self.norm2, salt=self._aln_salts[0])
+        fold = isinstance(self.multihead_attn, GlobalShareCrossAttention)
+        if fold:  # proj_drop and dropout2 are two masks on the same tensor: applied as one inside the fused launch
+            self.multihead_attn.defer_proj_drop = True
         branch, attn = self._cross(tgt2, memory, reference_point, reference_angle, enc_xyz, memory_mask,
                                    memory_key_padding_mask, pos, query_pos)
-        tgt, tgt2 = ALN.add_dropout_layer_norm(tgt, branch, self.dropout2, self.norm3, salt=self._aln_salts[1])
-        branch = linear(self.dropout(self.activation(linear(tgt2, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias)
+        if fold:
+            self.multihead_attn.defer_proj_drop = False
+        tgt, tgt2 = ALN.add_dropout_layer_norm(tgt, branch, self.dropout2, self.norm3, salt=self._aln_salts[1],
+                                               also_drop=self.multihead_attn.proj_drop if fold else None)
+        branch = linear(_act_drop(self, linear(tgt2, self.linear1.weight, self.linear1.bias)), self.linear2.weight,
+                        self.linear2.bias)
         if self.post_norms:  # the decoder's output norm (+ the next layer's norm1) ride in the same launch
             res = ALN.add_dropout_layer_norm(tgt, branch, self.dropout3, *self.post_norms, salt=self._aln_salts[2])
             tgt, self.post_normed = res[0], res[1:]
@@ -434,7 +453,8 @@ class FFNLayer(nn.Module):
             memory = self.norm(memory)
             return memory + self.dropout(linear(self.dropout(self.activation(linear(memory, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias))
         memory = ALN.layer_norm(memory, self.norm)
-        branch = linear(self.dropout(self.activation(linear(memory, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias)
+        branch = linear(_act_drop(self, linear(memory, self.linear1.weight, self.linear1.bias)), self.linear2.weight,
+                        self.linear2.bias)
         if self.post_norm is not None:
             if self._aln_salt is None:
                 self._aln_salt = ALN.new_salt()
@@ -741,11 +761,15 @@ class TransformerDecoder(nn.Module):
                 nxt = self.layers[idx + 1].norm1 if idx + 1 < len(self.layers) else None
                 layer.post_norms = (self.norm,) + ((nxt,) if nxt is not None else ())
             if idx > 0:
-                reference_point = convert_corners_camera2lidar(box_prediction["box_corners"].detach())
+                reference_point = box_prediction.pop("_reference_point_lidar", None)  # written by the fused box decode
+                if reference_point is None:
+                    reference_point = convert_corners_camera2lidar(box_prediction["box_corners"].detach())
                 reference_center = box_prediction["center_unnormalized"].detach()
                 reference_size = box_prediction["size_unnormalized"].detach()
                 reference_angle = box_prediction["angle_continuous"].detach()
-            query_reference = torch.cat([reference_center, reference_size], dim=-1)
+            query_reference = box_prediction.pop("_query_reference", None) if idx > 0 else None
+            if query_reference is None:
+                query_reference = torch.cat([reference_center, reference_size], dim=-1)
             query_pos = self.query_pos_projection[idx](query_reference).permute(2, 0, 1)
             if self.pos_for_key:
                 pos = self.key_pos_projection[idx](enc_xyz).permute(2, 0, 1)
@@ -773,6 +797,10 @@ class TransformerDecoder(nn.Module):
                     attn = torch.gather(attn, 3, inv)
                 attns.append(attn)
 
+        for extra in ("_reference_point_lidar", "_query_reference"):  # helpers of the loop, not part of the result
+            box_prediction.pop(extra, None)
+            if intermediate:
+                intermediate[0].pop(extra, None)
         if return_attn_weights:
             attns = torch.stack(attns)
         if self.return_intermediate:
