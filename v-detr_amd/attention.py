@@ -195,9 +195,15 @@ class _FusedAttention(Function):
             p_r = scores.view(B * H, nQ, nK)
             ds_r = dprob
             q_r, k_r = heads(q, nQ), heads(k, nK)
-            dv = torch.bmm(p_r.transpose(1, 2), do_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
-            dk = torch.bmm(ds_r.transpose(1, 2), q_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
-            dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
+            if B == 1:  # the GEMMs write straight into the [L, H*64] layout (row stride H*64): no permute copies
+                dv, dk, dq = q.new_empty((1, nK, C)), q.new_empty((1, nK, C)), q.new_empty((1, nQ, C))
+                torch.bmm(p_r.transpose(1, 2), do_r, out=dv.view(nK, H, HEAD_DIM).permute(1, 0, 2))
+                torch.bmm(ds_r.transpose(1, 2), q_r, out=dk.view(nK, H, HEAD_DIM).permute(1, 0, 2))
+                torch.bmm(ds_r, k_r, out=dq.view(nQ, H, HEAD_DIM).permute(1, 0, 2))
+            else:
+                dv = torch.bmm(p_r.transpose(1, 2), do_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
+                dk = torch.bmm(ds_r.transpose(1, 2), q_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
+                dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         return (dq, dk, dv, dtable) + (None,) * 12
 
 

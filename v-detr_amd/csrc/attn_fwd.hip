@@ -33,8 +33,8 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int b = blockIdx.z;
-  const int head = PERHEAD ? blockIdx.y : 0;
-  const int split = PERHEAD ? 0 : blockIdx.y;  // key split uses grid.y only for the shared kinds
+  const int head = PERHEAD ? (int)blockIdx.y % P.H : 0;
+  const int split = PERHEAD ? (int)blockIdx.y / P.H : (int)blockIdx.y;  // key split: grid.y = split (shared) or head + H*split
   const int H = P.H, nQ = P.nQ, nK = P.nK;
   const int rows_per_tile_q = PERHEAD ? 16 : 4;  // queries per workgroup
   const int q0 = blockIdx.x * rows_per_tile_q;
@@ -261,7 +261,14 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(AttnParams P) {
   }
   // row = (b*nQ + q)*H + h  ->  out[(b*nQ+q)*H*64 + h*64 + d] is the same flat offset
   P.out[row * kDh + d] = L > 0.f ? val / L : 0.f;
-  if (d == 0) P.lse[row] = L > 0.f ? M + __logf(L) : kNegBig;
+  if (d == 0) {
+    size_t li = row;  // shared kinds: lse rows are (b, q, h); per-head kind: (b, h, q)
+    if (P.kind == VDETR_ATTN_PER_HEAD) {
+      const size_t bq = row / P.H, h = row - bq * P.H, b = bq / P.nQ, q = bq - b * P.nQ;
+      li = (b * P.H + h) * P.nQ + q;
+    }
+    P.lse[li] = L > 0.f ? M + __logf(L) : kNegBig;
+  }
 }
 
 // ---- stand-alone RPE bias (parity hook for vdetr_transformer.py:710-731) ------------------------------
@@ -350,7 +357,13 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
 
 // key split so that small query counts still fill the chip (shared kinds only)
 static int choose_ksplit(const vdetr_attn_desc* d) {
-  if (d->kind != VDETR_ATTN_SHARED_KV) return 1;
+  if (d->kind != VDETR_ATTN_SHARED_KV) {
+    // per-head kind: the query self-attention launches H * nQ/16 = 256 workgroups at the model's size, i.e. exactly one
+    // per CU — two rounds whenever a CU is busy elsewhere (see below).  Two key halves per (head, query tile) instead.
+    const long wgs = (long)d->B * d->H * ((d->nQ + 15) / 16);
+    const int ntiles = (d->nK + 15) / 16;
+    return (wgs >= 128 && wgs <= 512 && ntiles >= 4 * kFwdWaves) ? 2 : 1;
+  }
   const long wgs = (long)d->B * ((d->nQ + 3) / 4);
   const int ntiles = (d->nK + 15) / 16;
   int ks = 1;
@@ -407,7 +420,7 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
                          : (size_t)kFwdWaves * kWave * 24 * 4;
   hipStream_t st = (hipStream_t)stream;
   if (perhead) {
-    dim3 grid((d->nQ + 15) / 16, d->H, d->B);
+    dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
     if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
     hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(kFwdThreads), lds, st, P);
   } else {
