@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="library heuristics instead of per-shape tuned GEMM solutions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                     "the N>1 code path with several ranks on one GPU)")
     a = ap.parse_args()
@@ -341,6 +342,9 @@ def main():
     rank, local, world = init_distributed(a.backend)
     assert world == a.gpus or (world == 1 and a.gpus == 1), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local)
+    if not a.no_gemm_tuning:
+        from vdetr_amd.runtime import enable_gemm_tuning
+        enable_gemm_tuning(rank)
 
     model = build_model(a.config, device)
     use_graph = not (a.no_graph or a.sync_bn)
