@@ -360,9 +360,11 @@ static int choose_ksplit(const vdetr_attn_desc* d) {
   if (d->kind != VDETR_ATTN_SHARED_KV) {
     // per-head kind: the query self-attention launches H * nQ/16 = 256 workgroups at the model's size, i.e. exactly one
     // per CU — two rounds whenever a CU is busy elsewhere (see below).  Two key halves per (head, query tile) instead.
-    const long wgs = (long)d->B * d->H * ((d->nQ + 15) / 16);
+    // (measured: no gain at nQ = nK = 1024 — the 25 us workgroups are prologue / merge dominated and the combine launch
+    // costs what the second round did; kept behind VDETR_FWD_KSPLIT_PERHEAD for larger self-attentions)
+    static const int ph = [] { const char* v = getenv("VDETR_FWD_KSPLIT_PERHEAD"); return v ? atoi(v) : 1; }();
     const int ntiles = (d->nK + 15) / 16;
-    return (wgs >= 128 && wgs <= 512 && ntiles >= 4 * kFwdWaves) ? 2 : 1;
+    return (ph > 1 && ntiles >= 2 * ph * kFwdWaves) ? ph : 1;
   }
   const long wgs = (long)d->B * ((d->nQ + 3) / 4);
   const int ntiles = (d->nK + 15) / 16;
