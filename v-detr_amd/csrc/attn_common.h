@@ -115,15 +115,6 @@ __device__ __forceinline__ AxisTap rpe_axis(float d, const AttnParams& P) {
   return a;
 }
 
-// the same tap as (base cell, sub-cell coordinate t): wa = sat(1-|t|), wb = sat(1-|t-1|)
-__device__ __forceinline__ int rpe_axis_base(float d, const AttnParams& P, float& t) {
-  const float L = __log2f(__builtin_fmaf(fabsf(d), P.log_scale, 1.0f));
-  const float pix = __builtin_fmaf(copysignf(L, d), P.pix_mul, P.pix_add);
-  const float bf = __builtin_amdgcn_fmed3f(floorf(pix), 0.f, (float)(P.T - 2));
-  t = pix - bf;
-  return (int)bf;
-}
-
 // x -> LAST table axis, y -> middle, z -> FIRST (grid_sample: x=W, y=H, z=D)
 __device__ __forceinline__ int rpe_cell(const AxisTap& ax, const AxisTap& ay, const AxisTap& az, int T) {
   return (az.base * T + ay.base) * T + ax.base;
