@@ -20,6 +20,7 @@ struct AttnParams {
   const float* k;
   const float* v;
   int k_stride, v_stride;  // floats between consecutive key rows
+  int box_path;            // forward: the axis-aligned-box instantiation is launched too (see attn_fwd.hip)
   const unsigned* bwd_aux; // {max |dO row|^2, max |V row|^2, query counter half 0, half 1} or NULL
   float* out;
   float* lse;
@@ -145,6 +146,65 @@ __device__ __forceinline__ void rpe_pair_bias(const AttnParams& P, const f32x4* 
     const f32x4 c100 = t[TT], c101 = t[TT + 1], c110 = t[TT + T], c111 = t[TT + T + 1];
     const float w000 = w00 * ax.wa, w001 = w00 * ax.wb, w010 = w01 * ax.wa, w011 = w01 * ax.wb;
     const float w100 = w10 * ax.wa, w101 = w10 * ax.wb, w110 = w11 * ax.wa, w111 = w11 * ax.wb;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      float s = acc[h];
+      s = __builtin_fmaf(w000, c000[h], s);
+      s = __builtin_fmaf(w001, c001[h], s);
+      s = __builtin_fmaf(w010, c010[h], s);
+      s = __builtin_fmaf(w011, c011[h], s);
+      s = __builtin_fmaf(w100, c100[h], s);
+      s = __builtin_fmaf(w101, c101[h], s);
+      s = __builtin_fmaf(w110, c110[h], s);
+      s = __builtin_fmaf(w111, c111[h], s);
+      acc[h] = s;
+    }
+  }
+}
+
+// ---- axis-aligned boxes: 6 axis taps per pair instead of 24 ---------------------------------------------------------
+// The eight RPE vertices are the corners of a box (box_util.py:338-346 sign pattern, converted to the lidar frame by
+// :98-102).  Without rotation (ScanNet: one angle bin) their coordinates take only two values per axis, so the per-axis
+// tap (log2, floor, hat weights: ~11 VALU instructions) is the same for four vertices at a time.  Vertex i uses
+//   x: value (i >> 1) & 1,   y: value 1 for i & 3 in {1, 2},   z: value i >> 2
+// (checked bit-wise against the actual vertices by rpe_box_pattern; anything else takes the general path).  Taps, weight
+// products and the accumulation order are those of rpe_pair_bias: the result is bit-identical.
+__device__ __forceinline__ constexpr int rpe_box_xi(int i) { return (i >> 1) & 1; }
+__device__ __forceinline__ constexpr int rpe_box_yi(int i) { return ((i & 3) == 1 || (i & 3) == 2) ? 1 : 0; }
+__device__ __forceinline__ constexpr int rpe_box_zi(int i) { return i >> 2; }
+__device__ __forceinline__ bool rpe_box_pattern(const float (&vx)[8], const float (&vy)[8], const float (&vz)[8]) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    ok = ok && vx[i] == vx[rpe_box_xi(i) ? 2 : 0] && vy[i] == vy[rpe_box_yi(i) ? 1 : 0] && vz[i] == vz[rpe_box_zi(i) ? 4 : 0];
+  return ok;
+}
+__device__ __forceinline__ void rpe_pair_bias_box(const AttnParams& P, const f32x4* tab, const float (&X)[2],
+                                                  const float (&Y)[2], const float (&Z)[2], float kx, float ky, float kz,
+                                                  float (&acc)[4]) {
+  const int T = P.T, TT = T * T, T3 = TT * T;
+  const AxisTap ax[2] = {rpe_axis(X[0] - kx, P), rpe_axis(X[1] - kx, P)};
+  const AxisTap ay[2] = {rpe_axis(Y[0] - ky, P), rpe_axis(Y[1] - ky, P)};
+  const AxisTap az[2] = {rpe_axis(Z[0] - kz, P), rpe_axis(Z[1] - kz, P)};
+  float w00[2][2], w01[2][2], w10[2][2], w11[2][2];
+  int zy[2][2];
+#pragma unroll
+  for (int zi = 0; zi < 2; ++zi)
+#pragma unroll
+    for (int yi = 0; yi < 2; ++yi) {
+      w00[zi][yi] = az[zi].wa * ay[yi].wa; w01[zi][yi] = az[zi].wa * ay[yi].wb;
+      w10[zi][yi] = az[zi].wb * ay[yi].wa; w11[zi][yi] = az[zi].wb * ay[yi].wb;
+      zy[zi][yi] = (az[zi].base * T + ay[yi].base) * T;
+    }
+#pragma unroll
+  for (int i = 0; i < kRpeVerts; ++i) {
+    const int xi = rpe_box_xi(i), yi = rpe_box_yi(i), zi = rpe_box_zi(i);
+    const f32x4* t = tab + i * T3 + zy[zi][yi] + ax[xi].base;
+    const f32x4 c000 = t[0], c001 = t[1], c010 = t[T], c011 = t[T + 1];
+    const f32x4 c100 = t[TT], c101 = t[TT + 1], c110 = t[TT + T], c111 = t[TT + T + 1];
+    const float w000 = w00[zi][yi] * ax[xi].wa, w001 = w00[zi][yi] * ax[xi].wb, w010 = w01[zi][yi] * ax[xi].wa,
+                w011 = w01[zi][yi] * ax[xi].wb, w100 = w10[zi][yi] * ax[xi].wa, w101 = w10[zi][yi] * ax[xi].wb,
+                w110 = w11[zi][yi] * ax[xi].wa, w111 = w11[zi][yi] * ax[xi].wb;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       float s = acc[h];

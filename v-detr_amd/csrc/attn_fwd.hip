@@ -26,7 +26,10 @@ constexpr int kFwdThreads = 512;
 constexpr int kFwdWaves = kFwdThreads / kWave;
 constexpr int kPPad = 20;  // floats per row of the P transpose pad (16 + 4: keeps float4 alignment)
 
-template <bool PERHEAD, bool RPE>
+// BOX (RPE only): this instantiation handles the workgroups whose four queries are axis-aligned boxes (6 axis taps per
+// pair, attn_common.h), the BOX = false one all the others; both are launched over the same grid and a workgroup exits
+// at once when it belongs to the other kind (the two paths in one kernel needed > 256 VGPRs).
+template <bool PERHEAD, bool RPE, bool BOX = false>
 __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   attn_load_rng(P);
@@ -44,6 +47,19 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   const int table_floats = RPE ? kRpeVerts * P.T * P.T * P.T * 4 : 0;
   f32x4* tab = reinterpret_cast<f32x4*>(smem);
   float* ppad = smem + table_floats + w * (16 * kPPad);
+  // ---- per-lane pair geometry (RPE): query g of the tile; decides which instantiation owns this workgroup ---------
+  float vx[8], vy[8], vz[8], rc = 1.f, rs = 0.f;
+  const bool rot = RPE && P.cos_sin != nullptr;
+  const int q_pair = min(q0 + g, nQ - 1);
+  if (RPE) {
+    const float* vp = P.vertices + ((size_t)b * nQ + q_pair) * 24;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
+    if (rot) { rc = P.cos_sin[((size_t)b * nQ + q_pair) * 2]; rs = P.cos_sin[((size_t)b * nQ + q_pair) * 2 + 1]; }
+    const bool box = !rot && P.box_path && __all(rpe_box_pattern(vx, vy, vz));  // same for the 8 waves: same 4 queries
+    if (box != BOX) return;
+  }
+  const float bX[2] = {vx[0], vx[2]}, bY[2] = {vy[0], vy[1]}, bZ[2] = {vz[0], vz[4]};
   if (RPE) rpe_stage_table(P, tab, tid, kFwdThreads);
 
   // ---- A operand of QK^T: row i = c ---------------------------------------------------------------
@@ -58,16 +74,6 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
     }
-  }
-  // ---- per-lane pair geometry (RPE): query g of the tile -------------------------------------------
-  float vx[8], vy[8], vz[8], rc = 1.f, rs = 0.f;
-  const bool rot = RPE && P.cos_sin != nullptr;
-  const int q_pair = min(q0 + g, nQ - 1);
-  if (RPE) {
-    const float* vp = P.vertices + ((size_t)b * nQ + q_pair) * 24;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
-    if (rot) { rc = P.cos_sin[((size_t)b * nQ + q_pair) * 2]; rs = P.cos_sin[((size_t)b * nQ + q_pair) * 2 + 1]; }
   }
   // query index of accumulator register r
   int qrow[4];
@@ -124,7 +130,10 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
     float sc[4] = {acc[0], acc[1], acc[2], acc[3]};
     // ---- + RPE bias -------------------------------------------------------------------------------
-    if (RPE) rpe_pair_bias(P, tab, vx, vy, vz, ops.kx, ops.ky, ops.kz, rot, rc, rs, sc);
+    if (RPE) {
+      if (BOX) rpe_pair_bias_box(P, tab, bX, bY, bZ, ops.kx, ops.ky, ops.kz, sc);
+      else rpe_pair_bias(P, tab, vx, vy, vz, ops.kx, ops.ky, ops.kz, rot, rc, rs, sc);
+    }
     // ---- mask, tail ------------------------------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -428,8 +437,14 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
   } else {
     dim3 grid((d->nQ + 3) / 4, ks, d->B);
     if (rpe) {
-      if (int e = set_lds(attn_fwd_kernel<false, true>, lds, "attn_fwd")) return e;
-      hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(kFwdThreads), lds, st, P);
+      static const int box_env = [] { const char* v = getenv("VDETR_FWD_BOX"); return v ? atoi(v) : 1; }();
+      P.box_path = box_env && !d->cos_sin;  // rotated boxes never take it: skip the launch
+      if (int e = set_lds(attn_fwd_kernel<false, true, false>, lds, "attn_fwd")) return e;
+      hipLaunchKernelGGL((attn_fwd_kernel<false, true, false>), grid, dim3(kFwdThreads), lds, st, P);
+      if (P.box_path) {
+        if (int e = set_lds(attn_fwd_kernel<false, true, true>, lds, "attn_fwd")) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<false, true, true>), grid, dim3(kFwdThreads), lds, st, P);
+      }
     } else {
       if (int e = set_lds(attn_fwd_kernel<false, false>, lds, "attn_fwd")) return e;
       hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(kFwdThreads), lds, st, P);
