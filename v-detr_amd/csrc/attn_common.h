@@ -144,8 +144,10 @@ __device__ __forceinline__ void rpe_pair_bias(const AttnParams& P, const f32x4* 
     const float w00 = az.wa * ay.wa, w01 = az.wa * ay.wb, w10 = az.wb * ay.wa, w11 = az.wb * ay.wb;
     const f32x4 c000 = t[0], c001 = t[1], c010 = t[T], c011 = t[T + 1];
     const f32x4 c100 = t[TT], c101 = t[TT + 1], c110 = t[TT + T], c111 = t[TT + T + 1];
-    const float w000 = w00 * ax.wa, w001 = w00 * ax.wb, w010 = w01 * ax.wa, w011 = w01 * ax.wb;
-    const float w100 = w10 * ax.wa, w101 = w10 * ax.wb, w110 = w11 * ax.wa, w111 = w11 * ax.wb;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 axw = {ax.wa, ax.wb};  // packed fp32: two corner weights per v_pk_mul_f32
+    const f32x2 p0 = axw * w00, p1 = axw * w01, p2 = axw * w10, p3 = axw * w11;
+    const float w000 = p0[0], w001 = p0[1], w010 = p1[0], w011 = p1[1], w100 = p2[0], w101 = p2[1], w110 = p3[0], w111 = p3[1];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       float s = acc[h];
@@ -202,9 +204,10 @@ __device__ __forceinline__ void rpe_pair_bias_box(const AttnParams& P, const f32
     const f32x4* t = tab + i * T3 + zy[zi][yi] + ax[xi].base;
     const f32x4 c000 = t[0], c001 = t[1], c010 = t[T], c011 = t[T + 1];
     const f32x4 c100 = t[TT], c101 = t[TT + 1], c110 = t[TT + T], c111 = t[TT + T + 1];
-    const float w000 = w00[zi][yi] * ax[xi].wa, w001 = w00[zi][yi] * ax[xi].wb, w010 = w01[zi][yi] * ax[xi].wa,
-                w011 = w01[zi][yi] * ax[xi].wb, w100 = w10[zi][yi] * ax[xi].wa, w101 = w10[zi][yi] * ax[xi].wb,
-                w110 = w11[zi][yi] * ax[xi].wa, w111 = w11[zi][yi] * ax[xi].wb;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 axw = {ax[xi].wa, ax[xi].wb};  // packed fp32: two corner weights per v_pk_mul_f32
+    const f32x2 p0 = axw * w00[zi][yi], p1 = axw * w01[zi][yi], p2 = axw * w10[zi][yi], p3 = axw * w11[zi][yi];
+    const float w000 = p0[0], w001 = p0[1], w010 = p1[0], w011 = p1[1], w100 = p2[0], w101 = p2[1], w110 = p3[0], w111 = p3[1];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       float s = acc[h];
