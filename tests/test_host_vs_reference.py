@@ -111,3 +111,20 @@ def test_position_embedding():
     assert_close(sine(xyz, num_channels=256, input_range=rng), g["sine_256"], 1e-4, 1e-4, "sine256")
     assert_close(sine(xyz, num_channels=100, input_range=rng), g["sine_100"], 1e-4, 1e-4, "sine100")
     assert xyz.equal(t(g["xyz"]))  # the input is not modified
+
+
+def test_decoder_plain_composition_paths(cpu_oracle_backend, monkeypatch):
+    """The decoder also has to work where the fused entry points do not apply (other norm types / widths, per-layer K/V):
+    with them switched off it takes the reference's plain composition and still reproduces the golden outputs."""
+    import vdetr_amd.add_ln as ALN
+    import vdetr_amd.vdetr_transformer as VT
+    g = load_golden("decoder_c1_l3")
+    dec = build_decoder(3, False)
+    monkeypatch.setattr(ALN, "supported", lambda *mods: False)             # no fused residual + LayerNorm launches
+    monkeypatch.setattr(VT.GlobalShareCrossAttention, "precompute", staticmethod(lambda mods, key: [None] * len(mods)))
+    stages, loss, gfeats = run_decoder_case(g, dec, "cpu")
+    for s, st in enumerate(stages):
+        for k in ("sem_cls_logits", "center_unnormalized", "size_unnormalized", "box_corners"):
+            assert_close(st[k], g[f"s{s}:{k}"], 1e-3, 1e-4, f"stage {s} {k}")
+    assert_close(loss, g["loss"], 1e-4, 1e-3, "loss")
+    assert_close(gfeats, g["grad_feats"], 2e-3, 1e-4 * np.abs(g["grad_feats"]).max(), "grad_feats")
