@@ -8,6 +8,7 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("B,C,N,p,relu", [(1, 1280, 1024, 0.3, True), (1, 288, 1024, 0.0, True), (3, 70, 333, 0.1, True),
+                                          (4, 96, 1024, 0.3, True), (2, 40, 256, 0.1, True),
                                           (2, 64, 4096, 0.0, False)])
 def test_bn_act_training_matches_oracle(B, C, N, p, relu):
     from oracle.bn_act_oracle import bn_act as ref_fn

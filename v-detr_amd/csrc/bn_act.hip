@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_kernel(vdetr_bnact_desc
 }
 
 
-// ---- register-resident variants: B == 1 and N == NCH * 256.  A lane holds NCH float4 of its channel's row: every load
+// ---- register-resident variants: B * N == NCH * 256 (N % 4 == 0).  A lane holds NCH float4 of its channel: every load
 // of the launch is issued before the first reduction (one memory latency), the row is read once.  (The sweep kernels
 // above took 17 / 20 us on the heads' [1, 1280, 1024] tensors: three resp. two dependent passes of scalar loads.)
 template <int NCH>
@@ -150,11 +150,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_reg_kernel(vdetr_bnact_
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.C) return;
-  constexpr int N = NCH * 256;
-  const f32x4* xc = reinterpret_cast<const f32x4*>(d.x + (size_t)c * N);
+  constexpr int N = NCH * 256;  // elements of the channel over the whole batch
+  const int n4 = d.N >> 2;      // float4 per (scene, channel) row
+  // float4 #idx of the channel -> scene idx / n4, offset idx % n4 (one scene: the identity)
+  auto at = [&](const float* base, int idx) {
+    const int b = idx / n4, i4 = idx - b * n4;
+    return reinterpret_cast<const f32x4*>(base + ((size_t)b * d.C + c) * d.N) + i4;
+  };
   f32x4 xr[NCH];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) xr[j] = xc[j * 64 + lane];
+  for (int j = 0; j < NCH; ++j) xr[j] = *at(d.x, j * 64 + lane);
   const float ga = d.gamma ? d.gamma[c] : 1.f, be = d.beta ? d.beta[c] : 0.f;
   float s = 0.f;
 #pragma unroll
@@ -179,7 +184,6 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_reg_kernel(vdetr_bnact_
   const float a = ga * invstd, sh = be - mean * a;
   const BnRng rg = bn_rng(d);
   const unsigned ck = bn_chankey(rg, c);
-  f32x4* yc = reinterpret_cast<f32x4*>(d.y + (size_t)c * N);
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     f32x4 v;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_reg_kernel(vdetr_bnact_
       if (rg.thresh) t = bn_keep(rg, ck, (j * 64 + lane) * 4 + e) ? t * rg.scale : 0.f;
       v[e] = t;
     }
-    yc[j * 64 + lane] = v;
+    *const_cast<f32x4*>(at(d.y, j * 64 + lane)) = v;
   }
 }
 
@@ -200,11 +204,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reg_kernel(vdetr_bnact_
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.C) return;
   constexpr int N = NCH * 256;
-  const f32x4* xc = reinterpret_cast<const f32x4*>(d.x + (size_t)c * N);
-  const f32x4* gc = reinterpret_cast<const f32x4*>(g.dy + (size_t)c * N);
+  const int n4 = d.N >> 2;
+  auto at = [&](const float* base, int idx) {
+    const int b = idx / n4, i4 = idx - b * n4;
+    return reinterpret_cast<const f32x4*>(base + ((size_t)b * d.C + c) * d.N) + i4;
+  };
   f32x4 xr[NCH], gr[NCH];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) { xr[j] = xc[j * 64 + lane]; gr[j] = gc[j * 64 + lane]; }
+  for (int j = 0; j < NCH; ++j) { xr[j] = *at(d.x, j * 64 + lane); gr[j] = *at(g.dy, j * 64 + lane); }
   const float mean = d.save_mean[c], invstd = d.save_invstd[c];
   const float ga = d.gamma ? d.gamma[c] : 1.f, be = d.beta ? d.beta[c] : 0.f;
   const BnRng rg = bn_rng(d);
@@ -230,13 +237,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reg_kernel(vdetr_bnact_
   }
   if (!g.dx) return;
   const float k = ga * invstd, m1 = dbeta * (1.f / (float)N), m2 = dgamma * (1.f / (float)N);
-  f32x4* dxc = reinterpret_cast<f32x4*>(g.dx + (size_t)c * N);
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = k * (gr[j][e] - m1 - xr[j][e] * m2);
-    dxc[j * 64 + lane] = v;
+    *const_cast<f32x4*>(at(g.dx, j * 64 + lane)) = v;
   }
 }
 
@@ -294,8 +300,10 @@ extern "C" int vdetr_bn_act_fwd_f32(const vdetr_bnact_desc* d, vdetr_stream_t st
   VDETR_REQUIRE(d->training || d->dropout_p == 0.f, "bn_act_fwd: dropout in eval mode");
   const dim3 grid(ceil_div(d->C, 4)), block(kBnThreads);
   hipStream_t st = (hipStream_t)stream;
-  const bool reg = d->training && d->B == 1 && d->N % 256 == 0 && ((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->y & 15) == 0;
-  switch (reg ? d->N / 256 : 0) {
+  const long tot = (long)d->B * d->N;
+  const bool reg = d->training && d->N % 4 == 0 && tot % 256 == 0 && tot <= 4096 && ((uintptr_t)d->x & 15) == 0 &&
+                   ((uintptr_t)d->y & 15) == 0;
+  switch (reg ? (int)(tot / 256) : 0) {
     case 1: hipLaunchKernelGGL(bn_act_fwd_reg_kernel<1>, grid, block, 0, st, *d); break;
     case 2: hipLaunchKernelGGL(bn_act_fwd_reg_kernel<2>, grid, block, 0, st, *d); break;
     case 4: hipLaunchKernelGGL(bn_act_fwd_reg_kernel<4>, grid, block, 0, st, *d); break;
@@ -313,9 +321,10 @@ extern "C" int vdetr_bn_act_bwd_f32(const vdetr_bnact_desc* d, const vdetr_bnact
   VDETR_REQUIRE(g->dx || g->d_gamma || g->d_beta, "bn_act_bwd: nothing to compute");
   const dim3 grid(ceil_div(d->C, 4)), block(kBnThreads);
   hipStream_t st = (hipStream_t)stream;
-  const bool reg = d->B == 1 && d->N % 256 == 0 && ((uintptr_t)d->x & 15) == 0 && ((uintptr_t)g->dy & 15) == 0 &&
-                   (!g->dx || ((uintptr_t)g->dx & 15) == 0);
-  switch (reg ? d->N / 256 : 0) {
+  const long tot = (long)d->B * d->N;
+  const bool reg = d->N % 4 == 0 && tot % 256 == 0 && tot <= 4096 && ((uintptr_t)d->x & 15) == 0 &&
+                   ((uintptr_t)g->dy & 15) == 0 && (!g->dx || ((uintptr_t)g->dx & 15) == 0);
+  switch (reg ? (int)(tot / 256) : 0) {
     case 1: hipLaunchKernelGGL(bn_act_bwd_reg_kernel<1>, grid, block, 0, st, *d, *g); break;
     case 2: hipLaunchKernelGGL(bn_act_bwd_reg_kernel<2>, grid, block, 0, st, *d, *g); break;
     case 4: hipLaunchKernelGGL(bn_act_bwd_reg_kernel<4>, grid, block, 0, st, *d, *g); break;
