@@ -706,7 +706,8 @@ using namespace vdetr;
 static int bwd_variant() {
   // 0: per-lane ds_add_f32, 1: wave-aggregated + ds_add_f32; matrix-core aggregation: 9 (default) split-bf16 product,
   // fixed-point histogram, two 16-wave workgroups per query, a wave walks the workgroup's 4 vertices per chunk;
-  // 8: as 9 with one vertex per wave; 10 / 4: one 8-wave workgroup per query with / without the vertex walk;
+  // 8: as 9 with one vertex per wave; 11 / 12: as 9 with 12 / 8 waves (no spills, measured 434 / 515 us vs 417 us);
+  // 10 / 4: one 8-wave workgroup per query with / without the vertex walk;
   // 5 / 7: fp32 MFMA with float / fixed-point histogram (8-wave workgroups, one vertex per wave)
   static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 9; }();
   return variant;
@@ -756,7 +757,7 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
   const int variant = bwd_variant();
   const int table_floats = kRpeVerts * P.T * P.T * P.T * 4;
   const bool mm = dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16;
-  const int split = mm && (variant == 8 || variant == 9) ? 2 : 1;  // workgroups per query
+  const int split = mm && (variant == 8 || variant == 9 || variant == 11 || variant == 12) ? 2 : 1;  // workgroups per query
   const int grid = bwd_grid(d, split);
   if (dtable) {
     const size_t need = vdetr_attn_bwd_workspace_bytes(d);
@@ -774,6 +775,8 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     else if (variant == 4) e = launch_mm<true, 8, 1, true, false>(P, grid, lds, st);
     else if (variant == 8) e = launch_mm<true, 4, 4, true, false>(P, grid, lds, st);
     else if (variant == 10) e = launch_mm<true, 8, 1, true, true>(P, grid, lds, st);
+    else if (variant == 11) e = launch_mm<true, 4, 3, true, true>(P, grid, (size_t)table_floats / 2 * sizeof(float) + (size_t)12 * kMmStripFloats * sizeof(float), st);
+    else if (variant == 12) e = launch_mm<true, 4, 2, true, true>(P, grid, (size_t)table_floats / 2 * sizeof(float) + (size_t)8 * kMmStripFloats * sizeof(float), st);
     else e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st);
     if (e) return e;
   } else {
