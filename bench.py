@@ -343,8 +343,11 @@ def main():
     assert world == a.gpus or (world == 1 and a.gpus == 1), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local)
     if not a.no_gemm_tuning:
-        from vdetr_amd.runtime import enable_gemm_tuning
-        enable_gemm_tuning(rank)
+        try:
+            from vdetr_amd.runtime import enable_gemm_tuning
+            enable_gemm_tuning(rank)
+        except Exception as exc:  # tuning is an optimisation: the library heuristics still work
+            print(f"[bench] GEMM tuning unavailable ({exc}); continuing with library defaults", file=sys.stderr)
 
     model = build_model(a.config, device)
     use_graph = not (a.no_graph or a.sync_bn)
