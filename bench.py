@@ -137,6 +137,8 @@ class Trainer:
         with torch.cuda.stream(s):
             for _ in range(3):  # warm allocator, lazy inits, LDS attribute grants
                 self._fwd_bwd()
+                if self.world > 1:
+                    self.reducer.reduce_all()  # real updates: the replicas must stay identical
                 self._update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
