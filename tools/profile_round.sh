@@ -9,6 +9,10 @@ rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py -
 db=$(find /tmp/rp_eager -name '*.db' | head -1); csv=$(find /tmp/rp_eager -name '*kernel_trace.csv' | head -1)
 python3 tools/rocprof_summary.py ${db:-$csv} 5 3 > $out/eager_kernel_summary.txt 2>&1
 python3 tools/kernel_bench.py c2 > $out/kernel_bench_c2.txt 2>&1
+# the same micro-benchmark under the kernel trace: the per-kernel averages bench.py's `roofline` objects must agree with
+rocprofv3 --kernel-trace --stats -d /tmp/rp_kb -o kb -- python3 tools/kernel_bench.py c2 > /dev/null 2>&1
+kdb=$(find /tmp/rp_kb -name '*.db' | head -1)
+[ -n "$kdb" ] && python3 tools/rocprof_summary.py $kdb > $out/kernel_bench_rocprof.txt 2>&1
 python3 tools/kernel_bench.py c2 --indexing > $out/kernel_bench_indexing.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$c -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_$c.log 2>&1
