@@ -405,7 +405,10 @@ def main():
                    "grad_allreduce_bytes": trainer.reducer.grad_bytes()},
         "loss": loss,
     }
-    if rank == 0 and world == 1:
+    if a.config == "c2":  # decoder fwd+bwd = 216 GFLOP per scene at the full configuration
+        result["end_to_end"] = {"gflop_per_scene": 216.0, "achieved_tflops": 216.0e-3 * result["value"],
+                                "note": "algorithmic decoder flops (SURVEY 8d) x scenes/s, all GPUs"}
+    if rank == 0:
         if not a.no_roofline:
             fwd_obj, bwd_obj = kernel_rooflines(a.config, device)
             layers = nl - 1
@@ -414,7 +417,7 @@ def main():
             other["share_of_step"] = layers * other["launch_us"] * 1e-3 / result["ms_per_step"]
             result["roofline"] = dom
             result["roofline_secondary"] = other
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(a.config)
     if rank == 0:
         print(json.dumps(result))
