@@ -203,6 +203,111 @@ def misc_cases(T, PE, Cfg):
          sine_100=np_(sine(xyz, num_channels=100, input_range=rng)))
 
 
+def import_reference_criterion():
+    """criterion.py imports three mmcv ops at module level (criterion.py:20-22).  mmcv is absent: points_in_boxes_all is
+    replaced by the restatement in oracle/criterion_oracle.py (so that one function stays unpinned), the rotated-IoU ops
+    are never reached with iou_type='giou'."""
+    from oracle import criterion_oracle as CO
+    ops = sys.modules["mmcv.ops"]
+    ops.points_in_boxes_all = CO.points_in_boxes_all
+    ops.diff_iou_rotated_3d = None
+    m = types.ModuleType("mmcv.ops.diff_iou_rotated")
+    m.box2corners = m.oriented_box_intersection_2d = None
+    sys.modules["mmcv.ops.diff_iou_rotated"] = m
+    import criterion as C  # noqa  (the reference's /root/reference/criterion.py)
+    return C
+
+
+def synthetic_stage(g, cfg, B, P, C, nbin=1):
+    """One stage's box-prediction dictionary with the keys/shapes of vdetr_transformer.py:319-333, from random heads."""
+    lo, ext = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([8.0, 6.0, 3.0])
+    pre_c = lo + torch.rand((B, P, 3), generator=g) * ext
+    pre_s = 0.3 + torch.rand((B, P, 3), generator=g) * 1.5
+    center_reg = (torch.randn((B, P, 3), generator=g) * 0.3).requires_grad_(True)
+    size_reg = (torch.randn((B, P, 3), generator=g) * 0.3).requires_grad_(True)
+    logits = (torch.randn((B, P, C), generator=g) * 2 - 2).requires_grad_(True)
+    angle_logits = torch.randn((B, P, nbin), generator=g).requires_grad_(True)
+    angle_res = (torch.randn((B, P, nbin), generator=g) * 0.5).requires_grad_(True)
+    center = center_reg * pre_s + pre_c
+    size = torch.exp(size_reg) * pre_s
+    # a leaf: the fixture holds d loss / d corners itself (the chain into centre/size is the box decode's business)
+    corners = cfg.box_parametrization_to_corners(center.detach(), size.detach(), torch.zeros((B, P))).requires_grad_(True)
+    return {"sem_cls_logits": logits, "sem_cls_prob": logits, "center_unnormalized": center, "size_unnormalized": size,
+            "center_normalized": center, "size_normalized": size,
+            "angle_logits": angle_logits, "angle_residual_normalized": angle_res,
+            "angle_continuous": torch.zeros((B, P)), "objectness_prob": torch.rand((B, P), generator=g),
+            "box_corners": corners, "pre_box_center_unnormalized": pre_c, "center_reg": center_reg,
+            "pre_box_size_unnormalized": pre_s, "size_reg": size_reg}
+
+
+def synthetic_targets(g, cfg, B, G, counts, nclass):
+    lo, ext = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([8.0, 6.0, 3.0])
+    centers = lo + torch.rand((B, G, 3), generator=g) * ext
+    sizes = 0.3 + torch.rand((B, G, 3), generator=g) * 1.7
+    present = torch.zeros((B, G))
+    for b, n in enumerate(counts):
+        present[b, :n] = 1
+    if counts[0] >= 3:       # a hole in the list: the compaction of repeat_ground_truth is exercised
+        present[0, 1] = 0
+    centers, sizes = centers * present[..., None], sizes * present[..., None]
+    corners = cfg.box_parametrization_to_corners(centers, sizes, torch.zeros((B, G))) * present[..., None, None]
+    labels = (torch.randint(0, nclass, (B, G), generator=g) * present.long())
+    return {"gt_box_corners": corners, "gt_box_centers": centers, "gt_box_centers_normalized": centers / 10.0,
+            "gt_box_sem_cls_label": labels, "gt_box_present": present, "gt_box_sizes": sizes,
+            "gt_box_sizes_normalized": sizes / 10.0, "gt_box_angles": torch.zeros((B, G)),
+            "gt_angle_class_label": torch.zeros((B, G), dtype=torch.int64),
+            "gt_angle_residual_label": torch.zeros((B, G)), "scan_idx": torch.arange(B)}
+
+
+def criterion_cases(Cfg):
+    C = import_reference_criterion()
+    cfg = Cfg()
+    base = dict(cls_loss="focalloss_0.25", is_bilable=True, repeat_num=5, iou_type="giou", point_cls_loss_weight=0.05,
+                matcher_giou_cost=2.0, matcher_cls_cost=3.0, matcher_center_cost=1.0, matcher_objectness_cost=0.0,
+                matcher_size_cost=0.5, matcher_anglecls_cost=0.0, matcher_anglereg_cost=0.0, loss_giou_weight=2.0,
+                loss_sem_cls_weight=3.0, loss_no_object_weight=0.0, loss_angle_cls_weight=0.1, loss_angle_reg_weight=0.5,
+                loss_center_weight=1.0, loss_size_weight=0.5)
+    # name, B, tokens of the first stage, queries, later stages, gt slots, gt per scene, repeat_num
+    for name, B, N0, P, S, G, counts, rep in [("criterion_small", 2, 96, 48, 2, 8, (5, 3), 5),
+                                              ("criterion_wide", 2, 64, 16, 1, 8, (7, 0), 5),   # 5*7 gt > 16 queries; empty scene
+                                              ("criterion_norepeat", 1, 80, 40, 1, 8, (6,), 1),
+                                              ("criterion_empty", 1, 32, 16, 1, 8, (0,), 5)]:
+        g = torch.Generator().manual_seed(sum(map(ord, name)))
+        a = Namespace(**{**base, "repeat_num": rep})
+        crit = C.build_criterion(a, cfg)
+        targets = synthetic_targets(g, cfg, B, G, counts, cfg.num_semcls)
+        stages = [synthetic_stage(g, cfg, B, N0, 1)] + [synthetic_stage(g, cfg, B, P, cfg.num_semcls) for _ in range(S + 1)]
+        seed_xyz = torch.tensor([1.0, 1.0, 1.0]) + torch.rand((B, N0, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0])
+        seed_xyz[:, :G] = targets["gt_box_centers"]                 # some seeds certainly inside a box
+        point_logits = (torch.randn((B, N0, cfg.num_semcls), generator=g) - 1).requires_grad_(True)
+        outputs = {"outputs": stages[-1], "aux_outputs": stages[:-1], "seed_inds": torch.zeros((B, N0), dtype=torch.int64),
+                   "seed_xyz": seed_xyz, "enc_outputs": {"point_cls_logits": point_logits}}
+        # the matcher's results are internal to the reference: record them through the matcher module
+        records = []
+        hook = crit.matcher.register_forward_hook(lambda m, i, o: records.append(o))
+        loss, loss_dict = crit(outputs, {k: v.clone() for k, v in targets.items()})
+        hook.remove()
+        loss.backward()
+        arrays = {"loss": np_(loss), "B": np.array(B), "N0": np.array(N0), "P": np.array(P), "S": np.array(S),
+                  "repeat_num": np.array(rep), "seed_xyz": np_(seed_xyz), "point_cls_logits": np_(point_logits),
+                  "grad:point_cls_logits": np_(point_logits.grad)}
+        for k, v in targets.items():
+            arrays["target:" + k] = np_(v)
+        for k, v in loss_dict.items():
+            arrays["loss:" + k] = np_(torch.as_tensor(v))
+        order = [len(stages) - 1] + list(range(len(stages) - 1))       # the reference matches "outputs" first
+        for si, rec in zip(order, records):
+            arrays[f"match{si}:inds"] = np_(rec["per_prop_gt_inds"])
+            arrays[f"match{si}:mask"] = np_(rec["proposal_matched_mask"])
+        for si, st in enumerate(stages):
+            for k in ("sem_cls_logits", "center_reg", "size_reg", "angle_logits", "angle_residual_normalized", "box_corners",
+                      "pre_box_center_unnormalized", "pre_box_size_unnormalized", "objectness_prob"):
+                arrays[f"stage{si}:{k}"] = np_(st[k])
+                if st[k].grad is not None:
+                    arrays[f"grad{si}:{k}"] = np_(st[k].grad)
+        save(name, **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -211,6 +316,7 @@ def main():
     share_self_attention_case(T)
     decoder_cases(T, Cfg)
     misc_cases(T, PE, Cfg)
+    criterion_cases(Cfg)
 
 
 if __name__ == "__main__":
