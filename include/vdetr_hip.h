@@ -334,6 +334,100 @@ int vdetr_pack_chunk_floats(void);
 int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk, int nblocks,
                    float* dst, vdetr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Set criterion on the device (reference criterion.py).  Replaces, without a host round trip:
+ *   repeat_ground_truth (criterion.py:511-600), the pairwise GIoU / centre / size matrices and the matcher's cost
+ *   (criterion.py:618-631, 122-196; utils/box_util.py:441-600 with rotated_boxes=False), the nine
+ *   scipy.optimize.linear_sum_assignment calls on the host (criterion.py:198-221), points_in_boxes_all
+ *   (criterion.py:270-289) and the matched losses with their gradients (criterion.py:77-98, 329-509).
+ * Ground truth travels as packed records of VDETR_GT_FLOATS floats per box slot.
+ * ---------------------------------------------------------------------------------------------- */
+#define VDETR_GT_CORNERS 0    /* 24: gt_box_corners[8][3], camera frame */
+#define VDETR_GT_CENTER 24    /* 3: gt_box_centers */
+#define VDETR_GT_SIZE 27      /* 3: gt_box_sizes */
+#define VDETR_GT_ANGLE 30     /* gt_box_angles */
+#define VDETR_GT_LABEL 31     /* gt_box_sem_cls_label (as float) */
+#define VDETR_GT_ANGLE_CLS 32 /* gt_angle_class_label (as float) */
+#define VDETR_GT_ANGLE_RES 33 /* gt_angle_residual_label */
+#define VDETR_GT_PRESENT 34   /* gt_box_present */
+#define VDETR_GT_FLOATS 36
+
+/* gt [B,G,F] -> gt_rep [B,G*repeat,F]: the list tiled `repeat` times, present boxes first in stable order, the rest
+ * zero (criterion.py:511-590); nactual[B] / nactual_rep[B] = present counts (:592, :660); sums[0] = sum nactual,
+ * sums[1] = sum nactual_rep as floats (the caller averages them over ranks and clamps at 1: :593, :661).  A present box
+ * with a positive angle would need the rotated-polygon GIoU (criterion.py:616, box_util.py:566-589), which is not
+ * implemented: both sums are then NaN so that every loss built on them is NaN. */
+int vdetr_gt_prepare_f32(const float* gt, int B, int G, int repeat, float* gt_rep, int64_t* nactual, int64_t* nactual_rep,
+                         float* sums, vdetr_stream_t stream);
+
+typedef struct vdetr_match_desc {
+  int32_t B, P, G;   /* scenes, proposals, ground-truth slots */
+  int32_t C, A;      /* class channels of `cls`, angle bins */
+  int32_t cls_kind;  /* VDETR_CLS_SIGMOID: focal cost of sigmoid(cls) (criterion.py:123-138); _SOFTMAX: -cls[label] (:139-146) */
+  int32_t label_override; /* >= 0: every box carries this class (the binary first stage, criterion.py:679-681); -1: records */
+  float w_cls, w_objectness, w_center, w_giou, w_size, w_angle_cls, w_angle_reg; /* matcher_*_cost (main.py:118-124) */
+  const float* cls;         /* [B,P,C] outputs["sem_cls_prob"] */
+  const float* objectness;  /* [B,P] */
+  const float *center_reg, *size_reg, *pre_center, *pre_size; /* [B,P,3] center_reg, size_reg, pre_box_*_unnormalized */
+  const float* corners;     /* [B,P,8,3] box_corners */
+  const float *angle_logits, *angle_res_norm; /* [B,P,A] */
+  const float* gt;          /* [B,G,VDETR_GT_FLOATS] */
+  const int64_t* nactual;   /* [B] */
+  float* cost_t;            /* [B,G,P]: final_cost[b,p,g] stored box-major (columns >= nactual[b] are not read by the solver) */
+  float* giou_t;            /* optional [B,G,P] pairwise GIoU (outputs["gious"], box-major), or NULL */
+} vdetr_match_desc;
+int vdetr_match_cost_f32(const vdetr_match_desc* d, vdetr_stream_t stream);
+
+/* Rectangular linear sum assignment, one workgroup per (problem, scene): scipy's shortest-augmenting-path solver
+ * (rectangular_lsap.cpp of scipy 1.5.1, requirements.txt:9) restated in fp64 with its traversal order and tie rules, so
+ * the result is the one linear_sum_assignment(final_cost[b, :, :nactual[b]]) returns.  Writes per_prop_gt_inds and
+ * proposal_matched_mask (criterion.py:200-221), zero where unmatched.  Limits: max(P, G) <= 8192, min(P, G) <= 2048.
+ * status[w] (optional, zero-filled by the caller; w counts the (problem, scene) pairs in order) is set to 1 if a cost is
+ * NaN/-inf or the matrix is infeasible (scipy raises ValueError there); that scene's outputs stay zero. */
+#define VDETR_LSA_MAX_PROBLEMS 16
+typedef struct vdetr_lsa_problem {
+  const float* cost_t;    /* [B,G,P] */
+  const int64_t* nactual; /* [B] */
+  int64_t* inds;          /* [B,P] */
+  float* mask;            /* [B,P] */
+  int32_t B, P, G;
+  int32_t reserved;
+} vdetr_lsa_problem;
+typedef struct vdetr_lsa_batch {
+  int32_t nproblems;
+  int32_t reserved;
+  vdetr_lsa_problem p[VDETR_LSA_MAX_PROBLEMS];
+} vdetr_lsa_batch;
+int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdetr_stream_t stream);
+
+/* Seed-point labels of loss_point_cls (criterion.py:270-301): label[b,n] = class of the smallest-volume box containing
+ * seed n (mmcv points_in_boxes_all semantics on (centre, size, angle) with the bottom face at z - dz/2), C = none. */
+int vdetr_point_labels_f32(const float* seed_xyz, const float* gt, const int64_t* nactual, int B, int N, int G, int C,
+                           int64_t* labels, vdetr_stream_t stream);
+
+typedef struct vdetr_setloss_desc {
+  int32_t B, P, G, C, A;
+  int32_t label_override;  /* as in vdetr_match_desc */
+  float focal_alpha;       /* cls_loss "focalloss_<alpha>" (criterion.py:238-239) */
+  float w_cls, w_angle_cls, w_angle_reg, w_center, w_size, w_giou; /* loss_*_weight (main.py:128-136); folded into values and gradients */
+  const float* cls_logits; /* [B,P,C] */
+  /* box terms; all NULL = classification only (the seed-point loss) */
+  const float *center_reg, *size_reg, *pre_center, *pre_size; /* [B,P,3] */
+  const float* corners;    /* [B,P,8,3] */
+  const float *angle_logits, *angle_res_norm; /* [B,P,A] */
+  const float* gt;         /* [B,G,VDETR_GT_FLOATS] */
+  const int64_t* nactual;  /* [B]: gates everything on sum > 0 (num_boxes_replica, criterion.py:331,...) */
+  const int64_t* inds;     /* [B,P] per_prop_gt_inds, or NULL with `labels` */
+  const float* mask;       /* [B,P] proposal_matched_mask */
+  const int64_t* labels;   /* [B,P] class per row directly (C = none); used when inds == NULL */
+  const float* num_boxes;  /* device scalar */
+  /* outputs.  losses[0..7] += {sem_cls, angle_cls, angle_reg, center, size, giou, cardinality, weighted total}
+     (the six losses already multiplied by their weights, as loss_dict holds them: criterion.py:648-651). */
+  float* losses;
+  float *d_cls_logits, *d_center_reg, *d_size_reg, *d_corners, *d_angle_logits, *d_angle_res_norm; /* d total / d input; written in full */
+} vdetr_setloss_desc;
+int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

@@ -93,6 +93,49 @@ class BnActGrads(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("dy", "dx", "d_gamma", "d_beta")]
 
 
+# ---- set criterion (criterion.hip) -------------------------------------------------------------------------------
+VDETR_GT_CORNERS, VDETR_GT_CENTER, VDETR_GT_SIZE, VDETR_GT_ANGLE, VDETR_GT_LABEL = 0, 24, 27, 30, 31
+VDETR_GT_ANGLE_CLS, VDETR_GT_ANGLE_RES, VDETR_GT_PRESENT, VDETR_GT_FLOATS = 32, 33, 34, 36
+VDETR_LSA_MAX_PROBLEMS = 16
+
+_MATCH_W = ("w_cls", "w_objectness", "w_center", "w_giou", "w_size", "w_angle_cls", "w_angle_reg")
+_MATCH_PTR = ("cls", "objectness", "center_reg", "size_reg", "pre_center", "pre_size", "corners", "angle_logits",
+              "angle_res_norm", "gt", "nactual", "cost_t", "giou_t")
+
+
+class MatchDesc(ctypes.Structure):
+    """Mirror of ``vdetr_match_desc``."""
+
+    _fields_ = ([(n, ctypes.c_int32) for n in ("B", "P", "G", "C", "A", "cls_kind", "label_override")] +
+                [(n, c_float) for n in _MATCH_W] + [(n, c_void_p) for n in _MATCH_PTR])
+
+
+class LsaProblem(ctypes.Structure):
+    """Mirror of ``vdetr_lsa_problem``."""
+
+    _fields_ = [(n, c_void_p) for n in ("cost_t", "nactual", "inds", "mask")] + [
+        (n, ctypes.c_int32) for n in ("B", "P", "G", "reserved")]
+
+
+class LsaBatch(ctypes.Structure):
+    """Mirror of ``vdetr_lsa_batch``."""
+
+    _fields_ = [("nproblems", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", LsaProblem * VDETR_LSA_MAX_PROBLEMS)]
+
+
+_LOSS_W = ("w_cls", "w_angle_cls", "w_angle_reg", "w_center", "w_size", "w_giou")
+_LOSS_PTR = ("cls_logits", "center_reg", "size_reg", "pre_center", "pre_size", "corners", "angle_logits", "angle_res_norm",
+             "gt", "nactual", "inds", "mask", "labels", "num_boxes", "losses", "d_cls_logits", "d_center_reg", "d_size_reg",
+             "d_corners", "d_angle_logits", "d_angle_res_norm")
+
+
+class SetLossDesc(ctypes.Structure):
+    """Mirror of ``vdetr_setloss_desc``."""
+
+    _fields_ = ([(n, ctypes.c_int32) for n in ("B", "P", "G", "C", "A", "label_override")] + [("focal_alpha", c_float)] +
+                [(n, c_float) for n in _LOSS_W] + [(n, c_void_p) for n in _LOSS_PTR])
+
+
 # name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
 _SIGNATURES = {
     "vdetr_abi_version": (c_int, []),
@@ -127,6 +170,11 @@ _SIGNATURES = {
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vdetr_gt_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vdetr_match_cost_f32": (c_int, [ctypes.POINTER(MatchDesc), c_void_p]),
+    "vdetr_lsa_f64": (c_int, [ctypes.POINTER(LsaBatch), c_void_p, c_void_p]),
+    "vdetr_point_labels_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_set_loss_f32": (c_int, [ctypes.POINTER(SetLossDesc), c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

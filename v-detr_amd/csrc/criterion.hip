@@ -1,0 +1,680 @@
+// criterion.hip — the set criterion on the device (reference criterion.py).
+//
+// The reference builds three [B,P,G] matrices with ~60 torch launches per stage, copies the cost to the host, runs
+// scipy's Hungarian solver there (9 x per step, each behind a device->host sync), copies the assignment back and
+// gathers the matched losses from the matrices.  Here, per stage:
+//   match_cost_kernel   one launch: GIoU + centre + size + class terms -> cost, stored box-major so the solver reads rows
+//   lsa_kernel          ONE launch for all stages: a workgroup per (stage, scene) runs the same shortest-augmenting-path
+//                       algorithm as scipy in fp64, columns spread over the lanes, state in registers / LDS
+//   set_loss_kernel     one launch: matched losses AND their gradients (the pairwise matrices are never needed again)
+// Everything is latency-bound integer/fp32 work of a few hundred KB; the design goals are launch count, no host round
+// trip (the whole step stays capturable in a hipGraph) and bit-identical assignments.
+#include "wave.h"
+
+namespace vdetr {
+namespace {
+
+constexpr int F = VDETR_GT_FLOATS;
+
+// ------------------------------------------------------------------------------------------------ ground truth
+// One workgroup; scenes in sequence (B is the per-GPU batch, 1..8).
+__global__ __launch_bounds__(256) void gt_prepare_kernel(const float* __restrict__ gt, int B, int G, int repeat,
+                                                         float* __restrict__ gt_rep, int64_t* __restrict__ nactual,
+                                                         int64_t* __restrict__ nactual_rep, float* __restrict__ sums) {
+  extern __shared__ int prefix[];  // [G + 1] exclusive count of present boxes; [G + 1] = rotated-box flag
+  int total = 0;
+  bool rotated = false;
+  for (int b = 0; b < B; ++b) {
+    const float* src = gt + (size_t)b * G * F;
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (int s = 0; s < G; ++s) {
+        prefix[s] = n;
+        const bool present = src[s * F + VDETR_GT_PRESENT] > 0.f;
+        n += present;
+        // the reference switches to polygon clipping when any angle is positive (criterion.py:616); not implemented
+        rotated |= present && src[s * F + VDETR_GT_ANGLE] > 0.f;
+      }
+      prefix[G] = n;
+    }
+    __syncthreads();
+    const int n = prefix[G];
+    total += n;
+    if (gt_rep != nullptr) {
+      float* dst = gt_rep + (size_t)b * G * repeat * F;
+      const int slots = G * repeat;
+      // present boxes of every tile move to the front, tile after tile (stable)
+      for (int e = threadIdx.x; e < slots * F; e += blockDim.x) {
+        const int t = e / F, f = e - t * F;
+        const int s = t % G, tile = t / G;
+        if (src[s * F + VDETR_GT_PRESENT] > 0.f) dst[(tile * n + prefix[s]) * F + f] = src[s * F + f];
+      }
+      for (int e = n * repeat * F + threadIdx.x; e < slots * F; e += blockDim.x) dst[e] = 0.f;
+    }
+    if (threadIdx.x == 0) {
+      nactual[b] = n;
+      if (nactual_rep != nullptr) nactual_rep[b] = (int64_t)n * repeat;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // rotated ground truth poisons the normaliser: every loss becomes NaN instead of mis-scored
+    sums[0] = rotated ? NAN : (float)total;
+    sums[1] = rotated ? NAN : (float)(total * repeat);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ box geometry
+struct BoxGeo {           // what the GIoU needs of one box given as 8 corners (camera frame, y down)
+  float mn[3], mx[3];     // extent over the corners
+  float c0x, c0y, c0z;    // corner 0 = (+l/2, +h/2, +w/2) side
+  float c2x, c2z;         // corner 2 = (-l/2, ., -w/2)
+  float c4y;              // corner 4: the other y face
+  float vol;              // clamped volume from three edges (box_util.py:441-463)
+};
+
+__device__ __forceinline__ float edge_len(const float* c, int i, int j) {
+  const float dx = c[i * 3] - c[j * 3], dy = c[i * 3 + 1] - c[j * 3 + 1], dz = c[i * 3 + 2] - c[j * 3 + 2];
+  return sqrtf(fmaxf((dx * dx + dy * dy) + dz * dz, 1e-6f));
+}
+
+template <typename Ptr>
+__device__ __forceinline__ BoxGeo box_geo(Ptr c) {
+  BoxGeo g;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float lo = c[a], hi = c[a];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      lo = fminf(lo, c[k * 3 + a]);
+      hi = fmaxf(hi, c[k * 3 + a]);
+    }
+    g.mn[a] = lo;
+    g.mx[a] = hi;
+  }
+  g.c0x = c[0], g.c0y = c[1], g.c0z = c[2];
+  g.c2x = c[6], g.c2z = c[8];
+  g.c4y = c[13];
+  float cc[24];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) cc[k] = c[k];
+  g.vol = fmaxf((edge_len(cc, 0, 1) * edge_len(cc, 1, 2)) * edge_len(cc, 0, 4), 1e-8f);
+  return g;
+}
+
+// generalized_box3d_iou_tensor with rotated_boxes=False (box_util.py:523-600) for one pair
+__device__ __forceinline__ float giou_pair(const BoxGeo& p, const BoxGeo& g) {
+  const float height = fmaxf(fminf(p.c0y, g.c0y) - fmaxf(p.c4y, g.c4y), 0.f);
+  const float wx = fmaxf(fminf(p.c0x, g.c0x) - fmaxf(p.c2x, g.c2x), 0.f);
+  const float wz = fmaxf(fminf(p.c0z, g.c0z) - fmaxf(p.c2z, g.c2z), 0.f);
+  const float ex = fabsf(fmaxf(p.mx[0], g.mx[0]) - fminf(p.mn[0], g.mn[0]));
+  const float ey = fabsf(fminf(-p.mx[1], -g.mx[1]) - fmaxf(-p.mn[1], -g.mn[1]));
+  const float ez = fabsf(fmaxf(p.mx[2], g.mx[2]) - fminf(p.mn[2], g.mn[2]));
+  const float enclosing = (ex * ey) * ez;
+  const float total = p.vol + g.vol;
+  const float inter = (wx * wz) * height;
+  const float uni = fmaxf(total - inter, 1e-8f);
+  const float giou = inter / uni + (-(1.f - uni / enclosing));
+  return (enclosing > 2e-8f && total > 4e-8f) ? giou : giou * 0.f;
+}
+
+__device__ __forceinline__ float huber1(float e) {
+  const float a = fabsf(e), q = fminf(a, 1.f);
+  return (0.5f * q) * q + (a - q);
+}
+
+// ------------------------------------------------------------------------------------------------ matcher cost
+constexpr int kMatchBoxes = 32;  // ground-truth boxes per workgroup
+
+struct GtDerived {
+  BoxGeo geo;
+  float center[3], size[3];
+  float ares_norm;
+  int label, alabel;
+};
+
+__global__ __launch_bounds__(256) void match_cost_kernel(vdetr_match_desc d) {
+  __shared__ GtDerived sh[kMatchBoxes];
+  const int b = blockIdx.z;
+  const int g0 = blockIdx.y * kMatchBoxes;
+  const int ng = min(kMatchBoxes, d.G - g0);
+  if ((int)threadIdx.x < ng) {
+    const float* r = d.gt + ((size_t)b * d.G + g0 + threadIdx.x) * F;
+    GtDerived& s = sh[threadIdx.x];
+    s.geo = box_geo(r + VDETR_GT_CORNERS);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) s.center[a] = r[VDETR_GT_CENTER + a], s.size[a] = r[VDETR_GT_SIZE + a];
+    s.label = d.label_override >= 0 ? d.label_override : (int)r[VDETR_GT_LABEL];
+    s.alabel = (int)r[VDETR_GT_ANGLE_CLS];
+    s.ares_norm = r[VDETR_GT_ANGLE_RES] / (3.14159265358979323846f / (float)d.A);
+  }
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.P) return;
+  const size_t row = (size_t)b * d.P + p;
+  const BoxGeo pg = box_geo(d.corners + row * 24);
+  float creg[3], sreg[3], pc[3], ps[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    creg[a] = d.center_reg[row * 3 + a], sreg[a] = d.size_reg[row * 3 + a];
+    pc[a] = d.pre_center[row * 3 + a], ps[a] = d.pre_size[row * 3 + a] + 1e-5f;
+  }
+  const float obj = -d.objectness[row];
+  for (int gi = 0; gi < ng; ++gi) {
+    const GtDerived& s = sh[gi];
+    const float giou = giou_pair(pg, s.geo);
+    float center = 0.f, size = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      center += fabsf(creg[a] - (s.center[a] - pc[a]) / ps[a]);
+      size += fabsf(sreg[a] - logf((s.size[a] + 1e-5f) / ps[a]));
+    }
+    float cls;
+    const float x = d.cls[row * d.C + s.label];
+    if (d.cls_kind == VDETR_CLS_SIGMOID) {
+      const float pr = 1.f / (1.f + expf(-x));
+      const float neg = (0.75f * (pr * pr)) * (-logf((1.f - pr) + 1e-8f));
+      const float pos = (0.25f * ((1.f - pr) * (1.f - pr))) * (-logf(pr + 1e-8f));
+      cls = pos - neg;
+    } else {
+      cls = -x;
+    }
+    const float acls = -d.angle_logits[row * d.A + s.alabel];
+    const float areg = huber1(d.angle_res_norm[row * d.A + s.alabel] - s.ares_norm);
+    float cost = d.w_cls * cls + d.w_objectness * obj;
+    cost += d.w_center * center;
+    cost += d.w_giou * (-giou);
+    cost += d.w_size * size;
+    cost += d.w_angle_cls * acls;
+    cost += d.w_angle_reg * areg;
+    const size_t o = ((size_t)b * d.G + g0 + gi) * d.P + p;
+    d.cost_t[o] = cost;
+    if (d.giou_t != nullptr) d.giou_t[o] = (g0 + gi) < (int)d.nactual[b] ? giou : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ assignment
+// fp64 -> u64 whose unsigned order is the numeric order
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+template <int CPT>
+__global__ __launch_bounds__(1024) void lsa_kernel(vdetr_lsa_batch batch, int32_t* __restrict__ status, int nr_cap, int nc_cap) {
+  extern __shared__ unsigned char smem[];
+  int wg = blockIdx.x, k = 0;
+  while (wg >= batch.p[k].B) wg -= batch.p[k++].B;
+  const vdetr_lsa_problem pr = batch.p[k];
+  const int b = wg, P = pr.P, G = pr.G;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  int64_t* inds = pr.inds + (size_t)b * P;
+  float* mask = pr.mask + (size_t)b * P;
+  for (int p = tid; p < P; p += nthr) inds[p] = 0, mask[p] = 0.f;
+  const int n = max(0, min((int)pr.nactual[b], G));
+  if (n == 0) return;
+  // scipy solves a tall matrix transposed (rectangular_lsap.cpp: `transpose = nc < nr`); final_cost[b,:, :n] is P x n
+  const bool transpose = n < P;
+  const int nr = transpose ? n : P, nc = transpose ? P : n;
+  const float* cost = pr.cost_t + (size_t)b * G * P;
+  const long rs = transpose ? P : 1, cs = transpose ? 1 : P;
+
+  double* u = reinterpret_cast<double*>(smem);                                   // [nr_cap]
+  unsigned long long* wkey = reinterpret_cast<unsigned long long*>(u + nr_cap);  // [2][16]
+  unsigned long long* wpay = wkey + 32;                                          // [2][16]
+  int* col4row = reinterpret_cast<int*>(wpay + 32);                              // [nr_cap]
+  int* row4col = col4row + nr_cap;                                               // [nc_cap]
+  int* path = row4col + nc_cap;                                                  // [nc_cap]
+  for (int i = tid; i < nr; i += nthr) u[i] = 0.0, col4row[i] = -1;
+  for (int j = tid; j < nc; j += nthr) row4col[j] = -1, path[j] = -1;
+  double v[CPT], spc[CPT];
+  int pos[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) v[c] = 0.0;
+  __syncthreads();
+
+  bool bad = false;   // this thread saw a NaN / -inf entry (checked for the workgroup once per row)
+  bool stop = false;  // uniform: no finite candidate left (infeasible matrix) or an invalid entry was reported
+  int step = 0;
+  for (int cur = 0; cur < nr; ++cur) {
+    unsigned scmask = 0, freemask = 0;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int j = tid + c * nthr;
+      spc[c] = __longlong_as_double(0x7FF0000000000000ll);
+      pos[c] = nc - 1 - j;
+      if (j < nc && row4col[j] == -1) freemask |= 1u << c;
+    }
+    double min_val = 0.0;
+    int i = cur, remaining = nc, sink = -1;
+    while (true) {
+      const double ui = u[i];
+      unsigned long long bkey = 0ull, bpay = 0ull;  // key inverted: larger = smaller cost; 0 = no candidate
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int j = tid + c * nthr;
+        if (j < nc && !((scmask >> c) & 1u)) {
+          const double cij = (double)cost[i * rs + j * cs];
+          if (!(cij == cij) || cij == -__longlong_as_double(0x7FF0000000000000ll)) bad = true;
+          const double r = ((min_val + cij) - ui) - v[c];
+          if (r < spc[c]) {
+            spc[c] = r;
+            path[j] = i;
+          }
+          const unsigned sec = ((freemask >> c) & 1u) ? (0x80000000u | (unsigned)pos[c]) : (0x7FFFFFFFu - (unsigned)pos[c]);
+          const unsigned long long key = ~f64_key(spc[c]);
+          const unsigned long long pay = ((unsigned long long)sec << 32) | (unsigned)j;
+          if (key > bkey || (key == bkey && pay > bpay)) bkey = key, bpay = pay;
+        }
+      }
+      // lexicographic (cost ascending, tie rank descending) over the wave, then over the waves through LDS
+      const unsigned long long wk = wave_allmax_u64(bkey);
+      const unsigned long long wp = wave_allmax_u64(bkey == wk ? bpay : 0ull);
+      const int buf = (step & 1) * 16;
+      ++step;
+      if (lane == 0) wkey[buf + wave] = wk, wpay[buf + wave] = wp;
+      __syncthreads();
+      unsigned long long gk = 0ull, gp = 0ull;
+      for (int w2 = 0; w2 < nwaves; ++w2) {
+        const unsigned long long k2 = wkey[buf + w2], p2 = wpay[buf + w2];
+        if (k2 > gk || (k2 == gk && p2 > gp)) gk = k2, gp = p2;
+      }
+      min_val = key_f64(~gk);
+      if (gk == 0ull || min_val == __longlong_as_double(0x7FF0000000000000ll)) {  // infeasible: scipy raises ValueError
+        stop = true;
+        break;
+      }
+      const int jstar = (int)(unsigned)gp;
+      const unsigned sec = (unsigned)(gp >> 32);
+      const bool is_free = sec >> 31;
+      const int pstar = is_free ? (int)(sec & 0x7FFFFFFFu) : (int)(0x7FFFFFFFu - sec);
+      --remaining;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int j = tid + c * nthr;
+        if (j == jstar) scmask |= 1u << c;
+        else if (!((scmask >> c) & 1u) && pos[c] == remaining) pos[c] = pstar;  // remaining[index] = remaining[--num_remaining]
+      }
+      if (is_free) {
+        sink = jstar;
+        break;
+      }
+      i = row4col[jstar];
+    }
+    if (stop) break;
+    // dual variables (rows of SR other than cur are the rows assigned to the scanned columns)
+    if (tid == 0) u[cur] += min_val;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int j = tid + c * nthr;
+      if ((scmask >> c) & 1u) {
+        const double dlt = min_val - spc[c];
+        if (j != sink) u[row4col[j]] += dlt;
+        v[c] -= dlt;
+      }
+    }
+    if (__syncthreads_or(bad)) {  // invalid numeric entry: scipy raises ValueError
+      stop = true;
+      break;
+    }
+    if (tid == 0) {  // augment along the path
+      int j = sink;
+      while (true) {
+        const int r = path[j];
+        row4col[j] = r;
+        const int t = col4row[r];
+        col4row[r] = j;
+        j = t;
+        if (r == cur) break;
+      }
+    }
+    __syncthreads();
+  }
+  if (stop) {
+    if (tid == 0 && status != nullptr) status[blockIdx.x] = 1;
+    return;
+  }
+  for (int r = tid; r < nr; r += nthr) {
+    const int c = col4row[r];
+    const int prop = transpose ? c : r, box = transpose ? r : c;
+    inds[prop] = box;
+    mask[prop] = 1.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ seed labels
+__global__ __launch_bounds__(256) void point_labels_kernel(const float* __restrict__ xyz, const float* __restrict__ gt,
+                                                           const int64_t* __restrict__ nactual, int N, int G, int C,
+                                                           int64_t* __restrict__ labels) {
+  const int b = blockIdx.y, nidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nidx >= N) return;
+  const float* p = xyz + ((size_t)b * N + nidx) * 3;
+  const float x = p[0], y = p[1], z = p[2];
+  const int n = max(0, min((int)nactual[b], G));
+  float best = 100.f;  // the appended "no box" column (criterion.py:288)
+  int pick = -1;
+  for (int g = 0; g < n; ++g) {
+    const float* r = gt + ((size_t)b * G + g) * F;
+    const float dx = r[VDETR_GT_SIZE], dy = r[VDETR_GT_SIZE + 1], dz = r[VDETR_GT_SIZE + 2];
+    const float zb = r[VDETR_GT_CENTER + 2] - dz / 2.f;  // bottom centre (criterion.py:277)
+    const float zc = zb + dz / 2.f;
+    if (fabsf(z - zc) > dz / 2.f) continue;
+    const float sx = x - r[VDETR_GT_CENTER], sy = y - r[VDETR_GT_CENTER + 1];
+    const float ang = -r[VDETR_GT_ANGLE];
+    const float ca = cosf(ang), sa = sinf(ang);
+    const float lx = sx * ca - sy * sa, ly = sx * sa + sy * ca;
+    if (!(lx > -dx / 2.f && lx < dx / 2.f && ly > -dy / 2.f && ly < dy / 2.f)) continue;
+    float vol = (dx * dy) * dz;
+    if (vol == 0.f) vol = 1000.f;
+    if (vol < best) best = vol, pick = g;
+  }
+  labels[(size_t)b * N + nidx] = pick >= 0 ? (int64_t)gt[((size_t)b * G + pick) * F + VDETR_GT_LABEL] : (int64_t)C;
+}
+
+// ------------------------------------------------------------------------------------------------ losses + gradients
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_allsum_f32(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// weights of the two arguments' gradients in torch.minimum / maximum(a, b): the smaller (larger) takes it, a tie splits
+__device__ __forceinline__ float take_min(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float take_max(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// d (1 - giou) * scale / d corners of the prediction; returns giou.  dc[24] is overwritten.
+__device__ __forceinline__ float giou_grad(const float* c, const BoxGeo& p, const BoxGeo& g, float scale, float* dc) {
+#pragma unroll
+  for (int k = 0; k < 24; ++k) dc[k] = 0.f;
+  const float top = fminf(p.c0y, g.c0y), bot = fmaxf(p.c4y, g.c4y);
+  const float hraw = top - bot, height = fmaxf(hraw, 0.f);
+  const float wxr = fminf(p.c0x, g.c0x) - fmaxf(p.c2x, g.c2x), wx = fmaxf(wxr, 0.f);
+  const float wzr = fminf(p.c0z, g.c0z) - fmaxf(p.c2z, g.c2z), wz = fmaxf(wzr, 0.f);
+  const float exr = fmaxf(p.mx[0], g.mx[0]) - fminf(p.mn[0], g.mn[0]);
+  const float eyr = fminf(-p.mx[1], -g.mx[1]) - fmaxf(-p.mn[1], -g.mn[1]);
+  const float ezr = fmaxf(p.mx[2], g.mx[2]) - fminf(p.mn[2], g.mn[2]);
+  const float ex = fabsf(exr), ey = fabsf(eyr), ez = fabsf(ezr);
+  const float enclosing = (ex * ey) * ez;
+  const float e01 = edge_len(c, 0, 1), e12 = edge_len(c, 1, 2), e04 = edge_len(c, 0, 4);
+  const float vraw = (e01 * e12) * e04;
+  const float total = p.vol + g.vol;
+  const float area = wx * wz, inter = area * height;
+  const float uraw = total - inter, uni = fmaxf(uraw, 1e-8f);
+  const float giou = inter / uni + (-(1.f - uni / enclosing));
+  const bool good = enclosing > 2e-8f && total > 4e-8f;
+  if (!good) return giou * 0.f;
+  const float s = -scale;                                   // d loss / d giou
+  float d_inter = s / uni;
+  const float d_uni = s * (-inter / (uni * uni) + 1.f / enclosing);
+  const float d_encl = s * (-uni / (enclosing * enclosing));
+  const float d_uraw = uraw >= 1e-8f ? d_uni : 0.f;
+  d_inter -= d_uraw;
+  const float d_vol = vraw >= 1e-8f ? d_uraw : 0.f;
+  // volume: three edges
+  {
+    const float de[3] = {d_vol * e12 * e04, d_vol * e01 * e04, d_vol * e01 * e12};
+    const int ei[3] = {0, 1, 0}, ej[3] = {1, 2, 4};
+    const float el[3] = {e01, e12, e04};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int i = ei[t], j = ej[t];
+      const float dx = c[i * 3] - c[j * 3], dy = c[i * 3 + 1] - c[j * 3 + 1], dz = c[i * 3 + 2] - c[j * 3 + 2];
+      const float sq = (dx * dx + dy * dy) + dz * dz;
+      const float dsq = sq >= 1e-6f ? de[t] * (0.5f / el[t]) : 0.f;
+      dc[i * 3] += 2.f * dx * dsq, dc[i * 3 + 1] += 2.f * dy * dsq, dc[i * 3 + 2] += 2.f * dz * dsq;
+      dc[j * 3] -= 2.f * dx * dsq, dc[j * 3 + 1] -= 2.f * dy * dsq, dc[j * 3 + 2] -= 2.f * dz * dsq;
+    }
+  }
+  // intersection
+  const float d_area = d_inter * height, d_height = d_inter * area;
+  const float d_hraw = hraw >= 0.f ? d_height : 0.f;
+  dc[1] += d_hraw * take_min(p.c0y, g.c0y);        // corner 0, y
+  dc[13] -= d_hraw * take_max(p.c4y, g.c4y);       // corner 4, y
+  const float d_wxr = wxr >= 0.f ? d_area * wz : 0.f;
+  const float d_wzr = wzr >= 0.f ? d_area * wx : 0.f;
+  dc[0] += d_wxr * take_min(p.c0x, g.c0x);         // corner 0, x
+  dc[6] -= d_wxr * take_max(p.c2x, g.c2x);         // corner 2, x
+  dc[2] += d_wzr * take_min(p.c0z, g.c0z);         // corner 0, z
+  dc[8] -= d_wzr * take_max(p.c2z, g.c2z);         // corner 2, z
+  // enclosing box: extremes over the 8 corners (the gradient of max/min(dim) goes to the first extreme index)
+  float d_mx[3], d_mn[3];
+  {
+    const float dex = d_encl * ey * ez * sgn(exr), dey = d_encl * ex * ez * sgn(eyr), dez = d_encl * ex * ey * sgn(ezr);
+    d_mx[0] = dex * take_max(p.mx[0], g.mx[0]);
+    d_mn[0] = -dex * take_min(p.mn[0], g.mn[0]);
+    d_mx[1] = -(dey * take_min(-p.mx[1], -g.mx[1]));
+    d_mn[1] = dey * take_max(-p.mn[1], -g.mn[1]);
+    d_mx[2] = dez * take_max(p.mx[2], g.mx[2]);
+    d_mn[2] = -dez * take_min(p.mn[2], g.mn[2]);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    bool mx_done = false, mn_done = false;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const float val = c[k2 * 3 + a];
+      if (!mx_done && val == p.mx[a]) dc[k2 * 3 + a] += d_mx[a], mx_done = true;
+      if (!mn_done && val == p.mn[a]) dc[k2 * 3 + a] += d_mn[a], mn_done = true;
+    }
+  }
+  return giou;
+}
+
+__global__ __launch_bounds__(1024) void set_loss_kernel(vdetr_setloss_desc d) {
+  __shared__ float red[16][8];
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  long total_boxes = 0;
+  for (int i = 0; i < d.B; ++i) total_boxes += d.nactual[i];
+  const bool gate = total_boxes > 0;
+  const float inv_nb = 1.f / d.num_boxes[0];
+  const bool boxes = d.center_reg != nullptr;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // sem_cls, angle_cls, angle_reg, center, size, giou, object count
+  for (int p = tid; p < d.P; p += nthr) {
+    const size_t row = (size_t)b * d.P + p;
+    // ---- label of this row
+    bool matched = false;
+    int gi = 0, label = d.C;
+    if (d.inds != nullptr) {
+      matched = d.mask[row] != 0.f;
+      gi = (int)d.inds[row];
+      if (matched) label = d.label_override >= 0 ? d.label_override : (int)d.gt[((size_t)b * d.G + gi) * F + VDETR_GT_LABEL];
+    } else {
+      label = (int)d.labels[row];
+    }
+    // ---- focal loss over the C logits (criterion.py:77-98); cardinality arg-max on the way (criterion.py:262-268)
+    {
+      const float* x = d.cls_logits + row * d.C;
+      float* dx = d.d_cls_logits + row * d.C;
+      float best = -INFINITY;
+      int arg = 0;
+      for (int c = 0; c < d.C; ++c) {
+        const float xv = x[c];
+        if (xv > best) best = xv, arg = c;
+        const bool t = c == label;
+        const float pr = 1.f / (1.f + expf(-xv));
+        const float ce = fmaxf(xv, 0.f) - (t ? xv : 0.f) + log1pf(expf(-fabsf(xv)));
+        const float one_m_pt = t ? 1.f - pr : pr;
+        const float at = t ? d.focal_alpha : 1.f - d.focal_alpha;
+        const float mod = one_m_pt * one_m_pt;
+        acc[0] += at * (ce * mod);
+        const float dpt = t ? pr * (1.f - pr) : -(pr * (1.f - pr));
+        const float g = at * ((pr - (t ? 1.f : 0.f)) * mod - ce * (2.f * one_m_pt) * dpt);
+        dx[c] = gate ? g * (d.w_cls * inv_nb) : 0.f;
+      }
+      acc[6] += arg != d.C - 1 ? 1.f : 0.f;
+    }
+    if (!boxes) continue;
+    // ---- box terms of the matched pair
+    float d_creg[3] = {0.f, 0.f, 0.f}, d_sreg[3] = {0.f, 0.f, 0.f};
+    float dc[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) dc[k] = 0.f;
+    int alabel = 0;
+    float g_acls = 0.f, g_areg = 0.f;
+    if (matched && gate) {
+      const float* r = d.gt + ((size_t)b * d.G + gi) * F;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float ps = d.pre_size[row * 3 + a] + 1e-5f;
+        const float ec = d.center_reg[row * 3 + a] - (r[VDETR_GT_CENTER + a] - d.pre_center[row * 3 + a]) / ps;
+        acc[3] += fabsf(ec);
+        d_creg[a] = sgn(ec) * (d.w_center * inv_nb);
+        const float es = d.size_reg[row * 3 + a] - logf((r[VDETR_GT_SIZE + a] + 1e-5f) / ps);
+        acc[4] += fabsf(es);
+        d_sreg[a] = sgn(es) * (d.w_size * inv_nb);
+      }
+      float c[24];
+#pragma unroll
+      for (int k = 0; k < 24; ++k) c[k] = d.corners[row * 24 + k];
+      const BoxGeo pg = box_geo(c), gg = box_geo(r + VDETR_GT_CORNERS);
+      const float giou = gi < (int)d.nactual[b] ? giou_grad(c, pg, gg, d.w_giou * inv_nb, dc) : 0.f;
+      acc[5] += 1.f - giou;
+      alabel = (int)r[VDETR_GT_ANGLE_CLS];
+      const float e = d.angle_res_norm[row * d.A + alabel] - r[VDETR_GT_ANGLE_RES] / (3.14159265358979323846f / (float)d.A);
+      acc[2] += huber1(e);
+      g_areg = fmaxf(-1.f, fminf(e, 1.f)) * (d.w_angle_reg * inv_nb);
+      // cross entropy over the angle bins
+      const float* al = d.angle_logits + row * d.A;
+      float m = al[0];
+      for (int a = 1; a < d.A; ++a) m = fmaxf(m, al[a]);
+      float se = 0.f;
+      for (int a = 0; a < d.A; ++a) se += expf(al[a] - m);
+      const float lse = m + logf(se);
+      acc[1] += lse - al[alabel];
+      g_acls = d.w_angle_cls * inv_nb;
+      for (int a = 0; a < d.A; ++a)
+        d.d_angle_logits[row * d.A + a] = (expf(al[a] - lse) - (a == alabel ? 1.f : 0.f)) * g_acls;
+    } else {
+      for (int a = 0; a < d.A; ++a) d.d_angle_logits[row * d.A + a] = 0.f;
+    }
+    for (int a = 0; a < d.A; ++a) d.d_angle_res_norm[row * d.A + a] = (matched && gate && a == alabel) ? g_areg : 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d.d_center_reg[row * 3 + a] = d_creg[a], d.d_size_reg[row * 3 + a] = d_sreg[a];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) d.d_corners[row * 24 + k] = dc[k];
+  }
+  // ---- workgroup sums -> one atomic per component
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const float s = wave_sum(acc[t]);
+    if (lane == 0) red[wave][t] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s[7];
+    for (int t = 0; t < 7; ++t) {
+      s[t] = 0.f;
+      for (int w2 = 0; w2 < nwaves; ++w2) s[t] += red[w2][t];
+    }
+    const float w[6] = {d.w_cls, d.w_angle_cls, d.w_angle_reg, d.w_center, d.w_size, d.w_giou};
+    float tot = 0.f;
+    for (int t = 0; t < 6; ++t) {
+      const float val = gate ? s[t] * inv_nb * w[t] : 0.f;
+      if (w[t] > 0.f) tot += val;
+      atomicAdd(d.losses + t, val);
+    }
+    atomicAdd(d.losses + 6, fabsf(s[6] - (float)d.nactual[b]) / (float)d.B);
+    atomicAdd(d.losses + 7, tot);
+  }
+}
+
+}  // namespace
+}  // namespace vdetr
+
+using namespace vdetr;
+
+extern "C" int vdetr_gt_prepare_f32(const float* gt, int B, int G, int repeat, float* gt_rep, int64_t* nactual,
+                                    int64_t* nactual_rep, float* sums, vdetr_stream_t stream) {
+  VDETR_REQUIRE(gt && nactual && sums, "gt_prepare: null pointer");
+  VDETR_REQUIRE(B >= 1 && G >= 1 && G <= 8192 && repeat >= 1, "gt_prepare: bad sizes B=%d G=%d repeat=%d", B, G, repeat);
+  hipLaunchKernelGGL(gt_prepare_kernel, dim3(1), dim3(256), (G + 1) * sizeof(int), (hipStream_t)stream, gt, B, G, repeat, gt_rep,
+                     nactual, nactual_rep, sums);
+  return check_launch("gt_prepare");
+}
+
+extern "C" int vdetr_match_cost_f32(const vdetr_match_desc* d, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr, "match_cost: null descriptor");
+  VDETR_REQUIRE(d->B >= 1 && d->P >= 1 && d->G >= 1 && d->C >= 1 && d->A >= 1, "match_cost: bad sizes");
+  VDETR_REQUIRE(d->cls && d->objectness && d->center_reg && d->size_reg && d->pre_center && d->pre_size && d->corners &&
+                    d->angle_logits && d->angle_res_norm && d->gt && d->nactual && d->cost_t,
+                "match_cost: null pointer");
+  VDETR_REQUIRE(d->label_override < d->C, "match_cost: label_override %d >= C %d", d->label_override, d->C);
+  const dim3 grid(ceil_div(d->P, 256), ceil_div(d->G, kMatchBoxes), d->B);
+  hipLaunchKernelGGL(match_cost_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
+  return check_launch("match_cost");
+}
+
+extern "C" int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdetr_stream_t stream) {
+  VDETR_REQUIRE(batch != nullptr && batch->nproblems >= 1 && batch->nproblems <= VDETR_LSA_MAX_PROBLEMS,
+                "lsa: 1..%d problems per launch", VDETR_LSA_MAX_PROBLEMS);
+  int nr_cap = 1, nc_cap = 1, wgs = 0;
+  vdetr_lsa_batch padded = *batch;
+  for (int k = 0; k < VDETR_LSA_MAX_PROBLEMS; ++k) {
+    if (k >= batch->nproblems) {
+      padded.p[k] = vdetr_lsa_problem{};
+      padded.p[k].B = 1 << 30;  // terminates the workgroup -> problem search
+      continue;
+    }
+    const vdetr_lsa_problem& p = batch->p[k];
+    VDETR_REQUIRE(p.cost_t && p.nactual && p.inds && p.mask, "lsa: null pointer in problem %d", k);
+    VDETR_REQUIRE(p.B >= 1 && p.P >= 1 && p.G >= 1, "lsa: bad sizes in problem %d", k);
+    const int lo = p.P < p.G ? p.P : p.G, hi = p.P < p.G ? p.G : p.P;
+    VDETR_REQUIRE(hi <= 8192 && lo <= 2048, "lsa: problem %d is %d x %d; limits are 8192 columns, 2048 rows", k, p.P, p.G);
+    nr_cap = lo > nr_cap ? lo : nr_cap;
+    nc_cap = hi > nc_cap ? hi : nc_cap;
+    wgs += p.B;
+  }
+  int threads = ((nc_cap + 63) / 64) * 64;
+  threads = threads > 1024 ? 1024 : threads;
+  const int cpt = (nc_cap + threads - 1) / threads;
+  const size_t lds = (size_t)nr_cap * 8 + 64 * 8 + (size_t)nr_cap * 4 + (size_t)nc_cap * 8;
+  int rc;
+#define VDETR_LSA_LAUNCH(CPT)                                                                                        \
+  rc = set_lds(lsa_kernel<CPT>, lds, "lsa");                                                                         \
+  if (rc != VDETR_OK) return rc;                                                                                     \
+  hipLaunchKernelGGL(lsa_kernel<CPT>, dim3(wgs), dim3(threads), lds, (hipStream_t)stream, padded, status, nr_cap, nc_cap)
+  if (cpt == 1) {
+    VDETR_LSA_LAUNCH(1);
+  } else if (cpt == 2) {
+    VDETR_LSA_LAUNCH(2);
+  } else if (cpt <= 4) {
+    VDETR_LSA_LAUNCH(4);
+  } else {
+    VDETR_LSA_LAUNCH(8);
+  }
+#undef VDETR_LSA_LAUNCH
+  return check_launch("lsa");
+}
+
+extern "C" int vdetr_point_labels_f32(const float* seed_xyz, const float* gt, const int64_t* nactual, int B, int N, int G,
+                                      int C, int64_t* labels, vdetr_stream_t stream) {
+  VDETR_REQUIRE(seed_xyz && gt && nactual && labels, "point_labels: null pointer");
+  VDETR_REQUIRE(B >= 1 && N >= 1 && G >= 1 && C >= 1, "point_labels: bad sizes");
+  hipLaunchKernelGGL(point_labels_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0, (hipStream_t)stream, seed_xyz, gt, nactual, N,
+                     G, C, labels);
+  return check_launch("point_labels");
+}
+
+extern "C" int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr, "set_loss: null descriptor");
+  VDETR_REQUIRE(d->B >= 1 && d->P >= 1 && d->C >= 1, "set_loss: bad sizes");
+  VDETR_REQUIRE(d->cls_logits && d->d_cls_logits && d->nactual && d->num_boxes && d->losses, "set_loss: null pointer");
+  VDETR_REQUIRE((d->inds != nullptr && d->mask != nullptr && d->gt != nullptr) || d->labels != nullptr,
+                "set_loss: need (inds, mask, gt) or labels");
+  if (d->center_reg != nullptr) {
+    VDETR_REQUIRE(d->size_reg && d->pre_center && d->pre_size && d->corners && d->angle_logits && d->angle_res_norm && d->gt &&
+                      d->inds && d->mask && d->d_center_reg && d->d_size_reg && d->d_corners && d->d_angle_logits &&
+                      d->d_angle_res_norm && d->A >= 1 && d->G >= 1,
+                  "set_loss: box terms need all box pointers");
+  }
+  int threads = ((d->P + 63) / 64) * 64;
+  threads = threads > 1024 ? 1024 : threads;
+  hipLaunchKernelGGL(set_loss_kernel, dim3(d->B), dim3(threads), 0, (hipStream_t)stream, *d);
+  return check_launch("set_loss");
+}
