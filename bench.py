@@ -75,6 +75,25 @@ def make_inputs(cfg_name, device, rank):
             "point_cloud_dims_min": stacked.min(1)[0], "point_cloud_dims_max": stacked.max(1)[0]}
 
 
+def make_targets(cfg_name, device, rank, boxes_per_scene=24):
+    """Synthetic ground truth with the keys / shapes of the reference loader (datasets/scannet.py:592-625): 64 box slots,
+    `boxes_per_scene` axis-aligned boxes inside the room, random classes."""
+    from vdetr_amd.dataset_config import ScannetDatasetConfig
+    npts, bs, *_ = CONFIGS[cfg_name]
+    cfg = ScannetDatasetConfig()
+    g = torch.Generator().manual_seed(7000 + rank)
+    G = cfg.max_num_obj
+    present = torch.zeros((bs, G))
+    present[:, :boxes_per_scene] = 1
+    centers = (torch.rand((bs, G, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0]) + 1.0) * present[..., None]
+    sizes = (0.3 + torch.rand((bs, G, 3), generator=g) * 1.7) * present[..., None]
+    corners = cfg.box_parametrization_to_corners(centers, sizes, torch.zeros((bs, G))) * present[..., None, None]
+    t = {"gt_box_corners": corners, "gt_box_centers": centers, "gt_box_sizes": sizes, "gt_box_angles": torch.zeros((bs, G)),
+         "gt_box_sem_cls_label": torch.randint(0, 10, (bs, G), generator=g) * present.long(), "gt_box_present": present,
+         "gt_angle_class_label": torch.zeros((bs, G), dtype=torch.int64), "gt_angle_residual_label": torch.zeros((bs, G))}
+    return {k: v.to(device) for k, v in t.items()}
+
+
 def loss_fn(out):
     """synthetic scalar loss of SURVEY.md §8d: sum over the 9 stages of sem_cls_logits + centre + size"""
     return sum(o["sem_cls_logits"].sum() + o["center_normalized"].sum() + o["size_normalized"].sum()
@@ -84,9 +103,13 @@ def loss_fn(out):
 class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
-    def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True):
+    def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True, criterion=None, targets=None):
         from vdetr_amd.dist import FlatParams, GradientReducer
         self.model, self.inputs, self.world = model, inputs, world
+        # criterion=None: the synthetic scalar loss of SURVEY.md §8d (the headline metric); otherwise the device set
+        # criterion (v-detr_amd/criterion.py) on `targets`, prepared once: their box counts do not depend on the model
+        self.criterion = criterion
+        self.targets = criterion.prepare_targets(targets) if criterion is not None else None
         self.params = [p for p in model.parameters() if p.requires_grad]
         # parameters / gradients as views of two flat buffers: one AdamW launch, one norm, slice-shaped buckets
         self.flat = FlatParams(self.params, groups=model.flat_param_groups())
@@ -117,7 +140,8 @@ class Trainer:
             with torch.cuda.stream(self.side):
                 next_inds = self.model.sample_indices(self.inputs)  # (the synthetic bench feeds the same scene again)
             self.inputs["fps_inds"] = self.cur_inds
-        self.loss = loss_fn(self.model(self.inputs))
+        out = self.model(self.inputs)
+        self.loss = loss_fn(out) if self.criterion is None else self.criterion(out, self.targets)[0]
         self.loss.backward()
         if not self.hooked:
             self.flat.pack_grads()  # one launch; (hooked eager mode accumulates straight into the flat buffer)
@@ -328,6 +352,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm as in main.py:512-514 (implies --no-graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss", default="synthetic", choices=["synthetic", "criterion"],
+                    help="synthetic: scalar loss of SURVEY 8d (headline); criterion: the device set criterion on synthetic boxes")
+    ap.add_argument("--no-criterion-leg", action="store_true", help="skip the extra N=1 measurement with the set criterion")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library heuristics instead of per-shape tuned GEMM solutions")
@@ -358,7 +385,16 @@ def main():
         if a.sync_bn:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     inputs = make_inputs(a.config, device, rank)
-    trainer = Trainer(model, inputs, world, use_graph, overlap=True, fps_prefetch=not a.no_fps_prefetch)
+    def make_trainer(with_criterion):
+        crit = targets = None
+        if with_criterion:
+            from vdetr_amd.criterion import build_criterion, default_criterion_args
+            crit = build_criterion(default_criterion_args(), model.dataset_config)
+            targets = make_targets(a.config, device, rank)
+        return Trainer(model, inputs, world, use_graph, overlap=True, fps_prefetch=not a.no_fps_prefetch, criterion=crit,
+                       targets=targets)
+
+    trainer = make_trainer(a.loss == "criterion")
     graph_ok = False
     if use_graph:
         try:
@@ -419,6 +455,25 @@ def main():
             result["roofline_secondary"] = other
         if not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(a.config)
+        if world == 1 and a.loss == "synthetic" and not a.no_criterion_leg:
+            # the same step with the reference's real loss: matcher + Hungarian + losses on the device
+            del trainer
+            t2 = make_trainer(True)
+            if use_graph:
+                t2.capture()
+            for _ in range(3):
+                t2.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                t2.step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / a.steps * 1e3
+            closs = float(t2.loss.item())
+            assert np.isfinite(closs), "non-finite criterion loss"
+            result["criterion"] = {"ms_per_step": ms, "scenes_per_s": bs / ms * 1e3, "added_ms": ms - result["ms_per_step"],
+                                   "loss": closs, "note": "same step with the set criterion (focal + L1 + GIoU on Hungarian "
+                                   "matches, 9 stages, 24 boxes/scene x repeat 5) instead of the synthetic scalar loss"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -382,8 +382,9 @@ int vdetr_match_cost_f32(const vdetr_match_desc* d, vdetr_stream_t stream);
  * (rectangular_lsap.cpp of scipy 1.5.1, requirements.txt:9) restated in fp64 with its traversal order and tie rules, so
  * the result is the one linear_sum_assignment(final_cost[b, :, :nactual[b]]) returns.  Writes per_prop_gt_inds and
  * proposal_matched_mask (criterion.py:200-221), zero where unmatched.  Limits: max(P, G) <= 8192, min(P, G) <= 2048.
- * status[w] (optional, zero-filled by the caller; w counts the (problem, scene) pairs in order) is set to 1 if a cost is
- * NaN/-inf or the matrix is infeasible (scipy raises ValueError there); that scene's outputs stay zero. */
+ * status (optional, 2 ints per (problem, scene) pair w in launch order, zero-filled by the caller): status[2w] is set to 1
+ * if a cost is NaN/-inf or the matrix is infeasible (scipy raises ValueError there; that scene's outputs stay zero);
+ * status[2w+1] receives the number of row scans the solve took (diagnostic). */
 #define VDETR_LSA_MAX_PROBLEMS 16
 typedef struct vdetr_lsa_problem {
   const float* cost_t;    /* [B,G,P] */
@@ -424,6 +425,7 @@ typedef struct vdetr_setloss_desc {
   /* outputs.  losses[0..7] += {sem_cls, angle_cls, angle_reg, center, size, giou, cardinality, weighted total}
      (the six losses already multiplied by their weights, as loss_dict holds them: criterion.py:648-651). */
   float* losses;
+  unsigned long long* card_ws; /* [B] zero-initialised scratch of the cardinality count (one 64-bit atomic per workgroup) */
   float *d_cls_logits, *d_center_reg, *d_size_reg, *d_corners, *d_angle_logits, *d_angle_res_norm; /* d total / d input; written in full */
 } vdetr_setloss_desc;
 int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream);

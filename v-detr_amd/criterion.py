@@ -120,8 +120,9 @@ class Matcher(nn.Module):
         return keep["cost_t"], keep["giou_t"]
 
     @staticmethod
-    def solve(problems):
-        """problems: list of (cost_t [B,G,P], nactual [B]).  One launch per 16 problems.  Returns [(inds, mask)]."""
+    def solve(problems, status=None):
+        """problems: list of (cost_t [B,G,P], nactual [B]).  One launch per 16 problems.  Returns [(inds, mask)].
+        ``status``: optional zero-filled int32 [sum B, 2] (<= 16 problems) -> (invalid flag, row scans) per scene."""
         out = []
         for s in range(0, len(problems), L.VDETR_LSA_MAX_PROBLEMS):
             chunk = problems[s:s + L.VDETR_LSA_MAX_PROBLEMS]
@@ -135,7 +136,7 @@ class Matcher(nn.Module):
                 pr.cost_t, pr.nactual, pr.inds, pr.mask = cost_t.data_ptr(), nactual.data_ptr(), inds.data_ptr(), mask.data_ptr()
                 pr.B, pr.P, pr.G = B, P, G
                 out.append((inds, mask))
-            L.check(L.lib().vdetr_lsa_f64(ctypes.byref(batch), None, L.stream_ptr()), "lsa")
+            L.check(L.lib().vdetr_lsa_f64(ctypes.byref(batch), L.ptr(status), L.stream_ptr()), "lsa")
         return out
 
     @torch.no_grad()
@@ -163,7 +164,9 @@ class _CriterionFn(torch.autograd.Function):
     def forward(ctx, crit, prep, stages, point, *diff):
         dev = diff[0].device
         ns = len(stages)
-        losses = torch.zeros((ns + 1, 8), dtype=torch.float32, device=dev)
+        B0 = diff[0].shape[0]
+        # per stage: 8 loss slots + B 64-bit cardinality tickets (kept in the same zero-filled allocation)
+        losses = torch.zeros((ns + 1, 8 + 2 * B0), dtype=torch.float32, device=dev)
         sizes = [t.numel() for t in diff]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
         grads, off = [], 0
@@ -200,6 +203,7 @@ class _CriterionFn(torch.autograd.Function):
             d.gt, d.nactual, d.inds, d.mask, d.labels = records.data_ptr(), nactual.data_ptr(), inds.data_ptr(), mask.data_ptr(), None
             d.num_boxes = nb.data_ptr()
             d.losses = losses[si].data_ptr()
+            d.card_ws = losses[si].data_ptr() + 32
             (d.d_cls_logits, d.d_center_reg, d.d_size_reg, d.d_corners, d.d_angle_logits,
              d.d_angle_res_norm) = (t.data_ptr() for t in g)
             L.check(lib.vdetr_set_loss_f32(ctypes.byref(d), st), "set_loss")
@@ -219,6 +223,7 @@ class _CriterionFn(torch.autograd.Function):
             d.w_cls = crit.args.point_cls_loss_weight
             d.cls_logits, d.labels, d.nactual, d.num_boxes = logits.data_ptr(), point_labels.data_ptr(), nactual.data_ptr(), nb.data_ptr()
             d.losses, d.d_cls_logits = losses[ns].data_ptr(), grads[-1].data_ptr()
+            d.card_ws = losses[ns].data_ptr() + 32
             L.check(lib.vdetr_set_loss_f32(ctypes.byref(d), st), "set_loss(point_cls)")
         total = losses[:, 7].sum()
         ctx.flat, ctx.grads = flat, grads

@@ -123,7 +123,7 @@ __device__ __forceinline__ float huber1(float e) {
 }
 
 // ------------------------------------------------------------------------------------------------ matcher cost
-constexpr int kMatchBoxes = 32;  // ground-truth boxes per workgroup
+constexpr int kMatchBoxes = 16;  // ground-truth boxes per workgroup
 
 struct GtDerived {
   BoxGeo geo;
@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void match_cost_kernel(vdetr_match_desc d) {
     pc[a] = d.pre_center[row * 3 + a], ps[a] = d.pre_size[row * 3 + a] + 1e-5f;
   }
   const float obj = -d.objectness[row];
+  const int nact = (int)d.nactual[b];
+  const float* __restrict__ cls_row = d.cls + row * d.C;
+  const float* __restrict__ al_row = d.angle_logits + row * d.A;
+  const float* __restrict__ ar_row = d.angle_res_norm + row * d.A;
+  float* __restrict__ cost_out = d.cost_t;
+  float* __restrict__ giou_out = d.giou_t;
+#pragma unroll 4
   for (int gi = 0; gi < ng; ++gi) {
     const GtDerived& s = sh[gi];
     const float giou = giou_pair(pg, s.geo);
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void match_cost_kernel(vdetr_match_desc d) {
       size += fabsf(sreg[a] - logf((s.size[a] + 1e-5f) / ps[a]));
     }
     float cls;
-    const float x = d.cls[row * d.C + s.label];
+    const float x = cls_row[s.label];
     if (d.cls_kind == VDETR_CLS_SIGMOID) {
       const float pr = 1.f / (1.f + expf(-x));
       const float neg = (0.75f * (pr * pr)) * (-logf((1.f - pr) + 1e-8f));
@@ -178,8 +185,8 @@ __global__ __launch_bounds__(256) void match_cost_kernel(vdetr_match_desc d) {
     } else {
       cls = -x;
     }
-    const float acls = -d.angle_logits[row * d.A + s.alabel];
-    const float areg = huber1(d.angle_res_norm[row * d.A + s.alabel] - s.ares_norm);
+    const float acls = -al_row[s.alabel];
+    const float areg = huber1(ar_row[s.alabel] - s.ares_norm);
     float cost = d.w_cls * cls + d.w_objectness * obj;
     cost += d.w_center * center;
     cost += d.w_giou * (-giou);
@@ -187,8 +194,8 @@ __global__ __launch_bounds__(256) void match_cost_kernel(vdetr_match_desc d) {
     cost += d.w_angle_cls * acls;
     cost += d.w_angle_reg * areg;
     const size_t o = ((size_t)b * d.G + g0 + gi) * d.P + p;
-    d.cost_t[o] = cost;
-    if (d.giou_t != nullptr) d.giou_t[o] = (g0 + gi) < (int)d.nactual[b] ? giou : 0.f;
+    cost_out[o] = cost;
+    if (giou_out != nullptr) giou_out[o] = (g0 + gi) < nact ? giou : 0.f;
   }
 }
 
@@ -203,87 +210,148 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
   return __longlong_as_double((long long)u);
 }
 
+// One workgroup per problem.  Lane t owns columns t, t+T, ... (<= CPT of them) with their dual variable, shortest-path
+// cost and position in scipy's `remaining` array in registers; T = 256 threads when the problem's columns fit (4 waves, one
+// per SIMD: the cheapest barrier), otherwise the whole 1024-thread workgroup (the surplus waves of a small problem exit
+// before the first barrier).  A scan step = one row of the cost matrix (coalesced, L2-resident after the warm-up pass), one
+// lexicographic arg-min over the workgroup (DPP inside the wave, one LDS slot per wave + one barrier across waves), one
+// LDS lookup of the row assigned to the winning column.
+constexpr int kLsaSmall = 256, kLsaLarge = 1024;
+
 template <int CPT>
-__global__ __launch_bounds__(1024) void lsa_kernel(vdetr_lsa_batch batch, int32_t* __restrict__ status, int nr_cap, int nc_cap) {
+__global__ __launch_bounds__(kLsaLarge) void lsa_kernel(vdetr_lsa_batch batch, int32_t* __restrict__ status, int nr_cap,
+                                                        int nc_cap) {
   extern __shared__ unsigned char smem[];
   int wg = blockIdx.x, k = 0;
   while (wg >= batch.p[k].B) wg -= batch.p[k++].B;
   const vdetr_lsa_problem pr = batch.p[k];
   const int b = wg, P = pr.P, G = pr.G;
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-  int64_t* inds = pr.inds + (size_t)b * P;
-  float* mask = pr.mask + (size_t)b * P;
-  for (int p = tid; p < P; p += nthr) inds[p] = 0, mask[p] = 0.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = max(0, min((int)pr.nactual[b], G));
-  if (n == 0) return;
   // scipy solves a tall matrix transposed (rectangular_lsap.cpp: `transpose = nc < nr`); final_cost[b,:, :n] is P x n
   const bool transpose = n < P;
   const int nr = transpose ? n : P, nc = transpose ? P : n;
-  const float* cost = pr.cost_t + (size_t)b * G * P;
+  const int nthr = nc <= kLsaSmall * CPT ? min(kLsaSmall, (int)blockDim.x) : (int)blockDim.x;
+  if (tid >= nthr) return;  // before any barrier: s_barrier only counts the waves still alive
+  const int nwaves = nthr >> 6;
+  int64_t* inds = pr.inds + (size_t)b * P;
+  float* mask = pr.mask + (size_t)b * P;
+  for (int p = tid; p < P; p += nthr) inds[p] = 0, mask[p] = 0.f;
+  if (n == 0) return;
+  const float* __restrict__ cost = pr.cost_t + (size_t)b * G * P;
   const long rs = transpose ? P : 1, cs = transpose ? 1 : P;
 
   double* u = reinterpret_cast<double*>(smem);                                   // [nr_cap]
-  unsigned long long* wkey = reinterpret_cast<unsigned long long*>(u + nr_cap);  // [2][16]
-  unsigned long long* wpay = wkey + 32;                                          // [2][16]
-  int* col4row = reinterpret_cast<int*>(wpay + 32);                              // [nr_cap]
+  unsigned long long* wslot = reinterpret_cast<unsigned long long*>(u + nr_cap);  // [2][16] x {key, payload}
+  int* col4row = reinterpret_cast<int*>(wslot + 64);                              // [nr_cap]
   int* row4col = col4row + nr_cap;                                               // [nc_cap]
   int* path = row4col + nc_cap;                                                  // [nc_cap]
   for (int i = tid; i < nr; i += nthr) u[i] = 0.0, col4row[i] = -1;
   for (int j = tid; j < nc; j += nthr) row4col[j] = -1, path[j] = -1;
+  const double kInf = __longlong_as_double(0x7FF0000000000000ll);
   double v[CPT], spc[CPT];
   int pos[CPT];
+  long off[CPT];      // element offset of this lane's columns inside a row
+  unsigned valid = 0; // bit c: column c of this lane exists
+  bool bad = false;   // this thread saw a NaN / -inf entry
 #pragma unroll
-  for (int c = 0; c < CPT; ++c) v[c] = 0.0;
-  __syncthreads();
+  for (int c = 0; c < CPT; ++c) {
+    const int j = tid + c * nthr;
+    v[c] = 0.0;
+    off[c] = (long)j * cs;
+    if (j < nc) valid |= 1u << c;
+  }
+  // warm-up: every row is scanned several times; pull the matrix into this XCD's L2 once, and validate it on the way
+  for (int r = 0; r < nr; ++r) {
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      if ((valid >> c) & 1u) {
+        const float cij = cost[r * rs + off[c]];
+        if (!(cij == cij) || cij == -INFINITY) bad = true;
+      }
+    }
+  }
+  if (__syncthreads_or(bad)) {  // invalid numeric entries: scipy raises ValueError
+    if (tid == 0 && status != nullptr) status[2 * blockIdx.x] = 1;
+    return;
+  }
 
-  bool bad = false;   // this thread saw a NaN / -inf entry (checked for the workgroup once per row)
-  bool stop = false;  // uniform: no finite candidate left (infeasible matrix) or an invalid entry was reported
+  bool stop = false;  // uniform: no finite candidate left (infeasible matrix)
   int step = 0;
   for (int cur = 0; cur < nr; ++cur) {
-    unsigned scmask = 0, freemask = 0;
+    unsigned live = valid, freemask = 0;  // live: not yet scanned (not in SC)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int j = tid + c * nthr;
-      spc[c] = __longlong_as_double(0x7FF0000000000000ll);
+      spc[c] = kInf;
       pos[c] = nc - 1 - j;
-      if (j < nc && row4col[j] == -1) freemask |= 1u << c;
+      if (((valid >> c) & 1u) && row4col[j] == -1) freemask |= 1u << c;
     }
     double min_val = 0.0;
     int i = cur, remaining = nc, sink = -1;
+    float cij[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) cij[c] = ((live >> c) & 1u) ? cost[i * rs + off[c]] : 0.f;
     while (true) {
       const double ui = u[i];
-      unsigned long long bkey = 0ull, bpay = 0ull;  // key inverted: larger = smaller cost; 0 = no candidate
+      // pass 1: relax this lane's columns with row i, keep the smallest shortest-path cost
+      double bval = kInf;
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
-        const int j = tid + c * nthr;
-        if (j < nc && !((scmask >> c) & 1u)) {
-          const double cij = (double)cost[i * rs + j * cs];
-          if (!(cij == cij) || cij == -__longlong_as_double(0x7FF0000000000000ll)) bad = true;
-          const double r = ((min_val + cij) - ui) - v[c];
+        if ((live >> c) & 1u) {
+          const double r = ((min_val + (double)cij[c]) - ui) - v[c];
           if (r < spc[c]) {
             spc[c] = r;
-            path[j] = i;
+            path[tid + c * nthr] = i;
           }
-          const unsigned sec = ((freemask >> c) & 1u) ? (0x80000000u | (unsigned)pos[c]) : (0x7FFFFFFFu - (unsigned)pos[c]);
-          const unsigned long long key = ~f64_key(spc[c]);
-          const unsigned long long pay = ((unsigned long long)sec << 32) | (unsigned)j;
-          if (key > bkey || (key == bkey && pay > bpay)) bkey = key, bpay = pay;
+          bval = fmin(bval, spc[c]);
         }
       }
-      // lexicographic (cost ascending, tie rank descending) over the wave, then over the waves through LDS
+      // wave minimum (key inverted: larger = smaller cost; 0 = no candidate)
+      const unsigned long long bkey = live ? ~f64_key(bval) : 0ull;
       const unsigned long long wk = wave_allmax_u64(bkey);
-      const unsigned long long wp = wave_allmax_u64(bkey == wk ? bpay : 0ull);
-      const int buf = (step & 1) * 16;
+      // pass 2: only the lanes holding the wave minimum rank their tied columns (scipy's tie rule as a sort key:
+      // an unassigned column beats an assigned one; among unassigned the LAST in `remaining` order, else the FIRST)
+      unsigned long long bpay = 0ull;
+      if (bkey == wk && live) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          if (((live >> c) & 1u) && spc[c] == bval) {
+            const unsigned sec = ((freemask >> c) & 1u) ? (0x80000000u | (unsigned)pos[c]) : (0x7FFFFFFFu - (unsigned)pos[c]);
+            const unsigned long long pay = ((unsigned long long)sec << 32) | (unsigned)(tid + c * nthr);
+            bpay = pay > bpay ? pay : bpay;
+          }
+        }
+      }
+      const unsigned long long owners = __ballot(bpay != 0ull);
+      unsigned long long wp;
+      if (__popcll(owners) == 1) {  // the common case: no tie inside the wave
+        const int src = __ffsll((long long)owners) - 1;
+        wp = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(bpay >> 32), src) << 32) |
+             (unsigned)__builtin_amdgcn_readlane((int)bpay, src);
+      } else {
+        wp = wave_allmax_u64(bpay);
+      }
+      const int buf = (step & 1) * 32;
       ++step;
-      if (lane == 0) wkey[buf + wave] = wk, wpay[buf + wave] = wp;
+      if (lane == 0) wslot[buf + 2 * wave] = wk, wslot[buf + 2 * wave + 1] = wp;
       __syncthreads();
       unsigned long long gk = 0ull, gp = 0ull;
-      for (int w2 = 0; w2 < nwaves; ++w2) {
-        const unsigned long long k2 = wkey[buf + w2], p2 = wpay[buf + w2];
-        if (k2 > gk || (k2 == gk && p2 > gp)) gk = k2, gp = p2;
+      if (nwaves == 4) {  // independent LDS reads: one latency
+        unsigned long long kk[4], pp[4];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) kk[w2] = wslot[buf + 2 * w2], pp[w2] = wslot[buf + 2 * w2 + 1];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2)
+          if (kk[w2] > gk || (kk[w2] == gk && pp[w2] > gp)) gk = kk[w2], gp = pp[w2];
+      } else {
+        for (int w2 = 0; w2 < nwaves; ++w2) {
+          const unsigned long long k2 = wslot[buf + 2 * w2], p2 = wslot[buf + 2 * w2 + 1];
+          if (k2 > gk || (k2 == gk && p2 > gp)) gk = k2, gp = p2;
+        }
       }
       min_val = key_f64(~gk);
-      if (gk == 0ull || min_val == __longlong_as_double(0x7FF0000000000000ll)) {  // infeasible: scipy raises ValueError
+      if (gk == 0ull || min_val == kInf) {  // infeasible: scipy raises ValueError
         stop = true;
         break;
       }
@@ -293,33 +361,34 @@ __global__ __launch_bounds__(1024) void lsa_kernel(vdetr_lsa_batch batch, int32_
       const int pstar = is_free ? (int)(sec & 0x7FFFFFFFu) : (int)(0x7FFFFFFFu - sec);
       --remaining;
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) {
-        const int j = tid + c * nthr;
-        if (j == jstar) scmask |= 1u << c;
-        else if (!((scmask >> c) & 1u) && pos[c] == remaining) pos[c] = pstar;  // remaining[index] = remaining[--num_remaining]
-      }
+      for (int c = 0; c < CPT; ++c)
+        if (tid + c * nthr == jstar) live &= ~(1u << c);
       if (is_free) {
         sink = jstar;
         break;
       }
       i = row4col[jstar];
+      // the next row's entries are requested before the bookkeeping below
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) cij[c] = ((live >> c) & 1u) ? cost[i * rs + off[c]] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c)
+        if (((live >> c) & 1u) && pos[c] == remaining) pos[c] = pstar;  // remaining[index] = remaining[--num_remaining]
     }
     if (stop) break;
     // dual variables (rows of SR other than cur are the rows assigned to the scanned columns)
     if (tid == 0) u[cur] += min_val;
+    const unsigned scanned = valid & ~live;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int j = tid + c * nthr;
-      if ((scmask >> c) & 1u) {
+      if ((scanned >> c) & 1u) {
+        const int j = tid + c * nthr;
         const double dlt = min_val - spc[c];
         if (j != sink) u[row4col[j]] += dlt;
         v[c] -= dlt;
       }
     }
-    if (__syncthreads_or(bad)) {  // invalid numeric entry: scipy raises ValueError
-      stop = true;
-      break;
-    }
+    __syncthreads();
     if (tid == 0) {  // augment along the path
       int j = sink;
       while (true) {
@@ -334,7 +403,7 @@ __global__ __launch_bounds__(1024) void lsa_kernel(vdetr_lsa_batch batch, int32_
     __syncthreads();
   }
   if (stop) {
-    if (tid == 0 && status != nullptr) status[blockIdx.x] = 1;
+    if (tid == 0 && status != nullptr) status[2 * blockIdx.x] = 1;
     return;
   }
   for (int r = tid; r < nr; r += nthr) {
@@ -343,6 +412,7 @@ __global__ __launch_bounds__(1024) void lsa_kernel(vdetr_lsa_batch batch, int32_
     inds[prop] = box;
     mask[prop] = 1.f;
   }
+  if (tid == 0 && status != nullptr) status[2 * blockIdx.x + 1] = step;
 }
 
 // ------------------------------------------------------------------------------------------------ seed labels
@@ -465,18 +535,24 @@ __device__ __forceinline__ float giou_grad(const float* c, const BoxGeo& p, cons
   return giou;
 }
 
-__global__ __launch_bounds__(1024) void set_loss_kernel(vdetr_setloss_desc d) {
-  __shared__ float red[16][8];
-  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+constexpr int kLossRows = 256;  // rows (proposals / seed points) per workgroup
+
+// Phase A, one thread per row: the row's label, the box terms of its matched pair with their gradients, the arg-max for
+// the cardinality count.  Phase B, all threads over the chunk's rows x C logits (coalesced): focal loss + gradient.
+__global__ __launch_bounds__(kLossRows) void set_loss_kernel(vdetr_setloss_desc d) {
+  __shared__ float red[kLossRows / 64][8];
+  __shared__ int lab[kLossRows];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int p0 = blockIdx.x * kLossRows;
+  const int rows = min(kLossRows, d.P - p0);
   long total_boxes = 0;
   for (int i = 0; i < d.B; ++i) total_boxes += d.nactual[i];
   const bool gate = total_boxes > 0;
   const float inv_nb = 1.f / d.num_boxes[0];
   const bool boxes = d.center_reg != nullptr;
   float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // sem_cls, angle_cls, angle_reg, center, size, giou, object count
-  for (int p = tid; p < d.P; p += nthr) {
-    const size_t row = (size_t)b * d.P + p;
-    // ---- label of this row
+  if (tid < rows) {
+    const size_t row = (size_t)b * d.P + p0 + tid;
     bool matched = false;
     int gi = 0, label = d.C;
     if (d.inds != nullptr) {
@@ -486,101 +562,119 @@ __global__ __launch_bounds__(1024) void set_loss_kernel(vdetr_setloss_desc d) {
     } else {
       label = (int)d.labels[row];
     }
-    // ---- focal loss over the C logits (criterion.py:77-98); cardinality arg-max on the way (criterion.py:262-268)
-    {
-      const float* x = d.cls_logits + row * d.C;
-      float* dx = d.d_cls_logits + row * d.C;
-      float best = -INFINITY;
+    lab[tid] = label;
+    {  // cardinality: arg-max over the logits, first maximum (criterion.py:262-268)
+      const float* __restrict__ x = d.cls_logits + row * d.C;
+      float best = x[0];
       int arg = 0;
-      for (int c = 0; c < d.C; ++c) {
+      for (int c = 1; c < d.C; ++c) {
         const float xv = x[c];
         if (xv > best) best = xv, arg = c;
-        const bool t = c == label;
-        const float pr = 1.f / (1.f + expf(-xv));
-        const float ce = fmaxf(xv, 0.f) - (t ? xv : 0.f) + log1pf(expf(-fabsf(xv)));
-        const float one_m_pt = t ? 1.f - pr : pr;
-        const float at = t ? d.focal_alpha : 1.f - d.focal_alpha;
-        const float mod = one_m_pt * one_m_pt;
-        acc[0] += at * (ce * mod);
-        const float dpt = t ? pr * (1.f - pr) : -(pr * (1.f - pr));
-        const float g = at * ((pr - (t ? 1.f : 0.f)) * mod - ce * (2.f * one_m_pt) * dpt);
-        dx[c] = gate ? g * (d.w_cls * inv_nb) : 0.f;
       }
-      acc[6] += arg != d.C - 1 ? 1.f : 0.f;
+      acc[6] = arg != d.C - 1 ? 1.f : 0.f;
     }
-    if (!boxes) continue;
-    // ---- box terms of the matched pair
-    float d_creg[3] = {0.f, 0.f, 0.f}, d_sreg[3] = {0.f, 0.f, 0.f};
-    float dc[24];
+    if (boxes) {
+      float d_creg[3] = {0.f, 0.f, 0.f}, d_sreg[3] = {0.f, 0.f, 0.f};
+      float dc[24];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) dc[k] = 0.f;
-    int alabel = 0;
-    float g_acls = 0.f, g_areg = 0.f;
-    if (matched && gate) {
-      const float* r = d.gt + ((size_t)b * d.G + gi) * F;
+      for (int k = 0; k < 24; ++k) dc[k] = 0.f;
+      int alabel = 0;
+      float g_areg = 0.f;
+      const bool active = matched && gate;
+      if (active) {
+        const float* __restrict__ r = d.gt + ((size_t)b * d.G + gi) * F;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float ps = d.pre_size[row * 3 + a] + 1e-5f;
-        const float ec = d.center_reg[row * 3 + a] - (r[VDETR_GT_CENTER + a] - d.pre_center[row * 3 + a]) / ps;
-        acc[3] += fabsf(ec);
-        d_creg[a] = sgn(ec) * (d.w_center * inv_nb);
-        const float es = d.size_reg[row * 3 + a] - logf((r[VDETR_GT_SIZE + a] + 1e-5f) / ps);
-        acc[4] += fabsf(es);
-        d_sreg[a] = sgn(es) * (d.w_size * inv_nb);
+        for (int a = 0; a < 3; ++a) {
+          const float ps = d.pre_size[row * 3 + a] + 1e-5f;
+          const float ec = d.center_reg[row * 3 + a] - (r[VDETR_GT_CENTER + a] - d.pre_center[row * 3 + a]) / ps;
+          acc[3] += fabsf(ec);
+          d_creg[a] = sgn(ec) * (d.w_center * inv_nb);
+          const float es = d.size_reg[row * 3 + a] - logf((r[VDETR_GT_SIZE + a] + 1e-5f) / ps);
+          acc[4] += fabsf(es);
+          d_sreg[a] = sgn(es) * (d.w_size * inv_nb);
+        }
+        float c[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) c[k] = d.corners[row * 24 + k];
+        const BoxGeo pg = box_geo(c), gg = box_geo(r + VDETR_GT_CORNERS);
+        const float giou = gi < (int)d.nactual[b] ? giou_grad(c, pg, gg, d.w_giou * inv_nb, dc) : 0.f;
+        acc[5] = 1.f - giou;
+        alabel = (int)r[VDETR_GT_ANGLE_CLS];
+        const float e = d.angle_res_norm[row * d.A + alabel] - r[VDETR_GT_ANGLE_RES] / (3.14159265358979323846f / (float)d.A);
+        acc[2] = huber1(e);
+        g_areg = fmaxf(-1.f, fminf(e, 1.f)) * (d.w_angle_reg * inv_nb);
+        // cross entropy over the angle bins
+        const float* __restrict__ al = d.angle_logits + row * d.A;
+        float m = al[0];
+        for (int a = 1; a < d.A; ++a) m = fmaxf(m, al[a]);
+        float se = 0.f;
+        for (int a = 0; a < d.A; ++a) se += expf(al[a] - m);
+        const float lse = m + logf(se);
+        acc[1] = lse - al[alabel];
+        const float g_acls = d.w_angle_cls * inv_nb;
+        for (int a = 0; a < d.A; ++a)
+          d.d_angle_logits[row * d.A + a] = (expf(al[a] - lse) - (a == alabel ? 1.f : 0.f)) * g_acls;
+      } else {
+        for (int a = 0; a < d.A; ++a) d.d_angle_logits[row * d.A + a] = 0.f;
       }
-      float c[24];
+      for (int a = 0; a < d.A; ++a) d.d_angle_res_norm[row * d.A + a] = (active && a == alabel) ? g_areg : 0.f;
 #pragma unroll
-      for (int k = 0; k < 24; ++k) c[k] = d.corners[row * 24 + k];
-      const BoxGeo pg = box_geo(c), gg = box_geo(r + VDETR_GT_CORNERS);
-      const float giou = gi < (int)d.nactual[b] ? giou_grad(c, pg, gg, d.w_giou * inv_nb, dc) : 0.f;
-      acc[5] += 1.f - giou;
-      alabel = (int)r[VDETR_GT_ANGLE_CLS];
-      const float e = d.angle_res_norm[row * d.A + alabel] - r[VDETR_GT_ANGLE_RES] / (3.14159265358979323846f / (float)d.A);
-      acc[2] += huber1(e);
-      g_areg = fmaxf(-1.f, fminf(e, 1.f)) * (d.w_angle_reg * inv_nb);
-      // cross entropy over the angle bins
-      const float* al = d.angle_logits + row * d.A;
-      float m = al[0];
-      for (int a = 1; a < d.A; ++a) m = fmaxf(m, al[a]);
-      float se = 0.f;
-      for (int a = 0; a < d.A; ++a) se += expf(al[a] - m);
-      const float lse = m + logf(se);
-      acc[1] += lse - al[alabel];
-      g_acls = d.w_angle_cls * inv_nb;
-      for (int a = 0; a < d.A; ++a)
-        d.d_angle_logits[row * d.A + a] = (expf(al[a] - lse) - (a == alabel ? 1.f : 0.f)) * g_acls;
-    } else {
-      for (int a = 0; a < d.A; ++a) d.d_angle_logits[row * d.A + a] = 0.f;
+      for (int a = 0; a < 3; ++a) d.d_center_reg[row * 3 + a] = d_creg[a], d.d_size_reg[row * 3 + a] = d_sreg[a];
+#pragma unroll
+      for (int k = 0; k < 24; ++k) d.d_corners[row * 24 + k] = dc[k];
     }
-    for (int a = 0; a < d.A; ++a) d.d_angle_res_norm[row * d.A + a] = (matched && gate && a == alabel) ? g_areg : 0.f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) d.d_center_reg[row * 3 + a] = d_creg[a], d.d_size_reg[row * 3 + a] = d_sreg[a];
-#pragma unroll
-    for (int k = 0; k < 24; ++k) d.d_corners[row * 24 + k] = dc[k];
+  }
+  __syncthreads();
+  {  // focal loss (criterion.py:77-98) over this chunk's logits
+    const size_t base = ((size_t)b * d.P + p0) * d.C;
+    const float* __restrict__ x = d.cls_logits + base;
+    float* __restrict__ dx = d.d_cls_logits + base;
+    const float gscale = gate ? d.w_cls * inv_nb : 0.f;
+    const int nel = rows * d.C;
+    for (int e = tid; e < nel; e += kLossRows) {
+      const int r = e / d.C, c = e - r * d.C;
+      const float xv = x[e];
+      const bool t = c == lab[r];
+      const float pr = 1.f / (1.f + expf(-xv));
+      const float ce = fmaxf(xv, 0.f) - (t ? xv : 0.f) + log1pf(expf(-fabsf(xv)));
+      const float one_m_pt = t ? 1.f - pr : pr;
+      const float at = t ? d.focal_alpha : 1.f - d.focal_alpha;
+      const float mod = one_m_pt * one_m_pt;
+      acc[0] += at * (ce * mod);
+      const float dpt = t ? pr * (1.f - pr) : -(pr * (1.f - pr));
+      dx[e] = at * ((pr - (t ? 1.f : 0.f)) * mod - ce * (2.f * one_m_pt) * dpt) * gscale;
+    }
   }
   // ---- workgroup sums -> one atomic per component
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
-    const float s = wave_sum(acc[t]);
-    if (lane == 0) red[wave][t] = s;
+    const float sm = wave_sum(acc[t]);
+    if (lane == 0) red[wave][t] = sm;
   }
   __syncthreads();
   if (tid == 0) {
-    float s[7];
+    float sm[7];
     for (int t = 0; t < 7; ++t) {
-      s[t] = 0.f;
-      for (int w2 = 0; w2 < nwaves; ++w2) s[t] += red[w2][t];
+      sm[t] = 0.f;
+      for (int w2 = 0; w2 < kLossRows / 64; ++w2) sm[t] += red[w2][t];
     }
     const float w[6] = {d.w_cls, d.w_angle_cls, d.w_angle_reg, d.w_center, d.w_size, d.w_giou};
     float tot = 0.f;
     for (int t = 0; t < 6; ++t) {
-      const float val = gate ? s[t] * inv_nb * w[t] : 0.f;
+      const float val = gate ? sm[t] * inv_nb * w[t] : 0.f;
       if (w[t] > 0.f) tot += val;
       atomicAdd(d.losses + t, val);
     }
-    atomicAdd(d.losses + 6, fabsf(s[6] - (float)d.nactual[b]) / (float)d.B);
     atomicAdd(d.losses + 7, tot);
+    // cardinality needs the scene's complete count: count and arrival ticket travel in ONE 64-bit atomic, so the
+    // workgroup that draws the last ticket holds the total without any fence
+    const unsigned long long add = (1ull << 32) | (unsigned long long)(unsigned)sm[6];
+    const unsigned long long old = atomicAdd(d.card_ws + b, add);
+    if ((unsigned)(old >> 32) == gridDim.x - 1) {
+      const float count = (float)((unsigned)old + (unsigned)sm[6]);
+      atomicAdd(d.losses + 6, fabsf(count - (float)d.nactual[b]) / (float)d.B);
+    }
   }
 }
 
@@ -630,20 +724,15 @@ extern "C" int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdet
     nc_cap = hi > nc_cap ? hi : nc_cap;
     wgs += p.B;
   }
-  int threads = ((nc_cap + 63) / 64) * 64;
-  threads = threads > 1024 ? 1024 : threads;
-  const int cpt = (nc_cap + threads - 1) / threads;
+  // 256 threads x 4 columns cover 1024 columns; larger problems get the 1024-thread workgroup (x 4 or x 8 columns)
+  const int threads = nc_cap <= kLsaSmall * 4 ? kLsaSmall : kLsaLarge;
   const size_t lds = (size_t)nr_cap * 8 + 64 * 8 + (size_t)nr_cap * 4 + (size_t)nc_cap * 8;
   int rc;
-#define VDETR_LSA_LAUNCH(CPT)                                                                                        \
-  rc = set_lds(lsa_kernel<CPT>, lds, "lsa");                                                                         \
-  if (rc != VDETR_OK) return rc;                                                                                     \
+#define VDETR_LSA_LAUNCH(CPT)                                                                                      \
+  rc = set_lds(lsa_kernel<CPT>, lds, "lsa");                                                                       \
+  if (rc != VDETR_OK) return rc;                                                                                   \
   hipLaunchKernelGGL(lsa_kernel<CPT>, dim3(wgs), dim3(threads), lds, (hipStream_t)stream, padded, status, nr_cap, nc_cap)
-  if (cpt == 1) {
-    VDETR_LSA_LAUNCH(1);
-  } else if (cpt == 2) {
-    VDETR_LSA_LAUNCH(2);
-  } else if (cpt <= 4) {
+  if (nc_cap <= kLsaLarge * 4) {
     VDETR_LSA_LAUNCH(4);
   } else {
     VDETR_LSA_LAUNCH(8);
@@ -673,8 +762,7 @@ extern "C" int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t st
                       d->d_angle_res_norm && d->A >= 1 && d->G >= 1,
                   "set_loss: box terms need all box pointers");
   }
-  int threads = ((d->P + 63) / 64) * 64;
-  threads = threads > 1024 ? 1024 : threads;
-  hipLaunchKernelGGL(set_loss_kernel, dim3(d->B), dim3(threads), 0, (hipStream_t)stream, *d);
+  VDETR_REQUIRE(d->card_ws != nullptr, "set_loss: card_ws (B zero-initialised uint64) is required");
+  hipLaunchKernelGGL(set_loss_kernel, dim3(ceil_div(d->P, kLossRows), d->B), dim3(kLossRows), 0, (hipStream_t)stream, *d);
   return check_launch("set_loss");
 }
