@@ -471,9 +471,24 @@ def main():
             ms = (time.perf_counter() - t0) / a.steps * 1e3
             closs = float(t2.loss.item())
             assert np.isfinite(closs), "non-finite criterion loss"
-            result["criterion"] = {"ms_per_step": ms, "scenes_per_s": bs / ms * 1e3, "added_ms": ms - result["ms_per_step"],
+            # the same criterion through the oracle (torch CPU + scipy: what the reference runs, minus its host syncs)
+            from oracle import criterion_oracle as CO
+            with torch.no_grad():
+                out = model(inputs)
+            cpu = lambda o: {k: v.detach().cpu().requires_grad_(v.is_floating_point()) for k, v in o.items()  # noqa: E731
+                             if torch.is_tensor(v) and not k.startswith("_")}
+            oc = {"outputs": cpu(out["outputs"]), "aux_outputs": [cpu(o) for o in out["aux_outputs"]],
+                  "seed_xyz": out["seed_xyz"].cpu(), "enc_outputs": cpu(out["enc_outputs"])}
+            tc = {k: v.cpu() for k, v in make_targets(a.config, device, rank).items()}
+            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            t0 = time.perf_counter()
+            ref_loss = CO.set_criterion(oc, tc)[0]
+            ref_loss.backward()
+            cpu_ms = (time.perf_counter() - t0) * 1e3
+            result["criterion"] = {"ms_per_step": ms, "cpu_oracle_ms": cpu_ms, "scenes_per_s": bs / ms * 1e3, "added_ms": ms - result["ms_per_step"],
                                    "loss": closs, "note": "same step with the set criterion (focal + L1 + GIoU on Hungarian "
-                                   "matches, 9 stages, 24 boxes/scene x repeat 5) instead of the synthetic scalar loss"}
+                                   "matches, 9 stages, 24 boxes/scene x repeat 5) instead of the synthetic scalar loss; "
+                                   "cpu_oracle_ms = the criterion alone (fwd+bwd) through oracle/criterion_oracle.py"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
