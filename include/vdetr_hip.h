@@ -392,7 +392,9 @@ typedef struct vdetr_lsa_problem {
   int64_t* inds;          /* [B,P] */
   float* mask;            /* [B,P] */
   int32_t B, P, G;
-  int32_t reserved;
+  int32_t row_repeat;     /* > 1: the first nactual box rows are `row_repeat` identical tiles (repeated ground truth,
+                             criterion.py:511-600): row r == row r % (nactual / row_repeat) bit for bit; lets the solver keep
+                             the distinct rows in LDS.  0 or 1: no structure assumed. */
 } vdetr_lsa_problem;
 typedef struct vdetr_lsa_batch {
   int32_t nproblems;

@@ -46,7 +46,7 @@ def main():
     problems = []
     for o, rep, ov in stages:
         records, G, nactual, _ = prep.stage(rep)
-        problems.append((crit.matcher.cost(o, records, G, nactual, label_override=ov)[0], nactual))
+        problems.append((crit.matcher.cost(o, records, G, nactual, label_override=ov)[0], nactual, prep.repeat if rep else 0))
     status = torch.zeros((sum(p[0].shape[0] for p in problems), 2), dtype=torch.int32, device=dev)
     for _ in range(2):
         Matcher.solve(problems, status)

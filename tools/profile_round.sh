@@ -9,6 +9,11 @@ rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py -
 db=$(find /tmp/rp_eager -name '*.db' | head -1); csv=$(find /tmp/rp_eager -name '*kernel_trace.csv' | head -1)
 python3 tools/rocprof_summary.py ${db:-$csv} 5 3 > $out/eager_kernel_summary.txt 2>&1
 python3 tools/kernel_bench.py c2 > $out/kernel_bench_c2.txt 2>&1
+# the step with the device criterion as its loss: kernel trace + the solver's scan counts
+rocprofv3 --kernel-trace --stats -d /tmp/rp_crit -o crit -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --loss criterion > $out/bench_criterion_eager.log 2>&1 < /dev/null
+cdb=$(find /tmp/rp_crit -name '*.db' | head -1)
+[ -n "$cdb" ] && python3 tools/rocprof_summary.py $cdb 5 3 > $out/criterion_eager_kernel_summary.txt 2>&1
+python3 tools/criterion_bench.py > $out/criterion_bench.txt 2>&1 < /dev/null
 # the same micro-benchmark under the kernel trace: the per-kernel averages bench.py's `roofline` objects must agree with
 rocprofv3 --kernel-trace --stats -d /tmp/rp_kb -o kb -- python3 tools/kernel_bench.py c2 > /dev/null 2>&1
 kdb=$(find /tmp/rp_kb -name '*.db' | head -1)

@@ -114,7 +114,7 @@ class LsaProblem(ctypes.Structure):
     """Mirror of ``vdetr_lsa_problem``."""
 
     _fields_ = [(n, c_void_p) for n in ("cost_t", "nactual", "inds", "mask")] + [
-        (n, ctypes.c_int32) for n in ("B", "P", "G", "reserved")]
+        (n, ctypes.c_int32) for n in ("B", "P", "G", "row_repeat")]
 
 
 class LsaBatch(ctypes.Structure):

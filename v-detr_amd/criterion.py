@@ -121,20 +121,22 @@ class Matcher(nn.Module):
 
     @staticmethod
     def solve(problems, status=None):
-        """problems: list of (cost_t [B,G,P], nactual [B]).  One launch per 16 problems.  Returns [(inds, mask)].
+        """problems: list of (cost_t [B,G,P], nactual [B][, row_repeat]).  One launch per 16 problems.  Returns
+        [(inds, mask)].  ``row_repeat`` > 1 promises that the first nactual rows of cost_t are that many identical tiles.
         ``status``: optional zero-filled int32 [sum B, 2] (<= 16 problems) -> (invalid flag, row scans) per scene."""
         out = []
         for s in range(0, len(problems), L.VDETR_LSA_MAX_PROBLEMS):
             chunk = problems[s:s + L.VDETR_LSA_MAX_PROBLEMS]
             batch = L.LsaBatch()
             batch.nproblems = len(chunk)
-            for k, (cost_t, nactual) in enumerate(chunk):
+            for k, (cost_t, nactual, *hint) in enumerate(chunk):
                 B, G, P = cost_t.shape
                 inds = torch.empty((B, P), dtype=torch.int64, device=cost_t.device)
                 mask = torch.empty((B, P), dtype=torch.float32, device=cost_t.device)
                 pr = batch.p[k]
                 pr.cost_t, pr.nactual, pr.inds, pr.mask = cost_t.data_ptr(), nactual.data_ptr(), inds.data_ptr(), mask.data_ptr()
                 pr.B, pr.P, pr.G = B, P, G
+                pr.row_repeat = int(hint[0]) if hint else 0
                 out.append((inds, mask))
             L.check(L.lib().vdetr_lsa_f64(ctypes.byref(batch), L.ptr(status), L.stream_ptr()), "lsa")
         return out
@@ -179,7 +181,7 @@ class _CriterionFn(torch.autograd.Function):
         for si, (o, repeated, override) in enumerate(stages):
             records, G, nactual, nb = prep.stage(repeated)
             cost_t, _ = m.cost(o, records, G, nactual, label_override=override)
-            problems.append((cost_t, nactual))
+            problems.append((cost_t, nactual, prep.repeat if repeated else 0))
             metas.append((records, G, nactual, nb, override))
         matches = m.solve(problems)
         lib, st = L.lib(), L.stream_ptr()

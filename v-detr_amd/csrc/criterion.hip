@@ -11,6 +11,8 @@
 // trip (the whole step stays capturable in a hipGraph) and bit-identical assignments.
 #include "wave.h"
 
+#include <stdlib.h>
+
 namespace vdetr {
 namespace {
 
@@ -211,16 +213,15 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
 }
 
 // One workgroup per problem.  Lane t owns columns t, t+T, ... (<= CPT of them) with their dual variable, shortest-path
-// cost and position in scipy's `remaining` array in registers; T = 256 threads when the problem's columns fit (4 waves, one
-// per SIMD: the cheapest barrier), otherwise the whole 1024-thread workgroup (the surplus waves of a small problem exit
-// before the first barrier).  A scan step = one row of the cost matrix (coalesced, L2-resident after the warm-up pass), one
-// lexicographic arg-min over the workgroup (DPP inside the wave, one LDS slot per wave + one barrier across waves), one
-// LDS lookup of the row assigned to the winning column.
-constexpr int kLsaSmall = 256, kLsaLarge = 1024;
-
-template <int CPT>
-__global__ __launch_bounds__(kLsaLarge) void lsa_kernel(vdetr_lsa_batch batch, int32_t* __restrict__ status, int nr_cap,
-                                                        int nc_cap) {
+// cost and position in scipy's `remaining` array in registers.  T is the smallest of {64, 256, MAXT} whose T*CPT covers
+// the problem's columns: ONE wave for <= 1024 columns (CPT = 16: no barrier and no LDS exchange inside a scan at all),
+// 4 waves (one per SIMD) up to 4096, the whole workgroup beyond; the surplus waves exit before the first barrier.
+// A scan step = one row of the cost matrix (coalesced, L2-resident after the warm-up pass), one lexicographic arg-min
+// (DPP inside the wave; across waves one LDS slot per wave + one barrier), one LDS lookup of the row assigned to the
+// winning column.
+template <int CPT, int MAXT>
+__global__ __launch_bounds__(MAXT) void lsa_kernel(vdetr_lsa_batch batch, int32_t* __restrict__ status, int nr_cap,
+                                                   int nc_cap, int cols_per_lane, int cache_bytes) {
   extern __shared__ unsigned char smem[];
   int wg = blockIdx.x, k = 0;
   while (wg >= batch.p[k].B) wg -= batch.p[k++].B;
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(kLsaLarge) void lsa_kernel(vdetr_lsa_batch batch, i
   // scipy solves a tall matrix transposed (rectangular_lsap.cpp: `transpose = nc < nr`); final_cost[b,:, :n] is P x n
   const bool transpose = n < P;
   const int nr = transpose ? n : P, nc = transpose ? P : n;
-  const int nthr = nc <= kLsaSmall * CPT ? min(kLsaSmall, (int)blockDim.x) : (int)blockDim.x;
+  // `cols_per_lane` columns per lane where the workgroup is wide enough, more (<= CPT) where it is not
+  const int nthr = min(((nc + cols_per_lane - 1) / cols_per_lane + 63) & ~63, (int)blockDim.x);
   if (tid >= nthr) return;  // before any barrier: s_barrier only counts the waves still alive
   const int nwaves = nthr >> 6;
   int64_t* inds = pr.inds + (size_t)b * P;
@@ -239,35 +241,47 @@ __global__ __launch_bounds__(kLsaLarge) void lsa_kernel(vdetr_lsa_batch batch, i
   for (int p = tid; p < P; p += nthr) inds[p] = 0, mask[p] = 0.f;
   if (n == 0) return;
   const float* __restrict__ cost = pr.cost_t + (size_t)b * G * P;
-  const long rs = transpose ? P : 1, cs = transpose ? 1 : P;
+  const int rs = transpose ? P : 1, cs = transpose ? 1 : P;  // max(P,G)^2 <= 2^26: int offsets
 
   double* u = reinterpret_cast<double*>(smem);                                   // [nr_cap]
   unsigned long long* wslot = reinterpret_cast<unsigned long long*>(u + nr_cap);  // [2][16] x {key, payload}
   int* col4row = reinterpret_cast<int*>(wslot + 64);                              // [nr_cap]
   int* row4col = col4row + nr_cap;                                               // [nc_cap]
   int* path = row4col + nc_cap;                                                  // [nc_cap]
-  for (int i = tid; i < nr; i += nthr) u[i] = 0.0, col4row[i] = -1;
+  float* rcache = reinterpret_cast<float*>(path + nc_cap);                       // [cache_rows][nc] cost rows
+  // Repeated ground truth (criterion.py:511-600) makes the box rows periodic: row r == row r % period, bit for bit (the
+  // same records through the same arithmetic).  Only `period` distinct rows exist; as many as fit stay in LDS.
+  int period = nr, cache_rows = 0;
+  if (transpose && pr.row_repeat > 1 && n % pr.row_repeat == 0) {
+    period = n / pr.row_repeat;
+    cache_rows = min(period, cache_bytes / (nc * (int)sizeof(float)));
+  }
+  int* rbase = reinterpret_cast<int*>(rcache);  // [nr_cap] distinct-row index of every row (in front of the row cache)
+  rcache += nr_cap;
+  for (int i = tid; i < nr; i += nthr) u[i] = 0.0, col4row[i] = -1, rbase[i] = i % period;
   for (int j = tid; j < nc; j += nthr) row4col[j] = -1, path[j] = -1;
   const double kInf = __longlong_as_double(0x7FF0000000000000ll);
   double v[CPT], spc[CPT];
-  int pos[CPT];
-  long off[CPT];      // element offset of this lane's columns inside a row
-  unsigned valid = 0; // bit c: column c of this lane exists
-  bool bad = false;   // this thread saw a NaN / -inf entry
+  int pos[CPT], pth[CPT];
+  int off[CPT];        // element offset of this lane's columns inside a global row (0 for columns that do not exist)
+  bool valid[CPT];     // the column exists
+  bool bad = false;    // this thread saw a NaN / -inf entry
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
     const int j = tid + c * nthr;
     v[c] = 0.0;
-    off[c] = (long)j * cs;
-    if (j < nc) valid |= 1u << c;
+    valid[c] = j < nc;
+    off[c] = valid[c] ? j * cs : 0;
   }
-  // warm-up: every row is scanned several times; pull the matrix into this XCD's L2 once, and validate it on the way
-  for (int r = 0; r < nr; ++r) {
+  // warm-up: every row is scanned several times; pull the distinct rows into LDS / this XCD's L2 once, and validate
+  // them on the way
+  for (int r = 0; r < period; ++r) {
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      if ((valid >> c) & 1u) {
-        const float cij = cost[r * rs + off[c]];
+      const float cij = cost[r * rs + off[c]];
+      if (valid[c]) {
         if (!(cij == cij) || cij == -INFINITY) bad = true;
+        if (r < cache_rows) rcache[r * nc + tid + c * nthr] = cij;
       }
     }
   }
@@ -279,45 +293,51 @@ __global__ __launch_bounds__(kLsaLarge) void lsa_kernel(vdetr_lsa_batch batch, i
   bool stop = false;  // uniform: no finite candidate left (infeasible matrix)
   int step = 0;
   for (int cur = 0; cur < nr; ++cur) {
-    unsigned live = valid, freemask = 0;  // live: not yet scanned (not in SC)
+    bool live[CPT], unassigned[CPT];  // live: not yet scanned (not in SC)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int j = tid + c * nthr;
       spc[c] = kInf;
       pos[c] = nc - 1 - j;
-      if (((valid >> c) & 1u) && row4col[j] == -1) freemask |= 1u << c;
+      live[c] = valid[c];
+      unassigned[c] = valid[c] && row4col[valid[c] ? j : 0] == -1;
     }
     double min_val = 0.0;
     int i = cur, remaining = nc, sink = -1;
     float cij[CPT];
+    auto fetch_row = [&](int base) {  // base: distinct-row index (uniform)
+      if (base < cache_rows) {
+        const float* __restrict__ src = rcache + base * nc + tid;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) cij[c] = ((live >> c) & 1u) ? cost[i * rs + off[c]] : 0.f;
+        for (int c = 0; c < CPT; ++c) cij[c] = src[valid[c] ? c * nthr : 0];
+      } else {
+        const float* __restrict__ src = cost + base * rs;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) cij[c] = src[off[c]];
+      }
+    };
+    fetch_row(rbase[i]);
     while (true) {
       const double ui = u[i];
-      // pass 1: relax this lane's columns with row i, keep the smallest shortest-path cost
+      // pass 1 (branch-free): relax this lane's columns with row i, keep the smallest shortest-path cost
       double bval = kInf;
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
-        if ((live >> c) & 1u) {
-          const double r = ((min_val + (double)cij[c]) - ui) - v[c];
-          if (r < spc[c]) {
-            spc[c] = r;
-            path[tid + c * nthr] = i;
-          }
-          bval = fmin(bval, spc[c]);
-        }
+        const double r = ((min_val + (double)cij[c]) - ui) - v[c];
+        const bool better = live[c] && r < spc[c];
+        spc[c] = better ? r : spc[c];
+        pth[c] = better ? i : pth[c];
+        bval = fmin(bval, live[c] ? spc[c] : kInf);
       }
-      // wave minimum (key inverted: larger = smaller cost; 0 = no candidate)
-      const unsigned long long bkey = live ? ~f64_key(bval) : 0ull;
-      const unsigned long long wk = wave_allmax_u64(bkey);
+      const double wm = wave_allmin_f64(bval);
       // pass 2: only the lanes holding the wave minimum rank their tied columns (scipy's tie rule as a sort key:
       // an unassigned column beats an assigned one; among unassigned the LAST in `remaining` order, else the FIRST)
       unsigned long long bpay = 0ull;
-      if (bkey == wk && live) {
+      if (bval == wm) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-          if (((live >> c) & 1u) && spc[c] == bval) {
-            const unsigned sec = ((freemask >> c) & 1u) ? (0x80000000u | (unsigned)pos[c]) : (0x7FFFFFFFu - (unsigned)pos[c]);
+          if (live[c] && spc[c] == wm) {
+            const unsigned sec = unassigned[c] ? (0x80000000u | (unsigned)pos[c]) : (0x7FFFFFFFu - (unsigned)pos[c]);
             const unsigned long long pay = ((unsigned long long)sec << 32) | (unsigned)(tid + c * nthr);
             bpay = pay > bpay ? pay : bpay;
           }
@@ -325,33 +345,40 @@ __global__ __launch_bounds__(kLsaLarge) void lsa_kernel(vdetr_lsa_batch batch, i
       }
       const unsigned long long owners = __ballot(bpay != 0ull);
       unsigned long long wp;
-      if (__popcll(owners) == 1) {  // the common case: no tie inside the wave
-        const int src = __ffsll((long long)owners) - 1;
+      if (__popcll(owners) <= 1) {  // the common case: no tie inside the wave (0 owners: nothing live, wm = inf)
+        const int src = owners ? __ffsll((long long)owners) - 1 : 0;
         wp = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(bpay >> 32), src) << 32) |
              (unsigned)__builtin_amdgcn_readlane((int)bpay, src);
       } else {
         wp = wave_allmax_u64(bpay);
       }
-      const int buf = (step & 1) * 32;
       ++step;
-      if (lane == 0) wslot[buf + 2 * wave] = wk, wslot[buf + 2 * wave + 1] = wp;
-      __syncthreads();
-      unsigned long long gk = 0ull, gp = 0ull;
-      if (nwaves == 4) {  // independent LDS reads: one latency
-        unsigned long long kk[4], pp[4];
+      double gm = wm;
+      unsigned long long gp = wp;
+      if (nwaves > 1) {  // one slot per wave, one barrier, independent reads
+        const int buf = (step & 1) * 32;
+        if (lane == 0) wslot[buf + 2 * wave] = (unsigned long long)__double_as_longlong(wm), wslot[buf + 2 * wave + 1] = wp;
+        __syncthreads();
+        gm = kInf, gp = 0ull;
+        if (nwaves == 4) {
+          double mm[4];
+          unsigned long long pp[4];
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) kk[w2] = wslot[buf + 2 * w2], pp[w2] = wslot[buf + 2 * w2 + 1];
+          for (int w2 = 0; w2 < 4; ++w2)
+            mm[w2] = __longlong_as_double((long long)wslot[buf + 2 * w2]), pp[w2] = wslot[buf + 2 * w2 + 1];
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2)
-          if (kk[w2] > gk || (kk[w2] == gk && pp[w2] > gp)) gk = kk[w2], gp = pp[w2];
-      } else {
-        for (int w2 = 0; w2 < nwaves; ++w2) {
-          const unsigned long long k2 = wslot[buf + 2 * w2], p2 = wslot[buf + 2 * w2 + 1];
-          if (k2 > gk || (k2 == gk && p2 > gp)) gk = k2, gp = p2;
+          for (int w2 = 0; w2 < 4; ++w2)
+            if (mm[w2] < gm || (mm[w2] == gm && pp[w2] > gp)) gm = mm[w2], gp = pp[w2];
+        } else {
+          for (int w2 = 0; w2 < nwaves; ++w2) {
+            const double m2 = __longlong_as_double((long long)wslot[buf + 2 * w2]);
+            const unsigned long long p2 = wslot[buf + 2 * w2 + 1];
+            if (m2 < gm || (m2 == gm && p2 > gp)) gm = m2, gp = p2;
+          }
         }
       }
-      min_val = key_f64(~gk);
-      if (gk == 0ull || min_val == kInf) {  // infeasible: scipy raises ValueError
+      min_val = gm;
+      if (gm == kInf) {  // infeasible: scipy raises ValueError
         stop = true;
         break;
       }
@@ -361,31 +388,28 @@ __global__ __launch_bounds__(kLsaLarge) void lsa_kernel(vdetr_lsa_batch batch, i
       const int pstar = is_free ? (int)(sec & 0x7FFFFFFFu) : (int)(0x7FFFFFFFu - sec);
       --remaining;
 #pragma unroll
-      for (int c = 0; c < CPT; ++c)
-        if (tid + c * nthr == jstar) live &= ~(1u << c);
+      for (int c = 0; c < CPT; ++c) live[c] = live[c] && (tid + c * nthr != jstar);
       if (is_free) {
         sink = jstar;
         break;
       }
       i = row4col[jstar];
-      // the next row's entries are requested before the bookkeeping below
+      fetch_row(rbase[i]);  // the next row's entries are requested before the bookkeeping below
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) cij[c] = ((live >> c) & 1u) ? cost[i * rs + off[c]] : 0.f;
-#pragma unroll
-      for (int c = 0; c < CPT; ++c)
-        if (((live >> c) & 1u) && pos[c] == remaining) pos[c] = pstar;  // remaining[index] = remaining[--num_remaining]
+      for (int c = 0; c < CPT; ++c) pos[c] = (live[c] && pos[c] == remaining) ? pstar : pos[c];  // remaining[index] = remaining[--num_remaining]
     }
     if (stop) break;
-    // dual variables (rows of SR other than cur are the rows assigned to the scanned columns)
+    // dual variables (rows of SR other than cur are the rows assigned to the scanned columns); the path entries of the
+    // scanned columns (the only ones the augmentation can visit) go to LDS once per row
     if (tid == 0) u[cur] += min_val;
-    const unsigned scanned = valid & ~live;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      if ((scanned >> c) & 1u) {
+      if (valid[c] && !live[c]) {
         const int j = tid + c * nthr;
         const double dlt = min_val - spc[c];
         if (j != sink) u[row4col[j]] += dlt;
         v[c] -= dlt;
+        path[j] = pth[c];
       }
     }
     __syncthreads();
@@ -708,6 +732,7 @@ extern "C" int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdet
   VDETR_REQUIRE(batch != nullptr && batch->nproblems >= 1 && batch->nproblems <= VDETR_LSA_MAX_PROBLEMS,
                 "lsa: 1..%d problems per launch", VDETR_LSA_MAX_PROBLEMS);
   int nr_cap = 1, nc_cap = 1, wgs = 0;
+  size_t cache_want = 0;
   vdetr_lsa_batch padded = *batch;
   for (int k = 0; k < VDETR_LSA_MAX_PROBLEMS; ++k) {
     if (k >= batch->nproblems) {
@@ -722,20 +747,35 @@ extern "C" int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdet
     VDETR_REQUIRE(hi <= 8192 && lo <= 2048, "lsa: problem %d is %d x %d; limits are 8192 columns, 2048 rows", k, p.P, p.G);
     nr_cap = lo > nr_cap ? lo : nr_cap;
     nc_cap = hi > nc_cap ? hi : nc_cap;
+    VDETR_REQUIRE(p.row_repeat >= 0, "lsa: negative row_repeat in problem %d", k);
+    if (p.row_repeat > 1) {  // distinct box rows of a repeated list: at most ceil(G / repeat), each P floats
+      const size_t want = (size_t)((p.G + p.row_repeat - 1) / p.row_repeat) * p.P * sizeof(float);
+      cache_want = want > cache_want ? want : cache_want;
+    }
     wgs += p.B;
   }
-  // 256 threads x 4 columns cover 1024 columns; larger problems get the 1024-thread workgroup (x 4 or x 8 columns)
-  const int threads = nc_cap <= kLsaSmall * 4 ? kLsaSmall : kLsaLarge;
-  const size_t lds = (size_t)nr_cap * 8 + 64 * 8 + (size_t)nr_cap * 4 + (size_t)nc_cap * 8;
+  // up to 4096 columns: <= 4 columns per lane in a 1024-thread workgroup; beyond: <= 8
+  const bool small = nc_cap <= 4096;
+  static const int cols_per_lane = [] {
+    const char* e = getenv("VDETR_LSA_COLS");
+    return e ? atoi(e) : 4;
+  }();
+  const int cpl = cols_per_lane < 1 ? 1 : (cols_per_lane > 8 ? 8 : cols_per_lane);
+  int threads = ((nc_cap + cpl - 1) / cpl + 63) & ~63;
+  threads = threads > 1024 ? 1024 : threads;
+  const size_t lds_base = (size_t)nr_cap * 8 + 64 * 8 + (size_t)nr_cap * 8 + (size_t)nc_cap * 8;  // + rbase
+  const size_t lds_room = lds_base < 150 * 1024 ? 150 * 1024 - lds_base : 0;  // 160 KB per CU on gfx950
+  const int cache_bytes = (int)(cache_want < lds_room ? cache_want : lds_room);
+  const size_t lds = lds_base + cache_bytes;
   int rc;
-#define VDETR_LSA_LAUNCH(CPT)                                                                                      \
-  rc = set_lds(lsa_kernel<CPT>, lds, "lsa");                                                                       \
-  if (rc != VDETR_OK) return rc;                                                                                   \
-  hipLaunchKernelGGL(lsa_kernel<CPT>, dim3(wgs), dim3(threads), lds, (hipStream_t)stream, padded, status, nr_cap, nc_cap)
-  if (nc_cap <= kLsaLarge * 4) {
-    VDETR_LSA_LAUNCH(4);
+#define VDETR_LSA_LAUNCH(CPT, MAXT)                                                                                  \
+  rc = set_lds(lsa_kernel<CPT, MAXT>, lds, "lsa");                                                                   \
+  if (rc != VDETR_OK) return rc;                                                                                     \
+  hipLaunchKernelGGL((lsa_kernel<CPT, MAXT>), dim3(wgs), dim3(threads), lds, (hipStream_t)stream, padded, status, nr_cap, nc_cap, cpl, cache_bytes)
+  if (small && cpl <= 4) {
+    VDETR_LSA_LAUNCH(4, 1024);
   } else {
-    VDETR_LSA_LAUNCH(8);
+    VDETR_LSA_LAUNCH(8, 1024);
   }
 #undef VDETR_LSA_LAUNCH
   return check_launch("lsa");

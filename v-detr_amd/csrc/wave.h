@@ -64,6 +64,32 @@ __device__ __forceinline__ unsigned long long wave_allmax_u64(unsigned long long
   return v;
 }
 
+// all-reduce min of a double over the whole wave (operands must not be NaN)
+__device__ __forceinline__ double wave_allmin_f64(double v) {
+  auto mn = [](double a, unsigned long long b) { return fmin(a, __longlong_as_double((long long)b)); };
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  v = mn(v, dpp_u64<kDppQuadXor1>(u));
+  u = (unsigned long long)__double_as_longlong(v);
+  v = mn(v, dpp_u64<kDppQuadXor2>(u));
+  u = (unsigned long long)__double_as_longlong(v);
+  v = mn(v, dpp_u64<kDppRowHalfMirror>(u));
+  u = (unsigned long long)__double_as_longlong(v);
+  v = mn(v, dpp_u64<kDppRowMirror>(u));
+  u = (unsigned long long)__double_as_longlong(v);
+  {
+    const pair_u32 lo = xrow16((unsigned)u), hi = xrow16((unsigned)(u >> 32));
+    v = fmin(__longlong_as_double((long long)(((unsigned long long)hi.a << 32) | lo.a)),
+             __longlong_as_double((long long)(((unsigned long long)hi.b << 32) | lo.b)));
+    u = (unsigned long long)__double_as_longlong(v);
+  }
+  {
+    const pair_u32 lo = xhalf32((unsigned)u), hi = xhalf32((unsigned)(u >> 32));
+    v = fmin(__longlong_as_double((long long)(((unsigned long long)hi.a << 32) | lo.a)),
+             __longlong_as_double((long long)(((unsigned long long)hi.b << 32) | lo.b)));
+  }
+  return v;
+}
+
 __device__ __forceinline__ float row_allmax_f32(float v) {
   v = fmaxf(v, dpp_f32<kDppQuadXor1>(v));
   v = fmaxf(v, dpp_f32<kDppQuadXor2>(v));
