@@ -67,12 +67,11 @@ def make_inputs(cfg_name, device, rank):
         x, f = make_scene(npts, rank * 1000 + i, device)
         xyzs.append(x)
         feats.append(f.requires_grad_(True))  # gradient flows back into the (out-of-scope) backbone
-    n = min(x.shape[0] for x in xyzs)          # equal token counts -> one batched FPS launch
-    xyzs = [x[:n].contiguous() for x in xyzs]
-    feats = [f.detach()[:n].contiguous().requires_grad_(True) for f in feats]
-    stacked = torch.stack(xyzs)
+    # scenes keep their own voxel counts (they differ after de-duplication): the batch is sampled by ONE variable-length
+    # FPS launch and gathered row-wise from the point-major tables
     return {"backbone_xyz": xyzs, "backbone_features": feats,
-            "point_cloud_dims_min": stacked.min(1)[0], "point_cloud_dims_max": stacked.max(1)[0]}
+            "point_cloud_dims_min": torch.stack([x.min(0)[0] for x in xyzs]),
+            "point_cloud_dims_max": torch.stack([x.max(0)[0] for x in xyzs])}
 
 
 def make_targets(cfg_name, device, rank, boxes_per_scene=24):

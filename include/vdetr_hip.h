@@ -53,6 +53,23 @@ size_t vdetr_fps_workspace_bytes(int b, int n);
 int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n, int m, int32_t* idx,
                                       void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
 
+/* Variable-length batch: scene i is its own cloud xyz[i] (counts[i],3); `xyz` and `counts` are HOST arrays of b entries
+ * (b <= 32), read at call time.  idx (b,m) holds indices relative to each scene.  One launch, one workgroup per scene;
+ * results per scene are those of vdetr_furthest_point_sampling_f32 on that scene alone.  Replaces the per-scene Python
+ * loop of the reference (models/model_vdetr.py:285-316: one FPS + gather launch pair per scene). */
+size_t vdetr_fps_varlen_workspace_bytes(const int32_t* counts, int b);
+int vdetr_furthest_point_sampling_varlen_f32(const float* const* xyz, const int32_t* counts, int b, int m, int32_t* idx,
+                                             void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
+
+/* gather_rows: out[i,j,:] = rows[i][idx[i,j], :] for point-major tables rows[i] (n_i, c) (HOST array of b <= 32 device
+ * pointers).  The backbone's out.C / out.F are point-major (model_vdetr.py:279-280); FPSModule.forward
+ * (model_vdetr.py:22-34) transposes the features to (b,c,n) to gather columns of them and transposes the result back.
+ * Row gathering needs neither copy and takes scenes of different sizes in one launch.  The gradient accumulates into
+ * zero-filled tables with atomics (as gather_points_grad does). */
+int vdetr_gather_rows_f32(const float* const* rows, const int32_t* idx, float* out, int b, int c, int m, vdetr_stream_t stream);
+int vdetr_gather_rows_grad_f32(const float* grad_out, const int32_t* idx, float* const* grad_rows, int b, int c, int m,
+                               vdetr_stream_t stream);
+
 /* gather_points(points, idx) — sampling.cpp:17-42, sampling_gpu.cu:11-33.
  *   points (b,c,n) f32, idx (b,m) i32 -> out (b,c,m) f32 */
 int vdetr_gather_points_f32(const float* points, const int32_t* idx, float* out, int b, int c, int n,

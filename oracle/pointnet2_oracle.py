@@ -132,3 +132,22 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     out = np.zeros((b, c, m), np.float32)
     lib().oracle_three_interpolate_grad(_p(grad_out), _p(idx), _p(weight), _p(out), b, c, n, m)
     return out
+
+
+# ---- variable-length batches of point-major tables (the product's encoder path; no counterpart in the reference's
+# ---- extension: per scene these are the reference ops above on that scene alone, model_vdetr.py:285-316) -------------
+def furthest_point_sampling_varlen(xyz_list, m):
+    return np.concatenate([furthest_point_sampling(np.ascontiguousarray(x)[None], m) for x in xyz_list], 0)
+
+
+def gather_rows(rows, idx):
+    return np.stack([np.asarray(r)[np.asarray(idx)[i]] for i, r in enumerate(rows)], 0).astype(np.float32)
+
+
+def gather_rows_grad(grad_out, idx, counts):
+    out = []
+    for i, n in enumerate(counts):
+        g = np.zeros((int(n), grad_out.shape[2]), dtype=np.float32)
+        np.add.at(g, np.asarray(idx)[i], grad_out[i])
+        out.append(g)
+    return out

@@ -44,7 +44,14 @@ class _OracleExt:
         from oracle import pointnet2_oracle as O
 
         def call(*args):
-            conv = [a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a for a in args]
+            def to_np(a):
+                if isinstance(a, torch.Tensor):
+                    return a.detach().cpu().numpy()
+                if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor):
+                    return [to_np(x) for x in a]
+                return a
+
+            conv = [to_np(a) for a in args]
             if name == "ball_query":
                 new_xyz, xyz, radius, nsample = conv
                 out = O.ball_query(new_xyz, xyz, radius, nsample)
@@ -52,6 +59,8 @@ class _OracleExt:
                 out = O.furthest_point_sampling(conv[0], conv[1])
             else:
                 out = getattr(O, name)(*conv)
+            if isinstance(out, list):
+                return [torch.from_numpy(np.ascontiguousarray(o)) for o in out]
             if isinstance(out, tuple):
                 return tuple(torch.from_numpy(np.ascontiguousarray(o)) for o in out)
             return torch.from_numpy(np.ascontiguousarray(out))

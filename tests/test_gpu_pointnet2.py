@@ -144,3 +144,46 @@ def test_query_and_group_module():
     exp = torch.gather(feats[0], 1, idx[0].reshape(1, -1).expand(5, -1)).view(5, 128, 8)
     assert torch.equal(out[0, 3:], exp)
     assert PU.GroupAll()(xyz, None, feats).shape == (1, 8, 1, xyz.shape[1])
+
+
+def test_fps_varlen_batch_equals_per_scene_sampling():
+    """One launch over scenes of different sizes (tie-heavy voxel grids, a 40k scene, a tiny one) == the fixed-size entry
+    point on each scene alone == the oracle, bit for bit."""
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(3)
+    sizes = [2978, 40000, 513, 64, 7001]
+    clouds = [grid_cloud(n, 10 + i) if i != 2 else (rng.normal(size=(n, 3)) * 2).astype(np.float32) for i, n in enumerate(sizes)]
+    m = 64
+    got = PU.furthest_point_sample_varlen([cu(c) for c in clouds], m).cpu().numpy()
+    assert got.shape == (len(clouds), m) and got.dtype == np.int32
+    for i, c in enumerate(clouds):
+        alone = PU.furthest_point_sample(cu(c[None]), m).cpu().numpy()[0]
+        assert np.array_equal(got[i], alone), f"scene {i} (n={c.shape[0]})"
+        if c.shape[0] <= 8000:
+            assert np.array_equal(got[i], O.furthest_point_sampling(c[None], m)[0]), f"scene {i} vs oracle"
+    # the full-size sampling in a mixed batch
+    big = PU.furthest_point_sample_varlen([cu(clouds[1]), cu(clouds[4])], 4096).cpu().numpy()
+    assert np.array_equal(big[0], PU.furthest_point_sample(cu(clouds[1][None]), 4096).cpu().numpy()[0])
+    assert np.array_equal(big[1], PU.furthest_point_sample(cu(clouds[4][None]), 4096).cpu().numpy()[0])
+
+
+@pytest.mark.parametrize("c", [3, 256, 10])
+def test_gather_rows_and_grad(c):
+    from vdetr_amd import pointnet2_utils as PU
+    g = torch.Generator().manual_seed(c)
+    sizes, m = [500, 1300, 64], 200
+    rows = [torch.randn((n, c), generator=g).to(DEV).requires_grad_(True) for n in sizes]
+    idx = torch.stack([torch.randint(0, n, (m,), generator=g) for n in sizes]).to(torch.int32)
+    idx[0, :10] = 7                      # repeated index: the gradient accumulates
+    idx = idx.to(DEV)
+    out = PU.gather_rows(rows, idx)
+    want = torch.stack([r[idx[i].long()] for i, r in enumerate(rows)])
+    assert torch.equal(out, want)
+    w = torch.randn(out.shape, generator=g).to(DEV)
+    (out * w).sum().backward()
+    for i, r in enumerate(rows):
+        ref = torch.zeros_like(r)
+        ref.index_add_(0, idx[i].long(), w[i])
+        torch.testing.assert_close(r.grad, ref, rtol=1e-5, atol=1e-6)
+    ref_np = O.gather_rows([r.detach().cpu().numpy() for r in rows], idx.cpu().numpy())
+    assert np.array_equal(out.detach().cpu().numpy(), ref_np)

@@ -142,6 +142,10 @@ _SIGNATURES = {
     "vdetr_last_error": (ctypes.c_char_p, []),
     "vdetr_fps_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vdetr_furthest_point_sampling_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_fps_varlen_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "vdetr_furthest_point_sampling_varlen_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vdetr_gather_rows_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vdetr_gather_points_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vdetr_gather_points_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vdetr_ball_query_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),

@@ -39,6 +39,13 @@ constexpr int kFpsMaxBuckets = kFpsWaves * kWave * kFpsSlots;  // 4096
 constexpr int kGridBits = 4;
 constexpr int kCells = 1 << (3 * kGridBits);  // 4096
 
+constexpr int kFpsMaxScenes = 32;  // scenes of one variable-length launch
+struct FpsScene {    // one scene of a variable-length batch: its own cloud, size and sorting geometry
+  const float* xyz;  // (n,3)
+  long ws_off;       // first workspace element of this scene
+  int n, npad, bucket_pts, nbuckets, ref_block, ref_log2;
+};
+
 struct FpsParams {
   const float* xyz;  // (b,n,3)
   int32_t* idx;      // (b,m)
@@ -49,6 +56,8 @@ struct FpsParams {
   int nbuckets;
   int ref_block;     // opt_n_threads(n) of the reference (cuda_utils.h:17-21)
   int ref_log2;
+  int nscenes;       // > 0: variable-length batch, workgroup bi takes its geometry from scenes[bi]
+  FpsScene scenes[kFpsMaxScenes];
 };
 
 __device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
@@ -84,7 +93,8 @@ __device__ __forceinline__ unsigned long long fps_clock() {
 }
 
 template <bool DEBUG>
-__global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
+__global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams Pin) {
+  FpsParams P = Pin;
   __shared__ int s_hist[kCells];
   __shared__ int s_wsum[kFpsWaves];
   __shared__ float s_red[kFpsWaves][6];
@@ -93,10 +103,18 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams P) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int bi = blockIdx.x;
-  const float* __restrict__ xyz = P.xyz + (size_t)bi * P.n * 3;
+  size_t ws_off = (size_t)bi * P.npad;
+  const float* xyz0 = P.xyz + (size_t)bi * P.n * 3;
+  if (P.nscenes > 0) {  // every scene of the batch has its own size: one workgroup each, all in this launch
+    const FpsScene S = Pin.scenes[bi];
+    P.n = S.n, P.npad = S.npad, P.bucket_pts = S.bucket_pts, P.nbuckets = S.nbuckets;
+    P.ref_block = S.ref_block, P.ref_log2 = S.ref_log2;
+    xyz0 = S.xyz, ws_off = (size_t)S.ws_off;
+  }
+  const float* __restrict__ xyz = xyz0;
   int32_t* __restrict__ out = P.idx + (size_t)bi * P.m;
-  float4* __restrict__ pts = P.pts + (size_t)bi * P.npad;
-  uint32_t* __restrict__ keys = P.keys + (size_t)bi * P.npad;
+  float4* __restrict__ pts = P.pts + ws_off;
+  uint32_t* __restrict__ keys = P.keys + ws_off;
   const int n = P.n;
 
   // ---- prologue 1: bounding box of the cloud ------------------------------------------------------
@@ -350,6 +368,13 @@ static int fps_geometry(int n, int* npad, int* bucket_pts, int* nbuckets) {
   return 0;
 }
 
+// opt_n_threads(n): 2^floor(log2 n) clamped to [1,512] (cuda_utils.h:17-21)
+static int ref_log2_of(int n) {
+  int lg = 0;
+  while ((2L << lg) <= (long)n) ++lg;
+  return lg > 9 ? 9 : lg;
+}
+
 extern "C" size_t vdetr_fps_workspace_bytes(int b, int n) {
   int npad, bp, nb;
   fps_geometry(n, &npad, &bp, &nb);
@@ -376,11 +401,8 @@ extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n,
   P.pts = (float4*)base;
   P.keys = (uint32_t*)(base + (size_t)b * P.npad * sizeof(float4));
   P.xyz = xyz; P.idx = idx; P.n = n; P.m = m;
-  // opt_n_threads(n): 2^floor(log2 n) clamped to [1,512] (cuda_utils.h:17-21)
-  int lg = 0;
-  while ((2L << lg) <= (long)n) ++lg;
-  if (lg > 9) lg = 9;
-  P.ref_log2 = lg; P.ref_block = 1 << lg;
+  P.nscenes = 0;
+  P.ref_log2 = ref_log2_of(n); P.ref_block = 1 << P.ref_log2;
   static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
   if (debug) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -395,4 +417,47 @@ extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n,
   }
   hipLaunchKernelGGL(fps_kernel<false>, dim3(b), dim3(kFpsThreads), 0, (hipStream_t)stream, P);
   return check_launch("furthest_point_sampling");
+}
+
+extern "C" size_t vdetr_fps_varlen_workspace_bytes(const int32_t* counts, int b) {
+  size_t total = 0;
+  for (int i = 0; i < b; ++i) {
+    int npad, bp, nb;
+    fps_geometry(counts[i], &npad, &bp, &nb);
+    total += (size_t)npad;
+  }
+  return b > 0 ? total * (sizeof(float4) + sizeof(uint32_t)) + 256 : 0;
+}
+
+extern "C" int vdetr_furthest_point_sampling_varlen_f32(const float* const* xyz, const int32_t* counts, int b, int m,
+                                                        int32_t* idx, void* workspace, size_t workspace_bytes,
+                                                        vdetr_stream_t stream) {
+  if (b == 0 || m <= 0) return VDETR_OK;
+  VDETR_REQUIRE(b > 0 && b <= kFpsMaxScenes, "furthest_point_sampling_varlen: 1..%d scenes per launch, got %d", kFpsMaxScenes, b);
+  VDETR_REQUIRE(xyz && counts && idx, "furthest_point_sampling_varlen: null pointer");
+  const size_t need = vdetr_fps_varlen_workspace_bytes(counts, b);
+  if (!workspace || workspace_bytes < need) {
+    set_error("furthest_point_sampling_varlen: workspace %zu B < required %zu B", workspace_bytes, need);
+    return VDETR_ERR_WORKSPACE;
+  }
+  FpsParams P{};
+  long total = 0;
+  for (int i = 0; i < b; ++i) {
+    VDETR_REQUIRE(counts[i] > 0 && (long)counts[i] < (1L << 30), "furthest_point_sampling_varlen: scene %d has %d points", i, counts[i]);
+    VDETR_REQUIRE(xyz[i] != nullptr, "furthest_point_sampling_varlen: scene %d: null pointer", i);
+    FpsScene& S = P.scenes[i];
+    S.xyz = xyz[i];
+    S.n = counts[i];
+    fps_geometry(S.n, &S.npad, &S.bucket_pts, &S.nbuckets);
+    S.ws_off = total;
+    total += S.npad;
+    S.ref_log2 = ref_log2_of(S.n);
+    S.ref_block = 1 << S.ref_log2;
+  }
+  uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  P.pts = (float4*)base;
+  P.keys = (uint32_t*)(base + (size_t)total * sizeof(float4));
+  P.idx = idx; P.m = m; P.nscenes = b;
+  hipLaunchKernelGGL(fps_kernel<false>, dim3(b), dim3(kFpsThreads), 0, (hipStream_t)stream, P);
+  return check_launch("furthest_point_sampling_varlen");
 }

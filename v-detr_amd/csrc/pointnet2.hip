@@ -52,6 +52,52 @@ __global__ __launch_bounds__(kThreads) void gather_points_grad_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// gather_rows: out[b,j,:] = rows_b[idx[b,j], :]  for point-major tables rows_b [n_b, c], one table per scene.
+// The backbone hands over voxel coordinates [n,3] and features [n,256] point-major (out.C / out.F,
+// model_vdetr.py:279-280); the reference transposes the features to (1,256,n) just to gather 4096 columns of it with a
+// stride of n floats (model_vdetr.py:22-34, sampling_gpu.cu:11-23) and transposes the result again for the decoder.
+// Gathering ROWS moves 1 KB contiguous per sampled point, needs no transposed copy of the 41 MB table in either
+// direction, and takes scenes of different sizes in one launch (per-scene base pointers travel as kernel arguments).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowScenes = 32;
+struct RowTables { const float* src[kRowScenes]; };
+struct RowGradTables { float* dst[kRowScenes]; };
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(RowTables T, const int32_t* __restrict__ idx,
+                                                               float* __restrict__ out, int c, int m) {
+  const int bi = blockIdx.y;
+  const int cv = c / VEC;
+  const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= (long)m * cv) return;
+  const int j = (int)(e / cv), q = (int)(e - (long)j * cv);
+  const long a = idx[(size_t)bi * m + j];
+  const float* __restrict__ src = T.src[bi] + a * c + q * VEC;
+  float* __restrict__ dst = out + ((size_t)bi * m + j) * c + q * VEC;
+  if (VEC == 4) {
+    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+  } else {
+    *dst = *src;
+  }
+}
+
+// grad_rows_b[idx[b,j], :] += grad_out[b,j,:]   (atomics: a sampling may repeat an index)
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void gather_rows_grad_kernel(RowGradTables T, const int32_t* __restrict__ idx,
+                                                                    const float* __restrict__ grad_out, int c, int m) {
+  const int bi = blockIdx.y;
+  const int cv = c / VEC;
+  const long e = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= (long)m * cv) return;
+  const int j = (int)(e / cv), q = (int)(e - (long)j * cv);
+  const long a = idx[(size_t)bi * m + j];
+  float* __restrict__ dst = T.dst[bi] + a * c + q * VEC;
+  const float* __restrict__ src = grad_out + ((size_t)bi * m + j) * c + q * VEC;
+#pragma unroll
+  for (int t = 0; t < VEC; ++t) unsafeAtomicAdd(dst + t, src[t]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // group_points: out[b,c,j,k] = points[b,c,idx[b,j,k]]                 (group_points_gpu.cu:11-31)
 // flat element e = j*nsample + k, so the (b,npoints,nsample) index tensor is read coalesced.
 // ---------------------------------------------------------------------------------------------
@@ -351,4 +397,48 @@ extern "C" int vdetr_ball_query_f32(const float* new_xyz, const float* xyz, int3
   hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, new_xyz, xyz, idx, n,
                      m, radius2, nsample);
   return check_launch("ball_query");
+}
+
+extern "C" int vdetr_gather_rows_f32(const float* const* rows, const int32_t* idx, float* out, int b, int c, int m,
+                                     vdetr_stream_t stream) {
+  VDETR_REQUIRE(b >= 0 && c >= 0 && m >= 0, "gather_rows: negative dimension");
+  if (b == 0 || c == 0 || m == 0) return VDETR_OK;
+  VDETR_REQUIRE(b <= kRowScenes, "gather_rows: %d scenes > %d per launch", b, kRowScenes);
+  VDETR_REQUIRE(rows && idx && out, "gather_rows: null pointer");
+  RowTables T{};
+  bool vec = c % 4 == 0 && ((uintptr_t)out & 15) == 0;
+  for (int i = 0; i < b; ++i) {
+    VDETR_REQUIRE(rows[i] != nullptr, "gather_rows: scene %d: null pointer", i);
+    T.src[i] = rows[i];
+    vec = vec && ((uintptr_t)rows[i] & 15) == 0;
+  }
+  if (vec) {
+    dim3 grid(ceil_div((long)m * (c / 4), kThreads), b);
+    hipLaunchKernelGGL(gather_rows_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, T, idx, out, c, m);
+  } else {
+    dim3 grid(ceil_div((long)m * c, kThreads), b);
+    hipLaunchKernelGGL(gather_rows_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, T, idx, out, c, m);
+  }
+  return check_launch("gather_rows");
+}
+
+extern "C" int vdetr_gather_rows_grad_f32(const float* grad_out, const int32_t* idx, float* const* grad_rows, int b, int c,
+                                          int m, vdetr_stream_t stream) {
+  VDETR_REQUIRE(b >= 0 && c >= 0 && m >= 0, "gather_rows_grad: negative dimension");
+  if (b == 0 || c == 0 || m == 0) return VDETR_OK;
+  VDETR_REQUIRE(b <= kRowScenes, "gather_rows_grad: %d scenes > %d per launch", b, kRowScenes);
+  VDETR_REQUIRE(grad_out && idx && grad_rows, "gather_rows_grad: null pointer");
+  RowGradTables T{};
+  for (int i = 0; i < b; ++i) {
+    VDETR_REQUIRE(grad_rows[i] != nullptr, "gather_rows_grad: scene %d: null pointer", i);
+    T.dst[i] = grad_rows[i];
+  }
+  if (c % 4 == 0) {
+    dim3 grid(ceil_div((long)m * (c / 4), kThreads), b);
+    hipLaunchKernelGGL(gather_rows_grad_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, T, idx, grad_out, c, m);
+  } else {
+    dim3 grid(ceil_div((long)m * c, kThreads), b);
+    hipLaunchKernelGGL(gather_rows_grad_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, T, idx, grad_out, c, m);
+  }
+  return check_launch("gather_rows_grad");
 }

@@ -103,18 +103,21 @@ class ModelVDETR(nn.Module):
         depends on the voxel COORDINATES, so a training loop can run it ahead of time — e.g. for the next batch on a
         side stream while the current batch is in the decoder — and pass the result as ``inputs["fps_inds"]``."""
         scenes = self.pre_encoder(inputs)
-        xyz = torch.stack([s[0] for s in scenes]).contiguous()
-        return pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        return pointnet2_utils.furthest_point_sample_varlen([s[0].contiguous() for s in scenes], self.npoint)
 
     def run_encoder(self, inputs):
         """Backbone output -> FPS to ``npoint`` tokens per scene (model_vdetr.py:279-326)."""
         scenes = self.pre_encoder(inputs)
-        same_n = len({s[0].shape[0] for s in scenes}) == 1
-        if same_n and not self.random_fps:
-            xyz = torch.stack([s[0] for s in scenes]).contiguous()                   # B,n,3
-            feats = torch.stack([s[1] for s in scenes]).transpose(1, 2).contiguous()  # B,C,n
-            enc_xyz, enc_features, enc_inds = self.fps_module(xyz, feats, self.npoint,  # one launch, B workgroups
-                                                              sample_inds=inputs.get("fps_inds"))
+        if not self.random_fps and len(scenes) <= 32:
+            # point-major tables as the backbone hands them over, scenes of any sizes: ONE FPS launch (a workgroup per
+            # scene) and two row gathers for the batch; no (B,C,n) transposed copy of the features in either direction
+            xyzs = [s[0].contiguous() for s in scenes]
+            enc_inds = inputs.get("fps_inds")
+            if enc_inds is None:
+                enc_inds = pointnet2_utils.furthest_point_sample_varlen(xyzs, self.npoint)
+            enc_xyz = pointnet2_utils.gather_rows(xyzs, enc_inds)                                  # B,m,3
+            enc_rows = pointnet2_utils.gather_rows([s[1].contiguous() for s in scenes], enc_inds)  # B,m,C
+            return enc_xyz, enc_rows.permute(1, 0, 2), enc_inds  # features: npoints x batch x channel
         else:
             out = []
             for xyz_i, feats_i in scenes:

@@ -8,6 +8,8 @@ API map (reference line → here):
   QueryAndGroup :291     GroupAll :376
 ``_ext`` below mirrors the nine raw extension functions of ``_ext_src/src/bindings.cpp:9-22``.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -131,6 +133,50 @@ class _Ext:
         return out
 
 
+    # ---- variable-length batches of point-major tables (see furthest_point_sample_varlen / gather_rows below) ----
+    @staticmethod
+    def _ptr_array(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def furthest_point_sampling_varlen(self, xyz_list, npoint):
+        for i, x in enumerate(xyz_list):
+            self._chk_f(x, f"xyz[{i}]")
+            if x.dim() != 2 or x.shape[1] != 3:
+                raise RuntimeError(f"xyz[{i}] must be [n,3]")
+        B, dev = len(xyz_list), xyz_list[0].device
+        counts = (ctypes.c_int32 * B)(*[int(x.shape[0]) for x in xyz_list])
+        idx = torch.empty((B, npoint), dtype=torch.int32, device=dev)
+        lib = L.lib()
+        nbytes = lib.vdetr_fps_varlen_workspace_bytes(counts, B)
+        ws = L.workspace(nbytes, dev)
+        L.check(lib.vdetr_furthest_point_sampling_varlen_f32(self._ptr_array(xyz_list), counts, B, npoint, L.ptr(idx),
+                                                             L.ptr(ws), nbytes, L.stream_ptr()), "furthest_point_sampling_varlen")
+        return idx
+
+    def gather_rows(self, rows, idx):
+        self._chk_i(idx, "idx")
+        B, m = idx.shape
+        if len(rows) != B:
+            raise RuntimeError(f"gather_rows: {len(rows)} tables for a batch of {B}")
+        C = rows[0].shape[1]
+        for i, r in enumerate(rows):
+            self._chk_f(r, f"rows[{i}]")
+            if r.dim() != 2 or r.shape[1] != C:
+                raise RuntimeError(f"rows[{i}] must be [n,{C}]")
+        out = torch.empty((B, m, C), dtype=torch.float32, device=idx.device)
+        L.check(L.lib().vdetr_gather_rows_f32(self._ptr_array(rows), L.ptr(idx), L.ptr(out), B, C, m, L.stream_ptr()),
+                "gather_rows")
+        return out
+
+    def gather_rows_grad(self, grad_out, idx, counts):
+        self._chk_f(grad_out, "grad_out")
+        self._chk_i(idx, "idx")
+        B, m, C = grad_out.shape
+        grads = [torch.zeros((int(n), C), dtype=torch.float32, device=grad_out.device) for n in counts]
+        L.check(L.lib().vdetr_gather_rows_grad_f32(L.ptr(grad_out), L.ptr(idx), self._ptr_array(grads), B, C, m,
+                                                   L.stream_ptr()), "gather_rows_grad")
+        return grads
+
 _ext = _Ext()
 
 
@@ -165,6 +211,39 @@ class GatherOperation(Function):
 
 
 gather_operation = GatherOperation.apply
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Variable-length batches of point-major tables (not in the reference's extension): what ModelVDETR's encoder uses.
+# The backbone hands over per scene xyz [n_i,3] and features [n_i,C]; the reference loops over the scenes in Python,
+# transposes each feature table to (1,C,n_i) and launches FPS + two gathers per scene (model_vdetr.py:285-316).
+# ------------------------------------------------------------------------------------------------------------------
+def furthest_point_sample_varlen(xyz_list, npoint):
+    """xyz_list: B tensors [n_i,3] (float32, GPU, contiguous) -> int32 [B,npoint], indices relative to each scene.
+    One launch for the whole batch; per scene the result is furthest_point_sample(xyz_i[None], npoint)."""
+    return _ext.furthest_point_sampling_varlen(list(xyz_list), int(npoint))
+
+
+class GatherRows(Function):
+    """out[i,j,:] = rows_i[idx[i,j], :] for B point-major tables rows_i [n_i,C]; differentiable w.r.t. the tables."""
+
+    @staticmethod
+    def forward(ctx, idx, *rows):
+        ctx.idx, ctx.shapes = idx, [tuple(r.shape) for r in rows]
+        return _ext.gather_rows(list(rows), idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        need = ctx.needs_input_grad[1:]
+        if not any(need):
+            return (None,) * (1 + len(ctx.shapes))
+        grads = _ext.gather_rows_grad(grad_out.contiguous(), ctx.idx, [sh[0] for sh in ctx.shapes])
+        return (None, *[g if n else None for g, n in zip(grads, need)])
+
+
+def gather_rows(rows, idx):
+    """rows: B tensors [n_i,C]; idx int32 [B,m] -> [B,m,C]"""
+    return GatherRows.apply(idx, *rows)
 
 
 class ThreeNN(Function):
