@@ -443,51 +443,67 @@ def main():
     if a.config == "c2":  # decoder fwd+bwd = 216 GFLOP per scene at the full configuration
         result["end_to_end"] = {"gflop_per_scene": 216.0, "achieved_tflops": 216.0e-3 * result["value"],
                                 "note": "algorithmic decoder flops (SURVEY 8d) x scenes/s, all GPUs"}
+    def leg(name, fn):
+        """The headline line must be printed whatever happens in a secondary measurement."""
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001
+            result[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            print(f"[bench] {name} leg failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+
+    def roofline_leg():
+        fwd_obj, bwd_obj = kernel_rooflines(a.config, device)
+        layers = nl - 1
+        dom, other = (bwd_obj, fwd_obj) if bwd_obj["launch_us"] >= fwd_obj["launch_us"] else (fwd_obj, bwd_obj)
+        dom["share_of_step"] = layers * dom["launch_us"] * 1e-3 / result["ms_per_step"]
+        other["share_of_step"] = layers * other["launch_us"] * 1e-3 / result["ms_per_step"]
+        result["roofline"] = dom
+        result["roofline_secondary"] = other
+
+    def cpu_leg():
+        result["cpu_baseline"] = cpu_baseline(a.config)
+
+    def criterion_leg():
+        # the same step with the reference's real loss (SURVEY 8f rank 1): matcher + Hungarian + losses on the device
+        t2 = make_trainer(True)
+        if use_graph:
+            t2.capture()
+        for _ in range(3):
+            t2.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            t2.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        closs = float(t2.loss.item())
+        assert np.isfinite(closs), "non-finite criterion loss"
+        # the same criterion through the oracle (torch CPU + scipy: what the reference runs, minus its host syncs)
+        from oracle import criterion_oracle as CO
+        with torch.no_grad():
+            out = model(inputs)
+        cpu = lambda o: {k: v.detach().cpu().requires_grad_(v.is_floating_point()) for k, v in o.items()  # noqa: E731
+                         if torch.is_tensor(v) and not k.startswith("_")}
+        oc = {"outputs": cpu(out["outputs"]), "aux_outputs": [cpu(o) for o in out["aux_outputs"]],
+              "seed_xyz": out["seed_xyz"].cpu(), "enc_outputs": cpu(out["enc_outputs"])}
+        tc = {k: v.cpu() for k, v in make_targets(a.config, device, rank).items()}
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        t0 = time.perf_counter()
+        ref_loss = CO.set_criterion(oc, tc)[0]
+        ref_loss.backward()
+        cpu_ms = (time.perf_counter() - t0) * 1e3
+        result["criterion"] = {"ms_per_step": ms, "cpu_oracle_ms": cpu_ms, "scenes_per_s": bs / ms * 1e3, "added_ms": ms - result["ms_per_step"],
+                               "loss": closs, "note": "same step with the set criterion (focal + L1 + GIoU on Hungarian "
+                               "matches, 9 stages, 24 boxes/scene x repeat 5) instead of the synthetic scalar loss; "
+                               "cpu_oracle_ms = the criterion alone (fwd+bwd) through oracle/criterion_oracle.py"}
+
     if rank == 0:
         if not a.no_roofline:
-            fwd_obj, bwd_obj = kernel_rooflines(a.config, device)
-            layers = nl - 1
-            dom, other = (bwd_obj, fwd_obj) if bwd_obj["launch_us"] >= fwd_obj["launch_us"] else (fwd_obj, bwd_obj)
-            dom["share_of_step"] = layers * dom["launch_us"] * 1e-3 / result["ms_per_step"]
-            other["share_of_step"] = layers * other["launch_us"] * 1e-3 / result["ms_per_step"]
-            result["roofline"] = dom
-            result["roofline_secondary"] = other
+            leg("roofline", roofline_leg)
         if not a.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(a.config)
+            leg("cpu_baseline", cpu_leg)
         if world == 1 and a.loss == "synthetic" and not a.no_criterion_leg:
-            # the same step with the reference's real loss: matcher + Hungarian + losses on the device
-            del trainer
-            t2 = make_trainer(True)
-            if use_graph:
-                t2.capture()
-            for _ in range(3):
-                t2.step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                t2.step()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / a.steps * 1e3
-            closs = float(t2.loss.item())
-            assert np.isfinite(closs), "non-finite criterion loss"
-            # the same criterion through the oracle (torch CPU + scipy: what the reference runs, minus its host syncs)
-            from oracle import criterion_oracle as CO
-            with torch.no_grad():
-                out = model(inputs)
-            cpu = lambda o: {k: v.detach().cpu().requires_grad_(v.is_floating_point()) for k, v in o.items()  # noqa: E731
-                             if torch.is_tensor(v) and not k.startswith("_")}
-            oc = {"outputs": cpu(out["outputs"]), "aux_outputs": [cpu(o) for o in out["aux_outputs"]],
-                  "seed_xyz": out["seed_xyz"].cpu(), "enc_outputs": cpu(out["enc_outputs"])}
-            tc = {k: v.cpu() for k, v in make_targets(a.config, device, rank).items()}
-            torch.set_num_threads(min(os.cpu_count() or 1, 32))
-            t0 = time.perf_counter()
-            ref_loss = CO.set_criterion(oc, tc)[0]
-            ref_loss.backward()
-            cpu_ms = (time.perf_counter() - t0) * 1e3
-            result["criterion"] = {"ms_per_step": ms, "cpu_oracle_ms": cpu_ms, "scenes_per_s": bs / ms * 1e3, "added_ms": ms - result["ms_per_step"],
-                                   "loss": closs, "note": "same step with the set criterion (focal + L1 + GIoU on Hungarian "
-                                   "matches, 9 stages, 24 boxes/scene x repeat 5) instead of the synthetic scalar loss; "
-                                   "cpu_oracle_ms = the criterion alone (fwd+bwd) through oracle/criterion_oracle.py"}
+            leg("criterion", criterion_leg)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
