@@ -123,3 +123,38 @@ def test_flat_params_update_matches_per_parameter_update():
             if not n.startswith("unused"):
                 torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-7, msg=f"step {step} {n}")
     assert all(p.data_ptr() >= flat.data.data_ptr() for p in m2.parameters())  # still views of the flat buffer
+
+
+def _loss_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vdetr_amd.dist import all_reduce_average, init_distributed, reduce_dict
+    init_distributed("gloo")
+    loss = torch.tensor(float(rank + 1))
+    avg = all_reduce_average(loss.clone())
+    separate = {"b": torch.tensor(2.0 * (rank + 1)), "a": torch.tensor(10.0 * (rank + 1))}
+    table = torch.arange(12, dtype=torch.float32).reshape(3, 4) * (rank + 1)     # the criterion's loss table layout
+    views = {"loss_x": table[0, 1], "loss_y_0": table[2, 3], "loss_z": table[1, 0]}
+    q.put((rank, float(avg), {k: float(v) for k, v in reduce_dict(separate).items()},
+           {k: float(v) for k, v in reduce_dict(views).items()}, {k: float(v) for k, v in reduce_dict(views, average=False).items()}))
+    dist.destroy_process_group()
+
+
+def test_loss_reductions_match_reference_semantics():
+    """all_reduce_average / reduce_dict (engine.py:97-98) on two gloo ranks, incl. the one-collective path for a dictionary
+    whose values are views of one loss table."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, avg, sep, views, sums in res:
+        assert avg == 1.5
+        assert sep == {"a": 15.0, "b": 3.0}
+        assert views == {"loss_x": 1.5, "loss_y_0": 16.5, "loss_z": 6.0}
+        assert sums == {"loss_x": 3.0, "loss_y_0": 33.0, "loss_z": 12.0}

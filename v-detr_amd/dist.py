@@ -303,3 +303,39 @@ def broadcast_parameters(module, src=0, process_group=None):
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=process_group)
+
+
+# ---- the engine's loss reductions (engine.py:97-98; utils/dist.py:67-110) -------------------------------------------
+def all_reduce_average(tensor):
+    """utils/dist.py:82-84: mean over ranks (identity on one rank).  In place, as the reference's all_reduce_sum is."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return tensor
+    t = tensor[None] if tensor.ndim == 0 else tensor
+    dist.all_reduce(t)
+    t /= dist.get_world_size()
+    return t[0] if tensor.ndim == 0 else t
+
+
+def reduce_dict(input_dict, average=True):
+    """utils/dist.py:88-110: every value averaged (or summed) over the ranks, keys sorted so that all ranks agree.  Values
+    that are views of ONE tensor (the device criterion's loss_dict: v-detr_amd/criterion.py) are reduced through that
+    tensor directly: one collective, no stack kernel."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        vals = [input_dict[k] for k in names]
+        base = vals[0]._base if vals and vals[0]._base is not None else None
+        if base is not None and all(v._base is base for v in vals):
+            red = base.detach().clone()
+            dist.all_reduce(red)
+            if average:
+                red /= dist.get_world_size()
+            off0 = base.storage_offset()
+            flat = red.reshape(-1)
+            return {k: flat[v.storage_offset() - off0] for k, v in zip(names, vals)}
+        values = torch.stack([v.detach() for v in vals], dim=0)
+        dist.all_reduce(values)
+        if average:
+            values /= dist.get_world_size()
+        return dict(zip(names, values))
