@@ -394,6 +394,8 @@ typedef struct vdetr_match_desc {
   float* giou_t;            /* optional [B,G,P] pairwise GIoU (outputs["gious"], box-major), or NULL */
 } vdetr_match_desc;
 int vdetr_match_cost_f32(const vdetr_match_desc* d, vdetr_stream_t stream);
+/* the same for n stage descriptors (HOST array; shapes may differ) in one launch per 12 descriptors */
+int vdetr_match_cost_batch_f32(const vdetr_match_desc* descs, int n, vdetr_stream_t stream);
 
 /* Rectangular linear sum assignment, one workgroup per (problem, scene): scipy's shortest-augmenting-path solver
  * (rectangular_lsap.cpp of scipy 1.5.1, requirements.txt:9) restated in fp64 with its traversal order and tie rules, so
@@ -448,6 +450,8 @@ typedef struct vdetr_setloss_desc {
   float *d_cls_logits, *d_center_reg, *d_size_reg, *d_corners, *d_angle_logits, *d_angle_res_norm; /* d total / d input; written in full */
 } vdetr_setloss_desc;
 int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream);
+/* the same for n descriptors (HOST array: all stages of a step + the seed-point loss) in one launch per 12 descriptors */
+int vdetr_set_loss_batch_f32(const vdetr_setloss_desc* descs, int n, vdetr_stream_t stream);
 
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */

@@ -176,9 +176,11 @@ _SIGNATURES = {
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vdetr_gt_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vdetr_match_cost_f32": (c_int, [ctypes.POINTER(MatchDesc), c_void_p]),
+    "vdetr_match_cost_batch_f32": (c_int, [ctypes.POINTER(MatchDesc), c_int, c_void_p]),
     "vdetr_lsa_f64": (c_int, [ctypes.POINTER(LsaBatch), c_void_p, c_void_p]),
     "vdetr_point_labels_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_set_loss_f32": (c_int, [ctypes.POINTER(SetLossDesc), c_void_p]),
+    "vdetr_set_loss_batch_f32": (c_int, [ctypes.POINTER(SetLossDesc), c_int, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

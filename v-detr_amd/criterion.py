@@ -94,6 +94,18 @@ class Matcher(nn.Module):
 
     def cost(self, o, records, G, nactual, label_override=-1, want_giou=False):
         """Launches the pairwise kernel of one stage.  Returns (cost_t [B,G,P], giou_t or None)."""
+        d, keep = self._cost_desc(o, records, G, nactual, label_override, want_giou)
+        L.check(L.lib().vdetr_match_cost_f32(ctypes.byref(d), L.stream_ptr()), "match_cost")
+        return keep["cost_t"], keep["giou_t"]
+
+    def cost_batch(self, items):
+        """items: [(stage outputs, records, G, nactual, label_override)] -> [cost_t]; ONE launch for all stages."""
+        built = [self._cost_desc(*it) for it in items]
+        arr = (L.MatchDesc * len(built))(*[d for d, _ in built])
+        L.check(L.lib().vdetr_match_cost_batch_f32(arr, len(built), L.stream_ptr()), "match_cost")
+        return [keep["cost_t"] for _, keep in built]
+
+    def _cost_desc(self, o, records, G, nactual, label_override=-1, want_giou=False):
         cls = o["sem_cls_prob"].detach().contiguous()
         B, P, C = cls.shape
         A = o["angle_logits"].shape[-1]
@@ -116,8 +128,7 @@ class Matcher(nn.Module):
         keep["giou_t"] = cls.new_empty((B, G, P)) if want_giou else None
         for k, t in keep.items():
             setattr(d, k, t.data_ptr() if t is not None else None)
-        L.check(L.lib().vdetr_match_cost_f32(ctypes.byref(d), L.stream_ptr()), "match_cost")
-        return keep["cost_t"], keep["giou_t"]
+        return d, keep
 
     @staticmethod
     def solve(problems, status=None):
@@ -177,15 +188,15 @@ class _CriterionFn(torch.autograd.Function):
             off += n
         m = crit.matcher
         # 1) cost matrices of every stage, 2) one assignment launch, 3) losses + gradients per stage
-        problems, metas = [], []
-        for si, (o, repeated, override) in enumerate(stages):
+        metas = []
+        for o, repeated, override in stages:
             records, G, nactual, nb = prep.stage(repeated)
-            cost_t, _ = m.cost(o, records, G, nactual, label_override=override)
-            problems.append((cost_t, nactual, prep.repeat if repeated else 0))
             metas.append((records, G, nactual, nb, override))
+        costs = m.cost_batch([(o, mt[0], mt[1], mt[2], mt[4]) for (o, _, _), mt in zip(stages, metas)])
+        problems = [(c, mt[2], prep.repeat if rep else 0) for c, mt, (_, rep, _) in zip(costs, metas, stages)]
         matches = m.solve(problems)
         lib, st = L.lib(), L.stream_ptr()
-        keep = []
+        keep, loss_descs = [], []
         for si, ((o, repeated, override), (records, G, nactual, nb, _), (inds, mask)) in enumerate(zip(stages, metas, matches)):
             ins = [t.detach().contiguous() for t in diff[si * 6:si * 6 + 6]]
             g = grads[si * 6:si * 6 + 6]
@@ -208,7 +219,7 @@ class _CriterionFn(torch.autograd.Function):
             d.card_ws = losses[si].data_ptr() + 32
             (d.d_cls_logits, d.d_center_reg, d.d_size_reg, d.d_corners, d.d_angle_logits,
              d.d_angle_res_norm) = (t.data_ptr() for t in g)
-            L.check(lib.vdetr_set_loss_f32(ctypes.byref(d), st), "set_loss")
+            loss_descs.append(d)
             keep.append((ins, pre_c, pre_s))
         point_labels = None
         if point is not None:
@@ -226,7 +237,11 @@ class _CriterionFn(torch.autograd.Function):
             d.cls_logits, d.labels, d.nactual, d.num_boxes = logits.data_ptr(), point_labels.data_ptr(), nactual.data_ptr(), nb.data_ptr()
             d.losses, d.d_cls_logits = losses[ns].data_ptr(), grads[-1].data_ptr()
             d.card_ws = losses[ns].data_ptr() + 32
-            L.check(lib.vdetr_set_loss_f32(ctypes.byref(d), st), "set_loss(point_cls)")
+            loss_descs.append(d)
+            keep.append((seed_xyz, logits))
+        # every stage's losses + gradients and the seed-point loss: ONE launch
+        arr = (L.SetLossDesc * len(loss_descs))(*loss_descs)
+        L.check(lib.vdetr_set_loss_batch_f32(arr, len(loss_descs), st), "set_loss")
         total = losses[:, 7].sum()
         ctx.flat, ctx.grads = flat, grads
         ctx.mark_non_differentiable(losses)

@@ -134,10 +134,24 @@ struct GtDerived {
   int label, alabel;
 };
 
-__global__ __launch_bounds__(256) void match_cost_kernel(vdetr_match_desc d) {
+constexpr int kCritBatch = 12;  // stage descriptors per launch (kernel arguments: 12 x 232 B < 4 KB)
+struct MatchBatch {
+  vdetr_match_desc d[kCritBatch];
+};
+struct LossBatch {
+  vdetr_setloss_desc d[kCritBatch];
+};
+
+// All stages of a step in ONE launch: blockIdx.z enumerates (stage, scene); the grid is sized for the largest stage and
+// the workgroups outside a smaller stage's extent leave at once.
+__global__ __launch_bounds__(256) void match_cost_kernel(MatchBatch batch) {
   __shared__ GtDerived sh[kMatchBoxes];
-  const int b = blockIdx.z;
+  int z = blockIdx.z, stage = 0;
+  while (z >= batch.d[stage].B) z -= batch.d[stage++].B;
+  const vdetr_match_desc d = batch.d[stage];
+  const int b = z;
   const int g0 = blockIdx.y * kMatchBoxes;
+  if (g0 >= d.G || (int)(blockIdx.x * blockDim.x) >= d.P) return;
   const int ng = min(kMatchBoxes, d.G - g0);
   if ((int)threadIdx.x < ng) {
     const float* r = d.gt + ((size_t)b * d.G + g0 + threadIdx.x) * F;
@@ -563,11 +577,16 @@ constexpr int kLossRows = 256;  // rows (proposals / seed points) per workgroup
 
 // Phase A, one thread per row: the row's label, the box terms of its matched pair with their gradients, the arg-max for
 // the cardinality count.  Phase B, all threads over the chunk's rows x C logits (coalesced): focal loss + gradient.
-__global__ __launch_bounds__(kLossRows) void set_loss_kernel(vdetr_setloss_desc d) {
+__global__ __launch_bounds__(kLossRows) void set_loss_kernel(LossBatch batch) {
   __shared__ float red[kLossRows / 64][8];
   __shared__ int lab[kLossRows];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  int z = blockIdx.y, stage = 0;
+  while (z >= batch.d[stage].B) z -= batch.d[stage++].B;
+  const vdetr_setloss_desc d = batch.d[stage];
+  const int b = z, tid = threadIdx.x;
   const int p0 = blockIdx.x * kLossRows;
+  if (p0 >= d.P) return;
+  const unsigned row_chunks = (unsigned)((d.P + kLossRows - 1) / kLossRows);  // this stage's workgroups per scene
   const int rows = min(kLossRows, d.P - p0);
   long total_boxes = 0;
   for (int i = 0; i < d.B; ++i) total_boxes += d.nactual[i];
@@ -695,7 +714,7 @@ __global__ __launch_bounds__(kLossRows) void set_loss_kernel(vdetr_setloss_desc 
     // workgroup that draws the last ticket holds the total without any fence
     const unsigned long long add = (1ull << 32) | (unsigned long long)(unsigned)sm[6];
     const unsigned long long old = atomicAdd(d.card_ws + b, add);
-    if ((unsigned)(old >> 32) == gridDim.x - 1) {
+    if ((unsigned)(old >> 32) == row_chunks - 1) {
       const float count = (float)((unsigned)old + (unsigned)sm[6]);
       atomicAdd(d.losses + 6, fabsf(count - (float)d.nactual[b]) / (float)d.B);
     }
@@ -716,16 +735,43 @@ extern "C" int vdetr_gt_prepare_f32(const float* gt, int B, int G, int repeat, f
   return check_launch("gt_prepare");
 }
 
-extern "C" int vdetr_match_cost_f32(const vdetr_match_desc* d, vdetr_stream_t stream) {
-  VDETR_REQUIRE(d != nullptr, "match_cost: null descriptor");
+static int check_match_desc(const vdetr_match_desc* d) {
   VDETR_REQUIRE(d->B >= 1 && d->P >= 1 && d->G >= 1 && d->C >= 1 && d->A >= 1, "match_cost: bad sizes");
   VDETR_REQUIRE(d->cls && d->objectness && d->center_reg && d->size_reg && d->pre_center && d->pre_size && d->corners &&
                     d->angle_logits && d->angle_res_norm && d->gt && d->nactual && d->cost_t,
                 "match_cost: null pointer");
   VDETR_REQUIRE(d->label_override < d->C, "match_cost: label_override %d >= C %d", d->label_override, d->C);
-  const dim3 grid(ceil_div(d->P, 256), ceil_div(d->G, kMatchBoxes), d->B);
-  hipLaunchKernelGGL(match_cost_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
-  return check_launch("match_cost");
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_match_cost_batch_f32(const vdetr_match_desc* descs, int n, vdetr_stream_t stream) {
+  VDETR_REQUIRE(descs != nullptr && n >= 1, "match_cost: null descriptors");
+  for (int s0 = 0; s0 < n; s0 += kCritBatch) {
+    const int cnt = n - s0 < kCritBatch ? n - s0 : kCritBatch;
+    MatchBatch batch{};
+    int maxp = 1, maxg = 1, zs = 0;
+    for (int k = 0; k < kCritBatch; ++k) {
+      if (k >= cnt) {
+        batch.d[k].B = 1 << 30;  // terminates the (stage, scene) search
+        continue;
+      }
+      if (int e = check_match_desc(descs + s0 + k)) return e;
+      batch.d[k] = descs[s0 + k];
+      maxp = batch.d[k].P > maxp ? batch.d[k].P : maxp;
+      maxg = batch.d[k].G > maxg ? batch.d[k].G : maxg;
+      zs += batch.d[k].B;
+    }
+    VDETR_REQUIRE(zs <= 65535, "match_cost: %d (stage, scene) pairs > 65535", zs);
+    const dim3 grid(ceil_div(maxp, 256), ceil_div(maxg, kMatchBoxes), zs);
+    hipLaunchKernelGGL(match_cost_kernel, grid, dim3(256), 0, (hipStream_t)stream, batch);
+    if (int e = check_launch("match_cost")) return e;
+  }
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_match_cost_f32(const vdetr_match_desc* d, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr, "match_cost: null descriptor");
+  return vdetr_match_cost_batch_f32(d, 1, stream);
 }
 
 extern "C" int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdetr_stream_t stream) {
@@ -790,8 +836,7 @@ extern "C" int vdetr_point_labels_f32(const float* seed_xyz, const float* gt, co
   return check_launch("point_labels");
 }
 
-extern "C" int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream) {
-  VDETR_REQUIRE(d != nullptr, "set_loss: null descriptor");
+static int check_loss_desc(const vdetr_setloss_desc* d) {
   VDETR_REQUIRE(d->B >= 1 && d->P >= 1 && d->C >= 1, "set_loss: bad sizes");
   VDETR_REQUIRE(d->cls_logits && d->d_cls_logits && d->nactual && d->num_boxes && d->losses, "set_loss: null pointer");
   VDETR_REQUIRE((d->inds != nullptr && d->mask != nullptr && d->gt != nullptr) || d->labels != nullptr,
@@ -803,6 +848,33 @@ extern "C" int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t st
                   "set_loss: box terms need all box pointers");
   }
   VDETR_REQUIRE(d->card_ws != nullptr, "set_loss: card_ws (B zero-initialised uint64) is required");
-  hipLaunchKernelGGL(set_loss_kernel, dim3(ceil_div(d->P, kLossRows), d->B), dim3(kLossRows), 0, (hipStream_t)stream, *d);
-  return check_launch("set_loss");
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_set_loss_batch_f32(const vdetr_setloss_desc* descs, int n, vdetr_stream_t stream) {
+  VDETR_REQUIRE(descs != nullptr && n >= 1, "set_loss: null descriptors");
+  for (int s0 = 0; s0 < n; s0 += kCritBatch) {
+    const int cnt = n - s0 < kCritBatch ? n - s0 : kCritBatch;
+    LossBatch batch{};
+    int maxp = 1, ys = 0;
+    for (int k = 0; k < kCritBatch; ++k) {
+      if (k >= cnt) {
+        batch.d[k].B = 1 << 30;
+        continue;
+      }
+      if (int e = check_loss_desc(descs + s0 + k)) return e;
+      batch.d[k] = descs[s0 + k];
+      maxp = batch.d[k].P > maxp ? batch.d[k].P : maxp;
+      ys += batch.d[k].B;
+    }
+    VDETR_REQUIRE(ys <= 65535, "set_loss: %d (stage, scene) pairs > 65535", ys);
+    hipLaunchKernelGGL(set_loss_kernel, dim3(ceil_div(maxp, kLossRows), ys), dim3(kLossRows), 0, (hipStream_t)stream, batch);
+    if (int e = check_launch("set_loss")) return e;
+  }
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr, "set_loss: null descriptor");
+  return vdetr_set_loss_batch_f32(d, 1, stream);
 }
