@@ -371,9 +371,9 @@ int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry,
 
 /* gt [B,G,F] -> gt_rep [B,G*repeat,F]: the list tiled `repeat` times, present boxes first in stable order, the rest
  * zero (criterion.py:511-590); nactual[B] / nactual_rep[B] = present counts (:592, :660); sums[0] = sum nactual,
- * sums[1] = sum nactual_rep as floats (the caller averages them over ranks and clamps at 1: :593, :661).  A present box
- * with a positive angle would need the rotated-polygon GIoU (criterion.py:616, box_util.py:566-589), which is not
- * implemented: both sums are then NaN so that every loss built on them is NaN. */
+ * sums[1] = sum nactual_rep as floats (the caller averages them over ranks and clamps at 1: :593, :661);
+ * sums[2] = 1 if any slot has a positive angle (torch.any(gt_box_angles > 0), criterion.py:616: selects the rotated GIoU),
+ * else 0.  `sums` holds 3 floats. */
 int vdetr_gt_prepare_f32(const float* gt, int B, int G, int repeat, float* gt_rep, int64_t* nactual, int64_t* nactual_rep,
                          float* sums, vdetr_stream_t stream);
 
@@ -392,6 +392,8 @@ typedef struct vdetr_match_desc {
   const int64_t* nactual;   /* [B] */
   float* cost_t;            /* [B,G,P]: final_cost[b,p,g] stored box-major (columns >= nactual[b] are not read by the solver) */
   float* giou_t;            /* optional [B,G,P] pairwise GIoU (outputs["gious"], box-major), or NULL */
+  const float* rotated;     /* device scalar (sums[2] of vdetr_gt_prepare_f32) != 0: footprint overlap by polygon clipping
+                               (rotated_boxes=True, criterion.py:616, box_util.py:566-589); NULL = axis-aligned */
 } vdetr_match_desc;
 int vdetr_match_cost_f32(const vdetr_match_desc* d, vdetr_stream_t stream);
 /* the same for n stage descriptors (HOST array; shapes may differ) in one launch per 12 descriptors */
@@ -448,6 +450,7 @@ typedef struct vdetr_setloss_desc {
   float* losses;
   unsigned long long* card_ws; /* [B] zero-initialised scratch of the cardinality count (one 64-bit atomic per workgroup) */
   float *d_cls_logits, *d_center_reg, *d_size_reg, *d_corners, *d_angle_logits, *d_angle_res_norm; /* d total / d input; written in full */
+  const float* rotated;    /* as in vdetr_match_desc */
 } vdetr_setloss_desc;
 int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream);
 /* the same for n descriptors (HOST array: all stages of a step + the seed-point loss) in one launch per 12 descriptors */

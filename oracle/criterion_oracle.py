@@ -16,8 +16,9 @@ Third-party pieces that are NOT under /root/reference:
     semantics (mmcv/ops/csrc/common/cuda/points_in_boxes_cuda_kernel.cuh, check_pt_in_box3d): a box is
     (x, y, z_bottom, dx, dy, dz, yaw); a point is inside iff |z - (z_bottom + dz/2)| <= dz/2 and, after rotating
     (x - cx, y - cy) by -yaw, -dx/2 < lx < dx/2 and -dy/2 < ly < dy/2 (strict).  PARITY UNPINNED for this one function.
-  * rotated boxes (gt angle > 0) go through a Python polygon-clipping triple loop in the reference
-    (box_util.py:566-589); not restated -- `rotated=True` raises.
+  * rotated boxes (any gt angle > 0, criterion.py:616) replace the axis-aligned footprint overlap by the area of the
+    Sutherland-Hodgman clip of the two footprint quadrilaterals (box_util.py:393-439, 566-589); restated in
+    `clip_area` with the reference's predicates and formulas (differentiable w.r.t. the prediction's corners).
 
 PINNED: tests/golden/criterion_*.npz hold inputs / losses / assignments / gradients produced by the reference's own
 criterion.py imported in the build container (oracle/make_golden.py, mmcv stubbed with the restatement above);
@@ -42,9 +43,48 @@ def _edge(c, i, j):
     return ((c[..., i, :] - c[..., j, :]) ** 2).sum(-1).clamp(min=1e-6).sqrt()
 
 
-def pairwise_giou(c1, c2, nactual):
+def _inside(c1, c2, p):
+    """box_util.py:405-407: p strictly on the left of the directed clip edge c1 -> c2"""
+    return bool((c2[0] - c1[0]) * (p[1] - c1[1]) > (c2[1] - c1[1]) * (p[0] - c1[0]))
+
+
+def _cross_point(c1, c2, s, e):
+    """box_util.py:393-402: intersection of the lines c1c2 and se"""
+    dcx, dcy = c1[0] - c2[0], c1[1] - c2[1]
+    dpx, dpy = s[0] - e[0], s[1] - e[1]
+    n1 = c1[0] * c2[1] - c1[1] * c2[0]
+    n2 = s[0] * e[1] - s[1] * e[0]
+    n3 = 1.0 / (dcx * dpy - dcy * dpx)
+    return torch.stack([(n1 * dpx - n2 * dcx) * n3, (n1 * dpy - n2 * dcy) * n3])
+
+
+def clip_area(subject, clip):
+    """Twice the area (before the reference's final *0.5, applied by the caller) of `subject` [4,2] clipped by the convex
+    `clip` [4,2] (box_util.py:410-439 + the shoelace sum of :583-588); 0 if nothing is left."""
+    poly = [subject[i] for i in range(subject.shape[0])]
+    c1 = clip[-1]
+    for c2 in clip:
+        src, poly = poly, []
+        s = src[-1]
+        for e in src:
+            if _inside(c1, c2, e):
+                if not _inside(c1, c2, s):
+                    poly.append(_cross_point(c1, c2, s, e))
+                poly.append(e)
+            elif _inside(c1, c2, s):
+                poly.append(_cross_point(c1, c2, s, e))
+            s = e
+        c1 = c2
+        if not poly:
+            return subject.new_zeros(())
+    xs = torch.stack([v[0] for v in poly])
+    ys = torch.stack([v[1] for v in poly])
+    return (torch.dot(xs, torch.roll(ys, 1)) - torch.dot(ys, torch.roll(xs, 1))).abs()
+
+
+def pairwise_giou(c1, c2, nactual, rotated=False):
     """c1 [B,P,8,3], c2 [B,G,8,3] camera-frame corners (y down), nactual [B] -> GIoU [B,P,G]; columns >= nactual are 0.
-    Axis-aligned intersection (box_util.py:545-556 with rotated_boxes=False)."""
+    rotated=False: axis-aligned footprint overlap (box_util.py:545-556); True: polygon clip where that overlap is > 0."""
     B, P, G = c1.shape[0], c1.shape[1], c2.shape[1]
     top = torch.minimum(c1[:, :, 0, 1, None], c2[:, None, :, 0, 1])          # y is negative-up: top = min
     bot = torch.maximum(c1[:, :, 4, 1, None], c2[:, None, :, 4, 1])
@@ -54,6 +94,18 @@ def pairwise_giou(c1, c2, nactual):
     wh = (hi - lo).clamp(min=0)
     valid = (torch.arange(G)[None, :] < nactual[:, None]).to(c1.dtype)[:, None, :]        # [B,1,G]
     area = wh[..., 0] * wh[..., 1] * valid
+    if rotated:
+        order = [3, 2, 1, 0]
+        r1, r2 = c1[:, :, order][..., [0, 2]], c2[:, :, order][..., [0, 2]]    # footprints, counter-clockwise (:539-544)
+        rows = []
+        for b in range(B):
+            cols = []
+            for p in range(P):
+                cols.append(torch.stack([0.5 * clip_area(r1[b, p], r2[b, g].detach())
+                                         if g < int(nactual[b]) and float(area[b, p, g]) != 0.0 else area.new_zeros(())
+                                         for g in range(G)]))
+            rows.append(torch.stack(cols))
+        area = torch.stack(rows)
     # enclosing axis-aligned box (box_util.py:466-505; y flipped, hence the swapped min/max on that axis)
     mn1, mx1 = c1.min(2).values, c1.max(2).values
     mn2, mx2 = c2.min(2).values, c2.max(2).values
@@ -131,7 +183,8 @@ def huber(e, delta=1.0):
 
 def pair_terms(o, t):
     """The three pairwise matrices single_output_forward attaches to the outputs (criterion.py:618-631)."""
-    giou = pairwise_giou(o["box_corners"], t["gt_box_corners"], t["nactual_gt"])
+    rotated = bool((t["gt_box_angles"] > 0).any())                                    # criterion.py:616
+    giou = pairwise_giou(o["box_corners"], t["gt_box_corners"], t["nactual_gt"], rotated)
     pc, ps = o["pre_box_center_unnormalized"][:, :, None], o["pre_box_size_unnormalized"][:, :, None]
     want_c = (t["gt_box_centers"][:, None] - pc) / (ps + 1e-5)
     center = (o["center_reg"][:, :, None] - want_c).abs().sum(-1)

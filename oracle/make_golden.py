@@ -218,11 +218,14 @@ def import_reference_criterion():
     return C
 
 
-def synthetic_stage(g, cfg, B, P, C, nbin=1):
+def synthetic_stage(g, cfg, B, P, C, nbin=1, rotated=False, near=None):
     """One stage's box-prediction dictionary with the keys/shapes of vdetr_transformer.py:319-333, from random heads."""
     lo, ext = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([8.0, 6.0, 3.0])
     pre_c = lo + torch.rand((B, P, 3), generator=g) * ext
     pre_s = 0.3 + torch.rand((B, P, 3), generator=g) * 1.5
+    if near is not None:  # some priors next to given centres, so that boxes really overlap
+        k = near.shape[1]
+        pre_c[:, :2 * k] = near.repeat(1, 2, 1) + 0.3 * torch.randn((B, 2 * k, 3), generator=g)
     center_reg = (torch.randn((B, P, 3), generator=g) * 0.3).requires_grad_(True)
     size_reg = (torch.randn((B, P, 3), generator=g) * 0.3).requires_grad_(True)
     logits = (torch.randn((B, P, C), generator=g) * 2 - 2).requires_grad_(True)
@@ -231,7 +234,8 @@ def synthetic_stage(g, cfg, B, P, C, nbin=1):
     center = center_reg * pre_s + pre_c
     size = torch.exp(size_reg) * pre_s
     # a leaf: the fixture holds d loss / d corners itself (the chain into centre/size is the box decode's business)
-    corners = cfg.box_parametrization_to_corners(center.detach(), size.detach(), torch.zeros((B, P))).requires_grad_(True)
+    angle = (torch.rand((B, P), generator=g) - 0.5) * 2.0 if rotated else torch.zeros((B, P))
+    corners = cfg.box_parametrization_to_corners(center.detach(), size.detach(), angle).requires_grad_(True)
     return {"sem_cls_logits": logits, "sem_cls_prob": logits, "center_unnormalized": center, "size_unnormalized": size,
             "center_normalized": center, "size_normalized": size,
             "angle_logits": angle_logits, "angle_residual_normalized": angle_res,
@@ -240,7 +244,7 @@ def synthetic_stage(g, cfg, B, P, C, nbin=1):
             "pre_box_size_unnormalized": pre_s, "size_reg": size_reg}
 
 
-def synthetic_targets(g, cfg, B, G, counts, nclass):
+def synthetic_targets(g, cfg, B, G, counts, nclass, rotated=False):
     lo, ext = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([8.0, 6.0, 3.0])
     centers = lo + torch.rand((B, G, 3), generator=g) * ext
     sizes = 0.3 + torch.rand((B, G, 3), generator=g) * 1.7
@@ -250,11 +254,12 @@ def synthetic_targets(g, cfg, B, G, counts, nclass):
     if counts[0] >= 3:       # a hole in the list: the compaction of repeat_ground_truth is exercised
         present[0, 1] = 0
     centers, sizes = centers * present[..., None], sizes * present[..., None]
-    corners = cfg.box_parametrization_to_corners(centers, sizes, torch.zeros((B, G))) * present[..., None, None]
+    angles = (torch.rand((B, G), generator=g) * 1.2 + 0.05) * present if rotated else torch.zeros((B, G))
+    corners = cfg.box_parametrization_to_corners(centers, sizes, angles) * present[..., None, None]
     labels = (torch.randint(0, nclass, (B, G), generator=g) * present.long())
     return {"gt_box_corners": corners, "gt_box_centers": centers, "gt_box_centers_normalized": centers / 10.0,
             "gt_box_sem_cls_label": labels, "gt_box_present": present, "gt_box_sizes": sizes,
-            "gt_box_sizes_normalized": sizes / 10.0, "gt_box_angles": torch.zeros((B, G)),
+            "gt_box_sizes_normalized": sizes / 10.0, "gt_box_angles": angles,
             "gt_angle_class_label": torch.zeros((B, G), dtype=torch.int64),
             "gt_angle_residual_label": torch.zeros((B, G)), "scan_idx": torch.arange(B)}
 
@@ -271,12 +276,17 @@ def criterion_cases(Cfg):
     for name, B, N0, P, S, G, counts, rep in [("criterion_small", 2, 96, 48, 2, 8, (5, 3), 5),
                                               ("criterion_wide", 2, 64, 16, 1, 8, (7, 0), 5),   # 5*7 gt > 16 queries; empty scene
                                               ("criterion_norepeat", 1, 80, 40, 1, 8, (6,), 1),
-                                              ("criterion_empty", 1, 32, 16, 1, 8, (0,), 5)]:
+                                              ("criterion_empty", 1, 32, 16, 1, 8, (0,), 5),
+                                              # rotated ground truth: the footprint overlap becomes a polygon clip
+                                              ("criterion_rotated", 1, 48, 24, 1, 8, (5,), 5)]:
         g = torch.Generator().manual_seed(sum(map(ord, name)))
         a = Namespace(**{**base, "repeat_num": rep})
         crit = C.build_criterion(a, cfg)
-        targets = synthetic_targets(g, cfg, B, G, counts, cfg.num_semcls)
-        stages = [synthetic_stage(g, cfg, B, N0, 1)] + [synthetic_stage(g, cfg, B, P, cfg.num_semcls) for _ in range(S + 1)]
+        rot = name == "criterion_rotated"
+        targets = synthetic_targets(g, cfg, B, G, counts, cfg.num_semcls, rotated=rot)
+        near = targets["gt_box_centers"][:, :counts[0]] if rot else None
+        stages = [synthetic_stage(g, cfg, B, N0, 1, rotated=rot, near=near)] + [
+            synthetic_stage(g, cfg, B, P, cfg.num_semcls, rotated=rot, near=near) for _ in range(S + 1)]
         seed_xyz = torch.tensor([1.0, 1.0, 1.0]) + torch.rand((B, N0, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0])
         seed_xyz[:, :G] = targets["gt_box_centers"]                 # some seeds certainly inside a box
         point_logits = (torch.randn((B, N0, cfg.num_semcls), generator=g) - 1).requires_grad_(True)

@@ -10,7 +10,7 @@ from oracle import criterion_oracle as CO
 from oracle.lsa_oracle import linear_sum_assignment as lsa_restated
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CASES = ["criterion_small", "criterion_wide", "criterion_norepeat", "criterion_empty"]
+CASES = ["criterion_small", "criterion_wide", "criterion_norepeat", "criterion_empty", "criterion_rotated"]
 DIFF = ("sem_cls_logits", "center_reg", "size_reg", "angle_logits", "angle_residual_normalized", "box_corners")
 
 

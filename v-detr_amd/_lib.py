@@ -100,7 +100,7 @@ VDETR_LSA_MAX_PROBLEMS = 16
 
 _MATCH_W = ("w_cls", "w_objectness", "w_center", "w_giou", "w_size", "w_angle_cls", "w_angle_reg")
 _MATCH_PTR = ("cls", "objectness", "center_reg", "size_reg", "pre_center", "pre_size", "corners", "angle_logits",
-              "angle_res_norm", "gt", "nactual", "cost_t", "giou_t")
+              "angle_res_norm", "gt", "nactual", "cost_t", "giou_t", "rotated")
 
 
 class MatchDesc(ctypes.Structure):
@@ -126,7 +126,7 @@ class LsaBatch(ctypes.Structure):
 _LOSS_W = ("w_cls", "w_angle_cls", "w_angle_reg", "w_center", "w_size", "w_giou")
 _LOSS_PTR = ("cls_logits", "center_reg", "size_reg", "pre_center", "pre_size", "corners", "angle_logits", "angle_res_norm",
              "gt", "nactual", "inds", "mask", "labels", "num_boxes", "losses", "card_ws", "d_cls_logits", "d_center_reg", "d_size_reg",
-             "d_corners", "d_angle_logits", "d_angle_res_norm")
+             "d_corners", "d_angle_logits", "d_angle_res_norm", "rotated")
 
 
 class SetLossDesc(ctypes.Structure):

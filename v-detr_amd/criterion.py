@@ -16,11 +16,10 @@ No host synchronisation anywhere (the reference has >= 30 per step: ``.item()``,
 integers), so the whole training step including the criterion can be captured in one hipGraph.  ``nactual_gt`` and
 ``num_boxes`` stay device tensors.
 
-Scope: ``cls_loss="focalloss_*"`` and ``iou_type="giou"`` on axis-aligned ground truth (the ScanNet configuration, the
-only one the reference ships a loader for).  Other settings raise; ground truth with a positive ``gt_box_angles`` entry
-would need the rotated-polygon GIoU (box_util.py:566-589) and poisons the loss with NaN instead of being mis-scored
-(no host check is possible without a sync; the reference's ``math.isfinite`` guard, engine.py:99-101, then stops).
-There is no CPU path: CPU tensors raise.
+Scope: ``cls_loss="focalloss_*"`` and ``iou_type="giou"`` (the reference defaults); other settings raise.  Rotated ground
+truth (any ``gt_box_angles`` > 0, criterion.py:616) switches the GIoU's footprint overlap to the polygon clip of
+box_util.py:566-589 through a device flag -- the reference decides that with ``.item()``.  There is no CPU path: CPU
+tensors raise.
 """
 import ctypes
 
@@ -58,7 +57,7 @@ class PreparedTargets:
         self.B, self.G, self.repeat = B, G, max(int(repeat_num), 1)
         self.gt = gt
         self.nactual = torch.empty(B, dtype=torch.int64, device=dev)
-        self.sums = torch.empty(2, dtype=torch.float32, device=dev)
+        self.sums = torch.empty(4, dtype=torch.float32, device=dev)  # box counts (plain, repeated), rotated flag, pad
         if self.repeat > 1:
             self.gt_rep = torch.empty((B, G * self.repeat, L.VDETR_GT_FLOATS), dtype=torch.float32, device=dev)
             self.nactual_rep = torch.empty(B, dtype=torch.int64, device=dev)
@@ -68,9 +67,11 @@ class PreparedTargets:
                                              L.ptr(self.nactual_rep), L.ptr(self.sums), L.stream_ptr()), "gt_prepare")
         # all_reduce_average(nactual.sum()) then clamp(min=1)  (criterion.py:593, 661; utils/dist.py)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.sums)
-            self.sums /= dist.get_world_size()
-        self.num_boxes = self.sums.clamp(min=1.0)
+            counts = self.sums[:2]
+            dist.all_reduce(counts)
+            counts /= dist.get_world_size()
+        self.num_boxes = self.sums[:2].clamp(min=1.0)
+        self.rotated = self.sums[2:3]  # device flag: any gt angle > 0 on this rank (criterion.py:616 is evaluated per rank)
         if self.repeat == 1:
             self.gt_rep, self.nactual_rep = self.gt, self.nactual
 
@@ -92,20 +93,21 @@ class Matcher(nn.Module):
         self.matcher_anglecls_cost = args.matcher_anglecls_cost
         self.matcher_anglereg_cost = args.matcher_anglereg_cost
 
-    def cost(self, o, records, G, nactual, label_override=-1, want_giou=False):
-        """Launches the pairwise kernel of one stage.  Returns (cost_t [B,G,P], giou_t or None)."""
-        d, keep = self._cost_desc(o, records, G, nactual, label_override, want_giou)
+    def cost(self, o, records, G, nactual, label_override=-1, want_giou=False, rotated=None):
+        """Launches the pairwise kernel of one stage.  Returns (cost_t [B,G,P], giou_t or None).  ``rotated``: device scalar
+        (PreparedTargets.rotated) selecting the polygon-clip footprint overlap, None = axis-aligned."""
+        d, keep = self._cost_desc(o, records, G, nactual, label_override, want_giou, rotated)
         L.check(L.lib().vdetr_match_cost_f32(ctypes.byref(d), L.stream_ptr()), "match_cost")
         return keep["cost_t"], keep["giou_t"]
 
-    def cost_batch(self, items):
+    def cost_batch(self, items, rotated=None):
         """items: [(stage outputs, records, G, nactual, label_override)] -> [cost_t]; ONE launch for all stages."""
-        built = [self._cost_desc(*it) for it in items]
+        built = [self._cost_desc(*it, rotated=rotated) for it in items]
         arr = (L.MatchDesc * len(built))(*[d for d, _ in built])
         L.check(L.lib().vdetr_match_cost_batch_f32(arr, len(built), L.stream_ptr()), "match_cost")
         return [keep["cost_t"] for _, keep in built]
 
-    def _cost_desc(self, o, records, G, nactual, label_override=-1, want_giou=False):
+    def _cost_desc(self, o, records, G, nactual, label_override=-1, want_giou=False, rotated=None):
         cls = o["sem_cls_prob"].detach().contiguous()
         B, P, C = cls.shape
         A = o["angle_logits"].shape[-1]
@@ -115,7 +117,7 @@ class Matcher(nn.Module):
         d.label_override = label_override
         d.w_cls, d.w_objectness, d.w_center, d.w_giou = self.cost_class, self.cost_objectness, self.cost_center, self.cost_giou
         d.w_size, d.w_angle_cls, d.w_angle_reg = self.cost_size, self.matcher_anglecls_cost, self.matcher_anglereg_cost
-        keep = {"cls": cls, "gt": records, "nactual": nactual}
+        keep = {"cls": cls, "gt": records, "nactual": nactual, "rotated": rotated}
         for dst, src in (("objectness", "objectness_prob"), ("center_reg", "center_reg"), ("size_reg", "size_reg"),
                          ("pre_center", "pre_box_center_unnormalized"), ("pre_size", "pre_box_size_unnormalized"),
                          ("corners", "box_corners"), ("angle_logits", "angle_logits"),
@@ -164,7 +166,10 @@ class Matcher(nn.Module):
             nactual = nactual.to(torch.int64).contiguous()
         else:
             records, G, nactual = targets
-        cost_t, _ = self.cost(outputs, records, G, nactual)
+        rotated = None
+        if isinstance(targets, dict):
+            rotated = (targets["gt_box_angles"] > 0).any().to(torch.float32).reshape(1)   # criterion.py:616, on the device
+        cost_t, _ = self.cost(outputs, records, G, nactual, rotated=rotated)
         inds, mask = self.solve([(cost_t, nactual)])[0]
         return {"per_prop_gt_inds": inds, "proposal_matched_mask": mask}
 
@@ -192,7 +197,7 @@ class _CriterionFn(torch.autograd.Function):
         for o, repeated, override in stages:
             records, G, nactual, nb = prep.stage(repeated)
             metas.append((records, G, nactual, nb, override))
-        costs = m.cost_batch([(o, mt[0], mt[1], mt[2], mt[4]) for (o, _, _), mt in zip(stages, metas)])
+        costs = m.cost_batch([(o, mt[0], mt[1], mt[2], mt[4]) for (o, _, _), mt in zip(stages, metas)], rotated=prep.rotated)
         problems = [(c, mt[2], prep.repeat if rep else 0) for c, mt, (_, rep, _) in zip(costs, metas, stages)]
         matches = m.solve(problems)
         lib, st = L.lib(), L.stream_ptr()
@@ -215,6 +220,7 @@ class _CriterionFn(torch.autograd.Function):
             d.pre_center, d.pre_size = pre_c.data_ptr(), pre_s.data_ptr()
             d.gt, d.nactual, d.inds, d.mask, d.labels = records.data_ptr(), nactual.data_ptr(), inds.data_ptr(), mask.data_ptr(), None
             d.num_boxes = nb.data_ptr()
+            d.rotated = prep.rotated.data_ptr()
             d.losses = losses[si].data_ptr()
             d.card_ws = losses[si].data_ptr() + 32
             (d.d_cls_logits, d.d_center_reg, d.d_size_reg, d.d_corners, d.d_angle_logits,

@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void gt_prepare_kernel(const float* __restrict
         prefix[s] = n;
         const bool present = src[s * F + VDETR_GT_PRESENT] > 0.f;
         n += present;
-        // the reference switches to polygon clipping when any angle is positive (criterion.py:616); not implemented
-        rotated |= present && src[s * F + VDETR_GT_ANGLE] > 0.f;
+        // the reference tests every slot, and absent slots are zero (criterion.py:616 on the padded tensor)
+        rotated |= src[s * F + VDETR_GT_ANGLE] > 0.f;
       }
       prefix[G] = n;
     }
@@ -59,9 +59,10 @@ __global__ __launch_bounds__(256) void gt_prepare_kernel(const float* __restrict
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {  // rotated ground truth poisons the normaliser: every loss becomes NaN instead of mis-scored
-    sums[0] = rotated ? NAN : (float)total;
-    sums[1] = rotated ? NAN : (float)(total * repeat);
+  if (threadIdx.x == 0) {
+    sums[0] = (float)total;
+    sums[1] = (float)(total * repeat);
+    sums[2] = rotated ? 1.f : 0.f;  // criterion.py:616: torch.any(gt_box_angles > 0) selects the polygon-clip overlap
   }
 }
 
@@ -104,19 +105,130 @@ __device__ __forceinline__ BoxGeo box_geo(Ptr c) {
 }
 
 // generalized_box3d_iou_tensor with rotated_boxes=False (box_util.py:523-600) for one pair
-__device__ __forceinline__ float giou_pair(const BoxGeo& p, const BoxGeo& g) {
+// `area` = footprint overlap: wx * wz for axis-aligned boxes, the polygon clip (where wx * wz != 0) for rotated ones
+__device__ __forceinline__ float giou_pair(const BoxGeo& p, const BoxGeo& g, float area) {
   const float height = fmaxf(fminf(p.c0y, g.c0y) - fmaxf(p.c4y, g.c4y), 0.f);
-  const float wx = fmaxf(fminf(p.c0x, g.c0x) - fmaxf(p.c2x, g.c2x), 0.f);
-  const float wz = fmaxf(fminf(p.c0z, g.c0z) - fmaxf(p.c2z, g.c2z), 0.f);
   const float ex = fabsf(fmaxf(p.mx[0], g.mx[0]) - fminf(p.mn[0], g.mn[0]));
   const float ey = fabsf(fminf(-p.mx[1], -g.mx[1]) - fmaxf(-p.mn[1], -g.mn[1]));
   const float ez = fabsf(fmaxf(p.mx[2], g.mx[2]) - fminf(p.mn[2], g.mn[2]));
   const float enclosing = (ex * ey) * ez;
   const float total = p.vol + g.vol;
-  const float inter = (wx * wz) * height;
+  const float inter = area * height;
   const float uni = fmaxf(total - inter, 1e-8f);
   const float giou = inter / uni + (-(1.f - uni / enclosing));
   return (enclosing > 2e-8f && total > 4e-8f) ? giou : giou * 0.f;
+}
+
+__device__ __forceinline__ float aligned_overlap(const BoxGeo& p, const BoxGeo& g) {
+  const float wx = fmaxf(fminf(p.c0x, g.c0x) - fmaxf(p.c2x, g.c2x), 0.f);
+  const float wz = fmaxf(fminf(p.c0z, g.c0z) - fmaxf(p.c2z, g.c2z), 0.f);
+  return wx * wz;
+}
+
+// ---- rotated boxes: footprint overlap by Sutherland-Hodgman clipping (box_util.py:393-439, 566-589) ----------------
+// A footprint is the quadrilateral of corners 3,2,1,0 in (x,z) (counter-clockwise, box_util.py:539-544).  The subject is
+// the prediction, the clip polygon the ground-truth box.  NT > 0 carries NT forward-mode tangents per coordinate (the 8
+// footprint coordinates of the prediction), which yields d area / d corners without recording the clip sequence.
+template <int NT>
+struct ClipPoly {
+  float x[8], y[8];
+  float tx[NT > 0 ? 8 : 1][NT > 0 ? NT : 1], ty[NT > 0 ? 8 : 1][NT > 0 ? NT : 1];
+};
+
+__device__ __forceinline__ bool clip_inside(float c1x, float c1y, float c2x, float c2y, float px, float py) {
+  return (c2x - c1x) * (py - c1y) > (c2y - c1y) * (px - c1x);
+}
+
+// twice the area of subject clipped by clip (abs of the shoelace sum); grad[t] = d(that)/d(input t) when NT > 0
+template <int NT>
+__device__ float clip_area2(const float* sx, const float* sy, const float* cx, const float* cy, float* grad) {
+  ClipPoly<NT> a, b;
+  ClipPoly<NT>* in = &a;
+  ClipPoly<NT>* out = &b;
+  int n = 4;
+  for (int i = 0; i < 4; ++i) {
+    out->x[i] = sx[i], out->y[i] = sy[i];
+    if (NT > 0)
+      for (int t = 0; t < NT; ++t) out->tx[i][t] = t == 2 * i ? 1.f : 0.f, out->ty[i][t] = t == 2 * i + 1 ? 1.f : 0.f;
+  }
+  float c1x = cx[3], c1y = cy[3];
+  for (int ce = 0; ce < 4; ++ce) {
+    const float c2x = cx[ce], c2y = cy[ce];
+    ClipPoly<NT>* tmp = in;
+    in = out;
+    out = tmp;
+    const int nin = n;
+    n = 0;
+    int si = nin - 1;
+    for (int ei = 0; ei < nin; ++ei) {
+      const float ex = in->x[ei], ey = in->y[ei], px = in->x[si], py = in->y[si];
+      const bool e_in = clip_inside(c1x, c1y, c2x, c2y, ex, ey);
+      const bool s_in = clip_inside(c1x, c1y, c2x, c2y, px, py);
+      if (e_in != s_in) {  // the edge s -> e crosses the clip line: helper_computeIntersection
+        const float dcx = c1x - c2x, dcy = c1y - c2y;
+        const float dpx = px - ex, dpy = py - ey;
+        const float n1 = c1x * c2y - c1y * c2x;
+        const float n2 = px * ey - py * ex;
+        const float den = dcx * dpy - dcy * dpx;
+        const float n3 = 1.f / den;
+        const float ax = n1 * dpx - n2 * dcx, ay = n1 * dpy - n2 * dcy;
+        out->x[n] = ax * n3, out->y[n] = ay * n3;
+        if (NT > 0)
+          for (int t = 0; t < NT; ++t) {
+            const float dpx_t = in->tx[si][t] - in->tx[ei][t], dpy_t = in->ty[si][t] - in->ty[ei][t];
+            const float n2_t = in->tx[si][t] * ey + px * in->ty[ei][t] - in->ty[si][t] * ex - py * in->tx[ei][t];
+            const float n3_t = -(dcx * dpy_t - dcy * dpx_t) * n3 * n3;
+            out->tx[n][t] = (n1 * dpx_t - n2_t * dcx) * n3 + ax * n3_t;
+            out->ty[n][t] = (n1 * dpy_t - n2_t * dcy) * n3 + ay * n3_t;
+          }
+        ++n;
+      }
+      if (e_in) {
+        out->x[n] = ex, out->y[n] = ey;
+        if (NT > 0)
+          for (int t = 0; t < NT; ++t) out->tx[n][t] = in->tx[ei][t], out->ty[n][t] = in->ty[ei][t];
+        ++n;
+      }
+      si = ei;
+    }
+    c1x = c2x, c1y = c2y;
+    if (n == 0) {
+      if (NT > 0)
+        for (int t = 0; t < NT; ++t) grad[t] = 0.f;
+      return 0.f;
+    }
+  }
+  // xs . roll(ys, 1) - ys . roll(xs, 1)
+  float sum = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const int j = i == 0 ? n - 1 : i - 1;
+    sum += out->x[i] * out->y[j];
+  }
+  float sum2 = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const int j = i == 0 ? n - 1 : i - 1;
+    sum2 += out->y[i] * out->x[j];
+  }
+  const float raw = sum - sum2;
+  if (NT > 0) {
+    const float sg = raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
+    for (int t = 0; t < NT; ++t) {
+      float g = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const int j = i == 0 ? n - 1 : i - 1;
+        g += out->tx[i][t] * out->y[j] + out->x[i] * out->ty[j][t] - out->ty[i][t] * out->x[j] - out->y[i] * out->tx[j][t];
+      }
+      grad[t] = sg * g;
+    }
+  }
+  return fabsf(raw);
+}
+
+// footprint (x,z) of corners 3,2,1,0
+template <typename Ptr>
+__device__ __forceinline__ void footprint(Ptr c, float* fx, float* fz) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fx[i] = c[(3 - i) * 3], fz[i] = c[(3 - i) * 3 + 2];
 }
 
 __device__ __forceinline__ float huber1(float e) {
@@ -129,6 +241,7 @@ constexpr int kMatchBoxes = 16;  // ground-truth boxes per workgroup
 
 struct GtDerived {
   BoxGeo geo;
+  float fx[4], fz[4];  // footprint (rotated boxes)
   float center[3], size[3];
   float ares_norm;
   int label, alabel;
@@ -157,6 +270,7 @@ __global__ __launch_bounds__(256) void match_cost_kernel(MatchBatch batch) {
     const float* r = d.gt + ((size_t)b * d.G + g0 + threadIdx.x) * F;
     GtDerived& s = sh[threadIdx.x];
     s.geo = box_geo(r + VDETR_GT_CORNERS);
+    footprint(r + VDETR_GT_CORNERS, s.fx, s.fz);
 #pragma unroll
     for (int a = 0; a < 3; ++a) s.center[a] = r[VDETR_GT_CENTER + a], s.size[a] = r[VDETR_GT_SIZE + a];
     s.label = d.label_override >= 0 ? d.label_override : (int)r[VDETR_GT_LABEL];
@@ -168,6 +282,9 @@ __global__ __launch_bounds__(256) void match_cost_kernel(MatchBatch batch) {
   if (p >= d.P) return;
   const size_t row = (size_t)b * d.P + p;
   const BoxGeo pg = box_geo(d.corners + row * 24);
+  const bool rot = d.rotated != nullptr && d.rotated[0] != 0.f;
+  float pfx[4], pfz[4];
+  footprint(d.corners + row * 24, pfx, pfz);
   float creg[3], sreg[3], pc[3], ps[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -184,7 +301,14 @@ __global__ __launch_bounds__(256) void match_cost_kernel(MatchBatch batch) {
 #pragma unroll 4
   for (int gi = 0; gi < ng; ++gi) {
     const GtDerived& s = sh[gi];
-    const float giou = giou_pair(pg, s.geo);
+    float area = aligned_overlap(pg, s.geo);
+    if (rot && area != 0.f && g0 + gi < nact) {  // box_util.py:571-589
+      float gfx[4], gfz[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gfx[i] = s.fx[i], gfz[i] = s.fz[i];
+      area = 0.5f * clip_area2<0>(pfx, pfz, gfx, gfz, nullptr);
+    }
+    const float giou = giou_pair(pg, s.geo, area);
     float center = 0.f, size = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -496,7 +620,8 @@ __device__ __forceinline__ float take_max(float a, float b) { return a > b ? 1.f
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
 // d (1 - giou) * scale / d corners of the prediction; returns giou.  dc[24] is overwritten.
-__device__ __forceinline__ float giou_grad(const float* c, const BoxGeo& p, const BoxGeo& g, float scale, float* dc) {
+__device__ __forceinline__ float giou_grad(const float* c, const BoxGeo& p, const BoxGeo& g, float scale, float* dc, bool rot,
+                                           const float* gt_corners) {
 #pragma unroll
   for (int k = 0; k < 24; ++k) dc[k] = 0.f;
   const float top = fminf(p.c0y, g.c0y), bot = fmaxf(p.c4y, g.c4y);
@@ -511,7 +636,19 @@ __device__ __forceinline__ float giou_grad(const float* c, const BoxGeo& p, cons
   const float e01 = edge_len(c, 0, 1), e12 = edge_len(c, 1, 2), e04 = edge_len(c, 0, 4);
   const float vraw = (e01 * e12) * e04;
   const float total = p.vol + g.vol;
-  const float area = wx * wz, inter = area * height;
+  float area = wx * wz;
+  float clip_grad[8];
+  bool clipped = false;
+  if (rot) {  // footprint overlap by polygon clipping where the axis-aligned test sees one (box_util.py:571-589)
+    if (area != 0.f) {
+      float pfx[4], pfz[4], gfx[4], gfz[4];
+      footprint(c, pfx, pfz);
+      footprint(gt_corners, gfx, gfz);
+      area = 0.5f * clip_area2<8>(pfx, pfz, gfx, gfz, clip_grad);
+      clipped = true;
+    }
+  }
+  const float inter = area * height;
   const float uraw = total - inter, uni = fmaxf(uraw, 1e-8f);
   const float giou = inter / uni + (-(1.f - uni / enclosing));
   const bool good = enclosing > 2e-8f && total > 4e-8f;
@@ -543,12 +680,20 @@ __device__ __forceinline__ float giou_grad(const float* c, const BoxGeo& p, cons
   const float d_hraw = hraw >= 0.f ? d_height : 0.f;
   dc[1] += d_hraw * take_min(p.c0y, g.c0y);        // corner 0, y
   dc[13] -= d_hraw * take_max(p.c4y, g.c4y);       // corner 4, y
-  const float d_wxr = wxr >= 0.f ? d_area * wz : 0.f;
-  const float d_wzr = wzr >= 0.f ? d_area * wx : 0.f;
-  dc[0] += d_wxr * take_min(p.c0x, g.c0x);         // corner 0, x
-  dc[6] -= d_wxr * take_max(p.c2x, g.c2x);         // corner 2, x
-  dc[2] += d_wzr * take_min(p.c0z, g.c0z);         // corner 0, z
-  dc[8] -= d_wzr * take_max(p.c2z, g.c2z);         // corner 2, z
+  if (!rot) {
+    const float d_wxr = wxr >= 0.f ? d_area * wz : 0.f;
+    const float d_wzr = wzr >= 0.f ? d_area * wx : 0.f;
+    dc[0] += d_wxr * take_min(p.c0x, g.c0x);         // corner 0, x
+    dc[6] -= d_wxr * take_max(p.c2x, g.c2x);         // corner 2, x
+    dc[2] += d_wzr * take_min(p.c0z, g.c0z);         // corner 0, z
+    dc[8] -= d_wzr * take_max(p.c2z, g.c2z);         // corner 2, z
+  } else if (clipped) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // footprint vertex i = corner 3 - i, (x, z)
+      dc[(3 - i) * 3] += d_area * (0.5f * clip_grad[2 * i]);
+      dc[(3 - i) * 3 + 2] += d_area * (0.5f * clip_grad[2 * i + 1]);
+    }
+  }
   // enclosing box: extremes over the 8 corners (the gradient of max/min(dim) goes to the first extreme index)
   float d_mx[3], d_mn[3];
   {
@@ -640,7 +785,8 @@ __global__ __launch_bounds__(kLossRows) void set_loss_kernel(LossBatch batch) {
 #pragma unroll
         for (int k = 0; k < 24; ++k) c[k] = d.corners[row * 24 + k];
         const BoxGeo pg = box_geo(c), gg = box_geo(r + VDETR_GT_CORNERS);
-        const float giou = gi < (int)d.nactual[b] ? giou_grad(c, pg, gg, d.w_giou * inv_nb, dc) : 0.f;
+        const bool rot = d.rotated != nullptr && d.rotated[0] != 0.f;
+        const float giou = gi < (int)d.nactual[b] ? giou_grad(c, pg, gg, d.w_giou * inv_nb, dc, rot, r + VDETR_GT_CORNERS) : 0.f;
         acc[5] = 1.f - giou;
         alabel = (int)r[VDETR_GT_ANGLE_CLS];
         const float e = d.angle_res_norm[row * d.A + alabel] - r[VDETR_GT_ANGLE_RES] / (3.14159265358979323846f / (float)d.A);
