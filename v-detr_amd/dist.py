@@ -281,10 +281,15 @@ class GradientReducer:
         self._pending = list(self._counts)
         self._launched = [False] * len(self.buckets)
 
+    _avg_unsupported = False
+
     def _allreduce_avg(self, t, async_op=False):
         """Average over the ranks.  RCCL averages inside the collective (ncclAvg); gloo (CPU tests) needs the division."""
-        if dist.get_backend(self.group) == "nccl":
-            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        if dist.get_backend(self.group) == "nccl" and not GradientReducer._avg_unsupported:
+            try:
+                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            except (RuntimeError, ValueError):  # a collective library without ncclAvg rejects the op on every rank alike,
+                GradientReducer._avg_unsupported = True  # before anything is enqueued: divide + sum from now on
         t.div_(self.world)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
