@@ -2,7 +2,7 @@
 
 ``enable_gemm_tuning``: the projections / FFNs / head MLPs are library GEMMs (hipBLASLt, rocBLAS); which Tensile solution
 is fastest for a [1024 x 256] x [256 x 256] fp32 product is not what the libraries' heuristics pick (measured: 15.9 ->
-14.8 ms per step with the 53 GEMM shapes of the training step tuned).  PyTorch's TunableOp times the candidate solutions
+14.8 ms per step with the GEMM shapes of the training step tuned).  PyTorch's TunableOp times the candidate solutions
 once per shape during the first (eager, un-captured) steps and caches the winners in a CSV; ``tuning/gfx950_tunableop.csv``
 is that cache as measured on an MI355X (TunableOp validates library versions and re-tunes on a mismatch).
 """
