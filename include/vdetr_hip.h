@@ -331,6 +331,9 @@ int vdetr_relu_dropout_fwd_f32(const float* x, float* y, long n, float dropout_p
 int vdetr_relu_dropout_bwd_f32(const float* y, const float* dy, float* dx, long n, float dropout_p, vdetr_stream_t stream);
 int vdetr_bn_act_fwd_f32(const vdetr_bnact_desc* d, vdetr_stream_t stream);
 int vdetr_bn_act_bwd_f32(const vdetr_bnact_desc* d, const vdetr_bnact_grads* g, vdetr_stream_t stream);
+/* n independent problems (HOST arrays) of the same B*N in one launch per 12: the hidden blocks of several decoder stages'
+ * box heads, whose backward v-detr_amd/vdetr_transformer.py:_DeferredHeads runs as one batched pass */
+int vdetr_bn_act_bwd_batch_f32(const vdetr_bnact_desc* descs, const vdetr_bnact_grads* grads, int n, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Gradient packing: n separate fp32 tensors -> slices of one flat buffer, one launch.  The role of the bucket copy in

@@ -315,3 +315,48 @@ def test_captured_step_equals_eager_step():
         s = float(pe[n].abs().max()) + 1e-6
         worst = max(worst, d / s)
     assert worst < 2e-3, worst  # (atomics in the table reduction + tuned GEMM choices: not bit-identical)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_deferred_heads_backward_equals_per_stage_autograd(batch):
+    """The box heads of stages >= 1 run outside autograd and are differentiated by ONE batched node (_DeferredHeads): same
+    losses, same gradients (features and every parameter), same BatchNorm running statistics as the per-stage autograd
+    chains, in training mode with dropout (the masks are counter-based, hence reproducible)."""
+    import copy
+    import vdetr_amd.vdetr_transformer as T
+    from vdetr_amd import attention as A
+    model = _make_model(nq=64, npre=512, nl=4).to(DEV).train()
+    inp = _inputs(3000, 5, DEV, batch)
+    model(inp)  # lazily created state (dropout streams, adjacent running statistics) exists before the comparison
+    state = copy.deepcopy(model.state_dict())  # (the SAME module runs twice: a deepcopy draws new attention dropout streams)
+    res = {}
+    saved = T._DEFER_HEADS
+    try:
+        for mode in (True, False):
+            T._DEFER_HEADS = mode
+            A.reset_rng()
+            torch.manual_seed(0)
+            with torch.no_grad():
+                for k, v in model.state_dict().items():
+                    v.copy_(state[k])
+            model.zero_grad(set_to_none=True)
+            for f in inp["backbone_features"]:
+                f.grad = None
+            out = model(inp)
+            loss = _loss(out) + sum((o["box_corners"] ** 2).sum() + o["angle_logits"].sum() for o in out["aux_outputs"])
+            loss.backward()
+            res[mode] = (float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+                         [f.grad.clone() for f in inp["backbone_features"]],
+                         {n: b.clone() for n, b in model.named_buffers() if "running" in n or "num_batches" in n})
+    finally:
+        T._DEFER_HEADS = saved
+    (l1, g1, f1, b1), (l0, g0, f0, b0) = res[True], res[False]
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    assert g1.keys() == g0.keys()
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-12
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * scale, n
+    for a, b in zip(f1, f0):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+    for n in b0:
+        assert torch.allclose(b1[n].float(), b0[n].float(), rtol=1e-5, atol=1e-6), n

@@ -171,6 +171,7 @@ _SIGNATURES = {
     "vdetr_relu_dropout_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p]),
     "vdetr_bn_act_fwd_f32": (c_int, [ctypes.POINTER(BnActDesc), c_void_p]),
     "vdetr_bn_act_bwd_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_void_p]),
+    "vdetr_bn_act_bwd_batch_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_int, c_void_p]),
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

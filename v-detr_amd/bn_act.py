@@ -87,6 +87,41 @@ def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, 
                         float(dropout_p), rng, int(salt), pre_bias, tuple(counters))
 
 
+def forward_record(x, gamma, beta, rm, rv, eps, momentum, p, salt, counters=(), y_out=None):
+    """Training-mode forward WITHOUT an autograd node: returns (y, record); ``backward_from_record(record, dy)`` gives
+    (dx, dgamma, dbeta) later.  For callers that batch the backward of several independent blocks themselves
+    (vdetr_transformer._DeferredHeads)."""
+    rng = None
+    if p > 0.0:
+        rng = A.current_rng(x.device)
+        if rng is None:
+            rng = A.begin_step(x.device)
+    with torch.no_grad():
+        x = x.detach().contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = y_out if y_out is not None else torch.empty_like(x)  # (a slice of a caller's stacked buffer)
+        assert y.is_contiguous() and y.shape == x.shape
+        C = x.shape[1]
+        smean = torch.empty(C, dtype=torch.float32, device=x.device)
+        sinv = torch.empty_like(smean)
+        d = _desc(x, g, b, rm, rv, y, smean, sinv, True, True, eps, momentum, p, salt, rng if p > 0 else None, None, tuple(counters))
+        L.check(L.lib().vdetr_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "bn_act_fwd")
+    return y, (x, g, b, smean, sinv, rng if p > 0 else None, (float(eps), float(momentum), float(p), int(salt)))
+
+
+def backward_from_record(record, dy, dx_out=None):
+    x, gamma, beta, smean, sinv, rng, (eps, momentum, p, salt) = record
+    dy = dy.contiguous()
+    d = _desc(x, gamma, beta, None, None, None, smean, sinv, True, True, eps, momentum, p, salt, rng)
+    g = L.BnActGrads()
+    dx = dx_out if dx_out is not None else torch.empty_like(x)
+    assert dx.is_contiguous() and dx.shape == x.shape
+    dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+    g.dy, g.dx, g.d_gamma, g.d_beta = dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr()
+    L.check(L.lib().vdetr_bn_act_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "bn_act_bwd")
+    return dx, dg, db
+
+
 class _ReluDropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, rng, salt):
@@ -120,3 +155,22 @@ def relu_dropout(x, drop, salt=0):
         if rng is None:
             rng = A.begin_step(x.device)
     return _ReluDropout.apply(x, p, rng, salt)
+
+
+def backward_from_records(records, dys, dx_outs):
+    """backward_from_record for several independent blocks of the same B*N in ONE launch.  Returns [(dx, dgamma, dbeta)]."""
+    n = len(records)
+    descs, grads = (L.BnActDesc * n)(), (L.BnActGrads * n)()
+    keep, out = [], []
+    for i, (rec, dy, dx) in enumerate(zip(records, dys, dx_outs)):
+        x, gamma, beta, smean, sinv, rng, (eps, momentum, p, salt) = rec
+        dy = dy.contiguous()
+        assert dx.is_contiguous() and dx.shape == x.shape
+        descs[i] = _desc(x, gamma, beta, None, None, None, smean, sinv, True, True, eps, momentum, p, salt, rng)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        g = grads[i]
+        g.dy, g.dx, g.d_gamma, g.d_beta = dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr()
+        keep.append(dy)
+        out.append((dx, dg, db))
+    L.check(L.lib().vdetr_bn_act_bwd_batch_f32(descs, grads, n, L.stream_ptr()), "bn_act_bwd_batch")
+    return out

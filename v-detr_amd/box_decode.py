@@ -95,6 +95,71 @@ class _BoxDecode(torch.autograd.Function):
 _JOINT_ORDER = ("cls", "center", "size", "angle_cls", "angle_res")  # slab order = TransformerDecoder._HEAD_NAMES
 
 
+def _joint_forward(y, chans, pre_center_norm, pre_size_norm, dims_min, dims_max, num_angle_bin, cls_kind):
+    """One launch: the five head slabs of y [B, 5, rows, N] -> every tensor of the stage.  Returns (outs, saved, meta)."""
+    for k, t in (("y", y), ("pre_center_norm", pre_center_norm), ("pre_size_norm", pre_size_norm),
+                 ("dims_min", dims_min), ("dims_max", dims_max)):
+        L.require_gpu(t, k)
+        L.require_float(t, k)
+    y = y.contiguous()
+    pre_center_norm, pre_size_norm = pre_center_norm.contiguous(), pre_size_norm.contiguous()
+    dims_min, dims_max = dims_min.contiguous(), dims_max.contiguous()
+    B, G, rows, N = y.shape
+    C1, A = chans[0], chans[3]
+    assert G == 5 and chans[1] == 3 and chans[2] == 3 and chans[4] == A and max(chans) <= rows
+    slab = rows * N * 4
+    ins = {k: y.data_ptr() + i * slab for i, k in enumerate(_JOINT_ORDER)}
+    new = y.new_empty
+    outs = {k: new((B, N, 3)) for k in _OUT3}
+    outs["angle_residual"] = new((B, N, A))
+    outs["angle_cont"], outs["angle_prob"], outs["objectness"] = new((B, N)), new((B, N)), new((B, N))
+    outs["angle_class"] = torch.empty((B, N), dtype=torch.int32, device=y.device)
+    outs["corners"] = new((B, N, 8, 3))
+    outs["corners_aa"] = new((B, N, 8, 3)) if A > 1 else None
+    outs["cls_prob"] = new((B, N, C1 - 1)) if cls_kind == L.VDETR_CLS_SOFTMAX else None
+    outs["cls_logits_t"], outs["angle_logits_t"], outs["angle_res_norm_t"] = new((B, N, C1)), new((B, N, A)), new((B, N, A))
+    outs["corners_lidar"], outs["center_size"] = new((B, N, 8, 3)), new((B, N, 6))
+    d = _desc(B, N, A, C1, num_angle_bin, cls_kind,
+              {**ins, "pre_center_norm": pre_center_norm, "pre_size_norm": pre_size_norm, "dims_min": dims_min,
+               "dims_max": dims_max, **outs, "in_batch_stride": G * rows * N})
+    L.check(L.lib().vdetr_box_decode_fwd_f32(ctypes.byref(d), L.stream_ptr()), "box_decode_fwd")
+    meta = (B, N, A, C1, num_angle_bin, cls_kind, G, rows)
+    saved = (y, dims_min, dims_max, outs["size_unnorm"], outs["pre_size_unnorm"], outs["angle_cont"], outs["angle_class"])
+    return outs, saved, meta
+
+
+_JOINT_NONDIFF = ("pre_center_unnorm", "pre_size_unnorm", "objectness", "corners_lidar", "center_size", "cls_prob")
+
+
+def _joint_backward(meta, saved, gin, d_y=None):
+    """gin: {output name: gradient or None}.  One launch; returns the complete gradient of y (written into d_y if given)."""
+    B, N, A, C1, num_angle_bin, cls_kind, G, rows = meta
+    y, dims_min, dims_max, size_unnorm, pre_size_unnorm, angle_cont, angle_class = saved
+    slab = rows * N * 4
+    d = _desc(B, N, A, C1, num_angle_bin, cls_kind,
+              {**{k: y.data_ptr() + i * slab for i, k in enumerate(_JOINT_ORDER)},
+               "dims_min": dims_min, "dims_max": dims_max, "size_unnorm": size_unnorm,
+               "pre_size_unnorm": pre_size_unnorm, "angle_cont": angle_cont, "angle_class": angle_class,
+               "pre_center_norm": size_unnorm, "pre_size_norm": size_unnorm, "in_batch_stride": G * rows * N})
+    g = L.BoxDecodeGrads()
+    keep = []
+    for k in L._BOX_GRAD_IN + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t"):
+        t = gin.get(k)
+        if t is not None:
+            t = t.contiguous()
+            keep.append(t)
+        setattr(g, k, t.data_ptr() if t is not None else None)
+    if d_y is None:
+        d_y = torch.empty_like(y)
+    assert d_y.is_contiguous() and d_y.shape == y.shape
+    base = d_y.data_ptr()
+    g.d_cls, g.d_center, g.d_size, g.d_angle_cls, g.d_angle_res = (base, base + slab, base + 2 * slab, base + 3 * slab,
+                                                                     base + 4 * slab)
+    g.out_batch_stride, g.slab_rows = G * rows * N, rows
+    L.check(L.lib().vdetr_box_decode_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "box_decode_bwd")
+    return d_y
+
+
 class _BoxDecodeJoint(torch.autograd.Function):
     """The five head outputs as slabs of ONE tensor y [B, 5, rows, N] (the batched output GEMM of the heads).  The logits
     the reference returns as transposed views are real (transposed) outputs here, so the whole backward is one launch
@@ -103,68 +168,36 @@ class _BoxDecodeJoint(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, chans, pre_center_norm, pre_size_norm, dims_min, dims_max, num_angle_bin, cls_kind):
-        for k, t in (("y", y), ("pre_center_norm", pre_center_norm), ("pre_size_norm", pre_size_norm),
-                     ("dims_min", dims_min), ("dims_max", dims_max)):
-            L.require_gpu(t, k)
-            L.require_float(t, k)
-        y = y.contiguous()
-        pre_center_norm, pre_size_norm = pre_center_norm.contiguous(), pre_size_norm.contiguous()
-        dims_min, dims_max = dims_min.contiguous(), dims_max.contiguous()
-        B, G, rows, N = y.shape
-        C1, A = chans[0], chans[3]
-        assert G == 5 and chans[1] == 3 and chans[2] == 3 and chans[4] == A and max(chans) <= rows
-        slab = rows * N * 4
-        ins = {k: y.data_ptr() + i * slab for i, k in enumerate(_JOINT_ORDER)}
-        new = y.new_empty
-        outs = {k: new((B, N, 3)) for k in _OUT3}
-        outs["angle_residual"] = new((B, N, A))
-        outs["angle_cont"], outs["angle_prob"], outs["objectness"] = new((B, N)), new((B, N)), new((B, N))
-        outs["angle_class"] = torch.empty((B, N), dtype=torch.int32, device=y.device)
-        outs["corners"] = new((B, N, 8, 3))
-        outs["corners_aa"] = new((B, N, 8, 3)) if A > 1 else None
-        outs["cls_prob"] = new((B, N, C1 - 1)) if cls_kind == L.VDETR_CLS_SOFTMAX else None
-        outs["cls_logits_t"], outs["angle_logits_t"], outs["angle_res_norm_t"] = new((B, N, C1)), new((B, N, A)), new((B, N, A))
-        outs["corners_lidar"], outs["center_size"] = new((B, N, 8, 3)), new((B, N, 6))
-        d = _desc(B, N, A, C1, num_angle_bin, cls_kind,
-                  {**ins, "pre_center_norm": pre_center_norm, "pre_size_norm": pre_size_norm, "dims_min": dims_min,
-                   "dims_max": dims_max, **outs, "in_batch_stride": G * rows * N})
-        L.check(L.lib().vdetr_box_decode_fwd_f32(ctypes.byref(d), L.stream_ptr()), "box_decode_fwd")
-        ctx.meta = (B, N, A, C1, num_angle_bin, cls_kind, G, rows)
-        ctx.save_for_backward(y, dims_min, dims_max, outs["size_unnorm"], outs["pre_size_unnorm"], outs["angle_cont"],
-                              outs["angle_class"])
+        outs, saved, meta = _joint_forward(y, chans, pre_center_norm, pre_size_norm, dims_min, dims_max, num_angle_bin,
+                                           cls_kind)
+        ctx.meta = meta
+        ctx.save_for_backward(*saved)
         ctx.set_materialize_grads(False)
-        nondiff = [outs[k] for k in ("pre_center_unnorm", "pre_size_unnorm", "objectness", "corners_lidar", "center_size")]
-        if outs["cls_prob"] is not None:
-            nondiff.append(outs["cls_prob"])
-        ctx.mark_non_differentiable(*nondiff)
+        ctx.mark_non_differentiable(*[outs[k] for k in _JOINT_NONDIFF if outs[k] is not None])
         return tuple(outs[k] for k in _BoxDecodeJoint.OUTS)
 
     @staticmethod
     def backward(ctx, *grads):
-        B, N, A, C1, num_angle_bin, cls_kind, G, rows = ctx.meta
-        y, dims_min, dims_max, size_unnorm, pre_size_unnorm, angle_cont, angle_class = ctx.saved_tensors
-        gin = dict(zip(_BoxDecodeJoint.OUTS, grads))
-        slab = rows * N * 4
-        d = _desc(B, N, A, C1, num_angle_bin, cls_kind,
-                  {**{k: y.data_ptr() + i * slab for i, k in enumerate(_JOINT_ORDER)},
-                   "dims_min": dims_min, "dims_max": dims_max, "size_unnorm": size_unnorm,
-                   "pre_size_unnorm": pre_size_unnorm, "angle_cont": angle_cont, "angle_class": angle_class,
-                   "pre_center_norm": size_unnorm, "pre_size_norm": size_unnorm, "in_batch_stride": G * rows * N})
-        g = L.BoxDecodeGrads()
-        keep = []
-        for k in L._BOX_GRAD_IN + ("cls_logits_t", "angle_logits_t", "angle_res_norm_t"):
-            t = gin.get(k)
-            if t is not None:
-                t = t.contiguous()
-                keep.append(t)
-            setattr(g, k, t.data_ptr() if t is not None else None)
-        d_y = torch.empty_like(y)
-        base = d_y.data_ptr()
-        g.d_cls, g.d_center, g.d_size, g.d_angle_cls, g.d_angle_res = (base, base + slab, base + 2 * slab, base + 3 * slab,
-                                                                         base + 4 * slab)
-        g.out_batch_stride, g.slab_rows = G * rows * N, rows
-        L.check(L.lib().vdetr_box_decode_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "box_decode_bwd")
+        d_y = _joint_backward(ctx.meta, ctx.saved_tensors, dict(zip(_BoxDecodeJoint.OUTS, grads)))
         return d_y, None, None, None, None, None, None, None
+
+
+def decode_boxes_joint_record(y, chans, pre_center_normalized, pre_size_normalized, point_cloud_dims, num_angle_bin,
+                              cls_loss="celoss"):
+    """decode_boxes_joint WITHOUT an autograd node: returns (outs by kernel name, saved, meta) for callers that run the
+    backward themselves (``_joint_backward``) -- vdetr_transformer._DeferredHeads."""
+    cls_kind = L.VDETR_CLS_SIGMOID if cls_loss.split("_")[0] == "focalloss" else L.VDETR_CLS_SOFTMAX
+    with torch.no_grad():
+        return _joint_forward(y.detach(), tuple(int(c) for c in chans), pre_center_normalized.detach(),
+                              pre_size_normalized.detach(), point_cloud_dims[0], point_cloud_dims[1], int(num_angle_bin),
+                              cls_kind)
+
+
+def joint_result(o):
+    """the reference's dictionary (+ the two loop helpers) from the kernel's named outputs"""
+    res = _result(o, o["cls_logits_t"], o["angle_logits_t"], o["angle_res_norm_t"])
+    res["_reference_point_lidar"], res["_query_reference"] = o["corners_lidar"], o["center_size"]
+    return res
 
 
 def decode_boxes_joint(y, chans, pre_center_normalized, pre_size_normalized, point_cloud_dims, num_angle_bin,

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_kernel(vdetr_bnact_desc
 
 // training-mode backward: g = dy through dropout and relu; dbeta = sum g, dgamma = sum g*xhat,
 // dx = gamma * invstd * (g - dbeta/n - xhat * dgamma/n)
-__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_kernel(vdetr_bnact_desc d, vdetr_bnact_grads g) {
+__device__ __forceinline__ void bn_act_bwd_body(const vdetr_bnact_desc& d, const vdetr_bnact_grads& g) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.C) return;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_reg_kernel(vdetr_bnact_
 }
 
 template <int NCH>
-__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reg_kernel(vdetr_bnact_desc d, vdetr_bnact_grads g) {
+__device__ __forceinline__ void bn_act_bwd_reg_body(const vdetr_bnact_desc& d, const vdetr_bnact_grads& g) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d.C) return;
@@ -244,6 +244,26 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reg_kernel(vdetr_bnact_
     for (int e = 0; e < 4; ++e) v[e] = k * (gr[j][e] - m1 - xr[j][e] * m2);
     *const_cast<f32x4*>(at(g.dx, j * 64 + lane)) = v;
   }
+}
+
+// kernels: one problem, or a batch of independent problems of the same B*N (blockIdx.y picks the problem; their
+// descriptors travel by value) -- the hidden blocks of several decoder stages' box heads in ONE backward launch
+constexpr int kBnBatch = 12;
+struct BnBwdBatch {
+  vdetr_bnact_desc d[kBnBatch];
+  vdetr_bnact_grads g[kBnBatch];
+};
+__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_kernel(vdetr_bnact_desc d, vdetr_bnact_grads g) { bn_act_bwd_body(d, g); }
+template <int NCH>
+__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reg_kernel(vdetr_bnact_desc d, vdetr_bnact_grads g) {
+  bn_act_bwd_reg_body<NCH>(d, g);
+}
+__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_batch_kernel(BnBwdBatch batch) {
+  bn_act_bwd_body(batch.d[blockIdx.y], batch.g[blockIdx.y]);
+}
+template <int NCH>
+__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reg_batch_kernel(BnBwdBatch batch) {
+  bn_act_bwd_reg_body<NCH>(batch.d[blockIdx.y], batch.g[blockIdx.y]);
 }
 
 // ---- y = dropout(relu(x)) element-wise (the FFN's `self.dropout(self.activation(self.linear1(.)))`,
@@ -359,4 +379,41 @@ extern "C" int vdetr_relu_dropout_bwd_f32(const float* y, const float* dy, float
   const int grid = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
   hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n4, rg.scale);
   return check_launch("relu_dropout_bwd");
+}
+
+extern "C" int vdetr_bn_act_bwd_batch_f32(const vdetr_bnact_desc* descs, const vdetr_bnact_grads* grads, int n,
+                                          vdetr_stream_t stream) {
+  VDETR_REQUIRE(descs && grads && n >= 1, "bn_act_bwd_batch: null descriptors");
+  hipStream_t st = (hipStream_t)stream;
+  for (int s0 = 0; s0 < n; s0 += kBnBatch) {
+    const int cnt = n - s0 < kBnBatch ? n - s0 : kBnBatch;
+    BnBwdBatch batch{};
+    bool reg = true;
+    int maxc = 1;
+    const long tot = (long)descs[s0].B * descs[s0].N;
+    for (int k = 0; k < cnt; ++k) {
+      const vdetr_bnact_desc* d = descs + s0 + k;
+      const vdetr_bnact_grads* g = grads + s0 + k;
+      if (int e = bnact_check(d, "bn_act_bwd_batch")) return e;
+      VDETR_REQUIRE(d->training, "bn_act_bwd_batch: only the training-mode backward is built (batch statistics)");
+      VDETR_REQUIRE(g->dy && d->save_mean && d->save_invstd, "bn_act_bwd_batch: null pointer");
+      VDETR_REQUIRE((long)d->B * d->N == tot, "bn_act_bwd_batch: problem %d has B*N = %ld, the first %ld", s0 + k, (long)d->B * d->N, tot);
+      reg = reg && d->N % 4 == 0 && ((uintptr_t)d->x & 15) == 0 && ((uintptr_t)g->dy & 15) == 0 && (!g->dx || ((uintptr_t)g->dx & 15) == 0);
+      maxc = d->C > maxc ? d->C : maxc;
+      batch.d[k] = *d;
+      batch.g[k] = *g;
+    }
+    reg = reg && tot % 256 == 0 && tot <= 4096;
+    const dim3 grid(ceil_div(maxc, 4), cnt), block(kBnThreads);
+    switch (reg ? (int)(tot / 256) : 0) {
+      case 1: hipLaunchKernelGGL(bn_act_bwd_reg_batch_kernel<1>, grid, block, 0, st, batch); break;
+      case 2: hipLaunchKernelGGL(bn_act_bwd_reg_batch_kernel<2>, grid, block, 0, st, batch); break;
+      case 4: hipLaunchKernelGGL(bn_act_bwd_reg_batch_kernel<4>, grid, block, 0, st, batch); break;
+      case 8: hipLaunchKernelGGL(bn_act_bwd_reg_batch_kernel<8>, grid, block, 0, st, batch); break;
+      case 16: hipLaunchKernelGGL(bn_act_bwd_reg_batch_kernel<16>, grid, block, 0, st, batch); break;
+      default: hipLaunchKernelGGL(bn_act_bwd_batch_kernel, grid, block, 0, st, batch); break;
+    }
+    if (int e = check_launch("bn_act_bwd_batch")) return e;
+  }
+  return VDETR_OK;
 }

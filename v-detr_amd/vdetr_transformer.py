@@ -24,6 +24,8 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+import os
+
 from . import add_ln as ALN
 from . import bn_act as BNA
 from . import attention as A
@@ -470,6 +472,92 @@ class FFNLayer(nn.Module):
 # =====================================================================================================
 # decoder
 # =====================================================================================================
+_DEFER_HEADS = os.environ.get("VDETR_DEFER_HEADS", "1") != "0"  # A/B switch (read once)
+
+
+class _DeferredHeads(torch.autograd.Function):
+    """Backward of the box heads of SEVERAL decoder stages as one batched pass.
+
+    Forward: nothing to compute -- the stages' heads and box decodes already ran, launch for launch as before but without
+    autograd nodes (their boxes feed the next layer detached, :408-415, so only the loss needs their graph); this node just
+    hands their results to autograd.  It is created after the last decoder layer, hence it is the first thing the backward
+    pass reaches: all stages' box-decode backward launches, then ONE batched GEMM per (layer of the MLP, operand) for all
+    stages and heads (S x 5 problems each) instead of S separate chains -- 8 stages: ~40 launches instead of ~100, and the
+    GEMMs are 8 x larger.  inputs: S feature tensors [nQ,B,C] followed by 8 parameter aliases per stage
+    (w1, g1, b1, w2, g2, b2, w3, b3)."""
+
+    @staticmethod
+    def forward(ctx, records, names, *tensors):
+        ctx.records, ctx.names = records, names
+        S = len(records)
+        ctx.set_materialize_grads(False)
+        outs, nondiff = [], []
+        for rec in records:
+            o = rec["outs"]
+            for k in names:
+                outs.append(o[k])
+                if k in box_decode._JOINT_NONDIFF:
+                    nondiff.append(o[k])
+        ctx.mark_non_differentiable(*nondiff)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        recs, names = ctx.records, ctx.names
+        S, K = len(recs), len(names)
+        r0 = recs[0]
+        Bsz, G, rows, N = r0["y"].shape
+        C = r0["f"].shape[1]
+        dev = r0["y"].device
+        # ---- box decode backward of every stage, straight into one stacked buffer
+        dY = torch.empty((S,) + tuple(r0["y"].shape), dtype=torch.float32, device=dev)
+        for s, rec in enumerate(recs):
+            gin = dict(zip(names, grads[s * K:(s + 1) * K]))
+            box_decode._joint_backward(rec["meta"], rec["saved"], gin, d_y=dY[s])
+        one = Bsz == 1
+
+        def fold(t, ch):  # [S,B,G*ch or G,ch..,N] -> [S*G, ch, B*N]: the batch joins the contraction
+            t = t.reshape(S, Bsz, G, ch, N)
+            return t.reshape(S * G, ch, N) if one else t.permute(0, 2, 3, 1, 4).reshape(S * G, ch, Bsz * N)
+
+        def stack(k):  # the forward wrote h1 / h2 of stage s into slice s of one buffer when all stages were deferred
+            st = [r["stack"] for r in recs]
+            if k != "f" and all(x is not None and x[0] is st[0][0] and x[1] == i for i, x in enumerate(st)) and \
+                    st[0][0][k].shape[0] == S:
+                return st[0][0][k]
+            return torch.stack([r[k] for r in recs])
+
+        h2, h1, f = stack("h2"), stack("h1"), stack("f")                      # [S,B,G*C,N] x2, [S,B,C,N]
+        w3 = torch.stack([r["w3"].detach().reshape(G, rows, C) for r in recs])  # [S,G,rows,C]
+        w2 = torch.stack([r["w2"].detach().reshape(G, C, C) for r in recs])
+        w1 = torch.stack([r["w1"].detach().reshape(G * C, C) for r in recs])    # [S,G*C,C]
+        # ---- output layer
+        db3 = dY.sum(dim=(1, 4))                                                                   # [S,G,rows]
+        dYf = fold(dY, rows)
+        dw3 = torch.bmm(dYf, fold(h2, C).transpose(1, 2)).view(S, G, rows, C)
+        dh2 = torch.matmul(w3.transpose(2, 3).unsqueeze(1), dY).view(S, Bsz, G * C, N)             # [S,B,G*C,N]
+        # ---- second hidden block
+        dx2 = torch.empty_like(dh2)
+        dbn2 = BNA.backward_from_records([r["bn2"] for r in recs], [dh2[s] for s in range(S)], [dx2[s] for s in range(S)])
+        dw2 = torch.bmm(fold(dx2, C), fold(h1, C).transpose(1, 2)).view(S, G, C, C)
+        dh1 = torch.matmul(w2.transpose(2, 3).unsqueeze(1), dx2.view(S, Bsz, G, C, N)).view(S, Bsz, G * C, N)
+        # ---- first hidden block
+        dx1 = torch.empty_like(dh1)
+        dbn1 = BNA.backward_from_records([r["bn1"] for r in recs], [dh1[s] for s in range(S)], [dx1[s] for s in range(S)])
+        if one:
+            dw1 = torch.bmm(dx1.view(S, G * C, N), f.view(S, C, N).transpose(1, 2))               # [S,G*C,C]
+        else:
+            dw1 = torch.bmm(dx1.permute(0, 2, 1, 3).reshape(S, G * C, Bsz * N),
+                            f.permute(0, 2, 1, 3).reshape(S, C, Bsz * N).transpose(1, 2))
+        df = torch.matmul(w1.transpose(1, 2).unsqueeze(1), dx1)                                    # [S,B,C,N]
+        out = [df[s].permute(2, 0, 1) for s in range(S)]                                           # as [nQ,B,C]
+        for s, r in enumerate(recs):
+            out += [dw1[s].reshape(r["w1"].shape), dbn1[s][1], dbn1[s][2], dw2[s].reshape(r["w2"].shape), dbn2[s][1],
+                    dbn2[s][2], dw3[s].reshape(r["w3"].shape), db3[s].reshape(r["b3"].shape)]
+        return (None, None, *out)
+
+
+
 class TransformerDecoder(nn.Module):
     """FFN stage on all tokens -> top-k proposals -> num_layers x GlobalDecoderLayer with per-stage box heads and
     iterative box refinement (reference :105-452).  Constructor arguments as in the reference."""
@@ -587,6 +675,15 @@ class TransformerDecoder(nn.Module):
                 torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
         return y
 
+    @staticmethod
+    def _bn_salt(heads, i):
+        """dropout stream of hidden block i of a group of heads; kept ON the module group so that copies of a model that
+        has run draw the same masks (a dictionary keyed by id() would not survive copy.deepcopy)"""
+        salts = heads.__dict__.setdefault("_vdetr_bn_salts", {})
+        if i not in salts:
+            salts[i] = BNA.new_salt()
+        return salts[i]
+
     def _bn_relu_drop(self, x, bns, p, key):
         """dropout(relu(batch_norm(x))) of G side-by-side channel groups: one HIP launch when training on the GPU with
         the statistics laid out adjacently, the ATen composition otherwise."""
@@ -595,9 +692,7 @@ class TransformerDecoder(nn.Module):
         rm, rv = buffers_alias([b.running_mean for b in bns]), buffers_alias([b.running_var for b in bns])
         if rm is None or rv is None:
             return F.dropout(F.relu(self._bn_group(x, bns, self.training)), p, self.training)  # (lays them out, once)
-        if not hasattr(self, "_bn_salts"):
-            self._bn_salts = {}
-        salt = self._bn_salts.setdefault(key, BNA.new_salt())
+        salt = self._bn_salt(*key)
         return BNA.bn_act(x, cat_params([b.weight for b in bns]), cat_params([b.bias for b in bns]), rm, rv, True,
                           bns[0].eps, bns[0].momentum, relu=True, dropout_p=p, salt=salt,
                           counters=[b.num_batches_tracked for b in bns])
@@ -645,10 +740,10 @@ class TransformerDecoder(nn.Module):
         Bsz, _, N = feats.shape
         w1 = cat_params([l[0].weight for l in L]).squeeze(-1)                            # [G*C, C]
         x = torch.mm(w1, feats.reshape(C, N)).unsqueeze(0) if Bsz == 1 else torch.matmul(w1, feats)  # [B, G*C, N]
-        x = self._bn_relu_drop(x, [l[1] for l in L], L[0][3].p, (id(heads), 1))
+        x = self._bn_relu_drop(x, [l[1] for l in L], L[0][3].p, (heads, 1))
         w2 = stack_params([l[4].weight for l in L]).squeeze(-1)                          # [G, C, C]
         x = torch.matmul(w2.unsqueeze(0), x.view(Bsz, G, C, N)).view(Bsz, G * C, N)
-        x = self._bn_relu_drop(x, [l[5] for l in L], L[0][7].p, (id(heads), 2))
+        x = self._bn_relu_drop(x, [l[5] for l in L], L[0][7].p, (heads, 2))
         outs = [l[8].weight.shape[0] for l in L]
         rows = max(outs)
         w3 = slot_stack_params([l[8].weight for l in L], rows)                            # [G, rows, C, 1] or None
@@ -662,6 +757,102 @@ class TransformerDecoder(nn.Module):
         # unbind (one stack kernel in backward) rather than five slices (five zero-fills + copies + adds)
         xs = x.view(Bsz, G, C, N).unbind(1)
         return {n: L[g][8](xs[g]) for g, n in enumerate(names)}
+
+    def _heads_recordable(self, heads, feats):
+        """the conditions under which a stage's heads can run without autograd nodes and be differentiated later by
+        _DeferredHeads: the batched layout with joint output slabs, fused BatchNorm launches, training on the GPU"""
+        if not (self.training and feats.is_cuda and torch.is_grad_enabled() and self._batchable(heads)):
+            return False
+        L = [heads[n].layers for n in self._HEAD_NAMES]
+        bns = [l[1] for l in L] + [l[5] for l in L]
+        if any(b.momentum is None or not b.track_running_stats for b in bns) or L[0][8].bias is None:
+            return False
+        for grp in ([l[1] for l in L], [l[5] for l in L]):
+            if buffers_alias([b.running_mean for b in grp]) is None or buffers_alias([b.running_var for b in grp]) is None:
+                return False
+        return True
+
+    def _run_heads_recorded(self, heads, feats, slot=None):
+        """_run_heads for one stage with every launch outside autograd; returns (y [B,5,rows,N], chans, record).  ``slot`` =
+        (shared dictionary, index, count): the hidden activations go straight into slice `index` of buffers stacked over
+        the `count` deferred stages, which is how the batched backward wants them."""
+        names = self._HEAD_NAMES
+        L = [heads[n].layers for n in names]
+        G, C = len(L), feats.shape[1]
+        Bsz, _, N = feats.shape
+        outs = [l[8].weight.shape[0] for l in L]
+        rows = max(outs)
+        # parameter aliases are created WITH autograd (they are inputs of the deferred node)
+        w1 = cat_params([l[0].weight for l in L])
+        g1, b1 = cat_params([l[1].weight for l in L]), cat_params([l[1].bias for l in L])
+        w2 = stack_params([l[4].weight for l in L])
+        g2, b2 = cat_params([l[5].weight for l in L]), cat_params([l[5].bias for l in L])
+        w3 = slot_stack_params([l[8].weight for l in L], rows)
+        b3 = slot_stack_params([l[8].bias for l in L], rows)
+        if w3 is None or b3 is None:
+            return None
+        salts = [self._bn_salt(heads, i) for i in (1, 2)]
+        stk = None
+        if slot is not None:
+            stk, si, ns = slot
+            for k in ("h1", "h2"):
+                if k not in stk:
+                    stk[k] = feats.new_empty((ns, Bsz, G * C, N))
+        with torch.no_grad():
+            f = feats.detach()  # [B,C,N] view of the [nQ,B,C] layer output: the GEMM reads it transposed, no copy
+            w1d = w1.detach().squeeze(-1)
+            x = torch.mm(w1d, f.reshape(C, N)).unsqueeze(0) if Bsz == 1 else torch.matmul(w1d, f)
+            bns = [l[1] for l in L]
+            h1, bn1 = BNA.forward_record(x, g1, b1, buffers_alias([b.running_mean for b in bns]),
+                                         buffers_alias([b.running_var for b in bns]), bns[0].eps, bns[0].momentum, L[0][3].p,
+                                         salts[0], counters=[b.num_batches_tracked for b in bns],
+                                         y_out=stk["h1"][si] if stk is not None else None)
+            x = torch.matmul(w2.detach().squeeze(-1).unsqueeze(0), h1.view(Bsz, G, C, N)).view(Bsz, G * C, N)
+            bns = [l[5] for l in L]
+            h2, bn2 = BNA.forward_record(x, g2, b2, buffers_alias([b.running_mean for b in bns]),
+                                         buffers_alias([b.running_var for b in bns]), bns[0].eps, bns[0].momentum, L[0][7].p,
+                                         salts[1], counters=[b.num_batches_tracked for b in bns],
+                                         y_out=stk["h2"][si] if stk is not None else None)
+            y = torch.matmul(w3.detach().squeeze(-1).unsqueeze(0), h2.view(Bsz, G, C, N))
+            y = y + b3.detach().view(1, G, rows, 1)
+        record = {"f": f, "h1": h1, "h2": h2, "bn1": bn1, "bn2": bn2, "y": y, "stack": (stk, si) if stk is not None else None,
+                  "w1": w1, "g1": g1, "b1": b1, "w2": w2, "g2": g2, "b2": b2, "w3": w3, "b3": b3}
+        return y, outs, record
+
+    def _stage_recorded(self, idx, point_cloud_dims, box_features, pre_center_normalized, pre_size_normalized, slot=None):
+        """get_proposal_box_predictions_refine for a stage whose autograd graph is built later (_DeferredHeads).  Returns
+        (box prediction dictionary of plain tensors, record) or None when the stage does not qualify."""
+        heads = self.mlp_heads[idx] if self.mlp_sep else self.mlp_heads
+        feats = box_features.permute(1, 2, 0)
+        if not self._heads_recordable(heads, feats):
+            return None
+        ran = self._run_heads_recorded(heads, feats, slot)
+        if ran is None:
+            return None
+        y, chans, record = ran
+        outs, saved, meta = box_decode.decode_boxes_joint_record(
+            y, chans, pre_center_normalized, pre_size_normalized, point_cloud_dims,
+            self.box_processor.dataset_config.num_angle_bin, self.box_processor.cls_loss)
+        record.update(outs=outs, saved=saved, meta=meta, feats_in=box_features)
+        return box_decode.joint_result(outs), record
+
+    @staticmethod
+    def _attach_deferred(records, predictions):
+        """One autograd node for the recorded stages; the dictionaries get the tracked tensors."""
+        names = tuple(k for k in box_decode._BoxDecodeJoint.OUTS if records[0]["outs"][k] is not None)
+        tensors = [r["feats_in"] for r in records]
+        for r in records:
+            tensors += [r["w1"], r["g1"], r["b1"], r["w2"], r["g2"], r["b2"], r["w3"], r["b3"]]
+        flat = _DeferredHeads.apply(records, names, *tensors)
+        K = len(names)
+        for s, (rec, pred) in enumerate(zip(records, predictions)):
+            o = dict(rec["outs"])
+            o.update(zip(names, flat[s * K:(s + 1) * K]))
+            tracked = box_decode.joint_result(o)
+            for k in list(pred.keys()):
+                if k in tracked and not k.startswith("_"):
+                    pred[k] = tracked[k]
+
 
     def _reset_parameters(self, weight_init_name):
         init = WEIGHT_INIT_DICT[weight_init_name]
@@ -754,6 +945,8 @@ class TransformerDecoder(nn.Module):
             isinstance(l, GlobalDecoderLayer) and l.normalize_before and ALN.supported(self.norm, l.norm1, l.norm2, l.norm3)
             for l in self.layers)
         carried = None  # norm1 of the next layer, produced by the previous layer's last launch
+        defer = _DEFER_HEADS and self.mlp_sep and self.return_intermediate and len(self.layers) > 1
+        deferred, stacked = [], {}
         for idx, layer in enumerate(self.layers):
             layer.cross_cache = caches[idx]
             if fuse_ln:
@@ -786,9 +979,15 @@ class TransformerDecoder(nn.Module):
             else:
                 normed = self.norm(output)
             # stages >= 1 decode relative to the FIXED stage-0 proposal centre / size (:427-431)
-            box_prediction = self.get_proposal_box_predictions_refine(
-                idx + 1, query_xyz, point_cloud_dims, normed,
-                pre_center_normalized=proposal_center_normalized, pre_size_normalized=proposal_size_normalized)
+            recorded = self._stage_recorded(idx + 1, point_cloud_dims, normed, proposal_center_normalized,
+                                            proposal_size_normalized, (stacked, idx, len(self.layers))) if defer else None
+            if recorded is not None:  # launches now, autograd graph after the loop (one batched backward for all stages)
+                box_prediction, rec = recorded
+                deferred.append((rec, box_prediction))
+            else:
+                box_prediction = self.get_proposal_box_predictions_refine(
+                    idx + 1, query_xyz, point_cloud_dims, normed,
+                    pre_center_normalized=proposal_center_normalized, pre_size_normalized=proposal_size_normalized)
             if self.return_intermediate:
                 intermediate.append(box_prediction)
             if return_attn_weights:
@@ -797,6 +996,8 @@ class TransformerDecoder(nn.Module):
                     attn = torch.gather(attn, 3, inv)
                 attns.append(attn)
 
+        if deferred:
+            self._attach_deferred([r for r, _ in deferred], [p for _, p in deferred])
         for extra in ("_reference_point_lidar", "_query_reference"):  # helpers of the loop, not part of the result
             box_prediction.pop(extra, None)
             if intermediate:
