@@ -528,9 +528,10 @@ class _DeferredHeads(torch.autograd.Function):
             return torch.stack([r[k] for r in recs])
 
         h2, h1, f = stack("h2"), stack("h1"), stack("f")                      # [S,B,G*C,N] x2, [S,B,C,N]
-        w3 = torch.stack([r["w3"].detach().reshape(G, rows, C) for r in recs])  # [S,G,rows,C]
-        w2 = torch.stack([r["w2"].detach().reshape(G, C, C) for r in recs])
-        w1 = torch.stack([r["w1"].detach().reshape(G * C, C) for r in recs])    # [S,G*C,C]
+        # (aliases of the parameter memory when dist.FlatParams laid the stages out next to each other, copies otherwise)
+        w3 = stack_params([r["w3"].detach().reshape(G, rows, C) for r in recs])  # [S,G,rows,C]
+        w2 = stack_params([r["w2"].detach().reshape(G, C, C) for r in recs])
+        w1 = stack_params([r["w1"].detach().reshape(G * C, C) for r in recs])    # [S,G*C,C]
         # ---- output layer
         db3 = dY.sum(dim=(1, 4))                                                                   # [S,G,rows]
         dYf = fold(dY, rows)
@@ -705,17 +706,23 @@ class TransformerDecoder(nn.Module):
         """Parameter groups the batched GEMMs read as ONE tensor (dist.FlatParams lays each group out contiguously,
         helpers.cat_params / stack_params / slot_stack_params then alias the memory instead of copying it)."""
         groups = []
-        stages = range(len(self.mlp_heads)) if self.mlp_sep else [0]
+        stages = list(range(len(self.mlp_heads))) if self.mlp_sep else [0]
+        stages = [st for st in stages if self._batchable(self.mlp_heads[st] if self.mlp_sep else self.mlp_heads)]
+        # stages whose heads have the same shapes share one group per parameter kind, stage after stage: the five heads of a
+        # stage stay adjacent (the per-stage batched GEMMs) AND the stages do (the stacked operands of _DeferredHeads)
+        by_shape = {}
         for st in stages:
-            heads = self.mlp_heads[st] if self.mlp_sep else self.mlp_heads
-            if not self._batchable(heads):
-                continue
             L = self._head_layers(st)
-            C = L[0][0].weight.shape[1]
-            rows = max(l[8].weight.shape[0] for l in L)
-            groups += [([l[0].weight for l in L], None), ([l[1].weight for l in L], None), ([l[1].bias for l in L], None),
-                       ([l[4].weight for l in L], None), ([l[5].weight for l in L], None), ([l[5].bias for l in L], None),
-                       ([l[8].weight for l in L], rows * C), ([l[8].bias for l in L], rows)]
+            by_shape.setdefault(tuple(tuple(l[8].weight.shape) for l in L), []).append(st)
+        for sts in by_shape.values():
+            Ls = [self._head_layers(st) for st in sts]
+            C = Ls[0][0][0].weight.shape[1]
+            rows = max(l[8].weight.shape[0] for l in Ls[0])
+            pick = lambda f: [f(l) for L in Ls for l in L]  # noqa: E731
+            groups += [(pick(lambda l: l[0].weight), None), (pick(lambda l: l[1].weight), None),
+                       (pick(lambda l: l[1].bias), None), (pick(lambda l: l[4].weight), None),
+                       (pick(lambda l: l[5].weight), None), (pick(lambda l: l[5].bias), None),
+                       (pick(lambda l: l[8].weight), rows * C), (pick(lambda l: l[8].bias), rows)]
         cross = [l.multihead_attn for l in self.layers]
         if all(type(m) is GlobalShareCrossAttention for m in cross):
             groups.append(([t for m in cross for t in (m.k.weight, m.v.weight)], None))
