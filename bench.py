@@ -102,13 +102,19 @@ def loss_fn(out):
 class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
-    def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True, criterion=None, targets=None):
+    def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True, criterion=None, targets=None,
+                 defer_wg=True):
         from vdetr_amd.dist import FlatParams, GradientReducer
+        global flush_weight_grads
+        from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
         self.model, self.inputs, self.world = model, inputs, world
         # criterion=None: the synthetic scalar loss of SURVEY.md §8d (the headline metric); otherwise the device set
         # criterion (v-detr_amd/criterion.py) on `targets`, prepared once: their box counts do not depend on the model
         self.criterion = criterion
         self.targets = criterion.prepare_targets(targets) if criterion is not None else None
+        # weight / bias gradients of the linear layers in shape-batched GEMMs after the backward (off its critical path)
+        self.defer_wg = defer_wg
+        defer_weight_grads(defer_wg)
         self.params = [p for p in model.parameters() if p.requires_grad]
         # parameters / gradients as views of two flat buffers: one AdamW launch, one norm, slice-shaped buckets
         self.flat = FlatParams(self.params, groups=model.flat_param_groups())
@@ -142,6 +148,8 @@ class Trainer:
         out = self.model(self.inputs)
         self.loss = loss_fn(out) if self.criterion is None else self.criterion(out, self.targets)[0]
         self.loss.backward()
+        if self.defer_wg:
+            flush_weight_grads()
         if not self.hooked:
             self.flat.pack_grads()  # one launch; (hooked eager mode accumulates straight into the flat buffer)
         if self.fps_prefetch:
@@ -353,6 +361,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss", default="synthetic", choices=["synthetic", "criterion"],
                     help="synthetic: scalar loss of SURVEY 8d (headline); criterion: the device set criterion on synthetic boxes")
+    ap.add_argument("--no-defer-wg", action="store_true", help="weight gradients inside the backward, one GEMM per layer")
     ap.add_argument("--no-criterion-leg", action="store_true", help="skip the extra N=1 measurement with the set criterion")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
@@ -391,7 +400,7 @@ def main():
             crit = build_criterion(default_criterion_args(), model.dataset_config)
             targets = make_targets(a.config, device, rank)
         return Trainer(model, inputs, world, use_graph, overlap=True, fps_prefetch=not a.no_fps_prefetch, criterion=crit,
-                       targets=targets)
+                       targets=targets, defer_wg=not a.no_defer_wg)
 
     trainer = make_trainer(a.loss == "criterion")
     graph_ok = False

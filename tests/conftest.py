@@ -98,3 +98,12 @@ def cpu_oracle_backend(monkeypatch):
 def load_golden(name):
     import numpy as np
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(autouse=True)
+def _no_leaked_runtime_switches():
+    """bench.Trainer turns process-wide switches on (deferred weight gradients); no test may inherit them."""
+    yield
+    from vdetr_amd.helpers import DeferredParamGrads
+    DeferredParamGrads.enabled = False
+    DeferredParamGrads.pending.clear()

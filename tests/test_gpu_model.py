@@ -360,3 +360,35 @@ def test_deferred_heads_backward_equals_per_stage_autograd(batch):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
     for n in b0:
         assert torch.allclose(b1[n].float(), b0[n].float(), rtol=1e-5, atol=1e-6), n
+
+
+def test_deferred_weight_gradients_equal_inline_ones():
+    """runtime.defer_weight_grads: dW / db of every `linear` as shape-batched GEMMs after the backward (flush) == the
+    per-layer GEMMs inside it, for plain parameters, unbound slices of a packed parameter and adjacent-parameter aliases."""
+    from vdetr_amd import attention as A
+    from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
+    model = _make_model(nq=64, npre=512, nl=4).to(DEV).train()
+    inp = _inputs(3000, 5, DEV, 1)
+    model(inp)
+    state = copy.deepcopy(model.state_dict()) if False else {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    for mode in (True, False):
+        defer_weight_grads(mode)
+        A.reset_rng()
+        torch.manual_seed(0)
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(state[k])
+        model.zero_grad(set_to_none=True)
+        for f in inp["backbone_features"]:
+            f.grad = None
+        _loss(model(inp)).backward()
+        if mode:
+            missing = [n for n, p in model.named_parameters() if p.grad is None and "in_proj_weight" in n]
+            assert missing, "the deferred gradients must not exist before the flush"
+            flush_weight_grads()
+        res[mode] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    defer_weight_grads(False)
+    assert res[True].keys() == res[False].keys()
+    for n, g in res[False].items():
+        assert float((res[True][n] - g).abs().max()) <= 2e-4 * (float(g.abs().max()) + 1e-12), n

@@ -23,21 +23,68 @@ def colsum(x2d):
     return out
 
 
+class DeferredParamGrads:
+    """Weight / bias gradients of the `linear` layers, computed in batches AFTER the backward pass.
+
+    Only dX is on the backward's critical path; dW = dY^T X and db = column sums of dY are ~130 launches of 5-11 us per
+    step, each a [256 x 1024] x [1024 x 256] product that fills a quarter of the GPU.  With this enabled
+    (runtime.defer_weight_grads) `_Linear.backward` only stores (dY, X) and returns the input gradient; `flush()` -- called
+    by the training loop right after `loss.backward()` -- groups the stored pairs by shape, computes each group as ONE
+    batched GEMM and ONE reduction, and hands the results to autograd (`torch.autograd.backward` on the weight / bias
+    tensors themselves, so parameter aliases and gradient accumulation behave as always)."""
+    enabled = False
+    pending = []
+
+    @classmethod
+    def flush(cls):
+        items, cls.pending = cls.pending, []
+        if not items:
+            return
+        groups = {}
+        for it in items:
+            groups.setdefault((tuple(it[2].shape), tuple(it[3].shape)), []).append(it)
+        roots, grads = [], []
+        with torch.no_grad():
+            for group in groups.values():
+                if len(group) == 1:
+                    w, b, g2, x2 = group[0]
+                    dws = [torch.mm(g2.t(), x2)] if w is not None else [None]
+                    dbs = [colsum(g2 if g2.stride(1) == 1 else g2.contiguous())] if b is not None else [None]
+                else:
+                    G = torch.stack([it[2] for it in group])                       # [n, rows, out]
+                    dws = torch.bmm(G.transpose(1, 2), torch.stack([it[3] for it in group])).unbind(0) \
+                        if any(it[0] is not None for it in group) else [None] * len(group)
+                    dbs = G.sum(1).unbind(0) if any(it[1] is not None for it in group) else [None] * len(group)
+                for (w, b, _, _), dw, db in zip(group, dws, dbs):
+                    if w is not None:
+                        roots.append(w)
+                        grads.append(dw)
+                    if b is not None:
+                        roots.append(b)
+                        grads.append(db)
+        if roots:
+            torch.autograd.backward(roots, grads)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b with the bias gradient as ONE launch (ATen: two-pass reduction, 2 launches / 14 us per layer)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(g2, w).view(x.shape)
+        if DeferredParamGrads.enabled and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            DeferredParamGrads.pending.append((w if ctx.needs_input_grad[1] else None, b if ctx.needs_input_grad[2] else None,
+                                               g2, x.reshape(-1, x.shape[-1])))
+            return dx, None, None
         if ctx.needs_input_grad[1]:
             dw = torch.mm(g2.t(), x.reshape(-1, x.shape[-1]))
         if ctx.needs_input_grad[2]:

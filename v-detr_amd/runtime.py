@@ -26,3 +26,18 @@ def enable_gemm_tuning(rank=0, cache_dir=None):
     tn.enable(True)
     tn.tuning_enable(True)
     return path
+
+
+def defer_weight_grads(enable=True):
+    """Compute the weight / bias gradients of the `helpers.linear` layers in shape-batched GEMMs after the backward pass
+    instead of one by one inside it (helpers.DeferredParamGrads).  The training loop must call ``flush_weight_grads()``
+    after ``loss.backward()`` and before anything reads a ``.grad``."""
+    from .helpers import DeferredParamGrads
+    DeferredParamGrads.enabled = bool(enable)
+    if not enable:
+        DeferredParamGrads.pending.clear()
+
+
+def flush_weight_grads():
+    from .helpers import DeferredParamGrads
+    DeferredParamGrads.flush()
