@@ -97,6 +97,9 @@ def linear(x, w, b=None):
     """F.linear; on the GPU with a bias, the backward computes the bias gradient with the one-launch column sum."""
     if b is not None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and (
             x.requires_grad or w.requires_grad or b.requires_grad):
+        if DeferredParamGrads.pending:  # a forward pass with gradients of the previous backward still waiting: they would be lost
+            raise RuntimeError("runtime.defer_weight_grads() is on but runtime.flush_weight_grads() was not called after "
+                               "the last backward pass")
         return _Linear.apply(x, w, b)
     return torch.nn.functional.linear(x, w, b)
 
