@@ -286,6 +286,11 @@ def kernel_rooflines(cfg_name, device, reps=20):
         if cfg_name == "c2":
             fwd_obj["traffic"] = tr["attn_fwd_kernel<false,true>"]["bytes"]
             bwd_obj["traffic"] = tr["attn_bwd_scores_rpe_mm_kernel"]["bytes"]
+            vi = tr["attn_bwd_scores_rpe_mm_kernel"].get("valu_wave_insts")
+            if vi:  # what actually bounds the kernel: VALU issue (1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction)
+                bwd_obj["valu_issue"] = {"wave_insts": vi, "limit_us": vi / 614.4e9 * 1e6, "frac": vi / 614.4e9 / t_bwd,
+                                         "note": "SQ_INSTS_VALU per launch (offline PMC pass) / chip issue rate / launch time: "
+                                                 "the kernel is VALU-bound, the HBM fraction above is low by construction"}
     except (OSError, KeyError):
         pass
     return fwd_obj, bwd_obj
