@@ -35,7 +35,7 @@ DEFAULT_WEIGHTS = dict(  # main.py:118-137
     matcher_cls_cost=3.0, matcher_giou_cost=2.0, matcher_center_cost=1.0, matcher_objectness_cost=0.0,
     matcher_size_cost=0.5, matcher_anglecls_cost=0.0, matcher_anglereg_cost=0.0,
     loss_giou_weight=2.0, loss_sem_cls_weight=3.0, loss_angle_cls_weight=0.1, loss_angle_reg_weight=0.5,
-    loss_center_weight=1.0, loss_size_weight=0.5, point_cls_loss_weight=0.05)
+    loss_center_weight=1.0, loss_size_weight=0.5, point_cls_loss_weight=0.05, loss_no_object_weight=0.0)
 
 
 # ------------------------------------------------------------------------------------------------ geometry
@@ -244,19 +244,32 @@ def focal_sum(logits, labels, alpha):
     return loss.mean(1).sum() * logits.shape[1]
 
 
+def ce_mean(logits, labels, no_object_weight):
+    """F.cross_entropy(..., weight=ones with the LAST class at `no_object_weight`, reduction="mean") of criterion.py:240-246,
+    366-371: the weighted mean over every row."""
+    wt = torch.ones(logits.shape[-1])
+    wt[-1] = no_object_weight
+    return F.cross_entropy(logits.transpose(2, 1), labels, wt, reduction="mean")
+
+
 def stage_losses(o, t, w, focal_alpha=0.25):
     """single_output_forward (criterion.py:602-657) for one stage.  Returns (weighted total, dict of weighted parts,
-    (inds, mask))."""
+    (inds, mask)).  focal_alpha=None selects the cross-entropy class loss (cls_loss="celoss")."""
+    focal = focal_alpha is not None
     giou, center, size = pair_terms(o, t)
-    cost = match_costs(o, t, giou.detach(), center.detach(), size.detach(), w)
+    cost = match_costs(o, t, giou.detach(), center.detach(), size.detach(), w, focal=focal)
     inds, mask = assign(cost, t["nactual_gt"])
     nb = t["num_boxes"]
     parts = {}
     if t["num_boxes_replica"] > 0:
         logits = o["sem_cls_logits"]
         lab = torch.gather(t["gt_box_sem_cls_label"], 1, inds)
-        lab = torch.where(mask > 0, lab, torch.full_like(lab, logits.shape[-1]))
-        parts["loss_sem_cls"] = focal_sum(logits, lab, focal_alpha) / nb
+        if focal:
+            lab = torch.where(mask > 0, lab, torch.full_like(lab, logits.shape[-1]))
+            parts["loss_sem_cls"] = focal_sum(logits, lab, focal_alpha) / nb
+        else:  # unmatched rows carry the last ("no object") class; weighted mean, not divided by num_boxes (:360-371)
+            lab = torch.where(mask > 0, lab, torch.full_like(lab, logits.shape[-1] - 1))
+            parts["loss_sem_cls"] = ce_mean(logits, lab, w["loss_no_object_weight"])
         alab = torch.gather(t["gt_angle_class_label"], 1, inds)
         nbin = o["angle_logits"].shape[-1]
         parts["loss_angle_cls"] = (F.cross_entropy(o["angle_logits"].transpose(2, 1), alab, reduction="none") * mask).sum() / nb
@@ -286,7 +299,7 @@ def stage_losses(o, t, w, focal_alpha=0.25):
 
 
 def point_cls_loss(enc, t, w, focal_alpha=0.25):
-    """criterion.py:270-327 (focal branch)."""
+    """criterion.py:270-327 (focal branch; focal_alpha=None: the cross-entropy branch :309-322)."""
     logits = enc["point_cls_logits"]
     if t["num_boxes_replica"] == 0:
         return logits.sum() * 0.0, None
@@ -303,6 +316,9 @@ def point_cls_loss(enc, t, w, focal_alpha=0.25):
     matched = pick != G
     pick = torch.where(matched, pick, torch.zeros_like(pick))
     lab = torch.gather(t["gt_box_sem_cls_label"], 1, pick)
+    if focal_alpha is None:
+        lab = torch.where(matched, lab, torch.full_like(lab, logits.shape[-1] - 1))
+        return ce_mean(logits, lab, w["loss_no_object_weight"]), lab
     lab = torch.where(matched, lab, torch.full_like(lab, logits.shape[-1]))
     return focal_sum(logits, lab, focal_alpha) / t["num_boxes"], lab
 

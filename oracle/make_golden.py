@@ -218,7 +218,7 @@ def import_reference_criterion():
     return C
 
 
-def synthetic_stage(g, cfg, B, P, C, nbin=1, rotated=False, near=None):
+def synthetic_stage(g, cfg, B, P, C, nbin=1, rotated=False, near=None, softmax=False):
     """One stage's box-prediction dictionary with the keys/shapes of vdetr_transformer.py:319-333, from random heads."""
     lo, ext = torch.tensor([1.0, 1.0, 1.0]), torch.tensor([8.0, 6.0, 3.0])
     pre_c = lo + torch.rand((B, P, 3), generator=g) * ext
@@ -236,7 +236,8 @@ def synthetic_stage(g, cfg, B, P, C, nbin=1, rotated=False, near=None):
     # a leaf: the fixture holds d loss / d corners itself (the chain into centre/size is the box decode's business)
     angle = (torch.rand((B, P), generator=g) - 0.5) * 2.0 if rotated else torch.zeros((B, P))
     corners = cfg.box_parametrization_to_corners(center.detach(), size.detach(), angle).requires_grad_(True)
-    return {"sem_cls_logits": logits, "sem_cls_prob": logits, "center_unnormalized": center, "size_unnormalized": size,
+    prob = torch.softmax(logits, -1)[..., :-1].detach() if softmax else logits   # compute_objectness_and_cls_prob (:74-86)
+    return {"sem_cls_logits": logits, "sem_cls_prob": prob, "center_unnormalized": center, "size_unnormalized": size,
             "center_normalized": center, "size_normalized": size,
             "angle_logits": angle_logits, "angle_residual_normalized": angle_res,
             "angle_continuous": torch.zeros((B, P)), "objectness_prob": torch.rand((B, P), generator=g),
@@ -278,18 +279,23 @@ def criterion_cases(Cfg):
                                               ("criterion_norepeat", 1, 80, 40, 1, 8, (6,), 1),
                                               ("criterion_empty", 1, 32, 16, 1, 8, (0,), 5),
                                               # rotated ground truth: the footprint overlap becomes a polygon clip
-                                              ("criterion_rotated", 1, 48, 24, 1, 8, (5,), 5)]:
+                                              ("criterion_rotated", 1, 48, 24, 1, 8, (5,), 5),
+                                              # cls_loss="celoss": softmax cost, weighted cross entropy, no binary first stage
+                                              ("criterion_celoss", 2, 64, 32, 1, 8, (4, 6), 5)]:
         g = torch.Generator().manual_seed(sum(map(ord, name)))
-        a = Namespace(**{**base, "repeat_num": rep})
+        ce = name == "criterion_celoss"
+        a = Namespace(**{**base, "repeat_num": rep, **({"cls_loss": "celoss", "is_bilable": False, "loss_no_object_weight": 0.25}
+                                                         if ce else {})})
         crit = C.build_criterion(a, cfg)
         rot = name == "criterion_rotated"
         targets = synthetic_targets(g, cfg, B, G, counts, cfg.num_semcls, rotated=rot)
         near = targets["gt_box_centers"][:, :counts[0]] if rot else None
-        stages = [synthetic_stage(g, cfg, B, N0, 1, rotated=rot, near=near)] + [
-            synthetic_stage(g, cfg, B, P, cfg.num_semcls, rotated=rot, near=near) for _ in range(S + 1)]
+        nc = cfg.num_semcls + (1 if ce else 0)
+        stages = [synthetic_stage(g, cfg, B, N0, nc if ce else 1, rotated=rot, near=near, softmax=ce)] + [
+            synthetic_stage(g, cfg, B, P, nc, rotated=rot, near=near, softmax=ce) for _ in range(S + 1)]
         seed_xyz = torch.tensor([1.0, 1.0, 1.0]) + torch.rand((B, N0, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0])
         seed_xyz[:, :G] = targets["gt_box_centers"]                 # some seeds certainly inside a box
-        point_logits = (torch.randn((B, N0, cfg.num_semcls), generator=g) - 1).requires_grad_(True)
+        point_logits = (torch.randn((B, N0, nc), generator=g) - 1).requires_grad_(True)
         outputs = {"outputs": stages[-1], "aux_outputs": stages[:-1], "seed_inds": torch.zeros((B, N0), dtype=torch.int64),
                    "seed_xyz": seed_xyz, "enc_outputs": {"point_cls_logits": point_logits}}
         # the matcher's results are internal to the reference: record them through the matcher module
@@ -299,7 +305,7 @@ def criterion_cases(Cfg):
         hook.remove()
         loss.backward()
         arrays = {"loss": np_(loss), "B": np.array(B), "N0": np.array(N0), "P": np.array(P), "S": np.array(S),
-                  "repeat_num": np.array(rep), "seed_xyz": np_(seed_xyz), "point_cls_logits": np_(point_logits),
+                  "repeat_num": np.array(rep), "celoss": np.array(int(ce)), "seed_xyz": np_(seed_xyz), "point_cls_logits": np_(point_logits),
                   "grad:point_cls_logits": np_(point_logits.grad)}
         for k, v in targets.items():
             arrays["target:" + k] = np_(v)

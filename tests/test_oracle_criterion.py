@@ -10,7 +10,7 @@ from oracle import criterion_oracle as CO
 from oracle.lsa_oracle import linear_sum_assignment as lsa_restated
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CASES = ["criterion_small", "criterion_wide", "criterion_norepeat", "criterion_empty", "criterion_rotated"]
+CASES = ["criterion_small", "criterion_wide", "criterion_norepeat", "criterion_empty", "criterion_rotated", "criterion_celoss"]
 DIFF = ("sem_cls_logits", "center_reg", "size_reg", "angle_logits", "angle_residual_normalized", "box_corners")
 
 
@@ -24,7 +24,8 @@ def load_case(name, device="cpu"):
         for k in DIFF + ("pre_box_center_unnormalized", "pre_box_size_unnormalized", "objectness_prob"):
             t = torch.from_numpy(z[f"stage{si}:{k}"]).to(device)
             st[k] = t.requires_grad_(True) if k in DIFF else t
-        st["sem_cls_prob"] = st["sem_cls_logits"]
+        ce = "celoss" in z.files and int(z["celoss"])  # cls_loss="celoss": the matcher sees softmax[..., :-1] (:80-86)
+        st["sem_cls_prob"] = torch.softmax(st["sem_cls_logits"].detach(), -1)[..., :-1] if ce else st["sem_cls_logits"]
         stages.append(st)
     targets = {k[len("target:"):]: torch.from_numpy(z[k]).to(device) for k in z.files if k.startswith("target:")}
     point_logits = torch.from_numpy(z["point_cls_logits"]).to(device).requires_grad_(True)
@@ -63,7 +64,10 @@ def check_against_golden(z, outputs, loss, loss_dict, matches, rtol=1e-4, atol=1
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_matches_reference_criterion(name):
     outputs, targets, z = load_case(name)
-    loss, loss_dict, assigns = CO.set_criterion(outputs, targets, repeat_num=int(z["repeat_num"]))
+    ce = "celoss" in z.files and int(z["celoss"])
+    loss, loss_dict, assigns = CO.set_criterion(outputs, targets, repeat_num=int(z["repeat_num"]),
+                                                **(dict(focal_alpha=None, is_bilable=False,
+                                                        weights={"loss_no_object_weight": 0.25}) if ce else {}))
     loss.backward()
     nst = int(z["S"]) + 2
     matches = {nst - 1: assigns["outputs"], **{k: assigns[k] for k in range(nst - 1)}}
