@@ -430,13 +430,17 @@ int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdetr_stream_t 
 /* Seed-point labels of loss_point_cls (criterion.py:270-301): label[b,n] = class of the smallest-volume box containing
  * seed n (mmcv points_in_boxes_all semantics on (centre, size, angle) with the bottom face at z - dz/2), C = none. */
 int vdetr_point_labels_f32(const float* seed_xyz, const float* gt, const int64_t* nactual, int B, int N, int G, int C,
-                           int64_t* labels, vdetr_stream_t stream);
+                           int64_t* labels, float* matched_count, vdetr_stream_t stream);
+/* matched_count (optional, zero-filled by the caller): += number of seeds inside a box */
 
 typedef struct vdetr_setloss_desc {
   int32_t B, P, G, C, A;
   int32_t label_override;  /* as in vdetr_match_desc */
   float focal_alpha;       /* cls_loss "focalloss_<alpha>" (criterion.py:238-239) */
   float w_cls, w_angle_cls, w_angle_reg, w_center, w_size, w_giou; /* loss_*_weight (main.py:128-136); folded into values and gradients */
+  int32_t cls_kind;        /* VDETR_CLS_SIGMOID: focal loss; VDETR_CLS_SOFTMAX: cross entropy over C classes whose LAST one is "no
+                              object" (cls_loss="celoss", criterion.py:360-371), weighted mean with w_no_object on that class */
+  float w_no_object;       /* loss_no_object_weight (main.py:131) */
   const float* cls_logits; /* [B,P,C] */
   /* box terms; all NULL = classification only (the seed-point loss) */
   const float *center_reg, *size_reg, *pre_center, *pre_size; /* [B,P,3] */
@@ -454,6 +458,8 @@ typedef struct vdetr_setloss_desc {
   unsigned long long* card_ws; /* [B] zero-initialised scratch of the cardinality count (one 64-bit atomic per workgroup) */
   float *d_cls_logits, *d_center_reg, *d_size_reg, *d_corners, *d_angle_logits, *d_angle_res_norm; /* d total / d input; written in full */
   const float* rotated;    /* as in vdetr_match_desc */
+  const float* ce_rows_matched; /* cross entropy with `labels`: device scalar = rows whose label is not C-1 (the weighted mean's
+                                   normaliser); NULL with (inds, mask): sum_b min(nactual_b, P) */
 } vdetr_setloss_desc;
 int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream);
 /* the same for n descriptors (HOST array: all stages of a step + the seed-point loss) in one launch per 12 descriptors */

@@ -93,7 +93,9 @@ def test_cost_matrix_matches_oracle(name):
     from oracle import criterion_oracle as CO
     from vdetr_amd.criterion import build_criterion, default_criterion_args, pack_ground_truth
     outputs, targets, z = _stage_and_targets(name)
-    crit = build_criterion(default_criterion_args(repeat_num=int(z["repeat_num"])), None)
+    ce = "celoss" in z.files and int(z["celoss"])
+    extra = dict(cls_loss="celoss", is_bilable=False, loss_no_object_weight=0.25) if ce else {}
+    crit = build_criterion(default_criterion_args(repeat_num=int(z["repeat_num"]), **extra), None)
     o = outputs["outputs"]
     records = pack_ground_truth(targets)
     nactual = targets["gt_box_present"].sum(1).long()
@@ -103,7 +105,7 @@ def test_cost_matrix_matches_oracle(name):
     tc = {k: v.cpu() for k, v in targets.items()}
     tc["nactual_gt"] = nactual.cpu()
     giou, center, size = CO.pair_terms(oc, tc)
-    ref = CO.match_costs(oc, tc, giou, center, size, CO.DEFAULT_WEIGHTS)
+    ref = CO.match_costs(oc, tc, giou, center, size, CO.DEFAULT_WEIGHTS, focal=not ce)
     for b in range(ref.shape[0]):
         n = int(nactual[b])
         np.testing.assert_allclose(cost_t[b, :n].T.cpu().numpy(), ref[b, :, :n].numpy(), rtol=1e-4, atol=1e-5)
@@ -137,7 +139,9 @@ def test_criterion_matches_reference_fixture(name):
     """loss, every loss_dict entry, assignments and the gradients of all inputs against criterion.py's own results."""
     from vdetr_amd.criterion import build_criterion, default_criterion_args
     outputs, targets, z = _stage_and_targets(name)
-    crit = build_criterion(default_criterion_args(repeat_num=int(z["repeat_num"])), None)
+    ce = "celoss" in z.files and int(z["celoss"])
+    extra = dict(cls_loss="celoss", is_bilable=False, loss_no_object_weight=0.25) if ce else {}
+    crit = build_criterion(default_criterion_args(repeat_num=int(z["repeat_num"]), **extra), None)
     loss, loss_dict = crit(outputs, targets)
     loss.backward()
     matches, _ = crit.last_assignments()

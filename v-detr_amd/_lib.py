@@ -126,14 +126,15 @@ class LsaBatch(ctypes.Structure):
 _LOSS_W = ("w_cls", "w_angle_cls", "w_angle_reg", "w_center", "w_size", "w_giou")
 _LOSS_PTR = ("cls_logits", "center_reg", "size_reg", "pre_center", "pre_size", "corners", "angle_logits", "angle_res_norm",
              "gt", "nactual", "inds", "mask", "labels", "num_boxes", "losses", "card_ws", "d_cls_logits", "d_center_reg", "d_size_reg",
-             "d_corners", "d_angle_logits", "d_angle_res_norm", "rotated")
+             "d_corners", "d_angle_logits", "d_angle_res_norm", "rotated", "ce_rows_matched")
 
 
 class SetLossDesc(ctypes.Structure):
     """Mirror of ``vdetr_setloss_desc``."""
 
     _fields_ = ([(n, ctypes.c_int32) for n in ("B", "P", "G", "C", "A", "label_override")] + [("focal_alpha", c_float)] +
-                [(n, c_float) for n in _LOSS_W] + [(n, c_void_p) for n in _LOSS_PTR])
+                [(n, c_float) for n in _LOSS_W] + [("cls_kind", ctypes.c_int32), ("w_no_object", c_float)] +
+                [(n, c_void_p) for n in _LOSS_PTR])
 
 
 # name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
@@ -179,7 +180,7 @@ _SIGNATURES = {
     "vdetr_match_cost_f32": (c_int, [ctypes.POINTER(MatchDesc), c_void_p]),
     "vdetr_match_cost_batch_f32": (c_int, [ctypes.POINTER(MatchDesc), c_int, c_void_p]),
     "vdetr_lsa_f64": (c_int, [ctypes.POINTER(LsaBatch), c_void_p, c_void_p]),
-    "vdetr_point_labels_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_point_labels_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vdetr_set_loss_f32": (c_int, [ctypes.POINTER(SetLossDesc), c_void_p]),
     "vdetr_set_loss_batch_f32": (c_int, [ctypes.POINTER(SetLossDesc), c_int, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),

@@ -16,7 +16,8 @@ No host synchronisation anywhere (the reference has >= 30 per step: ``.item()``,
 integers), so the whole training step including the criterion can be captured in one hipGraph.  ``nactual_gt`` and
 ``num_boxes`` stay device tensors.
 
-Scope: ``cls_loss="focalloss_*"`` and ``iou_type="giou"`` (the reference defaults); other settings raise.  Rotated ground
+Scope: ``cls_loss`` "focalloss_<alpha>" (default) or "celoss" (3DETR's weighted cross entropy), ``iou_type="giou"``; the
+mmcv-based diou / iou variants raise.  Rotated ground
 truth (any ``gt_box_angles`` > 0, criterion.py:616) switches the GIoU's footprint overlap to the polygon clip of
 box_util.py:566-589 through a device flag -- the reference decides that with ``.item()``.  There is no CPU path: CPU
 tensors raise.
@@ -209,6 +210,8 @@ class _CriterionFn(torch.autograd.Function):
             d = L.SetLossDesc()
             d.B, d.P, d.G, d.C, d.A, d.label_override = B, P, G, C, ins[4].shape[-1], override
             d.focal_alpha = crit.focal_alpha
+            d.cls_kind = L.VDETR_CLS_SIGMOID if crit.focal else L.VDETR_CLS_SOFTMAX
+            d.w_no_object = crit.no_object_weight
             w = crit.loss_weight_dict
             d.w_cls, d.w_angle_cls, d.w_angle_reg = w["loss_sem_cls_weight"], w["loss_angle_cls_weight"], w["loss_angle_reg_weight"]
             d.w_center, d.w_size, d.w_giou = w["loss_center_weight"], w["loss_size_weight"], w["loss_giou_weight"]
@@ -234,17 +237,22 @@ class _CriterionFn(torch.autograd.Function):
             B, N, C = logits.shape
             records, G, nactual, nb = prep.stage(False)
             point_labels = torch.empty((B, N), dtype=torch.int64, device=dev)
-            L.check(lib.vdetr_point_labels_f32(L.ptr(seed_xyz), L.ptr(records), L.ptr(nactual), B, N, G, C, L.ptr(point_labels),
-                                               st), "point_labels")
+            # seeds outside every box: label C (no class) for the focal loss, the trailing "no object" class for cross entropy
+            inside = None if crit.focal else torch.zeros(1, dtype=torch.float32, device=dev)
+            L.check(lib.vdetr_point_labels_f32(L.ptr(seed_xyz), L.ptr(records), L.ptr(nactual), B, N, G,
+                                               C if crit.focal else C - 1, L.ptr(point_labels), L.ptr(inside), st), "point_labels")
             d = L.SetLossDesc()
             d.B, d.P, d.G, d.C, d.A, d.label_override = B, N, G, C, 1, -1
             d.focal_alpha = crit.focal_alpha
+            d.cls_kind = L.VDETR_CLS_SIGMOID if crit.focal else L.VDETR_CLS_SOFTMAX
+            d.w_no_object = crit.no_object_weight
+            d.ce_rows_matched = inside.data_ptr() if inside is not None else None
             d.w_cls = crit.args.point_cls_loss_weight
             d.cls_logits, d.labels, d.nactual, d.num_boxes = logits.data_ptr(), point_labels.data_ptr(), nactual.data_ptr(), nb.data_ptr()
             d.losses, d.d_cls_logits = losses[ns].data_ptr(), grads[-1].data_ptr()
             d.card_ws = losses[ns].data_ptr() + 32
             loss_descs.append(d)
-            keep.append((seed_xyz, logits))
+            keep.append((seed_xyz, logits, inside))
         # every stage's losses + gradients and the seed-point loss: ONE launch
         arr = (L.SetLossDesc * len(loss_descs))(*loss_descs)
         L.check(lib.vdetr_set_loss_batch_f32(arr, len(loss_descs), st), "set_loss")
@@ -269,12 +277,16 @@ class SetCriterion(nn.Module):
         self.args, self.dataset_config, self.matcher = args, dataset_config, matcher
         self.loss_weight_dict = dict(loss_weight_dict)
         self.is_bilable, self.repeat_num, self.iou_type = args.is_bilable, args.repeat_num, args.iou_type
-        if args.cls_loss.split("_")[0] != "focalloss":
-            raise NotImplementedError("only cls_loss='focalloss_<alpha>' (the reference default, main.py:127) runs on the device")
         if self.iou_type != "giou":
             raise NotImplementedError("iou_type 'diou' / 'iou' need mmcv's rotated-IoU ops (criterion.py:21-22); only 'giou'")
-        self.focal_alpha = float(args.cls_loss.split("_")[1])
-        self.loss_weight_dict.pop("loss_no_object_weight", None)  # criterion.py:240
+        # class loss: "focalloss_<alpha>" (the default, main.py:127) or the weighted cross entropy of 3DETR ("celoss": the
+        # logits then carry a trailing "no object" class weighted by loss_no_object_weight, criterion.py:240-246)
+        self.focal = args.cls_loss.split("_")[0] == "focalloss"
+        self.focal_alpha = float(args.cls_loss.split("_")[1]) if self.focal else 0.0
+        self.no_object_weight = float(self.loss_weight_dict.pop("loss_no_object_weight", 0.0))  # criterion.py:240,245
+        if not self.focal and self.is_bilable:
+            raise ValueError("cls_loss='celoss' with is_bilable: the reference's class-weight vector does not fit the binary "
+                             "first stage (criterion.py:242-246, 679-684)")
         self._last = None
 
     def prepare_targets(self, targets):

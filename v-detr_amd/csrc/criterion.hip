@@ -580,7 +580,7 @@ __global__ __launch_bounds__(MAXT) void lsa_kernel(vdetr_lsa_batch batch, int32_
 // ------------------------------------------------------------------------------------------------ seed labels
 __global__ __launch_bounds__(256) void point_labels_kernel(const float* __restrict__ xyz, const float* __restrict__ gt,
                                                            const int64_t* __restrict__ nactual, int N, int G, int C,
-                                                           int64_t* __restrict__ labels) {
+                                                           int64_t* __restrict__ labels, float* __restrict__ matched_count) {
   const int b = blockIdx.y, nidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (nidx >= N) return;
   const float* p = xyz + ((size_t)b * N + nidx) * 3;
@@ -604,6 +604,10 @@ __global__ __launch_bounds__(256) void point_labels_kernel(const float* __restri
     if (vol < best) best = vol, pick = g;
   }
   labels[(size_t)b * N + nidx] = pick >= 0 ? (int64_t)gt[((size_t)b * G + pick) * F + VDETR_GT_LABEL] : (int64_t)C;
+  if (matched_count != nullptr) {  // rows that carry a real class: the normaliser of the weighted cross-entropy mean
+    const unsigned long long hit = __ballot(pick >= 0);
+    if ((threadIdx.x & 63) == 0 && hit) atomicAdd(matched_count, (float)__popcll(hit));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ losses + gradients
@@ -738,11 +742,23 @@ __global__ __launch_bounds__(kLossRows) void set_loss_kernel(LossBatch batch) {
   const bool gate = total_boxes > 0;
   const float inv_nb = 1.f / d.num_boxes[0];
   const bool boxes = d.center_reg != nullptr;
+  // class loss: focal (sum / num_boxes) or the weighted cross-entropy MEAN of criterion.py:360-371 with the last class = "no
+  // object" at weight w_no_object: its normaliser is sum of the row weights = M + (rows - M) * w_no_object, M = rows that
+  // carry a real class = sum_b min(nactual_b, P) after a Hungarian match (or the caller's count for the seed-point loss)
+  const bool ce = d.cls_kind == VDETR_CLS_SOFTMAX;
+  float cls_scale = inv_nb;
+  if (ce) {
+    float m = 0.f;
+    if (d.ce_rows_matched != nullptr) m = d.ce_rows_matched[0];
+    else
+      for (int i = 0; i < d.B; ++i) m += (float)min((long)d.nactual[i], (long)d.P);
+    cls_scale = 1.f / (m + ((float)d.B * (float)d.P - m) * d.w_no_object);
+  }
   float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // sem_cls, angle_cls, angle_reg, center, size, giou, object count
   if (tid < rows) {
     const size_t row = (size_t)b * d.P + p0 + tid;
     bool matched = false;
-    int gi = 0, label = d.C;
+    int gi = 0, label = ce ? d.C - 1 : d.C;
     if (d.inds != nullptr) {
       matched = d.mask[row] != 0.f;
       gi = (int)d.inds[row];
@@ -760,6 +776,16 @@ __global__ __launch_bounds__(kLossRows) void set_loss_kernel(LossBatch batch) {
         if (xv > best) best = xv, arg = c;
       }
       acc[6] = arg != d.C - 1 ? 1.f : 0.f;
+      if (ce) {  // weighted cross entropy of this row + its gradient
+        float se = 0.f;
+        for (int c = 0; c < d.C; ++c) se += expf(x[c] - best);
+        const float lse = best + logf(se);
+        const float wy = label == d.C - 1 ? d.w_no_object : 1.f;
+        acc[0] = wy * (lse - x[label]);
+        const float gs = gate ? wy * (d.w_cls * cls_scale) : 0.f;
+        float* __restrict__ dx = d.d_cls_logits + row * d.C;
+        for (int c = 0; c < d.C; ++c) dx[c] = (expf(x[c] - lse) - (c == label ? 1.f : 0.f)) * gs;
+      }
     }
     if (boxes) {
       float d_creg[3] = {0.f, 0.f, 0.f}, d_sreg[3] = {0.f, 0.f, 0.f};
@@ -814,7 +840,7 @@ __global__ __launch_bounds__(kLossRows) void set_loss_kernel(LossBatch batch) {
     }
   }
   __syncthreads();
-  {  // focal loss (criterion.py:77-98) over this chunk's logits
+  if (!ce) {  // focal loss (criterion.py:77-98) over this chunk's logits
     const size_t base = ((size_t)b * d.P + p0) * d.C;
     const float* __restrict__ x = d.cls_logits + base;
     float* __restrict__ dx = d.d_cls_logits + base;
@@ -851,7 +877,7 @@ __global__ __launch_bounds__(kLossRows) void set_loss_kernel(LossBatch batch) {
     const float w[6] = {d.w_cls, d.w_angle_cls, d.w_angle_reg, d.w_center, d.w_size, d.w_giou};
     float tot = 0.f;
     for (int t = 0; t < 6; ++t) {
-      const float val = gate ? sm[t] * inv_nb * w[t] : 0.f;
+      const float val = gate ? sm[t] * (t == 0 ? cls_scale : inv_nb) * w[t] : 0.f;
       if (w[t] > 0.f) tot += val;
       atomicAdd(d.losses + t, val);
     }
@@ -974,11 +1000,11 @@ extern "C" int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdet
 }
 
 extern "C" int vdetr_point_labels_f32(const float* seed_xyz, const float* gt, const int64_t* nactual, int B, int N, int G,
-                                      int C, int64_t* labels, vdetr_stream_t stream) {
+                                      int C, int64_t* labels, float* matched_count, vdetr_stream_t stream) {
   VDETR_REQUIRE(seed_xyz && gt && nactual && labels, "point_labels: null pointer");
   VDETR_REQUIRE(B >= 1 && N >= 1 && G >= 1 && C >= 1, "point_labels: bad sizes");
   hipLaunchKernelGGL(point_labels_kernel, dim3(ceil_div(N, 256), B), dim3(256), 0, (hipStream_t)stream, seed_xyz, gt, nactual, N,
-                     G, C, labels);
+                     G, C, labels, matched_count);
   return check_launch("point_labels");
 }
 
