@@ -465,6 +465,19 @@ int vdetr_set_loss_f32(const vdetr_setloss_desc* d, vdetr_stream_t stream);
 /* the same for n descriptors (HOST array: all stages of a step + the seed-point loss) in one launch per 12 descriptors */
 int vdetr_set_loss_batch_f32(const vdetr_setloss_desc* descs, int n, vdetr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Greedy 3-D NMS of a scene's predictions (reference utils/nms.py:78-162 nms_3d_faster /
+ * nms_3d_faster_samecls as called from utils/ap_calculator.py:165-220 on the min / max extents of the 8 box corners).
+ * corners (B,K,8,3) f32, score (B,K) f32, cls (B,K) i32 or NULL (class-agnostic nms_3d_faster), valid (B,K) u8 or NULL
+ * (the nonempty_box_mask: invalid boxes are neither kept nor suppress), order (B,K) i64 = ascending STABLE arg-sort of
+ * score (the reference's np.argsort; boxes are visited from its end) -> keep (B,K) u8.  IoU and the threshold test run in
+ * fp64 as in numpy (np.zeros((K, 8)) holds the float32 values as float64).  K <= 4096.
+ * ---------------------------------------------------------------------------------------------- */
+size_t vdetr_nms3d_workspace_bytes(int B, int K);
+int vdetr_nms3d_f32(const float* corners, const float* score, const int32_t* cls, const uint8_t* valid, const int64_t* order,
+                    int B, int K, double iou_threshold, int old_type, uint8_t* keep, void* workspace, size_t workspace_bytes,
+                    vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

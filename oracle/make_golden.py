@@ -324,6 +324,28 @@ def criterion_cases(Cfg):
         save(name, **arrays)
 
 
+def nms_cases():
+    """utils/nms.py is plain numpy: the reference's own picks on random scenes of overlapping boxes."""
+    from utils.nms import nms_3d_faster, nms_3d_faster_samecls  # noqa  (the reference's /root/reference/utils/nms.py)
+    rng = np.random.default_rng(7)
+    arrays = {}
+    for ci, (K, ncls) in enumerate([(300, 18), (64, 3), (1024, 18), (5, 1)]):
+        center = rng.uniform([1, 1, 1], [9, 7, 4], (K, 3)) if K != 300 else rng.uniform([1, 1, 1], [4, 3, 2], (K, 3))
+        size = rng.uniform(0.3, 2.0, (K, 3))
+        corners = np.stack([center + 0.5 * size * np.array(sg) for sg in
+                            [(1, 1, 1), (1, 1, -1), (-1, 1, -1), (-1, 1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1), (-1, -1, 1)]],
+                           1).astype(np.float32)
+        score = rng.random(K).astype(np.float32)
+        cls = rng.integers(0, ncls, K)
+        boxes = np.zeros((K, 8))                                   # float64, as ap_calculator.py:192 builds it
+        boxes[:, 0:3], boxes[:, 3:6], boxes[:, 6], boxes[:, 7] = corners.min(1), corners.max(1), score, cls
+        arrays[f"c{ci}:corners"], arrays[f"c{ci}:score"], arrays[f"c{ci}:cls"] = corners, score, cls.astype(np.int32)
+        arrays[f"c{ci}:pick_samecls"] = np.array(nms_3d_faster_samecls(boxes, 0.25), dtype=np.int64)
+        arrays[f"c{ci}:pick_any"] = np.array(nms_3d_faster(boxes[:, :7], 0.25), dtype=np.int64)
+        arrays[f"c{ci}:pick_samecls_old"] = np.array(nms_3d_faster_samecls(boxes, 0.5, True), dtype=np.int64)
+    arrays["ncases"] = np.array(4)
+    save("nms3d", **arrays)
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -333,6 +355,7 @@ def main():
     decoder_cases(T, Cfg)
     misc_cases(T, PE, Cfg)
     criterion_cases(Cfg)
+    nms_cases()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,227 @@
+// nms.hip — greedy 3-D non-maximum suppression of a scene's box predictions on the device (the
+// evaluation's post-processing; reference utils/nms.py:78-162 called from utils/ap_calculator.py:165-220).
+//
+// The reference copies corners / scores to the host and runs a numpy loop per scene: pick the best remaining box, delete
+// every remaining box of the same class whose IoU with it exceeds the threshold, repeat (~K numpy round trips of K-long
+// vectors; 50-100 ms for 1024 boxes).  Here one workgroup per scene:
+//   1. axis-aligned extents = min / max over the 8 corners (ap_calculator.py:168-214), volumes in fp64 as numpy has them
+//      (np.zeros((K, 8)) is a float64 array filled with float32 values);
+//   2. the K x K "i suppresses j" relation as a bit matrix in the caller's workspace, all threads, same fp64 expression
+//      `inter / (area_i + area_j - inter) > thr` (or inter / area_j for old_type) times the class equality;
+//   3. one wave walks the boxes in score order: a box still alive is kept and ORs its row into the dead set.
+// Greedy suppression is inherently sequential in the kept boxes; the walk costs ~100 cycles per box.
+#include "wave.h"
+
+namespace vdetr {
+namespace {
+
+struct NmsParams {
+  const float* corners;       // [B,K,8,3]
+  const int32_t* cls;         // [B,K] or NULL (class-agnostic)
+  const uint8_t* valid;       // [B,K] or NULL
+  const int64_t* order;       // [B,K] ascending stable arg-sort of score
+  uint8_t* keep;              // [B,K]
+  // workspace
+  float* ext;                 // [B,K,6] extents in rank order (rank r = r-th best box: order[K-1-r])
+  int* rcls;                  // [B,K] class in rank order; < 0: invalid box (matches nothing)
+  unsigned long long* rel;    // [B,K,W] "rank r suppresses rank 64w+t" bits, W = ceil(K/64)
+  int K, W, old_type;
+  double thr;
+};
+
+// 1. extents + classes in rank order
+__global__ __launch_bounds__(256) void nms3d_prepare_kernel(NmsParams P) {
+  const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x, K = P.K;
+  if (r >= K) return;
+  const int i = (int)P.order[(size_t)b * K + K - 1 - r];
+  const float* c = P.corners + ((size_t)b * K + i) * 24;
+  float lo[3] = {c[0], c[1], c[2]}, hi[3] = {c[0], c[1], c[2]};
+  for (int k = 1; k < 8; ++k)
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(lo[a], c[k * 3 + a]);
+      hi[a] = fmaxf(hi[a], c[k * 3 + a]);
+    }
+  float* e = P.ext + ((size_t)b * K + r) * 6;
+  for (int a = 0; a < 3; ++a) e[a] = lo[a], e[3 + a] = hi[a];
+  const bool ok = P.valid == nullptr || P.valid[(size_t)b * K + i] != 0;
+  P.rcls[(size_t)b * K + r] = ok ? (P.cls ? P.cls[(size_t)b * K + i] : 0) : -1 - r;
+}
+
+// 2. the K x K relation over the whole GPU: grid (K/256, 4W, B).  A thread owns rank r and builds a quarter (16 bits) of
+//    word blockIdx.y/4 of its row; the 16 partner boxes are staged in LDS as float64 extents + volume (broadcast
+//    reads), and only ranks worse than r are evaluated.  The division is skipped where no lane has an intersection.
+constexpr int kNmsQuarter = 16;
+__global__ __launch_bounds__(256) void nms3d_relation_kernel(NmsParams P) {
+  __shared__ double sbox[kNmsQuarter][8];
+  __shared__ int scls[kNmsQuarter];
+  const int b = blockIdx.z, piece = blockIdx.y, K = P.K, W = P.W;
+  const int r = blockIdx.x * 256 + threadIdx.x, s0 = piece * kNmsQuarter;
+  unsigned short* out = reinterpret_cast<unsigned short*>(P.rel + (size_t)b * K * W);
+  if (s0 + kNmsQuarter - 1 <= (int)(blockIdx.x * 256) || s0 >= K) {  // every pair of this block has s <= r
+    if (r < K) out[(size_t)r * W * 4 + piece] = 0;
+    return;
+  }
+  const float* __restrict__ ext = P.ext + (size_t)b * K * 6;
+  const int* __restrict__ cls = P.rcls + (size_t)b * K;
+  if (threadIdx.x < kNmsQuarter) {
+    const int s = s0 + threadIdx.x;
+    double c[6];
+    for (int q = 0; q < 6; ++q) c[q] = s < K ? (double)ext[(size_t)s * 6 + q] : 0.0;
+    for (int q = 0; q < 6; ++q) sbox[threadIdx.x][q] = c[q];
+    sbox[threadIdx.x][6] = ((c[3] - c[0]) * (c[4] - c[1])) * (c[5] - c[2]);  // float64 volumes, as numpy computes them
+    scls[threadIdx.x] = s < K ? cls[s] : -1;  // a negative class (invalid box, see prepare) matches nothing
+  }
+  __syncthreads();
+  if (r >= K) return;
+  unsigned bits = 0u;
+  const int cr = cls[r];
+  double a[6];
+  for (int q = 0; q < 6; ++q) a[q] = (double)ext[(size_t)r * 6 + q];
+  const double va = ((a[3] - a[0]) * (a[4] - a[1])) * (a[5] - a[2]);
+  const bool always_divide = !(P.thr >= 0.0);
+#pragma unroll
+  for (int t = 0; t < kNmsQuarter; ++t) {
+    const double* c = sbox[t];
+    const bool pair = s0 + t > r && scls[t] == cr;
+    const double l = fmax(0.0, fmin(a[3], c[3]) - fmax(a[0], c[0]));
+    const double wd = fmax(0.0, fmin(a[4], c[4]) - fmax(a[1], c[1]));
+    const double h = fmax(0.0, fmin(a[5], c[5]) - fmax(a[2], c[2]));
+    const double inter = (l * wd) * h;
+    if (pair && (inter > 0.0 || always_divide)) {  // inter == 0: the ratio is 0 or NaN, never above a threshold >= 0
+      const double o = P.old_type ? inter / c[6] : inter / ((va + c[6]) - inter);
+      if (o > P.thr) bits |= 1u << t;
+    }
+  }
+  out[(size_t)r * W * 4 + piece] = (unsigned short)(cr >= 0 ? bits : 0u);
+}
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// 3. the greedy walk, one workgroup per scene.  The relation is pulled into LDS when it fits (K <= 1024: 128 KB); then
+//    ONE wave walks the ranks 64 at a time: lane l owns word l of the dead set (K <= 4096: <= 64 words); inside a block
+//    of 64 ranks only the diagonal word decides, which is resolved with scalar instructions (lane t holds row t's
+//    diagonal word); the rows of the block's survivors are then OR-ed into every lane's word with 64 unconditional,
+//    masked loads (no dependent latency chain).  A box is kept iff its bit is still clear at the end: a row only has
+//    bits of worse ranks, so nothing can kill a rank after its own turn.
+constexpr int kNmsThreads = 1024;
+template <bool IN_LDS>
+__global__ __launch_bounds__(kNmsThreads) void nms3d_walk_kernel(NmsParams P) {
+  extern __shared__ unsigned long long srel[];
+  __shared__ unsigned long long dead0[64];
+  const int b = blockIdx.x, tid = threadIdx.x, K = P.K, W = P.W;
+  const unsigned long long* __restrict__ grel = P.rel + (size_t)b * K * W;
+  const int* cls = P.rcls + (size_t)b * K;
+  for (int r0 = 0; r0 < 64 * W; r0 += kNmsThreads) {  // invalid boxes and the tail of the last word start out dead
+    const int r = r0 + tid;
+    const unsigned long long m = __ballot(r >= K || cls[min(r, K - 1)] < 0);
+    if ((tid & 63) == 0 && (r >> 6) < W) dead0[r >> 6] = m;
+  }
+  if (IN_LDS) {  // 8 loads in flight per thread: the copy is one memory round trip, not sixteen
+    const int n = K * W;
+    for (int e0 = 0; e0 < n; e0 += 8 * kNmsThreads) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * kNmsThreads + tid;
+        v[q] = e < n ? grel[e] : 0ull;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * kNmsThreads + tid;
+        if (e < n) srel[e] = v[q];
+      }
+    }
+  }
+  __syncthreads();
+  // one address space per instantiation: a pointer that may be either would compile to flat loads
+  auto rel_at = [&](int e) -> unsigned long long { return IN_LDS ? srel[e] : grel[e]; };
+  if (tid < 64) {
+    // lane layout of the apply step: W2 = W rounded up to a power of two; lane = q * W2 + word, so one load instruction
+    // fetches 64 / W2 rows of the block at once
+    int W2 = 1;
+    while (W2 < W) W2 <<= 1;
+    const int rows_per_load = 64 / W2, q = tid / W2, wd = tid & (W2 - 1);
+    const bool word_ok = wd < W;
+    const int lw = min(wd, W - 1);
+    unsigned long long mine = tid < W ? dead0[tid] : ~0ull;
+    for (int w = 0; w < W; ++w) {
+      const unsigned long long diag = rel_at(min(64 * w + tid, K - 1) * W + w);
+      unsigned long long dw = readlane_u64(mine, w);
+#pragma unroll
+      for (int t = 0; t < 64; ++t) {
+        const unsigned long long d = readlane_u64(diag, t);
+        if (!((dw >> t) & 1ull)) dw |= d;
+      }
+      const unsigned long long alive = ~dw;  // survivors of this block (wave-uniform)
+      const int last = K - 1 - 64 * w;       // rows beyond the last box are clamped; their alive bit is clear
+      unsigned long long acc = 0ull;
+#pragma unroll 4
+      for (int i = 0; i < W2; ++i) {
+        const int t = i * rows_per_load + q;
+        const unsigned long long row = rel_at((64 * w + min(t, last)) * W + lw);
+        acc |= ((alive >> t) & 1ull) && word_ok ? row : 0ull;
+      }
+      for (int off = W2; off < 64; off <<= 1) acc |= __shfl_xor(acc, off);  // OR over the q groups
+      mine |= acc;                                                          // lane l < W: word l
+    }
+    dead0[tid] = mine;
+  }
+  __syncthreads();
+  for (int r = tid; r < K; r += kNmsThreads)
+    P.keep[(size_t)b * K + (int)P.order[(size_t)b * K + K - 1 - r]] = (uint8_t)(((~dead0[r >> 6]) >> (r & 63)) & 1ull);
+}
+
+}  // namespace
+}  // namespace vdetr
+
+using namespace vdetr;
+
+static size_t nms_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t vdetr_nms3d_workspace_bytes(int B, int K) {
+  if (B <= 0 || K <= 0) return 0;
+  const size_t W = (K + 63) / 64;
+  return nms_align((size_t)B * K * W * 8) + nms_align((size_t)B * K * 6 * 4) + nms_align((size_t)B * K * 4) + 256;
+}
+
+extern "C" int vdetr_nms3d_f32(const float* corners, const float* score, const int32_t* cls, const uint8_t* valid,
+                               const int64_t* order, int B, int K, double iou_threshold, int old_type, uint8_t* keep,
+                               void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+  VDETR_REQUIRE(B >= 0 && K >= 0, "nms3d: negative dimension");
+  if (B == 0 || K == 0) return VDETR_OK;
+  VDETR_REQUIRE(corners && score && order && keep, "nms3d: null pointer");
+  VDETR_REQUIRE(K <= 4096 && B <= 65535, "nms3d: %d scenes x %d boxes: limits are 65535 x 4096", B, K);
+  const size_t need = vdetr_nms3d_workspace_bytes(B, K);
+  if (!workspace || workspace_bytes < need) {
+    set_error("nms3d: workspace %zu B < required %zu B", workspace_bytes, need);
+    return VDETR_ERR_WORKSPACE;
+  }
+  NmsParams P;
+  P.corners = corners; P.cls = cls; P.valid = valid; P.order = order; P.keep = keep;
+  P.K = K; P.W = (K + 63) / 64; P.old_type = old_type; P.thr = iou_threshold;
+  uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  P.rel = reinterpret_cast<unsigned long long*>(base);
+  base += nms_align((size_t)B * K * P.W * 8);
+  P.ext = reinterpret_cast<float*>(base);
+  base += nms_align((size_t)B * K * 6 * 4);
+  P.rcls = reinterpret_cast<int*>(base);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(nms3d_prepare_kernel, dim3(ceil_div(K, 256), B), dim3(256), 0, st, P);
+  if (int e = check_launch("nms3d_prepare")) return e;
+  hipLaunchKernelGGL(nms3d_relation_kernel, dim3(ceil_div(K, 256), P.W * 4, B), dim3(256), 0, st, P);
+  if (int e = check_launch("nms3d_relation")) return e;
+  const size_t relb = (size_t)K * P.W * sizeof(unsigned long long);
+  const int in_lds = relb <= 150 * 1024;
+  const size_t lds = in_lds ? relb : 0;
+  if (in_lds) {
+    if (int rc = set_lds(nms3d_walk_kernel<true>, lds, "nms3d")) return rc;
+    hipLaunchKernelGGL(nms3d_walk_kernel<true>, dim3(B), dim3(kNmsThreads), lds, st, P);
+  } else {
+    hipLaunchKernelGGL(nms3d_walk_kernel<false>, dim3(B), dim3(kNmsThreads), 0, st, P);
+  }
+  return check_launch("nms3d_walk");
+}
