@@ -478,6 +478,13 @@ int vdetr_nms3d_f32(const float* corners, const float* score, const int32_t* cls
                     int B, int K, double iou_threshold, int old_type, uint8_t* keep, void* workspace, size_t workspace_bytes,
                     vdetr_stream_t stream);
 
+/* Points inside every predicted box: counts (B,K) i32 += #{n : points[b,n] in boxes[b,k]} (ZERO-FILLED by the caller).
+ * Replaces mmcv points_in_boxes_all + sum as used by parse_predictions' remove_empty_box (utils/ap_calculator.py:78-93)
+ * without the (B,N,K) flag tensor.  points (B,N,3) f32; boxes (B,K,7) f32 = centre xyz, sizes dx dy dz, yaw rz (the
+ * caller's bottom-centre shift and mmcv's shift back are applied inside, in the reference's operation order). */
+int vdetr_box_point_count_f32(const float* points, const float* boxes, int B, int N, int K, int32_t* counts,
+                              vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

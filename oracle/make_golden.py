@@ -326,7 +326,7 @@ def criterion_cases(Cfg):
 
 def nms_cases():
     """utils/nms.py is plain numpy: the reference's own picks on random scenes of overlapping boxes."""
-    from utils.nms import nms_3d_faster, nms_3d_faster_samecls  # noqa  (the reference's /root/reference/utils/nms.py)
+    from utils.nms import nms_2d_faster, nms_3d_faster, nms_3d_faster_samecls  # noqa  (the reference's /root/reference/utils/nms.py)
     rng = np.random.default_rng(7)
     arrays = {}
     for ci, (K, ncls) in enumerate([(300, 18), (64, 3), (1024, 18), (5, 1)]):
@@ -343,8 +343,74 @@ def nms_cases():
         arrays[f"c{ci}:pick_samecls"] = np.array(nms_3d_faster_samecls(boxes, 0.25), dtype=np.int64)
         arrays[f"c{ci}:pick_any"] = np.array(nms_3d_faster(boxes[:, :7], 0.25), dtype=np.int64)
         arrays[f"c{ci}:pick_samecls_old"] = np.array(nms_3d_faster_samecls(boxes, 0.5, True), dtype=np.int64)
+        boxes2d = np.zeros((K, 5))                                 # ap_calculator.py:119-135: x and z extents
+        boxes2d[:, 0], boxes2d[:, 1] = corners[:, :, 0].min(1), corners[:, :, 2].min(1)
+        boxes2d[:, 2], boxes2d[:, 3], boxes2d[:, 4] = corners[:, :, 0].max(1), corners[:, :, 2].max(1), score
+        arrays[f"c{ci}:pick_2d"] = np.array(nms_2d_faster(boxes2d, 0.25), dtype=np.int64)
     arrays["ncases"] = np.array(4)
     save("nms3d", **arrays)
+
+
+AP_VARIANTS = {  # name -> get_ap_config_dict overrides (ap_calculator.py:285-321)
+    "default": {},
+    "any_class": dict(cls_nms=False),
+    "nms2d": dict(use_3d_nms=False),
+    "old_type": dict(use_old_type_nms=True, nms_iou=0.5),
+    "cls_conf": dict(per_class_proposal=False, use_cls_confidence_only=True),
+    "obj_conf": dict(per_class_proposal=False, conf_thresh=0.3),
+    "angle": dict(angle_nms=True, angle_conf=True),
+    "no_nms": dict(no_nms=True),
+    "keep_empty": dict(remove_empty_box=False, conf_thresh=0.05),
+    "strict_points": dict(empty_pt_thre=400),   # no box holds 400 points in scene 1: the most confident box is kept
+}
+
+
+def ap_inputs(seed=11, B=2, K=96, N=3000, C=18):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array([1.0, 1.0, 1.0]), np.array([6.0, 5.0, 3.0])
+    points = rng.uniform(lo - 0.5, hi + 0.5, (B, N, 3)).astype(np.float32)
+    center = rng.uniform(lo, hi, (B, K, 3)).astype(np.float32)
+    size = rng.uniform(0.2, 1.6, (B, K, 3)).astype(np.float32)
+    size[1, :, :] *= 0.5                                            # scene 1: small boxes, some of them empty
+    yaw = np.zeros((B, K), np.float32)
+    yaw[1] = rng.uniform(-1.5, 1.5, K)                              # scene 1: rotated boxes
+    sg = np.array([(1, 1, 1), (1, 1, -1), (-1, 1, -1), (-1, 1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1), (-1, -1, 1)], np.float32)
+    local = 0.5 * size[:, :, None, :] * sg[None, None]
+    ca, sa = np.cos(yaw)[..., None], np.sin(yaw)[..., None]
+    rot = np.stack([local[..., 0] * ca - local[..., 1] * sa, local[..., 0] * sa + local[..., 1] * ca, local[..., 2]], -1)
+    corners = (center[:, :, None, :] + rot).astype(np.float32)
+    sem = rng.dirichlet(np.ones(C) * 0.3, (B, K)).astype(np.float32)
+    obj = rng.random((B, K)).astype(np.float32)
+    ang = rng.random((B, K)).astype(np.float32)
+    csa = np.concatenate([center, size, yaw[..., None]], -1).astype(np.float32)
+    return dict(corners=corners, sem=sem, obj=obj, ang=ang, points=points, csa=csa)
+
+
+def ap_cases():
+    """utils/ap_calculator.py parse_predictions, imported with the module stubs of import_reference (+ the CUDA extension
+    module names); mmcv's points_in_boxes_all is the restatement, as for the criterion."""
+    from oracle import criterion_oracle as CO
+    _, _, Cfg = import_reference()
+    ops = sys.modules["mmcv.ops"]
+    ops.nms3d = ops.nms3d_normal = None
+    ops.points_in_boxes_all = CO.points_in_boxes_all
+    for name in ("pointnet2", "pointnet2._ext"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import utils.ap_calculator as AP  # noqa  (the reference's /root/reference/utils/ap_calculator.py)
+    x = ap_inputs()
+    arrays = {"in:" + k: v for k, v in x.items()}
+    for name, over in AP_VARIANTS.items():
+        cfg = AP.get_ap_config_dict(dataset_config=Cfg(), **over)
+        t = {k: torch.from_numpy(v.copy()) for k, v in x.items()}
+        res = AP.parse_predictions(t["corners"], t["sem"], t["obj"], t["ang"], t["points"], cfg, t["csa"])
+        arrays[f"{name}:count"] = np.array([len(r) for r in res], np.int64)
+        flat = [d for r in res for d in r]
+        arrays[f"{name}:cls"] = np.array([d[0] for d in flat], np.int64)
+        arrays[f"{name}:corners"] = np.stack([d[1] for d in flat]).astype(np.float32) if flat else np.zeros((0, 8, 3), np.float32)
+        arrays[f"{name}:score"] = np.array([d[2] for d in flat], np.float32)
+        print(name, arrays[f"{name}:count"])
+    save("parse_predictions", **arrays)
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
@@ -356,6 +422,7 @@ def main():
     misc_cases(T, PE, Cfg)
     criterion_cases(Cfg)
     nms_cases()
+    ap_cases()
 
 
 if __name__ == "__main__":

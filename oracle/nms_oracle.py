@@ -31,6 +31,15 @@ def nms_3d(boxes, overlap_threshold, same_class=False, old_type=False, stable=Fa
     return picked
 
 
+def nms_2d(boxes, overlap_threshold, old_type=False, stable=False):
+    """utils/nms.py:43-76 nms_2d_faster: rows (x1, y1, x2, y2, score); the 3-D loop with the third extent fixed to [0, 1]
+    (areas and intersections times exactly 1.0)."""
+    boxes = np.asarray(boxes, dtype=np.float64)
+    K = boxes.shape[0]
+    rows = np.concatenate([boxes[:, 0:2], np.zeros((K, 1)), boxes[:, 2:4], np.ones((K, 1)), boxes[:, 4:5]], axis=1)
+    return nms_3d(rows, overlap_threshold, old_type=old_type, stable=stable)
+
+
 def extents_with_score(corners, score, cls=None):
     """ap_calculator.py:168-214: float64 rows (min xyz, max xyz, score[, cls]) of one scene's corners [K,8,3]."""
     cols = [corners.min(1), corners.max(1), score[:, None]] + ([cls[:, None]] if cls is not None else [])

@@ -21,3 +21,6 @@ def test_oracle_matches_reference_picks():
         assert NO.nms_3d(rows[:, :7], 0.25) == c["pick_any"].tolist(), ci
         assert NO.nms_3d(rows, 0.5, same_class=True, old_type=True) == c["pick_samecls_old"].tolist(), ci
         assert 0 < len(c["pick_samecls"]) <= len(c["score"])
+        co = c["corners"]
+        rows2d = np.stack([co[:, :, 0].min(1), co[:, :, 2].min(1), co[:, :, 0].max(1), co[:, :, 2].max(1), c["score"]], 1)
+        assert NO.nms_2d(rows2d, 0.25) == c["pick_2d"].tolist(), ci

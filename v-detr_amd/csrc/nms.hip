@@ -175,6 +175,47 @@ __global__ __launch_bounds__(kNmsThreads) void nms3d_walk_kernel(NmsParams P) {
     P.keep[(size_t)b * K + (int)P.order[(size_t)b * K + K - 1 - r]] = (uint8_t)(((~dead0[r >> 6]) >> (r & 63)) & 1ull);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// points inside every predicted box (parse_predictions' remove_empty_box, utils/ap_calculator.py:78-93: mmcv
+// points_in_boxes_all -> [B,N,K] flags -> sum over the points).  The flags are never materialised: a thread owns a box, a
+// workgroup walks a slice of the scene's points through LDS (broadcast reads) and adds its count with one integer atomic.
+// The test is mmcv's check_pt_in_box3d (bottom-centre z convention, strict x / y bounds in the box frame, yaw by -rz).
+constexpr int kCountChunk = 1024;  // points staged per round
+__global__ __launch_bounds__(256) void box_point_count_kernel(const float* __restrict__ points, const float* __restrict__ boxes,
+                                                              int N, int K, int slice, int* __restrict__ counts) {
+  __shared__ float4 pts[kCountChunk];
+  const int b = blockIdx.z, k = blockIdx.y * 256 + threadIdx.x;
+  const int n0 = blockIdx.x * slice, n1 = min(N, n0 + slice);
+  float cx = 0.f, cy = 0.f, zc = 0.f, hx = -1.f, hy = -1.f, hz = -1.f, ca = 1.f, sa = 0.f;
+  if (k < K) {
+    const float* r = boxes + ((size_t)b * K + k) * 7;  // centre xyz, sizes, yaw
+    const float zb = r[2] - r[5] / 2.f;                // the caller's bottom-centre shift (ap_calculator.py:80) ...
+    zc = zb + r[5] / 2.f;                              // ... and mmcv's shift back to the centre
+    cx = r[0]; cy = r[1];
+    hx = r[3] / 2.f; hy = r[4] / 2.f; hz = r[5] / 2.f;
+    ca = cosf(-r[6]); sa = sinf(-r[6]);
+  }
+  int cnt = 0;
+  for (int c0 = n0; c0 < n1; c0 += kCountChunk) {
+    const int m = min(kCountChunk, n1 - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 256) {
+      const float* p = points + ((size_t)b * N + c0 + i) * 3;
+      pts[i] = make_float4(p[0], p[1], p[2], 0.f);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < m; ++i) {
+      const float4 p = pts[i];
+      const float sx = p.x - cx, sy = p.y - cy;
+      const float lx = sx * ca - sy * sa, ly = sx * sa + sy * ca;
+      const bool in = !(fabsf(p.z - zc) > hz) && lx > -hx && lx < hx && ly > -hy && ly < hy;
+      cnt += in ? 1 : 0;
+    }
+  }
+  if (k < K && cnt) atomicAdd(counts + (size_t)b * K + k, cnt);
+}
+
 }  // namespace
 }  // namespace vdetr
 
@@ -224,4 +265,20 @@ extern "C" int vdetr_nms3d_f32(const float* corners, const float* score, const i
     hipLaunchKernelGGL(nms3d_walk_kernel<false>, dim3(B), dim3(kNmsThreads), 0, st, P);
   }
   return check_launch("nms3d_walk");
+}
+
+extern "C" int vdetr_box_point_count_f32(const float* points, const float* boxes, int B, int N, int K, int32_t* counts,
+                                         vdetr_stream_t stream) {
+  VDETR_REQUIRE(B >= 0 && N >= 0 && K >= 0, "box_point_count: negative dimension");
+  if (B == 0 || N == 0 || K == 0) return VDETR_OK;
+  VDETR_REQUIRE(points && boxes && counts, "box_point_count: null pointer");
+  VDETR_REQUIRE(B <= 65535, "box_point_count: %d scenes > 65535", B);
+  // enough point slices to fill the chip (~1024 workgroups = 4 per CU)
+  const int kb = ceil_div(K, 256);
+  int splits = 1024 / (kb * B > 0 ? kb * B : 1);
+  splits = splits < 1 ? 1 : splits;
+  int slice = ceil_div(ceil_div(N, splits), 64) * 64;
+  hipLaunchKernelGGL(box_point_count_kernel, dim3(ceil_div(N, slice), kb, B), dim3(256), 0, (hipStream_t)stream, points, boxes, N, K,
+                     slice, counts);
+  return check_launch("box_point_count");
 }
