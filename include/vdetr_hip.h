@@ -485,6 +485,15 @@ int vdetr_nms3d_f32(const float* corners, const float* score, const int32_t* cls
 int vdetr_box_point_count_f32(const float* points, const float* boxes, int B, int N, int K, int32_t* counts,
                               vdetr_stream_t stream);
 
+/* Best ground-truth box of every detection for the AP computation (utils/eval_det.py:160-172 with get_iou_obb =
+ * utils/box_util.py:122-147 box3d_iou).  pred_corners (P,8,3) f32 with image index pred_img (P) and class pred_cls (P);
+ * gt_corners (G,8,3) f32 grouped by image: the boxes of image i are rows img_gt_begin[i] .. img_gt_begin[i+1]-1, classes
+ * gt_cls (G).  -> ovmax (P) f64 = largest IoU with a ground-truth box of the same image and class (-inf if none),
+ * jmax (P) i32 = its row (the first of equal maxima; -1 if none).  float64 arithmetic on the float32 corners. */
+int vdetr_box3d_iou_max_f64(const float* pred_corners, const int32_t* pred_img, const int32_t* pred_cls, int P,
+                            const float* gt_corners, const int32_t* gt_cls, const int32_t* img_gt_begin, double* ovmax,
+                            int32_t* jmax, vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

@@ -412,6 +412,58 @@ def ap_cases():
     save("parse_predictions", **arrays)
 
 
+def eval_inputs(get_3d_box, seed=5, nimg=14, ncls=5):
+    """A small validation set: jittered copies of the ground truth (IoU around both thresholds), duplicates, false positives,
+    a class without ground truth (4), an image without ground truth (5), an image without detections (6).  Scores are
+    distinct: the reference ranks equal scores in the order numpy's (unstable) sort happens to leave them."""
+    rng = np.random.default_rng(seed)
+    gt_all, pred_all = {}, {}
+    for img in range(nimg):
+        gts = []
+        for _ in range(0 if img == 5 else rng.integers(1, 7)):
+            size, yaw = rng.uniform(0.4, 2.0, 3), rng.uniform(-3.1, 3.1) * (img % 2)
+            center = rng.uniform([0, 0, 0], [6, 2, 5])
+            gts.append((int(rng.integers(0, 4)), get_3d_box(size, yaw, center).astype(np.float32), size, yaw, center))
+        gt_all[f"scene{img}"] = [(c, b) for c, b, *_ in gts]
+        if img == 6:
+            continue
+        dets = []
+        for c, _, size, yaw, center in gts:
+            for _ in range(rng.integers(0, 4)):
+                jit = rng.choice([0.02, 0.15, 0.4])
+                b = get_3d_box(size * (1 + rng.normal(0, jit, 3)).clip(0.3, 2), yaw + rng.normal(0, jit), center + rng.normal(0, jit, 3) * size)
+                dets.append((c if rng.random() < 0.9 else int(rng.integers(0, ncls)), b.astype(np.float32), np.float32(rng.random())))
+        for _ in range(rng.integers(2, 8)):
+            b = get_3d_box(rng.uniform(0.4, 2.0, 3), rng.uniform(-3, 3), rng.uniform([0, 0, 0], [6, 2, 5]))
+            dets.append((int(rng.integers(0, ncls)), b.astype(np.float32), np.float32(rng.random())))
+        pred_all[f"scene{img}"] = dets
+    return pred_all, gt_all
+
+
+def eval_cases():
+    """utils/eval_det.py eval_det_multiprocessing (the form APCalculator.compute_metrics calls) on the synthetic set."""
+    import_reference()
+    from utils.box_util import get_3d_box  # noqa  (reference)
+    from utils.eval_det import eval_det_multiprocessing, get_iou_obb  # noqa  (reference)
+    pred_all, gt_all = eval_inputs(get_3d_box)
+    arrays = {}
+    pf = [(i, c, b, s) for i, dets in pred_all.items() for c, b, s in dets]
+    gf = [(i, c, b) for i, boxes in gt_all.items() for c, b in boxes]
+    arrays["pred_img"] = np.array([int(i[5:]) for i, *_ in pf]); arrays["pred_cls"] = np.array([c for _, c, _, _ in pf])
+    arrays["pred_box"] = np.stack([b for _, _, b, _ in pf]); arrays["pred_score"] = np.array([s for *_, s in pf], np.float32)
+    arrays["gt_img"] = np.array([int(i[5:]) for i, *_ in gf]); arrays["gt_cls"] = np.array([c for _, c, _ in gf])
+    arrays["gt_box"] = np.stack([b for *_, b in gf])
+    arrays["pred_imgs"] = np.array(sorted(int(i[5:]) for i in pred_all)); arrays["gt_imgs"] = np.array(sorted(int(i[5:]) for i in gt_all))
+    for thr in (0.25, 0.5):
+        rec, prec, ap = eval_det_multiprocessing(pred_all, gt_all, ovthresh=thr, get_iou_func=get_iou_obb)
+        for c in ap:
+            arrays[f"t{thr}:c{c}:ap"] = np.float64(ap[c])
+            arrays[f"t{thr}:c{c}:rec"] = np.asarray(rec[c], np.float64)
+            arrays[f"t{thr}:c{c}:prec"] = np.asarray(prec[c], np.float64)
+        print(thr, {c: round(float(a), 4) for c, a in ap.items()})
+    save("eval_det", **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -423,6 +475,7 @@ def main():
     criterion_cases(Cfg)
     nms_cases()
     ap_cases()
+    eval_cases()
 
 
 if __name__ == "__main__":

@@ -178,6 +178,8 @@ _SIGNATURES = {
     "vdetr_nms3d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_int, c_void_p,
                         c_void_p, c_size_t, c_void_p]),
     "vdetr_box_point_count_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_box3d_iou_max_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vdetr_gt_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

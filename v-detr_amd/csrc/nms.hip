@@ -216,6 +216,122 @@ __global__ __launch_bounds__(256) void box_point_count_kernel(const float* __res
   if (k < K && cnt) atomicAdd(counts + (size_t)b * K + k, cnt);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// best ground-truth box of every detection (utils/eval_det.py:160-172 -> get_iou_obb -> utils/box_util.py:122-147
+// box3d_iou): float64 on the float32 corners, the reference's Sutherland-Hodgman clip of the two x-z footprints
+// (box_util.py:37-84: strict `inside`, the same intersection formula and operation order), heights from corners 0 / 4,
+// volumes from three edge lengths.  The overlap area is the area of the convex hull of the clipped points, as the reference
+// takes it from qhull (see the end of footprint_intersection).
+struct P2 {
+  double x, y;
+};
+__device__ __forceinline__ double box3d_vol64(const float* c) {
+  auto len = [&](int i, int j) {
+    const double dx = (double)c[i * 3] - (double)c[j * 3], dy = (double)c[i * 3 + 1] - (double)c[j * 3 + 1],
+                 dz = (double)c[i * 3 + 2] - (double)c[j * 3 + 2];
+    return sqrt((dx * dx + dy * dy) + dz * dz);
+  };
+  return (len(0, 1) * len(1, 2)) * len(0, 4);
+}
+__device__ double footprint_intersection(const float* c1, const float* c2) {
+  P2 out[10], in[10];
+  int n = 4;
+  P2 clip[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // rect = corners 3, 2, 1, 0 (x, z): counter-clockwise (box_util.py:135-136)
+    out[i] = P2{(double)c1[(3 - i) * 3], (double)c1[(3 - i) * 3 + 2]};
+    clip[i] = P2{(double)c2[(3 - i) * 3], (double)c2[(3 - i) * 3 + 2]};
+  }
+  P2 cp1 = clip[3];
+  for (int cv = 0; cv < 4; ++cv) {
+    const P2 cp2 = clip[cv];
+    const int m = n;
+    for (int i = 0; i < m; ++i) in[i] = out[i];
+    n = 0;
+    auto inside = [&](const P2& p) { return (cp2.x - cp1.x) * (p.y - cp1.y) > (cp2.y - cp1.y) * (p.x - cp1.x); };
+    auto cross_point = [&](const P2& s, const P2& e) {
+      const double dc0 = cp1.x - cp2.x, dc1 = cp1.y - cp2.y, dp0 = s.x - e.x, dp1 = s.y - e.y;
+      const double n1 = cp1.x * cp2.y - cp1.y * cp2.x, n2 = s.x * e.y - s.y * e.x;
+      const double n3 = 1.0 / (dc0 * dp1 - dc1 * dp0);
+      return P2{(n1 * dp0 - n2 * dc0) * n3, (n1 * dp1 - n2 * dc1) * n3};
+    };
+    P2 sv = in[m - 1];
+    for (int i = 0; i < m; ++i) {
+      const P2 e = in[i];
+      if (inside(e)) {
+        if (!inside(sv) && n < 10) out[n++] = cross_point(sv, e);
+        if (n < 10) out[n++] = e;
+      } else if (inside(sv)) {
+        if (n < 10) out[n++] = cross_point(sv, e);
+      }
+      sv = e;
+    }
+    cp1 = cp2;
+    if (n == 0) return 0.0;
+  }
+  // The reference hands the clipped points to qhull and takes the hull's area (box_util.py:92-105).  For a well-conditioned
+  // clip that is the polygon itself; for nearly coincident rotated boxes the intersection formula divides by ~0 and the
+  // "polygon" is garbage whose HULL the reference still measures (IoU > 1 happens) -- so the hull it is: monotone chain
+  // over <= 10 points.  qhull raises on non-finite or degenerate input and the reference then counts no overlap.
+  if (n < 3) return 0.0;
+  for (int i = 0; i < n; ++i)
+    if (!(fabs(out[i].x) < INFINITY) || !(fabs(out[i].y) < INFINITY)) return 0.0;
+  for (int i = 1; i < n; ++i) {  // insertion sort by (x, y)
+    const P2 v = out[i];
+    int j = i - 1;
+    while (j >= 0 && (out[j].x > v.x || (out[j].x == v.x && out[j].y > v.y))) {
+      out[j + 1] = out[j];
+      --j;
+    }
+    out[j + 1] = v;
+  }
+  auto turn = [](const P2& o, const P2& a, const P2& b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
+  P2 chain[20];
+  int h = 0;
+  for (int i = 0; i < n; ++i) {  // lower chain
+    while (h >= 2 && turn(chain[h - 2], chain[h - 1], out[i]) <= 0.0) --h;
+    chain[h++] = out[i];
+  }
+  const int lower = h + 1;
+  for (int i = n - 2; i >= 0; --i) {  // upper chain
+    while (h >= lower && turn(chain[h - 2], chain[h - 1], out[i]) <= 0.0) --h;
+    chain[h++] = out[i];
+  }
+  --h;  // the last point repeats the first
+  if (h < 3) return 0.0;
+  double acc = 0.0;
+  for (int i = 0; i < h; ++i) {
+    const P2 a = chain[i], b = chain[(i + 1) % h];
+    acc += a.x * b.y - a.y * b.x;
+  }
+  return 0.5 * fabs(acc);
+}
+__global__ __launch_bounds__(128) void box3d_iou_max_kernel(const float* __restrict__ pred, const int* __restrict__ pred_img,
+                                                            const int* __restrict__ pred_cls, int P, const float* __restrict__ gt,
+                                                            const int* __restrict__ gt_cls, const int* __restrict__ img_gt_begin,
+                                                            double* __restrict__ ovmax, int* __restrict__ jmax) {
+  const int d = blockIdx.x * 128 + threadIdx.x;
+  if (d >= P) return;
+  float c1[24];
+  for (int k = 0; k < 24; ++k) c1[k] = pred[(size_t)d * 24 + k];
+  const int img = pred_img[d], cls = pred_cls[d];
+  const double vol1 = box3d_vol64(c1);
+  double best = -INFINITY;
+  int arg = -1;
+  for (int j = img_gt_begin[img]; j < img_gt_begin[img + 1]; ++j) {
+    if (gt_cls[j] != cls) continue;
+    float c2[24];
+    for (int k = 0; k < 24; ++k) c2[k] = gt[(size_t)j * 24 + k];
+    const double area = footprint_intersection(c1, c2);
+    const double ymax = fmin((double)c1[1], (double)c2[1]), ymin = fmax((double)c1[13], (double)c2[13]);
+    const double inter_vol = area * fmax(0.0, ymax - ymin);
+    const double iou = inter_vol / ((vol1 + box3d_vol64(c2)) - inter_vol);
+    if (iou > best) best = iou, arg = j;  // the first of equal maxima stays (eval_det.py:169-171)
+  }
+  ovmax[d] = best;
+  jmax[d] = arg;
+}
+
 }  // namespace
 }  // namespace vdetr
 
@@ -281,4 +397,15 @@ extern "C" int vdetr_box_point_count_f32(const float* points, const float* boxes
   hipLaunchKernelGGL(box_point_count_kernel, dim3(ceil_div(N, slice), kb, B), dim3(256), 0, (hipStream_t)stream, points, boxes, N, K,
                      slice, counts);
   return check_launch("box_point_count");
+}
+
+extern "C" int vdetr_box3d_iou_max_f64(const float* pred_corners, const int32_t* pred_img, const int32_t* pred_cls, int P,
+                                       const float* gt_corners, const int32_t* gt_cls, const int32_t* img_gt_begin,
+                                       double* ovmax, int32_t* jmax, vdetr_stream_t stream) {
+  VDETR_REQUIRE(P >= 0, "box3d_iou_max: negative count");
+  if (P == 0) return VDETR_OK;
+  VDETR_REQUIRE(pred_corners && pred_img && pred_cls && img_gt_begin && ovmax && jmax, "box3d_iou_max: null pointer");
+  hipLaunchKernelGGL(box3d_iou_max_kernel, dim3(ceil_div(P, 128)), dim3(128), 0, (hipStream_t)stream, pred_corners, pred_img, pred_cls,
+                     P, gt_corners, gt_cls, img_gt_begin, ovmax, jmax);
+  return check_launch("box3d_iou_max");
 }
