@@ -43,7 +43,8 @@ def box3d_iou(c1, c2):
     """float64 corners [8,3] -> 3-D IoU (box_util.py:122-147)."""
     r1 = [(c1[i, 0], c1[i, 2]) for i in (3, 2, 1, 0)]
     r2 = [(c2[i, 0], c2[i, 2]) for i in (3, 2, 1, 0)]
-    poly = clip_polygon(r1, r2)
+    with np.errstate(all="ignore"):  # nearly coincident boxes divide by ~0 in the reference too
+        poly = clip_polygon(r1, r2)
     area = 0.0
     if poly is not None:
         try:

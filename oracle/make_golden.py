@@ -464,6 +464,77 @@ def eval_cases():
     save("eval_det", **arrays)
 
 
+def apcalc_inputs(get_3d_box, seed=21, nbatch=3, B=2, K=48, G=6, N=2000, C=18):
+    """Batches of decoder outputs / targets with the keys APCalculator.step_meter reads (ap_calculator.py:378-398): predictions
+    are jittered copies of the ground truth plus random boxes; boxes in the upright camera frame (corners) and the depth
+    frame (centre / size / angle rows for the point test), points scattered around the box centres."""
+    rng = np.random.default_rng(seed)
+    batches = []
+    for _ in range(nbatch):
+        out = {k: [] for k in ("box_corners", "sem_cls_prob", "objectness_prob", "angle_prob", "center_unnormalized",
+                               "size_unnormalized", "angle_continuous")}
+        tgt = {k: [] for k in ("point_clouds", "gt_box_corners", "gt_box_sem_cls_label", "gt_box_present")}
+        for _b in range(B):
+            ng = int(rng.integers(1, G + 1))
+            g_size, g_yaw = rng.uniform(0.4, 1.8, (G, 3)), rng.uniform(-1.5, 1.5, G)
+            g_ctr, g_cls = rng.uniform([0, -1, 0], [6, 1, 5], (G, 3)), rng.integers(0, C, G)
+            present = (np.arange(G) < ng).astype(np.int64)
+            tgt["gt_box_corners"].append(np.stack([get_3d_box(g_size[j], g_yaw[j], g_ctr[j]) for j in range(G)]).astype(np.float32))
+            tgt["gt_box_sem_cls_label"].append(g_cls), tgt["gt_box_present"].append(present)
+            src = rng.integers(-1, ng, K)                             # -1: a random box
+            size = np.where(src[:, None] >= 0, g_size[src] * (1 + rng.normal(0, 0.08, (K, 3))), rng.uniform(0.4, 1.8, (K, 3)))
+            yaw = np.where(src >= 0, g_yaw[src] + rng.normal(0, 0.05, K), rng.uniform(-1.5, 1.5, K))
+            ctr = np.where(src[:, None] >= 0, g_ctr[src] + rng.normal(0, 0.08, (K, 3)), rng.uniform([0, -1, 0], [6, 1, 5], (K, 3)))
+            out["box_corners"].append(np.stack([get_3d_box(size[j], yaw[j], ctr[j]) for j in range(K)]).astype(np.float32))
+            sem = rng.dirichlet(np.ones(C) * 0.2, K)
+            hit = src >= 0
+            sem[hit] = 0.2 * sem[hit]
+            sem[hit, g_cls[src[hit]]] += 0.8
+            out["sem_cls_prob"].append(sem.astype(np.float32))
+            out["objectness_prob"].append(rng.random(K).astype(np.float32)), out["angle_prob"].append(rng.random(K).astype(np.float32))
+            depth_ctr = np.stack([ctr[:, 0], ctr[:, 2], -ctr[:, 1]], 1)     # camera (x, y, z) -> depth (x, z, -y)
+            out["center_unnormalized"].append(depth_ctr.astype(np.float32))
+            out["size_unnormalized"].append(size[:, [0, 2, 1]].astype(np.float32)), out["angle_continuous"].append(yaw.astype(np.float32))
+            pts = depth_ctr[rng.integers(0, K // 2, N)] + rng.normal(0, 0.25, (N, 3))   # the second half of the boxes sees few points
+            tgt["point_clouds"].append(pts.astype(np.float32))
+        batches.append(({k: np.stack(v) for k, v in out.items()}, {k: np.stack(v) for k, v in tgt.items()}))
+    return batches
+
+
+def apcalc_cases():
+    """utils/ap_calculator.py APCalculator (step_meter over 3 batches, compute_metrics, metrics_to_str) with its default
+    evaluation settings (get_ap_config_dict; remove_empty_box on), imported as in ap_cases."""
+    from oracle import criterion_oracle as CO
+    _, _, Cfg = import_reference()
+    ops = sys.modules["mmcv.ops"]
+    ops.nms3d = ops.nms3d_normal = None
+    ops.points_in_boxes_all = CO.points_in_boxes_all
+    for name in ("pointnet2", "pointnet2._ext"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import utils.ap_calculator as AP  # noqa  (reference)
+    from utils.box_util import get_3d_box  # noqa  (reference)
+    cfg = Cfg()
+    batches = apcalc_inputs(get_3d_box)
+    calc = AP.APCalculator(dataset_config=cfg, ap_iou_thresh=[0.25, 0.5], class2type_map=cfg.class2type, exact_eval=True,
+                           ap_config_dict=AP.get_ap_config_dict(dataset_config=cfg, remove_empty_box=True))
+    arrays = {}
+    for bi, (out, tgt) in enumerate(batches):
+        calc.step_meter({"outputs": {k: torch.from_numpy(v.copy()) for k, v in out.items()}},
+                        {k: torch.from_numpy(v.copy()) for k, v in tgt.items()})
+        arrays.update({f"b{bi}:out:{k}": v for k, v in out.items()})
+        arrays.update({f"b{bi}:tgt:{k}": v for k, v in tgt.items()})
+    ret = calc.compute_metrics()
+    for thr, d in ret.items():
+        arrays[f"t{thr}:keys"] = np.array(list(d.keys()))
+        arrays[f"t{thr}:values"] = np.array([float(v) for v in d.values()], np.float64)
+    arrays["text"] = np.array(calc.metrics_to_str(ret))
+    arrays["nbatch"] = np.array(len(batches))
+    arrays["class_ids"] = np.array(list(cfg.class2type.keys()))
+    arrays["class_names"] = np.array(list(cfg.class2type.values()))
+    print(calc.metrics_to_str(ret, per_class=False))
+    save("ap_calculator", **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -476,6 +547,7 @@ def main():
     nms_cases()
     ap_cases()
     eval_cases()
+    apcalc_cases()
 
 
 if __name__ == "__main__":

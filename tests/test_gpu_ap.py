@@ -49,3 +49,37 @@ def test_cpu_tensors_raise():
     from vdetr_amd.ap_calculator import box_point_counts
     with pytest.raises((RuntimeError, ValueError, TypeError)):
         box_point_counts(torch.zeros(1, 4, 3), torch.zeros(1, 2, 7))
+
+
+def test_ap_calculator_matches_reference_metrics():
+    """step_meter over 3 batches -> compute_metrics / metrics_to_str vs the reference's own APCalculator (fixture)."""
+    import os
+    from vdetr_amd.ap_calculator import APCalculator, get_ap_config_dict
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ap_calculator.npz"))
+    class2type = {int(i): str(n) for i, n in zip(z["class_ids"], z["class_names"])}
+    cfg = types.SimpleNamespace(num_semcls=NUM_SEMCLS)
+    calc = APCalculator(dataset_config=cfg, ap_iou_thresh=[0.25, 0.5], class2type_map=class2type, exact_eval=True,
+                        ap_config_dict=get_ap_config_dict(dataset_config=cfg, remove_empty_box=True))
+    for bi in range(int(z["nbatch"])):
+        out = {k.split(":")[2]: torch.from_numpy(z[k]).to(DEV) for k in z.files if k.startswith(f"b{bi}:out:")}
+        tgt = {k.split(":")[2]: torch.from_numpy(z[k]).to(DEV) for k in z.files if k.startswith(f"b{bi}:tgt:")}
+        calc.step_meter({"outputs": out}, tgt)
+    ret = calc.compute_metrics()
+    for thr in (0.25, 0.5):
+        assert list(ret[thr].keys()) == [str(k) for k in z[f"t{thr}:keys"]]
+        got = np.array([float(v) for v in ret[thr].values()])
+        assert np.allclose(got, z[f"t{thr}:values"], rtol=1e-7, atol=1e-12), thr
+    assert calc.metrics_to_str(ret) == str(z["text"])
+    assert str(calc) == str(z["text"])
+    # the list interface gives the same numbers
+    from vdetr_amd.ap_calculator import parse_predictions
+    calc2 = APCalculator(dataset_config=cfg, ap_iou_thresh=[0.25, 0.5], class2type_map=class2type, exact_eval=True,
+                         ap_config_dict=calc.ap_config_dict)
+    for bi in range(int(z["nbatch"])):
+        out = {k.split(":")[2]: torch.from_numpy(z[k]).to(DEV) for k in z.files if k.startswith(f"b{bi}:out:")}
+        tgt = {k.split(":")[2]: z[k] for k in z.files if k.startswith(f"b{bi}:tgt:")}
+        csa = torch.cat((out["center_unnormalized"], out["size_unnormalized"], out["angle_continuous"].unsqueeze(-1)), -1)
+        preds = parse_predictions(out["box_corners"], out["sem_cls_prob"], out["objectness_prob"], out["angle_prob"],
+                                  torch.from_numpy(tgt["point_clouds"]).to(DEV), calc.ap_config_dict, csa)
+        calc2.accumulate(preds, calc2.make_gt_list(tgt["gt_box_corners"], tgt["gt_box_sem_cls_label"], tgt["gt_box_present"]))
+    assert calc2.metrics_to_dict(calc2.compute_metrics()) == calc.metrics_to_dict(ret)

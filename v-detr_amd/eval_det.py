@@ -105,26 +105,34 @@ def eval_det_multiprocessing(pred_all, gt_all, ovthresh=0.25, use_07_metric=Fals
         for classname, bbox in boxes:
             names.setdefault(classname, len(names))
             gc.append(bbox), gi.append(img_index[img_id]), gk.append(names[classname])
-    pc = np.asarray(pc, np.float32).reshape(-1, 8, 3)
-    gc = np.asarray(gc, np.float32).reshape(-1, 8, 3)
-    pi, pk, ps = np.asarray(pi, np.int64), np.asarray(pk, np.int64), np.asarray(ps, np.float64)
-    gi, gk = np.asarray(gi, np.int64), np.asarray(gk, np.int64)
+    arrays = (np.asarray(pc, np.float32).reshape(-1, 8, 3), np.asarray(pi, np.int64), np.asarray(pk, np.int64), np.asarray(ps, np.float64),
+              np.asarray(gc, np.float32).reshape(-1, 8, 3), np.asarray(gi, np.int64), np.asarray(gk, np.int64))
+    return evaluate_flat(*arrays, len(img_index), list(names), ovthresh, use_07_metric, size, device)
+
+
+def evaluate_flat(pc, pi, pk, ps, gc, gi, gk, num_images, class_names, ovthresh=0.25, use_07_metric=False, size="", device="cuda"):
+    """The same evaluation on flat arrays: detections (corners [P,8,3], image index, class index, score) in insertion order,
+    ground truth (corners [G,8,3], image index, class index); ``class_names[k]`` is the key class index k is reported under."""
     if size != "":
         keep_p, keep_g = _size_filter(_volumes(pc), size), _size_filter(_volumes(gc), size)
         pc, pi, pk, ps, gc, gi, gk = pc[keep_p], pi[keep_p], pk[keep_p], ps[keep_p], gc[keep_g], gi[keep_g], gk[keep_g]
     g_order = np.argsort(gi, kind="stable")      # ground truth grouped by image for the kernel
     gc, gi, gk = gc[g_order], gi[g_order], gk[g_order]
-    order, tp = match_detections(pc, pi, pk, ps, gc, gi, gk, len(img_index), ovthresh, device) if len(ps) else (np.zeros(0, int), np.zeros(0, bool))
-    cls_sorted = pk[order]
+    if len(ps):
+        order, tp = match_detections(pc, pi, pk, ps, gc, gi, gk, num_images, ovthresh, device)
+    else:
+        order, tp = np.zeros(0, np.int64), np.zeros(0, bool)
+    cls_sorted, tp_sorted = pk[order], tp[order]
+    npos_all = np.bincount(gk, minlength=len(class_names))
+    has_pred = np.bincount(pk, minlength=len(class_names)) > 0
     rec, prec, ap = {}, {}, {}
-    has_pred = set(pk.tolist())
-    for classname, c in names.items():
-        if c not in has_pred:                    # eval_det.py:294-298
+    for c, classname in enumerate(class_names):
+        if not has_pred[c]:                      # eval_det.py:294-298
             rec[classname] = prec[classname] = ap[classname] = 0
             continue
-        sel = tp[order][cls_sorted == c]
+        sel = tp_sorted[cls_sorted == c]
         tpc, fpc = np.cumsum(sel.astype(np.float64)), np.cumsum((~sel).astype(np.float64))
-        npos = int(np.sum(gk == c))
+        npos = int(npos_all[c])
         r = tpc / float(npos) if npos else np.zeros_like(tpc)
         p = tpc / np.maximum(tpc + fpc, np.finfo(np.float64).eps)
         rec[classname], prec[classname], ap[classname] = r, p, voc_ap(r, p, use_07_metric)
