@@ -6,6 +6,7 @@ parameter NAMES and numerics matter for checkpoint compatibility:
   PositionEmbeddingLearned.position_embedding_head.{0,1,3}.*   (helpers.py:17-33)
 """
 import copy
+import os
 from functools import partial
 
 import torch
@@ -31,9 +32,11 @@ class DeferredParamGrads:
     (runtime.defer_weight_grads) `_Linear.backward` only stores (dY, X) and returns the input gradient; `flush()` -- called
     by the training loop right after `loss.backward()` -- groups the stored pairs by shape, computes each group as ONE
     batched GEMM and ONE reduction, and hands the results to autograd (`torch.autograd.backward` on the weight / bias
-    tensors themselves, so parameter aliases and gradient accumulation behave as always)."""
+    tensors themselves, so parameter aliases and gradient accumulation behave as always; a leaf parameter whose gradient is
+    still unset takes its slice of the batched result as `.grad` directly)."""
     enabled = False
     pending = []
+    direct = os.environ.get("VDETR_WG_DIRECT", "1") != "0"  # A/B switch (read once)
 
     @classmethod
     def flush(cls):
@@ -56,12 +59,16 @@ class DeferredParamGrads:
                         if any(it[0] is not None for it in group) else [None] * len(group)
                     dbs = G.sum(1).unbind(0) if any(it[1] is not None for it in group) else [None] * len(group)
                 for (w, b, _, _), dw, db in zip(group, dws, dbs):
-                    if w is not None:
-                        roots.append(w)
-                        grads.append(dw)
-                    if b is not None:
-                        roots.append(b)
-                        grads.append(db)
+                    for p, g in ((w, dw), (b, db)):
+                        if p is None:
+                            continue
+                        if cls.direct and p.is_leaf and p.grad is None:
+                            # a parameter without a gradient yet simply takes its slice of the batched result:
+                            # AccumulateGrad would clone every such slice (one copy launch per parameter, ~80 per step)
+                            p.grad = g
+                        else:
+                            roots.append(p)
+                            grads.append(g)
         if roots:
             torch.autograd.backward(roots, grads)
 
