@@ -38,6 +38,37 @@ class DeferredParamGrads:
     pending = []
     direct = os.environ.get("VDETR_WG_DIRECT", "1") != "0"  # A/B switch (read once)
 
+    @staticmethod
+    def _view_of_leaf(p):
+        """the leaf parameter `p` is a plain view of (e.g. one of in_proj_weight.view(3, E, E).unbind(0)), or None"""
+        if p is None or p.is_leaf or not p._is_view():
+            return None
+        base = p._base
+        return base if base is not None and base.is_leaf and p.is_contiguous() and base.is_contiguous() else None
+
+    @classmethod
+    def _deliver(cls, p, g, roots, grads):
+        """gradient g of the tensor p a `linear` call used as weight / bias: straight into `.grad` where no accumulation or
+        view bookkeeping is needed, through autograd otherwise"""
+        if cls.direct and p.is_leaf and p.grad is None:
+            # a parameter without a gradient yet simply takes its slice of the batched result:
+            # AccumulateGrad would clone every such slice (one copy launch per parameter, ~80 per step)
+            p.grad = g
+            return
+        fn = p.grad_fn
+        if cls.direct and type(fn).__name__ == "_AliasBackward":
+            # an alias of adjacent parameters (cat_params / stack_params / slot_stack_params): hand each parameter its
+            # slice, as _Alias.backward would, without one AccumulateGrad launch per parameter
+            parts = _Alias.backward(fn, g)[2:]
+            # next_functions holds one edge per TENSOR input of the Function (the two leading non-tensor arguments have none)
+            leaves = [nf[0].variable if nf[0] is not None and hasattr(nf[0], "variable") else None for nf in fn.next_functions]
+            if len(leaves) == len(parts) and all(l is not None for l in leaves):
+                for leaf, part in zip(leaves, parts):
+                    cls._deliver(leaf, part, roots, grads)
+                return
+        roots.append(p)
+        grads.append(g)
+
     @classmethod
     def flush(cls):
         items, cls.pending = cls.pending, []
@@ -49,26 +80,47 @@ class DeferredParamGrads:
         roots, grads = [], []
         with torch.no_grad():
             for group in groups.values():
-                if len(group) == 1:
+                n = len(group)
+                if n == 1:
                     w, b, g2, x2 = group[0]
-                    dws = [torch.mm(g2.t(), x2)] if w is not None else [None]
-                    dbs = [colsum(g2 if g2.stride(1) == 1 else g2.contiguous())] if b is not None else [None]
+                    dW = torch.mm(g2.t(), x2)[None] if w is not None else None
+                    dB = colsum(g2 if g2.stride(1) == 1 else g2.contiguous())[None] if b is not None else None
                 else:
+                    # views of one leaf (the q / k / v blocks of an in_proj_weight) next to each other, in memory order: their
+                    # rows of the batched result then ARE the leaf's gradient (no stack launch in an UnbindBackward)
+                    def order(e):
+                        i, it = e
+                        base = cls._view_of_leaf(it[0]) if cls.direct else None
+                        return (0, i, 0) if base is None else (1, id(base), it[0].storage_offset())
+                    group = [it for _, it in sorted(enumerate(group), key=order)]
                     G = torch.stack([it[2] for it in group])                       # [n, rows, out]
-                    dws = torch.bmm(G.transpose(1, 2), torch.stack([it[3] for it in group])).unbind(0) \
-                        if any(it[0] is not None for it in group) else [None] * len(group)
-                    dbs = G.sum(1).unbind(0) if any(it[1] is not None for it in group) else [None] * len(group)
-                for (w, b, _, _), dw, db in zip(group, dws, dbs):
-                    for p, g in ((w, dw), (b, db)):
+                    dW = torch.bmm(G.transpose(1, 2), torch.stack([it[3] for it in group])) \
+                        if any(it[0] is not None for it in group) else None
+                    dB = G.sum(1) if any(it[1] is not None for it in group) else None
+                for which, R in ((0, dW), (1, dB)):
+                    if R is None:
+                        continue
+                    i = 0
+                    while i < n:
+                        p = group[i][which]
                         if p is None:
+                            i += 1
                             continue
-                        if cls.direct and p.is_leaf and p.grad is None:
-                            # a parameter without a gradient yet simply takes its slice of the batched result:
-                            # AccumulateGrad would clone every such slice (one copy launch per parameter, ~80 per step)
-                            p.grad = g
-                        else:
-                            roots.append(p)
-                            grads.append(g)
+                        base = cls._view_of_leaf(p) if cls.direct else None
+                        k = 1
+                        if base is not None and base.numel() % p.numel() == 0:
+                            k = base.numel() // p.numel()
+                            tiles = i + k <= n and all(
+                                group[i + j][which] is not None and cls._view_of_leaf(group[i + j][which]) is base and
+                                group[i + j][which].shape == p.shape and
+                                group[i + j][which].storage_offset() == base.storage_offset() + j * p.numel() for j in range(k))
+                            if tiles:
+                                cls._deliver(base, R[i:i + k].view(base.shape), roots, grads)
+                                i += k
+                                continue
+                            k = 1
+                        cls._deliver(p, R[i], roots, grads)
+                        i += 1
         if roots:
             torch.autograd.backward(roots, grads)
 
