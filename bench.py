@@ -173,15 +173,19 @@ class Trainer:
                 self._update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # Capture on the stream the warm-up ran on: the warm-up's autograd graph (kept alive by tensors the modules hold)
+        # owns one AccumulateGrad node per parameter, bound to the stream it was created on; under a different capture
+        # stream the engine runs those nodes on the old stream and stitches cross-stream dependencies into the graph.
+        same = os.environ.get("VDETR_CAPTURE_SAME_STREAM", "1") != "0"
         self.g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_main):
+        with torch.cuda.graph(self.g_main, **({"stream": s} if same else {})):
             self._fwd_bwd()
             if self.world == 1:
                 self._update()
         if self.world > 1:
             self.reducer.reduce_all()  # the flat gradient buffer, in slices; not captured (RCCL outside the graph)
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
+            with torch.cuda.graph(self.g_opt, **({"stream": s} if same else {})):
                 self._update()
 
     def step(self):
