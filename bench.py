@@ -162,8 +162,12 @@ class Trainer:
         self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
         self.opt.step()
 
+    _capture_stream = None  # one per process: a second Trainer on the same model meets the first one's AccumulateGrad nodes
+
     def capture(self):
-        s = torch.cuda.Stream()
+        if Trainer._capture_stream is None:
+            Trainer._capture_stream = torch.cuda.Stream()
+        s = Trainer._capture_stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(3):  # warm allocator, lazy inits, LDS attribute grants
