@@ -293,6 +293,15 @@ typedef struct vdetr_addln_grads {
 int vdetr_add_ln_fwd_f32(const vdetr_addln_desc* d, vdetr_stream_t stream);
 size_t vdetr_add_ln_bwd_workspace_bytes(const vdetr_addln_desc* d);
 int vdetr_add_ln_bwd_f32(const vdetr_addln_desc* d, const vdetr_addln_grads* g, vdetr_stream_t stream);
+/* With d_gamma == d_beta == NULL vdetr_add_ln_bwd_f32 only leaves the per-workgroup partial sums in `partials`
+ * (nparts = workspace bytes / (4 * C * 4) rows of [4][C]); this call then reduces the partials of SEVERAL backward passes
+ * (HOST array of n items) in one launch per 32 items.  d_gamma2 / d_beta2 NULL: the pass had no second affine map. */
+typedef struct vdetr_addln_reduce {
+  const float* partials;
+  int32_t nparts, C;
+  float *d_gamma, *d_beta, *d_gamma2, *d_beta2;
+} vdetr_addln_reduce;
+int vdetr_add_ln_param_reduce_batch_f32(const vdetr_addln_reduce* items, int n, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * y = dropout(relu(BatchNorm1d(x))) on [B, C, N]: the hidden blocks of GenericMLP (models/helpers.py:74-141,

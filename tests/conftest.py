@@ -107,3 +107,5 @@ def _no_leaked_runtime_switches():
     from vdetr_amd.helpers import DeferredParamGrads
     DeferredParamGrads.enabled = False
     DeferredParamGrads.pending.clear()
+    from vdetr_amd.add_ln import DeferredLnGrads
+    DeferredLnGrads.pending.clear()

@@ -77,6 +77,13 @@ class AddLnGrads(ctypes.Structure):
                                         "partials")]
 
 
+class AddLnReduce(ctypes.Structure):
+    """Mirror of ``vdetr_addln_reduce``."""
+
+    _fields_ = [("partials", c_void_p), ("nparts", ctypes.c_int32), ("C", ctypes.c_int32), ("d_gamma", c_void_p), ("d_beta", c_void_p),
+                ("d_gamma2", c_void_p), ("d_beta2", c_void_p)]
+
+
 class BnActDesc(ctypes.Structure):
     """Mirror of ``vdetr_bnact_desc``."""
 
@@ -167,6 +174,7 @@ _SIGNATURES = {
     "vdetr_add_ln_fwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), c_void_p]),
     "vdetr_add_ln_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AddLnDesc)]),
     "vdetr_add_ln_bwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), ctypes.POINTER(AddLnGrads), c_void_p]),
+    "vdetr_add_ln_param_reduce_batch_f32": (c_int, [ctypes.POINTER(AddLnReduce), c_int, c_void_p]),
     "vdetr_relu_dropout_fwd_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_float, ctypes.c_uint64, ctypes.c_uint64, c_void_p,
                                            c_void_p]),
     "vdetr_relu_dropout_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p]),

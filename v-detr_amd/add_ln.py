@@ -13,6 +13,7 @@ import torch
 
 from . import _lib as L
 from . import attention as A
+from .helpers import DeferredParamGrads
 
 _salts = itertools.count(0x5EED0001)
 
@@ -44,6 +45,38 @@ def _desc(rows, C, eps, p, salt, rng, tensors):
     return d
 
 
+class DeferredLnGrads:
+    """dgamma / dbeta of the LayerNorms, reduced AFTER the backward: with runtime.defer_weight_grads() the backward kernel only
+    leaves its per-workgroup partial sums; `flush()` (runtime.flush_weight_grads) reduces all parked passes in ONE launch
+    (27 launches of ~7 us per step otherwise) and hands the sums to the parameters as DeferredParamGrads does."""
+    pending = []
+
+    @classmethod
+    def flush(cls):
+        items, cls.pending = cls.pending, []
+        if not items:
+            return
+        n = len(items)
+        dev = items[0][0].device
+        cmax = max(it[2] for it in items)
+        out = torch.empty((n, 4, cmax), dtype=torch.float32, device=dev)
+        descs = (L.AddLnReduce * n)()
+        for i, (ws, nparts, C, _, two) in enumerate(items):
+            d = descs[i]
+            d.partials, d.nparts, d.C = ws.data_ptr(), nparts, C
+            d.d_gamma, d.d_beta = out[i, 0].data_ptr(), out[i, 1].data_ptr()
+            d.d_gamma2, d.d_beta2 = (out[i, 2].data_ptr(), out[i, 3].data_ptr()) if two else (None, None)
+        L.check(L.lib().vdetr_add_ln_param_reduce_batch_f32(descs, n, L.stream_ptr()), "add_ln_param_reduce_batch")
+        roots, grads = [], []
+        with torch.no_grad():
+            for i, (_, _, C, params, two) in enumerate(items):
+                for k, p in enumerate(params[:4 if two else 2]):
+                    if p is not None and p.requires_grad:
+                        DeferredParamGrads._deliver(p, out[i, k, :C], roots, grads)
+        if roots:
+            torch.autograd.backward(roots, grads)
+
+
 class _AddLN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r, gamma, beta, gamma2, beta2, eps, p, rng, salt):
@@ -67,6 +100,7 @@ class _AddLN(torch.autograd.Function):
                        beta2=beta2.contiguous() if beta2 is not None else None, y=y, out=out, out2=out2, mean=mean, rstd=rstd))
         L.check(L.lib().vdetr_add_ln_fwd_f32(ctypes.byref(d), L.stream_ptr()), "add_ln_fwd")
         ctx.cfg = (rows, C, eps, p if use_drop else 0.0, salt, r is not None)
+        ctx.ln_params = (gamma, beta, gamma2, beta2)  # the tensors themselves: the deferred sums are delivered to them
         ctx.save_for_backward(y if r is not None else x, gamma, gamma2, mean, rstd, rng if use_drop else None)
         ctx.set_materialize_grads(False)
         return y, out, out2
@@ -85,15 +119,25 @@ class _AddLN(torch.autograd.Function):
         g = L.AddLnGrads()
         d_x = torch.empty_like(ysrc)
         d_r = torch.empty_like(ysrc) if (has_r and p > 0.0) else None
-        d_gamma, d_beta = torch.empty_like(gamma), torch.empty_like(gamma)
-        d_gamma2 = torch.empty_like(gamma2) if d_out2 is not None else None
-        d_beta2 = torch.empty_like(gamma2) if d_out2 is not None else None
         nbytes = L.lib().vdetr_add_ln_bwd_workspace_bytes(ctypes.byref(d))
-        ws = L.workspace(nbytes, ysrc.device)
+        # parameter sums after the backward, all LayerNorms in one launch (see DeferredLnGrads): the kernel only leaves
+        # its per-workgroup partial sums, in a buffer of their own
+        defer = DeferredParamGrads.enabled and DeferredParamGrads.direct and (d_out2 is not None or gamma2 is None)
+        if defer:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=ysrc.device)
+            d_gamma = d_beta = d_gamma2 = d_beta2 = None
+            DeferredLnGrads.pending.append((ws, nbytes // (16 * C), C, ctx.ln_params, d_out2 is not None))
+        else:
+            d_gamma, d_beta = torch.empty_like(gamma), torch.empty_like(gamma)
+            d_gamma2 = torch.empty_like(gamma2) if d_out2 is not None else None
+            d_beta2 = torch.empty_like(gamma2) if d_out2 is not None else None
+            ws = L.workspace(nbytes, ysrc.device)
         for k, t in (("d_out", d_out), ("d_out2", d_out2), ("d_y", d_y), ("d_x", d_x), ("d_r", d_r), ("d_gamma", d_gamma),
                      ("d_beta", d_beta), ("d_gamma2", d_gamma2), ("d_beta2", d_beta2), ("partials", ws)):
             setattr(g, k, t.data_ptr() if t is not None else None)
         L.check(L.lib().vdetr_add_ln_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "add_ln_bwd")
+        if defer:
+            return d_x, (d_r if d_r is not None else d_x) if has_r else None, None, None, None, None, None, None, None, None
         if d_out2 is None and gamma2 is not None:
             d_gamma2, d_beta2 = torch.zeros_like(gamma2), torch.zeros_like(gamma2)
         # without dropout the branch gradient IS the residual gradient

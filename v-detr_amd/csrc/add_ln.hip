@@ -204,13 +204,12 @@ __global__ __launch_bounds__(kLnThreadsBwd) void add_ln_bwd_kernel(vdetr_addln_d
 // Second (tiny) launch: fixed-order sum of the workgroups' partial rows.  A "last workgroup reduces" single-launch
 // variant was measured slower (17-30 us): its device-scope release/acquire fences write back and invalidate whole L2s
 // on a multi-XCD part, a kernel boundary is cheaper.
-__global__ __launch_bounds__(256) void add_ln_param_reduce_kernel(const float* __restrict__ partials, int nparts, int C,
-                                                                 float* d_gamma, float* d_beta, float* d_gamma2, float* d_beta2) {
+__device__ __forceinline__ void ln_param_reduce_body(const float* __restrict__ partials, int nparts, int C, int which, int cblock,
+                                                     float* dst) {
   // block = 64 channels x 4 groups of partial rows; each thread keeps up to 16 independent loads in flight (the sum is
   // latency-bound: 64 partial rows of 4 KB)
   __shared__ float comb[4][64];
-  const int which = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
-  float* dst = which == 0 ? d_gamma : (which == 1 ? d_beta : (which == 2 ? d_gamma2 : d_beta2));
+  const int c = cblock * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
   const float* src = partials + (size_t)which * C + c;
   const size_t pitch = (size_t)4 * C;
   float acc[16];
@@ -229,6 +228,28 @@ __global__ __launch_bounds__(256) void add_ln_param_reduce_kernel(const float* _
   comb[pg][threadIdx.x & 63] = t;
   __syncthreads();
   if (pg == 0) dst[c] = (comb[0][threadIdx.x] + comb[1][threadIdx.x]) + (comb[2][threadIdx.x] + comb[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void add_ln_param_reduce_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                                 float* d_gamma, float* d_beta, float* d_gamma2, float* d_beta2) {
+  const int which = blockIdx.y;
+  ln_param_reduce_body(partials, nparts, C, which, blockIdx.x,
+                       which == 0 ? d_gamma : (which == 1 ? d_beta : (which == 2 ? d_gamma2 : d_beta2)));
+}
+
+// the same sums for SEVERAL LayerNorm backward passes in one launch (descriptors by value, blockIdx.z = item): the per-layer
+// reductions of a decoder are 27 launches of ~7 us that nothing in the backward waits for
+constexpr int kLnReduceBatch = 32;
+struct LnReduceBatch {
+  vdetr_addln_reduce item[kLnReduceBatch];
+};
+__global__ __launch_bounds__(256) void add_ln_param_reduce_batch_kernel(LnReduceBatch b) {
+  const vdetr_addln_reduce& it = b.item[blockIdx.z];
+  const int which = blockIdx.y;
+  if ((int)blockIdx.x * 64 >= it.C) return;
+  float* dst = which == 0 ? it.d_gamma : (which == 1 ? it.d_beta : (which == 2 ? it.d_gamma2 : it.d_beta2));
+  if (dst == nullptr) return;
+  ln_param_reduce_body(it.partials, it.nparts, it.C, which, blockIdx.x, dst);
 }
 
 }  // namespace vdetr
@@ -268,9 +289,10 @@ extern "C" int vdetr_add_ln_fwd_f32(const vdetr_addln_desc* d, vdetr_stream_t st
 
 extern "C" int vdetr_add_ln_bwd_f32(const vdetr_addln_desc* d, const vdetr_addln_grads* g, vdetr_stream_t stream) {
   if (int e = addln_check(d, "add_ln_bwd")) return e;
-  VDETR_REQUIRE(g && g->d_x && g->d_gamma && g->d_beta && g->partials, "add_ln_bwd: null pointer");
+  VDETR_REQUIRE(g && g->d_x && g->partials && (g->d_gamma == nullptr) == (g->d_beta == nullptr), "add_ln_bwd: null pointer");
   VDETR_REQUIRE(g->d_out || g->d_out2 || g->d_y, "add_ln_bwd: no incoming gradient");
-  VDETR_REQUIRE(!g->d_out2 || (d->gamma2 && g->d_gamma2 && g->d_beta2), "add_ln_bwd: d_out2 needs gamma2 and its gradient buffers");
+  VDETR_REQUIRE(!g->d_out2 || (d->gamma2 && (g->d_gamma == nullptr || (g->d_gamma2 && g->d_beta2))),
+                "add_ln_bwd: d_out2 needs gamma2 and its gradient buffers");
   VDETR_REQUIRE(!g->d_r || d->r, "add_ln_bwd: d_r without a residual branch");
   const dim3 grid(ceil_div(d->rows, kLnRowsPerWgBwd)), block(kLnThreadsBwd);
   hipStream_t st = (hipStream_t)stream;
@@ -281,7 +303,28 @@ extern "C" int vdetr_add_ln_bwd_f32(const vdetr_addln_desc* d, const vdetr_addln
     default: hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, block, 0, st, *d, *g); break;
   }
   if (int e = check_launch("add_ln_bwd")) return e;
+  if (g->d_gamma == nullptr) return VDETR_OK;  // parameter sums left to vdetr_add_ln_param_reduce_batch_f32
   hipLaunchKernelGGL(add_ln_param_reduce_kernel, dim3(d->C / 64, g->d_out2 ? 4 : 2), dim3(256), 0, st, g->partials, (int)grid.x, d->C,
                      g->d_gamma, g->d_beta, g->d_gamma2, g->d_beta2);
   return check_launch("add_ln_param_reduce");
+}
+
+extern "C" int vdetr_add_ln_param_reduce_batch_f32(const vdetr_addln_reduce* items, int n, vdetr_stream_t stream) {
+  VDETR_REQUIRE(items != nullptr && n >= 1, "add_ln_param_reduce_batch: null items");
+  for (int i0 = 0; i0 < n; i0 += kLnReduceBatch) {
+    const int cnt = n - i0 < kLnReduceBatch ? n - i0 : kLnReduceBatch;
+    LnReduceBatch b{};
+    int maxc = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const vdetr_addln_reduce& it = items[i0 + k];
+      VDETR_REQUIRE(it.partials && it.d_gamma && it.d_beta && it.nparts >= 1 && it.C % 256 == 0 && it.C > 0 && it.C <= kLnMaxC,
+                    "add_ln_param_reduce_batch: bad item %d", i0 + k);
+      VDETR_REQUIRE((it.d_gamma2 == nullptr) == (it.d_beta2 == nullptr), "add_ln_param_reduce_batch: item %d: one of the *2 outputs", i0 + k);
+      b.item[k] = it;
+      maxc = it.C > maxc ? it.C : maxc;
+    }
+    hipLaunchKernelGGL(add_ln_param_reduce_batch_kernel, dim3(maxc / 64, 4, cnt), dim3(256), 0, (hipStream_t)stream, b);
+    if (int e = check_launch("add_ln_param_reduce_batch")) return e;
+  }
+  return VDETR_OK;
 }

@@ -30,14 +30,18 @@ def enable_gemm_tuning(rank=0, cache_dir=None):
 
 def defer_weight_grads(enable=True):
     """Compute the weight / bias gradients of the `helpers.linear` layers in shape-batched GEMMs after the backward pass
-    instead of one by one inside it (helpers.DeferredParamGrads).  The training loop must call ``flush_weight_grads()``
+    instead of one by one inside it (helpers.DeferredParamGrads), and the LayerNorm parameter sums in one launch (add_ln.DeferredLnGrads).  The training loop must call ``flush_weight_grads()``
     after ``loss.backward()`` and before anything reads a ``.grad``."""
+    from .add_ln import DeferredLnGrads
     from .helpers import DeferredParamGrads
     DeferredParamGrads.enabled = bool(enable)
     if not enable:
         DeferredParamGrads.pending.clear()
+        DeferredLnGrads.pending.clear()
 
 
 def flush_weight_grads():
+    from .add_ln import DeferredLnGrads
     from .helpers import DeferredParamGrads
     DeferredParamGrads.flush()
+    DeferredLnGrads.flush()
