@@ -109,3 +109,5 @@ def _no_leaked_runtime_switches():
     DeferredParamGrads.pending.clear()
     from vdetr_amd.add_ln import DeferredLnGrads
     DeferredLnGrads.pending.clear()
+    from vdetr_amd.helpers import DeferredPosEmbedGrads
+    DeferredPosEmbedGrads.pending.clear()

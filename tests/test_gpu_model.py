@@ -362,13 +362,15 @@ def test_deferred_heads_backward_equals_per_stage_autograd(batch):
         assert torch.allclose(b1[n].float(), b0[n].float(), rtol=1e-5, atol=1e-6), n
 
 
-def test_deferred_weight_gradients_equal_inline_ones():
+@pytest.mark.parametrize("batch", [1, 2])
+def test_deferred_weight_gradients_equal_inline_ones(batch):
     """runtime.defer_weight_grads: dW / db of every `linear` as shape-batched GEMMs after the backward (flush) == the
-    per-layer GEMMs inside it, for plain parameters, unbound slices of a packed parameter and adjacent-parameter aliases."""
+    per-layer GEMMs inside it, for plain parameters, unbound slices of a packed parameter and adjacent-parameter aliases;
+    likewise the LayerNorm parameter sums (one batched launch) and the query-position embeddings' parameters."""
     from vdetr_amd import attention as A
     from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
     model = _make_model(nq=64, npre=512, nl=4).to(DEV).train()
-    inp = _inputs(3000, 5, DEV, 1)
+    inp = _inputs(3000, 5, DEV, batch)
     model(inp)
     state = copy.deepcopy(model.state_dict()) if False else {k: v.clone() for k, v in model.state_dict().items()}
     res = {}

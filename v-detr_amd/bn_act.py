@@ -87,7 +87,7 @@ def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, 
                         float(dropout_p), rng, int(salt), pre_bias, tuple(counters))
 
 
-def forward_record(x, gamma, beta, rm, rv, eps, momentum, p, salt, counters=(), y_out=None):
+def forward_record(x, gamma, beta, rm, rv, eps, momentum, p, salt, counters=(), y_out=None, pre_bias=None):
     """Training-mode forward WITHOUT an autograd node: returns (y, record); ``backward_from_record(record, dy)`` gives
     (dx, dgamma, dbeta) later.  For callers that batch the backward of several independent blocks themselves
     (vdetr_transformer._DeferredHeads)."""
@@ -104,7 +104,8 @@ def forward_record(x, gamma, beta, rm, rv, eps, momentum, p, salt, counters=(), 
         C = x.shape[1]
         smean = torch.empty(C, dtype=torch.float32, device=x.device)
         sinv = torch.empty_like(smean)
-        d = _desc(x, g, b, rm, rv, y, smean, sinv, True, True, eps, momentum, p, salt, rng if p > 0 else None, None, tuple(counters))
+        d = _desc(x, g, b, rm, rv, y, smean, sinv, True, True, eps, momentum, p, salt, rng if p > 0 else None,
+                  pre_bias.detach().contiguous() if pre_bias is not None else None, tuple(counters))
         L.check(L.lib().vdetr_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "bn_act_fwd")
     return y, (x, g, b, smean, sinv, rng if p > 0 else None, (float(eps), float(momentum), float(p), int(salt)))
 

@@ -33,15 +33,17 @@ def defer_weight_grads(enable=True):
     instead of one by one inside it (helpers.DeferredParamGrads), and the LayerNorm parameter sums in one launch (add_ln.DeferredLnGrads).  The training loop must call ``flush_weight_grads()``
     after ``loss.backward()`` and before anything reads a ``.grad``."""
     from .add_ln import DeferredLnGrads
-    from .helpers import DeferredParamGrads
+    from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
     DeferredParamGrads.enabled = bool(enable)
     if not enable:
         DeferredParamGrads.pending.clear()
         DeferredLnGrads.pending.clear()
+        DeferredPosEmbedGrads.pending.clear()
 
 
 def flush_weight_grads():
     from .add_ln import DeferredLnGrads
-    from .helpers import DeferredParamGrads
+    from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
     DeferredParamGrads.flush()
     DeferredLnGrads.flush()
+    DeferredPosEmbedGrads.flush()
