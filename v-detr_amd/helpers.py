@@ -419,7 +419,32 @@ class GenericMLP(nn.Module):
                 init(p)
 
     def forward(self, x):
-        return self.layers(x)
+        mods = list(self.layers)
+        if not (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and torch.is_grad_enabled()):
+            return self.layers(x)
+        # Conv1d(k=1) -> BatchNorm1d -> ReLU [-> Dropout] blocks as GEMM + ONE fused launch (bn_act.py: statistics, affine,
+        # ReLU, dropout and the running-statistics bookkeeping; the convolution's bias only enters the running mean)
+        from . import bn_act as BNA
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1:i + 4]
+            if (type(m) is PointwiseConv1d and len(nxt) >= 2 and type(nxt[0]) is nn.BatchNorm1d and type(nxt[1]) is nn.ReLU
+                    and nxt[0].track_running_stats and nxt[0].momentum is not None and nxt[0].affine):
+                bn = nxt[0]
+                drop = nxt[2] if len(nxt) >= 3 and type(nxt[2]) is nn.Dropout else None
+                salts = self.__dict__.setdefault("_bn_salts", {})
+                if i not in salts:
+                    salts[i] = BNA.new_salt()
+                h = m(x) if m.bias is None else PointwiseConv1d.forward_no_bias(m, x)
+                x = BNA.bn_act(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, bn.eps, bn.momentum, relu=True,
+                               dropout_p=drop.p if drop is not None else 0.0, salt=salts[i], pre_bias=m.bias,
+                               counters=[bn.num_batches_tracked])
+                i += 3 if drop is None else 4
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 def get_clones(module, N):
