@@ -358,7 +358,7 @@ class PositionEmbeddingLearned(nn.Module):
         head = self.position_embedding_head
         x = xyz.transpose(1, 2)  # [B, C_in, N]; the 1x1 convolution reads the transposed operand in place
         bn = head[1]
-        if not (self.training and x.is_cuda and bn.momentum is not None and bn.track_running_stats):
+        if not (self.training and x.is_cuda and type(bn) is nn.BatchNorm1d and bn.momentum is not None and bn.track_running_stats):
             return head(x.contiguous())
         if DeferredParamGrads.enabled and DeferredParamGrads.direct and not x.requires_grad and torch.is_grad_enabled() \
                 and head[3].bias is not None:
