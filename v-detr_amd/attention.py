@@ -60,7 +60,31 @@ def begin_step(device):
     snap = _master[key].clone()
     _master[key][1] += 1
     _current[key] = snap
+    _zero_pool[key] = None  # a fresh pool of zeros for this step's backward passes (allocated on first use)
     return snap
+
+
+# Zero-initialised scratch of one step's backward passes (the table-gradient accumulators and the 4 counters of every
+# layer): ONE fill per step instead of two per layer.  Slices are handed out once and never reused within the step.
+_zero_pool = {}
+_ZERO_POOL_FLOATS = 1 << 19
+
+
+def _take_zeros(like, shape, dtype):
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    key = (like.device.type, like.device.index if like.device.index is not None else torch.cuda.current_device())
+    if key in _zero_pool and numel * 4 <= _ZERO_POOL_FLOATS:
+        pool = _zero_pool[key]
+        if pool is None:
+            pool = _zero_pool[key] = [torch.zeros(_ZERO_POOL_FLOATS, dtype=torch.float32, device=like.device), 0]
+        buf, used = pool
+        n4 = (numel + 3) // 4 * 4  # 16-byte aligned slices
+        if used + n4 <= buf.numel():
+            pool[1] = used + n4
+            return buf[used:used + numel].view(dtype).view(shape)
+    return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
 def current_rng(device):
@@ -73,6 +97,7 @@ def reset_rng(seed=None):
     """Forget every per-device state (e.g. after torch.manual_seed)."""
     _master.clear()
     _current.clear()
+    _zero_pool.clear()
 
 
 def _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng_state, salt=0,
@@ -156,7 +181,7 @@ class _FusedAttention(Function):
         want_table = table is not None and ctx.needs_input_grad[3]
         d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt, 0, v.stride(1))
         if want_table and DYNAMIC_BWD:  # norm maxima + query counters for the dynamic distribution (see vdetr_hip.h)
-            aux = torch.zeros(4, dtype=torch.int32, device=q.device)
+            aux = _take_zeros(q, (4,), torch.int32)
             d.bwd_aux = aux.data_ptr()
         delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
         L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),
@@ -173,7 +198,7 @@ class _FusedAttention(Function):
                 return t4[0] if B == 1 else t4.reshape(B * H, n, HEAD_DIM)
             do_r, v_r = heads(dout, nQ), heads(v, nK)
             dprob = torch.bmm(do_r, v_r.transpose(1, 2))  # [B*H, nQ, nK]
-        dtable = torch.zeros_like(table) if want_table else None
+        dtable = _take_zeros(table, tuple(table.shape), table.dtype) if want_table else None
         nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d)) if want_table else 0
         ws = L.workspace(nbytes, q.device) if nbytes else None
         # scores -> P~ (dropped probabilities), dprob -> dS.  In place where allowed; the table-gradient kernel
