@@ -338,7 +338,7 @@ class _PosEmbedDeferred(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        DeferredPosEmbedGrads.pending.append(ctx.rec + (d_out.contiguous(),))
+        DeferredPosEmbedGrads.pending.append(ctx.rec + (d_out,))  # (a permuted view: the flush's stack is the only copy)
         return (None,) * (2 + 5)
 
 

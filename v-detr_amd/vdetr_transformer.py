@@ -550,8 +550,12 @@ class _DeferredHeads(torch.autograd.Function):
         else:
             dw1 = torch.bmm(dx1.permute(0, 2, 1, 3).reshape(S, G * C, Bsz * N),
                             f.permute(0, 2, 1, 3).reshape(S, C, Bsz * N).transpose(1, 2))
-        df = torch.matmul(w1.transpose(1, 2).unsqueeze(1), dx1)                                    # [S,B,C,N]
-        out = [df[s].permute(2, 0, 1) for s in range(S)]                                           # as [nQ,B,C]
+        if one:  # the transposed product: rows = queries, i.e. the [nQ,B,C] layout the layers want (no permuted view to copy)
+            dft = torch.bmm(dx1.view(S, G * C, N).transpose(1, 2), w1)                             # [S,N,C]
+            out = [dft[s].view(N, 1, C) for s in range(S)]
+        else:
+            df = torch.matmul(w1.transpose(1, 2).unsqueeze(1), dx1)                                # [S,B,C,N]
+            out = [df[s].permute(2, 0, 1) for s in range(S)]                                       # as [nQ,B,C]
         for s, r in enumerate(recs):
             out += [dw1[s].reshape(r["w1"].shape), dbn1[s][1], dbn1[s][2], dw2[s].reshape(r["w2"].shape), dbn2[s][1],
                     dbn2[s][2], dw3[s].reshape(r["w3"].shape), db3[s].reshape(r["b3"].shape)]
