@@ -137,7 +137,7 @@ class ModelVDETR(nn.Module):
         bs, npoints, _ = enc_xyz.shape
         enc_features = self.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
 
-        point_cls_logits = self.decoder.pointcls_heads(enc_features.permute(1, 2, 0).contiguous()) \
+        point_cls_logits = self.decoder.pointcls_heads(enc_features.permute(1, 2, 0)) \
             .transpose(1, 2).reshape((bs, npoints, -1)).contiguous()
         class_idx = point_cls_logits.sigmoid().max(dim=-1)[1]
         size_unnormalized = self._anchor_sizes(enc_features)[class_idx]
