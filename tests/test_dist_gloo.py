@@ -125,6 +125,117 @@ def test_flat_params_update_matches_per_parameter_update():
     assert all(p.data_ptr() >= flat.data.data_ptr() for p in m2.parameters())  # still views of the flat buffer
 
 
+def test_flat_params_filter_biases_wd_and_state_interop():
+    """optimizer.py:12-21 (--filter_biases_wd: no decay for biases / 1-D parameters) through the one-tensor optimizer, and
+    the flat AdamW state <-> per-parameter state mapping a reference optimizer checkpoint needs."""
+    import copy
+    from vdetr_amd.dist import FlatParams
+    torch.manual_seed(1)
+    m1 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LayerNorm(5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(9, 6)
+    nodecay = [p for n, p in m1.named_parameters() if p.ndim == 1 or n.endswith("bias")]
+    decay = [p for n, p in m1.named_parameters() if not (p.ndim == 1 or n.endswith("bias"))]
+    lr, wd = 1e-2, 0.1
+    o1 = torch.optim.AdamW([{"params": nodecay, "weight_decay": 0.0}, {"params": decay, "weight_decay": wd}], lr=lr)
+    flat = FlatParams(m2.parameters())
+    o2 = torch.optim.AdamW([flat.param], lr=lr, weight_decay=0.0, fused=True)
+    vec = flat.decay_vector(list(m2.named_parameters()), lr, wd)
+    for step in range(3):
+        for m in (m1, m2):
+            for p in m.parameters():
+                p.grad = None
+            m(x * (step + 1)).square().sum().backward()
+        o1.step()
+        flat.pack_grads()
+        with torch.no_grad():
+            flat.data.mul_(vec)
+        o2.step()
+        for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+            torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-7, msg=f"step {step} {n}")
+    # flat state -> per-parameter state, in model.parameters() order
+    states = flat.per_param_optimizer_state(o2, list(m2.parameters()))
+    for p1, d in zip(m1.parameters(), states):
+        torch.testing.assert_close(d["exp_avg"], o1.state[p1]["exp_avg"], rtol=1e-5, atol=1e-8)
+        torch.testing.assert_close(d["exp_avg_sq"], o1.state[p1]["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+        assert float(d["step"]) == float(o1.state[p1]["step"]) == 3.0
+    # ... and back: a fresh one-tensor optimizer resumed from the per-parameter states continues identically
+    m3 = copy.deepcopy(m2)
+    flat3 = FlatParams(m3.parameters())
+    o3 = torch.optim.AdamW([flat3.param], lr=lr, weight_decay=0.0, fused=True)
+    flat3.load_per_param_optimizer_state(o3, [{k: o1.state[p][k] for k in ("step", "exp_avg", "exp_avg_sq")} for p in m1.parameters()],
+                                         list(m3.parameters()))
+    vec3 = flat3.decay_vector(list(m3.named_parameters()), lr, wd)
+    for m in (m1, m3):
+        for p in m.parameters():
+            p.grad = None
+        m(x * 0.5).square().sum().backward()
+    o1.step()
+    flat3.pack_grads()
+    with torch.no_grad():
+        flat3.data.mul_(vec3)
+    o3.step()
+    for (n, a), (_, b) in zip(m1.named_parameters(), m3.named_parameters()):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-7, msg=f"resumed {n}")
+
+
+def _multi_fire_worker(rank, world, port, q):
+    """hooks mode with parameters that receive gradient SEVERAL times per step (a shared weight + late accumulation after
+    loss.backward(), as the deferred weight-gradient flushes do): compared with pack_and_reduce."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vdetr_amd import runtime
+    from vdetr_amd.dist import GradientReducer, broadcast_parameters, init_distributed
+    init_distributed("gloo")
+    res = {}
+    for mode in ("hooks", "pack"):
+        torch.manual_seed(7)
+        lin_a, lin_b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+        model = torch.nn.ModuleList([lin_a, lin_b])
+        broadcast_parameters(model)
+        red = GradientReducer(model.parameters(), bucket_mb=0.00005, overlap=mode == "hooks", bucket_views=mode == "hooks")
+        runtime.defer_weight_grads(True)   # hooks must not launch buckets before the late gradients arrive
+        try:
+            torch.manual_seed(rank)
+            x = torch.randn(3, 4)
+            for step in range(2):
+                red.zero_grad()
+                h = lin_a(lin_a(x))            # lin_a used twice -> its hook fires once, after both uses accumulated
+                y = lin_b(h.detach())
+                h.square().sum().backward()
+                # "flush": a second autograd pass that adds to lin_b AND again to lin_a
+                (y.square().sum() + lin_a(x).sum()).backward()
+                if mode == "hooks":
+                    red.finish()
+                else:
+                    red.pack_and_reduce()
+            res[mode] = [p.grad.numpy().copy() for p in model.parameters()]
+        finally:
+            runtime.defer_weight_grads(False)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_hooks_with_deferred_multi_fire_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_multi_fire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for rank, r in res:
+        for a, b in zip(r["hooks"], r["pack"]):
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+    for a, b in zip(res[0][1]["hooks"], res[1][1]["hooks"]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)   # both ranks hold the same averaged gradient
+
+
 def _loss_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))

@@ -265,8 +265,13 @@ class _CriterionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_losses):
-        ctx.flat.mul_(g_total)
-        return (None, None, None, None, *ctx.grads)
+        # a fresh product (one launch, as an in-place scale would be): the cached buffer stays intact, so a second backward
+        # through this node (retain_graph, gradient-accumulation probes) sees the same gradients, and what is returned
+        # aliases nothing a later step can mutate
+        prod = ctx.flat * g_total
+        base = ctx.flat.storage_offset()
+        return (None, None, None, None,
+                *[prod[g.storage_offset() - base:g.storage_offset() - base + g.numel()].view(g.shape) for g in ctx.grads])
 
 
 class SetCriterion(nn.Module):

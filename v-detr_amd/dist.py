@@ -165,6 +165,58 @@ class FlatParams:
         for g in keep:
             g.record_stream(torch.cuda.current_stream())
 
+    # ---- optimizer interoperability (optimizer.py:6-26, utils/io.py:23-29) -----------------------------------------
+    def decay_vector(self, named_params, lr, weight_decay, filter_biases_wd=True):
+        """The reference's ``--filter_biases_wd`` (optimizer.py:12-15: no weight decay for 1-D parameters and ``*.bias``)
+        for the one-tensor optimizer: a per-element factor ``1 - lr * wd`` (decayed) or ``1`` (exempt, and the zero
+        padding).  Use with ``AdamW([flat.param], weight_decay=0)``: ``flat.data.mul_(vec)`` before ``opt.step()`` is
+        AdamW's decoupled decay (``p *= 1 - lr * wd`` precedes the Adam update and the update does not read ``p``)."""
+        vec = torch.ones_like(self.data)
+        names = {id(p): n for n, p in named_params}
+        for p in self.params:
+            n = names.get(id(p), "")
+            exempt = filter_biases_wd and (p.ndim == 1 or n.endswith("bias"))
+            if not exempt:
+                o = self.offsets[id(p)]
+                vec[o:o + p.numel()] = 1.0 - lr * weight_decay
+        return vec
+
+    def per_param_optimizer_state(self, opt, params=None):
+        """The one-tensor AdamW state (``exp_avg`` / ``exp_avg_sq`` of the flat buffer) as the per-parameter state
+        dictionaries a per-parameter ``torch.optim.AdamW`` over ``params`` (default: this buffer's parameters, e.g. in
+        ``model.parameters()`` order for a reference checkpoint, utils/io.py:23-29) would hold: a list aligned with
+        ``params``, copies, independent of the flat layout."""
+        st = opt.state.get(self.param, {})
+        out = []
+        for p in (self.params if params is None else params):
+            o, n = self.offsets[id(p)], p.numel()
+            d = {"step": st["step"].clone() if "step" in st else torch.tensor(0.0)}
+            for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                if k in st:
+                    d[k] = st[k][o:o + n].view(p.shape).clone()
+            out.append(d)
+        return out
+
+    def load_per_param_optimizer_state(self, opt, states, params=None):
+        """Inverse of ``per_param_optimizer_state``: per-parameter AdamW states (a reference optimizer checkpoint, in
+        ``params`` order) -> the one-tensor optimizer's state.  ``step`` must agree over the parameters."""
+        plist = self.params if params is None else list(params)
+        assert len(plist) == len(states)
+        st = opt.state[self.param]
+        steps = {float(d["step"]) for d in states if "step" in d}
+        assert len(steps) <= 1, "per-parameter AdamW steps differ: not representable as one tensor"
+        for k in ("exp_avg", "exp_avg_sq"):
+            st.setdefault(k, torch.zeros_like(self.data))
+        if steps:
+            step = torch.tensor(steps.pop(), dtype=torch.float32, device=self.data.device if opt.defaults.get("capturable") else "cpu")
+            st["step"] = step
+        with torch.no_grad():
+            for p, d in zip(plist, states):
+                o, n = self.offsets[id(p)], p.numel()
+                for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                    if k in d:
+                        st.setdefault(k, torch.zeros_like(self.data))[o:o + n].copy_(d[k].reshape(-1))
+
     def clip_scale(self, max_norm, eps=1e-6):
         """1 / clip coefficient of ``clip_grad_norm_(params, max_norm)`` as a device scalar: max(||g|| / max_norm, 1).
         Handed to a fused optimizer as ``grad_scale`` (it divides the gradient by it inside its own launch)."""
@@ -217,6 +269,7 @@ class GradientReducer:
             self._pending.append(len(g))
             self._launched.append(False)
         self._counts = list(self._pending)
+        self._seen = set()  # parameters whose hook has fired in the current step
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._handles = []
         if overlap and self.world > 1 and bucket_views:
@@ -225,10 +278,25 @@ class GradientReducer:
 
     # ---- hooks (eager mode) -------------------------------------------------------------------------
     def _hook(self, p):
+        """Post-accumulate hook.  A parameter may receive gradient more than once per step (several uses, or the
+        deferred weight-gradient flushes of runtime.defer_weight_grads() that run after loss.backward()): only its FIRST
+        fire of the step counts towards its bucket, and while deferral is on no bucket is launched from a hook at all --
+        its gradients are complete only after runtime.flush_weight_grads(), so finish() launches them."""
+        if id(p) in self._seen:
+            if self._launched[self._bucket_of[id(p)]]:
+                raise RuntimeError("GradientReducer: a parameter received gradient after its bucket's all-reduce was "
+                                   "launched (accumulate into it before backward ends, or use pack_and_reduce)")
+            return
+        self._seen.add(id(p))
         gi = self._bucket_of[id(p)]
         self._pending[gi] -= 1
-        if self._pending[gi] == 0 and not self._launched[gi]:
+        if self._pending[gi] == 0 and not self._launched[gi] and not self._hooks_deferred():
             self._launch(gi)
+
+    @staticmethod
+    def _hooks_deferred():
+        from . import runtime
+        return runtime.weight_grads_deferred()
 
     def _launch(self, gi):
         self._launched[gi] = True
@@ -285,6 +353,7 @@ class GradientReducer:
                 torch.cuda.current_stream().wait_stream(self._side)
         self._pending = list(self._counts)
         self._launched = [False] * len(self.buckets)
+        self._seen.clear()
 
     _avg_unsupported = False
 
@@ -336,14 +405,18 @@ def reduce_dict(input_dict, average=True):
         names = sorted(input_dict.keys())
         vals = [input_dict[k] for k in names]
         base = vals[0]._base if vals and vals[0]._base is not None else None
-        if base is not None and all(v._base is base for v in vals):
-            red = base.detach().clone()
+        if (base is not None and base.is_contiguous() and base.is_floating_point()
+                and all(v._base is base and v.ndim == 0 and v.dtype == base.dtype for v in vals)):
+            # reduce only the span of the base that the values occupy: other words of the base (the criterion's
+            # 64-bit cardinality tickets, reinterpreted as floats) must not go through a float sum
+            off0 = base.storage_offset()
+            offs = [v.storage_offset() - off0 for v in vals]
+            lo, hi = min(offs), max(offs) + 1
+            red = base.detach().reshape(-1)[lo:hi].clone()
             dist.all_reduce(red)
             if average:
                 red /= dist.get_world_size()
-            off0 = base.storage_offset()
-            flat = red.reshape(-1)
-            return {k: flat[v.storage_offset() - off0] for k, v in zip(names, vals)}
+            return {k: red[o - lo] for k, o in zip(names, offs)}
         values = torch.stack([v.detach() for v in vals], dim=0)
         dist.all_reduce(values)
         if average:

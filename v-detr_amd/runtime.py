@@ -16,15 +16,56 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SEED_RESULTS = os.path.join(_HERE, "tuning", "gfx950_tunableop.csv")
 
 
+def _default_cache_dir():
+    """Per user and per library version: a results file written by another torch / ROCm build (or another user's job in
+    a shared temp dir) must never be picked up."""
+    ver = f"torch{torch.__version__}-hip{torch.version.hip or 'none'}".replace("/", "_")
+    root = os.environ.get("VDETR_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "vdetr_amd")
+    return os.path.join(root, ver)
+
+
 def enable_gemm_tuning(rank=0, cache_dir=None):
-    """Turn TunableOp on for this process.  Returns the path of the results file in use."""
+    """Turn TunableOp on for this process.  Returns the path of the results file in use.  The file lives in a private
+    (0700) per-user, per-version directory and is unique to this process (rank AND pid: concurrent jobs of one user do not
+    share it); it is seeded from the committed MI355X measurements through a temp file + atomic rename."""
     import torch.cuda.tunable as tn
-    path = os.path.join(cache_dir or tempfile.gettempdir(), f"vdetr_tunableop_rank{rank}.csv")
-    if not os.path.exists(path) and os.path.exists(SEED_RESULTS):
-        shutil.copy(SEED_RESULTS, path)  # start from the committed measurements
+    d = cache_dir or _default_cache_dir()
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        if os.path.islink(d) or os.stat(d).st_uid != os.getuid():
+            raise OSError("cache directory is a symlink or owned by someone else")
+    except OSError:
+        d = tempfile.mkdtemp(prefix="vdetr_tunableop_")  # private by construction
+    path = os.path.join(d, f"tunableop_rank{rank}_pid{os.getpid()}.csv")
+    if os.path.exists(SEED_RESULTS):
+        fd, tmp = tempfile.mkstemp(dir=d, prefix=".seed_")
+        with os.fdopen(fd, "wb") as dst, open(SEED_RESULTS, "rb") as src:
+            shutil.copyfileobj(src, dst)
+        os.replace(tmp, path)  # always start from the committed measurements, never from a stale file
     tn.set_filename(path)
     tn.enable(True)
     tn.tuning_enable(True)
+    # the per-process file is scratch: removed at exit; VDETR_TUNABLEOP_SAVE=<file> keeps a copy of what this run tuned
+    # (how tuning/gfx950_tunableop.csv is refreshed on the GPU box)
+    if hasattr(tn, "write_file_on_exit"):  # older torch: results written at exit; newer: appended as they are found
+        tn.write_file_on_exit(False)
+    import atexit
+
+    def _finish(path=path):
+        try:
+            keep = os.environ.get("VDETR_TUNABLEOP_SAVE")
+            if keep:
+                if hasattr(tn, "write_file"):
+                    tn.write_file(path)
+                shutil.copy(path, keep)
+        except Exception:
+            pass
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+    atexit.register(_finish)
     return path
 
 
@@ -39,6 +80,13 @@ def defer_weight_grads(enable=True):
         DeferredParamGrads.pending.clear()
         DeferredLnGrads.pending.clear()
         DeferredPosEmbedGrads.pending.clear()
+
+
+def weight_grads_deferred():
+    """True while ``defer_weight_grads()`` is on: parameter gradients are then complete only after
+    ``flush_weight_grads()`` (dist.GradientReducer launches no bucket from its hooks in that mode)."""
+    from .helpers import DeferredParamGrads
+    return bool(DeferredParamGrads.enabled)
 
 
 def flush_weight_grads():
