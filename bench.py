@@ -259,7 +259,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
     dout = torch.randn((B, nQ, H * 64), generator=g).to(device) * 1e-3
     dprob = torch.bmm(dout.view(B, nQ * H, 64), v.transpose(1, 2)).view(B, nQ, H, nK).contiguous()  # dP~ = dO V^T
     delta = torch.zeros((B, nQ, H), device=device)
-    aux = torch.zeros(4, dtype=torch.int32, device=device)  # norm maxima + query counters (dynamic distribution)
+    aux = torch.zeros(8, dtype=torch.int32, device=device)  # norm maxima, query counters, non-box count (vdetr_hip.h)
     dtable = torch.zeros_like(table)
     probs, dscore = torch.empty_like(scores), torch.empty_like(dprob)
     wsf = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
@@ -303,7 +303,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
                "achieved": flops / t_fwd / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                "frac": flops / t_fwd / 1e12 / 157.3, "traffic": None, "launch_us": t_fwd * 1e6,
                "rpe_lookups_per_s": 8.0 * pairs / t_fwd}
-    bwd_obj = {"kernel": "attn_bwd_scores_rpe_mm_kernel (softmax backward + RPE table gradient)", "bound": "hbm",
+    bwd_obj = {"kernel": "attn_bwd_box_kernel (softmax backward + RPE table gradient, axis-aligned boxes)", "bound": "hbm",
                "achieved": bytes_bwd / t_bwd / 1e9, "peak": 8000.0, "unit": "GB/s",
                "frac": bytes_bwd / t_bwd / 1e9 / 8000.0, "traffic": None, "launch_us": t_bwd * 1e6,
                "rpe_scatter_per_s": 8.0 * pairs / t_bwd}

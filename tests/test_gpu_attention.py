@@ -63,6 +63,8 @@ CASES = [  # B, nQ, nK, shared, rpe, rot, mask
     (1, 37, 301, True, True, False, "bool"),
     (2, 16, 96, True, True, False, "float"),
     (1, 4, 4096, True, True, False, None),      # few queries -> key-split path
+    (1, 48, 1024, True, True, False, None),     # axis-aligned boxes, every wave of a backward workgroup busy
+    (1, 24, 640, True, True, "jitter", None),   # arbitrary vertices without a rotation operand: the general kernels
     (2, 9, 9, True, False, False, None),        # ShareSelfAttention core
     (1, 50, 50, False, False, False, None),     # nn.MultiheadAttention core
     (2, 130, 77, False, False, False, "float"),
@@ -75,7 +77,9 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
     from vdetr_amd import attention as A
     H = 4
     g = torch.Generator().manual_seed(B * 1000 + nQ + nK)
-    xyz, verts, tables, cs = _scene(B, nQ, nK, 7, rot)
+    xyz, verts, tables, cs = _scene(B, nQ, nK, 7, rot is True)
+    if rot == "jitter":  # one query that is not a box is enough to send the whole launch down the general path
+        verts[:, nQ // 2] += 0.05 * torch.randn(verts[:, nQ // 2].shape, generator=g)
     q = torch.randn((B, nQ, 256), generator=g)
     kd = 64 if shared else 256
     k = torch.randn((B, nK, kd), generator=g)
@@ -108,6 +112,35 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
             assert_close(o, r.detach().numpy(), 1e-4, 1e-5 * max(scale, 1.0), name)
         else:
             assert_close(o, r.detach().numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
+
+
+def test_box_backward_kernel_equals_general_kernel(monkeypatch):
+    """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
+    where every wave of every workgroup is busy (the size at which a packed-math code-generation problem once showed):
+    P~ and dS bit-identical (same element-wise code), table gradient within the fixed-point resolution, three times."""
+    from vdetr_amd import attention as A
+    B, nQ, nK = 1, 192, 2048
+    g = torch.Generator().manual_seed(11)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 5)
+    q, k, v = (torch.randn(s, generator=g).to(DEV) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g).to(DEV)
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True, rpe=A.RPEConfig(), vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV))
+
+    def run():
+        args = [x.clone().requires_grad_(True) for x in (q, k, v)]
+        tb = tables.to(DEV).requires_grad_(True)
+        (A.fused_attention(*args, table=tb, **kw) * wout).sum().backward()
+        return [a.grad for a in args] + [tb.grad]
+
+    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    ref = run()
+    monkeypatch.setenv("VDETR_BWD_BOX", "1")
+    for rep in range(3):
+        got = run()
+        for name, r, o in zip(("dq", "dk", "dv"), ref, got):
+            assert torch.equal(r, o), f"{name} differs between the box and the general kernel (rep {rep})"
+        scale = float(ref[3].abs().max())
+        assert float((got[3] - ref[3]).abs().max()) <= 3e-4 * scale, f"dtable rep {rep}"
 
 
 def test_attention_probabilities_and_dropout_statistics():

@@ -181,7 +181,7 @@ class _FusedAttention(Function):
         want_table = table is not None and ctx.needs_input_grad[3]
         d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt, 0, v.stride(1))
         if want_table and DYNAMIC_BWD:  # norm maxima + query counters for the dynamic distribution (see vdetr_hip.h)
-            aux = _take_zeros(q, (4,), torch.int32)
+            aux = _take_zeros(q, (8,), torch.int32)  # 5 words used (vdetr_hip.h: bwd_aux)
             d.bwd_aux = aux.data_ptr()
         delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
         L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),

@@ -20,27 +20,9 @@
 namespace vdetr {
 
 int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
+int launch_attn_bwd_box(const AttnParams& P, int grid, hipStream_t st);  // attn_bwd_box.hip
 
 constexpr int kBwdThreads = 1024;
-
-// element-wise part shared by both kernels: returns P~ and dS for one head of one (q,key) pair
-struct ScoreGrad {
-  float p_drop, ds;
-};
-__device__ __forceinline__ ScoreGrad score_grad(float s, float lse, bool keep, float drop_scale, bool have_grad,
-                                                float dprob, float delta, bool masked) {
-  const float p = __expf(s - lse);
-  ScoreGrad r;
-  r.p_drop = keep ? p * drop_scale : 0.f;
-  float ds = 0.f;
-  if (have_grad) {
-    const float dp = keep ? dprob * drop_scale : 0.f;
-    ds = p * (dp - delta);
-    if (masked) ds = 0.f;  // masked_fill_ overwrote the score: no gradient reaches q, k or the table
-  }
-  r.ds = ds;
-  return r;
-}
 
 // ---- generic kernel (no RPE): one thread per score element ----------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(AttnParams P) {
@@ -272,6 +254,8 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
   constexpr int kChunkStride = VLOOP ? VERTS * WPV : WPV;
   constexpr int kSplit = kRpeVerts / VERTS;  // workgroups per query
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy VERTS*T^3*4][strips]
+  // every query is an axis-aligned box (count of the others left by the delta launch): attn_bwd_box_kernel does this launch
+  if (P.box_path && P.bwd_aux[4] == 0) return;
   attn_load_rng(P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -647,7 +631,7 @@ constexpr int kDeltaKeys = 16;  // keys per wave in the |V row| pass
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                         float* __restrict__ delta, int B, int nQ, int H, int perhead,
                                                         unsigned* aux, const float* __restrict__ v, int nK, int v_stride,
-                                                        int qblocks) {
+                                                        int qblocks, const float* __restrict__ vertices) {
   __shared__ float wmax[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float n2max = 0.f;
@@ -671,6 +655,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
         const float s = wave_allsum_f32(g * out[e]);
         if (aux) n2max = fmaxf(n2max, wave_allsum_f32(g * g));
         if (lane == 0) delta[perhead ? ((size_t)b * H + h) * nQ + q : (size_t)row * H + h] = s;
+      }
+      if (aux && vertices) {  // aux[4] += 1 for a query whose 8 RPE vertices are not an axis-aligned box (attn_common.h)
+        const float* vp = vertices + (size_t)row * 24;
+        const int i = lane & 7;
+        const bool ok = vp[i * 3] == vp[rpe_box_xi(i) ? 6 : 0] && vp[i * 3 + 1] == vp[rpe_box_yi(i) ? 4 : 1] &&
+                        vp[i * 3 + 2] == vp[rpe_box_zi(i) ? 14 : 2];
+        if (!__all(ok) && lane == 0) atomicAdd(aux + 4, 1u);
       }
     }
   }
@@ -767,6 +758,14 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     }
     P.dtable_part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   }
+  // axis-aligned boxes (no rotation operand, table edge 10, dynamic distribution): the box kernel is launched next to the
+  // general one over the same grid / partial-table layout, and the device decides which of the two does the work
+  // opt-in (VDETR_BWD_BOX=1): measured 465 us against 406 us for the general kernel at C2 size; read per
+  // call because the parity test runs both kernels in one process
+  const char* box_var = getenv("VDETR_BWD_BOX");
+  const int box_env = box_var ? atoi(box_var) : 0;
+  const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && P.T == 10;
+  P.box_path = box ? 1 : 0;
   if (mm) {
     const size_t lds = (size_t)table_floats / split * sizeof(float) + (size_t)8 * split * kMmStripFloats * sizeof(float);
     int e;
@@ -779,6 +778,8 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     else if (variant == 12) e = launch_mm<true, 4, 2, true, true>(P, grid, (size_t)table_floats / 2 * sizeof(float) + (size_t)8 * kMmStripFloats * sizeof(float), st);
     else e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st);
     if (e) return e;
+    if (box)
+      if (int e2 = launch_attn_bwd_box(P, grid, st)) return e2;
   } else {
     const size_t lds = dtable ? (size_t)table_floats * sizeof(float) : 16;
     if (variant == 0) {
@@ -809,7 +810,7 @@ extern "C" int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout,
   const int vblocks = norms ? ceil_div((long)d->B * d->nK, 4 * kDeltaKeys) : 0;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(qblocks + vblocks), dim3(256), 0, (hipStream_t)stream, dout, out, delta, d->B,
                      d->nQ, d->H, d->kind == VDETR_ATTN_PER_HEAD ? 1 : 0, d->bwd_aux, v, d->nK,
-                     d->v_row_stride ? d->v_row_stride : 64, qblocks);
+                     d->v_row_stride ? d->v_row_stride : 64, qblocks, d->table && !d->cos_sin ? d->vertices : nullptr);
   return check_launch("attn_delta");
 }
 

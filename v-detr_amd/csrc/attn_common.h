@@ -89,6 +89,25 @@ __device__ __forceinline__ unsigned pick4(const uint4& r, int i) {
   return i == 0 ? r.x : (i == 1 ? r.y : (i == 2 ? r.z : r.w));
 }
 
+// ---- element-wise softmax backward: P~ and dS for one head of one (query, key) pair (attn_bwd*.hip) ------------------
+struct ScoreGrad {
+  float p_drop, ds;
+};
+__device__ __forceinline__ ScoreGrad score_grad(float s, float lse, bool keep, float drop_scale, bool have_grad,
+                                                float dprob, float delta, bool masked) {
+  const float p = __expf(s - lse);
+  ScoreGrad r;
+  r.p_drop = keep ? p * drop_scale : 0.f;
+  float ds = 0.f;
+  if (have_grad) {
+    const float dp = keep ? dprob * drop_scale : 0.f;
+    ds = p * (dp - delta);
+    if (masked) ds = 0.f;  // masked_fill_ overwrote the score: no gradient reaches q, k or the table
+  }
+  r.ds = ds;
+  return r;
+}
+
 // ---- 3DV-RPE lookup geometry ----------------------------------------------------------------------
 // Reference (vdetr_transformer.py:711-731 + F.grid_sample, bilinear/zeros/align_corners=False):
 //   g   = sign(d) * log2(|d|*log_scale + 1) / log2(8) / max_value
