@@ -505,6 +505,28 @@ int vdetr_box3d_iou_max_f64(const float* pred_corners, const int32_t* pred_img, 
                             const float* gt_corners, const int32_t* gt_cls, const int32_t* img_gt_begin, double* ovmax,
                             int32_t* jmax, vdetr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Sparse-convolution backbone: index kernels behind the MinkowskiEngine call sites of the
+ * reference (models/mink_resnet.py:38-84 ME.MinkowskiConvolution / BasicBlock, models/model_vdetr.py:141-176
+ * MinkowskiConvolution / MinkowskiConvolutionTranspose / MinkowskiGenerativeConvolutionTranspose, :250-280 run_encoder).
+ * MinkowskiEngine is an un-vendored dependency (README.md:47-53, no pinned commit): the operator restated is the published
+ * generalized sparse convolution  out[u] = sum_k in[u + offset_k] W_k  over occupied sites.
+ * A voxel KEY packs (batch, x, y, z) into an int64 as (batch << 48) | (x + 32768) << 32 | (y + 32768) << 16 | (z + 32768):
+ * ascending keys = lexicographic (batch, x, y, z).  Coordinates are in units of the finest voxel (tensor stride 1).
+ * ---------------------------------------------------------------------------------------------- */
+/* nbr[k][u] (K x nout, i32) = index into the SORTED in_keys of the site out_keys[u] + offsets[k] (offsets [K,3] i32 as
+ * dx, dy, dz), or -1 if it is not occupied.  Replaces the coordinate manager's kernel-map construction. */
+int vdetr_sp_kernel_map_i32(const int64_t* in_keys, int nin, const int64_t* out_keys, int nout, const int32_t* offsets, int K,
+                            int32_t* nbr, vdetr_stream_t stream);
+/* inv[k][i] (K x nin, i32, filled with -1 by the caller) = the output row u with nbr[k][u] == i (unique on a lattice). */
+int vdetr_sp_inverse_map_i32(const int32_t* nbr, int K, int nout, int nin, int32_t* inv, vdetr_stream_t stream);
+/* col[u][k][:] = in[nbr[k][u]][:] or zeros: in [nin,C] f32 -> col [nout,K,C] f32, C % 4 == 0.  The forward pass of a layer
+ * is col [nout, K*C] x W [K*C, Cout] (one library GEMM), its weight gradient col^T x dout. */
+int vdetr_sp_gather_cols_f32(const float* in, const int32_t* nbr, int K, int nout, int C, float* col, vdetr_stream_t stream);
+/* din[i][:] = sum_k dcol[inv[k][i]][k][:]: the adjoint of vdetr_sp_gather_cols_f32 written as a gather (fixed summation
+ * order, no atomics).  dcol [nout,K,C] f32, inv [K,nin] -> din [nin,C], written in full. */
+int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, int K, int nin, int C, float* din, vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

@@ -197,6 +197,10 @@ _SIGNATURES = {
     "vdetr_point_labels_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vdetr_set_loss_f32": (c_int, [ctypes.POINTER(SetLossDesc), c_void_p]),
     "vdetr_set_loss_batch_f32": (c_int, [ctypes.POINTER(SetLossDesc), c_int, c_void_p]),
+    "vdetr_sp_kernel_map_i32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vdetr_sp_inverse_map_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_sp_gather_cols_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_sp_gather_sum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -2,17 +2,23 @@
 features, projection, first-stage anchors and the decoder call, with the same ``forward(inputs)`` contract and the
 same state-dict keys (``encoder_to_decoder_projection.layers.{0,1}``, ``decoder.*``).
 
-The sparse-convolution backbone (MinkowskiEngine ResNet34 + FPN, model_vdetr.py:139-185,250-280) is OUT OF SCOPE:
-``pre_encoder`` here is any callable that returns what the reference takes from it at model_vdetr.py:279-280 —
-per scene, the voxel coordinates ``xyz [n,3]`` (= out.C[:,1:] * voxel_size) and features ``feats [n,C]`` (= out.F).
+``pre_encoder`` is either
+  * a ``mink_resnet.MinkResNet``: the model then owns the reference's FPN neck (``up_block_{1,2,3}``,
+    ``out_block_0``; model_vdetr.py:139-185) and runs ``run_encoder`` as the reference does (:248-280: voxelise, ResNet34,
+    top-down FPN, out block), on the sparse primitives of ``vdetr_amd.minkowski`` instead of MinkowskiEngine; or
+  * any callable that returns what the reference takes from the backbone at model_vdetr.py:279-280 — per scene, the voxel
+    coordinates ``xyz [n,3]`` (= out.C[:,1:] * voxel_size) and features ``feats [n,C]`` (= out.F) — e.g. ``TensorBackbone``
+    (benchmarks and tests of the post-backbone hot path).
 """
 from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
 
+from . import minkowski as ME
 from . import pointnet2_utils
 from .helpers import GenericMLP
+from .mink_resnet import MinkResNet
 from .position_embedding import PositionEmbeddingCoordsSine
 from .vdetr_transformer import FFNLayer, GlobalDecoderLayer, TransformerDecoder
 
@@ -60,6 +66,14 @@ class ModelVDETR(nn.Module):
         self.querypos_mlp = querypos_mlp
         self.voxel_size = voxel_size
         self.npoint = npoint
+        self.use_fpn, self.layer_idx, self.num_stages, self.woexpand_conv = use_fpn, layer_idx, num_stages, woexpand_conv
+        self.use_color = bool(getattr(args, "use_color", False))
+        self.xyz_color = bool(getattr(args, "xyz_color", False))
+        self.sparse_backbone = isinstance(pre_encoder, MinkResNet)
+        if self.sparse_backbone:
+            depth = int(getattr(args, "depth", 34))
+            channels = [(4 if depth > 34 else 1) * inplane * 2 ** i for i in range(num_stages)]
+            self._init_fpn_layers(channels, encoder_dim)
         # reads args.random_fps with a default: the reference never defines the flag
         self.random_fps = bool(getattr(args, "random_fps", False))
         self.fps_module = FPSModule()
@@ -77,6 +91,61 @@ class ModelVDETR(nn.Module):
         self.num_queries = num_queries
         self.dataset_config = dataset_config
         self.hard_anchor = bool(getattr(args, "hard_anchor", False))
+
+    # ---- FPN neck of the sparse backbone (model_vdetr.py:139-185) -----------------------------------------------------
+    @staticmethod
+    def _make_block(in_channels, out_channels):
+        return nn.Sequential(ME.MinkowskiConvolution(in_channels, out_channels, kernel_size=3, dimension=3),
+                             ME.MinkowskiBatchNorm(out_channels), ME.MinkowskiELU())
+
+    @staticmethod
+    def _make_up_block(in_channels, out_channels, woexpand_conv):
+        up = ME.MinkowskiConvolutionTranspose if woexpand_conv else ME.MinkowskiGenerativeConvolutionTranspose
+        return nn.Sequential(up(in_channels, out_channels, kernel_size=2, stride=2, dimension=3),
+                             ME.MinkowskiBatchNorm(out_channels), ME.MinkowskiELU(),
+                             ME.MinkowskiConvolution(out_channels, out_channels, kernel_size=3, dimension=3),
+                             ME.MinkowskiBatchNorm(out_channels), ME.MinkowskiELU())
+
+    def _init_fpn_layers(self, in_channels, out_channels):
+        if self.use_fpn:
+            for i in range(self.layer_idx + 1, len(in_channels)):
+                if i > 0:
+                    setattr(self, f"up_block_{i}", self._make_up_block(in_channels[i], in_channels[i - 1], self.woexpand_conv))
+        setattr(self, f"out_block_{self.layer_idx}", self._make_block(in_channels[self.layer_idx], out_channels))
+        for m in self.modules():  # the reference re-initialises EVERY Minkowski layer of the model here (:178-185)
+            if isinstance(m, ME.MinkowskiConvolution):
+                ME.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")
+            if isinstance(m, ME.MinkowskiBatchNorm):
+                nn.init.constant_(m.bn.weight, 1)
+                nn.init.constant_(m.bn.bias, 0)
+
+    def backbone_forward(self, inputs):
+        """model_vdetr.py:248-280: voxelise at ``voxel_size``, MinkResNet, top-down FPN, out block -> per scene
+        (xyz [n,3] = out.C[:,1:] * voxel_size, features [n,C] = out.F).  The reference's default (no colour) path reads an
+        undefined name (:259); the evident intent — xyz as the input features — is what runs here."""
+        clouds = inputs["point_clouds"]
+        if self.use_color:
+            data = [(p[:, :3] / self.voxel_size, p[:, :] if self.xyz_color else p[:, 3:]) for p in clouds]
+        else:
+            data = [(p[:, :3] / self.voxel_size, p[:, :3]) for p in clouds]
+        coordinates, features = ME.batch_sparse_collate(data)
+        x = ME.SparseTensor(features.contiguous(), coordinates=coordinates)
+        stages = self.pre_encoder(x)
+        x = stages[-1]
+        out = None
+        for i in range(len(stages) - 1, self.layer_idx - 1, -1):
+            if self.use_fpn:
+                if i < len(stages) - 1:
+                    x = getattr(self, f"up_block_{i + 1}")(x)
+                    x = stages[i] + x
+            else:
+                x = stages[i]
+            if i == self.layer_idx:
+                out = getattr(self, f"out_block_{i}")(x)
+        return [(c.to(out.F.dtype) * self.voxel_size, f) for c, f in out.decomposed()]
+
+    def _scenes(self, inputs):
+        return self.backbone_forward(inputs) if self.sparse_backbone else self.pre_encoder(inputs)
 
     def _anchor_sizes(self, ref):
         """per-class anchor sizes on ref's device (model_vdetr.py:348-352), cached so the forward has no H2D copy"""
@@ -102,12 +171,12 @@ class ModelVDETR(nn.Module):
         """FPS indices [B, npoint] (int32) of a batch whose scenes have equal voxel counts.  The sampling only
         depends on the voxel COORDINATES, so a training loop can run it ahead of time — e.g. for the next batch on a
         side stream while the current batch is in the decoder — and pass the result as ``inputs["fps_inds"]``."""
-        scenes = self.pre_encoder(inputs)
+        scenes = self._scenes(inputs)
         return pointnet2_utils.furthest_point_sample_varlen([s[0].contiguous() for s in scenes], self.npoint)
 
     def run_encoder(self, inputs):
         """Backbone output -> FPS to ``npoint`` tokens per scene (model_vdetr.py:279-326)."""
-        scenes = self.pre_encoder(inputs)
+        scenes = self._scenes(inputs)
         if not self.random_fps and len(scenes) <= 32:
             # point-major tables as the backbone hands them over, scenes of any sizes: ONE FPS launch (a workgroup per
             # scene) and two row gathers for the batch; no (B,C,n) transposed copy of the features in either direction
@@ -166,7 +235,10 @@ def default_args(**overrides):
              rpe_quant="bilinear_4_10", log_scale=512.0, pos_for_key=False, querypos_mlp=True, q_content="random",
              proj_nohid=True, share_selfattn=False, mlp_dropout=0.3, mlp_norm="bn1d", mlp_act="relu", mlp_sep=True,
              preenc_npoints=4096, nqueries=1024, is_bilable=True, angle_type="", hard_anchor=False,
-             cls_loss="focalloss_0.25", voxel_size=0.01, random_fps=False)
+             cls_loss="focalloss_0.25", voxel_size=0.01, random_fps=False,
+             # backbone flags (main.py:55-63,88,112,166-167)
+             depth=34, inplanes=64, num_stages=4, stem_bn=True, use_fpn=True, layer_idx=0, woexpand_conv=True,
+             use_color=False, xyz_color=False, use_normals=False)
     a.update(overrides)
     return SimpleNamespace(**a)
 
@@ -184,10 +256,25 @@ def build_decoder(args, dataset_config):
                               q_content=args.q_content, return_intermediate=True, args=args)
 
 
+def build_backbone(args):
+    """model_vdetr.py:392-410: MinkResNet on xyz (3), xyz + colour (6) [+ normals (+3)] input features."""
+    if args.use_color and args.xyz_color:
+        point_dim = 9 if args.use_normals else 6
+    else:
+        point_dim = 6 if args.use_normals else 3
+    return MinkResNet(depth=args.depth, in_channels=point_dim, inplanes=args.inplanes, num_stages=args.num_stages,
+                      stem_bn=args.stem_bn)
+
+
 def build_vdetr(args, dataset_config, pre_encoder=None):
-    """model_vdetr.py:450-474, with the backbone replaced by a provider (default: TensorBackbone)."""
+    """model_vdetr.py:450-474.  ``pre_encoder``: None = TensorBackbone (the post-backbone hot path on handed-in voxel
+    tables), "minkowski" = the reference's sparse ResNet34 + FPN backbone (build_backbone), or any provider."""
+    if isinstance(pre_encoder, str) and pre_encoder == "minkowski":
+        pre_encoder = build_backbone(args)
     return ModelVDETR(pre_encoder if pre_encoder is not None else TensorBackbone(), None,
                       build_decoder(args, dataset_config), dataset_config, encoder_dim=args.enc_dim,
                       decoder_dim=args.dec_dim, num_queries=args.nqueries, querypos_mlp=args.querypos_mlp,
-                      minkowski=True, voxel_size=args.voxel_size, npoint=args.preenc_npoints,
-                      proj_nohid=args.proj_nohid, args=args)
+                      minkowski=True, inplane=getattr(args, "inplanes", 64), num_stages=getattr(args, "num_stages", 4),
+                      voxel_size=args.voxel_size, npoint=args.preenc_npoints, use_fpn=getattr(args, "use_fpn", True),
+                      layer_idx=getattr(args, "layer_idx", 0), proj_nohid=args.proj_nohid,
+                      woexpand_conv=getattr(args, "woexpand_conv", True), args=args)
