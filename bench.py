@@ -45,6 +45,26 @@ def make_scene(npoints, seed, device):
     return xyz, feats
 
 
+def make_room_cloud(npoints, seed, device):
+    """Raw input points of a synthetic indoor scene for the sparse backbone: an 8x6x3 m room (floor, four walls) and a few
+    box-shaped pieces of furniture, points ON the surfaces with 5 mm noise, offset by +1 m (as make_scene)."""
+    rng = np.random.default_rng(seed)
+    surf = []  # (origin, edge u, edge v, area)
+    L, W, H = 8.0, 6.0, 3.0
+    planes = [((0, 0, 0), (L, 0, 0), (0, W, 0)), ((0, 0, 0), (L, 0, 0), (0, 0, H)), ((0, W, 0), (L, 0, 0), (0, 0, H)),
+              ((0, 0, 0), (0, W, 0), (0, 0, H)), ((L, 0, 0), (0, W, 0), (0, 0, H))]
+    for _ in range(12):  # furniture: top + four sides
+        sx, sy, sz = rng.uniform(0.4, 2.0), rng.uniform(0.4, 1.5), rng.uniform(0.4, 1.8)
+        ox, oy = rng.uniform(0.2, L - sx - 0.2), rng.uniform(0.2, W - sy - 0.2)
+        planes += [((ox, oy, sz), (sx, 0, 0), (0, sy, 0)), ((ox, oy, 0), (sx, 0, 0), (0, 0, sz)), ((ox, oy + sy, 0), (sx, 0, 0), (0, 0, sz)),
+                   ((ox, oy, 0), (0, sy, 0), (0, 0, sz)), ((ox + sx, oy, 0), (0, sy, 0), (0, 0, sz))]
+    areas = np.array([np.linalg.norm(np.cross(u, v)) for _, u, v in planes])
+    which = rng.choice(len(planes), size=npoints, p=areas / areas.sum())
+    o = np.array([planes[i][0] for i in which]); u = np.array([planes[i][1] for i in which]); v = np.array([planes[i][2] for i in which])
+    pts = o + rng.uniform(0, 1, (npoints, 1)) * u + rng.uniform(0, 1, (npoints, 1)) * v + rng.normal(0, 0.005, (npoints, 3))
+    return torch.from_numpy((pts + 1.0).astype(np.float32)).to(device)
+
+
 def build_model(cfg_name, device, seed=0):
     from vdetr_amd.dataset_config import RotatedBoxDatasetConfig, ScannetDatasetConfig
     from vdetr_amd.model_vdetr import build_vdetr, default_args

@@ -524,8 +524,11 @@ int vdetr_sp_inverse_map_i32(const int32_t* nbr, int K, int nout, int nin, int32
  * is col [nout, K*C] x W [K*C, Cout] (one library GEMM), its weight gradient col^T x dout. */
 int vdetr_sp_gather_cols_f32(const float* in, const int32_t* nbr, int K, int nout, int C, float* col, vdetr_stream_t stream);
 /* din[i][:] = sum_k dcol[inv[k][i]][k][:]: the adjoint of vdetr_sp_gather_cols_f32 written as a gather (fixed summation
- * order, no atomics).  dcol [nout,K,C] f32, inv [K,nin] -> din [nin,C], written in full. */
-int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, int K, int nin, int C, float* din, vdetr_stream_t stream);
+ * order, no atomics).  dcol [nout,K,C] f32, inv [K,nin] -> din [nin,C], written in full.  offset_major_rows = M > 0: the
+ * source is laid out [K,M,C] instead (row inv[k][i] of slice k): the per-offset compacted row lists, where slice k holds only
+ * the sites that HAVE a neighbour through offset k. */
+int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, int K, int nin, int C, int offset_major_rows, float* din,
+                            vdetr_stream_t stream);
 
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */

@@ -47,7 +47,7 @@ def test_transposed_map_bit_exact():
 
 
 @pytest.mark.parametrize("n,cin,cout,ks", [(800, 3, 16, 3), (2500, 64, 64, 3), (600, 32, 48, 1), (900, 8, 4, 2)])
-def test_sparse_conv_forward_backward(n, cin, cout, ks):
+def test_sparse_conv_forward_backward(n, cin, cout, ks, monkeypatch):
     from vdetr_amd import sparse_ops as S
     torch.manual_seed(n)
     coords = _cloud(n, n + 1, extent=14)
@@ -62,12 +62,24 @@ def test_sparse_conv_forward_backward(n, cin, cout, ks):
     fr, wr = f.double().requires_grad_(True), w.double().requires_grad_(True)
     ref = O.sparse_conv(fr, wr, nbr)
     (ref * g.double()).sum().backward()
-    fd, wd = f.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    got = S.sparse_conv(fd, wd, nbr.to(DEV), inv.to(DEV))
-    (got * g.to(DEV)).sum().backward()
-    for name, a, b in (("out", got, ref), ("dfeats", fd.grad, fr.grad), ("dweight", wd.grad, wr.grad)):
-        scale = float(b.abs().max())
-        assert float((a.detach().cpu().double() - b.detach()).abs().max()) <= 1e-4 * scale + 1e-6, name
+    for path in ("plan", "sorted", "im2col"):  # compacted per-offset row lists (two groupings) and the dense im2col GEMM
+        fd, wd = f.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        if path != "im2col":
+            plan = S.ConvPlan(nbr.to(DEV), keys.shape[0])
+            assert plan.pairs == int((nbr >= 0).sum()) and plan.padded_pairs >= plan.pairs
+            if path == "sorted":  # force the count-sorted grouping (normally chosen for wide layers only)
+                monkeypatch.setattr(S.ConvPlan, "SORTED_MIN_CHANNELS", 0)
+                assert sum(g["n"] * g["M"] for g in plan.grouping("sorted")) <= plan.padded_pairs or ks < 3
+            got = S.sparse_conv(fd, wd, nbr.to(DEV), inv.to(DEV), plan)
+            monkeypatch.undo()
+        else:
+            pad = (-cin) % 4
+            got = S._SparseConvFn.apply(torch.nn.functional.pad(fd, (0, pad)).contiguous(), torch.nn.functional.pad(wd, (0, 0, 0, pad)),
+                                        nbr.to(DEV), inv.to(DEV))
+        (got * g.to(DEV)).sum().backward()
+        for name, a, b in (("out", got, ref), ("dfeats", fd.grad, fr.grad), ("dweight", wd.grad, wr.grad)):
+            scale = float(b.abs().max())
+            assert float((a.detach().cpu().double() - b.detach()).abs().max()) <= 1e-4 * scale + 1e-6, (path, name)
     # gather kernels alone: exact copies / fixed-order sums
     col = S.gather_cols(torch.nn.functional.pad(f, (0, (-cin) % 4)).to(DEV).contiguous(), nbr.to(DEV))
     assert torch.equal(col.cpu(), O.gather_cols(torch.nn.functional.pad(f, (0, (-cin) % 4)), nbr))
@@ -107,7 +119,7 @@ def test_backbone_gpu_equals_cpu_oracle(monkeypatch):
         mp.setattr(S, "kernel_map", lambda ik, ok, off: O.kernel_map(ik, ok, off))
         mp.setattr(S, "inverse_map", lambda nbr, nin: O.inverse_map(nbr, nin))
         mp.setattr(S, "gather_cols", lambda f, nbr: O.gather_cols(f, nbr).contiguous())
-        mp.setattr(S, "gather_sum", lambda d, inv: O.gather_sum(d, inv))
+        mp.setattr(S, "gather_sum", lambda d, inv, offset_major=False: O.gather_sum(d.permute(1, 0, 2) if offset_major else d, inv))
         outs_c, y_c, loss_c = run(net, up, "cpu")
     for og, oc in zip(outs_g + [y_g], outs_c + [y_c]):
         assert torch.equal(og.keys.cpu(), oc.keys)
@@ -144,3 +156,13 @@ def test_full_model_with_sparse_backbone_runs():
     loss.backward()
     assert float(model.pre_encoder.conv1.kernel.grad.abs().sum()) > 0
     assert float(model.out_block_0[0].kernel.grad.abs().sum()) > 0
+    # geometry built ahead of time (coordinates only) gives the same backbone output and leaves the BN statistics alone
+    rm = model.pre_encoder.norm1.bn.running_mean.clone()
+    geo = model.prepare_geometry(inputs)
+    assert torch.equal(rm, model.pre_encoder.norm1.bn.running_mean) and model.training
+    model.eval()
+    with torch.no_grad():
+        a = model.backbone_forward(inputs)
+        b = model.backbone_forward(dict(inputs, geometry=geo))
+    for (xa, fa), (xb, fb) in zip(a, b):
+        assert torch.equal(xa, xb) and torch.equal(fa, fb)

@@ -71,7 +71,7 @@ def cpu_sparse_ops(monkeypatch):
     monkeypatch.setattr(S, "kernel_map", lambda ik, ok, off: O.kernel_map(ik, ok, off))
     monkeypatch.setattr(S, "inverse_map", lambda nbr, nin: O.inverse_map(nbr, nin))
     monkeypatch.setattr(S, "gather_cols", lambda f, nbr: O.gather_cols(f, nbr).contiguous())
-    monkeypatch.setattr(S, "gather_sum", lambda d, inv: O.gather_sum(d, inv))
+    monkeypatch.setattr(S, "gather_sum", lambda d, inv, offset_major=False: O.gather_sum(d.permute(1, 0, 2) if offset_major else d, inv))
     return S
 
 

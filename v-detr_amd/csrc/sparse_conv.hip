@@ -14,7 +14,8 @@
 //   vdetr_sp_kernel_map_i32   nbr[k][u]  = row of the input site at out_key[u] + offset[k], or -1         (geometry only:
 //   vdetr_sp_inverse_map_i32  inv[k][i]  = the output u that reads input i through offset k, or -1         once per scene)
 //   vdetr_sp_gather_cols_f32  col[u][k][:] = in[nbr[k][u]][:] or 0     (the im2col operand of ONE library GEMM per layer)
-//   vdetr_sp_gather_sum_f32   din[i][:] = sum_k dcol[inv[k][i]][k][:]  (its adjoint as a GATHER: no float atomics)
+//   vdetr_sp_gather_sum_f32   din[i][:] = sum_k dcol[inv[k][i]][k][:]  (its adjoint as a GATHER: no float atomics; the source
+//                             may also be offset-major [K][M][C]: the compacted per-offset row lists of sparse_ops.ConvPlan)
 // The two feature kernels are pure HBM streams of C-float rows (256 B - 2 KB each): float4 per lane, rows x offsets over
 // the whole chip.
 #include "common.h"
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const float* __restrict_
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K; ++k) {  // fixed order: deterministic sums
       const int u = map[(size_t)k * nrows + i];
-      if (u >= 0) acc += reinterpret_cast<const f32x4*>(src)[((size_t)u * K + k) * C4 + c4];
+      // nmap = 0: src is [rows][K][C] (the im2col layout); nmap = M > 0: src is offset-major [K][M][C]
+      if (u >= 0) acc += reinterpret_cast<const f32x4*>(src)[(nmap ? (size_t)k * nmap + u : (size_t)u * K + k) * C4 + c4];
     }
     reinterpret_cast<f32x4*>(dst)[t] = acc;
   }
@@ -129,14 +131,14 @@ extern "C" int vdetr_sp_gather_cols_f32(const float* in, const int32_t* nbr, int
   return check_launch("sp_gather_cols");
 }
 
-extern "C" int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, int K, int nin, int C, float* din,
-                                       vdetr_stream_t stream) {
-  VDETR_REQUIRE(K > 0 && nin >= 0 && C > 0, "sp_gather_sum: bad size (K=%d nin=%d C=%d)", K, nin, C);
+extern "C" int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, int K, int nin, int C, int offset_major_rows,
+                                       float* din, vdetr_stream_t stream) {
+  VDETR_REQUIRE(K > 0 && nin >= 0 && C > 0 && offset_major_rows >= 0, "sp_gather_sum: bad size (K=%d nin=%d C=%d)", K, nin, C);
   VDETR_REQUIRE(C % 4 == 0, "sp_gather_sum: C=%d must be a multiple of 4 (float4 rows)", C);
   if (nin == 0) return VDETR_OK;
   VDETR_REQUIRE(dcol && inv && din, "sp_gather_sum: null pointer");
   const long long total = (long long)nin * (C / 4);
   hipLaunchKernelGGL((sp_gather_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcol,
-                     inv, K, nin, 0, C / 4, din);
+                     inv, K, nin, offset_major_rows, C / 4, din);
   return check_launch("sp_gather_sum");
 }

@@ -36,6 +36,16 @@ class CoordinateManager:
         self.keys = {}    # tensor_stride -> canonical sorted int64 keys of that stride
         self.maps = {}    # (in key set, out key set, strides, kernel_size, transposed) -> (nbr [K,Nout], inv [K,Nin])
 
+    def insert_points(self, coordinates):
+        """raw integer coordinates [N,4] -> the sites of tensor stride 1 (+ ``unique_index``: the input row kept per site:
+        the first occurrence in input order; MinkowskiEngine: RANDOM_SUBSAMPLE)"""
+        keys_in = S.pack_keys(coordinates)
+        keys, inverse = torch.unique(keys_in, return_inverse=True)
+        first = torch.full((keys.shape[0],), keys_in.shape[0], dtype=torch.int64, device=keys.device)
+        first.scatter_reduce_(0, inverse, torch.arange(keys_in.shape[0], device=keys.device), reduce="amin")
+        self.keys[1] = keys
+        self.unique_index = first
+
     @staticmethod
     def _strided_keys(keys, new_ts):
         c = S.unpack_keys(keys).to(torch.int64)
@@ -68,8 +78,10 @@ class CoordinateManager:
             # out_stride of the input (coarse) site u reads v - offset * out_stride
             offsets = (reg * in_ts if not transposed else -reg * out_ts).to(self.device)
             nbr = S.kernel_map(in_keys, out_keys, offsets)
-            self.maps[key] = (nbr, S.inverse_map(nbr, in_keys.shape[0]), in_keys, out_keys)  # key tensors kept alive
-        return self.maps[key][:2]
+            inv = S.inverse_map(nbr, in_keys.shape[0])
+            plan = None if S._IM2COL else S.ConvPlan(nbr, in_keys.shape[0])
+            self.maps[key] = (nbr, inv, plan, in_keys, out_keys)  # key tensors kept alive
+        return self.maps[key][:3]
 
 
 class SparseTensor:
@@ -78,15 +90,9 @@ class SparseTensor:
     def __init__(self, features, coordinates=None, tensor_stride=1, coordinate_manager=None, keys=None):
         if coordinate_manager is None:
             assert coordinates is not None and tensor_stride == 1
-            keys_in = S.pack_keys(coordinates)
-            keys, inverse = torch.unique(keys_in, return_inverse=True)
-            # one feature row per site: the first occurrence in input order (MinkowskiEngine: RANDOM_SUBSAMPLE)
-            first = torch.full((keys.shape[0],), keys_in.shape[0], dtype=torch.int64, device=keys.device)
-            first.scatter_reduce_(0, inverse, torch.arange(keys_in.shape[0], device=keys.device), reduce="amin")
-            features = features[first]
             coordinate_manager = CoordinateManager(features.device)
-            coordinate_manager.keys[1] = keys
-            self.unique_index = first
+            coordinate_manager.insert_points(coordinates)
+            features = features[coordinate_manager.unique_index]  # one row per site, in site (key) order
         self.F = features
         self.tensor_stride = tensor_stride
         self.coordinate_manager = coordinate_manager
@@ -153,8 +159,8 @@ class MinkowskiConvolution(nn.Module):
             out_keys = cm.keys[out_ts]
         else:
             out_keys = x.keys if out_ts == ts else cm.strided(x.keys, ts, out_ts)
-        nbr, inv = cm.kernel_map(x.keys, out_keys, ts, out_ts, self.kernel_size, self.transposed)
-        f = S.sparse_conv(x.F, w, nbr, inv)
+        nbr, inv, plan = cm.kernel_map(x.keys, out_keys, ts, out_ts, self.kernel_size, self.transposed)
+        f = S.sparse_conv(x.F, w, nbr, inv, plan)
         if self.bias is not None:
             f = f + self.bias
         return SparseTensor(f, tensor_stride=out_ts, coordinate_manager=cm, keys=out_keys)

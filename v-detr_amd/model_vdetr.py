@@ -129,7 +129,13 @@ class ModelVDETR(nn.Module):
         else:
             data = [(p[:, :3] / self.voxel_size, p[:, :3]) for p in clouds]
         coordinates, features = ME.batch_sparse_collate(data)
-        x = ME.SparseTensor(features.contiguous(), coordinates=coordinates)
+        # the coordinate manager (sites per stride, kernel maps, compacted row lists) depends on the point COORDINATES only:
+        # like the FPS indices it may be built ahead of time (``prepare_geometry``) and handed in as inputs["geometry"]
+        geometry = inputs.get("geometry")
+        if geometry is None:
+            x = ME.SparseTensor(features.contiguous(), coordinates=coordinates)
+        else:
+            x = ME.SparseTensor(features[geometry.unique_index].contiguous(), coordinate_manager=geometry)
         stages = self.pre_encoder(x)
         x = stages[-1]
         out = None
@@ -143,6 +149,24 @@ class ModelVDETR(nn.Module):
             if i == self.layer_idx:
                 out = getattr(self, f"out_block_{i}")(x)
         return [(c.to(out.F.dtype) * self.voxel_size, f) for c, f in out.decomposed()]
+
+    @torch.no_grad()
+    def prepare_geometry(self, inputs):
+        """Everything of the backbone that depends on the point coordinates only — voxel sites of every tensor stride, the
+        kernel maps of every layer shape and their compacted row lists (sparse_ops.ConvPlan) — as a coordinate manager to
+        pass as ``inputs["geometry"]``.  A training loop can run this for the NEXT scene (data loader / side stream) while
+        the current one trains; the maps themselves are filled in by one feature-free forward pass."""
+        clouds = inputs["point_clouds"]
+        coordinates, _ = ME.batch_sparse_collate([(p[:, :3] / self.voxel_size, p[:, :0]) for p in clouds])
+        cm = ME.CoordinateManager(clouds[0].device)
+        cm.insert_points(coordinates)
+        was_training = self.training
+        self.eval()  # the dry run must not touch the BatchNorm statistics
+        try:
+            self.backbone_forward(dict(inputs, geometry=cm))
+        finally:
+            self.train(was_training)
+        return cm
 
     def _scenes(self, inputs):
         return self.backbone_forward(inputs) if self.sparse_backbone else self.pre_encoder(inputs)

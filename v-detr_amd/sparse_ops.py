@@ -7,6 +7,7 @@ are geometry / HBM-stream kernels; the contraction itself is ONE library GEMM pe
 (``col [N, K*Cin] @ W [K*Cin, Cout]``), its two gradients two more.  No CPU path: every entry point raises on CPU tensors.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -68,15 +69,18 @@ def gather_cols(feats, nbr):
     return col
 
 
-def gather_sum(dcol, inv):
-    """din [Nin, C] = sum_k dcol[inv[k, i], k] (the adjoint of ``gather_cols``, as a gather)."""
+def gather_sum(dcol, inv, offset_major=False):
+    """din [Nin, C] = sum_k dcol[inv[k, i], k] (the adjoint of ``gather_cols``, as a gather).  ``offset_major``: dcol is
+    [K, M, C] (slice k holds the compacted rows of offset k) instead of [Nout, K, C]."""
     L.require_gpu(dcol, "dcol")
     L.require_float(dcol, "dcol")
     L.require_contiguous(dcol, "dcol")
     K, nin = inv.shape
     C = dcol.shape[2]
+    M = dcol.shape[1] if offset_major else 0
+    assert dcol.shape[0 if offset_major else 1] == K
     din = torch.empty((nin, C), dtype=torch.float32, device=dcol.device)
-    L.check(L.lib().vdetr_sp_gather_sum_f32(L.ptr(dcol), L.ptr(inv), K, nin, C, L.ptr(din), L.stream_ptr()), "sp_gather_sum")
+    L.check(L.lib().vdetr_sp_gather_sum_f32(L.ptr(dcol), L.ptr(inv), K, nin, C, M, L.ptr(din), L.stream_ptr()), "sp_gather_sum")
     return din
 
 
@@ -105,11 +109,161 @@ class _SparseConvFn(Function):
         return dfeats, dw, None, None
 
 
-def sparse_conv(feats, weight, nbr, inv):
-    """feats [Nin, Cin] (any Cin: padded to a multiple of 4 here), weight [K, Cin, Cout], nbr [K, Nout], inv [K, Nin]."""
+class ConvPlan:
+    """Geometry of one sparse convolution, compacted per kernel offset (built once per scene and layer shape, no gradients).
+
+    On indoor scans a site has 3-7 of its 27 neighbours, so the im2col operand of ``_SparseConvFn`` is ~85 % zeros.  The
+    plan keeps, for every kernel offset k, only the n_k (output, input) pairs that exist; offsets with similar n_k form a
+    GROUP whose lists are padded to the group's longest (M) so that a group is ONE batched GEMM  [Kg, M, Cin] x [Kg, Cin, Cout]:
+      src  [Kg, M]    input row of pair j of offset k        (-1 padding)
+      rows [Kg, M]    output row of that pair
+      slot [Kg, Nout] pair index j of output u in offset k   (-1: u has no neighbour through k)
+      islot[Kg, Nin]  pair index j of input i in offset k
+    forward  out[u]  = sum_k (A[k] W[k])[slot[k][u]]   with A[k][j] = in[src[k][j]]       (gather, bmm, gather-sum)
+    backward din[i]  = sum_k (dP[k] W[k]^T)[islot[k][i]], dW[k] = A[k]^T dP[k], dP[k][j] = dout[rows[k][j]].
+    Both reductions are gathers in a fixed order: deterministic, no atomics.  The centre offset of a stride-1 layer is the
+    identity map: no gather at all."""
+
+    SORTED_MIN_CHANNELS = 128 * 128  # Cin * Cout from which gathering a group's weights costs less than its padding
+    SORTED_SPLIT = 1.3               # hit counts within a count-sorted group differ by at most this factor
+    SORTED_MAX_GROUPS = 6
+
+    def __init__(self, nbr, nin):
+        K, nout = nbr.shape
+        self.nin, self.nout, self.K = nin, nout, K
+        self.nbr = nbr
+        self.counts = (nbr >= 0).sum(1).tolist()  # geometry phase: one sync per plan
+        self.pairs = int(sum(self.counts))
+        self.ident = None  # the centre offset of a stride-1 layer maps every site to itself: a plain GEMM, no gather
+        if nin == nout and K % 2 == 1 and self.counts[K // 2] == nout:
+            if bool((nbr[K // 2] == torch.arange(nin, dtype=torch.int32, device=nbr.device)).all()):
+                self.ident = K // 2
+        self._groups = {}
+        self.groups = self.grouping("ranges")
+        self.padded_pairs = sum(g["n"] * g["M"] for g in self.groups)
+
+    def grouping(self, kind):
+        """"ranges": groups are CONTIGUOUS offset ranges, a group's weights are the view W[k0:k1] (no copy of the parameter,
+        no scatter of its gradient) — the identity offset on its own, the ranges before / after it as one batched GEMM each.
+        "sorted": offsets sorted by hit count and cut wherever the count drops by SORTED_SPLIT: ~1.15x padding instead of
+        ~1.6x, at the price of an index_select of W per group (worth it for wide layers)."""
+        if kind not in self._groups:
+            K, counts, ident = self.K, self.counts, self.ident
+            sets = []
+            if kind == "ranges":
+                for k0, k1 in ([(0, K)] if ident is None else [(0, ident), (ident + 1, K)]):
+                    ks = [k for k in range(k0, k1)]
+                    if ks and max(counts[k] for k in ks) > 0:
+                        sets.append(ks)
+            else:
+                order = sorted((k for k in range(K) if counts[k] > 0 and k != ident), key=lambda k: -counts[k])
+                while order:
+                    top = counts[order[0]]
+                    ks = [k for k in order if counts[k] * self.SORTED_SPLIT >= top] if len(sets) < self.SORTED_MAX_GROUPS - 1 else order
+                    order = [k for k in order if k not in ks]
+                    sets.append(sorted(ks))
+            groups = [self._build(ks) for ks in sets]
+            if ident is not None:
+                groups.insert(1 if kind == "ranges" and len(groups) > 1 else 0,
+                              {"ks": [ident], "k0": ident, "k1": ident + 1, "n": 1, "identity": True, "M": self.nout})
+            self._groups[kind] = groups
+        return self._groups[kind]
+
+    def _build(self, ks):
+        nbr, dev = self.nbr, self.nbr.device
+        contiguous = ks == list(range(ks[0], ks[-1] + 1))
+        sel = nbr[ks[0]:ks[-1] + 1] if contiguous else nbr[torch.tensor(ks, dtype=torch.int64, device=dev)]
+        M = max(self.counts[k] for k in ks)
+        v = sel >= 0
+        slot = torch.where(v, v.cumsum(1, dtype=torch.int32) - 1, torch.full_like(sel, -1))
+        kloc, u = torch.nonzero(v, as_tuple=True)
+        j = slot[kloc, u].long()
+        i = sel[kloc, u]
+        rows = torch.full((len(ks), M), -1, dtype=torch.int32, device=dev)
+        src = torch.full((len(ks), M), -1, dtype=torch.int32, device=dev)
+        islot = torch.full((len(ks), self.nin), -1, dtype=torch.int32, device=dev)
+        rows[kloc, j] = u.int()
+        src[kloc, j] = i
+        islot[kloc, i.long()] = j.int()
+        return {"ks": ks, "k0": ks[0] if contiguous else None, "k1": ks[-1] + 1 if contiguous else None, "n": len(ks),
+                "kidx": None if contiguous else torch.tensor(ks, dtype=torch.int64, device=dev), "identity": False, "M": M,
+                "src": src, "rows": rows, "slot": slot.contiguous(), "islot": islot}
+
+    def select(self, cin, cout):
+        return self.grouping("sorted" if cin * cout >= self.SORTED_MIN_CHANNELS and not _RANGES_ONLY else "ranges")
+
+
+def _group_weight(weight, g):
+    return weight[g["k0"]:g["k1"]] if g["k0"] is not None else weight.index_select(0, g["kidx"])
+
+
+class _PlannedConvFn(Function):
+    """out [Nout, Cout] = sum_k in[nbr[k]] @ W[k] through a ConvPlan (see there)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, plan):
+        groups = plan.select(weight.shape[1], weight.shape[2])
+        out, saved = None, []
+        for g in groups:
+            w = _group_weight(weight, g)
+            if g["identity"]:
+                part, a3 = feats @ w[0], feats
+            else:
+                kg, M = g["src"].shape
+                a3 = gather_cols(feats, g["src"].view(1, kg * M)).view(kg, M, feats.shape[1])
+                part = gather_sum(torch.bmm(a3, w), g["slot"], offset_major=True)
+            saved.append(a3)
+            out = part if out is None else out.add_(part)
+        if out is None:
+            out = feats.new_zeros((plan.nout, weight.shape[2]))
+        ctx.plan, ctx.groups = plan, groups
+        ctx.save_for_backward(weight, *saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        weight, *saved = ctx.saved_tensors
+        plan = ctx.plan
+        dout = dout.contiguous()
+        need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dfeats = None
+        dw = torch.zeros_like(weight) if need_w else None
+        for g, a3 in zip(ctx.groups, saved):
+            w = _group_weight(weight, g)
+            if g["identity"]:
+                if need_w:
+                    torch.mm(a3.t(), dout, out=dw[g["k0"]])
+                part = dout @ w[0].t() if need_f else None
+            else:
+                kg, M = g["rows"].shape
+                dp = gather_cols(dout, g["rows"].view(1, kg * M)).view(kg, M, dout.shape[1])
+                if need_w:
+                    if g["k0"] is not None:
+                        torch.bmm(a3.transpose(1, 2), dp, out=dw[g["k0"]:g["k1"]])
+                    else:
+                        dw.index_copy_(0, g["kidx"], torch.bmm(a3.transpose(1, 2), dp))
+                part = gather_sum(torch.bmm(dp, w.transpose(1, 2)), g["islot"], offset_major=True) if need_f else None
+            if need_f:
+                dfeats = part if dfeats is None else dfeats.add_(part)
+        if need_f and dfeats is None:
+            dfeats = dout.new_zeros((plan.nin, weight.shape[1]))
+        return dfeats, dw, None
+
+
+_RANGES_ONLY = os.environ.get("VDETR_SP_RANGES_ONLY", "0") == "1"  # A/B switch: never use the count-sorted grouping
+_IM2COL = os.environ.get("VDETR_SP_IM2COL", "0") == "1"  # A/B switch: one dense im2col GEMM per layer instead of the plan
+
+
+def sparse_conv(feats, weight, nbr, inv, plan=None):
+    """feats [Nin, Cin] (any Cin: padded to a multiple of 4 here), weight [K, Cin, Cout], nbr [K, Nout], inv [K, Nin];
+    ``plan``: the ConvPlan of (nbr, Nin) if the caller caches it (the coordinate manager does)."""
     cin = feats.shape[1]
     pad = (-cin) % 4
     if pad:
         feats = torch.nn.functional.pad(feats, (0, pad))
         weight = torch.nn.functional.pad(weight, (0, 0, 0, pad))
-    return _SparseConvFn.apply(feats.contiguous(), weight, nbr, inv)
+    if _IM2COL:
+        return _SparseConvFn.apply(feats.contiguous(), weight, nbr, inv)
+    if plan is None:
+        plan = ConvPlan(nbr, feats.shape[0])
+    return _PlannedConvFn.apply(feats.contiguous(), weight, plan)
