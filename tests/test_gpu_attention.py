@@ -114,7 +114,8 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
             assert_close(o, r.detach().numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
-def test_box_backward_kernel_equals_general_kernel(monkeypatch):
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant):
     """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
     where every wave of every workgroup is busy (the size at which a packed-math code-generation problem once showed):
     P~ and dS bit-identical (same element-wise code), table gradient within the fixed-point resolution, three times."""
@@ -134,7 +135,7 @@ def test_box_backward_kernel_equals_general_kernel(monkeypatch):
 
     monkeypatch.setenv("VDETR_BWD_BOX", "0")
     ref = run()
-    monkeypatch.setenv("VDETR_BWD_BOX", "1")
+    monkeypatch.setenv("VDETR_BWD_BOX", variant)  # 1: attn_bwd_box.hip, 2: attn_bwd_box2.hip
     for rep in range(3):
         got = run()
         for name, r, o in zip(("dq", "dk", "dv"), ref, got):

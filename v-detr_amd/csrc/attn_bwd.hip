@@ -20,7 +20,8 @@
 namespace vdetr {
 
 int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
-int launch_attn_bwd_box(const AttnParams& P, int grid, hipStream_t st);  // attn_bwd_box.hip
+int launch_attn_bwd_box(const AttnParams& P, int grid, hipStream_t st);   // attn_bwd_box.hip
+int launch_attn_bwd_box2(const AttnParams& P, int grid, hipStream_t st);  // attn_bwd_box2.hip
 
 constexpr int kBwdThreads = 1024;
 
@@ -760,10 +761,10 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
   }
   // axis-aligned boxes (no rotation operand, table edge 10, dynamic distribution): the box kernel is launched next to the
   // general one over the same grid / partial-table layout, and the device decides which of the two does the work
-  // opt-in (VDETR_BWD_BOX=1): measured 465 us against 406 us for the general kernel at C2 size; read per
-  // call because the parity test runs both kernels in one process
+  // VDETR_BWD_BOX: 2 (default) attn_bwd_box2.hip, 355 us at C2 size; 1 attn_bwd_box.hip, 465 us; 0 the general kernel
+  // only, 406 us.  Read per call: the parity test runs the kernels side by side in one process.
   const char* box_var = getenv("VDETR_BWD_BOX");
-  const int box_env = box_var ? atoi(box_var) : 0;
+  const int box_env = box_var ? atoi(box_var) : 2;
   const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && P.T == 10;
   P.box_path = box ? 1 : 0;
   if (mm) {
@@ -779,7 +780,7 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     else e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st);
     if (e) return e;
     if (box)
-      if (int e2 = launch_attn_bwd_box(P, grid, st)) return e2;
+      if (int e2 = box_env == 2 ? launch_attn_bwd_box2(P, grid, st) : launch_attn_bwd_box(P, grid, st)) return e2;
   } else {
     const size_t lds = dtable ? (size_t)table_floats * sizeof(float) : 16;
     if (variant == 0) {
