@@ -89,6 +89,21 @@ def main():
                               "groups": [(g["n"], g["M"]) for g in plan_.groups],
                               "sorted_padded": sum(g["n"] * g["M"] for g in plan_.grouping("sorted")),
                               "sorted_groups": [(g["n"], g["M"]) for g in plan_.grouping("sorted")]}))
+    if "--torch-profile" in sys.argv:  # per-kernel device time of 3 steady-state backbone steps
+        for _ in range(4):
+            backbone_step()
+        torch.cuda.synchronize()
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(3):
+                backbone_step()
+            torch.cuda.synchronize()
+        rows = sorted(prof.key_averages(), key=lambda r: -r.device_time_total)
+        tot = sum(r.device_time_total for r in rows)
+        print(f"# 3 backbone steps: {tot / 3e3:.2f} ms device time per step, {sum(r.count for r in rows) // 3} launches per step")
+        for r in rows[:32]:
+            print(f"{r.device_time_total / tot * 100:6.2f}% {r.count // 3:5d}/step {r.device_time_total / 3e3:8.3f} ms/step {r.device_time_total / max(r.count, 1):8.1f} us  {r.key[:110]}")
+        return
     if "--backbone-only" in sys.argv:  # for rocprofv3 --kernel-trace: 3 warm-up + 5 steps of the backbone alone
         print(json.dumps({"backbone_fwd_bwd_ms": timed(backbone_step)}))
         return

@@ -199,7 +199,12 @@ class ModelVDETR(nn.Module):
         return pointnet2_utils.furthest_point_sample_varlen([s[0].contiguous() for s in scenes], self.npoint)
 
     def run_encoder(self, inputs):
-        """Backbone output -> FPS to ``npoint`` tokens per scene (model_vdetr.py:279-326)."""
+        """Backbone output -> FPS to ``npoint`` tokens per scene (model_vdetr.py:279-326).  A caller that already holds
+        the sampled tokens (a training loop that runs the variable-size backbone eagerly and the fixed-size rest as a
+        captured hipGraph: bench.BackboneTrainer) hands them in as inputs["enc_xyz"] [B,m,3], ["enc_features"] [m,B,C],
+        ["enc_inds"] [B,m]."""
+        if "enc_features" in inputs:
+            return inputs["enc_xyz"], inputs["enc_features"], inputs.get("enc_inds")
         scenes = self._scenes(inputs)
         if not self.random_fps and len(scenes) <= 32:
             # point-major tables as the backbone hands them over, scenes of any sizes: ONE FPS launch (a workgroup per
