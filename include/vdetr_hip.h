@@ -529,6 +529,21 @@ int vdetr_sp_gather_cols_f32(const float* in, const int32_t* nbr, int K, int nou
  * the sites that HAVE a neighbour through offset k. */
 int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, int K, int nin, int C, int offset_major_rows, float* din,
                             vdetr_stream_t stream);
+/* offset_major_rows < 0: `inv` holds ABSOLUTE rows of a flat source [P,C] (the pair lists below). */
+
+/* Fused pair-list products (fp32 matrix cores, nothing padded, no gathered operand in memory).  A layer's geometry is the
+ * list of its (input row, output row) pairs sorted by kernel offset; `tiles` [ntiles,3] i32 = (offset k, first pair, pair
+ * count <= 128) cuts the list into 128-pair tiles that never straddle two offsets.
+ *   y[p][:] = x[arow[p]][:] * W[k(p)]              transposed = 0: x [.,cin], y [P,cout]  (forward: arow = input rows)
+ *   y[p][:] = x[arow[p]][:] * W[k(p)]^T            transposed = 1: x [.,cout], y [P,cin]  (input gradient: arow = output rows)
+ * w [K,cin,cout] f32 as MinkowskiConvolution.kernel stores it; the contraction width must be a multiple of 16. */
+int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, const float* w, const int32_t* tiles, int ntiles, int cin,
+                            int cout, int transposed, float* y, vdetr_stream_t stream);
+/* Weight gradient over the pair list: partials[slot] [cin,cout] = sum over the chunk's pairs of x[pin[p]]^T dy[pout[p]];
+ * `chunks` [nchunks,4] i32 = (offset k, first pair, pair count, partial slot).  A segment may be cut into several chunks
+ * (split-K for narrow layers); the caller sums the partial slots of an offset in a fixed order. */
+int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const int32_t* pin, const int32_t* pout, const int32_t* chunks,
+                             int nchunks, int cin, int cout, float* partials, vdetr_stream_t stream);
 
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */

@@ -72,6 +72,22 @@ def sparse_conv(feats, weight, nbr):
     return torch.einsum("nkc,kcd->nd", col, weight)
 
 
+def pairs_gemm(x, arow, weight, seg, transposed):
+    """restatement of vdetr_sp_pairs_gemm_f32: y[p] = x[arow[p]] @ W[k(p)] (or its transpose), k(p) from the segment table"""
+    K = weight.shape[0]
+    kidx = torch.repeat_interleave(torch.arange(K), torch.tensor([seg[k + 1] - seg[k] for k in range(K)]))
+    w = weight.transpose(1, 2) if transposed else weight
+    return torch.einsum("pc,pcd->pd", x[arow.long()], w[kidx])
+
+
+def pairs_wgrad(x, dy, pin, pout, seg, K):
+    out = []
+    for k in range(K):
+        a, b = seg[k], seg[k + 1]
+        out.append(x[pin[a:b].long()].t() @ dy[pout[a:b].long()])
+    return torch.stack(out)
+
+
 def region_offsets(kernel_size):
     r = range(-(kernel_size // 2), kernel_size // 2 + 1) if kernel_size % 2 else range(kernel_size)
     return np.array([(x, y, z) for z in r for y in r for x in r], dtype=np.int32)

@@ -11,6 +11,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _oracle_gather_sum(d, inv, offset_major=False, flat=False):
+    if flat:  # rows of a flat [P, C] source: present it as [P, K, C] with the row repeated along K
+        return O.gather_sum(d[:, None, :].expand(-1, inv.shape[0], -1), inv)
+    return O.gather_sum(d.permute(1, 0, 2) if offset_major else d, inv)
+
+
 def _cloud(n, seed, batch=2, extent=40, ts=1):
     rng = np.random.default_rng(seed)
     c = np.concatenate((rng.integers(0, batch, (n, 1)), rng.integers(-extent, extent, (n, 3)) * ts), 1)
@@ -46,7 +52,7 @@ def test_transposed_map_bit_exact():
     assert bool(((got >= 0).sum(0) == 1).all())
 
 
-@pytest.mark.parametrize("n,cin,cout,ks", [(800, 3, 16, 3), (2500, 64, 64, 3), (600, 32, 48, 1), (900, 8, 4, 2)])
+@pytest.mark.parametrize("n,cin,cout,ks", [(800, 3, 16, 3), (2500, 64, 64, 3), (600, 32, 48, 1), (900, 8, 4, 2), (1500, 128, 192, 3)])
 def test_sparse_conv_forward_backward(n, cin, cout, ks, monkeypatch):
     from vdetr_amd import sparse_ops as S
     torch.manual_seed(n)
@@ -62,9 +68,13 @@ def test_sparse_conv_forward_backward(n, cin, cout, ks, monkeypatch):
     fr, wr = f.double().requires_grad_(True), w.double().requires_grad_(True)
     ref = O.sparse_conv(fr, wr, nbr)
     (ref * g.double()).sum().backward()
-    for path in ("plan", "sorted", "im2col"):  # compacted per-offset row lists (two groupings) and the dense im2col GEMM
-        fd, wd = f.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-        if path != "im2col":
+    for path in ("pairs", "plan", "sorted", "im2col"):  # fused pair-list kernels (default), batched library GEMMs over
+        fd, wd = f.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)  # compacted row lists (two groupings), im2col
+        if path == "pairs":
+            pp = S.PairPlan(nbr.to(DEV), keys.shape[0])
+            assert pp.P == int((nbr >= 0).sum()) and pp.seg[-1] == pp.P
+            got = S.sparse_conv(fd, wd, nbr.to(DEV), inv.to(DEV), pp)
+        elif path != "im2col":
             plan = S.ConvPlan(nbr.to(DEV), keys.shape[0])
             assert plan.pairs == int((nbr >= 0).sum()) and plan.padded_pairs >= plan.pairs
             if path == "sorted":  # force the count-sorted grouping (normally chosen for wide layers only)
@@ -119,7 +129,9 @@ def test_backbone_gpu_equals_cpu_oracle(monkeypatch):
         mp.setattr(S, "kernel_map", lambda ik, ok, off: O.kernel_map(ik, ok, off))
         mp.setattr(S, "inverse_map", lambda nbr, nin: O.inverse_map(nbr, nin))
         mp.setattr(S, "gather_cols", lambda f, nbr: O.gather_cols(f, nbr).contiguous())
-        mp.setattr(S, "gather_sum", lambda d, inv, offset_major=False: O.gather_sum(d.permute(1, 0, 2) if offset_major else d, inv))
+        mp.setattr(S, "gather_sum", _oracle_gather_sum)
+        mp.setattr(S, "pairs_gemm", lambda x, arow, w, plan, tr: O.pairs_gemm(x, arow, w, plan.seg, tr))
+        mp.setattr(S, "pairs_wgrad", lambda x, dy, plan, cin, cout: O.pairs_wgrad(x, dy, plan.pin, plan.pout, plan.seg, plan.K))
         outs_c, y_c, loss_c = run(net, up, "cpu")
     for og, oc in zip(outs_g + [y_g], outs_c + [y_c]):
         assert torch.equal(og.keys.cpu(), oc.keys)

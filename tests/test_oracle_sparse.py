@@ -7,6 +7,12 @@ import torch
 from oracle import sparse_oracle as O
 
 
+def _oracle_gather_sum(d, inv, offset_major=False, flat=False):
+    if flat:  # rows of a flat [P, C] source: present it as [P, K, C] with the row repeated along K
+        return O.gather_sum(d[:, None, :].expand(-1, inv.shape[0], -1), inv)
+    return O.gather_sum(d.permute(1, 0, 2) if offset_major else d, inv)
+
+
 def _cloud(n, seed, batch=2, extent=12, ts=1):
     rng = np.random.default_rng(seed)
     c = np.concatenate((rng.integers(0, batch, (n, 1)), rng.integers(-extent, extent, (n, 3)) * ts), 1)
@@ -71,7 +77,9 @@ def cpu_sparse_ops(monkeypatch):
     monkeypatch.setattr(S, "kernel_map", lambda ik, ok, off: O.kernel_map(ik, ok, off))
     monkeypatch.setattr(S, "inverse_map", lambda nbr, nin: O.inverse_map(nbr, nin))
     monkeypatch.setattr(S, "gather_cols", lambda f, nbr: O.gather_cols(f, nbr).contiguous())
-    monkeypatch.setattr(S, "gather_sum", lambda d, inv, offset_major=False: O.gather_sum(d.permute(1, 0, 2) if offset_major else d, inv))
+    monkeypatch.setattr(S, "gather_sum", _oracle_gather_sum)
+    monkeypatch.setattr(S, "pairs_gemm", lambda x, arow, w, plan, tr: O.pairs_gemm(x, arow, w, plan.seg, tr))
+    monkeypatch.setattr(S, "pairs_wgrad", lambda x, dy, plan, cin, cout: O.pairs_wgrad(x, dy, plan.pin, plan.pout, plan.seg, plan.K))
     return S
 
 

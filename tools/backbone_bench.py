@@ -37,9 +37,7 @@ def main():
     nbr, _, plan4 = x.coordinate_manager.kernel_map(stages[0].keys, stages[0].keys, 4, 4, 3, False)
     print(json.dumps({"points": npts, "voxels_per_stride": dict(sorted(counts.items())),
                       "mean_neighbours_of_27_at_stride_4": float((nbr >= 0).float().sum(0).mean()),
-                      "plan_stride_4": None if plan4 is None else {"groups": [(g["n"], g["M"]) for g in plan4.groups],
-                                                                   "pairs": plan4.pairs, "padded_pairs": plan4.padded_pairs,
-                                                                   "dense_pairs": 27 * nbr.shape[1]}}))
+                      "pairs_stride_4": None if plan4 is None else plan4.pairs, "dense_pairs_stride_4": 27 * nbr.shape[1]}))
 
     def timed(fn, reps=5, warm=3):
         ts = []
@@ -85,10 +83,7 @@ def main():
     for key, (nbr_, inv_, plan_, ik, ok) in inputs["geometry"].maps.items():
         if plan_ is not None:
             print(json.dumps({"map": f"stride {key[2]}->{key[3]} k{key[4]}{' T' if key[5] else ''}", "nin": plan_.nin, "nout": plan_.nout,
-                              "pairs": plan_.pairs, "padded": plan_.padded_pairs, "dense": plan_.K * plan_.nout,
-                              "groups": [(g["n"], g["M"]) for g in plan_.groups],
-                              "sorted_padded": sum(g["n"] * g["M"] for g in plan_.grouping("sorted")),
-                              "sorted_groups": [(g["n"], g["M"]) for g in plan_.grouping("sorted")]}))
+                              "pairs": plan_.pairs, "dense": plan_.K * plan_.nout}))
     if "--torch-profile" in sys.argv:  # per-kernel device time of 3 steady-state backbone steps
         for _ in range(4):
             backbone_step()

@@ -201,6 +201,8 @@ _SIGNATURES = {
     "vdetr_sp_inverse_map_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_sp_gather_cols_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_sp_gather_sum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_sp_pairs_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_sp_pairs_wgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

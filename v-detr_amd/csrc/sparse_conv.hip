@@ -87,8 +87,10 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const float* __restrict_
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K; ++k) {  // fixed order: deterministic sums
       const int u = map[(size_t)k * nrows + i];
-      // nmap = 0: src is [rows][K][C] (the im2col layout); nmap = M > 0: src is offset-major [K][M][C]
-      if (u >= 0) acc += reinterpret_cast<const f32x4*>(src)[(nmap ? (size_t)k * nmap + u : (size_t)u * K + k) * C4 + c4];
+      // nmap = 0: src is [rows][K][C] (the im2col layout); nmap = M > 0: src is offset-major [K][M][C]; nmap < 0: the map
+      // holds absolute rows of a flat [P][C] source (the pair lists)
+      if (u >= 0)
+        acc += reinterpret_cast<const f32x4*>(src)[(nmap > 0 ? (size_t)k * nmap + u : nmap < 0 ? (size_t)u : (size_t)u * K + k) * C4 + c4];
     }
     reinterpret_cast<f32x4*>(dst)[t] = acc;
   }
@@ -133,7 +135,7 @@ extern "C" int vdetr_sp_gather_cols_f32(const float* in, const int32_t* nbr, int
 
 extern "C" int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, int K, int nin, int C, int offset_major_rows,
                                        float* din, vdetr_stream_t stream) {
-  VDETR_REQUIRE(K > 0 && nin >= 0 && C > 0 && offset_major_rows >= 0, "sp_gather_sum: bad size (K=%d nin=%d C=%d)", K, nin, C);
+  VDETR_REQUIRE(K > 0 && nin >= 0 && C > 0, "sp_gather_sum: bad size (K=%d nin=%d C=%d)", K, nin, C);
   VDETR_REQUIRE(C % 4 == 0, "sp_gather_sum: C=%d must be a multiple of 4 (float4 rows)", C);
   if (nin == 0) return VDETR_OK;
   VDETR_REQUIRE(dcol && inv && din, "sp_gather_sum: null pointer");
@@ -141,4 +143,246 @@ extern "C" int vdetr_sp_gather_sum_f32(const float* dcol, const int32_t* inv, in
   hipLaunchKernelGGL((sp_gather_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcol,
                      inv, K, nin, offset_major_rows, C / 4, din);
   return check_launch("sp_gather_sum");
+}
+
+// ====================================================================================================================
+// Fused pair-list convolution (fp32 matrix cores).  The geometry of a layer is a list of (input row, output row) PAIRS
+// sorted by kernel offset (segment k = the pairs of offset k); the three products of a layer run over that list directly:
+//   vdetr_sp_pairs_gemm_f32    Y[p][:] = X[arow[p]][:] * W[k(p)]        (forward: X = features, W[k] as stored [Cin, Cout];
+//                                                                      input gradient: X = dout, W[k] transposed)
+//   vdetr_sp_pairs_wgrad_f32   dW[k]   = sum_{p in segment k} X[pin[p]]^T dY[pout[p]]
+// followed by the fixed-order gather-sum over the (<= K) pairs of a row (vdetr_sp_gather_sum_f32, flat mode).  Nothing is
+// padded to a common length and no gathered operand is ever written to memory: rows are gathered straight into the MFMA
+// A operand.  Tile = 64 pairs x 64 channels per 256-thread workgroup, v_mfma_f32_16x16x4_f32 (exact fp32), contraction
+// index permuted (k = 4 g + s) so that a lane's four A values are one float4.
+// ====================================================================================================================
+namespace vdetr {
+
+// Workgroup tile = (WR x RT x 16) pairs x (WC x CT x 16) channels: the 4 waves form a WR x WC grid, a wave owns RT x CT
+// MFMA tiles.  <2,2,4,4>: 128 x 128 (16 accumulators per wave; per contraction step of 16 a wave loads 4 float4 of A and
+// 4 float4 / 16 dwords of B for 64 MFMAs), <4,1,2,4>: 128 x 64 for layers with <= 64 output channels.
+// tiles [ntiles][3] = (offset k, first pair, pair count <= 128)
+constexpr int kSpTileM = 128;
+
+template <bool TRANS, int WR, int WC, int RT, int CT>
+__global__ __launch_bounds__(256) void sp_pairs_gemm_kernel(const float* __restrict__ X, const int* __restrict__ arow,
+                                                           const float* __restrict__ W, const int* __restrict__ tiles,
+                                                           int CA, int CB, int wk_stride, float* __restrict__ Y) {
+  // CA = contraction width (row length of X), CB = output width.  W[k] is [Cin][Cout] row-major; !TRANS: CA = Cin, CB = Cout,
+  // B[c][n] = W[k][c][n];  TRANS: CA = Cout, CB = Cin, B[c][n] = W[k][n][c].
+  static_assert(WR * WC == 4 && WR * RT * 16 == kSpTileM, "tile shape");
+  constexpr int TN = WC * CT * 16;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int wr = w / WC, wc = w % WC;
+  const int k = tiles[blockIdx.x * 3], p0 = tiles[blockIdx.x * 3 + 1], cnt = tiles[blockIdx.x * 3 + 2];
+  const int n0 = blockIdx.y * TN + wc * CT * 16;
+  const int r0 = wr * RT * 16;
+  // No bounds tests inside the loop: rows past the tile's count read the tile's first pair and columns past CB read column
+  // CB - 1 (valid memory); what they produce is never stored.
+  const float* xrow[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int rl = r0 + 16 * i + c;
+    xrow[i] = X + (size_t)arow[p0 + (rl < cnt ? rl : 0)] * CA + 4 * g;
+  }
+  const float* wk = W + (size_t)k * wk_stride;
+  const float* wcol[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int n = min(n0 + 16 * t + c, CB - 1);
+    wcol[t] = TRANS ? wk + (size_t)n * CA + 4 * g : wk + (size_t)(4 * g) * CB + n;
+  }
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < CA; kc += 16) {
+    f32x4 a[RT];
+    float b[CT][4];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const f32x4*>(xrow[i] + kc);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      if (TRANS) {  // W[k][n][kc + 4g .. +3]: one float4
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wcol[t] + kc);
+        b[t][0] = v[0]; b[t][1] = v[1]; b[t][2] = v[2]; b[t][3] = v[3];
+      } else {      // W[k][kc + 4g + s][n]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[t][s] = wcol[t][(size_t)(kc + s) * CB];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[t][s], acc[i][t], 0, 0, 0);
+  }
+  // accumulator: lane (g, c) holds rows 4 g + r, column c of every 16 x 16 tile
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 16 * i + 4 * g + r;
+      if (row >= cnt) continue;
+      float* y = Y + (size_t)(p0 + row) * CB + n0 + c;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+        if (n0 + 16 * t + c < CB) y[16 * t] = acc[i][t][r];
+    }
+}
+
+// dW[k][ci][co] (+ split partials): workgroup = (segment chunk, ci tile, co tile); the 4 waves form a WR x WC grid over the
+// (ci, co) tile, a wave owns RT x CT MFMA tiles: <4,1,1,4> = 64 x 64, <2,2,4,4> = 128 x 128 (wide layers: half the
+// re-gathering of rows per channel tile, 8 LDS reads per 16 MFMAs instead of 5 per 4).
+// The chunk's pairs are walked SB at a time: the 256 threads stage the gathered X rows (TCI channels) and dY rows (TCO
+// channels) in LDS (float4 per thread, rows of >= 256 B: coalesced), double-buffered, and the waves read their MFMA operands
+// from there (a pair is one k-slot: A[m = ci][k] = X[pair][ci], B[k][n = co] = dY[pair][co]).
+template <int WR, int WC, int RT, int CT, int SB>
+__global__ __launch_bounds__(256) void sp_pairs_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                            const int* __restrict__ pin, const int* __restrict__ pout,
+                                                            const int* __restrict__ chunks, int Cin, int Cout,
+                                                            float* __restrict__ part) {
+  constexpr int TCI = WR * RT * 16, TCO = WC * CT * 16;
+  constexpr int LX = TCI + 16, LY = TCO + 16;  // row strides = 16 mod 32 floats: the 32 lanes of a read hit 32 different banks
+  constexpr int XV = SB * TCI / 4 / 256, YV = SB * TCO / 4 / 256;  // float4 per thread and stage
+  static_assert(WR * WC == 4 && XV >= 1 && YV >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) float lx[2][SB][LX], ly[2][SB][LY];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int wr = w / WC, wc = w % WC;
+  const int p0 = chunks[blockIdx.x * 4 + 1], cnt = chunks[blockIdx.x * 4 + 2], slot = chunks[blockIdx.x * 4 + 3];
+  const int ci0 = blockIdx.y * TCI, co0 = blockIdx.z * TCO;
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging roles: float4 e of the X stage = (pair e / (TCI/4), channels 4 (e % (TCI/4)) ..), e = tid + 256 v
+  // row indices are fetched TWO stages ahead of their rows (index -> row is a dependent chain of two memory latencies)
+  int ri[XV], ro[YV], ri_n[XV], ro_n[YV];
+  auto index_load = [&](int j, int (&a)[XV], int (&b)[YV]) {
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int p = j + (tid + 256 * v) / (TCI / 4);
+      a[v] = p < cnt ? pin[p0 + p] : -1;
+    }
+#pragma unroll
+    for (int v = 0; v < YV; ++v) {
+      const int p = j + (tid + 256 * v) / (TCO / 4);
+      b[v] = p < cnt ? pout[p0 + p] : -1;
+    }
+  };
+  f32x4 vx[XV], vy[YV];
+  auto row_load = [&](const int (&a)[XV], const int (&b)[YV]) {
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int col = ci0 + 4 * ((tid + 256 * v) % (TCI / 4));
+      vx[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a[v] >= 0 && col < Cin) vx[v] = *reinterpret_cast<const f32x4*>(X + (size_t)a[v] * Cin + col);
+    }
+#pragma unroll
+    for (int v = 0; v < YV; ++v) {
+      const int col = co0 + 4 * ((tid + 256 * v) % (TCO / 4));
+      vy[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (b[v] >= 0 && col < Cout) vy[v] = *reinterpret_cast<const f32x4*>(dY + (size_t)b[v] * Cout + col);
+    }
+  };
+  index_load(0, ri, ro);
+  index_load(SB, ri_n, ro_n);
+  row_load(ri, ro);
+  int buf = 0;
+  for (int j = 0; j < cnt; j += SB) {
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int e = tid + 256 * v;
+      *reinterpret_cast<f32x4*>(&lx[buf][e / (TCI / 4)][4 * (e % (TCI / 4))]) = vx[v];
+    }
+#pragma unroll
+    for (int v = 0; v < YV; ++v) {
+      const int e = tid + 256 * v;
+      *reinterpret_cast<f32x4*>(&ly[buf][e / (TCO / 4)][4 * (e % (TCO / 4))]) = vy[v];
+    }
+    __syncthreads();
+    if (j + SB < cnt) {  // next stage's rows in flight while this one is multiplied; the stage after next: its indices
+#pragma unroll
+      for (int v = 0; v < XV; ++v) ri[v] = ri_n[v];
+#pragma unroll
+      for (int v = 0; v < YV; ++v) ro[v] = ro_n[v];
+      row_load(ri, ro);
+      index_load(j + 2 * SB, ri_n, ro_n);
+    }
+#pragma unroll
+    for (int s = 0; s < SB / 4; ++s) {
+      float a[RT], b[CT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) a[i] = lx[buf][4 * s + g][(wr * RT + i) * 16 + c];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) b[t] = ly[buf][4 * s + g][(wc * CT + t) * 16 + c];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t], acc[i][t], 0, 0, 0);
+    }
+    buf ^= 1;  // the other buffer was last read before the previous barrier
+  }
+  float* dst = part + (size_t)slot * Cin * Cout;
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = ci0 + (wr * RT + i) * 16 + 4 * g + r;
+      if (row >= Cin) continue;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int co = co0 + (wc * CT + t) * 16 + c;
+        if (co < Cout) dst[(size_t)row * Cout + co] = acc[i][t][r];
+      }
+    }
+}
+
+}  // namespace vdetr
+
+extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, const float* w, const int32_t* tiles, int ntiles,
+                                       int cin, int cout, int transposed, float* y, vdetr_stream_t stream) {
+  VDETR_REQUIRE(ntiles >= 0 && cin > 0 && cout > 0, "sp_pairs_gemm: bad size");
+  if (ntiles == 0) return VDETR_OK;
+  VDETR_REQUIRE(x && arow && w && tiles && y, "sp_pairs_gemm: null pointer");
+  const int CA = transposed ? cout : cin, CB = transposed ? cin : cout;
+  VDETR_REQUIRE(CA % 16 == 0, "sp_pairs_gemm: contraction width %d must be a multiple of 16", CA);
+  hipStream_t st = (hipStream_t)stream;
+  if (CB <= 64) {  // narrow output: 128 x 64 tiles
+    dim3 grid(ntiles, ceil_div(CB, 64));
+    if (transposed)
+      hipLaunchKernelGGL((sp_pairs_gemm_kernel<true, 4, 1, 2, 4>), grid, dim3(256), 0, st, x, arow, w, tiles, CA, CB, cin * cout, y);
+    else
+      hipLaunchKernelGGL((sp_pairs_gemm_kernel<false, 4, 1, 2, 4>), grid, dim3(256), 0, st, x, arow, w, tiles, CA, CB, cin * cout, y);
+  } else {
+    dim3 grid(ntiles, ceil_div(CB, 128));
+    if (transposed)
+      hipLaunchKernelGGL((sp_pairs_gemm_kernel<true, 2, 2, 4, 4>), grid, dim3(256), 0, st, x, arow, w, tiles, CA, CB, cin * cout, y);
+    else
+      hipLaunchKernelGGL((sp_pairs_gemm_kernel<false, 2, 2, 4, 4>), grid, dim3(256), 0, st, x, arow, w, tiles, CA, CB, cin * cout, y);
+  }
+  return check_launch("sp_pairs_gemm");
+}
+
+extern "C" int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const int32_t* pin, const int32_t* pout,
+                                        const int32_t* chunks, int nchunks, int cin, int cout, float* partials,
+                                        vdetr_stream_t stream) {
+  VDETR_REQUIRE(nchunks >= 0 && cin > 0 && cout > 0, "sp_pairs_wgrad: bad size");
+  if (nchunks == 0) return VDETR_OK;
+  VDETR_REQUIRE(x && dy && pin && pout && chunks && partials, "sp_pairs_wgrad: null pointer");
+  VDETR_REQUIRE(ceil_div(cout, 64) <= 65535 && ceil_div(cin, 64) <= 65535, "sp_pairs_wgrad: too many channel tiles");
+  VDETR_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "sp_pairs_wgrad: channel counts must be multiples of 4 (float4 rows)");
+  if (cin >= 128 && cout >= 128) {
+    dim3 grid(nchunks, ceil_div(cin, 128), ceil_div(cout, 128));
+    hipLaunchKernelGGL((sp_pairs_wgrad_kernel<2, 2, 4, 4, 16>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin, pout, chunks,
+                       cin, cout, partials);
+  } else {
+    dim3 grid(nchunks, ceil_div(cin, 64), ceil_div(cout, 64));
+    hipLaunchKernelGGL((sp_pairs_wgrad_kernel<4, 1, 1, 4, 32>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin, pout, chunks,
+                       cin, cout, partials);
+  }
+  return check_launch("sp_pairs_wgrad");
 }

@@ -79,7 +79,7 @@ class CoordinateManager:
             offsets = (reg * in_ts if not transposed else -reg * out_ts).to(self.device)
             nbr = S.kernel_map(in_keys, out_keys, offsets)
             inv = S.inverse_map(nbr, in_keys.shape[0])
-            plan = None if S._IM2COL else S.ConvPlan(nbr, in_keys.shape[0])
+            plan = None if S._IM2COL else (S.PairPlan if S._MODE == "pairs" else S.ConvPlan)(nbr, in_keys.shape[0])
             self.maps[key] = (nbr, inv, plan, in_keys, out_keys)  # key tensors kept alive
         return self.maps[key][:3]
 

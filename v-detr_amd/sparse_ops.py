@@ -69,16 +69,17 @@ def gather_cols(feats, nbr):
     return col
 
 
-def gather_sum(dcol, inv, offset_major=False):
+def gather_sum(dcol, inv, offset_major=False, flat=False):
     """din [Nin, C] = sum_k dcol[inv[k, i], k] (the adjoint of ``gather_cols``, as a gather).  ``offset_major``: dcol is
-    [K, M, C] (slice k holds the compacted rows of offset k) instead of [Nout, K, C]."""
+    [K, M, C] (slice k holds the compacted rows of offset k) instead of [Nout, K, C]; ``flat``: dcol is [P, C] and ``inv``
+    holds absolute rows (the pair lists of PairPlan)."""
     L.require_gpu(dcol, "dcol")
     L.require_float(dcol, "dcol")
     L.require_contiguous(dcol, "dcol")
     K, nin = inv.shape
-    C = dcol.shape[2]
-    M = dcol.shape[1] if offset_major else 0
-    assert dcol.shape[0 if offset_major else 1] == K
+    C = dcol.shape[-1]
+    M = -1 if flat else (dcol.shape[1] if offset_major else 0)
+    assert flat or dcol.shape[0 if offset_major else 1] == K
     din = torch.empty((nin, C), dtype=torch.float32, device=dcol.device)
     L.check(L.lib().vdetr_sp_gather_sum_f32(L.ptr(dcol), L.ptr(inv), K, nin, C, M, L.ptr(din), L.stream_ptr()), "sp_gather_sum")
     return din
@@ -251,13 +252,132 @@ class _PlannedConvFn(Function):
 
 
 _RANGES_ONLY = os.environ.get("VDETR_SP_RANGES_ONLY", "0") == "1"  # A/B switch: never use the count-sorted grouping
-_IM2COL = os.environ.get("VDETR_SP_IM2COL", "0") == "1"  # A/B switch: one dense im2col GEMM per layer instead of the plan
+class PairPlan:
+    """Geometry of one sparse convolution as a PAIR LIST sorted by kernel offset (built once per scene and layer shape):
+      pin [P], pout [P]   input / output row of pair p; the pairs of offset k are the segment seg[k] .. seg[k+1]
+      slot [K, Nout]      pair (absolute index) through which output u reads offset k, -1 if none
+      islot [K, Nin]      pair through which input i is read with offset k
+      tiles [T, 3]        (k, first pair, count <= 128): the 128-pair tiles of vdetr_sp_pairs_gemm_f32
+    Nothing is padded: the fused kernels (csrc/sparse_conv.hip) gather rows straight into the matrix-core operands."""
+
+    def __init__(self, nbr, nin):
+        K, nout = nbr.shape
+        dev = nbr.device
+        self.K, self.nin, self.nout = K, nin, nout
+        valid = nbr >= 0
+        counts = valid.sum(1).tolist()  # geometry phase: one sync per plan
+        self.counts = counts
+        pk, pout = torch.nonzero(valid, as_tuple=True)      # sorted by (k, u)
+        self.P = int(pk.shape[0])
+        self.pairs = self.P
+        self.pout = pout.int().contiguous()
+        self.pin = nbr[pk, pout].contiguous()
+        idx = torch.arange(self.P, dtype=torch.int32, device=dev)
+        self.slot = torch.full((K, nout), -1, dtype=torch.int32, device=dev)
+        self.slot[pk, pout] = idx
+        self.islot = torch.full((K, nin), -1, dtype=torch.int32, device=dev)
+        self.islot[pk, self.pin.long()] = idx
+        seg, tiles = [0], []
+        for k in range(K):
+            for s0 in range(0, counts[k], 128):
+                tiles.append((k, seg[-1] + s0, min(128, counts[k] - s0)))
+            seg.append(seg[-1] + counts[k])
+        self.seg = seg
+        self.ntiles = len(tiles)
+        self.tiles = torch.tensor(tiles if tiles else [(0, 0, 0)], dtype=torch.int32, device=dev)
+        self._chunks = {}
+
+    def wgrad_chunks(self, cin, cout):
+        """(chunks [K*S, 4] i32, S): every offset's segment cut into S chunks (multiples of 4 pairs; S chosen so that the
+        launch has >= ~512 workgroups), chunk (k, s) writes partial slot k * S + s"""
+        t = 128 if (cin >= 128 and cout >= 128) else 64  # channel tile of vdetr_sp_pairs_wgrad_f32
+        key = (-(-cin // t)) * (-(-cout // t))
+        if key not in self._chunks:
+            S = max(1, min(32, -(-512 // (self.K * key))))
+            rows = []
+            for k in range(self.K):
+                n = self.counts[k]
+                per = -(-(-(-n // S)) // 4) * 4 if n else 0
+                for s in range(S):
+                    a = min(n, s * per)
+                    rows.append((k, self.seg[k] + a, max(0, min(n, (s + 1) * per) - a), k * S + s))
+            self._chunks[key] = (torch.tensor(rows, dtype=torch.int32, device=self.pin.device), S)
+        return self._chunks[key]
+
+
+def pairs_gemm(x, arow, weight, plan, transposed):
+    """y [P, Cout] = x[arow[p]] @ W[k(p)]  (transposed: y [P, Cin] = x[arow[p]] @ W[k(p)]^T)"""
+    L.require_gpu(x, "x")
+    L.require_float(x, "x")
+    L.require_contiguous(x, "x")
+    K, cin, cout = weight.shape
+    y = torch.empty((plan.P, cin if transposed else cout), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vdetr_sp_pairs_gemm_f32(L.ptr(x), L.ptr(arow), L.ptr(weight), L.ptr(plan.tiles), plan.ntiles, cin, cout,
+                                            1 if transposed else 0, L.ptr(y), L.stream_ptr()), "sp_pairs_gemm")
+    return y
+
+
+def pairs_wgrad(x, dy, plan, cin, cout):
+    """dW [K, Cin, Cout] = sum over the pairs of offset k of x[pin[p]]^T dy[pout[p]]"""
+    L.require_gpu(x, "x")
+    L.require_contiguous(x, "x")
+    L.require_contiguous(dy, "dy")
+    chunks, S = plan.wgrad_chunks(cin, cout)
+    part = torch.empty((plan.K, S, cin, cout), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vdetr_sp_pairs_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(plan.pin), L.ptr(plan.pout), L.ptr(chunks),
+                                             chunks.shape[0], cin, cout, L.ptr(part), L.stream_ptr()), "sp_pairs_wgrad")
+    return part[:, 0] if S == 1 else part.sum(1)
+
+
+class _PairsConvFn(Function):
+    """out [Nout, Cout] = sum_k in[nbr[k]] @ W[k] through a PairPlan and the fused matrix-core kernels."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, plan):
+        weight = weight.contiguous()
+        if plan.P == 0:  # no site of the layer has a neighbour (a 1x1x1 stride-2 layer on a tiny cloud)
+            out = feats.new_zeros((plan.nout, weight.shape[2]))
+        else:
+            out = gather_sum(pairs_gemm(feats, plan.pin, weight, plan, False), plan.slot, flat=True)
+        ctx.plan = plan
+        ctx.save_for_backward(feats, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, weight = ctx.saved_tensors
+        plan = ctx.plan
+        dout = dout.contiguous()
+        K, cin, cout = weight.shape
+        dfeats = dw = None
+        if plan.P == 0:
+            return (feats.new_zeros(feats.shape) if ctx.needs_input_grad[0] else None,
+                    torch.zeros_like(weight) if ctx.needs_input_grad[1] else None, None)
+        if ctx.needs_input_grad[0]:
+            dfeats = gather_sum(pairs_gemm(dout, plan.pout, weight, plan, True), plan.islot, flat=True)
+        if ctx.needs_input_grad[1]:
+            dw = pairs_wgrad(feats, dout, plan, cin, cout)
+        return dfeats, dw, None
+
+
+_MODE = os.environ.get("VDETR_SP_MODE", "pairs")  # pairs (fused kernels) | plan (batched library GEMMs) | im2col
+_IM2COL = _MODE == "im2col" or os.environ.get("VDETR_SP_IM2COL", "0") == "1"  # A/B switch: one dense im2col GEMM per layer instead of the plan
 
 
 def sparse_conv(feats, weight, nbr, inv, plan=None):
     """feats [Nin, Cin] (any Cin: padded to a multiple of 4 here), weight [K, Cin, Cout], nbr [K, Nout], inv [K, Nin];
     ``plan``: the ConvPlan of (nbr, Nin) if the caller caches it (the coordinate manager does)."""
-    cin = feats.shape[1]
+    cin, cout = feats.shape[1], weight.shape[2]
+    if isinstance(plan, PairPlan) or (plan is None and _MODE == "pairs"):
+        if plan is None:
+            plan = PairPlan(nbr, feats.shape[0])
+        # the fused kernels contract over multiples of 16 channels on either side (forward: Cin, input gradient: Cout)
+        pi, po = (-cin) % 16, (-cout) % 16
+        if pi or po:
+            feats = torch.nn.functional.pad(feats, (0, pi))
+            weight = torch.nn.functional.pad(weight, (0, po, 0, pi))
+        out = _PairsConvFn.apply(feats.contiguous(), weight, plan)
+        return out[:, :cout] if po else out
     pad = (-cin) % 4
     if pad:
         feats = torch.nn.functional.pad(feats, (0, pad))
