@@ -545,6 +545,29 @@ int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, const float* w,
 int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const int32_t* pin, const int32_t* pout, const int32_t* chunks,
                              int nchunks, int cin, int cout, float* partials, vdetr_stream_t stream);
 
+/* BatchNorm (+ residual) (+ activation) over the point-major feature table [N,C] of a sparse tensor: ME.MinkowskiBatchNorm
+ * followed by MinkowskiReLU / MinkowskiELU and, in the residual blocks, `out += residual` in front of the ReLU
+ * (models/mink_resnet.py:38-84 via MinkowskiEngine's BasicBlock; models/model_vdetr.py:141-176).
+ *   y = act((x - mean) * invstd * gamma + beta + residual),  act: 0 none, 1 ReLU, 2 ELU(alpha = 1)
+ * training != 0: batch statistics (biased variance for the normalisation; running statistics updated with `momentum` and the
+ * unbiased variance, num_batches_tracked += 1, as nn.BatchNorm1d); 0: running statistics.  save_mean / save_invstd [C] are
+ * written for the backward.  workspace: vdetr_sp_bn_workspace_bytes(N, C), shared by forward and backward.  C % 4 == 0. */
+typedef struct vdetr_spbn_desc {
+  int32_t N, C, act, training;
+  float eps, momentum;
+  const float *x, *gamma, *beta, *residual; /* gamma / beta / residual may be NULL */
+  float *running_mean, *running_var;        /* may be NULL in training mode */
+  int64_t* num_batches_tracked;             /* optional */
+  float *y, *save_mean, *save_invstd;
+  void* workspace;
+} vdetr_spbn_desc;
+size_t vdetr_sp_bn_workspace_bytes(int N, int C);
+int vdetr_sp_bn_act_fwd_f32(const vdetr_spbn_desc* d, vdetr_stream_t stream);
+/* dx [N,C] (or NULL), dresidual [N,C] (or NULL: = dy * act'), dgamma / dbeta [C] (or NULL) from dy [N,C], the forward's x, y,
+ * save_mean, save_invstd */
+int vdetr_sp_bn_act_bwd_f32(const vdetr_spbn_desc* d, const float* dy, float* dx, float* dresidual, float* dgamma, float* dbeta,
+                            vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

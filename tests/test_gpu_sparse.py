@@ -97,6 +97,45 @@ def test_sparse_conv_forward_backward(n, cin, cout, ks, monkeypatch):
     torch.testing.assert_close(S.gather_sum(dc.to(DEV), inv.to(DEV)).cpu(), O.gather_sum(dc, inv), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,c,act,res,training", [(5000, 64, "relu", True, True), (777, 256, "elu", False, True),
+                                                  (130, 16, None, True, True), (3000, 512, "relu", False, False), (1, 8, "relu", False, True)])
+def test_fused_batchnorm_activation(n, c, act, res, training):
+    """csrc/sp_bn.hip against nn.BatchNorm1d + residual + activation in float64: outputs, all gradients, running statistics"""
+    from vdetr_amd import sparse_ops as S
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c) * 3 + torch.linspace(-50, 50, c)  # large per-channel means: E[x^2] - mean^2 would cancel
+    r = torch.randn(n, c) if res else None
+    g = torch.randn(n, c)
+    bn_ref = torch.nn.BatchNorm1d(c).double()
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.uniform_(-1, 1)
+        bn_ref.running_mean.uniform_(-1, 1); bn_ref.running_var.uniform_(0.5, 2)
+    bn_gpu = torch.nn.BatchNorm1d(c).to(DEV)
+    bn_gpu.load_state_dict({k: v.float() for k, v in bn_ref.state_dict().items()})
+    bn_ref.train(training); bn_gpu.train(training)
+    fn = {"relu": torch.relu, "elu": torch.nn.functional.elu, None: lambda t: t}[act]
+
+    xr = x.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    yr = fn(bn_ref(xr) + (rr if res else 0)) if n > 1 or not training else None
+    if yr is None:
+        return  # nn.BatchNorm1d refuses a single row in training mode; the kernel handles it (variance 0)
+    (yr * g.double()).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    rg = r.to(DEV).requires_grad_(True) if res else None
+    yg = S.bn_act(xg, bn_gpu, act, rg)
+    (yg * g.to(DEV)).sum().backward()
+    checks = [("y", yg, yr), ("dx", xg.grad, xr.grad), ("dgamma", bn_gpu.weight.grad, bn_ref.weight.grad),
+              ("dbeta", bn_gpu.bias.grad, bn_ref.bias.grad), ("running_mean", bn_gpu.running_mean, bn_ref.running_mean),
+              ("running_var", bn_gpu.running_var, bn_ref.running_var)]
+    if res:
+        checks.append(("dres", rg.grad, rr.grad))
+    for name, a, b in checks:
+        scale = float(b.detach().abs().max())
+        assert float((a.detach().cpu().double() - b.detach()).abs().max()) <= 2e-4 * scale + 1e-5, name
+    assert int(bn_gpu.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
 def test_sparse_ops_refuse_cpu_tensors():
     from vdetr_amd import sparse_ops as S
     with pytest.raises(RuntimeError, match="CPU not supported"):

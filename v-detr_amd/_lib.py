@@ -144,6 +144,14 @@ class SetLossDesc(ctypes.Structure):
                 [(n, c_void_p) for n in _LOSS_PTR])
 
 
+class SpBnDesc(ctypes.Structure):
+    """Mirror of ``vdetr_spbn_desc``."""
+
+    _fields_ = ([(n, ctypes.c_int32) for n in ("N", "C", "act", "training")] + [("eps", c_float), ("momentum", c_float)] +
+                [(n, c_void_p) for n in ("x", "gamma", "beta", "residual", "running_mean", "running_var", "num_batches_tracked",
+                                         "y", "save_mean", "save_invstd", "workspace")])
+
+
 # name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
 _SIGNATURES = {
     "vdetr_abi_version": (c_int, []),
@@ -203,6 +211,9 @@ _SIGNATURES = {
     "vdetr_sp_gather_sum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_sp_pairs_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_sp_pairs_wgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_sp_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vdetr_sp_bn_act_fwd_f32": (c_int, [ctypes.POINTER(SpBnDesc), c_void_p]),
+    "vdetr_sp_bn_act_bwd_f32": (c_int, [ctypes.POINTER(SpBnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

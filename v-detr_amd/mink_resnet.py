@@ -55,7 +55,8 @@ class MinkResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.relu(self.norm1(self.conv1(x)))
+        x = self.conv1(x)
+        x = self.norm1(x, act="relu") if isinstance(self.norm1, ME.MinkowskiBatchNorm) else self.relu(self.norm1(x))
         outs = []
         for i in range(self.num_stages):
             x = getattr(self, f"layer{i + 1}")(x)

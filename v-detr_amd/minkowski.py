@@ -182,8 +182,13 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
 
-    def forward(self, x):
-        return x._like(self.bn(x.F))
+    fused_act = None  # "elu" / "relu": the activation module that follows in an nn.Sequential is folded into this layer
+
+    def forward(self, x, act=None, residual=None):
+        act = act or self.fused_act
+        out = x._like(S.bn_act(x.F, self.bn, act, None if residual is None else residual.F))
+        out.applied_act = act
+        return out
 
 
 class MinkowskiInstanceNorm(nn.Module):
@@ -206,17 +211,25 @@ class MinkowskiInstanceNorm(nn.Module):
 
 
 class _Pointwise(nn.Module):
+    kind = None
+
     def forward(self, x):
+        if getattr(x, "applied_act", None) == self.kind:  # already applied by the fused BatchNorm in front (fuse_activations)
+            return x._like(x.F)
         return x._like(self.fn(x.F))
 
 
 class MinkowskiReLU(_Pointwise):
+    kind = "relu"
+
     def __init__(self, inplace=False):
         super().__init__()
         self.fn = nn.ReLU()
 
 
 class MinkowskiELU(_Pointwise):
+    kind = "elu"
+
     def __init__(self, alpha=1.0, inplace=False):
         super().__init__()
         self.fn = nn.ELU(alpha)
@@ -237,12 +250,9 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        residual = x
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.norm2(self.conv2(out))
-        if self.downsample is not None:
-            residual = self.downsample(x)
-        return self.relu(out + residual)
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.norm1(self.conv1(x), act="relu")
+        return self.norm2(self.conv2(out), act="relu", residual=residual)  # relu(bn(conv) + residual) in one pass
 
 
 class Bottleneck(nn.Module):
@@ -262,13 +272,23 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        residual = x
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.relu(self.norm2(self.conv2(out)))
-        out = self.norm3(self.conv3(out))
-        if self.downsample is not None:
-            residual = self.downsample(x)
-        return self.relu(out + residual)
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.norm1(self.conv1(x), act="relu")
+        out = self.norm2(self.conv2(out), act="relu")
+        return self.norm3(self.conv3(out), act="relu", residual=residual)
+
+
+def fuse_activations(module):
+    """In every nn.Sequential, fold a MinkowskiReLU / MinkowskiELU (alpha 1) that directly follows a MinkowskiBatchNorm into
+    that layer's fused kernel (the activation module stays in place — state-dict indices are unchanged — and passes
+    tensors that already carry its activation through)."""
+    for m in module.modules():
+        if isinstance(m, nn.Sequential):
+            mods = list(m)
+            for a, b in zip(mods, mods[1:]):
+                if isinstance(a, MinkowskiBatchNorm) and isinstance(b, _Pointwise) and (b.kind == "relu" or b.fn.alpha == 1.0):
+                    a.fused_act = b.kind
+    return module
 
 
 def kaiming_normal_(tensor, a=0, mode="fan_in", nonlinearity="leaky_relu"):

@@ -118,6 +118,7 @@ class ModelVDETR(nn.Module):
             if isinstance(m, ME.MinkowskiBatchNorm):
                 nn.init.constant_(m.bn.weight, 1)
                 nn.init.constant_(m.bn.bias, 0)
+        ME.fuse_activations(self)  # BatchNorm -> ELU pairs of the neck run as one fused pass
 
     def backbone_forward(self, inputs):
         """model_vdetr.py:248-280: voxelise at ``voxel_size``, MinkResNet, top-down FPN, out block -> per scene

@@ -360,6 +360,72 @@ class _PairsConvFn(Function):
         return dfeats, dw, None
 
 
+_ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
+
+
+class _SpBnActFn(Function):
+    """y = act(batch_norm(x) + residual) over a point-major table [N, C] (csrc/sp_bn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, training, momentum, eps, act):
+        L.require_gpu(x, "x")
+        L.require_float(x, "x")
+        x = x.contiguous()
+        N, C = x.shape
+        lib = L.lib()
+        d = L.SpBnDesc()
+        d.N, d.C, d.act, d.training, d.eps, d.momentum = N, C, act, 1 if training else 0, float(eps), float(momentum)
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = L.workspace(lib.vdetr_sp_bn_workspace_bytes(N, C), x.device)
+        res = residual.contiguous() if residual is not None else None
+        d.x, d.gamma, d.beta, d.residual = x.data_ptr(), L.ptr(gamma).value, L.ptr(beta).value, L.ptr(res).value
+        d.running_mean, d.running_var = L.ptr(running_mean).value, L.ptr(running_var).value
+        d.num_batches_tracked = L.ptr(nbt).value if training else None
+        d.y, d.save_mean, d.save_invstd, d.workspace = y.data_ptr(), save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr()
+        L.check(lib.vdetr_sp_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "sp_bn_act_fwd")
+        ctx.save_for_backward(x, gamma, y, save_mean, save_invstd)
+        ctx.cfg = (act, training, eps, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, y, save_mean, save_invstd = ctx.saved_tensors
+        act, training, eps, has_res = ctx.cfg
+        N, C = x.shape
+        lib = L.lib()
+        dy = dy.contiguous()
+        d = L.SpBnDesc()
+        d.N, d.C, d.act, d.training, d.eps = N, C, act, 1 if training else 0, float(eps)
+        ws = L.workspace(lib.vdetr_sp_bn_workspace_bytes(N, C), x.device)
+        d.x, d.gamma, d.y = x.data_ptr(), L.ptr(gamma).value, y.data_ptr()
+        d.save_mean, d.save_invstd, d.workspace = save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[3]) else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        L.check(lib.vdetr_sp_bn_act_bwd_f32(ctypes.byref(d), L.ptr(dy), L.ptr(dx), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta),
+                                            L.stream_ptr()), "sp_bn_act_bwd")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
+
+
+def bn_act(x, bn, act=None, residual=None):
+    """act(bn(x) + residual) for an ``nn.BatchNorm1d`` module over the rows of x [N, C]: one fused HIP pass on the GPU; any
+    other module type (SyncBatchNorm) or a CPU tensor goes through the module itself and plain torch ops."""
+    fused = x.is_cuda and type(bn) is torch.nn.BatchNorm1d and x.shape[1] % 4 == 0 and x.shape[0] > 0 and not _NO_FUSED_BN
+    if not fused:
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if act == "relu" else torch.nn.functional.elu(y) if act == "elu" else y
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _SpBnActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                            bn.num_batches_tracked if bn.track_running_stats else None, training, momentum, bn.eps, _ACT[act])
+
+
+_NO_FUSED_BN = os.environ.get("VDETR_SP_FUSED_BN", "1") == "0"  # A/B switch
 _MODE = os.environ.get("VDETR_SP_MODE", "pairs")  # pairs (fused kernels) | plan (batched library GEMMs) | im2col
 _IM2COL = _MODE == "im2col" or os.environ.get("VDETR_SP_IM2COL", "0") == "1"  # A/B switch: one dense im2col GEMM per layer instead of the plan
 
