@@ -409,18 +409,18 @@ def kernel_rooflines(cfg_name, device, reps=20):
                "achieved": flops / t_fwd / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                "frac": flops / t_fwd / 1e12 / 157.3, "traffic": None, "launch_us": t_fwd * 1e6,
                "rpe_lookups_per_s": 8.0 * pairs / t_fwd}
-    bwd_obj = {"kernel": "attn_bwd_box_kernel (softmax backward + RPE table gradient, axis-aligned boxes)", "bound": "hbm",
+    bwd_obj = {"kernel": "attn_bwd_box2_kernel (softmax backward + RPE table gradient, axis-aligned boxes)", "bound": "hbm",
                "achieved": bytes_bwd / t_bwd / 1e9, "peak": 8000.0, "unit": "GB/s",
                "frac": bytes_bwd / t_bwd / 1e9 / 8000.0, "traffic": None, "launch_us": t_bwd * 1e6,
                "rpe_scatter_per_s": 8.0 * pairs / t_bwd}
     # HBM traffic per launch measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/README.md)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
             tr = json.load(fh)
         if cfg_name == "c2":
-            fwd_obj["traffic"] = tr["attn_fwd_kernel<false,true>"]["bytes"]
-            bwd_obj["traffic"] = tr["attn_bwd_scores_rpe_mm_kernel"]["bytes"]
-            vi = tr["attn_bwd_scores_rpe_mm_kernel"].get("valu_wave_insts")
+            fwd_obj["traffic"] = tr["attn_fwd_kernel<false,true,true>"]["bytes"]
+            bwd_obj["traffic"] = tr["attn_bwd_box2_kernel"]["bytes"]
+            vi = tr["attn_bwd_box2_kernel"].get("valu_wave_insts")
             if vi:  # what actually bounds the kernel: VALU issue (1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction)
                 bwd_obj["valu_issue"] = {"wave_insts": vi, "limit_us": vi / 614.4e9 * 1e6, "frac": vi / 614.4e9 / t_bwd,
                                          "note": "SQ_INSTS_VALU per launch (offline PMC pass) / chip issue rate / launch time: "

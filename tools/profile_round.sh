@@ -5,12 +5,12 @@ tag=${1:-x}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-criterion-leg > $out/bench_eager.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-criterion-leg --no-backbone-leg > $out/bench_eager.log 2>&1
 db=$(find /tmp/rp_eager -name '*.db' | head -1); csv=$(find /tmp/rp_eager -name '*kernel_trace.csv' | head -1)
 python3 tools/rocprof_summary.py ${db:-$csv} 5 3 > $out/eager_kernel_summary.txt 2>&1
 python3 tools/kernel_bench.py c2 > $out/kernel_bench_c2.txt 2>&1
 # the step with the device criterion as its loss: kernel trace + the solver's scan counts
-rocprofv3 --kernel-trace --stats -d /tmp/rp_crit -o crit -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --loss criterion > $out/bench_criterion_eager.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/rp_crit -o crit -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-backbone-leg --loss criterion > $out/bench_criterion_eager.log 2>&1 < /dev/null
 cdb=$(find /tmp/rp_crit -name '*.db' | head -1)
 [ -n "$cdb" ] && python3 tools/rocprof_summary.py $cdb 5 3 > $out/criterion_eager_kernel_summary.txt 2>&1
 python3 tools/criterion_bench.py > $out/criterion_bench.txt 2>&1 < /dev/null
@@ -54,5 +54,9 @@ for k, cs in agg.items():
 PY
   pass=$((pass+1))
 done
+# sparse-convolution backbone: per-kernel device time of a backbone step, per-layer kernel rates, geometry
+python3 tools/backbone_bench.py 40000 --torch-profile > $out/backbone_profile.txt 2>&1 < /dev/null
+python3 tools/backbone_bench.py 40000 > $out/backbone_bench.txt 2>&1 < /dev/null
+python3 tools/spconv_bench.py > $out/spconv_bench.txt 2>&1 < /dev/null
 python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400
