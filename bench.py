@@ -669,7 +669,7 @@ def main():
             result["with_backbone"] = {
                 "ms_per_step": ms, "scenes_per_s": 1e3 / ms, "geometry_ms": bt.geometry_ms, "input_points": 40000,
                 "voxels_per_stride": bt.voxels, "backbone_parameters": sum(p.numel() for p in bt.bb_params), "loss": bloss,
-                "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP index kernels + library GEMMs, eager) -> FPS tokens -> "
+                "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP kernel maps, fused pair-list convolutions on the fp32 matrix cores, fused BatchNorm; eager) -> FPS tokens -> "
                         "decoder step (captured hipGraph) -> backbone backward -> clip + AdamW over all 79 M parameters; "
                         "geometry_ms = voxel sites, kernel maps, row lists and FPS indices built ahead of time from the coordinates"}
         finally:
