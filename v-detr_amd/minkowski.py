@@ -16,11 +16,30 @@ The ORDER of the sites of a MinkowskiEngine tensor is an implementation detail o
 against torch's dense convolutions.
 """
 import math
+import threading
 
 import torch
 import torch.nn as nn
 
 from . import sparse_ops as S
+
+
+# Geometry-only pass (ModelVDETR.prepare_geometry): convolutions build their sites / kernel maps / pair lists and hand on an
+# UNINITIALISED feature table of the right shape; every other layer is the identity.  Nothing is computed on features.
+# The switch is per THREAD: a loader thread prepares the next scene while the training thread runs the model.
+_tls = threading.local()
+
+
+def _geometry_only():
+    return getattr(_tls, "geometry_only", False)
+
+
+class geometry_only:
+    def __enter__(self):
+        self._prev, _tls.geometry_only = _geometry_only(), True
+
+    def __exit__(self, *exc):
+        _tls.geometry_only = self._prev
 
 
 def _region_offsets(kernel_size):
@@ -111,7 +130,7 @@ class SparseTensor:
 
     def __add__(self, other):
         assert self.keys is other.keys or torch.equal(self.keys, other.keys), "sparse tensors on different coordinate maps"
-        return self._like(self.F + other.F)
+        return self if _geometry_only() else self._like(self.F + other.F)
 
     def decomposed(self):
         """per batch element: (coordinates [n,3] int32, features [n,C]) — key order keeps the scenes contiguous"""
@@ -160,6 +179,9 @@ class MinkowskiConvolution(nn.Module):
         else:
             out_keys = x.keys if out_ts == ts else cm.strided(x.keys, ts, out_ts)
         nbr, inv, plan = cm.kernel_map(x.keys, out_keys, ts, out_ts, self.kernel_size, self.transposed)
+        if _geometry_only():
+            return SparseTensor(x.F.new_empty((out_keys.shape[0], self.out_channels)), tensor_stride=out_ts,
+                                coordinate_manager=cm, keys=out_keys)
         f = S.sparse_conv(x.F, w, nbr, inv, plan)
         if self.bias is not None:
             f = f + self.bias
@@ -185,6 +207,8 @@ class MinkowskiBatchNorm(nn.Module):
     fused_act = None  # "elu" / "relu": the activation module that follows in an nn.Sequential is folded into this layer
 
     def forward(self, x, act=None, residual=None):
+        if _geometry_only():
+            return x
         act = act or self.fused_act
         out = x._like(S.bn_act(x.F, self.bn, act, None if residual is None else residual.F))
         out.applied_act = act
@@ -201,6 +225,8 @@ class MinkowskiInstanceNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
+        if _geometry_only():
+            return x
         b = x.keys >> 48
         nb = int(b.max()) + 1
         cnt = torch.bincount(b, minlength=nb).clamp(min=1).to(x.F.dtype)[:, None]
@@ -214,6 +240,8 @@ class _Pointwise(nn.Module):
     kind = None
 
     def forward(self, x):
+        if _geometry_only():
+            return x
         if getattr(x, "applied_act", None) == self.kind:  # already applied by the fused BatchNorm in front (fuse_activations)
             return x._like(x.F)
         return x._like(self.fn(x.F))

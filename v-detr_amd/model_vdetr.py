@@ -156,17 +156,13 @@ class ModelVDETR(nn.Module):
         """Everything of the backbone that depends on the point coordinates only — voxel sites of every tensor stride, the
         kernel maps of every layer shape and their compacted row lists (sparse_ops.ConvPlan) — as a coordinate manager to
         pass as ``inputs["geometry"]``.  A training loop can run this for the NEXT scene (data loader / side stream) while
-        the current one trains; the maps themselves are filled in by one feature-free forward pass."""
+        the current one trains; the maps themselves are filled in by one geometry-only pass over the layers."""
         clouds = inputs["point_clouds"]
         coordinates, _ = ME.batch_sparse_collate([(p[:, :3] / self.voxel_size, p[:, :0]) for p in clouds])
         cm = ME.CoordinateManager(clouds[0].device)
         cm.insert_points(coordinates)
-        was_training = self.training
-        self.eval()  # the dry run must not touch the BatchNorm statistics
-        try:
+        with ME.geometry_only():  # the layers only register their sites / maps / pair lists: no feature arithmetic
             self.backbone_forward(dict(inputs, geometry=cm))
-        finally:
-            self.train(was_training)
         return cm
 
     def _scenes(self, inputs):
