@@ -366,6 +366,16 @@ int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry,
                    float* dst, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Z-order permutation of a scene's key points, one launch (one workgroup per scene).  Replaces the tensor expression the
+ * decoder would otherwise spend ~50 launches on in front of the cross attention (v-detr_amd/pc_util.py:morton_argsort; the
+ * reference attends in FPS order, models/vdetr_transformer.py:400-436 — attention does not depend on the key order).
+ *   xyz [B,n,3] fp32 -> codes [B,n] int32 (30-bit Morton code of the point in the scene's bounding box; may be NULL)
+ *                       order [B,n] int64 (indices sorted by (code, index); may be NULL; n <= vdetr_morton_sort_max())
+ * ---------------------------------------------------------------------------------------------- */
+int vdetr_morton_sort_max(void);
+int vdetr_morton_order_f32(const float* xyz, int B, int n, int* codes, long long* order, vdetr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Set criterion on the device (reference criterion.py).  Replaces, without a host round trip:
  *   repeat_ground_truth (criterion.py:511-600), the pairwise GIoU / centre / size matrices and the matcher's cost
  *   (criterion.py:618-631, 122-196; utils/box_util.py:441-600 with rotated_boxes=False), the nine

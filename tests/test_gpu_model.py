@@ -394,3 +394,24 @@ def test_deferred_weight_gradients_equal_inline_ones(batch):
     assert res[True].keys() == res[False].keys()
     for n, g in res[False].items():
         assert float((res[True][n] - g).abs().max()) <= 2e-4 * (float(g.abs().max()) + 1e-12), n
+
+
+@pytest.mark.parametrize("B,N", [(1, 4096), (3, 1000), (2, 1), (1, 8192), (2, 9000), (1, 77)])
+def test_morton_order_equals_the_tensor_expression(B, N):
+    """csrc/morton.hip (one launch) against pc_util.morton_codes evaluated on the CPU: same codes bit for bit, the order is the
+    stable sort of the codes; N > 8192 goes through the codes-only launch + a library sort."""
+    from vdetr_amd import pc_util
+    from vdetr_amd import _lib as L
+    g = torch.Generator().manual_seed(B * 10007 + N)
+    xyz = torch.rand(B, N, 3, generator=g) * torch.tensor([8.0, 6.0, 3.0]) + 1.0
+    xyz[:, : N // 3] = (xyz[:, : N // 3] / 0.5).floor() * 0.5  # many equal codes: the tie order matters
+    if N > 2:
+        xyz[0, 1] = xyz[0, 0]
+    ref_codes = pc_util.morton_codes(xyz)
+    ref = torch.argsort(ref_codes, dim=1, stable=True)
+    dev = xyz.cuda()
+    got = pc_util.morton_argsort(dev)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref)
+    codes = torch.empty((B, N), dtype=torch.int32, device="cuda")
+    L.check(L.lib().vdetr_morton_order_f32(L.ptr(dev), B, N, L.ptr(codes), None, L.stream_ptr()), "morton_order")
+    assert torch.equal(codes.cpu().long(), ref_codes)

@@ -196,6 +196,8 @@ _SIGNATURES = {
     "vdetr_box_point_count_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_box3d_iou_max_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),
+    "vdetr_morton_sort_max": (c_int, []),
+    "vdetr_morton_order_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vdetr_gt_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

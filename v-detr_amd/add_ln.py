@@ -56,23 +56,39 @@ class DeferredLnGrads:
         items, cls.pending = cls.pending, []
         if not items:
             return
+        # passes that share their first LayerNorm (the decoder's output norm closes all 9 stages) next to each other: their
+        # sums are then added by ONE reduction over a slice of `out` instead of one accumulation launch per pass and parameter
+        items.sort(key=lambda it: id(it[3][0]))
         n = len(items)
         dev = items[0][0].device
         cmax = max(it[2] for it in items)
-        out = torch.empty((n, 4, cmax), dtype=torch.float32, device=dev)
+        out = torch.empty((4, n, cmax), dtype=torch.float32, device=dev)
         descs = (L.AddLnReduce * n)()
         for i, (ws, nparts, C, _, two) in enumerate(items):
             d = descs[i]
             d.partials, d.nparts, d.C = ws.data_ptr(), nparts, C
-            d.d_gamma, d.d_beta = out[i, 0].data_ptr(), out[i, 1].data_ptr()
-            d.d_gamma2, d.d_beta2 = (out[i, 2].data_ptr(), out[i, 3].data_ptr()) if two else (None, None)
+            d.d_gamma, d.d_beta = out[0, i].data_ptr(), out[1, i].data_ptr()
+            d.d_gamma2, d.d_beta2 = (out[2, i].data_ptr(), out[3, i].data_ptr()) if two else (None, None)
         L.check(L.lib().vdetr_add_ln_param_reduce_batch_f32(descs, n, L.stream_ptr()), "add_ln_param_reduce_batch")
         roots, grads = [], []
         with torch.no_grad():
-            for i, (_, _, C, params, two) in enumerate(items):
-                for k, p in enumerate(params[:4 if two else 2]):
-                    if p is not None and p.requires_grad:
-                        DeferredParamGrads._deliver(p, out[i, k, :C], roots, grads)
+            i = 0
+            while i < n:
+                C, params = items[i][2], items[i][3]
+                j = i + 1
+                while j < n and items[j][3][0] is params[0] and items[j][3][1] is params[1] and items[j][2] == C:
+                    j += 1
+                first = out[0:2, i:j].sum(1) if j - i > 1 else out[0:2, i]  # [2, cmax]: d_gamma, d_beta of the shared norm
+                for k in range(2):
+                    if params[k] is not None and params[k].requires_grad:
+                        DeferredParamGrads._deliver(params[k], first[k, :C], roots, grads)
+                for m in range(i, j):
+                    if items[m][4]:
+                        for k in (2, 3):
+                            p = items[m][3][k]
+                            if p is not None and p.requires_grad:
+                                DeferredParamGrads._deliver(p, out[k, m, :C], roots, grads)
+                i = j
         if roots:
             torch.autograd.backward(roots, grads)
 

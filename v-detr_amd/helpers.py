@@ -213,10 +213,16 @@ class _Alias(torch.autograd.Function):
         t0 = ts[0]
         out = torch.empty(0, dtype=t0.dtype, device=t0.device)
         out.set_(t0.untyped_storage(), t0.storage_offset(), shape)  # contiguous alias of the parameters' memory
+        # no zero gradients for an alias nobody differentiated: with deferred weight gradients `_Linear.backward` returns None
+        # for the alias, and a materialised zero would reach every parameter through AccumulateGrad (a fill, and one add_ per
+        # parameter when DeferredParamGrads.flush delivers the real gradient: 34 launches per step at C2)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None, None) + (None,) * len(ctx.shapes)
         g = g.contiguous()
         if ctx.mode == "cat":
             parts, off = [], 0

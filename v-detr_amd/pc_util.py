@@ -71,6 +71,24 @@ def morton_argsort(xyz):
     box.  Attention is invariant to the order of its keys; the HIP kernels are not indifferent to it: neighbouring
     lanes = neighbouring keys = the same RPE table cell (LDS broadcast in the forward, wave-level aggregation of
     the table gradient in the backward)."""
+    if xyz.is_cuda:  # one launch: bounding box, codes and (up to 8192 points) the sort, csrc/morton.hip
+        from . import _lib as L
+        L.require_float(xyz, "xyz")
+        x = xyz.contiguous()
+        B, N = x.shape[0], x.shape[1]
+        lib = L.lib()
+        if N <= lib.vdetr_morton_sort_max():
+            order = torch.empty((B, N), dtype=torch.int64, device=x.device)
+            L.check(lib.vdetr_morton_order_f32(L.ptr(x), B, N, None, L.ptr(order), L.stream_ptr()), "morton_order")
+            return order
+        codes = torch.empty((B, N), dtype=torch.int32, device=x.device)
+        L.check(lib.vdetr_morton_order_f32(L.ptr(x), B, N, L.ptr(codes), None, L.stream_ptr()), "morton_order")
+        return torch.argsort(codes, dim=1, stable=True)
+    return torch.argsort(morton_codes(xyz), dim=1, stable=True)
+
+
+def morton_codes(xyz):
+    """[B,N,3] -> [B,N] int64 30-bit Morton codes as tensor expressions (host-side statement of csrc/morton.hip)"""
     lo = xyz.min(dim=1, keepdim=True)[0]
     ext = (xyz.max(dim=1, keepdim=True)[0] - lo).clamp(min=1e-6)
     q = ((xyz - lo) / ext * 1023.0).long().clamp_(0, 1023)
@@ -81,5 +99,4 @@ def morton_argsort(xyz):
         v = (v | (v << 4)) & 0x030C30C3
         return (v | (v << 2)) & 0x09249249
 
-    code = spread(q[..., 0]) | (spread(q[..., 1]) << 1) | (spread(q[..., 2]) << 2)
-    return torch.argsort(code, dim=1)
+    return spread(q[..., 0]) | (spread(q[..., 1]) << 1) | (spread(q[..., 2]) << 2)
