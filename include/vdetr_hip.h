@@ -554,6 +554,9 @@ int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, const float* w,
  * (split-K for narrow layers); the caller sums the partial slots of an offset in a fixed order. */
 int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const int32_t* pin, const int32_t* pout, const int32_t* chunks,
                              int nchunks, int cin, int cout, float* partials, vdetr_stream_t stream);
+/* dw[k][:] = sum of partials[c][:] over c in [seg[k], seg[k+1]) (seg: K+1 ints on the device; elems = Cin*Cout, a multiple of 4):
+ * the chunk partials of vdetr_sp_pairs_wgrad_f32 -> the weight gradient, in chunk order (deterministic). */
+int vdetr_sp_wgrad_reduce_f32(const float* partials, const int32_t* seg, int K, long elems, float* dw, vdetr_stream_t stream);
 
 /* BatchNorm (+ residual) (+ activation) over the point-major feature table [N,C] of a sparse tensor: ME.MinkowskiBatchNorm
  * followed by MinkowskiReLU / MinkowskiELU and, in the residual blocks, `out += residual` in front of the ReLU

@@ -15,6 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvdetr_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", f"--offload-arch={ARCH}"]
+FLAGS += os.environ.get("VDETR_EXTRA_HIPCC_FLAGS", "").split()  # probe builds (-DVDETR_SP_PROBE=1 ...); part of the fingerprint
 
 
 def sources():

@@ -18,6 +18,7 @@
 //                             may also be offset-major [K][M][C]: the compacted per-offset row lists of sparse_ops.ConvPlan)
 // The two feature kernels are pure HBM streams of C-float rows (256 B - 2 KB each): float4 per lane, rows x offsets over
 // the whole chip.
+#include <stdlib.h>
 #include "common.h"
 
 namespace vdetr {
@@ -164,8 +165,11 @@ namespace vdetr {
 // tiles [ntiles][3] = (offset k, first pair, pair count <= 128)
 constexpr int kSpTileM = 128;
 
+#ifndef VDETR_SP_WAVES
+#define VDETR_SP_WAVES 2  // waves per SIMD of the matrix-core kernels (more than 2 halves the MFMA rate)
+#endif
 template <bool TRANS, int WR, int WC, int RT, int CT>
-__global__ __launch_bounds__(256) void sp_pairs_gemm_kernel(const float* __restrict__ X, const int* __restrict__ arow,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP_WAVES))) void sp_pairs_gemm_kernel(const float* __restrict__ X, const int* __restrict__ arow,
                                                            const float* __restrict__ W, const int* __restrict__ tiles,
                                                            int CA, int CB, int wk_stride, float* __restrict__ Y) {
   // CA = contraction width (row length of X), CB = output width.  W[k] is [Cin][Cout] row-major; !TRANS: CA = Cin, CB = Cout,
@@ -197,27 +201,41 @@ __global__ __launch_bounds__(256) void sp_pairs_gemm_kernel(const float* __restr
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef VDETR_SP_PROBE
+#define VDETR_SP_PROBE 0  // measurements only.  1: operands loaded once (MFMA loop alone), 2: loads alone (folded with adds)
+#endif
   for (int kc = 0; kc < CA; kc += 16) {
     f32x4 a[RT];
     float b[CT][4];
+    const int kl = (VDETR_SP_PROBE == 1 || VDETR_SP_PROBE == 3) ? 0 : kc;
+    if (VDETR_SP_PROBE == 3) asm volatile("" ::: "memory");  // 3: the loads stay in the loop but always hit the same lines
 #pragma unroll
-    for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const f32x4*>(xrow[i] + kc);
+    for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const f32x4*>(xrow[i] + kl);
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       if (TRANS) {  // W[k][n][kc + 4g .. +3]: one float4
-        const f32x4 v = *reinterpret_cast<const f32x4*>(wcol[t] + kc);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wcol[t] + kl);
         b[t][0] = v[0]; b[t][1] = v[1]; b[t][2] = v[2]; b[t][3] = v[3];
       } else {      // W[k][kc + 4g + s][n]
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[t][s] = wcol[t][(size_t)(kc + s) * CB];
+        for (int s = 0; s < 4; ++s) b[t][s] = wcol[t][(size_t)(kl + s) * CB];
       }
     }
+#if VDETR_SP_PROBE == 2
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[i][t][s] += a[i][s] + b[t][s];
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int t = 0; t < CT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[t][s], acc[i][t], 0, 0, 0);
+#endif
   }
   // accumulator: lane (g, c) holds rows 4 g + r, column c of every 16 x 16 tile
 #pragma unroll
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(256) void sp_pairs_gemm_kernel(const float* __restr
 // channels) in LDS (float4 per thread, rows of >= 256 B: coalesced), double-buffered, and the waves read their MFMA operands
 // from there (a pair is one k-slot: A[m = ci][k] = X[pair][ci], B[k][n = co] = dY[pair][co]).
 template <int WR, int WC, int RT, int CT, int SB>
-__global__ __launch_bounds__(256) void sp_pairs_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP_WAVES))) void sp_pairs_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                             const int* __restrict__ pin, const int* __restrict__ pout,
                                                             const int* __restrict__ chunks, int Cin, int Cout,
                                                             float* __restrict__ part) {
@@ -341,6 +359,27 @@ __global__ __launch_bounds__(256) void sp_pairs_wgrad_kernel(const float* __rest
     }
 }
 
+// dW[k] = sum of the partial products of offset k's chunks (partials [seg[k], seg[k+1]) of `part`), fixed order: deterministic.
+__global__ __launch_bounds__(256) void sp_wgrad_reduce_kernel(const f32x4* __restrict__ part, const int* __restrict__ seg, long elems4,
+                                                             f32x4* __restrict__ dw) {
+  const int k = blockIdx.y;
+  const int c0 = seg[k], c1 = seg[k + 1];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < elems4; e += (long)gridDim.x * 256) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {  // four loads in flight; the additions keep the chunk order
+      const f32x4 v0 = part[(size_t)c * elems4 + e], v1 = part[(size_t)(c + 1) * elems4 + e];
+      const f32x4 v2 = part[(size_t)(c + 2) * elems4 + e], v3 = part[(size_t)(c + 3) * elems4 + e];
+      acc += v0;
+      acc += v1;
+      acc += v2;
+      acc += v3;
+    }
+    for (; c < c1; ++c) acc += part[(size_t)c * elems4 + e];
+    dw[(size_t)k * elems4 + e] = acc;
+  }
+}
+
 }  // namespace vdetr
 
 extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, const float* w, const int32_t* tiles, int ntiles,
@@ -351,6 +390,16 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
   const int CA = transposed ? cout : cin, CB = transposed ? cin : cout;
   VDETR_REQUIRE(CA % 16 == 0, "sp_pairs_gemm: contraction width %d must be a multiple of 16", CA);
   hipStream_t st = (hipStream_t)stream;
+#ifdef VDETR_SP_PADTEST
+  static const int pad = getenv("VDETR_SP_LDS_PAD") ? atoi(getenv("VDETR_SP_LDS_PAD")) : 0;  // unused LDS: caps the workgroups per CU
+  if (pad > 0) {
+    dim3 grid(ntiles, ceil_div(CB, 128));
+    auto kern = transposed ? sp_pairs_gemm_kernel<true, 2, 2, 4, 4> : sp_pairs_gemm_kernel<false, 2, 2, 4, 4>;
+    if (set_lds(kern, pad, "sp_pairs_gemm") != VDETR_OK) return VDETR_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(256), pad, st, x, arow, w, tiles, CA, CB, cin * cout, y);
+    return check_launch("sp_pairs_gemm");
+  }
+#endif
   if (CB <= 64) {  // narrow output: 128 x 64 tiles
     dim3 grid(ntiles, ceil_div(CB, 64));
     if (transposed)
@@ -377,12 +426,26 @@ extern "C" int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const i
   VDETR_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "sp_pairs_wgrad: channel counts must be multiples of 4 (float4 rows)");
   if (cin >= 128 && cout >= 128) {
     dim3 grid(nchunks, ceil_div(cin, 128), ceil_div(cout, 128));
-    hipLaunchKernelGGL((sp_pairs_wgrad_kernel<2, 2, 4, 4, 16>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin, pout, chunks,
-                       cin, cout, partials);
+#ifndef VDETR_SP_WGRAD_SB
+#define VDETR_SP_WGRAD_SB 16
+#endif
+    hipLaunchKernelGGL((sp_pairs_wgrad_kernel<2, 2, 4, 4, VDETR_SP_WGRAD_SB>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin,
+                       pout, chunks, cin, cout, partials);
   } else {
     dim3 grid(nchunks, ceil_div(cin, 64), ceil_div(cout, 64));
     hipLaunchKernelGGL((sp_pairs_wgrad_kernel<4, 1, 1, 4, 32>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin, pout, chunks,
                        cin, cout, partials);
   }
   return check_launch("sp_pairs_wgrad");
+}
+
+extern "C" int vdetr_sp_wgrad_reduce_f32(const float* partials, const int32_t* seg, int K, long elems, float* dw,
+                                         vdetr_stream_t stream) {
+  VDETR_REQUIRE(K > 0 && elems > 0 && elems % 4 == 0, "sp_wgrad_reduce: bad size K=%d elems=%ld", K, elems);
+  VDETR_REQUIRE(partials && seg && dw, "sp_wgrad_reduce: null pointer");
+  const long e4 = elems / 4;
+  dim3 grid((unsigned)((e4 + 255) / 256 < 1024 ? (e4 + 255) / 256 : 1024), K);
+  hipLaunchKernelGGL(sp_wgrad_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(partials), seg,
+                     e4, reinterpret_cast<f32x4*>(dw));
+  return check_launch("sp_wgrad_reduce");
 }

@@ -288,20 +288,24 @@ class PairPlan:
         self._chunks = {}
 
     def wgrad_chunks(self, cin, cout):
-        """(chunks [K*S, 4] i32, S): every offset's segment cut into S chunks (multiples of 4 pairs; S chosen so that the
-        launch has >= ~512 workgroups), chunk (k, s) writes partial slot k * S + s"""
+        """(chunks [n, 4] i32, cseg [K+1] i32, n): every offset's segment cut into chunks of at most L pairs, L chosen so that
+        the launch has ~3 workgroups per CU.  Chunks of EQUAL length, not an equal number of chunks per offset: the centre
+        offset holds a quarter of all pairs, and a launch is as slow as its longest workgroup.  Chunk c writes partial c;
+        the partials of offset k are cseg[k] .. cseg[k+1]."""
         t = 128 if (cin >= 128 and cout >= 128) else 64  # channel tile of vdetr_sp_pairs_wgrad_f32
         key = (-(-cin // t)) * (-(-cout // t))
         if key not in self._chunks:
-            S = max(1, min(32, -(-512 // (self.K * key))))
-            rows = []
+            want = max(1, 768 // key)
+            L = max(64, -(-(-(-self.P // want)) // 16) * 16)
+            rows, cseg = [], [0]
             for k in range(self.K):
                 n = self.counts[k]
-                per = -(-(-(-n // S)) // 4) * 4 if n else 0
-                for s in range(S):
-                    a = min(n, s * per)
-                    rows.append((k, self.seg[k] + a, max(0, min(n, (s + 1) * per) - a), k * S + s))
-            self._chunks[key] = (torch.tensor(rows, dtype=torch.int32, device=self.pin.device), S)
+                for a in range(0, n, L):
+                    rows.append((k, self.seg[k] + a, min(L, n - a), len(rows)))
+                cseg.append(len(rows))
+            dev = self.pin.device
+            self._chunks[key] = (torch.tensor(rows if rows else [(0, 0, 0, 0)], dtype=torch.int32, device=dev),
+                                 torch.tensor(cseg, dtype=torch.int32, device=dev), len(rows))
         return self._chunks[key]
 
 
@@ -322,11 +326,14 @@ def pairs_wgrad(x, dy, plan, cin, cout):
     L.require_gpu(x, "x")
     L.require_contiguous(x, "x")
     L.require_contiguous(dy, "dy")
-    chunks, S = plan.wgrad_chunks(cin, cout)
-    part = torch.empty((plan.K, S, cin, cout), dtype=torch.float32, device=x.device)
+    chunks, cseg, n = plan.wgrad_chunks(cin, cout)
+    part = torch.empty((max(n, 1), cin, cout), dtype=torch.float32, device=x.device)
     L.check(L.lib().vdetr_sp_pairs_wgrad_f32(L.ptr(x), L.ptr(dy), L.ptr(plan.pin), L.ptr(plan.pout), L.ptr(chunks),
-                                             chunks.shape[0], cin, cout, L.ptr(part), L.stream_ptr()), "sp_pairs_wgrad")
-    return part[:, 0] if S == 1 else part.sum(1)
+                                             n, cin, cout, L.ptr(part), L.stream_ptr()), "sp_pairs_wgrad")
+    dw = torch.empty((plan.K, cin, cout), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vdetr_sp_wgrad_reduce_f32(L.ptr(part), L.ptr(cseg), plan.K, cin * cout, L.ptr(dw), L.stream_ptr()),
+            "sp_wgrad_reduce")
+    return dw
 
 
 class _PairsConvFn(Function):
