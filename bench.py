@@ -332,16 +332,22 @@ class BackboneTrainer:
         # feeds the same cloud again, so "next" is recomputed from it every step: its cost is inside ms_per_step)
         # ... by a loader THREAD (building the maps involves host syncs: counts, nonzero), as a data-loader worker would
         self.side = torch.cuda.Stream()
+        self.sides = [torch.cuda.Stream(), torch.cuda.Stream()]  # inline mode: scene i+2 is prepared while i+1's sampling may still run
+        self._queue, self._tick = [], 0
         self._next, self._keep, self._worker = None, None, None
 
-    def _prepare_next(self):
+    def _prepare_next(self, stream=None):
         from vdetr_amd import pointnet2_utils as PU
         from vdetr_amd import sparse_ops as S
         torch.cuda.set_device(self.static_xyz.device)
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(stream or self.side):
             geo = self.model.prepare_geometry({k: v for k, v in self.inputs.items() if k != "geometry"})
             xyz4 = (S.unpack_keys(geo.keys[4])[:, 1:].float() * self.model.voxel_size).contiguous()
             self._next = (geo, PU.furthest_point_sample_varlen([xyz4], self.inds.shape[1]))
+            if stream is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                return self._next + (ev,)
 
     def _decoder_fwd_bwd(self):
         for p in self.dec_params:
@@ -366,16 +372,28 @@ class BackboneTrainer:
 
     def step(self):
         from vdetr_amd import pointnet2_utils as PU
-        if self._worker is not None:  # what the loader thread prepared during the previous step
+        if len(self._queue) >= 2:  # inline mode: the scene prepared one full step ago
+            geo, inds, ev = self._queue.pop(0)
+            torch.cuda.current_stream().wait_event(ev)
+            self._keep = self.inputs["geometry"]  # stays alive while kernels of the previous step may still read it
+            self.inputs["geometry"] = geo
+            self.inds.copy_(inds)
+        if self._worker is not None:  # thread mode: what the loader thread prepared during the previous step
             self._worker.join()
             self._worker = None
             torch.cuda.current_stream().wait_stream(self.side)
-            self._keep = self.inputs["geometry"]  # stays alive while kernels of the previous step may still read it
+            self._keep = self.inputs["geometry"]
             self.inputs["geometry"], inds = self._next
             self.inds.copy_(inds)
         import threading
-        self._worker = threading.Thread(target=self._prepare_next, daemon=True)  # runs while this thread enqueues the step
-        self._worker.start()
+        mode = os.environ.get("VDETR_BENCH_GEOMETRY", "thread")  # A/B switch: thread | inline | static (first scene's geometry reused)
+        marks = getattr(self, "marks", None)  # (tools/backbone_step_probe.py --timeline: events between the phases of the step)
+        def mark():
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
+        mark()
         for p in self.bb_params:
             p.grad = None
         xyz, feats = self.model.backbone_forward(self.inputs)[0]
@@ -383,15 +401,31 @@ class BackboneTrainer:
         with torch.no_grad():
             self.static_xyz.copy_(PU.gather_rows([xyz.contiguous()], self.inds))
             self.static_feat.copy_(enc_rows.permute(1, 0, 2))
+        mark()
         if self.graph is not None:
             self.graph.replay()
         else:
             self._decoder_fwd_bwd()
+        mark()
+        if mode == "thread":
+            # started HERE, not at the top of the step: the forward pass is ~500 launches of 5-100 us, the host barely keeps ahead
+            # of the device there and a second Python thread taking turns on the interpreter lock starves it (backbone forward
+            # 5.8 -> 9.9 ms measured); now the device has the forward and the captured decoder step (14 ms) queued
+            self._worker = threading.Thread(target=self._prepare_next, daemon=True)
+            self._worker.start()
         enc_rows.backward(self.static_feat.grad.permute(1, 0, 2))
+        mark()
         self.flat.pack_grads()
         self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
         self.opt.step()
-
+        mark()
+        if mode == "inline":
+            # A/B variant: the host builds the geometry of scene i+2 itself once step i is enqueued (lookahead 2, alternating side
+            # streams).  Measured slower than the loader thread (35-37 vs 29-31 ms per step): the pack event keeps the host at
+            # most one step ahead, so the device has caught up by the time the 5 ms of geometry calls are through ("gap to next
+            # step" in tools/backbone_step_probe.py --timeline).
+            self._queue.append(self._prepare_next(self.sides[self._tick & 1]))
+            self._tick += 1
 
     def close(self):
         if self._worker is not None:

@@ -557,6 +557,15 @@ int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const int32_t* pin
 /* dw[k][:] = sum of partials[c][:] over c in [seg[k], seg[k+1]) (seg: K+1 ints on the device; elems = Cin*Cout, a multiple of 4):
  * the chunk partials of vdetr_sp_pairs_wgrad_f32 -> the weight gradient, in chunk order (deterministic). */
 int vdetr_sp_wgrad_reduce_f32(const float* partials, const int32_t* seg, int K, long elems, float* dw, vdetr_stream_t stream);
+/* The pair lists of a kernel map, built on the device: pairs sorted by (offset k, output row u).
+ *   nbr [K][nout] (vdetr_sp_kernel_map_i32)  ->  pin, pout [capacity K*nout; the first P entries are written]
+ *                                                slot [K][nout], islot [K][nin]  (pair index or -1)
+ *                                                counts [K+1] (device): pairs per offset, counts[K] = P
+ * workspace: vdetr_sp_pair_plan_workspace_ints(K, nout) ints.  No host synchronisation: the caller copies `counts` back
+ * when it needs the sizes (v-detr_amd/sparse_ops.py:PairPlan).  Deterministic (ranks, no atomics). */
+int vdetr_sp_pair_plan_workspace_ints(int K, int nout);
+int vdetr_sp_pair_plan_i32(const int32_t* nbr, int K, int nout, int nin, int32_t* pin, int32_t* pout, int32_t* slot,
+                           int32_t* islot, int32_t* counts, int32_t* workspace, vdetr_stream_t stream);
 
 /* BatchNorm (+ residual) (+ activation) over the point-major feature table [N,C] of a sparse tensor: ME.MinkowskiBatchNorm
  * followed by MinkowskiReLU / MinkowskiELU and, in the residual blocks, `out += residual` in front of the ReLU

@@ -217,3 +217,26 @@ def test_full_model_with_sparse_backbone_runs():
         b = model.backbone_forward(dict(inputs, geometry=geo))
     for (xa, fa), (xb, fb) in zip(a, b):
         assert torch.equal(xa, xb) and torch.equal(fa, fb)
+
+
+@pytest.mark.parametrize("n,ks,seed", [(3000, 3, 0), (700, 2, 1), (5, 3, 2), (20000, 3, 3)])
+def test_pair_plan_device_builder_equals_host_statement(n, ks, seed):
+    """vdetr_sp_pair_plan_i32 (three launches, no host round trip) against PairPlan._build_host on the CPU copy of the same map:
+    identical pair lists, slots and tables (integer work: bit-exact)."""
+    from vdetr_amd import sparse_ops as S
+    rng = np.random.default_rng(seed)
+    coords = np.unique(rng.integers(0, 24, size=(n, 3)), axis=0).astype(np.int32)
+    coords = np.concatenate([np.zeros((coords.shape[0], 1), np.int32), coords], 1)
+    keys = torch.sort(S.pack_keys(torch.from_numpy(coords)))[0].cuda()
+    offs = torch.tensor(O.region_offsets(ks), dtype=torch.int32).cuda()
+    sub = keys[::2].contiguous()  # different input / output site sets
+    for ink, outk in ((keys, keys), (keys, sub), (sub, keys)):
+        nbr = S.kernel_map(ink, outk, offs)
+        dev = S.PairPlan(nbr, ink.shape[0])
+        assert dev._pending is not None            # nothing has waited for the device yet
+        host = S.PairPlan(nbr.cpu(), ink.shape[0])
+        assert dev.P == host.P and dev.counts == host.counts and dev.seg == host.seg and dev.ntiles == host.ntiles
+        for name in ("pin", "pout", "slot", "islot", "tiles"):
+            assert torch.equal(getattr(dev, name).cpu(), getattr(host, name)), name
+        c_dev, c_host = dev.wgrad_chunks(64, 64), host.wgrad_chunks(64, 64)
+        assert torch.equal(c_dev[0].cpu(), c_host[0]) and torch.equal(c_dev[1].cpu(), c_host[1]) and c_dev[2] == c_host[2]

@@ -212,6 +212,9 @@ _SIGNATURES = {
     "vdetr_sp_gather_cols_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_sp_gather_sum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_sp_pairs_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_sp_pair_plan_workspace_ints": (c_int, [c_int, c_int]),
+    "vdetr_sp_pair_plan_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
     "vdetr_sp_wgrad_reduce_f32": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p, c_void_p]),
     "vdetr_sp_pairs_wgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_sp_bn_workspace_bytes": (c_size_t, [c_int, c_int]),

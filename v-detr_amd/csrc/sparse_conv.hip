@@ -63,6 +63,65 @@ __global__ __launch_bounds__(256) void sp_inverse_map_kernel(const int* __restri
   if (i >= 0) inv[(size_t)k * nin + i] = u;  // (i, k) has at most one reader: u = i - offset[k] on the output lattice
 }
 
+// ---- pair lists of a kernel map, built on the device (no host round trip until the counts are needed) ------------------
+// pairs sorted by (offset k, output row u): pass 1 counts the occupied neighbours per (k, block of 256 rows), pass 2 scans the
+// block counts, pass 3 writes pin / pout / slot / islot at block offset + rank in the block.  Deterministic (no atomics).
+__global__ __launch_bounds__(256) void sp_plan_count_kernel(const int* __restrict__ nbr, int nout, int nb, int* __restrict__ bc) {
+  __shared__ int w[4];
+  const int b = blockIdx.x, k = blockIdx.y, u = b * 256 + threadIdx.x;
+  const bool v = u < nout && nbr[(size_t)k * nout + u] >= 0;
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) bc[k * nb + b] = w[0] + w[1] + w[2] + w[3];
+}
+
+__global__ __launch_bounds__(1024) void sp_plan_scan_kernel(int* __restrict__ bc, int n, int nb, int K, int* __restrict__ counts) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (n + 1023) / 1024;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += bc[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int i = lo; i < hi; ++i) {
+    const int c = bc[i];
+    bc[i] = run;  // exclusive offset of block i in (k, b) order
+    run += c;
+  }
+  __syncthreads();
+  const int total = part[1023];
+  if (t < K) counts[t] = (t + 1 < K ? bc[(t + 1) * nb] : total) - bc[t * nb];
+  if (t == 0) counts[K] = total;
+}
+
+__global__ __launch_bounds__(256) void sp_plan_fill_kernel(const int* __restrict__ nbr, int nout, int nin, int nb,
+                                                          const int* __restrict__ boff, int* __restrict__ pin,
+                                                          int* __restrict__ pout, int* __restrict__ slot, int* __restrict__ islot) {
+  __shared__ int w[4];
+  const int b = blockIdx.x, k = blockIdx.y, u = b * 256 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = u < nout ? nbr[(size_t)k * nout + u] : -1;
+  const bool v = i >= 0;
+  const unsigned long long m = __ballot(v);
+  if (lane == 0) w[wv] = __popcll(m);
+  __syncthreads();
+  int p = boff[k * nb + b] + __popcll(m & ((1ull << lane) - 1ull));
+  for (int j = 0; j < wv; ++j) p += w[j];
+  if (v) {
+    pin[p] = i;
+    pout[p] = u;
+    islot[(size_t)k * nin + i] = p;
+  }
+  if (u < nout) slot[(size_t)k * nout + u] = v ? p : -1;
+}
+
 // col[u][k][c4] <- in[nbr[k][u]][c4]: one float4 per thread, threads of a workgroup walk consecutive (k, c4) of a row u
 template <bool SUM>
 __global__ __launch_bounds__(256) void sp_gather_kernel(const float* __restrict__ src, const int* __restrict__ map, int K,
@@ -448,4 +507,21 @@ extern "C" int vdetr_sp_wgrad_reduce_f32(const float* partials, const int32_t* s
   hipLaunchKernelGGL(sp_wgrad_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(partials), seg,
                      e4, reinterpret_cast<f32x4*>(dw));
   return check_launch("sp_wgrad_reduce");
+}
+
+extern "C" int vdetr_sp_pair_plan_workspace_ints(int K, int nout) { return K * ceil_div(nout > 0 ? nout : 1, 256); }
+
+extern "C" int vdetr_sp_pair_plan_i32(const int32_t* nbr, int K, int nout, int nin, int32_t* pin, int32_t* pout, int32_t* slot,
+                                      int32_t* islot, int32_t* counts, int32_t* workspace, vdetr_stream_t stream) {
+  VDETR_REQUIRE(K > 0 && K <= 1024 && nout >= 0 && nin >= 0, "sp_pair_plan: bad size (K=%d nout=%d nin=%d)", K, nout, nin);
+  VDETR_REQUIRE(counts, "sp_pair_plan: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (nout == 0) return hipMemsetAsync(counts, 0, sizeof(int32_t) * (K + 1), st) == hipSuccess ? VDETR_OK : VDETR_ERR_LAUNCH;
+  VDETR_REQUIRE(nbr && pin && pout && slot && (islot || nin == 0) && workspace, "sp_pair_plan: null pointer");
+  const int nb = ceil_div(nout, 256);
+  if (nin > 0 && hipMemsetAsync(islot, 0xFF, sizeof(int32_t) * (size_t)K * nin, st) != hipSuccess) return VDETR_ERR_LAUNCH;
+  hipLaunchKernelGGL(sp_plan_count_kernel, dim3(nb, K), dim3(256), 0, st, nbr, nout, nb, workspace);
+  hipLaunchKernelGGL(sp_plan_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, K * nb, nb, K, counts);
+  hipLaunchKernelGGL(sp_plan_fill_kernel, dim3(nb, K), dim3(256), 0, st, nbr, nout, nin, nb, workspace, pin, pout, slot, islot);
+  return check_launch("sp_pair_plan");
 }

@@ -147,15 +147,16 @@ class FlatParams:
             host = P["host"]
             if P["event"] is not None:
                 P["event"].synchronize()  # the previous upload has left the pinned table
-        keep = []
-        for i, g in enumerate(src):
+        keep, ptrs = [], []
+        for g in src:
             if g is None:
-                host[i, 0] = 0
+                ptrs.append(0)
                 continue
             if g.dtype != self.grad.dtype or not g.is_contiguous():
                 g = g.to(self.grad.dtype).contiguous()
                 keep.append(g)
-            host[i, 0] = g.data_ptr()
+            ptrs.append(g.data_ptr())
+        host[:, 0] = torch.tensor(ptrs, dtype=torch.int64)  # one strided copy (an element assignment per tensor costs ~1 us each)
         P["dev"].copy_(host, non_blocking=True)
         L.check(L.lib().vdetr_pack_f32(L.ptr(P["dev"]), L.ptr(P["block_entry"]), L.ptr(P["block_chunk"]), P["nblocks"],
                                        L.ptr(self.grad), L.stream_ptr()), "pack")

@@ -163,7 +163,7 @@ class ModelVDETR(nn.Module):
         cm.insert_points(coordinates)
         with ME.geometry_only():  # the layers only register their sites / maps / pair lists: no feature arithmetic
             self.backbone_forward(dict(inputs, geometry=cm))
-        return cm
+        return cm.finalize()
 
     def _scenes(self, inputs):
         return self.backbone_forward(inputs) if self.sparse_backbone else self.pre_encoder(inputs)

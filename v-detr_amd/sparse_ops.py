@@ -8,6 +8,7 @@ are geometry / HBM-stream kernels; the contraction itself is ONE library GEMM pe
 """
 import ctypes
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -252,40 +253,114 @@ class _PlannedConvFn(Function):
 
 
 _RANGES_ONLY = os.environ.get("VDETR_SP_RANGES_ONLY", "0") == "1"  # A/B switch: never use the count-sorted grouping
+class _PinnedCounts:
+    """a ring of pinned host rows for the asynchronous copies of the plans' pair counts (one allocation per process)"""
+    rows, width = 512, 64
+    _buf, _next = None, 0
+    _lock = threading.Lock()
+
+    @classmethod
+    def take(cls, n):
+        assert n <= cls.width
+        with cls._lock:
+            if cls._buf is None:
+                cls._buf = torch.empty((cls.rows, cls.width), dtype=torch.int32, pin_memory=True)
+            row = cls._buf[cls._next % cls.rows]
+            cls._next += 1
+        return row[:n]
+
+
 class PairPlan:
     """Geometry of one sparse convolution as a PAIR LIST sorted by kernel offset (built once per scene and layer shape):
       pin [P], pout [P]   input / output row of pair p; the pairs of offset k are the segment seg[k] .. seg[k+1]
       slot [K, Nout]      pair (absolute index) through which output u reads offset k, -1 if none
       islot [K, Nin]      pair through which input i is read with offset k
       tiles [T, 3]        (k, first pair, count <= 128): the 128-pair tiles of vdetr_sp_pairs_gemm_f32
-    Nothing is padded: the fused kernels (csrc/sparse_conv.hip) gather rows straight into the matrix-core operands."""
+    Nothing is padded: the fused kernels (csrc/sparse_conv.hip) gather rows straight into the matrix-core operands.
+
+    On the GPU the lists are built by vdetr_sp_pair_plan_i32 without a host round trip; what needs the pair COUNTS on the host
+    (P, seg, tiles, the weight-gradient chunks) is derived on first use from an asynchronous copy, so that a whole scene's
+    plans cost one synchronisation instead of three each."""
+
+    _LAZY = ("P", "pairs", "counts", "seg", "tiles", "ntiles", "pin", "pout")
 
     def __init__(self, nbr, nin):
         K, nout = nbr.shape
-        dev = nbr.device
         self.K, self.nin, self.nout = K, nin, nout
+        self._chunks = {}
+        self._pending = None
+        if nbr.is_cuda and K + 1 <= _PinnedCounts.width:
+            self._launch(nbr)
+        else:
+            self._build_host(nbr)
+
+    # ---- tensor-expression construction (CPU tensors: the host statement the device builder is tested against) --------
+    def _build_host(self, nbr):
+        K, nout, nin, dev = self.K, self.nout, self.nin, nbr.device
         valid = nbr >= 0
-        counts = valid.sum(1).tolist()  # geometry phase: one sync per plan
-        self.counts = counts
+        counts = valid.sum(1).tolist()
         pk, pout = torch.nonzero(valid, as_tuple=True)      # sorted by (k, u)
-        self.P = int(pk.shape[0])
-        self.pairs = self.P
+        P = int(pk.shape[0])
         self.pout = pout.int().contiguous()
         self.pin = nbr[pk, pout].contiguous()
-        idx = torch.arange(self.P, dtype=torch.int32, device=dev)
+        idx = torch.arange(P, dtype=torch.int32, device=dev)
         self.slot = torch.full((K, nout), -1, dtype=torch.int32, device=dev)
         self.slot[pk, pout] = idx
         self.islot = torch.full((K, nin), -1, dtype=torch.int32, device=dev)
         self.islot[pk, self.pin.long()] = idx
+        self._tables(counts)
+
+    # ---- device construction ------------------------------------------------------------------------------------------
+    def _launch(self, nbr):
+        K, nout, nin, dev = self.K, self.nout, self.nin, nbr.device
+        lib = L.lib()
+        nbr = nbr.contiguous()
+        cap = max(K * nout, 1)
+        self._pin_buf = torch.empty(cap, dtype=torch.int32, device=dev)
+        self._pout_buf = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.slot = torch.empty((K, nout), dtype=torch.int32, device=dev)
+        self.islot = torch.empty((K, nin), dtype=torch.int32, device=dev)
+        counts_dev = torch.empty(K + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(lib.vdetr_sp_pair_plan_workspace_ints(K, nout), 1), dtype=torch.int32, device=dev)
+        L.check(lib.vdetr_sp_pair_plan_i32(L.ptr(nbr), K, nout, nin, L.ptr(self._pin_buf), L.ptr(self._pout_buf), L.ptr(self.slot),
+                                           L.ptr(self.islot) if nin else None, L.ptr(counts_dev), L.ptr(ws), L.stream_ptr()),
+                "sp_pair_plan")
+        host = _PinnedCounts.take(K + 1)
+        host.copy_(counts_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (host, ev, counts_dev, ws)  # device buffers kept alive until the copy has landed
+
+    def finalize(self):
+        """wait for the pair counts (no-op once done) and derive the host-side tables"""
+        if self._pending is not None:
+            host, ev, _, _ = self._pending
+            ev.synchronize()
+            counts = host.tolist()
+            self._pending = None
+            P = counts[self.K]
+            self.pin, self.pout = self._pin_buf[:P], self._pout_buf[:P]
+            self._tables(counts[:self.K])
+        return self
+
+    def __getattr__(self, name):  # only reached for attributes not set yet
+        if name in PairPlan._LAZY and self.__dict__.get("_pending") is not None:
+            self.finalize()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def _tables(self, counts):
+        dev = self.slot.device
+        self.counts = counts
+        self.P = self.pairs = int(sum(counts))
         seg, tiles = [0], []
-        for k in range(K):
+        for k in range(self.K):
             for s0 in range(0, counts[k], 128):
                 tiles.append((k, seg[-1] + s0, min(128, counts[k] - s0)))
             seg.append(seg[-1] + counts[k])
         self.seg = seg
         self.ntiles = len(tiles)
         self.tiles = torch.tensor(tiles if tiles else [(0, 0, 0)], dtype=torch.int32, device=dev)
-        self._chunks = {}
 
     def wgrad_chunks(self, cin, cout):
         """(chunks [n, 4] i32, cseg [K+1] i32, n): every offset's segment cut into chunks of at most L pairs, L chosen so that
