@@ -25,6 +25,10 @@ namespace vdetr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VDETR_SP_PROBE
+#define VDETR_SP_PROBE 0  // measurements only.  1: operands loaded once (MFMA loop alone), 2: loads alone (folded with adds)
+#endif
+
 constexpr long long kKeyBias = 32768;
 
 __device__ __forceinline__ long long sp_key_add(long long key, int dx, int dy, int dz, bool& ok) {
@@ -260,9 +264,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef VDETR_SP_PROBE
-#define VDETR_SP_PROBE 0  // measurements only.  1: operands loaded once (MFMA loop alone), 2: loads alone (folded with adds)
-#endif
   for (int kc = 0; kc < CA; kc += 16) {
     f32x4 a[RT];
     float b[CT][4];
@@ -308,6 +309,154 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP
       for (int t = 0; t < CT; ++t)
         if (n0 + 16 * t + c < CB) y[16 * t] = acc[i][t][r];
     }
+}
+
+// Persistent form of the 128 x 128 kernel (layers with > 64 output channels and a contraction width that is a multiple of 32):
+// 2 workgroups per CU walk the (pair tile, channel tile) work items with a stride of the grid, and everything a work item has
+// to wait for is fetched under the previous one's MFMAs: the operands of K-step s+1 are loaded into a second register set
+// before the 64 MFMAs of step s are issued (the plain kernel issues its loads, waits, then multiplies), the next item's tile
+// descriptor and row indices are fetched when the current item starts, and its first operands under the current item's
+// last K-step.  The 14 us of MFMA of a 256-channel item were sitting behind an index -> row -> operand chain of three dependent
+// memory round trips and 64 KB of stores per workgroup; a persistent workgroup pays that chain once.
+// B operand addresses are a uniform row pointer (scalar registers) + a per-lane column offset: no 64-bit vector address
+// arithmetic in the loop (the plain kernel: 16 v_lshl_add_u64 per K-step).
+template <bool TRANS, int KSUB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 1 ? 2 : 1))) void sp_pairs_gemm_persistent_kernel(
+    const float* __restrict__ X, const int* __restrict__ arow, const float* __restrict__ W, const int* __restrict__ tiles,
+    int ntiles, int CA, int CB, int wk_stride, float* __restrict__ Y) {
+  constexpr int RT = 4, CT = 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int wr = w >> 1, wc = w & 1;
+  const int r0 = wr * 64;
+  const int NT = (CB + 127) >> 7, nwork = ntiles * NT, NS = CA / (16 * KSUB);  // K-steps of 16 * KSUB, taken in pairs
+  int item = blockIdx.x;
+  if (item >= nwork) return;
+
+  struct Work {
+    int k, p0, cnt, n0;
+  };
+  auto describe = [&](int it) {
+    const int t = it / NT, nt = it - t * NT;
+    Work d;
+    d.k = tiles[t * 3];
+    d.p0 = tiles[t * 3 + 1];
+    d.cnt = tiles[t * 3 + 2];
+    d.n0 = nt * 128 + wc * 64;
+    return d;
+  };
+  auto rows_of = [&](const Work& d, int (&ri)[RT]) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int rl = r0 + 16 * i + c;
+      ri[i] = arow[d.p0 + (rl < d.cnt ? rl : 0)];  // rows past the tile's count read its first pair (never stored)
+    }
+  };
+  // operand addresses of a work item as buffer loads: a descriptor in scalar registers (X once, W[k] per item), a per-lane byte
+  // offset that does not change inside an item and a scalar offset per K-step — no 64-bit vector address arithmetic in the loop
+  // (the plain kernel: 16 v_lshl_add_u64 per K-step) and no pointer pairs held in vector registers
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  auto make_rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000); };
+  const rsrc_t rX = make_rsrc(X);
+  auto a_offsets = [&](const int (&ri)[RT], unsigned (&xo)[RT]) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) xo[i] = ((unsigned)ri[i] * (unsigned)CA + 4u * g) * 4u;
+  };
+  unsigned bo[CT];  // per-lane part of the B address (bytes)
+  auto b_offsets = [&](const Work& d) {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int n = min(d.n0 + 16 * t + c, CB - 1);  // columns past CB read column CB - 1 (never stored)
+      bo[t] = (TRANS ? (unsigned)n * (unsigned)CA + 4u * g : (unsigned)(4 * g) * (unsigned)CB + (unsigned)n) * 4u;
+    }
+  };
+  auto load_ops = [&](const unsigned (&xo)[RT], rsrc_t rW, int kc0, f32x4 (&a)[KSUB][RT], f32x4 (&b)[KSUB][CT]) {
+#if defined(VDETR_SP_PROBE) && (VDETR_SP_PROBE == 1 || VDETR_SP_PROBE == 3)
+    kc0 = 0;  // measurements only: every K-step reads the same (cache-resident) operands
+#endif
+#pragma unroll
+    for (int u = 0; u < KSUB; ++u) {
+      const int kc = kc0 + 16 * u;
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+        a[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, (int)xo[i], kc * 4, 0));
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        if (TRANS) {
+          b[u][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)bo[t], kc * 4, 0));
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2)
+            b[u][t][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, (int)bo[t], (kc + s2) * CB * 4, 0));
+        }
+      }
+    }
+  };
+
+  Work cur = describe(item);
+  int ri[RT];
+  rows_of(cur, ri);
+  unsigned xo[RT];
+  a_offsets(ri, xo);
+  b_offsets(cur);
+  rsrc_t rW = make_rsrc(W + (size_t)cur.k * wk_stride);
+  f32x4 a0[KSUB][RT], b0[KSUB][CT], a1[KSUB][RT], b1[KSUB][CT];
+  load_ops(xo, rW, 0, a0, b0);
+
+  for (;;) {
+    const int nitem = item + gridDim.x;
+    const bool more = nitem < nwork;
+    Work nxt = cur;
+    int rin[RT];
+    if (more) {  // descriptor and row indices of the next item: in flight during this item's K-loop
+      nxt = describe(nitem);
+      rows_of(nxt, rin);
+    }
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma_step = [&](const f32x4 (&a)[KSUB][RT], const f32x4 (&b)[KSUB][CT]) {
+#pragma unroll
+      for (int u = 0; u < KSUB; ++u)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+              acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i][s2], b[u][t][s2], acc[i][t], 0, 0, 0);
+    };
+    // K-steps in pairs (NS is even): set 0 -> set 1 -> set 0; the last step of the item fetches the next item's first operands
+    for (int s = 0; s < NS; s += 2) {
+      load_ops(xo, rW, (s + 1) * 16 * KSUB, a1, b1);
+      mfma_step(a0, b0);
+      if (s + 2 < NS) {
+        load_ops(xo, rW, (s + 2) * 16 * KSUB, a0, b0);
+      } else if (more) {  // the operand addresses switch to the next item (the epilogue below only needs cur.p0 / cnt / n0)
+        a_offsets(rin, xo);
+        b_offsets(nxt);
+        rW = make_rsrc(W + (size_t)nxt.k * wk_stride);
+        load_ops(xo, rW, 0, a0, b0);
+      }
+      mfma_step(a1, b1);
+    }
+    // accumulator: lane (g, c) holds rows 4 g + r, column c of every 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 16 * i + 4 * g + r;
+        if (row >= cur.cnt) continue;
+        float* y = Y + (size_t)(cur.p0 + row) * CB + cur.n0 + c;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+          if (cur.n0 + 16 * t + c < CB) y[16 * t] = acc[i][t][r];
+      }
+    if (!more) break;
+    item = nitem;
+    cur = nxt;
+  }
 }
 
 // dW[k][ci][co] (+ split partials): workgroup = (segment chunk, ci tile, co tile); the 4 waves form a WR x WC grid over the
@@ -466,6 +615,25 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
     else
       hipLaunchKernelGGL((sp_pairs_gemm_kernel<false, 4, 1, 2, 4>), grid, dim3(256), 0, st, x, arow, w, tiles, CA, CB, cin * cout, y);
   } else {
+    // persistent = 2 (default): one workgroup per CU, K-steps of 32 (the next 32 x (A, B) operands in flight under 128 MFMAs =
+    // 1.7 us: covers a row fetched from HBM); 1: two workgroups per CU, K-steps of 16; 0: the plain kernel.  A/B switch.
+    static const int persistent = getenv("VDETR_SP_PERSISTENT") ? atoi(getenv("VDETR_SP_PERSISTENT")) : 2;
+    const int ksub = persistent == 2 && CA % 64 == 0 ? 2 : 1;
+    if (persistent && CA % 32 == 0) {
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+      const int per_cu = ksub == 2 ? 1 : 2;
+      const int nwork = ntiles * ceil_div(CB, 128);
+      dim3 grid(nwork < per_cu * cus ? nwork : per_cu * cus);
+      auto kern = ksub == 2 ? (transposed ? sp_pairs_gemm_persistent_kernel<true, 2> : sp_pairs_gemm_persistent_kernel<false, 2>)
+                            : (transposed ? sp_pairs_gemm_persistent_kernel<true, 1> : sp_pairs_gemm_persistent_kernel<false, 1>);
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, x, arow, w, tiles, ntiles, CA, CB, cin * cout, y);
+      return check_launch("sp_pairs_gemm");
+    }
     dim3 grid(ntiles, ceil_div(CB, 128));
     if (transposed)
       hipLaunchKernelGGL((sp_pairs_gemm_kernel<true, 2, 2, 4, 4>), grid, dim3(256), 0, st, x, arow, w, tiles, CA, CB, cin * cout, y);
