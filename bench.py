@@ -330,9 +330,12 @@ class BackboneTrainer:
         self.graph, self.loss = None, None
         # the NEXT scene's geometry and FPS indices are built on a side stream while this scene trains (the synthetic bench
         # feeds the same cloud again, so "next" is recomputed from it every step: its cost is inside ms_per_step)
-        # ... by a loader THREAD (building the maps involves host syncs: counts, nonzero), as a data-loader worker would
-        self.side = torch.cuda.Stream()
-        self.sides = [torch.cuda.Stream(), torch.cuda.Stream()]  # inline mode: scene i+2 is prepared while i+1's sampling may still run
+        # (VDETR_BENCH_GEOMETRY: "inline" = by the launching thread once the step is enqueued, "thread" = by a loader thread)
+        # (VDETR_BENCH_SIDE_PRIORITY=-1: high-priority side streams, A/B switch.  Measured worse with the loader thread: 35.8 vs
+        # 26.7 ms per step — the geometry kernels and the sampling kernel then win every dispatch against the step's kernels.)
+        prio = int(os.environ.get("VDETR_BENCH_SIDE_PRIORITY", "0"))
+        self.side = torch.cuda.Stream(priority=prio)
+        self.sides = [torch.cuda.Stream(priority=prio), torch.cuda.Stream(priority=prio)]  # scene i+2 is prepared while i+1's sampling may still run
         self._queue, self._tick = [], 0
         self._next, self._keep, self._worker = None, None, None
 
@@ -408,9 +411,9 @@ class BackboneTrainer:
             self._decoder_fwd_bwd()
         mark()
         if mode == "thread":
-            # started HERE, not at the top of the step: the forward pass is ~500 launches of 5-100 us, the host barely keeps ahead
-            # of the device there and a second Python thread taking turns on the interpreter lock starves it (backbone forward
-            # 5.8 -> 9.9 ms measured); now the device has the forward and the captured decoder step (14 ms) queued
+            # (A/B variant) started HERE, not at the top of the step: the forward pass is ~500 launches of 5-100 us, the host barely
+            # keeps ahead of the device there and a second Python thread taking turns on the interpreter lock starves it (backbone
+            # forward 5.8 -> 9.9 ms measured); now the device has the forward and the captured decoder step (14 ms) queued
             self._worker = threading.Thread(target=self._prepare_next, daemon=True)
             self._worker.start()
         enc_rows.backward(self.static_feat.grad.permute(1, 0, 2))
@@ -420,10 +423,10 @@ class BackboneTrainer:
         self.opt.step()
         mark()
         if mode == "inline":
-            # A/B variant: the host builds the geometry of scene i+2 itself once step i is enqueued (lookahead 2, alternating side
-            # streams).  Measured slower than the loader thread (35-37 vs 29-31 ms per step): the pack event keeps the host at
-            # most one step ahead, so the device has caught up by the time the 5 ms of geometry calls are through ("gap to next
-            # step" in tools/backbone_step_probe.py --timeline).
+            # (A/B variant) the step is enqueued: the host builds the geometry of scene i+2 now, on a side stream (two alternate:
+            # scene i+1's one-CU sampling kernel may still be running on the other); lookahead 2 = a two-scene loader queue.
+            # 26.0 ms per step in tools/backbone_step_probe.py, but 32.7 inside bench.py's process (after the decoder-only
+            # trainer; forward and captured decoder step stretched by ~50 %, cause not found), where the loader thread gives 26.7.
             self._queue.append(self._prepare_next(self.sides[self._tick & 1]))
             self._tick += 1
 
@@ -721,7 +724,7 @@ def main():
         try:
             if use_graph:
                 bt.capture()
-            for _ in range(3):
+            for _ in range(max(a.warmup, 8)):  # (the two-scene queue and the allocator pools of its two streams take a few steps to settle)
                 bt.step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -729,6 +732,18 @@ def main():
                 bt.step()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / a.steps * 1e3
+            if os.environ.get("VDETR_BENCH_TIMELINE"):  # device time of the step's phases (events on the main stream)
+                bt.marks = []
+                for _ in range(10):
+                    bt.step()
+                torch.cuda.synchronize()
+                m, bt.marks = bt.marks, None
+                names = ["backbone fwd", "decoder graph", "backbone bwd", "pack+clip+adamw", "gap to next step"]
+                acc = [0.0] * 5
+                for i in range(0, len(m) - 5, 5):
+                    for j in range(5):
+                        acc[j] += m[i + j].elapsed_time(m[i + j + 1])
+                print("[bench] with_backbone timeline (ms):", {k: round(v / ((len(m) - 5) // 5), 2) for k, v in zip(names, acc)}, file=sys.stderr)
             bloss = float(bt.loss.item())
             assert np.isfinite(bloss), "non-finite loss with the backbone"
             result["with_backbone"] = {
@@ -736,8 +751,8 @@ def main():
                 "voxels_per_stride": bt.voxels, "backbone_parameters": sum(p.numel() for p in bt.bb_params), "loss": bloss,
                 "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP kernel maps, fused pair-list convolutions on the fp32 matrix cores, fused BatchNorm; eager) -> FPS tokens -> "
                         "decoder step (captured hipGraph) -> backbone backward -> clip + AdamW over all 79 M parameters; "
-                        "the next scene's geometry (voxel sites, kernel maps, pair lists) and FPS indices are built from its coordinates on a "
-                        "side stream DURING the step (inside ms_per_step); geometry_ms = that work alone"}
+                        "the geometry (voxel sites, kernel maps, pair lists) and FPS indices of the scene after next are built from its "
+                        "coordinates on a side stream inside every timed step (a two-scene loader queue); geometry_ms = that work alone"}
         finally:
             bt.close()
             defer_weight_grads(not a.no_defer_wg)

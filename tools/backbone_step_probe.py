@@ -35,7 +35,7 @@ def main():
         pass
     tr = bench.BackboneTrainer("c2", dev)
     tr.capture()
-    for mode in ("static", "thread", "inline", "static", "inline"):
+    for mode in os.environ.get("PROBE_MODES", "static thread inline static inline").split():
         if ":" in mode:
             sys.setswitchinterval(float(mode.split(":")[1]))
             mode = "thread"

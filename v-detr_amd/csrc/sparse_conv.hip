@@ -19,6 +19,7 @@
 // The two feature kernels are pure HBM streams of C-float rows (256 B - 2 KB each): float4 per lane, rows x offsets over
 // the whole chip.
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 
 namespace vdetr {
@@ -323,8 +324,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP
 template <bool TRANS, int KSUB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 1 ? 2 : 1))) void sp_pairs_gemm_persistent_kernel(
     const float* __restrict__ X, const int* __restrict__ arow, const float* __restrict__ W, const int* __restrict__ tiles,
-    int ntiles, int CA, int CB, int wk_stride, float* __restrict__ Y) {
+    int ntiles, int CA, int CB, int wk_stride, float* __restrict__ Y, int* __restrict__ ticket) {
   constexpr int RT = 4, CT = 4;
+  // ticket != NULL (VDETR_SP_TICKET=1): work items are handed out by a device counter (the first gridDim.x statically), so that
+  // a CU busy with another stream's long kernel takes no items.  Measured: no gain in the step and -7 % alone (a barrier per
+  // item), so the default is the static stride.
+  __shared__ int next_item[2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const int wr = w >> 1, wc = w & 1;
   const int r0 = wr * 64;
@@ -402,8 +407,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 
   f32x4 a0[KSUB][RT], b0[KSUB][CT], a1[KSUB][RT], b1[KSUB][CT];
   load_ops(xo, rW, 0, a0, b0);
 
-  for (;;) {
-    const int nitem = item + gridDim.x;
+  for (int round = 0;; ++round) {
+    int nitem = item + (int)gridDim.x;
+    if (ticket) {
+      if (threadIdx.x == 0) next_item[round & 1] = (int)gridDim.x + atomicAdd(ticket, 1);
+      __syncthreads();
+      nitem = next_item[round & 1];
+    }
     const bool more = nitem < nwork;
     Work nxt = cur;
     int rin[RT];
@@ -631,7 +641,20 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
       dim3 grid(nwork < per_cu * cus ? nwork : per_cu * cus);
       auto kern = ksub == 2 ? (transposed ? sp_pairs_gemm_persistent_kernel<true, 2> : sp_pairs_gemm_persistent_kernel<false, 2>)
                             : (transposed ? sp_pairs_gemm_persistent_kernel<true, 1> : sp_pairs_gemm_persistent_kernel<false, 1>);
-      hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, x, arow, w, tiles, ntiles, CA, CB, cin * cout, y);
+      int* ticket = nullptr;
+      static const int use_ticket = getenv("VDETR_SP_TICKET") ? atoi(getenv("VDETR_SP_TICKET")) : 0;  // A/B switch
+      if (use_ticket) {  // one work counter per launch out of a ring (launches of different streams may overlap), zeroed in stream order
+        static int* ring = nullptr;
+        static std::atomic<unsigned> ring_next{0};
+        constexpr unsigned kRing = 4096;
+        if (!ring && hipMalloc(&ring, kRing * sizeof(int)) != hipSuccess) {
+          set_error("sp_pairs_gemm: cannot allocate the work counters");
+          return VDETR_ERR_LAUNCH;
+        }
+        ticket = ring + (ring_next.fetch_add(1) % kRing);
+        if (hipMemsetAsync(ticket, 0, sizeof(int), st) != hipSuccess) return VDETR_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, x, arow, w, tiles, ntiles, CA, CB, cin * cout, y, ticket);
       return check_launch("sp_pairs_gemm");
     }
     dim3 grid(ntiles, ceil_div(CB, 128));

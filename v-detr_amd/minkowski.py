@@ -198,6 +198,8 @@ class MinkowskiConvolution(nn.Module):
             out_keys = x.keys if out_ts == ts else cm.strided(x.keys, ts, out_ts)
         nbr, inv, plan = cm.kernel_map(x.keys, out_keys, ts, out_ts, self.kernel_size, self.transposed)
         if _geometry_only():
+            if hasattr(plan, "request_wgrad"):  # the weight-gradient chunk table of this layer's width: built with the geometry
+                plan.request_wgrad(w.shape[1], w.shape[2])
             return SparseTensor(x.F.new_empty((out_keys.shape[0], self.out_channels)), tensor_stride=out_ts,
                                 coordinate_manager=cm, keys=out_keys)
         f = S.sparse_conv(x.F, w, nbr, inv, plan)

@@ -10,6 +10,7 @@ import ctypes
 import os
 import threading
 
+import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -341,6 +342,8 @@ class PairPlan:
             P = counts[self.K]
             self.pin, self.pout = self._pin_buf[:P], self._pout_buf[:P]
             self._tables(counts[:self.K])
+            for cin, cout in sorted(self.__dict__.pop("_wanted", ())):
+                self.wgrad_chunks(cin, cout)
         return self
 
     def __getattr__(self, name):  # only reached for attributes not set yet
@@ -349,18 +352,41 @@ class PairPlan:
             return self.__dict__[name]
         raise AttributeError(name)
 
+    @staticmethod
+    def _cut(counts, seg, L):
+        """every segment k (seg[k], counts[k]) cut into pieces of at most L: (k, start, length) arrays and pieces per segment;
+        array arithmetic instead of a Python loop per piece (a scene has ~10^4 pieces over its 16 plans, and the loader thread
+        that builds them shares the interpreter lock with the thread that launches the training step)"""
+        counts = np.asarray(counts, dtype=np.int64)
+        per = -(-counts // L)
+        kidx = np.repeat(np.arange(counts.shape[0], dtype=np.int64), per)
+        first = np.cumsum(per) - per
+        within = np.arange(kidx.shape[0], dtype=np.int64) - first[kidx]
+        start = np.asarray(seg[:-1], dtype=np.int64)[kidx] + within * L
+        length = np.minimum(L, counts[kidx] - within * L)
+        return kidx, start, length, per
+
     def _tables(self, counts):
         dev = self.slot.device
         self.counts = counts
         self.P = self.pairs = int(sum(counts))
-        seg, tiles = [0], []
-        for k in range(self.K):
-            for s0 in range(0, counts[k], 128):
-                tiles.append((k, seg[-1] + s0, min(128, counts[k] - s0)))
-            seg.append(seg[-1] + counts[k])
+        seg = [0]
+        for c in counts:
+            seg.append(seg[-1] + c)
         self.seg = seg
-        self.ntiles = len(tiles)
-        self.tiles = torch.tensor(tiles if tiles else [(0, 0, 0)], dtype=torch.int32, device=dev)
+        kidx, start, length, _ = PairPlan._cut(counts, seg, 128)
+        self.ntiles = int(kidx.shape[0])
+        tiles = np.stack([kidx, start, length], 1).astype(np.int32) if self.ntiles else np.zeros((1, 3), np.int32)
+        self.tiles = torch.from_numpy(tiles).to(dev)
+
+    def request_wgrad(self, cin, cout):
+        """a layer of cin x cout channels will ask for wgrad_chunks: build that table with the geometry (`finalize`), not inside
+        the backward pass, where its upload would make the launching thread wait for the device"""
+        cin, cout = cin + (-cin) % 16, cout + (-cout) % 16  # (sparse_conv pads the channels of the fused kernels to 16)
+        if self.__dict__.get("_pending") is None:
+            self.wgrad_chunks(cin, cout)
+        else:
+            self.__dict__.setdefault("_wanted", set()).add((cin, cout))
 
     def wgrad_chunks(self, cin, cout):
         """(chunks [n, 4] i32, cseg [K+1] i32, n): every offset's segment cut into chunks of at most L pairs, L chosen so that
@@ -372,15 +398,12 @@ class PairPlan:
         if key not in self._chunks:
             want = max(1, 768 // key)
             L = max(64, -(-(-(-self.P // want)) // 16) * 16)
-            rows, cseg = [], [0]
-            for k in range(self.K):
-                n = self.counts[k]
-                for a in range(0, n, L):
-                    rows.append((k, self.seg[k] + a, min(L, n - a), len(rows)))
-                cseg.append(len(rows))
-            dev = self.pin.device
-            self._chunks[key] = (torch.tensor(rows if rows else [(0, 0, 0, 0)], dtype=torch.int32, device=dev),
-                                 torch.tensor(cseg, dtype=torch.int32, device=dev), len(rows))
+            kidx, start, length, per = PairPlan._cut(self.counts, self.seg, L)
+            n = int(kidx.shape[0])
+            rows = np.stack([kidx, start, length, np.arange(n, dtype=np.int64)], 1).astype(np.int32) if n else np.zeros((1, 4), np.int32)
+            cseg = np.concatenate([[0], np.cumsum(per)]).astype(np.int32)
+            dev = self.slot.device
+            self._chunks[key] = (torch.from_numpy(rows).to(dev), torch.from_numpy(cseg).to(dev), n)
         return self._chunks[key]
 
 
