@@ -58,5 +58,10 @@ done
 python3 tools/backbone_bench.py 40000 --torch-profile > $out/backbone_profile.txt 2>&1 < /dev/null
 python3 tools/backbone_bench.py 40000 > $out/backbone_bench.txt 2>&1 < /dev/null
 python3 tools/spconv_bench.py > $out/spconv_bench.txt 2>&1 < /dev/null
+python3 tools/backbone_step_probe.py --timeline > $out/backbone_step_probe.txt 2>&1 < /dev/null
+python3 tools/op_census.py --top 60 > $out/op_census.txt 2>&1 < /dev/null
+[ -x tools/probes/bin/mfma_f32_rate ] && timeout 120 tools/probes/bin/mfma_f32_rate > $out/mfma_f32_rate.txt 2>&1
+[ -x tools/probes/bin/mfma_patterns ] && timeout 120 tools/probes/bin/mfma_patterns > $out/mfma_patterns.txt 2>&1
+bash tools/pmc_spconv.sh $tag > /dev/null 2>&1; cat gpurun_out/pmc_sp_$tag/pmc_sq_pass*.txt > $out/spconv_pmc_sq.txt 2>/dev/null
 python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400
