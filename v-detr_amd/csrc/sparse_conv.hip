@@ -326,9 +326,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 
     const float* __restrict__ X, const int* __restrict__ arow, const float* __restrict__ W, const int* __restrict__ tiles,
     int ntiles, int CA, int CB, int wk_stride, float* __restrict__ Y, int* __restrict__ ticket) {
   constexpr int RT = 4, CT = 4;
-  // ticket != NULL (VDETR_SP_TICKET=1): work items are handed out by a device counter (the first gridDim.x statically), so that
-  // a CU busy with another stream's long kernel takes no items.  Measured: no gain in the step and -7 % alone (a barrier per
-  // item), so the default is the static stride.
+  // ticket != NULL (default; VDETR_SP_TICKET=0 for the static stride): work items are handed out by a device counter (the first
+  // gridDim.x statically), so that a CU busy with another stream's long kernel — the next scene's 9 ms sampling — takes no
+  // items instead of making its workgroup start a round late.  Alone the barrier per item costs 7 % (133 -> 142 us at 256
+  // channels); in the training step with the sampling alongside it is worth 1.1-2 ms of 26.7.
   __shared__ int next_item[2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const int wr = w >> 1, wc = w & 1;
@@ -638,11 +639,15 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
       }
       const int per_cu = ksub == 2 ? 1 : 2;
       const int nwork = ntiles * ceil_div(CB, 128);
-      dim3 grid(nwork < per_cu * cus ? nwork : per_cu * cus);
+      // `spare` CUs are left to whatever else is running (A/B switch): with a grid of exactly one workgroup per CU, a CU that is
+      // busy with another stream's long kernel (the next scene's 9 ms sampling) makes its workgroup start a round late
+      static const int spare = getenv("VDETR_SP_SPARE_CUS") ? atoi(getenv("VDETR_SP_SPARE_CUS")) : 0;
+      const int slots = per_cu * (cus - spare) > 0 ? per_cu * (cus - spare) : 1;
+      dim3 grid(nwork < slots ? nwork : slots);
       auto kern = ksub == 2 ? (transposed ? sp_pairs_gemm_persistent_kernel<true, 2> : sp_pairs_gemm_persistent_kernel<false, 2>)
                             : (transposed ? sp_pairs_gemm_persistent_kernel<true, 1> : sp_pairs_gemm_persistent_kernel<false, 1>);
       int* ticket = nullptr;
-      static const int use_ticket = getenv("VDETR_SP_TICKET") ? atoi(getenv("VDETR_SP_TICKET")) : 0;  // A/B switch
+      static const int use_ticket = getenv("VDETR_SP_TICKET") ? atoi(getenv("VDETR_SP_TICKET")) : 1;  // A/B switch
       if (use_ticket) {  // one work counter per launch out of a ring (launches of different streams may overlap), zeroed in stream order
         static int* ring = nullptr;
         static std::atomic<unsigned> ring_next{0};
