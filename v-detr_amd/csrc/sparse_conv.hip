@@ -328,8 +328,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 
   constexpr int RT = 4, CT = 4;
   // ticket != NULL (default; VDETR_SP_TICKET=0 for the static stride): work items are handed out by a device counter (the first
   // gridDim.x statically), so that a CU busy with another stream's long kernel — the next scene's 9 ms sampling — takes no
-  // items instead of making its workgroup start a round late.  Alone the barrier per item costs 7 % (133 -> 142 us at 256
-  // channels); in the training step with the sampling alongside it is worth 1.1-2 ms of 26.7.
+  // items instead of making its workgroup start a round late: worth 1.1-2 ms of 26.7 in the training step.  (Tried: every
+  // WAVE drawing 64 x 64 quadrants on its own, no LDS / barrier — the four quadrants of an item then run on four CUs and their
+  // shared rows / columns miss the L1: 153 instead of 143 us at 256 channels.)
   __shared__ int next_item[2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const int wr = w >> 1, wc = w & 1;
@@ -467,6 +468,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 
     if (!more) break;
     item = nitem;
     cur = nxt;
+  }
+  // the last workgroup to leave resets the launch's counter pair, so that the ring slot is zero again when it comes round:
+  // no memset in front of every launch (a 5-10 us node of its own on the stream)
+  if (ticket) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket + 1, 1) == (int)gridDim.x - 1) {
+      ticket[0] = 0;
+      ticket[1] = 0;
+    }
   }
 }
 
@@ -648,16 +658,18 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
                             : (transposed ? sp_pairs_gemm_persistent_kernel<true, 1> : sp_pairs_gemm_persistent_kernel<false, 1>);
       int* ticket = nullptr;
       static const int use_ticket = getenv("VDETR_SP_TICKET") ? atoi(getenv("VDETR_SP_TICKET")) : 1;  // A/B switch
-      if (use_ticket) {  // one work counter per launch out of a ring (launches of different streams may overlap), zeroed in stream order
+      if (use_ticket) {  // a (work counter, exit counter) pair per launch out of a ring: launches of different streams may overlap
         static int* ring = nullptr;
         static std::atomic<unsigned> ring_next{0};
         constexpr unsigned kRing = 4096;
-        if (!ring && hipMalloc(&ring, kRing * sizeof(int)) != hipSuccess) {
-          set_error("sp_pairs_gemm: cannot allocate the work counters");
-          return VDETR_ERR_LAUNCH;
+        if (!ring) {  // zeroed once; every launch leaves its pair zeroed again (the kernel's last workgroup resets it)
+          if (hipMalloc(&ring, 2 * kRing * sizeof(int)) != hipSuccess || hipMemset(ring, 0, 2 * kRing * sizeof(int)) != hipSuccess) {
+            set_error("sp_pairs_gemm: cannot allocate the work counters");
+            ring = nullptr;
+            return VDETR_ERR_LAUNCH;
+          }
         }
-        ticket = ring + (ring_next.fetch_add(1) % kRing);
-        if (hipMemsetAsync(ticket, 0, sizeof(int), st) != hipSuccess) return VDETR_ERR_LAUNCH;
+        ticket = ring + 2 * (ring_next.fetch_add(1) % kRing);
       }
       hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, x, arow, w, tiles, ntiles, CA, CB, cin * cout, y, ticket);
       return check_launch("sp_pairs_gemm");
