@@ -254,6 +254,9 @@ class _PlannedConvFn(Function):
 
 
 _RANGES_ONLY = os.environ.get("VDETR_SP_RANGES_ONLY", "0") == "1"  # A/B switch: never use the count-sorted grouping
+_WGRAD_WGS = int(os.environ.get("VDETR_SP_WGRAD_WGS", "768"))  # workgroups per weight-gradient launch (A/B switch)
+
+
 class _PinnedCounts:
     """a ring of pinned host rows for the asynchronous copies of the plans' pair counts (one allocation per process)"""
     rows, width = 512, 64
@@ -396,7 +399,7 @@ class PairPlan:
         t = 128 if (cin >= 128 and cout >= 128) else 64  # channel tile of vdetr_sp_pairs_wgrad_f32
         key = (-(-cin // t)) * (-(-cout // t))
         if key not in self._chunks:
-            want = max(1, 768 // key)
+            want = max(1, _WGRAD_WGS // key)
             L = max(64, -(-(-(-self.P // want)) // 16) * 16)
             kidx, start, length, per = PairPlan._cut(self.counts, self.seg, L)
             n = int(kidx.shape[0])
