@@ -125,3 +125,57 @@ def test_model_with_sparse_backbone_state_dict_layout():
         assert tuple(sd[k].shape) == shape, k
     n = sum(p.numel() for name, p in m.named_parameters() if not name.startswith(("decoder", "encoder_to")))
     assert 67_000_000 < n < 68_500_000  # ResNet34 + FPN: the ~67 M parameters of SURVEY.md §2d
+
+
+def test_pair_plan_tables_cover_every_pair_once():
+    """host statement of the pair lists (PairPlan on CPU tensors): tiles of <= 128 pairs and weight-gradient chunks of equal
+    length partition every offset's segment exactly; the chunk partials of an offset are a contiguous range"""
+    import numpy as np
+    from vdetr_amd import sparse_ops as S
+    rng = np.random.default_rng(3)
+    K, nout, nin = 27, 700, 650
+    nbr = torch.from_numpy(np.where(rng.random((K, nout)) < 0.3, rng.integers(0, nin, (K, nout)), -1).astype(np.int32))
+    nbr[5] = -1                      # an offset without pairs
+    nbr[13] = torch.arange(nout, dtype=torch.int32) % nin  # a full one (the centre offset of a same-stride map)
+    plan = S.PairPlan(nbr, nin)
+    counts = (nbr >= 0).sum(1).tolist()
+    assert plan.counts == counts and plan.P == sum(counts) and plan.seg[-1] == plan.P
+    tiles = plan.tiles.numpy()
+    assert plan.ntiles == sum(-(-c // 128) for c in counts)
+    covered = np.zeros(plan.P, np.int32)
+    for k, start, n in tiles[:plan.ntiles]:
+        assert 0 < n <= 128 and plan.seg[k] <= start and start + n <= plan.seg[k + 1]
+        covered[start:start + n] += 1
+    assert (covered == 1).all()
+    for cin, cout in ((64, 64), (256, 256), (128, 512)):
+        chunks, cseg, n = plan.wgrad_chunks(cin, cout)
+        chunks, cseg = chunks.numpy(), cseg.numpy()
+        assert cseg[0] == 0 and cseg[-1] == n and (np.diff(cseg) >= 0).all() and cseg[6] - cseg[5] == 0
+        covered[:] = 0
+        L = chunks[:n, 2].max()
+        for k, start, ln, slot in chunks[:n]:
+            assert cseg[k] <= slot < cseg[k + 1] and 0 < ln <= L
+            covered[start:start + ln] += 1
+        assert (covered == 1).all()
+        # equal length: only the last chunk of an offset may be shorter
+        for k in range(K):
+            lens = chunks[cseg[k]:cseg[k + 1], 2]
+            assert (lens[:-1] == L).all() if len(lens) > 1 else True
+
+
+def test_morton_codes_order_points_along_the_curve():
+    """pc_util.morton_codes (the tensor-expression statement of csrc/morton.hip): 30-bit codes, monotone along each axis alone,
+    and the stable argsort keeps equal codes in index order"""
+    from vdetr_amd import pc_util
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.rand(2, 500, 3, generator=g) * torch.tensor([8.0, 6.0, 3.0])
+    codes = pc_util.morton_codes(xyz)
+    assert codes.dtype == torch.int64 and int(codes.min()) >= 0 and int(codes.max()) < (1 << 30)
+    line = torch.zeros(1, 64, 3)
+    line[0, :, 1] = torch.linspace(0, 1, 64)
+    c = pc_util.morton_codes(line)[0]
+    assert (c[1:] >= c[:-1]).all()
+    dup = xyz[:1].clone()
+    dup[0, 100] = dup[0, 7]
+    order = pc_util.morton_argsort(dup)[0].tolist()
+    assert order.index(7) < order.index(100)
