@@ -273,9 +273,16 @@ class GradientReducer:
         self._seen = set()  # parameters whose hook has fired in the current step
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._handles = []
+        self._hook_handles = []
         if overlap and self.world > 1 and bucket_views:
             for p in self.params:
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def remove_hooks(self):
+        """detach this reducer from its parameters (before another reducer takes them over)"""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
 
     # ---- hooks (eager mode) -------------------------------------------------------------------------
     def _hook(self, p):
