@@ -240,3 +240,37 @@ def test_pair_plan_device_builder_equals_host_statement(n, ks, seed):
             assert torch.equal(getattr(dev, name).cpu(), getattr(host, name)), name
         c_dev, c_host = dev.wgrad_chunks(64, 64), host.wgrad_chunks(64, 64)
         assert torch.equal(c_dev[0].cpu(), c_host[0]) and torch.equal(c_dev[1].cpu(), c_host[1]) and c_dev[2] == c_host[2]
+
+
+def test_persistent_conv_kernel_work_counters_survive_reuse():
+    """The persistent forward / input-gradient kernel draws its work items from a (work, exit) counter pair out of a ring of 4096
+    that the launch's last workgroup resets.  More launches than the ring has slots, on two streams whose launches overlap:
+    every result must equal the first one bit for bit (a counter left non-zero would silently drop work items)."""
+    from vdetr_amd import sparse_ops as S
+    rng = np.random.default_rng(0)
+    coords = np.unique(rng.integers(0, 14, size=(1500, 3)), axis=0).astype(np.int32)
+    coords = np.concatenate([np.zeros((coords.shape[0], 1), np.int32), coords], 1)
+    keys = torch.sort(S.pack_keys(torch.from_numpy(coords)))[0].cuda()
+    offs = torch.tensor(O.region_offsets(3), dtype=torch.int32).cuda()
+    nbr = S.kernel_map(keys, keys, offs)
+    plan = S.PairPlan(nbr, keys.shape[0]).finalize()
+    assert plan.ntiles > 27
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((keys.shape[0], 128), generator=g).cuda()
+    w = (torch.randn((27, 128, 128), generator=g) / 30).cuda()
+    ref_f = S.pairs_gemm(x, plan.pin, w, plan, False)
+    ref_d = S.pairs_gemm(x, plan.pout, w, plan, True)
+    want = S.gather_sum(ref_f, plan.slot, flat=True)
+    oracle = O.sparse_conv(x.cpu(), w.cpu(), nbr.cpu())
+    assert float((want.cpu() - oracle).abs().max()) <= 2e-5 * float(oracle.abs().max())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    bad = 0
+    for i in range(2300):  # 2 x 2300 launches > 4096 ring slots
+        with torch.cuda.stream(streams[i & 1]):
+            yf = S.pairs_gemm(x, plan.pin, w, plan, False)
+            yd = S.pairs_gemm(x, plan.pout, w, plan, True)
+            if i % 97 == 0 or i > 2290:
+                bad += int(not torch.equal(yf, ref_f)) + int(not torch.equal(yd, ref_d))
+    torch.cuda.synchronize()
+    assert bad == 0
