@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+# (GPU_MAX_HW_QUEUES is left at HIP's default of 4, on purpose — see DESIGN.md §4.12 "Hardware queues": 16 queues cure the
+# backbone leg's `inline` geometry mode but make the criterion leg's captured step 2.3x slower.)
 import numpy as np
 import torch
 
@@ -425,8 +427,9 @@ class BackboneTrainer:
         if mode == "inline":
             # (A/B variant) the step is enqueued: the host builds the geometry of scene i+2 now, on a side stream (two alternate:
             # scene i+1's one-CU sampling kernel may still be running on the other); lookahead 2 = a two-scene loader queue.
-            # 26.0 ms per step in tools/backbone_step_probe.py, but 32.7 inside bench.py's process (after the decoder-only
-            # trainer; forward and captured decoder step stretched by ~50 %, cause not found), where the loader thread gives 26.7.
+            # 26.0-26.2 ms per step in a fresh process or with GPU_MAX_HW_QUEUES=16, 32.7 inside this file's process with HIP's
+            # default of 4 hardware queues (its two side streams then share a queue with the captured decoder step: the 9 ms
+            # sampling kernel sits in front of the step's kernels); the loader thread, on ONE side stream: 25.7-26.3.
             self._queue.append(self._prepare_next(self.sides[self._tick & 1]))
             self._tick += 1
 
