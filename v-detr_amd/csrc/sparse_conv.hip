@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 
   // offset that does not change inside an item and a scalar offset per K-step — no 64-bit vector address arithmetic in the loop
   // (the plain kernel: 16 v_lshl_add_u64 per K-step) and no pointer pairs held in vector registers
   using rsrc_t = __amdgpu_buffer_rsrc_t;
-  auto make_rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000); };
+  // (num_records = 2^32 - 1: the per-lane byte offsets are 32-bit, so the feature table must stay below 4 GB — checked by the
+  // caller, v-detr_amd/sparse_ops.py:pairs_gemm)
+  auto make_rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000); };
   const rsrc_t rX = make_rsrc(X);
   auto a_offsets = [&](const int (&ri)[RT], unsigned (&xo)[RT]) {
 #pragma unroll

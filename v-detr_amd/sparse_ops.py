@@ -416,6 +416,8 @@ def pairs_gemm(x, arow, weight, plan, transposed):
     L.require_float(x, "x")
     L.require_contiguous(x, "x")
     K, cin, cout = weight.shape
+    if x.numel() * 4 >= 2 ** 32 or cin * cout * 4 >= 2 ** 32:
+        raise RuntimeError("pairs_gemm: a feature table of 4 GB or more (32-bit buffer offsets in the persistent kernel): split the batch")
     y = torch.empty((plan.P, cin if transposed else cout), dtype=torch.float32, device=x.device)
     L.check(L.lib().vdetr_sp_pairs_gemm_f32(L.ptr(x), L.ptr(arow), L.ptr(weight), L.ptr(plan.tiles), plan.ntiles, cin, cout,
                                             1 if transposed else 0, L.ptr(y), L.stream_ptr()), "sp_pairs_gemm")
