@@ -217,6 +217,18 @@ def test_full_model_with_sparse_backbone_runs():
         b = model.backbone_forward(dict(inputs, geometry=geo))
     for (xa, fa), (xb, fb) in zip(a, b):
         assert torch.equal(xa, xb) and torch.equal(fa, fb)
+    # ... and the same gradients: its weight-gradient chunk tables were requested by the geometry-only pass and built by
+    # finalize(), the plain pass builds them inside the backward
+    model.train()
+    grads = []
+    for extra in ({}, {"geometry": model.prepare_geometry(inputs)}):
+        model.zero_grad(set_to_none=True)
+        feats = model.backbone_forward(dict(inputs, **extra))
+        sum(f.square().sum() for _, f in feats).backward()
+        grads.append([model.pre_encoder.conv1.kernel.grad.clone(), model.pre_encoder.layer3[0].conv1.kernel.grad.clone(),
+                      model.out_block_0[0].kernel.grad.clone()])
+    for ga, gb in zip(*grads):
+        assert torch.equal(ga, gb)
 
 
 @pytest.mark.parametrize("n,ks,seed", [(3000, 3, 0), (700, 2, 1), (5, 3, 2), (20000, 3, 3)])
