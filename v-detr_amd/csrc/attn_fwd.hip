@@ -370,7 +370,9 @@ static int choose_ksplit(const vdetr_attn_desc* d) {
     // per-head kind: the query self-attention launches H * nQ/16 = 256 workgroups at the model's size, i.e. exactly one
     // per CU — two rounds whenever a CU is busy elsewhere (see below).  Two key halves per (head, query tile) instead.
     // (measured: no gain at nQ = nK = 1024 — the 25 us workgroups are prologue / merge dominated and the combine launch
-    // costs what the second round did; kept behind VDETR_FWD_KSPLIT_PERHEAD for larger self-attentions)
+    // costs what the second round did; kept behind VDETR_FWD_KSPLIT_PERHEAD for larger self-attentions.  Also tried: the
+    // per-head instantiation compiled for 128 VGPRs (two workgroups per CU, so that the 256 workgroups fit next to a busy
+    // CU): 27 spilled registers, 48.7 instead of 41.4 us inside the step)
     static const int ph = [] { const char* v = getenv("VDETR_FWD_KSPLIT_PERHEAD"); return v ? atoi(v) : 1; }();
     const int ntiles = (d->nK + 15) / 16;
     return (ph > 1 && ntiles >= 2 * ph * kFwdWaves) ? ph : 1;
