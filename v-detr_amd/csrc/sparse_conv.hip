@@ -150,12 +150,30 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const float* __restrict_
     const int c4 = (int)(t % C4);
     const int i = (int)(t / C4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < K; ++k) {  // fixed order: deterministic sums
-      const int u = map[(size_t)k * nrows + i];
-      // nmap = 0: src is [rows][K][C] (the im2col layout); nmap = M > 0: src is offset-major [K][M][C]; nmap < 0: the map
-      // holds absolute rows of a flat [P][C] source (the pair lists)
-      if (u >= 0)
-        acc += reinterpret_cast<const f32x4*>(src)[(nmap > 0 ? (size_t)k * nmap + u : nmap < 0 ? (size_t)u : (size_t)u * K + k) * C4 + c4];
+    // nmap = 0: src is [rows][K][C] (the im2col layout); nmap = M > 0: src is offset-major [K][M][C]; nmap < 0: the map
+    // holds absolute rows of a flat [P][C] source (the pair lists).
+    // Eight offsets at a time: their map entries are loaded together, then their rows — an index -> row chain per offset
+    // (27 dependent round trips per thread) left the kernel latency-bound at 3.4 TB/s.  The additions keep the offset order:
+    // deterministic sums.
+#ifndef VDETR_SP_GATHER_G
+#define VDETR_SP_GATHER_G 8
+#endif
+    constexpr int G = VDETR_SP_GATHER_G;
+    for (int k0 = 0; k0 < K; k0 += G) {
+      int u[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) u[j] = k0 + j < K ? map[(size_t)(k0 + j) * nrows + i] : -1;
+      f32x4 v[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int k = k0 + j;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u[j] >= 0)
+          v[j] = reinterpret_cast<const f32x4*>(src)[(nmap > 0 ? (size_t)k * nmap + u[j] : nmap < 0 ? (size_t)u[j] : (size_t)u[j] * K + k) * C4 + c4];
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+        if (u[j] >= 0) acc += v[j];
     }
     reinterpret_cast<f32x4*>(dst)[t] = acc;
   }
