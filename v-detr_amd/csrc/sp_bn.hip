@@ -103,23 +103,35 @@ struct SpBnParams {
 // one workgroup per 4 channels: thread t merges the partials t, t + 256, ... ; the 256 aggregates are merged in index order by
 // a fixed tree through LDS (deterministic); thread 0 stores mean / invstd and updates the running statistics
 __global__ __launch_bounds__(256) void sp_bn_finalize_kernel(SpBnParams P) {
-  __shared__ float lds[256][9];
+  __shared__ float lds[4][9];
   const int c4 = blockIdx.x, tid = threadIdx.x;
   BnAgg a{0.f, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   for (int b = tid; b < P.nblk; b += 256) {
     const float* p = P.part + (size_t)b * 3 * P.C;
     bn_agg_add(a, p[c4 * 4], reinterpret_cast<const f32x4*>(p + P.C)[c4], reinterpret_cast<const f32x4*>(p + 2 * P.C)[c4]);
   }
-  for (int half = 128; half >= 1; half >>= 1) {
-    lds[tid][0] = a.n;
+  // fixed merge tree (deterministic): inside a wave through lane shuffles (no barrier), then the 4 wave aggregates through LDS.
+  // (The first version merged all 256 aggregates through LDS: 8 levels, 16 barriers, 7.8 us for a few KB.)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { lds[tid][1 + e] = a.mu[e]; lds[tid][5 + e] = a.m2[e]; }
-    __syncthreads();
-    if (tid < half) {
-      const float* o = lds[tid + half];
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float on = __shfl_down(a.n, off);
+    f32x4 omu, om2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { omu[e] = __shfl_down(a.mu[e], off); om2[e] = __shfl_down(a.m2[e], off); }
+    if ((tid & 63) < off) bn_agg_add(a, on, omu, om2);
+  }
+  if ((tid & 63) == 0) {
+    float* o = lds[tid >> 6];
+    o[0] = a.n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[1 + e] = a.mu[e]; o[5 + e] = a.m2[e]; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const float* o = lds[w2];
       bn_agg_add(a, o[0], f32x4{o[1], o[2], o[3], o[4]}, f32x4{o[5], o[6], o[7], o[8]});
     }
-    __syncthreads();
   }
   if (tid == 0) {
     const f32x4 mean = a.mu, var = a.m2 / a.n;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void sp_bn_bwd_stats_kernel(SpBnParams P, SpBn
 
 // one workgroup per 4 channels: sums of the partials (thread t: partials t, t + 256, ...; fixed tree) -> sums, dgamma, dbeta
 __global__ __launch_bounds__(256) void sp_bn_bwd_finalize_kernel(SpBnParams P, SpBnGrads G) {
-  __shared__ f32x4 red[2][256];
+  __shared__ f32x4 red[2][4];
   const int c4 = blockIdx.x, tid = threadIdx.x;
   f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
   for (int b = tid; b < P.nblk; b += 256) {
@@ -211,14 +223,19 @@ __global__ __launch_bounds__(256) void sp_bn_bwd_finalize_kernel(SpBnParams P, S
     sg += reinterpret_cast<const f32x4*>(p)[c4];
     sgx += reinterpret_cast<const f32x4*>(p + P.C)[c4];
   }
-  for (int half = 128; half >= 1; half >>= 1) {
-    red[0][tid] = sg;
-    red[1][tid] = sgx;
-    __syncthreads();
-    if (tid < half) { sg += red[0][tid + half]; sgx += red[1][tid + half]; }
-    __syncthreads();
+  // fixed tree: lane shuffles inside a wave, the 4 wave sums through LDS (one barrier instead of 16)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = __shfl_down(sg[e], off), b = __shfl_down(sgx[e], off);
+      if ((tid & 63) < off) { sg[e] += a; sgx[e] += b; }
+    }
   }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sg; red[1][tid >> 6] = sgx; }
+  __syncthreads();
   if (tid == 0) {
+    for (int w2 = 1; w2 < 4; ++w2) { sg += red[0][w2]; sgx += red[1][w2]; }
     reinterpret_cast<f32x4*>(P.sums)[c4] = sg;
     reinterpret_cast<f32x4*>(P.sums + P.C)[c4] = sgx;
     if (G.dgamma) reinterpret_cast<f32x4*>(G.dgamma)[c4] = sgx;
