@@ -145,7 +145,7 @@ class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
     def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True, criterion=None, targets=None,
-                 defer_wg=True):
+                 defer_wg=True, fps_depth=None):
         from vdetr_amd.dist import FlatParams, GradientReducer
         global flush_weight_grads
         from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
@@ -178,9 +178,10 @@ class Trainer:
         # step the way a forked branch of the hipGraph must.  What a data loader with a two-scene queue provides.
         # Measured: C4 (80k points, FPS 10.7 ms) 12.15 -> 11.14 ms per step; C2 (FPS 9.5 ms < step) 10.65 -> 11.12 ms (two
         # CUs busy, eager launches between the replays): used when the sampling does not fit inside a step.
-        depth = os.environ.get("VDETR_FPS_DEPTH", "auto")
-        big = max(int(x.shape[0]) for x in inputs["backbone_xyz"]) >= 60000
-        self.fps_depth2 = fps_prefetch and use_graph and (depth == "2" or (depth == "auto" and big))
+        # Which one: main() MEASURES it (`choose_fps_depth`: when the sampling alone takes more than 0.8 of the captured
+        # depth-1 step, a depth-2 trainer is captured as well and the faster one kept); VDETR_FPS_DEPTH=1 / 2 forces it.
+        depth = str(fps_depth) if fps_depth is not None else os.environ.get("VDETR_FPS_DEPTH", "auto")
+        self.fps_depth2 = fps_prefetch and use_graph and depth == "2"
         if fps_prefetch:
             self.side = torch.cuda.Stream()
             self.cur_inds = model.sample_indices(inputs)
@@ -433,6 +434,29 @@ class BackboneTrainer:
             self._queue.append(self._prepare_next(self.sides[self._tick & 1]))
             self._tick += 1
 
+    def calibrate_side_stream(self, candidates=4, steps=4):
+        """HIP maps the streams of a process onto 4 hardware queues; a side stream that lands on the queue of the step's own
+        streams puts the next scene's 9 ms sampling kernel IN FRONT of the step's kernels (25 -> 29-33 ms per step, depending on
+        how many streams the process created before: measured in this file's own process).  Which queue a stream gets cannot be
+        asked, but it can be measured: a few steps with each of several candidate streams, keep the fastest.  Once per process."""
+        best = (None, float("inf"))
+        for cand in [self.side] + [torch.cuda.Stream() for _ in range(candidates - 1)]:
+            self.close()
+            self.side = cand
+            for _ in range(3):
+                self.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            if ms < best[1]:
+                best = (cand, ms)
+        self.close()
+        self.side = best[0]
+        return best[1]
+
     def close(self):
         if self._worker is not None:
             self._worker.join()
@@ -646,15 +670,67 @@ def main():
             from vdetr_amd.criterion import build_criterion, default_criterion_args
             crit = build_criterion(default_criterion_args(), model.dataset_config)
             targets = make_targets(a.config, device, rank)
+            crit_holder[0], crit_holder[1] = crit, targets
         return Trainer(model, inputs, world, use_graph, overlap=True, fps_prefetch=not a.no_fps_prefetch, criterion=crit,
                        targets=targets, defer_wg=not a.no_defer_wg)
 
+    def replay_ms(tr, reps=6):
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tr.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def choose_fps_depth(tr):
+        """depth 1 (the next scene's sampling as a forked branch of the captured step) or depth 2 (two scenes' samplings in
+        flight on side streams outside the graph)?  Measured, not guessed: the one-CU sampling kernel takes 2.1 ms (4k points)
+        to 10.7 ms (80k), the rest of the step 3 to 11 ms.  Every rank decides for itself (the graphs are rank-local)."""
+        if os.environ.get("VDETR_FPS_DEPTH", "auto") != "auto" or a.no_fps_prefetch or tr.fps_depth2:
+            return tr
+        t1 = replay_ms(tr)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        model.sample_indices(inputs)
+        ev0.record()
+        model.sample_indices(inputs)
+        ev1.record()
+        ev1.synchronize()
+        t_fps = ev0.elapsed_time(ev1)
+
+        def over_ranks(x):  # the ranks must take the same branches (the steps below contain collectives): max over the ranks
+            if world == 1:
+                return x
+            t = torch.tensor([x], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+        t1, t_fps = over_ranks(t1), over_ranks(t_fps)
+        if t_fps <= 0.8 * t1:
+            return tr
+        tr2 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=tr.criterion and crit_holder[0],
+                      targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=2)
+        tr2.capture()
+        t2 = over_ranks(replay_ms(tr2))
+        if rank == 0:
+            print(f"[bench] sampling {t_fps:.2f} ms vs captured step {t1:.2f} ms (one scene's sampling in flight) / {t2:.2f} ms (two): "
+                  f"fps_lookahead {2 if t2 < 0.97 * t1 else 1}", file=sys.stderr)
+        if t2 < 0.97 * t1:  # (a tie goes to the simpler form: one side stream, no eager launches between the replays)
+            return tr2
+        # (tr2 has re-laid the parameters into flat buffers of its own: the first trainer's graph points at the old ones)
+        tr1 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=tr.criterion and crit_holder[0],
+                      targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=1)
+        tr1.capture()
+        return tr1
+
+    crit_holder = [None, None]
     trainer = make_trainer(a.loss == "criterion")
     graph_ok = False
     if use_graph:
         try:
             trainer.capture()
             graph_ok = True
+            trainer = choose_fps_depth(trainer)
         except Exception as e:  # capture is an optimisation: report and fall back to eager launches
             if rank == 0:
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
@@ -727,6 +803,8 @@ def main():
         try:
             if use_graph:
                 bt.capture()
+            if os.environ.get("VDETR_BENCH_GEOMETRY", "thread") == "thread":
+                bt.calibrate_side_stream()
             for _ in range(max(a.warmup, 8)):  # (the two-scene queue and the allocator pools of its two streams take a few steps to settle)
                 bt.step()
             torch.cuda.synchronize()
