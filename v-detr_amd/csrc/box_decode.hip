@@ -30,8 +30,12 @@ __device__ __forceinline__ void box_corners(float l, float w, float h, float c, 
   }
 }
 
-__global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_desc d) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+// One wave per workgroup: a query's ~130 outputs are scattered stores (stride 96 B for the corners), i.e. ~64 memory transactions
+// per wave instruction, and the four waves of a 256-thread workgroup queued them all on ONE CU's address unit (15 us for 1024
+// queries on 4 CUs); 64-thread workgroups spread the same waves over 16 CUs.
+constexpr int kBoxThreads = 64;
+__global__ __launch_bounds__(kBoxThreads) void box_decode_fwd_kernel(vdetr_box_decode_desc d) {
+  const int t = blockIdx.x * kBoxThreads + threadIdx.x;
   if (t >= d.B * d.N) return;
   const int b = t / d.N, n = t - b * d.N;
   const size_t o3 = (size_t)t * 3;
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(256) void box_decode_fwd_kernel(vdetr_box_decode_de
 }
 
 // Backward: every incoming gradient pointer may be NULL (that output was not used).
-__global__ __launch_bounds__(256) void box_decode_bwd_kernel(vdetr_box_decode_desc d, vdetr_box_decode_grads g) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(kBoxThreads) void box_decode_bwd_kernel(vdetr_box_decode_desc d, vdetr_box_decode_grads g) {
+  const int t = blockIdx.x * kBoxThreads + threadIdx.x;
   if (t >= d.B * d.N) return;
   const int b = t / d.N, n = t - b * d.N;
   const size_t o3 = (size_t)t * 3;
@@ -254,7 +258,7 @@ extern "C" int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_st
                     d->angle_class && d->corners && d->objectness,
                 "box_decode_fwd: null output pointer");
   VDETR_REQUIRE(d->cls_kind != VDETR_CLS_SOFTMAX || d->cls_prob, "box_decode_fwd: cls_prob is required for the softmax kind");
-  hipLaunchKernelGGL(box_decode_fwd_kernel, dim3(ceil_div((long)d->B * d->N, 256)), dim3(256), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(box_decode_fwd_kernel, dim3(ceil_div((long)d->B * d->N, kBoxThreads)), dim3(kBoxThreads), 0, (hipStream_t)stream, *d);
   return check_launch("box_decode_fwd");
 }
 
@@ -265,6 +269,6 @@ extern "C" int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vd
   VDETR_REQUIRE(d->size_unnorm && d->pre_size_unnorm && d->angle_cont && d->angle_class,
                 "box_decode_bwd: the forward's size_unnorm / pre_size_unnorm / angle_cont / angle_class are required");
   VDETR_REQUIRE(g->d_center && g->d_size && g->d_angle_cls && g->d_angle_res, "box_decode_bwd: null output pointer");
-  hipLaunchKernelGGL(box_decode_bwd_kernel, dim3(ceil_div((long)d->B * d->N, 256)), dim3(256), 0, (hipStream_t)stream, *d, *g);
+  hipLaunchKernelGGL(box_decode_bwd_kernel, dim3(ceil_div((long)d->B * d->N, kBoxThreads)), dim3(kBoxThreads), 0, (hipStream_t)stream, *d, *g);
   return check_launch("box_decode_bwd");
 }
