@@ -286,3 +286,40 @@ def test_persistent_conv_kernel_work_counters_survive_reuse():
                 bad += int(not torch.equal(yf, ref_f)) + int(not torch.equal(yd, ref_d))
     torch.cuda.synchronize()
     assert bad == 0
+
+
+def test_sparse_conv_full_size_linearity_and_adjoints():
+    """BASELINE-size geometry (40k-point room scan, stride-4 sites, 3x3x3 kernel, 64 -> 128 channels), where the CPU oracle
+    would take minutes: size-independent properties instead.  Linearity of the forward map; the input gradient is its adjoint
+    (<conv(x), y> = <x, dgrad(y)>); the weight gradient is the adjoint in W (<conv_W(x), y> = <W, dW>)."""
+    import bench
+    from vdetr_amd import minkowski as ME
+    from vdetr_amd import sparse_ops as S
+    dev = torch.device("cuda")
+    cloud = bench.make_room_cloud(40000, 0, dev)
+    coords, _ = ME.batch_sparse_collate([(cloud / 0.01, cloud)])
+    cm = ME.CoordinateManager(dev)
+    cm.insert_points(coords)
+    k2 = cm.strided(cm.keys[1], 1, 2)
+    k4 = cm.strided(k2, 2, 4)
+    nbr, inv, plan = cm.kernel_map(k4, k4, 4, 4, 3, False)
+    n = k4.shape[0]
+    assert n > 30000 and plan.P > 3 * n
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((n, 64), generator=g).to(dev).requires_grad_(True)
+    z = torch.randn((n, 64), generator=g).to(dev)
+    w = (torch.randn((27, 64, 128), generator=g) / 20).to(dev).requires_grad_(True)
+    y = torch.randn((n, 128), generator=g).to(dev)
+    out = S.sparse_conv(x, w, nbr, inv, plan)
+    lin = S.sparse_conv((2.0 * x + 3.0 * z).detach(), w.detach(), nbr, inv, plan)
+    ref = 2.0 * out.detach() + 3.0 * S.sparse_conv(z, w.detach(), nbr, inv, plan)
+    assert float((lin - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    inner = (out.detach().double() * y.double()).sum()
+    out.backward(y)
+    via_x = (x.detach().double() * x.grad.double()).sum()
+    via_w = (w.detach().double() * w.grad.double()).sum()
+    assert abs(float(via_x - inner)) <= 1e-5 * abs(float(inner)) + 1e-3
+    assert abs(float(via_w - inner)) <= 1e-5 * abs(float(inner)) + 1e-3
+    # every output row that has no neighbour at all is exactly zero, and the centre offset alone reproduces x W[13]
+    centre_only = S.sparse_conv(x.detach(), w.detach() * (torch.arange(27, device=dev) == 13).float()[:, None, None], nbr, inv, plan)
+    assert float((centre_only - x.detach() @ w.detach()[13]).abs().max()) <= 1e-5 * float(centre_only.abs().max())
