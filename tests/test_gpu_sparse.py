@@ -323,3 +323,32 @@ def test_sparse_conv_full_size_linearity_and_adjoints():
     # every output row that has no neighbour at all is exactly zero, and the centre offset alone reproduces x W[13]
     centre_only = S.sparse_conv(x.detach(), w.detach() * (torch.arange(27, device=dev) == 13).float()[:, None, None], nbr, inv, plan)
     assert float((centre_only - x.detach() @ w.detach()[13]).abs().max()) <= 1e-5 * float(centre_only.abs().max())
+
+
+def test_fused_batchnorm_full_size_properties():
+    """36k rows x 128 channels (a stride-4 feature table of a 40k-point scene): per-channel mean / variance of the normalised
+    output, running statistics, and the two orthogonality relations of BatchNorm's input gradient (sum_r dx = 0,
+    sum_r dx * xhat = 0 per channel), with a badly centred input (mean 50 x std: E[x^2] - mean^2 would cancel)."""
+    from vdetr_amd import sparse_ops as S
+    g = torch.Generator().manual_seed(2)
+    N, C = 36363, 128
+    x = (torch.randn((N, C), generator=g) * 0.7 + 35.0).cuda().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+    y = S.bn_act(x, bn)
+    yd = y.detach().double()
+    assert float((yd.mean(0) - bn.bias.detach().double()).abs().max()) < 2e-5
+    assert float((yd.var(0, unbiased=False).sqrt() - bn.weight.detach().double().abs()).abs().max()) < 2e-4
+    xd = x.detach().double()
+    assert float((bn.running_mean.double() - 0.1 * xd.mean(0)).abs().max()) < 1e-4
+    assert float((bn.running_var.double() - (0.9 + 0.1 * xd.var(0, unbiased=True))).abs().max()) < 1e-4
+    dy = torch.randn((N, C), generator=g).cuda()
+    y.backward(dy)
+    dx = x.grad.double()
+    xhat = (xd - xd.mean(0)) / xd.var(0, unbiased=False).add(bn.eps).sqrt()
+    scale = float(dx.abs().sum(0).max())
+    assert float(dx.sum(0).abs().max()) < 1e-5 * scale
+    assert float((dx * xhat).sum(0).abs().max()) < 1e-5 * scale
+    assert float((bn.bias.grad.double() - dy.double().sum(0)).abs().max()) < 1e-4 * float(dy.double().sum(0).abs().max() + 1)
