@@ -352,3 +352,34 @@ def test_fused_batchnorm_full_size_properties():
     assert float(dx.sum(0).abs().max()) < 1e-5 * scale
     assert float((dx * xhat).sum(0).abs().max()) < 1e-5 * scale
     assert float((bn.bias.grad.double() - dy.double().sum(0)).abs().max()) < 1e-4 * float(dy.double().sum(0).abs().max() + 1)
+
+
+def test_kernel_map_full_size_symmetry():
+    """same-stride 3x3x3 map of a 40k-point scene's stride-4 sites: offset k and its opposite 26 - k are inverse relations
+    (u reads i through k  <=>  i reads u through 26 - k), the centre offset is the identity, and the device-built pair lists
+    agree with the map entry by entry (integer work: exact)."""
+    import bench
+    from vdetr_amd import minkowski as ME
+    dev = torch.device("cuda")
+    cloud = bench.make_room_cloud(40000, 1, dev)
+    coords, _ = ME.batch_sparse_collate([(cloud / 0.01, cloud)])
+    cm = ME.CoordinateManager(dev)
+    cm.insert_points(coords)
+    k4 = cm.strided(cm.strided(cm.keys[1], 1, 2), 2, 4)
+    nbr, _, plan = cm.kernel_map(k4, k4, 4, 4, 3, False)
+    n = k4.shape[0]
+    ar = torch.arange(n, device=dev, dtype=torch.int32)
+    assert torch.equal(nbr[13], ar)
+    for k in (0, 5, 12):
+        u = torch.nonzero(nbr[k] >= 0)[:, 0]
+        i = nbr[k][u].long()
+        assert torch.equal(nbr[26 - k][i].long(), u)
+        assert int((nbr[k] >= 0).sum()) == int((nbr[26 - k] >= 0).sum())
+    plan.finalize()
+    assert plan.P == int((nbr >= 0).sum()) and plan.counts[13] == n
+    p = torch.arange(plan.P, device=dev)
+    kidx = torch.repeat_interleave(torch.arange(27, device=dev), torch.tensor(plan.counts, device=dev))
+    assert torch.equal(nbr[kidx, plan.pout.long()], plan.pin)                     # pair p is (pin, pout) of offset k(p)
+    assert torch.equal(plan.slot[kidx, plan.pout.long()].long(), p)              # slot finds the pair back from its output row
+    assert torch.equal(plan.islot[kidx, plan.pin.long()].long(), p)              # islot from its input row
+    assert int((plan.slot >= 0).sum()) == plan.P and int((plan.islot >= 0).sum()) == plan.P
