@@ -51,6 +51,23 @@ def test_argument_errors_do_not_exit():
     assert b"4 heads" in lib.vdetr_last_error()
 
 
+def test_round2_entry_points_reject_bad_arguments():
+    """the sparse-convolution / Morton entry points added in round 2: argument errors are status codes with a message"""
+    from vdetr_amd import _lib
+    lib = _lib.lib()
+    assert lib.vdetr_sp_pair_plan_workspace_ints(27, 1000) == 27 * 4
+    assert lib.vdetr_sp_pair_plan_i32(None, 0, 10, 10, None, None, None, None, None, None, None) == 1
+    assert b"sp_pair_plan" in lib.vdetr_last_error()
+    assert lib.vdetr_sp_wgrad_reduce_f32(None, None, 27, 6, None, None) == 1      # elems not a multiple of 4
+    assert b"sp_wgrad_reduce" in lib.vdetr_last_error()
+    assert lib.vdetr_morton_sort_max() == 8192
+    assert lib.vdetr_morton_order_f32(None, 1, 16, None, None, None) == 1
+    assert b"morton_order" in lib.vdetr_last_error()
+    assert lib.vdetr_sp_pairs_gemm_f32(None, None, None, None, 5, 24, 64, 0, None, None) == 1
+    assert b"sp_pairs_gemm" in lib.vdetr_last_error()
+    assert lib.vdetr_sp_pairs_gemm_f32(None, None, None, None, 0, 16, 16, 0, None, None) == 0   # no tiles: no-op
+
+
 def test_ops_refuse_cpu_tensors():
     """No CPU fallback: the reference asserts "CPU not supported" (sampling.cpp:36,62,84)."""
     from vdetr_amd import pointnet2_utils as PU
