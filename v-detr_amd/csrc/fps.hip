@@ -25,8 +25,7 @@
 //             any reduction shape reproduces it.
 // Work drops from n*(m-1) distance evaluations to roughly 4 n ln m; the per-round cost is a few L2
 // round trips instead of a 640 KB sweep.
-#include "common.h"
-#include "wave.h"
+#include "fps.h"
 
 #include <stdlib.h>
 
@@ -39,7 +38,6 @@ constexpr int kFpsMaxBuckets = kFpsWaves * kWave * kFpsSlots;  // 4096
 constexpr int kGridBits = 4;
 constexpr int kCells = 1 << (3 * kGridBits);  // 4096
 
-constexpr int kFpsMaxScenes = 32;  // scenes of one variable-length launch
 struct FpsScene {    // one scene of a variable-length batch: its own cloud, size and sorting geometry
   const float* xyz;  // (n,3)
   long ws_off;       // first workspace element of this scene
@@ -60,14 +58,11 @@ struct FpsParams {
   FpsScene scenes[kFpsMaxScenes];
 };
 
-__device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
 __device__ __forceinline__ unsigned spread3(unsigned v) {  // 4 bits -> every third bit
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
-// Candidate order: largest running distance t, then smallest tie key.  t >= 0 for every candidate, so its bit
-// pattern is monotone as an unsigned; non-candidates (origin-skip, padding: t = -inf) rank as 0.
-__device__ __forceinline__ unsigned rank_of(float t) { return t >= 0.f ? __float_as_uint(t) + 1u : 0u; }
-__device__ __forceinline__ float t_of_rank(unsigned r) { return r ? __uint_as_float(r - 1u) : -INFINITY; }
+__device__ __forceinline__ unsigned rank_of(float t) { return fps_rank_of(t); }
+__device__ __forceinline__ float t_of_rank(unsigned r) { return fps_t_of_rank(r); }
 
 // wave arg-max of (rank desc, key asc): two 32-bit all-reduces; returns the winning lane
 struct WaveBest {
@@ -190,7 +185,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams Pin) {
     const float mag = __fmaf_rn(z, z, __fmaf_rn(x, x, __fmul_rn(y, y)));
     const bool skip = (double)mag <= 1e-3;
     pts[pos] = make_float4(x, y, z, skip ? -INFINITY : 1e10f);
-    keys[pos] = (bitrev((unsigned)k % rb, P.ref_log2) << 22) | ((unsigned)k / rb);
+    keys[pos] = fps_tie_key((unsigned)k, rb, P.ref_log2);
   }
   const float p0x = xyz[0], p0y = xyz[1], p0z = xyz[2];
   for (int k = n + tid; k < P.npad; k += kFpsThreads) {
@@ -339,7 +334,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(FpsParams Pin) {
     const int ws = (__ffsll((long long)__ballot(srank == grank && skey == gkey)) - 1) & (kFpsWaves - 1);
     int winner = 0;
     if (grank) {
-      winner = (int)((gkey & 0x3FFFFFu) * rb + bitrev(gkey >> 22, P.ref_log2));
+      winner = fps_decode_key(gkey, rb, P.ref_log2);
       cx = s_bxyz[par][ws][0]; cy = s_bxyz[par][ws][1]; cz = s_bxyz[par][ws][2];
     } else {  // no candidate at all: the reference's reduction returns besti = 0 (:93-94)
       cx = p0x; cy = p0y; cz = p0z;
@@ -368,18 +363,19 @@ static int fps_geometry(int n, int* npad, int* bucket_pts, int* nbuckets) {
   return 0;
 }
 
-// opt_n_threads(n): 2^floor(log2 n) clamped to [1,512] (cuda_utils.h:17-21)
-static int ref_log2_of(int n) {
-  int lg = 0;
-  while ((2L << lg) <= (long)n) ++lg;
-  return lg > 9 ? 9 : lg;
+static int ref_log2_of(int n) { return fps_ref_log2_of(n); }
+
+// points of workspace one scene of n points needs: whichever kernel takes it (their paddings differ)
+static size_t ws_points(int n) {
+  int npad, bp, nb;
+  fps_geometry(n, &npad, &bp, &nb);
+  const size_t rows = n > 0 ? (size_t)n + kWave : 0;  // fps_rows.hip pads to a multiple of 16/32/64
+  return rows > (size_t)npad ? rows : (size_t)npad;
 }
 
 extern "C" size_t vdetr_fps_workspace_bytes(int b, int n) {
-  int npad, bp, nb;
-  fps_geometry(n, &npad, &bp, &nb);
   if (b <= 0) return 0;
-  return (size_t)b * (size_t)npad * (sizeof(float4) + sizeof(uint32_t)) + 256;
+  return (size_t)b * ws_points(n) * (sizeof(float4) + sizeof(uint32_t)) + 256;
 }
 
 extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n, int m, int32_t* idx,
@@ -390,14 +386,32 @@ extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n,
   VDETR_REQUIRE(n > 0, "furthest_point_sampling: empty cloud with nsamples=%d", m);
   VDETR_REQUIRE(xyz && idx, "furthest_point_sampling: null pointer");
   VDETR_REQUIRE((long)n < (1L << 30), "furthest_point_sampling: n=%d too large", n);
-  FpsParams P;
-  fps_geometry(n, &P.npad, &P.bucket_pts, &P.nbuckets);
   const size_t need = vdetr_fps_workspace_bytes(b, n);
   if (!workspace || workspace_bytes < need) {
     set_error("furthest_point_sampling: workspace %zu B < required %zu B", workspace_bytes, need);
     return VDETR_ERR_WORKSPACE;
   }
   uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  RowsPlan plan;
+  if (b <= kFpsMaxScenes && fps_rows_plan(n, &plan)) {  // the row-per-bucket kernel (fps_rows.hip)
+    RowsParams R{};
+    const long npad = fps_rows_npad(n, plan);
+    R.pts = (float4*)base;
+    R.keys = (uint32_t*)(base + (size_t)b * npad * sizeof(float4));
+    R.m = m;
+    for (int i = 0; i < b; ++i) {
+      RowsScene& S = R.scenes[i];
+      S.xyz = xyz + (size_t)i * n * 3;
+      S.idx = idx + (size_t)i * m;
+      S.ws_off = (long)i * npad;
+      S.n = n;
+      S.ref_log2 = ref_log2_of(n);
+      S.ref_block = 1 << S.ref_log2;
+    }
+    return fps_rows_launch(R, b, plan, (hipStream_t)stream);
+  }
+  FpsParams P;
+  fps_geometry(n, &P.npad, &P.bucket_pts, &P.nbuckets);
   P.pts = (float4*)base;
   P.keys = (uint32_t*)(base + (size_t)b * P.npad * sizeof(float4));
   P.xyz = xyz; P.idx = idx; P.n = n; P.m = m;
@@ -422,9 +436,7 @@ extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n,
 extern "C" size_t vdetr_fps_varlen_workspace_bytes(const int32_t* counts, int b) {
   size_t total = 0;
   for (int i = 0; i < b; ++i) {
-    int npad, bp, nb;
-    fps_geometry(counts[i], &npad, &bp, &nb);
-    total += (size_t)npad;
+    total += ws_points(counts[i]);
   }
   return b > 0 ? total * (sizeof(float4) + sizeof(uint32_t)) + 256 : 0;
 }
@@ -440,11 +452,35 @@ extern "C" int vdetr_furthest_point_sampling_varlen_f32(const float* const* xyz,
     set_error("furthest_point_sampling_varlen: workspace %zu B < required %zu B", workspace_bytes, need);
     return VDETR_ERR_WORKSPACE;
   }
-  FpsParams P{};
-  long total = 0;
+  int nmax = 0;
   for (int i = 0; i < b; ++i) {
     VDETR_REQUIRE(counts[i] > 0 && (long)counts[i] < (1L << 30), "furthest_point_sampling_varlen: scene %d has %d points", i, counts[i]);
     VDETR_REQUIRE(xyz[i] != nullptr, "furthest_point_sampling_varlen: scene %d: null pointer", i);
+    nmax = counts[i] > nmax ? counts[i] : nmax;
+  }
+  RowsPlan plan;
+  if (fps_rows_plan(nmax, &plan)) {  // one bucket size for the launch, chosen for the largest scene
+    RowsParams R{};
+    long total = 0;
+    for (int i = 0; i < b; ++i) {
+      RowsScene& S = R.scenes[i];
+      S.xyz = xyz[i];
+      S.idx = idx + (size_t)i * m;
+      S.ws_off = total;
+      S.n = counts[i];
+      S.ref_log2 = ref_log2_of(S.n);
+      S.ref_block = 1 << S.ref_log2;
+      total += fps_rows_npad(S.n, plan);
+    }
+    uintptr_t rbase = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    R.pts = (float4*)rbase;
+    R.keys = (uint32_t*)(rbase + (size_t)total * sizeof(float4));
+    R.m = m;
+    return fps_rows_launch(R, b, plan, (hipStream_t)stream);
+  }
+  FpsParams P{};
+  long total = 0;
+  for (int i = 0; i < b; ++i) {
     FpsScene& S = P.scenes[i];
     S.xyz = xyz[i];
     S.n = counts[i];

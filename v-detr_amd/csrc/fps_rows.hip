@@ -1,0 +1,464 @@
+// fps_rows.hip — furthest point sampling, row-per-bucket kernel: the fast path of
+// vdetr_furthest_point_sampling(_varlen)_f32.  Bit-exact with the reference's result
+// (third_party/pointnet2/_ext_src/src/sampling_gpu.cu:73-176), like fps.hip, and built on the same exact
+// box-skip argument (see fps.hip's header); what differs is how a round's dependent chain is laid out.
+//
+// One workgroup of W waves per scene.  The cloud is counting-sorted into Z-order over 2^15 near-cubic cells
+// (the split sequence follows the cloud's aspect ratio) and cut into BUCKETS of BP = 16/32/64 consecutive points.
+// Bucket g belongs to wave g % W for good: its bounding box, current max running distance (as an order-preserving
+// rank) and the tie key of that max live in the registers of an owner lane of that wave, the coordinates of the
+// max in LDS (cand[g]).
+//
+// Round j, per wave, ONE workgroup barrier:
+//   test    every owner lane: is the new sample closer to my box than my bucket's max?       (13 VALU per slot)
+//   passes  the wave's surviving buckets, 64/BP of them per pass, one bucket per group of BP lanes: one 16-B load
+//           per lane, distance/min/store, a log2(BP)-stage DPP all-reduce of the rank, a second one of the tie
+//           key; the winner lane refreshes cand[g], the owner lane takes (rank, key) by v_readlane.
+//   reduce  arg-max over the wave's owner lanes (6+6 stages), its coordinates from cand[], 5 words to LDS
+//   barrier (LDS only: the running-distance stores are re-read by the same wave, nobody else needs them)
+//   decode  every 16-lane row all-reduces the W entries (4+4 stages), v_readlane of the winner's coordinates.
+// fps.hip spends a 64-lane reduction per surviving bucket and keeps 4 buckets in flight per wave; here a pass
+// retires 64/BP buckets with shorter reductions, the boxes are smaller (fewer survivors), and the exchange
+// carries the coordinates, so no dependent lookup follows the barrier.
+#include "fps.h"
+
+#include <stdlib.h>
+
+namespace vdetr {
+
+constexpr int kRowsCellBits = 15;
+constexpr int kRowsCells = 1 << kRowsCellBits;
+constexpr int kRowsHistWords = kRowsCells + (kRowsCells >> 5);  // one pad word per 32 cells
+__device__ __forceinline__ int hidx(int c) { return c + (c >> 5); }
+
+template <int BP>
+__device__ __forceinline__ unsigned grp_allmax_u32(unsigned v) {
+  v = row_allmax_u32_fx(v);
+  if (BP >= 32) { const pair_u32 p = xrow16(v); v = max(p.a, p.b); }
+  if (BP >= 64) { const pair_u32 p = xhalf32(v); v = max(p.a, p.b); }
+  return v;
+}
+template <int BP>
+__device__ __forceinline__ unsigned grp_allmin_u32(unsigned v) {
+  v = row_allmin_u32_fx(v);
+  if (BP >= 32) { const pair_u32 p = xrow16(v); v = min(p.a, p.b); }
+  if (BP >= 64) { const pair_u32 p = xhalf32(v); v = min(p.a, p.b); }
+  return v;
+}
+template <int BP>
+__device__ __forceinline__ float grp_allmax_f32(float v) {
+  v = row_allmax_f32(v);
+  if (BP >= 32) { const pair_u32 p = xrow16(__float_as_uint(v)); v = fmaxf(__uint_as_float(p.a), __uint_as_float(p.b)); }
+  if (BP >= 64) { const pair_u32 p = xhalf32(__float_as_uint(v)); v = fmaxf(__uint_as_float(p.a), __uint_as_float(p.b)); }
+  return v;
+}
+template <int BP>
+__device__ __forceinline__ float grp_allmin_f32(float v) { return -grp_allmax_f32<BP>(-v); }
+
+// deposits the low bits of c at the set bits of m, lowest first (m is wave-uniform: a scalar loop)
+__device__ __forceinline__ unsigned deposit_bits(unsigned c, unsigned m) {
+  unsigned r = 0;
+  while (m) {
+    const unsigned low = m & (0u - m);
+    if (c & 1u) r |= low;
+    c >>= 1;
+    m ^= low;
+  }
+  return r;
+}
+
+__device__ unsigned long long g_rows_cyc[16][8];
+__device__ __forceinline__ unsigned long long rows_clock() {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+template <int W, int BP, bool DEBUG>
+__global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
+  constexpr int T = W * kWave;
+  constexpr int GPP = kWave / BP;  // buckets per pass
+  extern __shared__ __align__(16) unsigned char smem[];
+  int* const s_hist = reinterpret_cast<int*>(smem);     // prologue
+  float4* const s_cand = reinterpret_cast<float4*>(smem);  // rounds: (x,y,z,key) of every bucket's max
+  __shared__ int s_wsum[W];
+  __shared__ float s_red[W][6];
+  __shared__ unsigned s_xr[2][16];
+  __shared__ float4 s_xc[2][16];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const RowsScene S = Pin.scenes[blockIdx.x];
+  const float* __restrict__ xyz = S.xyz;
+  int32_t* __restrict__ out = S.idx;
+  float4* __restrict__ pts = Pin.pts + S.ws_off;
+  uint32_t* __restrict__ keys = Pin.keys + S.ws_off;
+  const int n = S.n, nb = S.nbuckets, npad = nb * BP, m = Pin.m;
+  const unsigned rb = (unsigned)S.ref_block;
+
+  // ---- prologue 1: bounding box of the cloud, the split sequence of the cell grid ------------------------------
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = tid; k < n; k += T) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = xyz[k * 3 + a];
+      lo[a] = fminf(lo[a], v);
+      hi[a] = fmaxf(hi[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_allmin_f32(lo[a]);
+    hi[a] = wave_allmax_f32(hi[a]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s_red[w][a] = lo[a]; s_red[w][3 + a] = hi[a]; }
+  }
+  for (int c = tid; c < kRowsHistWords; c += T) s_hist[c] = 0;
+  __syncthreads();
+  float scale[3], cmaxf[3];
+  unsigned dep[3] = {0u, 0u, 0u};
+  {
+    float ext[3];
+    int bits[3] = {0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float l = s_red[0][a], h = s_red[0][3 + a];
+      for (int ww = 1; ww < W; ++ww) { l = fminf(l, s_red[ww][a]); h = fmaxf(h, s_red[ww][3 + a]); }
+      lo[a] = l;
+      const float e = h - l;
+      ext[a] = (e > 0.f && e < INFINITY) ? e : 0.f;
+    }
+    float cell[3] = {ext[0], ext[1], ext[2]};
+    for (int i = 0; i < kRowsCellBits; ++i) {  // halve the longest cell edge: near-cubic cells whatever the aspect ratio
+      const int a = (cell[0] >= cell[1] && cell[0] >= cell[2]) ? 0 : (cell[1] >= cell[2] ? 1 : 2);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (q == a) { dep[q] |= 1u << (kRowsCellBits - 1 - i); ++bits[q]; cell[q] *= 0.5f; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      scale[a] = ext[a] > 0.f ? (float)(1 << bits[a]) / ext[a] : 0.f;
+      cmaxf[a] = (float)((1 << bits[a]) - 1);
+    }
+  }
+  auto cell_of = [&](float x, float y, float z) -> int {
+    // NaN / inf coordinates fall into cell 0 of their axis (the cast of NaN is made harmless by the integer clamp)
+    int cx = (int)fminf(fmaxf((x - lo[0]) * scale[0], 0.f), cmaxf[0]);
+    int cy = (int)fminf(fmaxf((y - lo[1]) * scale[1], 0.f), cmaxf[1]);
+    int cz = (int)fminf(fmaxf((z - lo[2]) * scale[2], 0.f), cmaxf[2]);
+    cx = min(max(cx, 0), (int)cmaxf[0]); cy = min(max(cy, 0), (int)cmaxf[1]); cz = min(max(cz, 0), (int)cmaxf[2]);
+    return (int)(deposit_bits((unsigned)cx, dep[0]) | deposit_bits((unsigned)cy, dep[1]) | deposit_bits((unsigned)cz, dep[2]));
+  };
+
+  // ---- prologue 2: histogram, exclusive scan, scatter ------------------------------------------------------------
+  for (int k = tid; k < n; k += T) atomicAdd(&s_hist[hidx(cell_of(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]))], 1);
+  __syncthreads();
+  {
+    constexpr int kPer = kRowsCells / T;  // consecutive cells per thread (32 or 64)
+    int sum = 0;
+    for (int i = 0; i < kPer; ++i) sum += s_hist[hidx(tid * kPer + i)];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) s_wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int ww = 0; ww < w; ++ww) base += s_wsum[ww];
+    int run = base + incl - sum;
+    for (int i = 0; i < kPer; ++i) {
+      const int v = s_hist[hidx(tid * kPer + i)];
+      s_hist[hidx(tid * kPer + i)] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += T) {
+    const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+    const int pos = atomicAdd(&s_hist[hidx(cell_of(x, y, z))], 1);
+    // origin-skip rule: `if (mag <= 1e-3) continue;` compares the float mag against a DOUBLE literal
+    // (sampling_gpu.cu:103-104); mag in the same contraction order as the distance.
+    const float mag = __fmaf_rn(z, z, __fmaf_rn(x, x, __fmul_rn(y, y)));
+    const bool skip = (double)mag <= 1e-3;
+    pts[pos] = make_float4(x, y, z, skip ? -INFINITY : 1e10f);
+    keys[pos] = fps_tie_key((unsigned)k, rb, S.ref_log2);
+  }
+  const float p0x = xyz[0], p0y = xyz[1], p0z = xyz[2];
+  for (int k = n + tid; k < npad; k += T) {
+    pts[k] = make_float4(p0x, p0y, p0z, -INFINITY);
+    keys[k] = 0xFFFFFFFFu;
+  }
+  __syncthreads();  // the sorted cloud is visible to every wave; s_hist is dead, s_cand may be written
+
+  // ---- prologue 3: bucket boxes into owner-lane registers, cand[] ----------------------------------------------
+  // bucket g: wave g % W, owner lane (g / W) % 64, slot g / (64 W)
+  const int grp = lane / BP, gl = lane % BP;
+  const int nslots = (nb + W * kWave - 1) / (W * kWave);
+  float blo[kRowsSlots][3], bhi[kRowsSlots][3];
+  unsigned brank[kRowsSlots], bkey[kRowsSlots];
+#pragma unroll
+  for (int s = 0; s < kRowsSlots; ++s) {
+    brank[s] = 0u; bkey[s] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { blo[s][a] = 0.f; bhi[s][a] = 0.f; }
+    if (s < nslots) {
+      for (int k = 0; k < kWave / GPP; ++k) {
+        if (w + W * (k * GPP + kWave * s) >= nb) break;
+        const int g = w + W * (k * GPP + grp + kWave * s);
+        const bool valid = g < nb;
+        float4 p = make_float4(0.f, 0.f, 0.f, -INFINITY);
+        unsigned key = 0xFFFFFFFFu;
+        if (valid) { p = pts[g * BP + gl]; key = keys[g * BP + gl]; }
+        const bool cnd = p.w >= 0.f;
+        float l3[3], h3[3];
+        l3[0] = grp_allmin_f32<BP>(cnd ? p.x : INFINITY); h3[0] = grp_allmax_f32<BP>(cnd ? p.x : -INFINITY);
+        l3[1] = grp_allmin_f32<BP>(cnd ? p.y : INFINITY); h3[1] = grp_allmax_f32<BP>(cnd ? p.y : -INFINITY);
+        l3[2] = grp_allmin_f32<BP>(cnd ? p.z : INFINITY); h3[2] = grp_allmax_f32<BP>(cnd ? p.z : -INFINITY);
+        const float anyv = grp_allmax_f32<BP>(cnd ? p.w : -INFINITY);  // 1e10 if the bucket holds a candidate
+        const unsigned kmin = grp_allmin_u32<BP>(cnd ? key : 0xFFFFFFFFu);
+        if (valid && cnd && key == kmin) s_cand[g] = make_float4(p.x, p.y, p.z, __uint_as_float(key));
+#pragma unroll
+        for (int u = 0; u < GPP; ++u) {
+          const float ql0 = readlane_f32(l3[0], u * BP), ql1 = readlane_f32(l3[1], u * BP), ql2 = readlane_f32(l3[2], u * BP);
+          const float qh0 = readlane_f32(h3[0], u * BP), qh1 = readlane_f32(h3[1], u * BP), qh2 = readlane_f32(h3[2], u * BP);
+          const float qa = readlane_f32(anyv, u * BP);
+          const unsigned qk = readlane_u32(kmin, u * BP);
+          if (lane == k * GPP + u) {
+            blo[s][0] = ql0; blo[s][1] = ql1; blo[s][2] = ql2;
+            bhi[s][0] = qh0; bhi[s][1] = qh1; bhi[s][2] = qh2;
+            brank[s] = fps_rank_of(qa); bkey[s] = qk;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- rounds ------------------------------------------------------------------------------------------------
+  // The round loop is bound by VALU issue (every wave of a SIMD walks the same dependent chain), so it is written
+  // for instruction count: the tie keys are reduced only when a maximum is not unique, the owner lanes are
+  // updated with v_writelane, whatever is wave-uniform stays in SGPRs, a wave without a pass keeps last round's result.
+  constexpr unsigned long long kGrpMask = BP == 64 ? ~0ull : ((1ull << (BP & 63)) - 1ull);
+  float cx = p0x, cy = p0y, cz = p0z;  // the reference starts from index 0 unconditionally (:89-90)
+  if (tid == 0) out[0] = 0;
+  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+  bool dirty = true;                       // wave-uniform: a bucket of this wave changed since (wrank, wkey, cw) were formed
+  unsigned wrank = 0u, wkey = 0xFFFFFFFFu;
+  float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);  // lane 0: coordinates of this wave's best
+  for (int j = 1; j < m; ++j) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if (DEBUG) t0 = rows_clock();
+    unsigned long long todo[kRowsSlots];
+#pragma unroll
+    for (int s = 0; s < kRowsSlots; ++s) {
+      todo[s] = 0;
+      if (s < nslots) {
+        // distance of the sample to the bucket box, same arithmetic as a point distance; d >= +0, so
+        // d < max  <=>  bits(d) + 1 < rank(max)   (rank 0, no candidate: never)
+        const float dx = fmaxf(fmaxf(blo[s][0] - cx, cx - bhi[s][0]), 0.f);
+        const float dy = fmaxf(fmaxf(blo[s][1] - cy, cy - bhi[s][1]), 0.f);
+        const float dz = fmaxf(fmaxf(blo[s][2] - cz, cz - bhi[s][2]), 0.f);
+        todo[s] = __ballot(__float_as_uint(sqdist3(dx, dy, dz)) + 1u < brank[s]);
+      }
+    }
+    if (DEBUG) t1 = rows_clock();
+#pragma unroll
+    for (int s = 0; s < kRowsSlots; ++s) {
+      unsigned long long td = todo[s];
+      while (td) {
+        dirty = true;
+        int ol[GPP];
+#pragma unroll
+        for (int u = 0; u < GPP; ++u) {
+          ol[u] = td ? __ffsll((long long)td) - 1 : -1;
+          td &= td - 1;  // 0 stays 0
+        }
+        int mol = ol[0];
+#pragma unroll
+        for (int u = 1; u < GPP; ++u) mol = grp == u ? ol[u] : mol;
+        const bool valid = mol >= 0;
+        const unsigned g = (unsigned)(w + W * (mol + kWave * s));
+        unsigned rk = 0u, ky = 0xFFFFFFFFu;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+          const unsigned pos = g * BP + (unsigned)gl;
+          p = pts[pos];
+          ky = keys[pos];
+          const float d = sqdist3(p.x - cx, p.y - cy, p.z - cz);
+          const float t = fminf(d, p.w);  // -inf (non-candidate) stays -inf
+          if (t < p.w) pts[pos].w = t;
+          rk = fps_rank_of(t);
+        }
+        const unsigned gmax = grp_allmax_u32<BP>(rk);
+        // an active bucket holds a candidate, so gmax >= 1 there and padding lanes (rank 0) never match
+        bool win = valid && rk == gmax;
+        unsigned long long tm = __ballot(win);
+        bool multi = false;
+#pragma unroll
+        for (int u = 0; u < GPP; ++u) {
+          const unsigned long long bits = (tm >> (u * BP)) & kGrpMask;
+          multi |= (bits & (bits - 1ull)) != 0ull;
+        }
+        if (multi) {  // wave-uniform: equal maxima inside a bucket, the smallest tie key wins
+          const unsigned gkey = grp_allmin_u32<BP>(win ? ky : 0xFFFFFFFFu);
+          win = win && ky == gkey;
+          tm = __ballot(win);
+        }
+        if (win) s_cand[g] = make_float4(p.x, p.y, p.z, __uint_as_float(ky));
+#pragma unroll
+        for (int u = 0; u < GPP; ++u) {
+          if (ol[u] >= 0) {  // wave-uniform
+            const int wlane = __ffsll((long long)((tm >> (u * BP)) & kGrpMask)) - 1 + u * BP;
+            const unsigned qr = readlane_u32(rk, wlane), qk = readlane_u32(ky, wlane);
+            brank[s] = writelane_u32(brank[s], qr, ol[u]);
+            bkey[s] = writelane_u32(bkey[s], qk, ol[u]);
+          }
+        }
+        if (DEBUG) ++acc[5];
+      }
+    }
+    if (DEBUG) t2 = rows_clock();
+    // arg-max over this wave's buckets (only if one of them changed), its coordinates from cand[]
+    if (dirty) {
+      dirty = false;
+      unsigned mrank = brank[0], mkey = bkey[0];
+      int mslot = 0;
+#pragma unroll
+      for (int s = 1; s < kRowsSlots; ++s) {
+        if (s < nslots) {
+          const bool b = (brank[s] > mrank) | ((brank[s] == mrank) & (bkey[s] < mkey));
+          mrank = b ? brank[s] : mrank;
+          mkey = b ? bkey[s] : mkey;
+          mslot = b ? s : mslot;
+        }
+      }
+      wrank = grp_allmax_u32<kWave>(mrank);
+      bool win = mrank == wrank;
+      unsigned long long tm = __ballot(win);
+      if (tm & (tm - 1ull)) {
+        const unsigned k2 = grp_allmin_u32<kWave>(win ? mkey : 0xFFFFFFFFu);
+        tm = __ballot(win && mkey == k2);
+      }
+      const int wl = __ffsll((long long)tm) - 1;
+      wkey = readlane_u32(mkey, wl);
+      const int wslot = (int)readlane_u32((unsigned)mslot, wl);
+      if (lane == 0) {
+        const int gw = min(w + W * (wl + kWave * wslot), nb - 1);  // wrank == 0: any bucket, the entry is ignored
+        cw = s_cand[gw];
+      }
+    }
+    const int par = j & 1;
+    if (lane == 0) {
+      s_xr[par][w] = wrank;
+      s_xc[par][w] = make_float4(cw.x, cw.y, cw.z, __uint_as_float(wkey));
+    }
+    if (DEBUG) t3 = rows_clock();
+    // LDS-only barrier: a full __syncthreads() would also drain vmcnt, i.e. wait for the L2 acknowledgement of this
+    // round's running-distance stores, which only this wave reads back.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (DEBUG) t4 = rows_clock();
+    {
+      const int sl = lane & (W - 1);  // lanes 0..W-1 hold the W entries (the other rows repeat them)
+      const unsigned xr = s_xr[par][sl];
+      float4 xc = s_xc[par][sl];
+      asm volatile("" : "+v"(xc.x), "+v"(xc.y), "+v"(xc.z), "+v"(xc.w));  // one ds_read_b128 here, not a dependent read later
+      const unsigned xk = __float_as_uint(xc.w);
+      const unsigned grank = row_allmax_u32_fx(xr);
+      bool win = xr == grank;
+      unsigned long long tm = __ballot(win) & ((1ull << W) - 1ull);
+      if (tm & (tm - 1ull)) {
+        const unsigned k2 = row_allmin_u32_fx(win ? xk : 0xFFFFFFFFu);
+        tm = __ballot(win && xk == k2) & ((1ull << W) - 1ull);
+      }
+      const int ws = __ffsll((long long)tm) - 1;
+      const unsigned gkey = readlane_u32(xk, ws);
+      const float nx = readlane_f32(xc.x, ws), ny = readlane_f32(xc.y, ws), nz = readlane_f32(xc.z, ws);
+      // no candidate at all: the reference's reduction returns besti = 0 (:93-94)
+      const int winner = grank ? fps_decode_key(gkey, rb, S.ref_log2) : 0;
+      cx = grank ? nx : p0x; cy = grank ? ny : p0y; cz = grank ? nz : p0z;
+      if (tid == 0) out[j] = winner;
+    }
+    if (DEBUG) {
+      const unsigned long long t5 = rows_clock();
+      acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
+    }
+  }
+  if (DEBUG && lane == 0 && blockIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g_rows_cyc[w][i] = acc[i];
+  }
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------
+
+bool fps_rows_plan(int nmax, RowsPlan* plan) {
+  static const int env_impl = getenv("VDETR_FPS_IMPL") ? atoi(getenv("VDETR_FPS_IMPL")) : 0;  // 2: fps.hip's kernel always
+  static const int env_waves = getenv("VDETR_FPS_WAVES") ? atoi(getenv("VDETR_FPS_WAVES")) : 0;
+  static const int env_bp = getenv("VDETR_FPS_BP") ? atoi(getenv("VDETR_FPS_BP")) : 0;
+  if (env_impl == 2 || nmax <= 0) return false;
+  const int waves = env_waves == 8 ? 8 : 16;
+  const long lanes = (long)waves * kWave;
+  int bp = 0;
+  if (env_bp == 16 || env_bp == 32 || env_bp == 64) {
+    bp = env_bp;
+  } else {  // measured (tools/fps_variants.py, 40k and 80k points): 64-point buckets, one box test per owner lane
+    bp = 64;
+  }
+  if (((long)nmax + bp - 1) / bp > (long)kRowsSlots * lanes) {
+    if (env_bp) return false;
+    bp = 64;
+    if (((long)nmax + bp - 1) / bp > (long)kRowsSlots * lanes) return false;
+  }
+  plan->waves = waves;
+  plan->bucket_pts = bp;
+  return true;
+}
+
+template <int W, int BP>
+static int launch_rows(RowsParams& P, int b, size_t lds, bool debug, hipStream_t stream) {
+  if (debug) {
+    int rc = set_lds(fps_rows_kernel<W, BP, true>, lds, "furthest_point_sampling");
+    if (rc != VDETR_OK) return rc;
+    hipLaunchKernelGGL((fps_rows_kernel<W, BP, true>), dim3(b), dim3(W * kWave), lds, stream, P);
+    (void)hipDeviceSynchronize();
+    unsigned long long z[16][8];
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rows_cyc), sizeof(z));
+    const unsigned long long r = P.m > 1 ? P.m - 1 : 1;
+    for (int i = 0; i < W; ++i)
+      fprintf(stderr, "[fps rows debug] W=%d BP=%d wave %2d cycles/round: test %llu passes %llu reduce %llu barrier %llu decode %llu | passes/round %.2f\n",
+              W, BP, i, z[i][0] / r, z[i][1] / r, z[i][2] / r, z[i][3] / r, z[i][4] / r, (double)z[i][5] / (double)r);
+    return check_launch("furthest_point_sampling");
+  }
+  int rc = set_lds(fps_rows_kernel<W, BP, false>, lds, "furthest_point_sampling");
+  if (rc != VDETR_OK) return rc;
+  hipLaunchKernelGGL((fps_rows_kernel<W, BP, false>), dim3(b), dim3(W * kWave), lds, stream, P);
+  return check_launch("furthest_point_sampling");
+}
+
+int fps_rows_launch(RowsParams& P, int b, const RowsPlan& pl, hipStream_t stream) {
+  static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
+  int nbmax = 0;
+  for (int i = 0; i < b; ++i) {
+    P.scenes[i].nbuckets = (int)(((long)P.scenes[i].n + pl.bucket_pts - 1) / pl.bucket_pts);
+    nbmax = nbmax > P.scenes[i].nbuckets ? nbmax : P.scenes[i].nbuckets;
+  }
+  size_t lds = (size_t)kRowsHistWords * sizeof(int);
+  if ((size_t)nbmax * sizeof(float4) > lds) lds = (size_t)nbmax * sizeof(float4);
+  const int key = pl.waves * 100 + pl.bucket_pts;
+  switch (key) {
+    case 1616: return launch_rows<16, 16>(P, b, lds, debug, stream);
+    case 1632: return launch_rows<16, 32>(P, b, lds, debug, stream);
+    case 1664: return launch_rows<16, 64>(P, b, lds, debug, stream);
+    case 816: return launch_rows<8, 16>(P, b, lds, debug, stream);
+    case 832: return launch_rows<8, 32>(P, b, lds, debug, stream);
+    case 864: return launch_rows<8, 64>(P, b, lds, debug, stream);
+  }
+  set_error("furthest_point_sampling: no kernel for %d waves x %d-point buckets", pl.waves, pl.bucket_pts);
+  return VDETR_ERR_ARG;
+}
+
+}  // namespace vdetr

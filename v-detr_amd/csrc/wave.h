@@ -24,6 +24,15 @@ __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The same exchange with bound_ctrl:0 and a zero `old` operand: hipcc then folds the permutation into the consuming
+// VALU op (one `v_max_u32_dpp` per stage instead of v_mov / s_nop / v_mov_dpp / v_max).  A source lane that is
+// switched off reads as 0 instead of the lane's own value, so these are for code that runs with every lane of the
+// wave active (the patterns used here have no out-of-row sources).
+template <int CTRL>
+__device__ __forceinline__ unsigned dppz_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
 // Cross-row / cross-half exchange.  permlane16_swap(vdst, src) swaps the odd 16-lane rows of vdst with
 // the even rows of src; permlane32_swap swaps lanes 32-63 of vdst with lanes 0-31 of src.  Called with
 // vdst = src = v the two results are A' = [r0,r0,r2,r2] / [lo,lo] and B' = [r1,r1,r3,r3] / [hi,hi], so
@@ -135,6 +144,21 @@ __device__ __forceinline__ unsigned row_allmin_u32(unsigned v) {
   v = min(v, dpp_u32<kDppRowMirror>(v));
   return v;
 }
+// full-exec forms (see dppz_u32)
+__device__ __forceinline__ unsigned row_allmax_u32_fx(unsigned v) {
+  v = max(v, dppz_u32<kDppQuadXor1>(v));
+  v = max(v, dppz_u32<kDppQuadXor2>(v));
+  v = max(v, dppz_u32<kDppRowHalfMirror>(v));
+  v = max(v, dppz_u32<kDppRowMirror>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned row_allmin_u32_fx(unsigned v) {
+  v = min(v, dppz_u32<kDppQuadXor1>(v));
+  v = min(v, dppz_u32<kDppQuadXor2>(v));
+  v = min(v, dppz_u32<kDppRowHalfMirror>(v));
+  v = min(v, dppz_u32<kDppRowMirror>(v));
+  return v;
+}
 __device__ __forceinline__ unsigned wave_allmax_u32(unsigned v) {
   v = row_allmax_u32(v);
   pair_u32 p = xrow16(v);
@@ -152,6 +176,13 @@ __device__ __forceinline__ unsigned wave_allmin_u32(unsigned v) {
 
 __device__ __forceinline__ float readlane_f32(float v, int lane) {
   return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+// v with lane `lane` replaced by the wave-uniform value x: one v_writelane_b32.  (This clang has no writelane
+// builtin.  Two different SGPR sources would break the one-constant-bus-read rule, so the lane select goes through
+// M0; the s_nop covers the wait states a VALU-written data SGPR may need, inline asm is not scanned for hazards.)
+__device__ __forceinline__ unsigned writelane_u32(unsigned v, unsigned x, int lane) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(lane) : "m0");
+  return v;
 }
 __device__ __forceinline__ unsigned readlane_u32(unsigned v, int lane) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, lane);
