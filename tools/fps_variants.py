@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""A/B of the furthest-point-sampling kernels on the GPU box: for every (waves, bucket size) geometry of
+"""A/B of the furthest-point-sampling kernels on the GPU box: for every workgroup size (4, 8, 16 waves) of
 fps_rows.hip and for fps.hip's kernel, time the C2 (40k -> 4096) and C4 (80k -> 4096) scenes, compare the indices
 with the C oracle bit for bit, and (with --debug) print the in-kernel phase counters.
 
     python tools/fps_variants.py [--debug] [--quick]
 
-The geometry is read from the environment once per process (VDETR_FPS_IMPL / _WAVES / _BP), so every variant runs
+The geometry is read from the environment once per process (VDETR_FPS_IMPL / _WAVES), so every variant runs
 in a child process; this parent never touches the GPU."""
 import json
 import os
@@ -61,9 +61,8 @@ def main():
     if "--sizes" in sys.argv:
         sizes = sys.argv[sys.argv.index("--sizes") + 1]
     variants = [("v2", {"VDETR_FPS_IMPL": "2"})]
-    for wv in (16, 8):
-        for bp in (16, 32, 64):
-            variants.append((f"rows W={wv} BP={bp}", {"VDETR_FPS_WAVES": str(wv), "VDETR_FPS_BP": str(bp)}))
+    for wv in (16, 8, 4):
+        variants.append((f"rows W={wv}", {"VDETR_FPS_WAVES": str(wv)}))
     variants.append(("default", {}))
     if "--only" in sys.argv:
         keep = sys.argv[sys.argv.index("--only") + 1].split(";")

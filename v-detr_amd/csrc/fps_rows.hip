@@ -1,28 +1,31 @@
-// fps_rows.hip — furthest point sampling, row-per-bucket kernel: the fast path of
-// vdetr_furthest_point_sampling(_varlen)_f32.  Bit-exact with the reference's result
-// (third_party/pointnet2/_ext_src/src/sampling_gpu.cu:73-176), like fps.hip, and built on the same exact
-// box-skip argument (see fps.hip's header); what differs is how a round's dependent chain is laid out.
+// fps_rows.hip — furthest point sampling, the fast path of vdetr_furthest_point_sampling(_varlen)_f32.
+// Bit-exact with the reference's result (third_party/pointnet2/_ext_src/src/sampling_gpu.cu:73-176), like fps.hip,
+// and built on the same exact box-skip argument (see fps.hip's header); what differs is how a round's dependent
+// chain is laid out.  Measured with tools/probes/lat_probe.hip on one CU: a dependent VALU op costs ~8 cycles to a
+// wave whatever it is, a second independent chain interleaved with it is free, an L2-resident 1 KB bucket fetch
+// costs ~280-340, an LDS round trip ~60, and waves sharing a SIMD slow each other's chains down 2-2.5x.  So a
+// round is a LATENCY chain: few waves, short chains, independent work interleaved.
 //
-// One workgroup of W waves per scene.  The cloud is counting-sorted into Z-order over 2^15 near-cubic cells
-// (the split sequence follows the cloud's aspect ratio) and cut into BUCKETS of BP = 16/32/64 consecutive points.
-// Bucket g belongs to wave g % W for good: its bounding box, current max running distance (as an order-preserving
-// rank) and the tie key of that max live in the registers of an owner lane of that wave, the coordinates of the
-// max in LDS (cand[g]).
+// One workgroup of W waves per scene.  The cloud is counting-sorted into Z-order over 2^15 near-cubic cells (the
+// split sequence follows the cloud's aspect ratio) and cut into BUCKETS of 64 consecutive points.  Bucket g belongs
+// to wave g % W for good: its bounding box, current max running distance (as an order-preserving rank) and the tie
+// key of that max live in the registers of an owner lane of that wave, the coordinates of the max in LDS (cand[g]).
 //
 // Round j, per wave, ONE workgroup barrier:
-//   test    every owner lane: is the new sample closer to my box than my bucket's max?       (13 VALU per slot)
-//   passes  the wave's surviving buckets, 64/BP of them per pass, one bucket per group of BP lanes: one 16-B load
-//           per lane, distance/min/store, a log2(BP)-stage DPP all-reduce of the rank, a second one of the tie
-//           key; the winner lane refreshes cand[g], the owner lane takes (rank, key) by v_readlane.
-//   reduce  arg-max over the wave's owner lanes (6+6 stages), its coordinates from cand[], 5 words to LDS
-//   barrier (LDS only: the running-distance stores are re-read by the same wave, nobody else needs them)
-//   decode  every 16-lane row all-reduces the W entries (4+4 stages), v_readlane of the winner's coordinates.
-// fps.hip spends a 64-lane reduction per surviving bucket and keeps 4 buckets in flight per wave; here a pass
-// retires 64/BP buckets with shorter reductions, the boxes are smaller (fewer survivors), and the exchange
-// carries the coordinates, so no dependent lookup follows the barrier.
+//   test    every owner lane: is the new sample closer to my box than my bucket's max?  (14 VALU per slot, slots
+//           independent)
+//   batch   up to 4 surviving buckets at a time, picked across slots: the four 16-B loads are issued back to back,
+//           then four independent chains (distance, min, store, 6-stage DPP/permlane max of the rank) interleave;
+//           the tie keys are reduced only if a bucket's maximum is not unique; the winner lane refreshes cand[g],
+//           the owner lane gets (rank, key) by v_readlane / v_writelane.
+//   reduce  (only if a bucket of this wave changed) arg-max over the owner lanes, coordinates from cand[]
+//   barrier LDS only: the running-distance stores are re-read by the same wave, nobody else needs them
+//   decode  every 16-lane row all-reduces the W entries, v_readlane of the winner's coordinates; the sample is
+//           recorded as its tie key and translated to the point index after the last round.
 #include "fps.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace vdetr {
 
@@ -76,12 +79,15 @@ __device__ __forceinline__ unsigned long long rows_clock() {
   return t;
 }
 
-template <int W, int BP, bool DEBUG>
+constexpr int kBP = 64;  // points per bucket: one wave-wide load
+constexpr int kKB = 4;   // buckets in flight per wave
+
+// W waves per scene, at most NS buckets per owner lane (compile-time bound of the slot loops)
+template <int W, int NS, bool DEBUG>
 __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   constexpr int T = W * kWave;
-  constexpr int GPP = kWave / BP;  // buckets per pass
   extern __shared__ __align__(16) unsigned char smem[];
-  int* const s_hist = reinterpret_cast<int*>(smem);     // prologue
+  int* const s_hist = reinterpret_cast<int*>(smem);        // prologue
   float4* const s_cand = reinterpret_cast<float4*>(smem);  // rounds: (x,y,z,key) of every bucket's max
   __shared__ int s_wsum[W];
   __shared__ float s_red[W][6];
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   int32_t* __restrict__ out = S.idx;
   float4* __restrict__ pts = Pin.pts + S.ws_off;
   uint32_t* __restrict__ keys = Pin.keys + S.ws_off;
-  const int n = S.n, nb = S.nbuckets, npad = nb * BP, m = Pin.m;
+  const int n = S.n, nb = S.nbuckets, npad = nb * kBP, m = Pin.m;
   const unsigned rb = (unsigned)S.ref_block;
 
   // ---- prologue 1: bounding box of the cloud, the split sequence of the cell grid ------------------------------
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   for (int k = tid; k < n; k += T) atomicAdd(&s_hist[hidx(cell_of(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]))], 1);
   __syncthreads();
   {
-    constexpr int kPer = kRowsCells / T;  // consecutive cells per thread (32 or 64)
+    constexpr int kPer = kRowsCells / T;  // consecutive cells per thread
     int sum = 0;
     for (int i = 0; i < kPer; ++i) sum += s_hist[hidx(tid * kPer + i)];
     int incl = sum;
@@ -197,64 +203,129 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
 
   // ---- prologue 3: bucket boxes into owner-lane registers, cand[] ----------------------------------------------
   // bucket g: wave g % W, owner lane (g / W) % 64, slot g / (64 W)
-  const int grp = lane / BP, gl = lane % BP;
   const int nslots = (nb + W * kWave - 1) / (W * kWave);
-  float blo[kRowsSlots][3], bhi[kRowsSlots][3];
-  unsigned brank[kRowsSlots], bkey[kRowsSlots];
+  float blo[NS][3], bhi[NS][3];
+  unsigned brank[NS], bkey[NS];
 #pragma unroll
-  for (int s = 0; s < kRowsSlots; ++s) {
+  for (int s = 0; s < NS; ++s) {
     brank[s] = 0u; bkey[s] = 0xFFFFFFFFu;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { blo[s][a] = 0.f; bhi[s][a] = 0.f; }
     if (s < nslots) {
-      for (int k = 0; k < kWave / GPP; ++k) {
-        if (w + W * (k * GPP + kWave * s) >= nb) break;
-        const int g = w + W * (k * GPP + grp + kWave * s);
-        const bool valid = g < nb;
-        float4 p = make_float4(0.f, 0.f, 0.f, -INFINITY);
-        unsigned key = 0xFFFFFFFFu;
-        if (valid) { p = pts[g * BP + gl]; key = keys[g * BP + gl]; }
+      for (int li = 0; li < kWave; ++li) {
+        const int g = w + W * (li + kWave * s);
+        if (g >= nb) break;
+        const float4 p = pts[g * kBP + lane];
+        const unsigned key = keys[g * kBP + lane];
         const bool cnd = p.w >= 0.f;
         float l3[3], h3[3];
-        l3[0] = grp_allmin_f32<BP>(cnd ? p.x : INFINITY); h3[0] = grp_allmax_f32<BP>(cnd ? p.x : -INFINITY);
-        l3[1] = grp_allmin_f32<BP>(cnd ? p.y : INFINITY); h3[1] = grp_allmax_f32<BP>(cnd ? p.y : -INFINITY);
-        l3[2] = grp_allmin_f32<BP>(cnd ? p.z : INFINITY); h3[2] = grp_allmax_f32<BP>(cnd ? p.z : -INFINITY);
-        const float anyv = grp_allmax_f32<BP>(cnd ? p.w : -INFINITY);  // 1e10 if the bucket holds a candidate
-        const unsigned kmin = grp_allmin_u32<BP>(cnd ? key : 0xFFFFFFFFu);
-        if (valid && cnd && key == kmin) s_cand[g] = make_float4(p.x, p.y, p.z, __uint_as_float(key));
+        l3[0] = wave_allmin_f32(cnd ? p.x : INFINITY); h3[0] = wave_allmax_f32(cnd ? p.x : -INFINITY);
+        l3[1] = wave_allmin_f32(cnd ? p.y : INFINITY); h3[1] = wave_allmax_f32(cnd ? p.y : -INFINITY);
+        l3[2] = wave_allmin_f32(cnd ? p.z : INFINITY); h3[2] = wave_allmax_f32(cnd ? p.z : -INFINITY);
+        const float anyv = wave_allmax_f32(cnd ? p.w : -INFINITY);  // 1e10 if the bucket holds a candidate
+        const unsigned kmin = grp_allmin_u32<kWave>(cnd ? key : 0xFFFFFFFFu);
+        if (cnd && key == kmin) s_cand[g] = make_float4(p.x, p.y, p.z, __uint_as_float(key));
+        if (lane == li) {
 #pragma unroll
-        for (int u = 0; u < GPP; ++u) {
-          const float ql0 = readlane_f32(l3[0], u * BP), ql1 = readlane_f32(l3[1], u * BP), ql2 = readlane_f32(l3[2], u * BP);
-          const float qh0 = readlane_f32(h3[0], u * BP), qh1 = readlane_f32(h3[1], u * BP), qh2 = readlane_f32(h3[2], u * BP);
-          const float qa = readlane_f32(anyv, u * BP);
-          const unsigned qk = readlane_u32(kmin, u * BP);
-          if (lane == k * GPP + u) {
-            blo[s][0] = ql0; blo[s][1] = ql1; blo[s][2] = ql2;
-            bhi[s][0] = qh0; bhi[s][1] = qh1; bhi[s][2] = qh2;
-            brank[s] = fps_rank_of(qa); bkey[s] = qk;
-          }
+          for (int a = 0; a < 3; ++a) { blo[s][a] = l3[a]; bhi[s][a] = h3[a]; }
+          brank[s] = fps_rank_of(anyv); bkey[s] = kmin;
         }
       }
     }
   }
 
   // ---- rounds ------------------------------------------------------------------------------------------------
-  // The round loop is bound by VALU issue (every wave of a SIMD walks the same dependent chain), so it is written
-  // for instruction count: the tie keys are reduced only when a maximum is not unique, the owner lanes are
-  // updated with v_writelane, whatever is wave-uniform stays in SGPRs, a wave without a pass keeps last round's result.
-  constexpr unsigned long long kGrpMask = BP == 64 ? ~0ull : ((1ull << (BP & 63)) - 1ull);
   float cx = p0x, cy = p0y, cz = p0z;  // the reference starts from index 0 unconditionally (:89-90)
   if (tid == 0) out[0] = 0;
-  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
-  bool dirty = true;                       // wave-uniform: a bucket of this wave changed since (wrank, wkey, cw) were formed
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool dirty = true;  // wave-uniform: a bucket of this wave changed since (wrank, wkey, cw) were formed
   unsigned wrank = 0u, wkey = 0xFFFFFFFFu;
   float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);  // lane 0: coordinates of this wave's best
+  unsigned long long todo[NS];
+
+  // next surviving bucket of this wave, across slots (scalar code)
+  auto pick = [&](int& l, int& sl) __attribute__((always_inline)) -> bool {
+    bool found = false;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {  // no early exit: every todo[] index stays a compile-time constant (registers, not scratch)
+      const bool hit = !found && todo[q] != 0ull;
+      if (hit) { l = __ffsll((long long)todo[q]) - 1; sl = q; }
+      todo[q] = hit ? (todo[q] & (todo[q] - 1ull)) : todo[q];
+      found |= hit;
+    }
+    return found;
+  };
+  // NC buckets (owner lane bl[u], slot bs[u]) as NC interleaved chains
+  int bl[kKB] = {0, 0, 0, 0}, bs[kKB] = {0, 0, 0, 0};
+  auto process = [&](auto nc_tag) __attribute__((always_inline)) {
+    constexpr int NC = decltype(nc_tag)::value;
+    unsigned g[NC], pos[NC], ky[NC], rk[NC], v[NC];
+    float4 p[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      g[u] = (unsigned)(w + W * (bl[u] + kWave * bs[u]));
+      pos[u] = g[u] * kBP + (unsigned)lane;
+      p[u] = pts[pos[u]];
+      ky[u] = keys[pos[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const float d = sqdist3(p[u].x - cx, p[u].y - cy, p[u].z - cz);
+      const float t = fminf(d, p[u].w);  // -inf (non-candidate) stays -inf
+      pts[pos[u]].w = t;                 // unconditional: a predicated store would split the chains into blocks
+      rk[u] = fps_rank_of(t);
+      v[u] = rk[u];
+    }
+    // 6-stage all-reduce of the ranks, stage by stage over the chains
+#pragma unroll
+    for (int u = 0; u < NC; ++u) v[u] = max(v[u], dppz_u32<kDppQuadXor1>(v[u]));
+#pragma unroll
+    for (int u = 0; u < NC; ++u) v[u] = max(v[u], dppz_u32<kDppQuadXor2>(v[u]));
+#pragma unroll
+    for (int u = 0; u < NC; ++u) v[u] = max(v[u], dppz_u32<kDppRowHalfMirror>(v[u]));
+#pragma unroll
+    for (int u = 0; u < NC; ++u) v[u] = max(v[u], dppz_u32<kDppRowMirror>(v[u]));
+#pragma unroll
+    for (int u = 0; u < NC; ++u) { const pair_u32 q = xrow16(v[u]); v[u] = max(q.a, q.b); }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) { const pair_u32 q = xhalf32(v[u]); v[u] = max(q.a, q.b); }
+    // an active bucket holds a candidate, so its max rank is >= 1 and padding lanes (rank 0) never match
+    unsigned long long tm[NC];
+    bool multi = false;
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      tm[u] = __ballot(rk[u] == v[u]);
+      multi |= (tm[u] & (tm[u] - 1ull)) != 0ull;
+    }
+    if (multi) {  // wave-uniform, rare: equal maxima inside a bucket, the smallest tie key wins
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {
+        const bool top = rk[u] == v[u];
+        const unsigned gk = grp_allmin_u32<kWave>(top ? ky[u] : 0xFFFFFFFFu);
+        tm[u] = __ballot(top && ky[u] == gk);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const int wl = __ffsll((long long)tm[u]) - 1;
+      const unsigned qr = readlane_u32(rk[u], wl), qk = readlane_u32(ky[u], wl);
+      if (lane == wl) s_cand[g[u]] = make_float4(p[u].x, p[u].y, p[u].z, __uint_as_float(ky[u]));
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        if (bs[u] == q) {  // wave-uniform
+          brank[q] = writelane_u32(brank[q], qr, bl[u]);
+          bkey[q] = writelane_u32(bkey[q], qk, bl[u]);
+        }
+      }
+    }
+  };
+
   for (int j = 1; j < m; ++j) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     if (DEBUG) t0 = rows_clock();
-    unsigned long long todo[kRowsSlots];
+    bool any = false;
 #pragma unroll
-    for (int s = 0; s < kRowsSlots; ++s) {
+    for (int s = 0; s < NS; ++s) {
       todo[s] = 0;
       if (s < nslots) {
         // distance of the sample to the bucket box, same arithmetic as a point distance; d >= +0, so
@@ -263,63 +334,26 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
         const float dy = fmaxf(fmaxf(blo[s][1] - cy, cy - bhi[s][1]), 0.f);
         const float dz = fmaxf(fmaxf(blo[s][2] - cz, cz - bhi[s][2]), 0.f);
         todo[s] = __ballot(__float_as_uint(sqdist3(dx, dy, dz)) + 1u < brank[s]);
+        any |= todo[s] != 0ull;
       }
     }
     if (DEBUG) t1 = rows_clock();
+    while (any) {
+      dirty = true;
+      int cnt = 0;
 #pragma unroll
-    for (int s = 0; s < kRowsSlots; ++s) {
-      unsigned long long td = todo[s];
-      while (td) {
-        dirty = true;
-        int ol[GPP];
-#pragma unroll
-        for (int u = 0; u < GPP; ++u) {
-          ol[u] = td ? __ffsll((long long)td) - 1 : -1;
-          td &= td - 1;  // 0 stays 0
-        }
-        int mol = ol[0];
-#pragma unroll
-        for (int u = 1; u < GPP; ++u) mol = grp == u ? ol[u] : mol;
-        const bool valid = mol >= 0;
-        const unsigned g = (unsigned)(w + W * (mol + kWave * s));
-        unsigned rk = 0u, ky = 0xFFFFFFFFu;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) {
-          const unsigned pos = g * BP + (unsigned)gl;
-          p = pts[pos];
-          ky = keys[pos];
-          const float d = sqdist3(p.x - cx, p.y - cy, p.z - cz);
-          const float t = fminf(d, p.w);  // -inf (non-candidate) stays -inf
-          if (t < p.w) pts[pos].w = t;
-          rk = fps_rank_of(t);
-        }
-        const unsigned gmax = grp_allmax_u32<BP>(rk);
-        // an active bucket holds a candidate, so gmax >= 1 there and padding lanes (rank 0) never match
-        bool win = valid && rk == gmax;
-        unsigned long long tm = __ballot(win);
-        bool multi = false;
-#pragma unroll
-        for (int u = 0; u < GPP; ++u) {
-          const unsigned long long bits = (tm >> (u * BP)) & kGrpMask;
-          multi |= (bits & (bits - 1ull)) != 0ull;
-        }
-        if (multi) {  // wave-uniform: equal maxima inside a bucket, the smallest tie key wins
-          const unsigned gkey = grp_allmin_u32<BP>(win ? ky : 0xFFFFFFFFu);
-          win = win && ky == gkey;
-          tm = __ballot(win);
-        }
-        if (win) s_cand[g] = make_float4(p.x, p.y, p.z, __uint_as_float(ky));
-#pragma unroll
-        for (int u = 0; u < GPP; ++u) {
-          if (ol[u] >= 0) {  // wave-uniform
-            const int wlane = __ffsll((long long)((tm >> (u * BP)) & kGrpMask)) - 1 + u * BP;
-            const unsigned qr = readlane_u32(rk, wlane), qk = readlane_u32(ky, wlane);
-            brank[s] = writelane_u32(brank[s], qr, ol[u]);
-            bkey[s] = writelane_u32(bkey[s], qk, ol[u]);
-          }
-        }
-        if (DEBUG) ++acc[5];
+      for (int u = 0; u < kKB; ++u) {
+        int l = bl[0], sl = bs[0];  // a missing entry repeats the first bucket (harmless: min and max are idempotent)
+        if (pick(l, sl)) ++cnt;
+        bl[u] = l; bs[u] = sl;
       }
+      any = false;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) any |= todo[s] != 0ull;
+      if (cnt == 1) process(std::integral_constant<int, 1>());
+      else if (cnt == 2) process(std::integral_constant<int, 2>());
+      else process(std::integral_constant<int, kKB>());
+      if (DEBUG) { ++acc[5]; acc[6] += cnt; }
     }
     if (DEBUG) t2 = rows_clock();
     // arg-max over this wave's buckets (only if one of them changed), its coordinates from cand[]
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
       unsigned mrank = brank[0], mkey = bkey[0];
       int mslot = 0;
 #pragma unroll
-      for (int s = 1; s < kRowsSlots; ++s) {
+      for (int s = 1; s < NS; ++s) {
         if (s < nslots) {
           const bool b = (brank[s] > mrank) | ((brank[s] == mrank) & (bkey[s] < mkey));
           mrank = b ? brank[s] : mrank;
@@ -337,15 +371,15 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
         }
       }
       wrank = grp_allmax_u32<kWave>(mrank);
-      bool win = mrank == wrank;
-      unsigned long long tm = __ballot(win);
+      const bool top = mrank == wrank;
+      unsigned long long tm = __ballot(top);
       if (tm & (tm - 1ull)) {
-        const unsigned k2 = grp_allmin_u32<kWave>(win ? mkey : 0xFFFFFFFFu);
-        tm = __ballot(win && mkey == k2);
+        const unsigned k2 = grp_allmin_u32<kWave>(top ? mkey : 0xFFFFFFFFu);
+        tm = __ballot(top && mkey == k2);
       }
       const int wl = __ffsll((long long)tm) - 1;
       wkey = readlane_u32(mkey, wl);
-      const int wslot = (int)readlane_u32((unsigned)mslot, wl);
+      const int wslot = NS > 1 ? (int)readlane_u32((unsigned)mslot, wl) : 0;
       if (lane == 0) {
         const int gw = min(w + W * (wl + kWave * wslot), nb - 1);  // wrank == 0: any bucket, the entry is ignored
         cw = s_cand[gw];
@@ -368,28 +402,33 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
       asm volatile("" : "+v"(xc.x), "+v"(xc.y), "+v"(xc.z), "+v"(xc.w));  // one ds_read_b128 here, not a dependent read later
       const unsigned xk = __float_as_uint(xc.w);
       const unsigned grank = row_allmax_u32_fx(xr);
-      bool win = xr == grank;
-      unsigned long long tm = __ballot(win) & ((1ull << W) - 1ull);
+      const bool top = xr == grank;
+      unsigned long long tm = __ballot(top) & ((1ull << W) - 1ull);
       if (tm & (tm - 1ull)) {
-        const unsigned k2 = row_allmin_u32_fx(win ? xk : 0xFFFFFFFFu);
-        tm = __ballot(win && xk == k2) & ((1ull << W) - 1ull);
+        const unsigned k2 = row_allmin_u32_fx(top ? xk : 0xFFFFFFFFu);
+        tm = __ballot(top && xk == k2) & ((1ull << W) - 1ull);
       }
       const int ws = __ffsll((long long)tm) - 1;
       const unsigned gkey = readlane_u32(xk, ws);
       const float nx = readlane_f32(xc.x, ws), ny = readlane_f32(xc.y, ws), nz = readlane_f32(xc.z, ws);
-      // no candidate at all: the reference's reduction returns besti = 0 (:93-94)
-      const int winner = grank ? fps_decode_key(gkey, rb, S.ref_log2) : 0;
+      // no candidate at all: the reference's reduction returns besti = 0 (:93-94), whose key is 0
       cx = grank ? nx : p0x; cy = grank ? ny : p0y; cz = grank ? nz : p0z;
-      if (tid == 0) out[j] = winner;
+      if (tid == 0) out[j] = (int32_t)(grank ? gkey : 0u);  // translated to the point index below
     }
     if (DEBUG) {
       const unsigned long long t5 = rows_clock();
       acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
     }
   }
+  // ---- epilogue: tie keys -> point indices (wave 0 wrote the keys; they are read past this CU's L1) ---------------
+  __syncthreads();
+  for (int k = 1 + tid; k < m; k += T) {
+    const unsigned key = (unsigned)__hip_atomic_load(&out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[k] = fps_decode_key(key, rb, S.ref_log2);
+  }
   if (DEBUG && lane == 0 && blockIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) g_rows_cyc[w][i] = acc[i];
+    for (int i = 0; i < 8; ++i) g_rows_cyc[w][i] = acc[i];
   }
 }
 
@@ -398,44 +437,34 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
 bool fps_rows_plan(int nmax, RowsPlan* plan) {
   static const int env_impl = getenv("VDETR_FPS_IMPL") ? atoi(getenv("VDETR_FPS_IMPL")) : 0;  // 2: fps.hip's kernel always
   static const int env_waves = getenv("VDETR_FPS_WAVES") ? atoi(getenv("VDETR_FPS_WAVES")) : 0;
-  static const int env_bp = getenv("VDETR_FPS_BP") ? atoi(getenv("VDETR_FPS_BP")) : 0;
   if (env_impl == 2 || nmax <= 0) return false;
-  const int waves = env_waves == 8 ? 8 : 16;
-  const long lanes = (long)waves * kWave;
-  int bp = 0;
-  if (env_bp == 16 || env_bp == 32 || env_bp == 64) {
-    bp = env_bp;
-  } else {  // measured (tools/fps_variants.py, 40k and 80k points): 64-point buckets, one box test per owner lane
-    bp = 64;
-  }
-  if (((long)nmax + bp - 1) / bp > (long)kRowsSlots * lanes) {
-    if (env_bp) return false;
-    bp = 64;
-    if (((long)nmax + bp - 1) / bp > (long)kRowsSlots * lanes) return false;
-  }
+  const long nb = ((long)nmax + kBP - 1) / kBP;
+  int waves = (env_waves == 4 || env_waves == 8 || env_waves == 16) ? env_waves : 16;
+  while (waves < 16 && nb > (long)kRowsSlots * kWave * waves) waves *= 2;
+  if (nb > (long)kRowsSlots * kWave * waves) return false;
   plan->waves = waves;
-  plan->bucket_pts = bp;
+  plan->bucket_pts = kBP;
   return true;
 }
 
-template <int W, int BP>
+template <int W, int NS>
 static int launch_rows(RowsParams& P, int b, size_t lds, bool debug, hipStream_t stream) {
   if (debug) {
-    int rc = set_lds(fps_rows_kernel<W, BP, true>, lds, "furthest_point_sampling");
+    int rc = set_lds(fps_rows_kernel<W, NS, true>, lds, "furthest_point_sampling");
     if (rc != VDETR_OK) return rc;
-    hipLaunchKernelGGL((fps_rows_kernel<W, BP, true>), dim3(b), dim3(W * kWave), lds, stream, P);
+    hipLaunchKernelGGL((fps_rows_kernel<W, NS, true>), dim3(b), dim3(W * kWave), lds, stream, P);
     (void)hipDeviceSynchronize();
     unsigned long long z[16][8];
     (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rows_cyc), sizeof(z));
     const unsigned long long r = P.m > 1 ? P.m - 1 : 1;
     for (int i = 0; i < W; ++i)
-      fprintf(stderr, "[fps rows debug] W=%d BP=%d wave %2d cycles/round: test %llu passes %llu reduce %llu barrier %llu decode %llu | passes/round %.2f\n",
-              W, BP, i, z[i][0] / r, z[i][1] / r, z[i][2] / r, z[i][3] / r, z[i][4] / r, (double)z[i][5] / (double)r);
+      fprintf(stderr, "[fps rows debug] W=%d NS=%d wave %2d cycles/round: test %llu batches %llu reduce %llu barrier %llu decode %llu | batches/round %.2f buckets/round %.2f\n",
+              W, NS, i, z[i][0] / r, z[i][1] / r, z[i][2] / r, z[i][3] / r, z[i][4] / r, (double)z[i][5] / (double)r, (double)z[i][6] / (double)r);
     return check_launch("furthest_point_sampling");
   }
-  int rc = set_lds(fps_rows_kernel<W, BP, false>, lds, "furthest_point_sampling");
+  int rc = set_lds(fps_rows_kernel<W, NS, false>, lds, "furthest_point_sampling");
   if (rc != VDETR_OK) return rc;
-  hipLaunchKernelGGL((fps_rows_kernel<W, BP, false>), dim3(b), dim3(W * kWave), lds, stream, P);
+  hipLaunchKernelGGL((fps_rows_kernel<W, NS, false>), dim3(b), dim3(W * kWave), lds, stream, P);
   return check_launch("furthest_point_sampling");
 }
 
@@ -443,21 +472,26 @@ int fps_rows_launch(RowsParams& P, int b, const RowsPlan& pl, hipStream_t stream
   static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
   int nbmax = 0;
   for (int i = 0; i < b; ++i) {
-    P.scenes[i].nbuckets = (int)(((long)P.scenes[i].n + pl.bucket_pts - 1) / pl.bucket_pts);
+    P.scenes[i].nbuckets = (int)(((long)P.scenes[i].n + kBP - 1) / kBP);
     nbmax = nbmax > P.scenes[i].nbuckets ? nbmax : P.scenes[i].nbuckets;
   }
   size_t lds = (size_t)kRowsHistWords * sizeof(int);
   if ((size_t)nbmax * sizeof(float4) > lds) lds = (size_t)nbmax * sizeof(float4);
-  const int key = pl.waves * 100 + pl.bucket_pts;
-  switch (key) {
-    case 1616: return launch_rows<16, 16>(P, b, lds, debug, stream);
-    case 1632: return launch_rows<16, 32>(P, b, lds, debug, stream);
-    case 1664: return launch_rows<16, 64>(P, b, lds, debug, stream);
-    case 816: return launch_rows<8, 16>(P, b, lds, debug, stream);
-    case 832: return launch_rows<8, 32>(P, b, lds, debug, stream);
-    case 864: return launch_rows<8, 64>(P, b, lds, debug, stream);
+  const int ns = (nbmax + pl.waves * kWave - 1) / (pl.waves * kWave);
+  switch (pl.waves) {
+    case 16:
+      if (ns <= 1) return launch_rows<16, 1>(P, b, lds, debug, stream);
+      if (ns <= 2) return launch_rows<16, 2>(P, b, lds, debug, stream);
+      return launch_rows<16, kRowsSlots>(P, b, lds, debug, stream);
+    case 8:
+      if (ns <= 2) return launch_rows<8, 2>(P, b, lds, debug, stream);
+      if (ns <= 3) return launch_rows<8, 3>(P, b, lds, debug, stream);
+      return launch_rows<8, kRowsSlots>(P, b, lds, debug, stream);
+    case 4:
+      if (ns <= 3) return launch_rows<4, 3>(P, b, lds, debug, stream);
+      return launch_rows<4, kRowsSlots>(P, b, lds, debug, stream);
   }
-  set_error("furthest_point_sampling: no kernel for %d waves x %d-point buckets", pl.waves, pl.bucket_pts);
+  set_error("furthest_point_sampling: no kernel for %d waves", pl.waves);
   return VDETR_ERR_ARG;
 }
 

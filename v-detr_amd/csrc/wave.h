@@ -181,6 +181,8 @@ __device__ __forceinline__ float readlane_f32(float v, int lane) {
 // builtin.  Two different SGPR sources would break the one-constant-bus-read rule, so the lane select goes through
 // M0; the s_nop covers the wait states a VALU-written data SGPR may need, inline asm is not scanned for hazards.)
 __device__ __forceinline__ unsigned writelane_u32(unsigned v, unsigned x, int lane) {
+  x = (unsigned)__builtin_amdgcn_readfirstlane((int)x);  // no-ops for SGPR values; an "s" operand left in a VGPR is not legalised
+  lane = __builtin_amdgcn_readfirstlane(lane);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(lane) : "m0");
   return v;
 }
