@@ -590,6 +590,19 @@ int vdetr_sp_bn_act_fwd_f32(const vdetr_spbn_desc* d, vdetr_stream_t stream);
 int vdetr_sp_bn_act_bwd_f32(const vdetr_spbn_desc* d, const float* dy, float* dx, float* dresidual, float* dgamma, float* dbeta,
                             vdetr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Fixed coordinate embeddings — PositionEmbeddingCoordsSine (models/position_embedding.py:21-148); one launch each.
+ *   xyz (b,n,3); range_min / range_max (b,3) = the scene extent for `normalize=True` (shift_scale_points,
+ *   utils/pc_util.py:38-66), both NULL for normalize=False.
+ * fourier (:98-127): out (b, 2*d_out, n); channel c = sin(2 pi x . gauss_b[:,c]), channel d_out + c = its cos;
+ *   gauss_b (3, ldb) row-major is the module's checkpointed buffer, d_out <= ldb columns of it are used.
+ * sine (:51-96): out (b, num_channels, n), num_channels even; per axis a block of channels
+ *   (even i: sin, odd i: cos)(x * scale / temperature^(2 floor(i/2) / cdim)); scale == 0 leaves x unscaled. */
+int vdetr_pos_embed_fourier_f32(const float* xyz, int b, int n, const float* range_min, const float* range_max,
+                                const float* gauss_b, int ldb, int d_out, float* out, vdetr_stream_t stream);
+int vdetr_pos_embed_sine_f32(const float* xyz, int b, int n, const float* range_min, const float* range_max,
+                             int num_channels, float temperature, float scale, float* out, vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

@@ -52,6 +52,48 @@ def test_fps_full_size_scene():
     assert len(set(got[0].tolist())) == 4096  # size-independent property: samples are distinct
 
 
+def test_fps_c4_size_scene():
+    """BASELINE config 4 size: 80k-point voxelised scene -> 4096 samples, against the oracle (two buckets per owner
+    lane in fps_rows.hip)."""
+    from vdetr_amd import pointnet2_utils as PU
+    x = grid_cloud(80000, 12)
+    ref = O.furthest_point_sampling(x[None], 4096)
+    got = PU.furthest_point_sample(cu(x[None]), 4096).cpu().numpy()
+    bad = np.nonzero(ref != got)[1]
+    assert bad.size == 0, f"first mismatch at sample {bad[:1]}: ref {ref[0, bad[:3]]} got {got[0, bad[:3]]}"
+
+
+@pytest.mark.parametrize("kind", ["line", "plane", "duplicates", "two_clusters", "huge_coords"])
+def test_fps_degenerate_clouds_bit_exact(kind):
+    """Clouds that defeat the cell grid (everything in a few cells, empty axes, ties everywhere): the buckets are
+    still runs of 64 sorted points with exact boxes, so the result must not change."""
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(5)
+    n, m = 5000, 300
+    if kind == "line":
+        x = np.zeros((n, 3), np.float32); x[:, 0] = rng.permutation(n) * 0.01 + 1.0
+    elif kind == "plane":
+        x = np.stack([rng.integers(0, 60, n) * 0.05 + 1, rng.integers(0, 60, n) * 0.05 + 1, np.full(n, 2.0)], 1).astype(np.float32)
+    elif kind == "duplicates":
+        x = np.repeat(rng.uniform(1, 3, (50, 3)).astype(np.float32), 100, 0)
+        rng.shuffle(x)
+    elif kind == "two_clusters":
+        x = np.concatenate([rng.normal(1, 1e-3, (n // 2, 3)), rng.normal(500, 1e-3, (n - n // 2, 3))]).astype(np.float32)
+    else:  # squared distances beyond the reference's 1e10 initial value
+        x = (rng.uniform(-1, 1, (n, 3)) * 3e5).astype(np.float32)
+    ref = O.furthest_point_sampling(x[None], m)
+    got = PU.furthest_point_sample(cu(x[None]), m).cpu().numpy()
+    assert np.array_equal(ref, got), np.nonzero(ref != got)[1][:3]
+
+
+def test_fps_200k_property():
+    """Four buckets per owner lane (the largest geometry of fps_rows.hip): the defining FPS property + the oracle on a prefix."""
+    from vdetr_amd import pointnet2_utils as PU
+    x = np.random.default_rng(4).uniform(1, 9, size=(1, 200000, 3)).astype(np.float32)
+    got = PU.furthest_point_sample(cu(x), 256).cpu().numpy()[0]
+    assert np.array_equal(got, O.furthest_point_sampling(x, 256)[0])
+
+
 def test_fps_large_property():
     """n beyond one bucket per lane-slot (bucket size > 64): distinct samples, first index 0, and the min pairwise
     distance of the sample set is non-increasing in sampling order (the defining FPS property)."""

@@ -160,6 +160,8 @@ _SIGNATURES = {
     "vdetr_furthest_point_sampling_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_fps_varlen_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "vdetr_furthest_point_sampling_varlen_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_pos_embed_fourier_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vdetr_pos_embed_sine_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]),
     "vdetr_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vdetr_gather_rows_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vdetr_gather_points_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -33,7 +33,7 @@ inline int fps_ref_log2_of(int n) {
 }
 
 // ---- row-per-bucket kernel (fps_rows.hip) ------------------------------------------------------------------
-constexpr int kRowsSlots = 6;  // buckets per owner lane, at most
+constexpr int kRowsSlots = 4;  // buckets per owner lane, at most (a power of two)
 
 struct RowsScene {
   const float* xyz;  // (n,3)
@@ -46,6 +46,7 @@ struct RowsParams {
   float4* pts;     // workspace: sorted (x,y,z,t), all scenes back to back
   uint32_t* keys;  // workspace: tie-order key of each sorted point
   int m;
+  int ablate;      // timing experiments only (VDETR_FPS_ABLATE): bit 0 no processing, 1 no test, 2 no best, 3 no decide
   RowsScene scenes[kFpsMaxScenes];
 };
 

@@ -1,13 +1,26 @@
 """Fixed (non-learned) coordinate embeddings — same constructor, buffer name (``gauss_B``) and forward signature as
 the reference's models/position_embedding.py:21-148.  Dead code in the default config (querypos_mlp=True), kept for
-the querypos_mlp=False path of ModelVDETR (model_vdetr.py:121-132)."""
+the querypos_mlp=False path of ModelVDETR (model_vdetr.py:121-132).
+
+Device tensors go through one HIP launch per call (csrc/pos_embed.hip, ``vdetr_pos_embed_{fourier,sine}_f32``) and
+come back as the reference's layout, a contiguous (B, d_pos, N).  Host tensors take the op-by-op restatement below,
+which is what the CPU tests pin against the reference's golden vectors."""
 import math
 
 import numpy as np
 import torch
 from torch import nn
 
+from . import _lib as L
 from .pc_util import shift_scale_points
+
+
+def _range_ptrs(xyz, normalize, input_range):
+    if not normalize:
+        return None, None
+    lo, hi = (r.to(device=xyz.device, dtype=torch.float32).contiguous() for r in input_range)
+    assert lo.shape == (xyz.shape[0], 3) and hi.shape == (xyz.shape[0], 3)
+    return lo, hi
 
 
 class PositionEmbeddingCoordsSine(nn.Module):
@@ -31,6 +44,16 @@ class PositionEmbeddingCoordsSine(nn.Module):
     def get_sine_embeddings(self, xyz, num_channels, input_range):
         """position_embedding.py:51-96: per-axis sin/cos with geometric frequencies, remainder channels go to the
         first axes in steps of two."""
+        if xyz.is_cuda:
+            assert xyz.shape[2] == 3 and num_channels % 2 == 0
+            L.require_float(xyz, "xyz")
+            x = xyz.contiguous()
+            lo, hi = _range_ptrs(x, self.normalize, input_range)
+            out = x.new_empty((x.shape[0], num_channels, x.shape[1]))
+            L.check(L.lib().vdetr_pos_embed_sine_f32(L.ptr(x), x.shape[0], x.shape[1], L.ptr(lo), L.ptr(hi), num_channels,
+                                                     float(self.temperature), float(self.scale or 0.0), L.ptr(out),
+                                                     L.stream_ptr()), "pos_embed_sine")
+            return out
         xyz = xyz.clone()
         if self.normalize:
             xyz = shift_scale_points(xyz, src_range=input_range)
@@ -62,6 +85,15 @@ class PositionEmbeddingCoordsSine(nn.Module):
         assert num_channels > 0 and num_channels % 2 == 0
         d_in, d_out = self.gauss_B.shape[0], num_channels // 2
         assert d_out <= self.gauss_B.shape[1] and d_in == xyz.shape[-1]
+        if xyz.is_cuda:
+            assert d_in == 3
+            L.require_float(xyz, "xyz")
+            x, gb = xyz.contiguous(), self.gauss_B.contiguous()
+            lo, hi = _range_ptrs(x, self.normalize, input_range)
+            out = x.new_empty((bsize, num_channels, npoints))
+            L.check(L.lib().vdetr_pos_embed_fourier_f32(L.ptr(x), bsize, npoints, L.ptr(lo), L.ptr(hi), L.ptr(gb), gb.shape[1],
+                                                        d_out, L.ptr(out), L.stream_ptr()), "pos_embed_fourier")
+            return out
         xyz = xyz.clone()
         if self.normalize:
             xyz = shift_scale_points(xyz, src_range=input_range)
