@@ -70,7 +70,7 @@ __device__ __forceinline__ unsigned deposit_bits(unsigned c, unsigned m) {
   return r;
 }
 
-__device__ unsigned long long g_rows_cyc[16][12];
+__device__ unsigned long long g_rows_cyc[16][8];
 __device__ __forceinline__ unsigned long long rows_clock() {
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -80,24 +80,19 @@ __device__ __forceinline__ unsigned long long rows_clock() {
 }
 
 constexpr int kBP = 64;  // points per bucket: one wave-wide load
+constexpr int kKB = 4;   // buckets in flight per wave
 
 // W waves per scene, at most NS buckets per owner lane (compile-time bound of the slot loops)
 template <int W, int NS, bool DEBUG>
 __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   constexpr int T = W * kWave;
-  constexpr int SP = NS * kWave;  // LDS entries per wave (NS is a power of two)
   extern __shared__ __align__(16) unsigned char smem[];
-  int* const s_hist = reinterpret_cast<int*>(smem);  // prologue; the rounds' arrays below alias it
-  float4* const s_cand = reinterpret_cast<float4*>(smem);                 // (x,y,z) of every bucket's max
-  unsigned* const s_rank = reinterpret_cast<unsigned*>(s_cand + W * SP);  // its rank
-  unsigned* const s_key = s_rank + W * SP;                                // its tie key
-  unsigned* const s_list = s_key + W * SP;                                // this round's surviving buckets
+  int* const s_hist = reinterpret_cast<int*>(smem);        // prologue
+  float4* const s_cand = reinterpret_cast<float4*>(smem);  // rounds: (x,y,z,key) of every bucket's max
   __shared__ int s_wsum[W];
   __shared__ float s_red[W][6];
-  __shared__ float4 s_c[2];
-  __shared__ unsigned s_cnt[2];
-  __shared__ unsigned s_dirty[W];
-  __shared__ uint4 s_wb[W];
+  __shared__ unsigned s_xr[2][16];
+  __shared__ float4 s_xc[2][16];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const RowsScene S = Pin.scenes[blockIdx.x];
@@ -206,23 +201,20 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   }
   __syncthreads();  // the sorted cloud is visible to every wave; s_hist is dead, s_cand may be written
 
-  // ---- prologue 3: bucket boxes into owner-lane registers; rank / key / cand of every bucket into LDS ----------------
-  // bucket g: wave g % W, owner lane (g / W) % 64, slot g / (64 W); its LDS index p = wave * SP + slot * 64 + lane keeps a
-  // wave's buckets contiguous (conflict-free owner reads) and gives g back with shifts: g = p / SP + W * (p % SP).
+  // ---- prologue 3: bucket boxes into owner-lane registers, cand[] ----------------------------------------------
+  // bucket g: wave g % W, owner lane (g / W) % 64, slot g / (64 W)
   const int nslots = (nb + W * kWave - 1) / (W * kWave);
   float blo[NS][3], bhi[NS][3];
+  unsigned brank[NS], bkey[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int pown = w * SP + s * kWave + lane;
-    s_rank[pown] = 0u;
-    s_key[pown] = 0xFFFFFFFFu;
+    brank[s] = 0u; bkey[s] = 0xFFFFFFFFu;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { blo[s][a] = 0.f; bhi[s][a] = 0.f; }
     if (s < nslots) {
       for (int li = 0; li < kWave; ++li) {
         const int g = w + W * (li + kWave * s);
         if (g >= nb) break;
-        const int pb = w * SP + s * kWave + li;
         const float4 p = pts[g * kBP + lane];
         const unsigned key = keys[g * kBP + lane];
         const bool cnd = p.w >= 0.f;
@@ -232,54 +224,104 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
         l3[2] = wave_allmin_f32(cnd ? p.z : INFINITY); h3[2] = wave_allmax_f32(cnd ? p.z : -INFINITY);
         const float anyv = wave_allmax_f32(cnd ? p.w : -INFINITY);  // 1e10 if the bucket holds a candidate
         const unsigned kmin = grp_allmin_u32<kWave>(cnd ? key : 0xFFFFFFFFu);
-        if (cnd && key == kmin) {
-          s_cand[pb] = p;
-          s_key[pb] = key;
-          s_rank[pb] = fps_rank_of(p.w);
-        }
+        if (cnd && key == kmin) s_cand[g] = p;
         if (lane == li) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) { blo[s][a] = l3[a]; bhi[s][a] = h3[a]; }
+          brank[s] = fps_rank_of(anyv); bkey[s] = kmin;
         }
       }
     }
   }
-  if (tid == 0) {
-    s_c[1] = make_float4(p0x, p0y, p0z, 0.f);  // round 1 starts from index 0 unconditionally (:89-90)
-    s_cnt[0] = 0u; s_cnt[1] = 0u;
-    out[0] = 0;
-  }
-  if (lane == 0) { s_dirty[w] = 1u; s_wb[w] = make_uint4(0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u); }
-  __syncthreads();
 
   // ---- rounds ------------------------------------------------------------------------------------------------
-  // Round j (sample c = s_c[j & 1]), four LDS-only barriers:
-  //   test      every owner lane: is c closer to my box than my bucket's max?  Survivors go to a shared list.
-  //   process   entry i of the list is taken by wave i % W, whoever owns it: a round touches ~15 buckets, with the
-  //             list every wave gets one (a wave that had to process its own would, one round in two, find 3 or 4).
-  //             One 16-B load per lane, distance / min / store, 6-stage DPP max of the rank (tie keys only if the
-  //             max is not unique); the winner lane writes the bucket's rank, key and coordinates to LDS.
-  //   best      a wave whose best bucket was processed recomputes the arg-max over its buckets (ranks only decrease:
-  //             nothing else can invalidate it)
-  //   decide    wave 0 alone (the others are parked at the barrier, its chain runs uncontended): arg-max of the W
-  //             entries, publishes the next sample.
-  unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  auto lds_barrier = [&]() __attribute__((always_inline)) {
-    // not __syncthreads(): that would also drain vmcnt, i.e. wait for the L2 acknowledgement of the running-distance
-    // stores.  Their readers are waves of this CU, behind the same in-order vector memory pipeline and L1.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  for (int j = 1; j < m; ++j) {
-    unsigned long long tt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (DEBUG) tt[0] = rows_clock();
-    const int par = j & 1;
-    const float4 c4 = s_c[par];
-    unsigned br[NS];
+  float cx = p0x, cy = p0y, cz = p0z;  // the reference starts from index 0 unconditionally (:89-90)
+  if (tid == 0) out[0] = 0;
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool dirty = true;  // wave-uniform: the wave's best bucket (owner lane best_l, slot best_s) was processed
+  int best_l = -1, best_s = -1;
+  unsigned wrank = 0u, wkey = 0xFFFFFFFFu;
+  float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);  // lane 0: coordinates of this wave's best
+  unsigned long long todo[NS];
+
+  // next surviving bucket of this wave, across slots (scalar code)
+  auto pick = [&](int& l, int& sl) __attribute__((always_inline)) {  // the caller knows one exists
+    if (NS == 1) {
+      l = __ffsll((long long)todo[0]) - 1;
+      sl = 0;
+      todo[0] &= todo[0] - 1ull;
+      return;
+    }
+    bool found = false;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) br[s] = s_rank[w * SP + s * kWave + lane];
-    const float cx = readlane_f32(c4.x, 0), cy = readlane_f32(c4.y, 0), cz = readlane_f32(c4.z, 0);
-    unsigned long long todo[NS];
-    int nme = 0;
+    for (int q = 0; q < NS; ++q) {  // no early exit: every todo[] index stays a compile-time constant (registers, not scratch)
+      const bool hit = !found && todo[q] != 0ull;
+      if (hit) { l = __ffsll((long long)todo[q]) - 1; sl = q; }
+      todo[q] = hit ? (todo[q] & (todo[q] - 1ull)) : todo[q];
+      found |= hit;
+    }
+  };
+  // NC buckets (owner lane bl[u], slot bs[u]) as NC interleaved chains
+  int bl[kKB] = {0, 0, 0, 0}, bs[kKB] = {0, 0, 0, 0};
+  auto process = [&](auto nc_tag) __attribute__((always_inline)) {
+    constexpr int NC = decltype(nc_tag)::value;
+    unsigned g[NC], pos[NC], ky[NC], rk[NC], v[NC];
+    float4 p[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      g[u] = (unsigned)(w + W * (bl[u] + kWave * bs[u]));
+      pos[u] = g[u] * kBP + (unsigned)lane;
+      p[u] = pts[pos[u]];
+      ky[u] = keys[pos[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const float d = sqdist3(p[u].x - cx, p[u].y - cy, p[u].z - cz);
+      const float t = fminf(d, p[u].w);  // -inf (non-candidate) stays -inf
+      pts[pos[u]].w = t;                 // unconditional: a predicated store would split the chains into blocks
+      rk[u] = fps_rank_of(t);
+      v[u] = rk[u];
+    }
+    // wave max of the ranks as a scalar: six DPP stages + v_readlane
+#pragma unroll
+    for (int u = 0; u < NC; ++u) v[u] = wave_max_u32_s(v[u]);
+    // an active bucket holds a candidate, so its max rank is >= 1 and padding lanes (rank 0) never match
+    unsigned long long tm[NC];
+    bool multi = false;
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      tm[u] = __ballot(rk[u] == v[u]);
+      multi |= (tm[u] & (tm[u] - 1ull)) != 0ull;
+    }
+    if (__builtin_expect(multi, 0)) {  // wave-uniform, rare: equal maxima inside a bucket, the smallest tie key wins
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {
+        const bool top = rk[u] == v[u];
+        const unsigned gk = wave_min_u32_s(top ? ky[u] : 0xFFFFFFFFu);
+        tm[u] = __ballot(top && ky[u] == gk);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const int wl = __ffsll((long long)tm[u]) - 1;
+      const unsigned qr = readlane_u32(rk[u], wl), qk = readlane_u32(ky[u], wl);
+      if (lane == wl) s_cand[g[u]] = p[u];  // (x,y,z) of the bucket's new max; .w is not read
+      // ranks only ever decrease, so the wave's arg-max stays valid unless it was THIS bucket
+      dirty |= (bl[u] == best_l) & (bs[u] == best_s);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        if (bs[u] == q) {  // wave-uniform
+          brank[q] = writelane_u32(brank[q], qr, bl[u]);
+          bkey[q] = writelane_u32(bkey[q], qk, bl[u]);
+        }
+      }
+    }
+  };
+
+  for (int j = 1; j < m; ++j) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if (DEBUG) t0 = rows_clock();
+    int left = 0;  // surviving buckets of this wave
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       todo[s] = 0;
@@ -289,119 +331,96 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
         const float dx = fmaxf(fmaxf(blo[s][0] - cx, cx - bhi[s][0]), 0.f);
         const float dy = fmaxf(fmaxf(blo[s][1] - cy, cy - bhi[s][1]), 0.f);
         const float dz = fmaxf(fmaxf(blo[s][2] - cz, cz - bhi[s][2]), 0.f);
-        todo[s] = __ballot(__float_as_uint(sqdist3(dx, dy, dz)) + 1u < br[s]);
-        nme += __popcll(todo[s]);
+        todo[s] = __ballot(__float_as_uint(sqdist3(dx, dy, dz)) + 1u < brank[s]);
+        left += __popcll(todo[s]);
       }
     }
-    if (Pin.ablate & 2) nme = 0;
-    if (nme) {  // wave-uniform
-      unsigned base = 0u;
-      if (lane == 0) base = atomicAdd(&s_cnt[par], (unsigned)nme);
-      base = readlane_u32(base, 0);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (todo[s]) {
-          const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(todo[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo[s], 0u));
-          if ((todo[s] >> lane) & 1ull) s_list[base + below] = (unsigned)(w * SP + s * kWave + lane);
-          base += (unsigned)__popcll(todo[s]);
+    if (DEBUG) t1 = rows_clock();
+    while (__builtin_expect(left > 0, 1)) {
+      const int cnt = left < kKB ? left : kKB;
+      left -= cnt;
+      pick(bl[0], bs[0]);
+      if (__builtin_expect(cnt == 1, 1)) {
+        process(std::integral_constant<int, 1>());
+      } else {
+        pick(bl[1], bs[1]);
+        if (cnt == 2) {
+          process(std::integral_constant<int, 2>());
+        } else {
+          pick(bl[2], bs[2]);
+          bl[3] = bl[0]; bs[3] = bs[0];  // a missing fourth repeats the first bucket (harmless: min and max are idempotent)
+          if (cnt == 4) pick(bl[3], bs[3]);
+          process(std::integral_constant<int, kKB>());
         }
       }
+      if (DEBUG) { ++acc[5]; acc[6] += cnt; }
     }
-    if (DEBUG) tt[1] = rows_clock();
-    lds_barrier();
-    if (DEBUG) tt[2] = rows_clock();
-    const int total = (Pin.ablate & 1) ? 0 : (int)readlane_u32(s_cnt[par], 0);
-    for (int i = w; i < total; i += W) {
-      const unsigned pb = readlane_u32(s_list[i], 0);
-      const unsigned obest = s_wb[pb / SP].z;  // the owner wave's current best bucket
-      const unsigned g = (pb / SP) + (unsigned)W * (pb % SP);
-      const unsigned pos = g * kBP + (unsigned)lane;
-      const float4 p = pts[pos];
-      const unsigned ky = keys[pos];
-      const float d = sqdist3(p.x - cx, p.y - cy, p.z - cz);
-      const float t = fminf(d, p.w);  // -inf (non-candidate) stays -inf
-      pts[pos].w = t;                 // unconditional: cheaper than the predicate
-      const unsigned rk = fps_rank_of(t);
-      const unsigned v = grp_allmax_u32<kWave>(rk);
-      // a listed bucket holds a candidate, so its max rank is >= 1 and padding lanes (rank 0) never match
-      const bool top = rk == v;
-      unsigned long long tm = __ballot(top);
-      if (tm & (tm - 1ull)) {  // wave-uniform: equal maxima inside the bucket, the smallest tie key wins
-        const unsigned gk = grp_allmin_u32<kWave>(top ? ky : 0xFFFFFFFFu);
-        tm = __ballot(top && ky == gk);
-      }
-      if (lane == __ffsll((long long)tm) - 1) {
-        s_cand[pb] = p;  // (x,y,z) of the bucket's new max; .w is not read
-        s_rank[pb] = rk;
-        s_key[pb] = ky;
-        // ranks only ever decrease, so the owner's arg-max stays valid unless it was THIS bucket
-        if (obest == pb) s_dirty[pb / SP] = 1u;
-      }
-      if (DEBUG) ++acc[8];
-    }
-    if (DEBUG) tt[3] = rows_clock();
-    lds_barrier();
-    if (DEBUG) tt[4] = rows_clock();
-    if (!(Pin.ablate & 4) && readlane_u32(s_dirty[w], 0)) {  // arg-max over this wave's buckets
-      unsigned mrank = 0u, mkey = 0xFFFFFFFFu;
-      int mp = 0;
+    if (DEBUG) t2 = rows_clock();
+    // arg-max over this wave's buckets (only if one of them changed), its coordinates from cand[]
+    if (dirty) {
+      dirty = false;
+      unsigned mrank = brank[0], mkey = bkey[0];
+      int mslot = 0;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int s = 1; s < NS; ++s) {
         if (s < nslots) {
-          const int pown = w * SP + s * kWave + lane;
-          const unsigned r = s_rank[pown], k = s_key[pown];
-          const bool b = (r > mrank) | ((r == mrank) & (k < mkey));
-          mrank = b ? r : mrank;
-          mkey = b ? k : mkey;
-          mp = b ? pown : mp;
+          const bool b = (brank[s] > mrank) | ((brank[s] == mrank) & (bkey[s] < mkey));
+          mrank = b ? brank[s] : mrank;
+          mkey = b ? bkey[s] : mkey;
+          mslot = b ? s : mslot;
         }
       }
-      const unsigned wrank = grp_allmax_u32<kWave>(mrank);
+      wrank = wave_max_u32_s(mrank);
       const bool top = mrank == wrank;
       unsigned long long tm = __ballot(top);
-      if (tm & (tm - 1ull)) {
-        const unsigned k2 = grp_allmin_u32<kWave>(top ? mkey : 0xFFFFFFFFu);
+      if (__builtin_expect((tm & (tm - 1ull)) != 0ull, 0)) {
+        const unsigned k2 = wave_min_u32_s(top ? mkey : 0xFFFFFFFFu);
         tm = __ballot(top && mkey == k2);
       }
       const int wl = __ffsll((long long)tm) - 1;
-      const unsigned wkey = readlane_u32(mkey, wl), wp = readlane_u32((unsigned)mp, wl);
+      wkey = readlane_u32(mkey, wl);
+      const int wslot = NS > 1 ? (int)readlane_u32((unsigned)mslot, wl) : 0;
+      best_l = wl; best_s = wslot;
       if (lane == 0) {
-        s_wb[w] = make_uint4(wrank, wkey, wp, 0u);
-        s_dirty[w] = 0u;
+        const int gw = min(w + W * (wl + kWave * wslot), nb - 1);  // wrank == 0: any bucket, the entry is ignored
+        cw = s_cand[gw];
       }
-      if (DEBUG) ++acc[9];
     }
-    if (DEBUG) tt[5] = rows_clock();
-    lds_barrier();
-    if (DEBUG) tt[6] = rows_clock();
-    if (w == 0 && (Pin.ablate & 8)) {
-      if (lane == 0) { s_c[par ^ 1] = make_float4(p0x, p0y, p0z, 0.f); s_cnt[par ^ 1] = 0u; out[j] = 0; }
-    } else if (w == 0) {
-      const uint4 e = s_wb[lane & (W - 1)];  // lanes 0..W-1 hold the W entries (the other rows repeat them)
-      const unsigned grank = row_allmax_u32_fx(e.x);
-      const bool top = e.x == grank;
+    const int par = j & 1;
+    if (lane == 0) {
+      s_xr[par][w] = wrank;
+      s_xc[par][w] = make_float4(cw.x, cw.y, cw.z, __uint_as_float(wkey));
+    }
+    if (DEBUG) t3 = rows_clock();
+    // LDS-only barrier: a full __syncthreads() would also drain vmcnt, i.e. wait for the L2 acknowledgement of this
+    // round's running-distance stores, which only this wave reads back.
+    // (Tried: the last wave to arrive, found with a returning LDS add, decodes alone and publishes the sample while the
+    // others are parked at the barrier: +8 %, the add's round trip and the extra read cost more than the contention.)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (DEBUG) t4 = rows_clock();
+    {
+      const int sl = lane & (W - 1);  // lanes 0..W-1 hold the W entries (the other rows repeat them)
+      const unsigned xr = s_xr[par][sl];
+      float4 xc = s_xc[par][sl];
+      asm volatile("" : "+v"(xc.x), "+v"(xc.y), "+v"(xc.z), "+v"(xc.w));  // one ds_read_b128 here, not a dependent read later
+      const unsigned xk = __float_as_uint(xc.w);
+      const unsigned grank = row_allmax_u32_fx(xr);
+      const bool top = xr == grank;
       unsigned long long tm = __ballot(top) & ((1ull << W) - 1ull);
-      if (tm & (tm - 1ull)) {
-        const unsigned k2 = row_allmin_u32_fx(top ? e.y : 0xFFFFFFFFu);
-        tm = __ballot(top && e.y == k2) & ((1ull << W) - 1ull);
+      if (__builtin_expect((tm & (tm - 1ull)) != 0ull, 0)) {
+        const unsigned k2 = row_allmin_u32_fx(top ? xk : 0xFFFFFFFFu);
+        tm = __ballot(top && xk == k2) & ((1ull << W) - 1ull);
       }
       const int ws = __ffsll((long long)tm) - 1;
-      const unsigned gkey = readlane_u32(e.y, ws), gp = readlane_u32(e.z, ws);
-      if (lane == 0) {
-        float4 nc = s_cand[gp];
-        // no candidate at all: the reference's reduction returns besti = 0 (:93-94), whose key is 0
-        if (!grank) nc = make_float4(p0x, p0y, p0z, 0.f);
-        s_c[par ^ 1] = nc;
-        s_cnt[par ^ 1] = 0u;
-        out[j] = (int32_t)(grank ? gkey : 0u);  // translated to the point index below
-      }
+      const unsigned gkey = readlane_u32(xk, ws);
+      const float nx = readlane_f32(xc.x, ws), ny = readlane_f32(xc.y, ws), nz = readlane_f32(xc.z, ws);
+      // no candidate at all: the reference's reduction returns besti = 0 (:93-94), whose key is 0
+      cx = grank ? nx : p0x; cy = grank ? ny : p0y; cz = grank ? nz : p0z;
+      if (tid == 0) out[j] = (int32_t)(grank ? gkey : 0u);  // translated to the point index below
     }
-    if (DEBUG) tt[7] = rows_clock();
-    lds_barrier();
     if (DEBUG) {
-      tt[8] = rows_clock();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += tt[i + 1] - tt[i];
+      const unsigned long long t5 = rows_clock();
+      acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4;
     }
   }
   // ---- epilogue: tie keys -> point indices (wave 0 wrote the keys; they are read past this CU's L1) ---------------
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   }
   if (DEBUG && lane == 0 && blockIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) g_rows_cyc[w][i] = acc[i];
+    for (int i = 0; i < 8; ++i) g_rows_cyc[w][i] = acc[i];
   }
 }
 
@@ -423,7 +442,7 @@ bool fps_rows_plan(int nmax, RowsPlan* plan) {
   static const int env_waves = getenv("VDETR_FPS_WAVES") ? atoi(getenv("VDETR_FPS_WAVES")) : 0;
   if (env_impl == 2 || nmax <= 0) return false;
   const long nb = ((long)nmax + kBP - 1) / kBP;
-  int waves = (env_waves == 8 || env_waves == 16) ? env_waves : 16;
+  int waves = (env_waves == 4 || env_waves == 8 || env_waves == 16) ? env_waves : 16;
   while (waves < 16 && nb > (long)kRowsSlots * kWave * waves) waves *= 2;
   if (nb > (long)kRowsSlots * kWave * waves) return false;
   plan->waves = waves;
@@ -432,22 +451,18 @@ bool fps_rows_plan(int nmax, RowsPlan* plan) {
 }
 
 template <int W, int NS>
-static int launch_rows(RowsParams& P, int b, bool debug, hipStream_t stream) {
-  size_t lds = (size_t)kRowsHistWords * sizeof(int);
-  const size_t rounds = (size_t)W * NS * kWave * (sizeof(float4) + 3 * sizeof(unsigned));
-  if (rounds > lds) lds = rounds;
+static int launch_rows(RowsParams& P, int b, size_t lds, bool debug, hipStream_t stream) {
   if (debug) {
     int rc = set_lds(fps_rows_kernel<W, NS, true>, lds, "furthest_point_sampling");
     if (rc != VDETR_OK) return rc;
     hipLaunchKernelGGL((fps_rows_kernel<W, NS, true>), dim3(b), dim3(W * kWave), lds, stream, P);
     (void)hipDeviceSynchronize();
-    unsigned long long z[16][12];
+    unsigned long long z[16][8];
     (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rows_cyc), sizeof(z));
     const unsigned long long r = P.m > 1 ? P.m - 1 : 1;
     for (int i = 0; i < W; ++i)
-      fprintf(stderr, "[fps rows debug] W=%d NS=%d wave %2d cycles/round: test+list %llu wait %llu process %llu wait %llu best %llu wait %llu decide %llu wait %llu | buckets/round %.2f best/round %.2f\n",
-              W, NS, i, z[i][0] / r, z[i][1] / r, z[i][2] / r, z[i][3] / r, z[i][4] / r, z[i][5] / r, z[i][6] / r, z[i][7] / r,
-              (double)z[i][8] / (double)r, (double)z[i][9] / (double)r);
+      fprintf(stderr, "[fps rows debug] W=%d NS=%d wave %2d cycles/round: test %llu batches %llu reduce %llu barrier %llu decode %llu | batches/round %.2f buckets/round %.2f\n",
+              W, NS, i, z[i][0] / r, z[i][1] / r, z[i][2] / r, z[i][3] / r, z[i][4] / r, (double)z[i][5] / (double)r, (double)z[i][6] / (double)r);
     return check_launch("furthest_point_sampling");
   }
   int rc = set_lds(fps_rows_kernel<W, NS, false>, lds, "furthest_point_sampling");
@@ -458,23 +473,26 @@ static int launch_rows(RowsParams& P, int b, bool debug, hipStream_t stream) {
 
 int fps_rows_launch(RowsParams& P, int b, const RowsPlan& pl, hipStream_t stream) {
   static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
-  static const int ablate = getenv("VDETR_FPS_ABLATE") ? atoi(getenv("VDETR_FPS_ABLATE")) : 0;
-  P.ablate = ablate;
+  P.ablate = 0;
   int nbmax = 0;
   for (int i = 0; i < b; ++i) {
     P.scenes[i].nbuckets = (int)(((long)P.scenes[i].n + kBP - 1) / kBP);
     nbmax = nbmax > P.scenes[i].nbuckets ? nbmax : P.scenes[i].nbuckets;
   }
+  size_t lds = (size_t)kRowsHistWords * sizeof(int);
+  if ((size_t)nbmax * sizeof(float4) > lds) lds = (size_t)nbmax * sizeof(float4);
   const int ns = (nbmax + pl.waves * kWave - 1) / (pl.waves * kWave);
-  if (pl.waves == 16) {
-    if (ns <= 1) return launch_rows<16, 1>(P, b, debug, stream);
-    if (ns <= 2) return launch_rows<16, 2>(P, b, debug, stream);
-    return launch_rows<16, kRowsSlots>(P, b, debug, stream);
-  }
-  if (pl.waves == 8) {
-    if (ns <= 1) return launch_rows<8, 1>(P, b, debug, stream);
-    if (ns <= 2) return launch_rows<8, 2>(P, b, debug, stream);
-    return launch_rows<8, kRowsSlots>(P, b, debug, stream);
+  switch (pl.waves) {
+    case 16:
+      if (ns <= 1) return launch_rows<16, 1>(P, b, lds, debug, stream);
+      if (ns <= 2) return launch_rows<16, 2>(P, b, lds, debug, stream);
+      return launch_rows<16, 4>(P, b, lds, debug, stream);
+    case 8:
+      if (ns <= 2) return launch_rows<8, 2>(P, b, lds, debug, stream);
+      return launch_rows<8, 4>(P, b, lds, debug, stream);
+    case 4:
+      if (ns <= 2) return launch_rows<4, 2>(P, b, lds, debug, stream);
+      return launch_rows<4, 4>(P, b, lds, debug, stream);
   }
   set_error("furthest_point_sampling: no kernel for %d waves", pl.waves);
   return VDETR_ERR_ARG;

@@ -159,6 +159,23 @@ __device__ __forceinline__ unsigned row_allmin_u32_fx(unsigned v) {
   v = min(v, dppz_u32<kDppRowMirror>(v));
   return v;
 }
+// Wave-wide max / min as a SCALAR (full exec): the row butterflies, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3 leave the result in row 3; six DPP-fused ops and one v_readlane instead of the
+// twelve VALU ops of the permlane-swap all-reduce.  (`old` = the op's identity: rows outside the row mask keep v.)
+constexpr int kDppRowBcast15 = 0x142;
+constexpr int kDppRowBcast31 = 0x143;
+__device__ __forceinline__ unsigned wave_max_u32_s(unsigned v) {
+  v = row_allmax_u32_fx(v);
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppRowBcast15, 0xA, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kDppRowBcast31, 0xC, 0xF, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32_s(unsigned v) {
+  v = row_allmin_u32_fx(v);
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, kDppRowBcast15, 0xA, 0xF, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, kDppRowBcast31, 0xC, 0xF, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned wave_allmax_u32(unsigned v) {
   v = row_allmax_u32(v);
   pair_u32 p = xrow16(v);
