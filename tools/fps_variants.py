@@ -61,17 +61,15 @@ def main():
     if "--sizes" in sys.argv:
         sizes = sys.argv[sys.argv.index("--sizes") + 1]
     variants = [("v2", {"VDETR_FPS_IMPL": "2"})]
-    for wv in (16, 8):
+    for wv in (16, 8, 4):
         variants.append((f"rows W={wv}", {"VDETR_FPS_WAVES": str(wv)}))
     variants.append(("default", {}))
-    if "--ablate" in sys.argv:  # timing experiments: results are wrong by construction
-        variants = [(f"ablate {a}", {"VDETR_FPS_ABLATE": str(a)}) for a in (0, 1, 2, 3)]
     if "--only" in sys.argv:
         keep = sys.argv[sys.argv.index("--only") + 1].split(";")
         variants = [v for v in variants if v[0] in keep]
     for name, env in variants:
         e = dict(os.environ)
-        for k in ("VDETR_FPS_IMPL", "VDETR_FPS_WAVES", "VDETR_FPS_BP", "VDETR_FPS_DEBUG", "VDETR_FPS_ABLATE"):
+        for k in ("VDETR_FPS_IMPL", "VDETR_FPS_WAVES", "VDETR_FPS_DEBUG"):
             e.pop(k, None)
         e.update(env)
         if debug:

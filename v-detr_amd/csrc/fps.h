@@ -1,5 +1,5 @@
-// fps.h — shared between the two furthest-point-sampling kernels (fps.hip: wave-per-bucket, any n;
-// fps_rows.hip: row-per-bucket, the fast path for clouds up to kRowsMaxPoints).
+// fps.h — shared between the two furthest-point-sampling kernels (fps.hip: any n; fps_rows.hip: the fast path for
+// clouds of up to 64 * 64 * 16 * kRowsSlots = 262,144 points).
 #pragma once
 #include "common.h"
 #include "wave.h"
@@ -32,7 +32,7 @@ inline int fps_ref_log2_of(int n) {
   return lg > 9 ? 9 : lg;
 }
 
-// ---- row-per-bucket kernel (fps_rows.hip) ------------------------------------------------------------------
+// ---- fps_rows.hip ------------------------------------------------------------------
 constexpr int kRowsSlots = 4;  // buckets per owner lane, at most (a power of two)
 
 struct RowsScene {
@@ -46,13 +46,12 @@ struct RowsParams {
   float4* pts;     // workspace: sorted (x,y,z,t), all scenes back to back
   uint32_t* keys;  // workspace: tie-order key of each sorted point
   int m;
-  int ablate;      // timing experiments only (VDETR_FPS_ABLATE): bit 0 no processing, 1 no test, 2 no best, 3 no decide
   RowsScene scenes[kFpsMaxScenes];
 };
 
 struct RowsPlan {  // geometry chosen on the host for one launch
-  int waves;       // 8 or 16 waves per workgroup
-  int bucket_pts;  // 16, 32 or 64 points per bucket
+  int waves;       // 4, 8 or 16 waves per workgroup
+  int bucket_pts;  // 64 points per bucket
 };
 
 // false: the cloud is too large for the row kernel (the caller uses fps.hip's kernel)

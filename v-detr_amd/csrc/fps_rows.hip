@@ -1,10 +1,15 @@
 // fps_rows.hip — furthest point sampling, the fast path of vdetr_furthest_point_sampling(_varlen)_f32.
 // Bit-exact with the reference's result (third_party/pointnet2/_ext_src/src/sampling_gpu.cu:73-176), like fps.hip,
 // and built on the same exact box-skip argument (see fps.hip's header); what differs is how a round's dependent
-// chain is laid out.  Measured with tools/probes/lat_probe.hip on one CU: a dependent VALU op costs ~8 cycles to a
-// wave whatever it is, a second independent chain interleaved with it is free, an L2-resident 1 KB bucket fetch
-// costs ~280-340, an LDS round trip ~60, and waves sharing a SIMD slow each other's chains down 2-2.5x.  So a
-// round is a LATENCY chain: few waves, short chains, independent work interleaved.
+// chain is laid out.  What the measurements behind it say (tools/probes/lat_probe.hip, tools/fps_variants.py, one CU):
+//   * a wave retires one instruction of this kind of code every ~8-10 cycles, dependent or not, and every TAKEN
+//     branch costs a refetch: the round is an instruction-count and control-flow problem, not a bandwidth one
+//     (an L2-resident 1 KB bucket fetch is ~300 cycles, an LDS round trip ~60, s_barrier ~25);
+//   * more waves help as long as they do different buckets (16 waves beat 8 and 4 by 1.5x / 2x), but whatever all
+//     waves repeat after the barrier is slowed down by the SIMD they share;
+//   * variants that lost: 16/32-point buckets with several buckets per wave pass (more box tests than they save),
+//     a shared survivor list that hands every wave one bucket per round (3 more barriers: 6.2 ms against 4.8),
+//     the last wave to arrive decoding alone (+8 %), runtime-selected code paths in the loop (+13 %).
 //
 // One workgroup of W waves per scene.  The cloud is counting-sorted into Z-order over 2^15 near-cubic cells (the
 // split sequence follows the cloud's aspect ratio) and cut into BUCKETS of 64 consecutive points.  Bucket g belongs
@@ -12,13 +17,13 @@
 // key of that max live in the registers of an owner lane of that wave, the coordinates of the max in LDS (cand[g]).
 //
 // Round j, per wave, ONE workgroup barrier:
-//   test    every owner lane: is the new sample closer to my box than my bucket's max?  (14 VALU per slot, slots
-//           independent)
-//   batch   up to 4 surviving buckets at a time, picked across slots: the four 16-B loads are issued back to back,
-//           then four independent chains (distance, min, store, 6-stage DPP/permlane max of the rank) interleave;
-//           the tie keys are reduced only if a bucket's maximum is not unique; the winner lane refreshes cand[g],
-//           the owner lane gets (rank, key) by v_readlane / v_writelane.
-//   reduce  (only if a bucket of this wave changed) arg-max over the owner lanes, coordinates from cand[]
+//   test    every owner lane: is the new sample closer to my box than my bucket's max?  (14 VALU per slot)
+//   batch   the wave's surviving buckets, 1, 2 or 4 at a time (the count is known from the ballots, the common case
+//           of one bucket is the fall-through path): 16-B load per lane, distance, min, store, wave max of the rank as
+//           a scalar (6 DPP stages + v_readlane); the tie keys are reduced only if the maximum is not unique; the
+//           winner lane refreshes cand[g], the owner lane gets (rank, key) by v_writelane.
+//   reduce  arg-max over the owner lanes, ONLY if the wave's best bucket was one of those processed: running
+//           distances never grow, so nothing else can invalidate it
 //   barrier LDS only: the running-distance stores are re-read by the same wave, nobody else needs them
 //   decode  every 16-lane row all-reduces the W entries, v_readlane of the winner's coordinates; the sample is
 //           recorded as its tie key and translated to the point index after the last round.
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       todo[s] = 0;
-      if (s < nslots) {
+      if (NS == 1 || s < nslots) {
         // distance of the sample to the bucket box, same arithmetic as a point distance; d >= +0, so
         // d < max  <=>  bits(d) + 1 < rank(max)   (rank 0, no candidate: never)
         const float dx = fmaxf(fmaxf(blo[s][0] - cx, cx - bhi[s][0]), 0.f);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
     }
     if (DEBUG) t2 = rows_clock();
     // arg-max over this wave's buckets (only if one of them changed), its coordinates from cand[]
-    if (dirty) {
+    if (__builtin_expect(dirty, 0)) {
       dirty = false;
       unsigned mrank = brank[0], mkey = bkey[0];
       int mslot = 0;
@@ -473,7 +478,6 @@ static int launch_rows(RowsParams& P, int b, size_t lds, bool debug, hipStream_t
 
 int fps_rows_launch(RowsParams& P, int b, const RowsPlan& pl, hipStream_t stream) {
   static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
-  P.ablate = 0;
   int nbmax = 0;
   for (int i = 0; i < b; ++i) {
     P.scenes[i].nbuckets = (int)(((long)P.scenes[i].n + kBP - 1) / kBP);
