@@ -467,6 +467,14 @@ class BackboneTrainer:
 # ---------------------------------------------------------------------------------------------------------------
 # roofline of the dominant kernels, measured live with HIP events on the launch stream
 # ---------------------------------------------------------------------------------------------------------------
+def _pmc_traffic():
+    """The newest profiles/rNN_pmc_traffic.json (tools/pmc_traffic.py writes it from a round's final PMC passes)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    with open(os.environ.get("VDETR_PMC_TRAFFIC") or cands[-1]) as fh:
+        return json.load(fh)
+
+
 def kernel_rooflines(cfg_name, device, reps=20):
     import ctypes
     from vdetr_amd import _lib as L
@@ -546,8 +554,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
                "rpe_scatter_per_s": 8.0 * pairs / t_bwd}
     # HBM traffic per launch measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/README.md)
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
-            tr = json.load(fh)
+        tr = _pmc_traffic()
         if cfg_name == "c2":
             fwd_obj["traffic"] = tr["attn_fwd_kernel<false,true,true>"]["bytes"]
             bwd_obj["traffic"] = tr["attn_bwd_box2_kernel"]["bytes"]
@@ -556,9 +563,43 @@ def kernel_rooflines(cfg_name, device, reps=20):
                 bwd_obj["valu_issue"] = {"wave_insts": vi, "limit_us": vi / 614.4e9 * 1e6, "frac": vi / 614.4e9 / t_bwd,
                                          "note": "SQ_INSTS_VALU per launch (offline PMC pass) / chip issue rate / launch time: "
                                                  "the kernel is VALU-bound, the HBM fraction above is low by construction"}
-    except (OSError, KeyError):
+    except (OSError, KeyError, IndexError, ValueError):
         pass
     return fwd_obj, bwd_obj
+
+
+def fps_roofline(cfg_name, device, reps=5):
+    """The sampling launch alone (HIP events on the launching stream) at the configuration's cloud size.  Its §8(d) figure is
+    the STREAMING-EQUIVALENT traffic of the reference kernel, 20 B x n x (m-1) (12 B xyz + 4 B read + 4 B write of the running
+    distance per point per round, sampling_gpu.cu:98-112); this kernel moves far less (it skips whole buckets), so the
+    fraction says how far one CU's latency chain is from an HBM stream, not how busy HBM is."""
+    from vdetr_amd import pointnet2_utils as PU
+    npts, _, npre, *_ = CONFIGS[cfg_name]
+    xyz, _ = make_scene(npts, 0, device)
+    x = xyz[None].contiguous()
+    n, m = int(x.shape[1]), min(npre, int(x.shape[1]))
+    ts = []
+    for i in range(reps + 2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        PU.furthest_point_sample(x, m)
+        e1.record()
+        e1.synchronize()
+        if i >= 2:
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.mean(ts))
+    eq_bytes = 20.0 * n * (m - 1)
+    traffic = None
+    try:
+        if cfg_name == "c2":
+            traffic = _pmc_traffic()["fps_rows_kernel"]["bytes"]
+    except (OSError, KeyError, IndexError, ValueError):
+        pass
+    return {"kernel": "fps_rows_kernel (furthest point sampling, one workgroup per scene)", "bound": "hbm",
+            "achieved": eq_bytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": eq_bytes / t / 1e9 / 8000.0, "traffic": traffic,
+            "launch_us": t * 1e6, "us_per_round": t * 1e6 / max(m - 1, 1), "points": n, "samples": m,
+            "note": "achieved = streaming-equivalent bytes of the reference kernel (20 B x n x (m-1)) / launch time; the kernel is a "
+                    "serial latency chain on ONE CU (m-1 dependent rounds), hidden behind the decoder on a side stream"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -614,8 +655,8 @@ def cpu_baseline(cfg_name):
         ALN.layer_norm, ALN.add_dropout_layer_norm = saved_ln
     per_layer = max(times[3] - times[2], 1e-9)
     full = t_fps + times[2] + (nl - 2) * per_layer
-    return {"value": bs / (full * bs), "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"FPS {npts}->{npre} pts with the C oracle on 1 thread ({t_fps:.2f} s) + decoder fwd+bwd with 1 and 2 of "
+    return {"value": bs / (full * bs), "unit": "scenes/s", "cores": cores, "kind": "port", "extrapolated": True,
+            "sample": f"EXTRAPOLATED from a bounded sample: FPS {npts}->{npre} pts with the C oracle on 1 thread ({t_fps:.2f} s) + decoder fwd+bwd with 1 and 2 of "
                       f"{nl - 1} RPE layers at full nQ={nq}/nK={npre} through the torch CPU oracle (RPE via F.grid_sample, as the reference) on {cores} threads "
                       f"({times[2]:.1f} s, {times[3]:.1f} s), extrapolated linearly to {nl - 1} layers = {full:.1f} s/scene"}
 
@@ -772,6 +813,10 @@ def main():
                    "fps_lookahead": 2 if getattr(trainer, "fps_depth2", False) and graph_ok else (1 if not a.no_fps_prefetch else 0),
                    "grad_allreduce_bytes": trainer.reducer.grad_bytes()},
         "loss": loss,
+        "arith": {"activations": "f32", "qk_pv": "v_mfma_f32_16x16x4_f32 (exact f32)", "softmax_log2_table_lookup": "f32",
+                  "dtable_products": "split-bf16 2^-15 (two bf16 terms per f32 factor)", "dtable_accum": "int32 fixed point in LDS",
+                  "note": "dtype f32 is the arithmetic of every tensor the model sees; the RPE-table gradient alone is formed from "
+                          "2-term split-bf16 products accumulated in int32 fixed point (DESIGN.md 4.4b), measured 2.5e-5 relative"},
     }
     if a.config == "c2":  # decoder fwd+bwd = 216 GFLOP per scene at the full configuration
         result["end_to_end"] = {"gflop_per_scene": 216.0, "achieved_tflops": 216.0e-3 * result["value"],
@@ -786,12 +831,17 @@ def main():
 
     def roofline_leg():
         fwd_obj, bwd_obj = kernel_rooflines(a.config, device)
+        fps_obj = fps_roofline(a.config, device)
         layers = nl - 1
-        dom, other = (bwd_obj, fwd_obj) if bwd_obj["launch_us"] >= fwd_obj["launch_us"] else (fwd_obj, bwd_obj)
-        dom["share_of_step"] = layers * dom["launch_us"] * 1e-3 / result["ms_per_step"]
-        other["share_of_step"] = layers * other["launch_us"] * 1e-3 / result["ms_per_step"]
-        result["roofline"] = dom
-        result["roofline_secondary"] = other
+        fwd_obj["step_us"], bwd_obj["step_us"] = layers * fwd_obj["launch_us"], layers * bwd_obj["launch_us"]
+        # one workgroup per scene: the launch time does not grow with the batch
+        fps_obj["step_us"] = fps_obj["launch_us"]
+        objs = sorted((fps_obj, bwd_obj, fwd_obj), key=lambda o: -o["step_us"])
+        for o in objs:  # device time of the kernel's launches in one step / step time (the sampling runs on a side stream)
+            o["share_of_step"] = o["step_us"] * 1e-3 / result["ms_per_step"]
+        result["roofline"] = objs[0]        # the kernel with the most device time per step
+        result["roofline_secondary"] = objs[1]
+        result["roofline_tertiary"] = objs[2]
 
     def cpu_leg():
         result["cpu_baseline"] = cpu_baseline(a.config)

@@ -63,5 +63,9 @@ python3 tools/op_census.py --top 60 > $out/op_census.txt 2>&1 < /dev/null
 [ -x tools/probes/bin/mfma_f32_rate ] && timeout 120 tools/probes/bin/mfma_f32_rate > $out/mfma_f32_rate.txt 2>&1
 [ -x tools/probes/bin/mfma_patterns ] && timeout 120 tools/probes/bin/mfma_patterns > $out/mfma_patterns.txt 2>&1
 bash tools/pmc_spconv.sh $tag > /dev/null 2>&1; cat gpurun_out/pmc_sp_$tag/pmc_sq_pass*.txt > $out/spconv_pmc_sq.txt 2>/dev/null
-python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
+# per-launch HBM bytes for bench.py's `roofline.traffic`, from THIS run's PMC passes (copy to profiles/rNN_pmc_traffic.json)
+python3 tools/pmc_traffic.py $out > $out/pmc_traffic.json 2>/dev/null
+python3 tools/fps_variants.py > $out/fps_variants.txt 2>&1 < /dev/null
+[ -x tools/probes/bin/lat_probe ] && timeout 120 tools/probes/bin/lat_probe > $out/lat_probe.txt 2>&1
+VDETR_PMC_TRAFFIC=$out/pmc_traffic.json python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400

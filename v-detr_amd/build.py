@@ -32,6 +32,61 @@ def _fingerprint():
     return h.hexdigest()
 
 
+# Packed fp32 math with a HIGH-BROADCAST source: op_sel[i] = 1 (the low result lane reads the high register of source
+# pair i) together with op_sel_hi[i] = 1 (so does the high lane; 1 is the default when op_sel_hi is not printed), e.g.
+# `v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]`.  hipcc emits it for `float2 * float2[1]`; on MI355X / ROCm 7.2 a
+# kernel using it produced wrong sums (root cause not isolated).  The low-broadcast and the crossed forms
+# (op_sel:[0,1] op_sel_hi:[1,0]) are fine.  The sources avoid the pattern; this makes the build enforce it.
+_PACKED = r"\b(v_pk_(?:mul|fma|add)_f32)\b([^\n/]*)"
+
+
+def _hi_broadcast(operands):
+    import re
+    sel = re.search(r"op_sel:\[([01,]+)\]", operands)
+    if not sel:
+        return False
+    lo = [int(v) for v in sel.group(1).split(",")]
+    hi_m = re.search(r"op_sel_hi:\[([01,]+)\]", operands)
+    hi = [int(v) for v in hi_m.group(1).split(",")] if hi_m else [1] * len(lo)
+    return any(a == 1 and b == 1 for a, b in zip(lo, hi))
+
+
+def check_code_objects(lib, verbose=False):
+    """Disassembles every gfx950 code object of `lib` and raises if a hazardous packed-math encoding is present."""
+    import re
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump = os.path.join(llvm, "llvm-objdump")
+    if not os.path.exists(objdump):
+        raise RuntimeError("llvm-objdump not found: cannot check the code objects")
+    hits, nobj = [], 0
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, copy)
+        subprocess.check_call([objdump, "--offloading", copy], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tmp)
+        for f in sorted(os.listdir(tmp)):
+            if ARCH not in f:
+                continue
+            nobj += 1
+            asm = subprocess.run([objdump, "-d", os.path.join(tmp, f)], capture_output=True, text=True).stdout
+            kernel = "?"
+            for line in asm.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+                if m:
+                    kernel = m.group(1)
+                else:
+                    m = re.search(_PACKED, line)
+                    if m and _hi_broadcast(m.group(2)):
+                        hits.append(f"{kernel}: {m.group(1)}{m.group(2).rstrip()}")
+    if nobj == 0:
+        raise RuntimeError(f"no {ARCH} code object found in {lib}")
+    if hits:
+        raise RuntimeError("packed fp32 math with a high-broadcast source (DESIGN.md 4.4b) in:\n  " + "\n  ".join(hits[:20]))
+    if verbose:
+        print(f"checked {nobj} {ARCH} code objects: no packed fp32 op with a high-broadcast source")
+    return nobj
+
+
 def build(force=False, verbose=False):
     """Compile if the sources changed since the last build.  Returns the path of the shared object."""
     os.makedirs(LIBDIR, exist_ok=True)
@@ -61,6 +116,7 @@ def build(force=False, verbose=False):
             print(out.decode())
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
     subprocess.check_call(cmd)
+    check_code_objects(LIB, verbose)
     with open(stamp, "w") as fh:
         fh.write(fp)
     return LIB
