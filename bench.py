@@ -340,7 +340,7 @@ class BackboneTrainer:
         self.side = torch.cuda.Stream(priority=prio)
         self.sides = [torch.cuda.Stream(priority=prio), torch.cuda.Stream(priority=prio)]  # scene i+2 is prepared while i+1's sampling may still run
         self._queue, self._tick = [], 0
-        self._next, self._keep, self._worker = None, None, None
+        self._next, self._worker = None, None
 
     def _prepare_next(self, stream=None):
         from vdetr_amd import pointnet2_utils as PU
@@ -381,14 +381,12 @@ class BackboneTrainer:
         if len(self._queue) >= 2:  # inline mode: the scene prepared one full step ago
             geo, inds, ev = self._queue.pop(0)
             torch.cuda.current_stream().wait_event(ev)
-            self._keep = self.inputs["geometry"]  # stays alive while kernels of the previous step may still read it
             self.inputs["geometry"] = geo
             self.inds.copy_(inds)
         if self._worker is not None:  # thread mode: what the loader thread prepared during the previous step
             self._worker.join()
             self._worker = None
             torch.cuda.current_stream().wait_stream(self.side)
-            self._keep = self.inputs["geometry"]
             self.inputs["geometry"], inds = self._next
             self.inds.copy_(inds)
         import threading

@@ -79,3 +79,20 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="CPU not supported"):
         A.fused_attention(torch.rand(1, 4, 256), torch.rand(1, 8, 64), torch.rand(1, 8, 64), num_heads=4, scale=0.125,
                           shared_kv=True)
+
+
+def test_build_rejects_the_packed_multiply_form_of_design_4_4b():
+    """build.py disassembles the library and refuses `v_pk_mul/fma_f32` with a high-broadcast second source."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vdetr_build", os.path.join(root, "v-detr_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b._hi_broadcast(" v[0:1], v[2:3], v[4:5] op_sel:[0,1]")                      # the failing kernel's form
+    assert b._hi_broadcast(" v[0:1], v[2:3], v[4:5], v[0:1] op_sel:[1,1,0] op_sel_hi:[0,1,1]")
+    assert not b._hi_broadcast(" v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]")  # crossed: fine
+    assert not b._hi_broadcast(" v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]")               # low-broadcast: fine
+    assert not b._hi_broadcast(" v[0:1], v[2:3], v[4:5] op_sel:[1,0]")                  # first source: covered by parity tests
+    assert not b._hi_broadcast(" v[0:1], v[2:3], v[4:5]")
+    assert b.check_code_objects(b.build()) >= 15  # every .hip of the library is a code object, none has the form

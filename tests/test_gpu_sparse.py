@@ -229,6 +229,27 @@ def test_full_model_with_sparse_backbone_runs():
                       model.out_block_0[0].kernel.grad.clone()])
     for ga, gb in zip(*grads):
         assert torch.equal(ga, gb)
+    # a manager built on a loader stream and dropped right after the step: backbone_forward ties its memory to the
+    # consuming stream (CoordinateManager.use_on), so the loader's next scene cannot be handed its blocks early
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        geo2 = model.prepare_geometry(inputs)
+    torch.cuda.current_stream().wait_stream(side)
+    main = torch.cuda.current_stream().cuda_stream
+    model.zero_grad(set_to_none=True)
+    feats = model.backbone_forward(dict(inputs, geometry=geo2))
+    held = geo2.device_tensors()
+    assert len(held) > 20 and all((id(t), main) in geo2._recorded for t in held)
+    del geo2
+    with torch.cuda.stream(side):  # the loader's next scene allocates on its own stream while the step is still queued
+        geo3 = model.prepare_geometry(inputs)
+    sum(f.square().sum() for _, f in feats).backward()
+    torch.cuda.synchronize()
+    for ga, gb in zip(grads[0], [model.pre_encoder.conv1.kernel.grad, model.pre_encoder.layer3[0].conv1.kernel.grad,
+                                 model.out_block_0[0].kernel.grad]):
+        assert torch.equal(ga, gb)
+    del geo3
 
 
 @pytest.mark.parametrize("n,ks,seed", [(3000, 3, 0), (700, 2, 1), (5, 3, 2), (20000, 3, 3)])

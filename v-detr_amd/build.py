@@ -23,7 +23,7 @@ def sources():
 
 
 def _fingerprint():
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + "|noslp:" + ",".join(NO_SLP)).encode())
     root = os.path.dirname(HERE)
     for f in sorted(os.listdir(CSRC)) + [os.path.join(root, "include", "vdetr_hip.h")]:
         p = f if os.path.isabs(f) else os.path.join(CSRC, f)
@@ -32,15 +32,19 @@ def _fingerprint():
     return h.hexdigest()
 
 
-# Packed fp32 math with a HIGH-BROADCAST source: op_sel[i] = 1 (the low result lane reads the high register of source
-# pair i) together with op_sel_hi[i] = 1 (so does the high lane; 1 is the default when op_sel_hi is not printed), e.g.
-# `v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]`.  hipcc emits it for `float2 * float2[1]`; on MI355X / ROCm 7.2 a
-# kernel using it produced wrong sums (root cause not isolated).  The low-broadcast and the crossed forms
-# (op_sel:[0,1] op_sel_hi:[1,0]) are fine.  The sources avoid the pattern; this makes the build enforce it.
-_PACKED = r"\b(v_pk_(?:mul|fma|add)_f32)\b([^\n/]*)"
+# Packed fp32 multiply / fma whose SECOND source is high-broadcast: op_sel[1] = 1 (the low result lane reads the high
+# register of the source pair) together with op_sel_hi[1] = 1 (so does the high lane; 1 is the default when op_sel_hi is not
+# printed), e.g. `v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]` — what hipcc emits for `float2 * float2[1]`.  A round-2
+# kernel built around that form produced wrong sums on MI355X / ROCm 7.2 and right ones with scalar multiplies (DESIGN.md
+# 4.4b).  tools/probes/pk_opsel_probe.hip has since shown that the hardware executes every op_sel form of v_pk_mul / add /
+# fma_f32 exactly (16-wave workgroups on every CU, LDS traffic around them, 0 mismatches), so the encoding alone is not the
+# cause and the real one is still unknown; until it is, the form the failing kernel used stays out of the library.
+# (Other broadcast forms, e.g. the first source high-broadcast in attn_fwd_kernel, are covered by the parity tests.)
+_PACKED = r"\b(v_pk_(?:mul|fma)_f32)\b([^\n/]*)"
+NO_SLP = ("criterion.hip",)  # -fno-slp-vectorize: their scalar float code was being packed into the form above
 
 
-def _hi_broadcast(operands):
+def _hi_broadcast(operands, src=1):
     import re
     sel = re.search(r"op_sel:\[([01,]+)\]", operands)
     if not sel:
@@ -48,7 +52,7 @@ def _hi_broadcast(operands):
     lo = [int(v) for v in sel.group(1).split(",")]
     hi_m = re.search(r"op_sel_hi:\[([01,]+)\]", operands)
     hi = [int(v) for v in hi_m.group(1).split(",")] if hi_m else [1] * len(lo)
-    return any(a == 1 and b == 1 for a, b in zip(lo, hi))
+    return len(lo) > src and lo[src] == 1 and hi[src] == 1
 
 
 def check_code_objects(lib, verbose=False):
@@ -81,9 +85,9 @@ def check_code_objects(lib, verbose=False):
     if nobj == 0:
         raise RuntimeError(f"no {ARCH} code object found in {lib}")
     if hits:
-        raise RuntimeError("packed fp32 math with a high-broadcast source (DESIGN.md 4.4b) in:\n  " + "\n  ".join(hits[:20]))
+        raise RuntimeError("packed fp32 multiply with a high-broadcast second source (DESIGN.md 4.4b) in:\n  " + "\n  ".join(hits[:20]))
     if verbose:
-        print(f"checked {nobj} {ARCH} code objects: no packed fp32 op with a high-broadcast source")
+        print(f"checked {nobj} {ARCH} code objects: no v_pk_mul/fma_f32 with a high-broadcast second source")
     return nobj
 
 
@@ -104,7 +108,8 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        extra = ["-fno-slp-vectorize"] if os.path.basename(src) in NO_SLP else []
+        cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

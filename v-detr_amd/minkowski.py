@@ -115,6 +115,42 @@ class CoordinateManager:
             cache[key] = (torch.bincount(b, minlength=nb).tolist(), keys)  # the key tensor is kept alive with its entry
         return cache[key][0]
 
+    def device_tensors(self):
+        """every device tensor this manager holds, directly or through its cached plans (sites, kernel maps, pair lists,
+        tile tables ...)"""
+        seen, stack, out = set(), [self], []
+        while stack:
+            o = stack.pop()
+            if id(o) in seen:
+                continue
+            seen.add(id(o))
+            if torch.is_tensor(o):
+                if o.is_cuda:
+                    out.append(o)
+            elif isinstance(o, dict):
+                stack.extend(o.values())
+            elif isinstance(o, (list, tuple, set)):
+                stack.extend(o)
+            elif hasattr(o, "__dict__") and not isinstance(o, (type, torch.nn.Module)):
+                stack.extend(vars(o).values())
+        return out
+
+    def use_on(self, stream=None):
+        """Tell the caching allocator that `stream` (default: the current one) reads this manager's tensors.  A manager
+        built by ``prepare_geometry`` on a loader stream is consumed by forward and backward kernels of the training
+        stream; without this, dropping the manager lets the allocator hand its blocks to the loader stream's next scene
+        while those kernels are still queued.  Idempotent per stream; plans added later are picked up on the next call."""
+        stream = stream or torch.cuda.current_stream()
+        if torch.cuda.is_current_stream_capturing():
+            return self
+        done = self.__dict__.setdefault("_recorded", {})
+        for t in self.device_tensors():
+            key = (id(t), stream.cuda_stream)
+            if key not in done:
+                t.record_stream(stream)
+                done[key] = True
+        return self
+
     def finalize(self):
         """wait for the pair counts of every plan built so far (one synchronisation for the whole scene)"""
         for entry in self.maps.values():

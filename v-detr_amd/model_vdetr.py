@@ -136,6 +136,8 @@ class ModelVDETR(nn.Module):
         if geometry is None:
             x = ME.SparseTensor(features.contiguous(), coordinates=coordinates)
         else:
+            if features.is_cuda:
+                geometry.use_on()  # built on another stream (loader thread / side stream): this stream reads it from here on
             x = ME.SparseTensor(features[geometry.unique_index].contiguous(), coordinate_manager=geometry)
         stages = self.pre_encoder(x)
         x = stages[-1]
@@ -156,7 +158,9 @@ class ModelVDETR(nn.Module):
         """Everything of the backbone that depends on the point coordinates only — voxel sites of every tensor stride, the
         kernel maps of every layer shape and their compacted row lists (sparse_ops.ConvPlan) — as a coordinate manager to
         pass as ``inputs["geometry"]``.  A training loop can run this for the NEXT scene (data loader / side stream) while
-        the current one trains; the maps themselves are filled in by one geometry-only pass over the layers."""
+        the current one trains; the maps themselves are filled in by one geometry-only pass over the layers.  The consumer
+        must first wait for the producing stream (event / wait_stream); the manager's memory is then tied to the consuming
+        stream by ``backbone_forward`` itself (``CoordinateManager.use_on``), so it may be dropped right after the step."""
         clouds = inputs["point_clouds"]
         coordinates, _ = ME.batch_sparse_collate([(p[:, :3] / self.voxel_size, p[:, :0]) for p in clouds])
         cm = ME.CoordinateManager(clouds[0].device)
