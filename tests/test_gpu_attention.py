@@ -114,6 +114,57 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
             assert_close(o, r.detach().numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
+@pytest.mark.parametrize("boxes", [True, False])
+def test_full_size_forward_backward_vs_oracle(boxes):
+    """The launch bench.py times (B=1, nQ=1024, nK=4096, H=4: BASELINE config 2's layer size) against the fp64 oracle:
+    out, dq, dk, dv and the RPE-table gradient within 1e-3 relative.  boxes=True: axis-aligned box vertices, i.e.
+    attn_bwd_box2_kernel with its dynamic query distribution and every wave of every workgroup busy; boxes=False: a few
+    perturbed vertices send the same launch down the general kernel.  The oracle is evaluated in chunks of 32 queries
+    (softmax rows are independent; dk, dv and dtable are sums over the chunks)."""
+    from oracle.attention_oracle import fused_attention_reference
+    from vdetr_amd import attention as A
+    B, nQ, nK, H = 1, 1024, 4096, 4
+    g = torch.Generator().manual_seed(21)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 5)
+    if not boxes:
+        verts[:, ::97] += 0.05 * torch.randn(verts[:, ::97].shape, generator=g)
+    q, k, v = (torch.randn(s, generator=g) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g)
+    cfg = A.RPEConfig()
+    kw = dict(num_heads=H, scale=0.125, shared_kv=True, rpe=cfg)
+    # device
+    dq, dk, dv = (x.to(DEV).requires_grad_(True) for x in (q, k, v))
+    dtb = tables.to(DEV).requires_grad_(True)
+    out = A.fused_attention(dq, dk, dv, table=dtb, vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV), **kw)
+    (out * wout.to(DEV)).sum().backward()
+    # oracle, 32 queries at a time
+    rk, rv = k.double().requires_grad_(True), v.double().requires_grad_(True)
+    rtb = tables.double().requires_grad_(True)
+    routs, rdq = [], []
+    for c in range(0, nQ, 32):
+        sl = slice(c, c + 32)
+        rq = q[:, sl].double().requires_grad_(True)
+        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
+        (o * wout[:, sl].double()).sum().backward()
+        routs.append(o.detach())
+        rdq.append(rq.grad)
+    ref = [torch.cat(routs, 1), torch.cat(rdq, 1), rk.grad, rv.grad, rtb.grad]
+    got = [out.detach(), dq.grad, dk.grad, dv.grad, dtb.grad]
+    for name, r, o in zip(["out", "dq", "dk", "dv", "dtable"], ref, got):
+        scale = float(r.abs().max())
+        if name == "out":
+            assert_close(o, r.numpy(), 1e-4, 1e-5 * max(scale, 1.0), name)
+        elif name == "dtable":
+            # 33.5 M (query, key, vertex) contributions, formed from 2-term split-bf16 products and summed in int32 fixed
+            # point whose scale comes from a worst-case BOUND of a bin's sum (all of a query's attention mass in one bin,
+            # DESIGN.md 4.4); real bins hold ~1e-3 of that, so single contributions keep ~10 bits.  The rounding is
+            # unbiased and absolute: measured 2.0e-4 of the largest entry whatever the entry's size, 4.3e-4 relative L2.
+            assert_close(o, r.numpy(), 1e-3, 3e-4 * scale, name)
+            assert float((o.cpu().double() - r).norm() / r.norm()) < 1e-3, "dtable, relative L2 error"
+        else:
+            assert_close(o, r.numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
+
+
 @pytest.mark.parametrize("variant", ["1", "2"])
 def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant):
     """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
@@ -238,11 +289,13 @@ def test_decoder_vs_reference_vectors(case, nl, share):
         for k in ("sem_cls_logits", "center_unnormalized", "size_unnormalized", "box_corners"):
             assert_close(st[k], g[f"s{s}:{k}"], 1e-3, 2e-4, f"stage {s} {k}")   # 1e-3 relative (north_star)
     assert_close(loss, g["loss"], 1e-3, 1e-2, "loss")
-    assert_close(gfeats, g["grad_feats"], 5e-3, 2e-4 * np.abs(g["grad_feats"]).max(), "grad_feats")
+    # gradients: 1e-3 relative (north_star) + 1e-4 of the tensor's largest entry (the golden vectors are the reference's own
+    # fp32 CPU run: its summation-order noise is of that size; measured need <= 6e-5, worst in the cpb_mlps of the last layer)
+    assert_close(gfeats, g["grad_feats"], 1e-3, 1e-4 * np.abs(g["grad_feats"]).max(), "grad_feats")
     params = dict(dec.named_parameters())
     for k in g.files:
         if k.startswith("grad_param:"):
-            assert_close(params[k[11:]].grad, g[k], 5e-3, max(5e-4 * np.abs(g[k]).max(), 2e-6), k)
+            assert_close(params[k[11:]].grad, g[k], 1e-3, max(1e-4 * np.abs(g[k]).max(), 2e-6), k)
 
 
 @pytest.mark.parametrize("B", [1, 2])
