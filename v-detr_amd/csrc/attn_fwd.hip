@@ -160,11 +160,11 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
     float p[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float tmax = row_allmax_f32(sc[r]);
+      const float tmax = row_allmax_f32_fx(sc[r]);
       const float mn = fmaxf(m[r], tmax);
       const float alpha = __expf(m[r] - mn);
       const float e = kvalid ? __expf(sc[r] - mn) : 0.f;
-      l[r] = l[r] * alpha + row_allsum_f32(e);
+      l[r] = l[r] * alpha + row_allsum_f32_fx(e);
       m[r] = mn;
       p[r] = e;
 #pragma unroll

@@ -113,6 +113,30 @@ __device__ __forceinline__ float row_allsum_f32(float v) {
   v += dpp_f32<kDppRowMirror>(v);
   return v;
 }
+// full-exec float forms for hot loops (see dppz_u32).  The sum folds into v_add_f32_dpp by itself; for the max hipcc
+// would canonicalise the permuted operand first (v_mov_dpp + v_max v,v + v_max), so its four stages are written out:
+// v_max_f32 of two ordinary (non signalling-NaN) floats needs no canonicalisation.  s_nop 1: the two wait states a DPP
+// read of a VALU result needs, which nobody inserts inside inline asm.
+__device__ __forceinline__ float row_allsum_f32_fx(float v) {
+  v += __uint_as_float(dppz_u32<kDppQuadXor1>(__float_as_uint(v)));
+  v += __uint_as_float(dppz_u32<kDppQuadXor2>(__float_as_uint(v)));
+  v += __uint_as_float(dppz_u32<kDppRowHalfMirror>(__float_as_uint(v)));
+  v += __uint_as_float(dppz_u32<kDppRowMirror>(__float_as_uint(v)));
+  return v;
+}
+__device__ __forceinline__ float row_allmax_f32_fx(float v) {
+  asm(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ float wave_allmax_f32(float v) {
   v = row_allmax_f32(v);
   pair_u32 p = xrow16(__float_as_uint(v));
