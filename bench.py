@@ -145,7 +145,7 @@ class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
     def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True, criterion=None, targets=None,
-                 defer_wg=True, fps_depth=None):
+                 defer_wg=True, fps_depth=None, force_dist=False):
         from vdetr_amd.dist import FlatParams, GradientReducer
         global flush_weight_grads
         from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
@@ -162,9 +162,14 @@ class Trainer:
         self.flat = FlatParams(self.params, groups=model.flat_param_groups())
         # hooks + bucket views only pay off when they overlap communication with an EAGER backward; otherwise
         # gradients stay ordinary tensors and are packed with one multi-tensor copy before the all-reduce
-        self.hooked = world > 1 and overlap and not use_graph
-        self.reducer = GradientReducer(self.params, bucket_mb=25.0, overlap=self.hooked, bucket_views=self.hooked,
-                                       flat=self.flat)
+        self.hooked = (world > 1 or force_dist) and overlap and not use_graph
+        self.reducer = GradientReducer(self.params, bucket_mb=float(os.environ.get("VDETR_BUCKET_MB", "64")), overlap=self.hooked,
+                                       bucket_views=self.hooked, flat=self.flat, force=force_dist)
+        # Captured step on several ranks: the gradient buckets are all-reduced INSIDE the hipGraph, each on the side stream as
+        # soon as its slice of the flat buffer is packed, while the parked weight gradients of the next bucket are computed
+        # (GradientReducer.reduce_phased); the optimizer step follows in the same graph: one replay per step, no eager gap
+        # between backward, RCCL and AdamW.  VDETR_PHASED_REDUCE=0: the round-2 sequence (graph, eager all-reduce, graph).
+        self.phased = use_graph and self.reducer.active and os.environ.get("VDETR_PHASED_REDUCE", "1") != "0"
         self.opt = torch.optim.AdamW([self.flat.param], lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
         self.use_graph = use_graph
         self.g_main = self.g_opt = None
@@ -206,10 +211,13 @@ class Trainer:
         out = self.model(self.inputs)
         self.loss = loss_fn(out) if self.criterion is None else self.criterion(out, self.targets)[0]
         self.loss.backward()
-        if self.defer_wg:
-            flush_weight_grads()
-        if not self.hooked:
-            self.flat.pack_grads()  # one launch; (hooked eager mode accumulates straight into the flat buffer)
+        if self.phased:
+            self.reducer.reduce_phased()  # parked weight gradients, slice packs and all-reduces, bucket by bucket
+        else:
+            if self.defer_wg:
+                flush_weight_grads()
+            if not self.hooked:
+                self.flat.pack_grads()  # one launch; (hooked eager mode accumulates straight into the flat buffer)
         if self.fps_prefetch and not self.fps_depth2:
             main.wait_stream(self.side)
             self.cur_inds.copy_(next_inds)
@@ -230,7 +238,7 @@ class Trainer:
         with torch.cuda.stream(s):
             for _ in range(3):  # warm allocator, lazy inits, LDS attribute grants
                 self._fwd_bwd()
-                if self.world > 1:
+                if self.reducer.active and not self.phased:
                     self.reducer.reduce_all()  # real updates: the replicas must stay identical
                 self._update()
         torch.cuda.current_stream().wait_stream(s)
@@ -242,9 +250,9 @@ class Trainer:
         self.g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_main, **({"stream": s} if same else {})):
             self._fwd_bwd()
-            if self.world == 1:
+            if self.phased or not self.reducer.active:
                 self._update()
-        if self.world > 1:
+        if self.reducer.active and not self.phased:
             self.reducer.reduce_all()  # the flat gradient buffer, in slices; not captured (RCCL outside the graph)
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, **({"stream": s} if same else {})):
@@ -274,14 +282,14 @@ class Trainer:
             if self.fps_depth2:
                 self._fps_lookahead()
             self.g_main.replay()
-            if self.world > 1:
+            if self.g_opt is not None:
                 self.reducer.reduce_all()
                 self.g_opt.replay()
         else:
             self._fwd_bwd()
             if self.hooked:
                 self.reducer.finish()
-            elif self.world > 1:
+            elif self.reducer.active and not self.phased:
                 self.reducer.reduce_all()
             self._update()
 
@@ -666,7 +674,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
-    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm as in main.py:512-514 (implies --no-graph)")
+    ap.add_argument("--sync-bn", action="store_true", help="batch statistics over all ranks, as the reference's SyncBatchNorm conversion (main.py:512-514)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss", default="synthetic", choices=["synthetic", "criterion"],
                     help="synthetic: scalar loss of SURVEY 8d (headline); criterion: the device set criterion on synthetic boxes")
@@ -676,6 +684,8 @@ def main():
     ap.add_argument("--no-backbone-leg", action="store_true", help="skip the extra N=1 measurement with the sparse-conv backbone")
     ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library heuristics instead of per-shape tuned GEMM solutions")
+    ap.add_argument("--force-dist", action="store_true", help="N=1 only: a 1-rank RCCL communicator, so that the multi-GPU step "
+                    "(captured all-reduces on the side stream) runs on a single GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                     "the N>1 code path with several ranks on one GPU)")
     a = ap.parse_args()
@@ -687,6 +697,11 @@ def main():
     if a.backend != "nccl":
         os.environ["LOCAL_RANK"] = str(local)
     rank, local, world = init_distributed(a.backend)
+    if a.force_dist and world == 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group(backend=a.backend, rank=0, world_size=1,
+                                             **({"device_id": torch.device("cuda", local)} if a.backend == "nccl" else {}))
     assert world == a.gpus or (world == 1 and a.gpus == 1), f"--gpus {a.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local)
     if not a.no_gemm_tuning:
@@ -697,11 +712,12 @@ def main():
             print(f"[bench] GEMM tuning unavailable ({exc}); continuing with library defaults", file=sys.stderr)
 
     model = build_model(a.config, device)
-    use_graph = not (a.no_graph or a.sync_bn)
+    use_graph = not a.no_graph
     if world > 1:
         broadcast_parameters(model)
-        if a.sync_bn:
-            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    if a.sync_bn:  # batch statistics over all ranks inside the fused BatchNorm launches (bn_act.set_sync), graph-capturable
+        from vdetr_amd import bn_act as _bna
+        _bna.set_sync(True, force=a.force_dist)
     inputs = make_inputs(a.config, device, rank)
     def make_trainer(with_criterion):
         crit = targets = None
@@ -711,7 +727,7 @@ def main():
             targets = make_targets(a.config, device, rank)
             crit_holder[0], crit_holder[1] = crit, targets
         return Trainer(model, inputs, world, use_graph, overlap=True, fps_prefetch=not a.no_fps_prefetch, criterion=crit,
-                       targets=targets, defer_wg=not a.no_defer_wg)
+                       targets=targets, defer_wg=not a.no_defer_wg, force_dist=a.force_dist)
 
     def replay_ms(tr, reps=6):
         for _ in range(3):
@@ -748,7 +764,7 @@ def main():
         if t_fps <= 0.8 * t1:
             return tr
         tr2 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=tr.criterion and crit_holder[0],
-                      targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=2)
+                      targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=2, force_dist=a.force_dist)
         tr2.capture()
         t2 = over_ranks(replay_ms(tr2))
         if rank == 0:
@@ -758,7 +774,7 @@ def main():
             return tr2
         # (tr2 has re-laid the parameters into flat buffers of its own: the first trainer's graph points at the old ones)
         tr1 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=tr.criterion and crit_holder[0],
-                      targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=1)
+                      targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=1, force_dist=a.force_dist)
         tr1.capture()
         return tr1
 
@@ -770,11 +786,25 @@ def main():
             trainer.capture()
             graph_ok = True
             trainer = choose_fps_depth(trainer)
-        except Exception as e:  # capture is an optimisation: report and fall back to eager launches
+        except Exception as e:  # capture is an optimisation: report and fall back
             if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            trainer.g_main = trainer.g_opt = None
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
             torch.cuda.synchronize()
+            if trainer.phased:  # the collectives inside the graph are the newest part: retry with them outside
+                try:
+                    os.environ["VDETR_PHASED_REDUCE"] = "0"
+                    trainer = make_trainer(a.loss == "criterion")
+                    trainer.capture()
+                    graph_ok = True
+                    if rank == 0:
+                        print("[bench] captured with the all-reduce outside the graph", file=sys.stderr)
+                except Exception as e2:
+                    if rank == 0:
+                        print(f"[bench] second capture failed too ({type(e2).__name__}: {e2}); running eager", file=sys.stderr)
+                    trainer.g_main = trainer.g_opt = None
+                    torch.cuda.synchronize()
+            else:
+                trainer.g_main = trainer.g_opt = None
 
     def barrier():
         if world > 1:
@@ -809,7 +839,11 @@ def main():
                    "step": "FPS+gather, projection, decoder fwd, loss, backward, grad all-reduce (N>1), clip, AdamW",
                    "hip_graph": graph_ok, "sync_bn": bool(a.sync_bn), "fps_prefetch": not a.no_fps_prefetch,
                    "fps_lookahead": 2 if getattr(trainer, "fps_depth2", False) and graph_ok else (1 if not a.no_fps_prefetch else 0),
-                   "grad_allreduce_bytes": trainer.reducer.grad_bytes()},
+                   "grad_allreduce_bytes": trainer.reducer.grad_bytes(),
+                   "grad_allreduce": ("none (1 rank)" if not trainer.reducer.active else
+                                      "inside the hipGraph, bucket by bucket on a side stream while the next bucket's weight gradients are computed"
+                                      if trainer.phased and graph_ok else
+                                      "bucket hooks on a side stream during backward" if trainer.hooked else "after the replayed backward")},
         "loss": loss,
         "arith": {"activations": "f32", "qk_pv": "v_mfma_f32_16x16x4_f32 (exact f32)", "softmax_log2_table_lookup": "f32",
                   "dtable_products": "split-bf16 2^-15 (two bf16 terms per f32 factor)", "dtable_accum": "int32 fixed point in LDS",

@@ -37,7 +37,7 @@ extern "C" {
 typedef void* vdetr_stream_t; /* hipStream_t */
 
 /* library / diagnostics */
-int vdetr_abi_version(void);
+int vdetr_abi_version(void); /* 2: vdetr_bnact_desc / vdetr_bnact_grads grew; attention bwd_aux is 8 words */
 const char* vdetr_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -327,12 +327,18 @@ typedef struct vdetr_bnact_desc {
                                 statistics; the running mean is kept as that of conv(x) + bias) */
   int64_t* counters[8];      /* num_batches_tracked of the modules that make up the channel group: += 1 (training) */
   int32_t ncounters;
+  int32_t stats_given;       /* training only.  1: save_mean / save_invstd are INPUTS (statistics of the batch over all
+                                data-parallel ranks, SyncBatchNorm: reference main.py:512-514); the kernel normalises with them
+                                and leaves the running statistics alone (the caller keeps them, it knows the global count) */
 } vdetr_bnact_desc;
 
 typedef struct vdetr_bnact_grads {
   const float* dy;            /* [B, C, N] */
   float* dx;                  /* [B, C, N] or NULL */
-  float *d_gamma, *d_beta;    /* [C] or NULL */
+  float *d_gamma, *d_beta;    /* [C] or NULL: THIS rank's sums (sum g * xhat, sum g) */
+  /* cross-replica statistics: the two sums over ALL ranks ([C] each) and 1 / (global element count) as a device scalar;
+   * all NULL: dx uses the launch's own sums and B * N */
+  const float *sum_dy_xhat, *sum_dy, *inv_count;
 } vdetr_bnact_grads;
 
 /* y = dropout(relu(x)), element-wise over n floats (n % 4 == 0, 16-B aligned): the FFN's
@@ -341,6 +347,9 @@ int vdetr_relu_dropout_fwd_f32(const float* x, float* y, long n, float dropout_p
                                const uint64_t* rng_state, vdetr_stream_t stream);
 int vdetr_relu_dropout_bwd_f32(const float* y, const float* dy, float* dx, long n, float dropout_p, vdetr_stream_t stream);
 int vdetr_bn_act_fwd_f32(const vdetr_bnact_desc* d, vdetr_stream_t stream);
+/* this rank's per-channel mean and M2 = sum (x - mean)^2 of x [B, C, N] (what ranks exchange for SyncBatchNorm; merged with
+ * the counts by Chan's formula on the caller's side) */
+int vdetr_bn_stats_f32(const vdetr_bnact_desc* d, float* mean, float* m2, vdetr_stream_t stream);
 int vdetr_bn_act_bwd_f32(const vdetr_bnact_desc* d, const vdetr_bnact_grads* g, vdetr_stream_t stream);
 /* n independent problems (HOST arrays) of the same B*N in one launch per 12: the hidden blocks of several decoder stages'
  * box heads, whose backward v-detr_amd/vdetr_transformer.py:_DeferredHeads runs as one batched pass */

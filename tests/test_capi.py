@@ -25,7 +25,7 @@ def test_library_exports_every_symbol():
     handle = _lib.lib()
     for sym in header_symbols():
         assert hasattr(handle, sym), sym
-    assert handle.vdetr_abi_version() == 1
+    assert handle.vdetr_abi_version() == 2
 
 
 def test_descriptor_layout():

@@ -269,3 +269,76 @@ def test_loss_reductions_match_reference_semantics():
         assert sep == {"a": 15.0, "b": 3.0}
         assert views == {"loss_x": 1.5, "loss_y_0": 16.5, "loss_z": 6.0}
         assert sums == {"loss_x": 3.0, "loss_y_0": 33.0, "loss_z": 12.0}
+
+
+class _ParkedMLP(torch.nn.Module):
+    """linear layers through helpers._Linear (weight gradients parked while runtime.defer_weight_grads is on), an
+    in_proj-style weight used as three views, and a LayerNorm-free tail with an ordinary autograd gradient"""
+
+    def __init__(self):
+        super().__init__()
+        self.fcs = torch.nn.ModuleList([torch.nn.Linear(16, 16) for _ in range(6)])
+        self.in_proj = torch.nn.Parameter(torch.randn(48, 16) * 0.1)
+        self.scale = torch.nn.Parameter(torch.ones(16))
+
+    def forward(self, x):
+        from vdetr_amd.helpers import _Linear
+        for fc in self.fcs:
+            x = torch.relu(_Linear.apply(x, fc.weight, fc.bias))
+        q, k, v = self.in_proj.view(3, 16, 16).unbind(0)
+        x = _Linear.apply(x, q, None) + _Linear.apply(x, k, None) * 0.5 + _Linear.apply(x, v, None) * 0.25
+        return x * self.scale
+
+
+def _phased_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vdetr_amd import runtime
+    from vdetr_amd.dist import FlatParams, GradientReducer, broadcast_parameters, init_distributed
+    init_distributed("gloo")
+    torch.manual_seed(7)
+    model = _ParkedMLP()
+    broadcast_parameters(model)
+    params = list(model.parameters())
+    flat = FlatParams(params)
+    red = GradientReducer(params, bucket_mb=0.002, overlap=False, bucket_views=False, flat=flat)  # ~500 floats per bucket
+    assert len(red.buckets) >= 3
+    torch.manual_seed(rank)
+    x = torch.randn(9, 16)
+    runtime.defer_weight_grads(True)
+    res = {}
+    for mode in ("one_shot", "phased"):
+        red.zero_grad()
+        model(x).square().sum().backward()
+        if mode == "one_shot":       # all parked gradients, one pack, then every bucket
+            runtime.flush_weight_grads()
+            red.pack_and_reduce()
+        else:                        # bucket by bucket: parked gradients of bucket k, pack its slice, its all-reduce
+            red.reduce_phased()
+        res[mode] = [p.grad.detach().numpy().copy() for p in params]
+    runtime.defer_weight_grads(False)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_phased_flush_pack_reduce_equals_one_shot_bit_for_bit():
+    """reduce_phased (what the captured multi-GPU step runs: per bucket parked weight gradients -> slice pack -> all-reduce
+    overlapping the next bucket) delivers exactly the gradients of flush + pack + reduce_all, on both ranks."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_phased_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        for a, b in zip(r["one_shot"], r["phased"]):
+            assert np.array_equal(a, b), f"rank {rank}"
+        assert all(np.abs(a).sum() > 0 for a in r["phased"])
+    for a, b in zip(res[0][1]["phased"], res[1][1]["phased"]):
+        assert np.array_equal(a, b)   # both ranks hold the same averaged gradient

@@ -82,3 +82,76 @@ def test_two_ranks_real_decoder_hooked_reducer_equals_pack_and_reduce():
     assert nonzero > 100
     for a, b in zip(res[0][1]["hooks"], res[1][1]["hooks"]):
         np.testing.assert_array_equal(a, b)                # both ranks hold the same averaged gradient
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from vdetr_amd import bn_act as BNA
+    from vdetr_amd.dist import init_distributed
+    torch.cuda.set_device(0)
+    init_distributed("gloo")
+    g = torch.Generator().manual_seed(3)
+    C = 20
+    full = torch.randn((1, C, 1024 + 512), generator=g) * 2 + 0.5          # the batch of BOTH ranks (different sizes per rank)
+    wfull = torch.randn(full.shape, generator=g)
+    sl = slice(0, 1024) if rank == 0 else slice(1024, 1536)
+    x = full[:, :, sl].contiguous().cuda().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda().requires_grad_(True)
+    beta = torch.randn(C, generator=g).cuda().requires_grad_(True)
+    pre = torch.randn(C, generator=g).cuda()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    cnt = torch.zeros((), dtype=torch.int64).cuda()
+    BNA.set_sync(True)
+    try:
+        y = BNA.bn_act(x, gamma, beta, rm, rv, True, 1e-5, 0.1, relu=True, dropout_p=0.0, pre_bias=pre, counters=[cnt])
+        (y * wfull[:, :, sl].cuda()).sum().backward()
+        # the record-based entry points (deferred heads) share the statistics code: same numbers
+        y2, rec = BNA.forward_record(x.detach(), gamma, beta, None, None, 1e-5, 0.1, 0.0, 0)
+        dx2, dg2, db2 = BNA.backward_from_record(rec, wfull[:, :, sl].cuda().contiguous())
+    finally:
+        BNA.set_sync(False)
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.detach().cpu().numpy().copy() for k, v in dict(y=y, dx=x.grad, dg=gamma.grad, db=beta.grad, rm=rm, rv=rv,
+                                                                    y2=y2, dx2=dx2, dg2=dg2, db2=db2).items()}, int(cnt)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sync_batchnorm_equals_one_big_batch():
+    """bn_act with cross-replica statistics on two ranks holding 1024 and 512 tokens == BatchNorm1d + ReLU of the 1536-token
+    batch in one process (fp64): outputs, input gradients, the SUM over the ranks of the parameter gradients, and the running
+    statistics (unbiased variance of the global batch, bias of the convolution in front folded into the running mean)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(3)
+    C = 20
+    full = (torch.randn((1, C, 1536), generator=g) * 2 + 0.5).double().requires_grad_(True)
+    wfull = torch.randn(full.shape, generator=g).double()
+    gamma = (torch.rand(C, generator=g) + 0.5).double().requires_grad_(True)
+    beta = torch.randn(C, generator=g).double().requires_grad_(True)
+    pre = torch.randn(C, generator=g).double()
+    rm, rv = torch.zeros(C).double(), torch.ones(C).double()
+    ref = torch.relu(torch.nn.functional.batch_norm(full + pre[None, :, None], rm, rv, gamma, beta, True, 0.1, 1e-5))
+    (ref * wfull).sum().backward()
+    y = np.concatenate([res[0][1]["y"], res[1][1]["y"]], 2)
+    dx = np.concatenate([res[0][1]["dx"], res[1][1]["dx"]], 2)
+    np.testing.assert_allclose(y, ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dx, full.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(res[0][1]["dg"] + res[1][1]["dg"], gamma.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(res[0][1]["db"] + res[1][1]["db"], beta.grad.numpy(), rtol=1e-4, atol=1e-4)
+    for r in res:
+        np.testing.assert_allclose(r[1]["rm"], rm.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r[1]["rv"], rv.numpy(), rtol=1e-5, atol=1e-6)
+        assert r[2] == 1
+        np.testing.assert_allclose(r[1]["y2"], r[1]["y"], rtol=0, atol=0)
+        np.testing.assert_allclose(r[1]["dx2"], r[1]["dx"], rtol=0, atol=0)
+        np.testing.assert_allclose(r[1]["dg2"], r[1]["dg"], rtol=0, atol=0)

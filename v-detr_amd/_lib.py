@@ -91,13 +91,14 @@ class BnActDesc(ctypes.Structure):
         ("eps", c_float), ("momentum", c_float), ("dropout_p", c_float), ("seed", ctypes.c_uint64),
         ("offset", ctypes.c_uint64), ("rng_state", c_void_p)] + [
         (n, c_void_p) for n in ("x", "gamma", "beta", "running_mean", "running_var", "y", "save_mean", "save_invstd",
-                                "pre_bias")] + [("counters", c_void_p * 8), ("ncounters", ctypes.c_int32)]
+                                "pre_bias")] + [("counters", c_void_p * 8), ("ncounters", ctypes.c_int32),
+                                                ("stats_given", ctypes.c_int32)]
 
 
 class BnActGrads(ctypes.Structure):
     """Mirror of ``vdetr_bnact_grads``."""
 
-    _fields_ = [(n, c_void_p) for n in ("dy", "dx", "d_gamma", "d_beta")]
+    _fields_ = [(n, c_void_p) for n in ("dy", "dx", "d_gamma", "d_beta", "sum_dy_xhat", "sum_dy", "inv_count")]
 
 
 # ---- set criterion (criterion.hip) -------------------------------------------------------------------------------
@@ -189,6 +190,7 @@ _SIGNATURES = {
                                            c_void_p]),
     "vdetr_relu_dropout_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p]),
     "vdetr_bn_act_fwd_f32": (c_int, [ctypes.POINTER(BnActDesc), c_void_p]),
+    "vdetr_bn_stats_f32": (c_int, [ctypes.POINTER(BnActDesc), c_void_p, c_void_p, c_void_p]),
     "vdetr_bn_act_bwd_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_void_p]),
     "vdetr_bn_act_bwd_batch_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_int, c_void_p]),
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),

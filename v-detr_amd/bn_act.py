@@ -14,6 +14,48 @@ from . import attention as A
 
 _salts = itertools.count(0xB0A70001)
 
+# ---- cross-replica statistics (SyncBatchNorm: the reference converts every BatchNorm before wrapping the model in DDP,
+# main.py:512-514; at one scene per GPU a per-rank BatchNorm would see 1/8 of the reference's batch) -----------------------
+_sync = {"on": False, "group": None, "force": False}
+
+
+def set_sync(enabled, group=None, force=False):
+    """Batch statistics over ALL data-parallel ranks for every training-mode call of this module (the fused launches stay:
+    a statistics launch + one all-gather of [3, C] per call forward, one all-reduce of [2, C] backward).  ``force``: also on
+    a 1-rank group (tests)."""
+    _sync.update(on=bool(enabled), group=group, force=bool(force))
+
+
+def sync_active():
+    import torch.distributed as dist
+    return _sync["on"] and dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size(_sync["group"]) > 1 or _sync["force"])
+
+
+def _global_stats(d, x, eps, momentum, rm, rv, pre_bias, counters):
+    """local (mean, M2) -> all ranks' -> merged (Chan et al.): returns (mean, invstd, inv_count) device tensors and updates
+    the running statistics / counters the way nn.SyncBatchNorm does (unbiased variance of the GLOBAL batch)."""
+    import torch.distributed as dist
+    C = x.shape[1]
+    loc = torch.empty((3, C), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vdetr_bn_stats_f32(ctypes.byref(d), L.ptr(loc[0]), L.ptr(loc[1]), L.stream_ptr()), "bn_stats")
+    loc[2].fill_(float(x.shape[0] * x.shape[2]))
+    world = dist.get_world_size(_sync["group"])
+    allr = torch.empty((world, 3, C), dtype=torch.float32, device=x.device)
+    dist.all_gather(list(allr.unbind(0)), loc, group=_sync["group"])  # (the list form: gloo's flat variant wants other shapes)
+    cnt = allr[:, 2]                                      # [W, C] element counts (ranks may hold different N)
+    n = cnt.sum(0)
+    mean = (allr[:, 0] * cnt).sum(0) / n
+    m2 = (allr[:, 1] + cnt * (allr[:, 0] - mean) ** 2).sum(0)
+    var = m2 / n
+    invstd = torch.rsqrt(var + eps)
+    if rm is not None:
+        rm.mul_(1.0 - momentum).add_((mean + pre_bias) if pre_bias is not None else mean, alpha=momentum)
+        rv.mul_(1.0 - momentum).add_(m2 / torch.clamp(n - 1.0, min=1.0), alpha=momentum)
+    for c in counters:
+        c += 1
+    return mean, invstd, (1.0 / n[:1]).contiguous()
+
 
 def new_salt():
     return next(_salts)
@@ -48,10 +90,19 @@ class _BnAct(torch.autograd.Function):
         smean = torch.empty(C, dtype=torch.float32, device=x.device) if training else None
         sinv = torch.empty_like(smean) if training else None
         p = p if training else 0.0
-        d = _desc(x, gamma_c, beta_c, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng if p > 0 else None,
-                  pre_bias.detach().contiguous() if pre_bias is not None else None, counters)
+        pb = pre_bias.detach().contiguous() if pre_bias is not None else None
+        inv_n = None
+        if training and sync_active():
+            d0 = _desc(x, None, None, None, None, None, None, None, True, relu, eps, momentum, 0.0, 0, None)
+            smean, sinv, inv_n = _global_stats(d0, x, eps, momentum, rm, rv, pb, counters)
+            d = _desc(x, gamma_c, beta_c, None, None, y, smean, sinv, True, relu, eps, momentum, p, salt, rng if p > 0 else None)
+            d.stats_given = 1
+        else:
+            d = _desc(x, gamma_c, beta_c, rm, rv, y, smean, sinv, training, relu, eps, momentum, p, salt, rng if p > 0 else None,
+                      pb, counters)
         L.check(L.lib().vdetr_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "bn_act_fwd")
         ctx.cfg = (training, relu, eps, momentum, p, salt)
+        ctx.inv_n = inv_n
         ctx.save_for_backward(x, gamma_c, beta_c, smean, sinv, rng if p > 0 else None)
         return y
 
@@ -67,10 +118,35 @@ class _BnAct(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dg = torch.empty_like(gamma) if gamma is not None and ctx.needs_input_grad[1] else None
         db = torch.empty_like(beta) if beta is not None and ctx.needs_input_grad[2] else None
+        if ctx.inv_n is not None:
+            dx2, dg2, db2 = _sync_backward(d, dy, dx, ctx.inv_n)
+            return dx2, (dg2 if dg is not None else None), (db2 if db is not None else None), None, None, None, None, None, \
+                None, None, None, None, None, None
         g.dy, g.dx = dy.data_ptr(), dx.data_ptr() if dx is not None else None
         g.d_gamma, g.d_beta = (dg.data_ptr() if dg is not None else None), (db.data_ptr() if db is not None else None)
         L.check(L.lib().vdetr_bn_act_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "bn_act_bwd")
         return dx, dg, db, None, None, None, None, None, None, None, None, None, None, None
+
+
+def _sync_backward(d, dy, dx, inv_n):
+    """backward with statistics over all ranks: this rank's two sums (a launch without dx), their all-reduce, dx with the
+    global sums.  Returns (dx, dgamma, dbeta); the parameter gradients are THIS rank's sums, as nn.SyncBatchNorm returns
+    them (the gradient all-reduce averages them like every other parameter gradient)."""
+    import torch.distributed as dist
+    C = d.C
+    loc = torch.empty((2, C), dtype=torch.float32, device=dy.device)
+    g = L.BnActGrads()
+    g.dy, g.dx, g.d_gamma, g.d_beta = dy.data_ptr(), None, loc[0].data_ptr(), loc[1].data_ptr()
+    L.check(L.lib().vdetr_bn_act_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "bn_act_bwd")
+    if dx is not None:
+        tot = loc.clone()
+        dist.all_reduce(tot, group=_sync["group"])
+        g2 = L.BnActGrads()
+        g2.dy, g2.dx = dy.data_ptr(), dx.data_ptr()
+        g2.sum_dy_xhat, g2.sum_dy, g2.inv_count = tot[0].data_ptr(), tot[1].data_ptr(), inv_n.data_ptr()
+        L.check(L.lib().vdetr_bn_act_bwd_f32(ctypes.byref(d), ctypes.byref(g2), L.stream_ptr()), "bn_act_bwd")
+        tot.record_stream(torch.cuda.current_stream())
+    return dx, loc[0], loc[1]
 
 
 def bn_act(x, weight, bias, running_mean, running_var, training, eps, momentum, relu=True, dropout_p=0.0, salt=0,
@@ -104,19 +180,28 @@ def forward_record(x, gamma, beta, rm, rv, eps, momentum, p, salt, counters=(), 
         C = x.shape[1]
         smean = torch.empty(C, dtype=torch.float32, device=x.device)
         sinv = torch.empty_like(smean)
-        d = _desc(x, g, b, rm, rv, y, smean, sinv, True, True, eps, momentum, p, salt, rng if p > 0 else None,
-                  pre_bias.detach().contiguous() if pre_bias is not None else None, tuple(counters))
+        pb = pre_bias.detach().contiguous() if pre_bias is not None else None
+        inv_n = None
+        if sync_active():
+            d0 = _desc(x, None, None, None, None, None, None, None, True, True, eps, momentum, 0.0, 0, None)
+            smean, sinv, inv_n = _global_stats(d0, x, eps, momentum, rm, rv, pb, tuple(counters))
+            d = _desc(x, g, b, None, None, y, smean, sinv, True, True, eps, momentum, p, salt, rng if p > 0 else None)
+            d.stats_given = 1
+        else:
+            d = _desc(x, g, b, rm, rv, y, smean, sinv, True, True, eps, momentum, p, salt, rng if p > 0 else None, pb, tuple(counters))
         L.check(L.lib().vdetr_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "bn_act_fwd")
-    return y, (x, g, b, smean, sinv, rng if p > 0 else None, (float(eps), float(momentum), float(p), int(salt)))
+    return y, (x, g, b, smean, sinv, rng if p > 0 else None, (float(eps), float(momentum), float(p), int(salt)), inv_n)
 
 
 def backward_from_record(record, dy, dx_out=None):
-    x, gamma, beta, smean, sinv, rng, (eps, momentum, p, salt) = record
+    x, gamma, beta, smean, sinv, rng, (eps, momentum, p, salt), inv_n = record
     dy = dy.contiguous()
     d = _desc(x, gamma, beta, None, None, None, smean, sinv, True, True, eps, momentum, p, salt, rng)
     g = L.BnActGrads()
     dx = dx_out if dx_out is not None else torch.empty_like(x)
     assert dx.is_contiguous() and dx.shape == x.shape
+    if inv_n is not None:
+        return _sync_backward(d, dy, dx, inv_n)
     dg, db = torch.empty_like(gamma), torch.empty_like(beta)
     g.dy, g.dx, g.d_gamma, g.d_beta = dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr()
     L.check(L.lib().vdetr_bn_act_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "bn_act_bwd")
@@ -161,10 +246,12 @@ def relu_dropout(x, drop, salt=0):
 def backward_from_records(records, dys, dx_outs):
     """backward_from_record for several independent blocks of the same B*N in ONE launch.  Returns [(dx, dgamma, dbeta)]."""
     n = len(records)
+    if any(rec[7] is not None for rec in records):  # cross-replica statistics: each block has its own collective
+        return [backward_from_record(rec, dy, dx) for rec, dy, dx in zip(records, dys, dx_outs)]
     descs, grads = (L.BnActDesc * n)(), (L.BnActGrads * n)()
     keep, out = [], []
     for i, (rec, dy, dx) in enumerate(zip(records, dys, dx_outs)):
-        x, gamma, beta, smean, sinv, rng, (eps, momentum, p, salt) = rec
+        x, gamma, beta, smean, sinv, rng, (eps, momentum, p, salt), _ = rec
         dy = dy.contiguous()
         assert dx.is_contiguous() and dx.shape == x.shape
         descs[i] = _desc(x, gamma, beta, None, None, None, smean, sinv, True, True, eps, momentum, p, salt, rng)

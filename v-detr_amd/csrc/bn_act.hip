@@ -60,7 +60,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_kernel(vdetr_bnact_desc
   const size_t bstride = (size_t)d.C * N;
   const float* xc = d.x + (size_t)c * N;
   float mean, invstd;
-  if (d.training) {
+  if (d.training && d.stats_given) {  // statistics of the batch over all ranks, from the caller
+    mean = d.save_mean[c];
+    invstd = d.save_invstd[c];
+  } else if (d.training) {
     float s = 0.f;
     for (int b = 0; b < d.B; ++b)
       for (int i = lane; i < N; i += 64) s += xc[b * bstride + i];
@@ -97,6 +100,25 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_kernel(vdetr_bnact_desc
     }
 }
 
+// this rank's share of a cross-replica BatchNorm: per channel the local mean and M2 = sum (x - mean)^2
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(vdetr_bnact_desc d, float* __restrict__ mean_out, float* __restrict__ m2_out) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= d.C) return;
+  const int N = d.N, n = d.B * N;
+  const size_t bstride = (size_t)d.C * N;
+  const float* xc = d.x + (size_t)c * N;
+  float s = 0.f;
+  for (int b = 0; b < d.B; ++b)
+    for (int i = lane; i < N; i += 64) s += xc[b * bstride + i];
+  const float mean = wave_allsum_f32(s) / (float)n;
+  float q = 0.f;
+  for (int b = 0; b < d.B; ++b)
+    for (int i = lane; i < N; i += 64) { const float t = xc[b * bstride + i] - mean; q += t * t; }
+  q = wave_allsum_f32(q);
+  if (lane == 0) { mean_out[c] = mean; m2_out[c] = q; }
+}
+
 // training-mode backward: g = dy through dropout and relu; dbeta = sum g, dgamma = sum g*xhat,
 // dx = gamma * invstd * (g - dbeta/n - xhat * dgamma/n)
 __device__ __forceinline__ void bn_act_bwd_body(const vdetr_bnact_desc& d, const vdetr_bnact_grads& g) {
@@ -131,7 +153,8 @@ __device__ __forceinline__ void bn_act_bwd_body(const vdetr_bnact_desc& d, const
     if (g.d_beta) g.d_beta[c] = dbeta;
   }
   if (!g.dx) return;
-  const float k = ga * invstd, m1 = dbeta / (float)n, m2 = dgamma / (float)n;
+  const float inv_n = g.inv_count ? g.inv_count[0] : 1.f / (float)n;
+  const float k = ga * invstd, m1 = (g.sum_dy ? g.sum_dy[c] : dbeta) * inv_n, m2 = (g.sum_dy_xhat ? g.sum_dy_xhat[c] : dgamma) * inv_n;
   float* dxc = g.dx + (size_t)c * N;
   for (int b = 0; b < d.B; ++b)
     for (int i = lane; i < N; i += 64) {
@@ -164,15 +187,18 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_fwd_reg_kernel(vdetr_bnact_
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NCH; ++j) s += (xr[j][0] + xr[j][1]) + (xr[j][2] + xr[j][3]);
-  const float mean = wave_allsum_f32(s) * (1.f / (float)N);
+  float mean = wave_allsum_f32(s) * (1.f / (float)N);
   float q = 0.f;
 #pragma unroll
   for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const float t = xr[j][e] - mean; q += t * t; }
   const float var = wave_allsum_f32(q) * (1.f / (float)N);
-  const float invstd = rsqrtf(var + d.eps);
-  if (lane == 0) {
+  float invstd = rsqrtf(var + d.eps);
+  if (d.stats_given) {  // statistics of the batch over all ranks, from the caller
+    mean = d.save_mean[c];
+    invstd = d.save_invstd[c];
+  } else if (lane == 0) {
     d.save_mean[c] = mean;
     d.save_invstd[c] = invstd;
     if (d.running_mean) {
@@ -236,7 +262,8 @@ __device__ __forceinline__ void bn_act_bwd_reg_body(const vdetr_bnact_desc& d, c
     if (g.d_beta) g.d_beta[c] = dbeta;
   }
   if (!g.dx) return;
-  const float k = ga * invstd, m1 = dbeta * (1.f / (float)N), m2 = dgamma * (1.f / (float)N);
+  const float inv_n = g.inv_count ? g.inv_count[0] : 1.f / (float)N;
+  const float k = ga * invstd, m1 = (g.sum_dy ? g.sum_dy[c] : dbeta) * inv_n, m2 = (g.sum_dy_xhat ? g.sum_dy_xhat[c] : dgamma) * inv_n;
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     f32x4 v;
@@ -315,6 +342,7 @@ static int bnact_check(const vdetr_bnact_desc* d, const char* op) {
 extern "C" int vdetr_bn_act_fwd_f32(const vdetr_bnact_desc* d, vdetr_stream_t stream) {
   if (int e = bnact_check(d, "bn_act_fwd")) return e;
   VDETR_REQUIRE(d->y, "bn_act_fwd: null output");
+  VDETR_REQUIRE(!d->stats_given || d->training, "bn_act_fwd: stats_given is a training-mode option");
   VDETR_REQUIRE(d->training ? (d->save_mean && d->save_invstd) : (d->running_mean != nullptr),
                 "bn_act_fwd: training needs save_mean / save_invstd, eval needs the running statistics");
   VDETR_REQUIRE(d->training || d->dropout_p == 0.f, "bn_act_fwd: dropout in eval mode");
@@ -334,11 +362,20 @@ extern "C" int vdetr_bn_act_fwd_f32(const vdetr_bnact_desc* d, vdetr_stream_t st
   return check_launch("bn_act_fwd");
 }
 
+extern "C" int vdetr_bn_stats_f32(const vdetr_bnact_desc* d, float* mean, float* m2, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr && d->x && mean && m2, "bn_stats: null pointer");
+  VDETR_REQUIRE(d->B > 0 && d->C > 0 && d->N > 0, "bn_stats: empty tensor B=%d C=%d N=%d", d->B, d->C, d->N);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(ceil_div(d->C, 4)), dim3(kBnThreads), 0, (hipStream_t)stream, *d, mean, m2);
+  return check_launch("bn_stats");
+}
+
 extern "C" int vdetr_bn_act_bwd_f32(const vdetr_bnact_desc* d, const vdetr_bnact_grads* g, vdetr_stream_t stream) {
   if (int e = bnact_check(d, "bn_act_bwd")) return e;
   VDETR_REQUIRE(d->training, "bn_act_bwd: only the training-mode backward is built (batch statistics)");
   VDETR_REQUIRE(g && g->dy && d->save_mean && d->save_invstd, "bn_act_bwd: null pointer");
   VDETR_REQUIRE(g->dx || g->d_gamma || g->d_beta, "bn_act_bwd: nothing to compute");
+  VDETR_REQUIRE((g->sum_dy == nullptr) == (g->sum_dy_xhat == nullptr) && (g->sum_dy == nullptr) == (g->inv_count == nullptr),
+                "bn_act_bwd: the cross-replica sums and the inverse count go together");
   const dim3 grid(ceil_div(d->C, 4)), block(kBnThreads);
   hipStream_t st = (hipStream_t)stream;
   const long tot = (long)d->B * d->N;

@@ -31,5 +31,5 @@ int reserve_lds(const void* kernel, size_t bytes, const char* op) {
 }
 }  // namespace vdetr
 
-extern "C" int vdetr_abi_version(void) { return 1; }
+extern "C" int vdetr_abi_version(void) { return 2; }
 extern "C" const char* vdetr_last_error(void) { return vdetr::g_err; }

@@ -76,7 +76,16 @@ class FlatParams:
                 layout.append((p, off))
                 placed.add(id(p))
                 off += slot if slot is not None else p.numel()
-        for p in reversed(plist):
+        # the rest in reverse parameter order, matrices of one shape next to each other: the parked weight gradients are
+        # computed per shape as ONE batched GEMM (helpers.DeferredParamGrads), and a gradient bucket that holds whole shape
+        # groups lets reduce_phased() finish and send it without splitting such a batch
+        rest = [p for p in reversed(plist) if id(p) not in placed]
+        order = {}
+        for p in rest:
+            if p.ndim == 2:
+                order.setdefault((p.shape[1], p.shape[0] % p.shape[1] == 0), len(order))  # [k*C, C] stacks go with [C, C]
+        rest.sort(key=lambda p: order[(p.shape[1], p.shape[0] % p.shape[1] == 0)] if p.ndim == 2 else len(order))  # stable
+        for p in rest:
             if id(p) not in placed:
                 off = (off + 3) // 4 * 4  # 16-B aligned slices (vectorised pack / fused optimizer)
                 layout.append((p, off))
@@ -98,6 +107,21 @@ class FlatParams:
         self.param = torch.nn.Parameter(self.data)  # what the optimizer sees; shares the storage
         self.param.grad = self.grad
 
+    def pack_grads_span(self, start, end):
+        """``pack_grads`` for the parameters whose slice lies in [start, end) of the flat buffer only (one gradient bucket
+        of a data-parallel step: its parameters' ``.grad`` are final, the others' may still be missing)."""
+        sel = [i for i, p in enumerate(self.params) if start <= self.offsets[id(p)] < end]
+        src = [self.params[i].grad for i in sel]
+        if self.grad.is_cuda:
+            return self._pack_hip(src, span=(start, end), sel=sel)
+        views = [self.grad_views[i] for i in sel]
+        missing = [v for v, g in zip(views, src) if g is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        have = [(v, g) for v, g in zip(views, src) if g is not None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+
     def pack_grads(self, grads=None):
         """``p.grad`` (or the given tensors, in ``self.params`` order) -> the flat gradient buffer; parameters that
         received no gradient contribute zeros.  GPU: ONE launch of ``vdetr_pack_f32`` (the source-pointer table goes up
@@ -114,30 +138,37 @@ class FlatParams:
         if have_g:
             torch._foreach_copy_(have_v, have_g)
 
-    def _pack_tables(self):
+    def _pack_tables(self, sel=None):
         from . import _lib as L
         chunk = L.lib().vdetr_pack_chunk_floats()
-        n = len(self.params)
+        params = self.params if sel is None else [self.params[i] for i in sel]
+        n = len(params)
         tab = torch.zeros((n, 3), dtype=torch.int64)
         be, bc = [], []
-        for i, p in enumerate(self.params):
+        for i, p in enumerate(params):
             tab[i, 1], tab[i, 2] = self.offsets[id(p)], p.numel()
             nch = (p.numel() + chunk - 1) // chunk
             be += [i] * nch
             bc += list(range(nch))
         dev = self.grad.device
-        self._pack = {"static": tab, "block_entry": torch.tensor(be, dtype=torch.int32, device=dev),
+        return {"static": tab, "block_entry": torch.tensor(be, dtype=torch.int32, device=dev),
                       "block_chunk": torch.tensor(bc, dtype=torch.int32, device=dev), "nblocks": len(be),
                       "dev": torch.empty((n, 3), dtype=torch.int64, device=dev), "host": tab.clone().pin_memory(),
                       "event": None, "captured": [],
                       # pinned tables for hipGraph captures, allocated up front (no host allocation while capturing)
                       "spare": [tab.clone().pin_memory() for _ in range(4)]}
 
-    def _pack_hip(self, src):
+    def _pack_hip(self, src, span=None, sel=None):
         from . import _lib as L
-        if not hasattr(self, "_pack"):
-            self._pack_tables()
-        P = self._pack
+        if span is None:
+            if not hasattr(self, "_pack"):
+                self._pack = self._pack_tables()
+            P = self._pack
+        else:  # one table set per gradient bucket
+            spans = self.__dict__.setdefault("_pack_spans", {})
+            if span not in spans:
+                spans[span] = self._pack_tables(sel)
+            P = spans[span]
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing:  # a captured upload reads ITS host table at every replay: never reuse it
             assert P["spare"], "FlatParams: more than 4 graph captures of pack_grads (call it once eagerly first)"
@@ -226,10 +257,14 @@ class FlatParams:
 
 
 class GradientReducer:
-    def __init__(self, params, bucket_mb=25.0, overlap=True, process_group=None, bucket_views=True, flat=None):
+    def __init__(self, params, bucket_mb=25.0, overlap=True, process_group=None, bucket_views=True, flat=None, force=False):
+        """``force``: issue the collectives even on ONE rank (a 1-rank RCCL communicator: how the captured, overlapped path
+        is exercised on a single GPU)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        self._spans = []
         self.overlap = overlap
         assert self.params, "no trainable parameters"
         dev, dtype = self.params[0].device, self.params[0].dtype
@@ -256,6 +291,7 @@ class GradientReducer:
                 start = self.flat.offsets[id(g[0])]
                 end = self.flat.offsets[id(g[-1])] + g[-1].numel()
                 flat = self.flat.grad[start:end]
+                self._spans.append((start, end))
             else:
                 flat = torch.zeros(n_g, dtype=dtype, device=dev)
             off = 0
@@ -274,7 +310,7 @@ class GradientReducer:
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._handles = []
         self._hook_handles = []
-        if overlap and self.world > 1 and bucket_views:
+        if overlap and self.active and bucket_views:
             for p in self.params:
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
@@ -348,9 +384,30 @@ class GradientReducer:
         for p, v in self._views:
             p.grad = v
 
+    def reduce_phased(self):
+        """The data-parallel step of a loop that parks its weight gradients (runtime.defer_weight_grads) and keeps ordinary
+        ``p.grad`` tensors (bucket_views=False, flat buffer): bucket by bucket, compute the parked gradients that belong to
+        it, pack its slice of the flat buffer (one launch), and start its all-reduce on the side stream while the next
+        bucket's gradients are computed; join, point ``p.grad`` at the reduced views.  Every call is stream-ordered (no host
+        wait), so the whole sequence — RCCL launches included — can sit inside ONE captured hipGraph together with the
+        forward, the backward and the optimizer step: the fork / join of the side stream become graph dependencies.
+        The reference gets this overlap from DistributedDataParallel's bucket hooks (main.py:515-517)."""
+        from . import runtime
+        assert self.flat is not None and not self.bucket_views, "reduce_phased: flat buffer + plain gradients"
+
+        def after_phase(k):
+            self.flat.pack_grads_span(*self._spans[k])
+            if self.active:
+                self._launch(k)
+
+        runtime.flush_weight_grads_phased(lambda p: self._bucket_of.get(id(p), 0), len(self.buckets), after_phase)
+        self.finish()
+        for p, v in self._views:
+            p.grad = v
+
     def finish(self):
         """End of backward: flush buckets that never completed (unused parameters), join the side stream."""
-        if self.world > 1:
+        if self.active:
             for gi in range(len(self.buckets)):
                 if not self._launched[gi]:
                     self._launch(gi)
@@ -376,8 +433,8 @@ class GradientReducer:
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def reduce_all(self):
-        """Graph mode: average every bucket after the captured forward+backward has been replayed."""
-        if self.world > 1:
+        """Average every bucket on the current stream (after a captured forward+backward has been replayed)."""
+        if self.active:
             for b in self.buckets:
                 self._allreduce_avg(b)
 

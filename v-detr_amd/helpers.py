@@ -70,8 +70,32 @@ class DeferredParamGrads:
         grads.append(g)
 
     @classmethod
-    def flush(cls):
-        items, cls.pending = cls.pending, []
+    def leaves_of(cls, p):
+        """the leaf parameters the gradient of `p` (a weight / bias a `linear` call used) ends up in, or None if that takes
+        an autograd walk to find out"""
+        if p is None:
+            return []
+        if p.is_leaf:
+            return [p]
+        base = cls._view_of_leaf(p)
+        if base is not None:
+            return [base]
+        fn = p.grad_fn
+        if type(fn).__name__ == "_AliasBackward":
+            leaves = [nf[0].variable if nf[0] is not None and hasattr(nf[0], "variable") else None for nf in fn.next_functions]
+            if all(l is not None for l in leaves):
+                return leaves
+        return None
+
+    @classmethod
+    def flush(cls, select=None):
+        """``select(item) -> bool``: flush only those parked items now (the others stay parked): gradient buckets of a
+        data-parallel step complete one after the other that way (runtime.flush_weight_grads_phased)."""
+        if select is None:
+            items, cls.pending = cls.pending, []
+        else:
+            items = [it for it in cls.pending if select(it)]
+            cls.pending = [it for it in cls.pending if not select(it)]
         if not items:
             return
         groups = {}
@@ -84,7 +108,8 @@ class DeferredParamGrads:
                 if n == 1:
                     w, b, g2, x2 = group[0]
                     dW = torch.mm(g2.t(), x2)[None] if w is not None else None
-                    dB = colsum(g2 if g2.stride(1) == 1 else g2.contiguous())[None] if b is not None else None
+                    dB = (colsum(g2 if g2.stride(1) == 1 else g2.contiguous()) if g2.is_cuda else g2.sum(0))[None] \
+                        if b is not None else None
                 else:
                     # views of one leaf (the q / k / v blocks of an in_proj_weight) next to each other, in memory order: their
                     # rows of the batched result then ARE the leaf's gradient (no stack launch in an UnbindBackward)

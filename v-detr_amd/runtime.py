@@ -95,3 +95,29 @@ def flush_weight_grads():
     DeferredParamGrads.flush()
     DeferredLnGrads.flush()
     DeferredPosEmbedGrads.flush()
+
+
+def flush_weight_grads_phased(phase_of_param, nphases, after_phase):
+    """``flush_weight_grads()`` in ``nphases`` steps for a data-parallel step whose gradient buckets are all-reduced one by
+    one: a parked weight gradient is computed in the phase of the EARLIEST bucket one of its parameters belongs to
+    (``phase_of_param(leaf) -> int``; what cannot be attributed without an autograd walk goes first), so that after phase k
+    the buckets 0..k are final and ``after_phase(k)`` may pack and launch bucket k's all-reduce while phase k+1 computes.
+    The shape-batched GEMMs split into at most ``nphases`` smaller batches; the values are those of the one-shot flush."""
+    from .add_ln import DeferredLnGrads
+    from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
+    DeferredLnGrads.flush()        # a handful of launches whose parameters may sit in any bucket: before the first one leaves
+    DeferredPosEmbedGrads.flush()
+
+    def phase(it):
+        ph = nphases - 1
+        for t in (it[0], it[1]):
+            leaves = DeferredParamGrads.leaves_of(t)
+            if leaves is None:
+                return 0
+            for l in leaves:
+                ph = min(ph, phase_of_param(l))
+        return ph
+
+    for k in range(nphases):
+        DeferredParamGrads.flush(select=(lambda it, k=k: phase(it) <= k) if k < nphases - 1 else None)
+        after_phase(k)
