@@ -301,11 +301,11 @@ class BackboneTrainer:
     What depends on the point coordinates only — voxel sites, kernel maps, compacted row lists, FPS indices — is built
     ahead of time (`geometry_ms`), as a data loader / side stream would for the next scene."""
 
-    def __init__(self, cfg_name, device, npoints=40000, seed=0):
+    def __init__(self, cfg_name, device, npoints=40000, seed=0, force_dist=False, scene_seed=None):
         from vdetr_amd import pointnet2_utils as PU
         from vdetr_amd import sparse_ops as S
         from vdetr_amd.dataset_config import ScannetDatasetConfig
-        from vdetr_amd.dist import FlatParams
+        from vdetr_amd.dist import FlatParams, GradientReducer
         from vdetr_amd.model_vdetr import build_vdetr, default_args
         global flush_weight_grads
         from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
@@ -317,7 +317,7 @@ class BackboneTrainer:
             for h in model.decoder.mlp_heads:
                 for k in ("center_head", "size_head"):
                     h[k].layers[-1].weight.add_(0.01 * torch.randn_like(h[k].layers[-1].weight))
-        cloud = make_room_cloud(npoints, seed, device)
+        cloud = make_room_cloud(npoints, seed if scene_seed is None else scene_seed, device)  # same weights, own scene per rank
         self.inputs = {"point_clouds": [cloud], "point_cloud_dims_min": cloud.min(0)[0][None], "point_cloud_dims_max": cloud.max(0)[0][None]}
         for rep in range(2):  # the second pass is the timed one (the first also tunes the library GEMMs of the dry run)
             torch.cuda.synchronize()
@@ -336,7 +336,15 @@ class BackboneTrainer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.dec_params = [p for n, p in model.named_parameters() if n.startswith(("decoder.", "encoder_to_decoder"))]
         self.bb_params = [p for n, p in model.named_parameters() if not n.startswith(("decoder.", "encoder_to_decoder"))]
-        self.flat = FlatParams(self.params, groups=model.flat_param_groups())
+        self.flat = FlatParams(self.params, groups=model.flat_param_groups(), first=self.dec_params)
+        # data parallel: the decoder's gradients (47 MB) are final after its captured backward and are all-reduced on the side
+        # stream while the backbone's backward (the larger half of the step) runs; the backbone's 268 MB follow in 64 MB buckets
+        first_bb = next(p for p in self.flat.params if any(p is q for q in self.bb_params))
+        self.reducer = GradientReducer(self.params, bucket_mb=float(os.environ.get("VDETR_BUCKET_MB", "64")), overlap=False,
+                                       bucket_views=False, flat=self.flat, force=force_dist, break_before=[first_bb])
+        self.dec_buckets = self.reducer.buckets_of(self.dec_params)
+        self.bb_buckets = [k for k in range(len(self.reducer.buckets)) if k not in self.dec_buckets]
+        assert not set(self.reducer.buckets_of(self.bb_params)) & set(self.dec_buckets), "decoder / backbone gradients share a bucket"
         self.opt = torch.optim.AdamW([self.flat.param], lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
         self.graph, self.loss = None, None
         # the NEXT scene's geometry and FPS indices are built on a side stream while this scene trains (the synthetic bench
@@ -425,9 +433,15 @@ class BackboneTrainer:
             # forward 5.8 -> 9.9 ms measured); now the device has the forward and the captured decoder step (14 ms) queued
             self._worker = threading.Thread(target=self._prepare_next, daemon=True)
             self._worker.start()
+        if self.reducer.active:
+            self.reducer.pack_and_launch(self.dec_buckets)  # overlaps the backbone's backward
         enc_rows.backward(self.static_feat.grad.permute(1, 0, 2))
         mark()
-        self.flat.pack_grads()
+        if self.reducer.active:
+            self.reducer.pack_and_launch(self.bb_buckets)
+            self.reducer.finish()
+        else:
+            self.flat.pack_grads()
         self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
         self.opt.step()
         mark()
@@ -684,6 +698,8 @@ def main():
     ap.add_argument("--no-backbone-leg", action="store_true", help="skip the extra N=1 measurement with the sparse-conv backbone")
     ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library heuristics instead of per-shape tuned GEMM solutions")
+    ap.add_argument("--with-backbone-dist", action="store_true", help="N>1: also time the step with the sparse-conv backbone on "
+                    "every rank (decoder gradients all-reduced under the backbone's backward)")
     ap.add_argument("--force-dist", action="store_true", help="N=1 only: a 1-rank RCCL communicator, so that the multi-GPU step "
                     "(captured all-reduces on the side stream) runs on a single GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
@@ -881,7 +897,10 @@ def main():
     def backbone_leg():
         # the step with the sparse-convolution backbone in front, on a synthetic 40k-point room scan
         from vdetr_amd.runtime import defer_weight_grads
-        bt = BackboneTrainer(a.config, device)
+        bt = BackboneTrainer(a.config, device, force_dist=a.force_dist, scene_seed=rank)
+        if world > 1:
+            from vdetr_amd.dist import broadcast_parameters as _bcast
+            _bcast(bt.model)
         try:
             if use_graph:
                 bt.capture()
@@ -895,6 +914,10 @@ def main():
                 bt.step()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / a.steps * 1e3
+            if world > 1:  # the slowest rank's time, as for the headline
+                tt = torch.tensor([ms], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                ms = float(tt.item())
             if os.environ.get("VDETR_BENCH_TIMELINE"):  # device time of the step's phases (events on the main stream)
                 bt.marks = []
                 for _ in range(10):
@@ -910,7 +933,8 @@ def main():
             bloss = float(bt.loss.item())
             assert np.isfinite(bloss), "non-finite loss with the backbone"
             result["with_backbone"] = {
-                "ms_per_step": ms, "scenes_per_s": 1e3 / ms, "geometry_ms": bt.geometry_ms, "input_points": 40000,
+                "ms_per_step": ms, "scenes_per_s": world * 1e3 / ms, "n_gpus": world, "geometry_ms": bt.geometry_ms, "input_points": 40000,
+                "grad_allreduce_bytes": bt.reducer.grad_bytes() if bt.reducer.active else 0,
                 "voxels_per_stride": bt.voxels, "backbone_parameters": sum(p.numel() for p in bt.bb_params), "loss": bloss,
                 "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP kernel maps, fused pair-list convolutions on the fp32 matrix cores, fused BatchNorm; eager) -> FPS tokens -> "
                         "decoder step (captured hipGraph) -> backbone backward -> clip + AdamW over all 79 M parameters; "
@@ -954,6 +978,8 @@ def main():
                                "matches, 9 stages, 24 boxes/scene x repeat 5) instead of the synthetic scalar loss; "
                                "cpu_oracle_ms = the criterion alone (fwd+bwd) through oracle/criterion_oracle.py"}
 
+    if world > 1 and a.with_backbone_dist and a.config == "c2":
+        leg("with_backbone", backbone_leg)  # collective: every rank runs it (own scene each); opt-in, it follows the headline
     if rank == 0:
         if not a.no_roofline:
             leg("roofline", roofline_leg)

@@ -342,3 +342,34 @@ def test_phased_flush_pack_reduce_equals_one_shot_bit_for_bit():
         assert all(np.abs(a).sum() > 0 for a in r["phased"])
     for a, b in zip(res[0][1]["phased"], res[1][1]["phased"]):
         assert np.array_equal(a, b)   # both ranks hold the same averaged gradient
+
+
+def test_flat_layout_parts_and_forced_bucket_breaks():
+    """FlatParams(first=...) lays one part of the model out in front of the other and GradientReducer(break_before=...) ends
+    a bucket there, so that the part whose gradients are final first owns whole buckets; pack_and_launch over all buckets
+    fills the flat gradient buffer exactly as pack_grads does (one rank: no collective)."""
+    from vdetr_amd.dist import FlatParams, GradientReducer
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 8))       # "backbone"
+    b = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 3))       # "decoder": final first
+    params = list(a.parameters()) + list(b.parameters())
+    flat = FlatParams(params, first=list(b.parameters()))
+    nb = sum(p.numel() for p in b.parameters())
+    offs_b = sorted(flat.offsets[id(p)] for p in b.parameters())
+    offs_a = sorted(flat.offsets[id(p)] for p in a.parameters())
+    assert offs_b[-1] < offs_a[0] and offs_a[0] >= nb
+    first_a = next(p for p in flat.params if any(p is q for q in a.parameters()))
+    red = GradientReducer(params, bucket_mb=1.0, overlap=False, bucket_views=False, flat=flat, break_before=[first_a])
+    assert len(red.buckets) == 2
+    assert red.buckets_of(list(b.parameters())) == [0] and red.buckets_of(list(a.parameters())) == [1]
+    x = torch.randn(4, 8)
+    b(a(x)).square().sum().backward()
+    flat.pack_grads()
+    ref = flat.grad.clone()
+    flat.grad.fill_(7.0)
+    red.pack_and_launch([0])
+    red.pack_and_launch([1])
+    red.finish()
+    for p in params:  # (the alignment padding between parameters is not part of any span: compare the views)
+        o = flat.offsets[id(p)]
+        assert torch.equal(flat.grad[o:o + p.numel()], ref[o:o + p.numel()])

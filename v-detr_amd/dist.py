@@ -58,11 +58,15 @@ class FlatParams:
     Layout = the model's adjacency groups first, then REVERSE parameter order, so that slices complete roughly
     front-to-back during backward."""
 
-    def __init__(self, params, groups=None):
+    def __init__(self, params, groups=None, first=None):
         """``groups``: optional list of (parameters, slot) — parameters a model wants ADJACENT in memory, in this order
         (see helpers.cat_params).  slot = None packs them back to back; slot = n gives every parameter a zero-padded
-        slab of n elements (helpers.slot_stack_params).  Everything else follows in reverse parameter order."""
+        slab of n elements (helpers.slot_stack_params).  Everything else follows in reverse parameter order.
+        ``first``: parameters to lay out before all others of the ungrouped rest (e.g. the part of a model whose gradients
+        are final first, so that its gradient buckets are contiguous and can be all-reduced while the rest is still in
+        its backward pass)."""
         plist = [p for p in params if p.requires_grad]
+        first_ids = {id(p) for p in (first or [])}
         assert plist, "no trainable parameters"
         known = {id(p) for p in plist}
         layout, placed, off = [], set(), 0  # (param, offset)
@@ -85,6 +89,7 @@ class FlatParams:
             if p.ndim == 2:
                 order.setdefault((p.shape[1], p.shape[0] % p.shape[1] == 0), len(order))  # [k*C, C] stacks go with [C, C]
         rest.sort(key=lambda p: order[(p.shape[1], p.shape[0] % p.shape[1] == 0)] if p.ndim == 2 else len(order))  # stable
+        rest.sort(key=lambda p: 0 if id(p) in first_ids else 1)  # stable: keeps the shape runs inside each part
         for p in rest:
             if id(p) not in placed:
                 off = (off + 3) // 4 * 4  # 16-B aligned slices (vectorised pack / fused optimizer)
@@ -257,9 +262,10 @@ class FlatParams:
 
 
 class GradientReducer:
-    def __init__(self, params, bucket_mb=25.0, overlap=True, process_group=None, bucket_views=True, flat=None, force=False):
+    def __init__(self, params, bucket_mb=25.0, overlap=True, process_group=None, bucket_views=True, flat=None, force=False,
+                 break_before=()):
         """``force``: issue the collectives even on ONE rank (a 1-rank RCCL communicator: how the captured, overlapped path
-        is exercised on a single GPU)."""
+        is exercised on a single GPU).  ``break_before``: parameters at which a new bucket starts whatever its size."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -271,10 +277,11 @@ class GradientReducer:
         # buckets in REVERSE parameter order: backward produces gradients roughly last-layer-first
         cap = max(int(bucket_mb * (1 << 20) / 4), 1)
         groups, cur, cur_n = [], [], 0
+        breaks = {id(p) for p in break_before}
         self.flat = flat  # FlatParams: the buckets are consecutive slices of its gradient buffer
         for p in (flat.params if flat is not None else reversed(self.params)):
             assert p.device == dev and p.dtype == dtype, "one device / dtype per reducer"
-            if cur and cur_n + p.numel() > cap:
+            if cur and (cur_n + p.numel() > cap or id(p) in breaks):
                 groups.append(cur)
                 cur, cur_n = [], 0
             cur.append(p)
@@ -383,6 +390,20 @@ class GradientReducer:
         self.reduce_all()
         for p, v in self._views:
             p.grad = v
+
+    def pack_and_launch(self, buckets):
+        """flat-buffer, plain-gradient mode: the parameters of these buckets hold their final ``.grad``: pack the slices and
+        start the all-reduces on the side stream (join with ``finish()``).  For a step whose gradients become final part by
+        part (the decoder's after its captured backward, the backbone's later)."""
+        assert self.flat is not None and not self.bucket_views
+        for k in buckets:
+            self.flat.pack_grads_span(*self._spans[k])
+            if self.active:
+                self._launch(k)
+
+    def buckets_of(self, params):
+        """indices of the buckets that hold these parameters"""
+        return sorted({self._bucket_of[id(p)] for p in params if id(p) in self._bucket_of})
 
     def reduce_phased(self):
         """The data-parallel step of a loop that parks its weight gradients (runtime.defer_weight_grads) and keeps ordinary
