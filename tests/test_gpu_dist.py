@@ -155,3 +155,68 @@ def test_two_ranks_sync_batchnorm_equals_one_big_batch():
         np.testing.assert_allclose(r[1]["y2"], r[1]["y"], rtol=0, atol=0)
         np.testing.assert_allclose(r[1]["dx2"], r[1]["dx"], rtol=0, atol=0)
         np.testing.assert_allclose(r[1]["dg2"], r[1]["dg"], rtol=0, atol=0)
+
+
+def _sp_syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from vdetr_amd import bn_act as BNA
+    from vdetr_amd import sparse_ops as S
+    from vdetr_amd.dist import init_distributed
+    torch.cuda.set_device(0)
+    init_distributed("gloo")
+    g = torch.Generator().manual_seed(9)
+    C, n0, n1 = 32, 700, 1300
+    full, res, w = (torch.randn((n0 + n1, C), generator=g) for _ in range(3))
+    sl = slice(0, n0) if rank == 0 else slice(n0, n0 + n1)
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+    x = (full[sl] * 1.5 + 0.3).cuda().requires_grad_(True)
+    r = res[sl].cuda().requires_grad_(True)
+    BNA.set_sync(True)
+    try:
+        y = S.bn_act(x, bn, "relu", r)
+        (y * w[sl].cuda()).sum().backward()
+    finally:
+        BNA.set_sync(False)
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.detach().cpu().numpy().copy() for k, v in dict(y=y, dx=x.grad, dr=r.grad, dg=bn.weight.grad, db=bn.bias.grad,
+                                                                    rm=bn.running_mean, rv=bn.running_var).items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sparse_sync_batchnorm_equals_one_big_batch():
+    """sparse_ops.bn_act (BatchNorm + residual + ReLU over site tables) with cross-replica statistics on two ranks holding
+    700 and 1300 sites == the same block on the 2000-site table in one process (fp64)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sp_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(9)
+    C, n0, n1 = 32, 700, 1300
+    full, rs, w = (torch.randn((n0 + n1, C), generator=g) for _ in range(3))
+    gamma = (torch.rand(C, generator=g) + 0.5).double().requires_grad_(True)
+    beta = torch.randn(C, generator=g).double().requires_grad_(True)
+    x = (full * 1.5 + 0.3).double().requires_grad_(True)
+    r = rs.double().requires_grad_(True)
+    rm, rv = torch.zeros(C).double(), torch.ones(C).double()
+    ref = torch.relu(torch.nn.functional.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5) + r)
+    (ref * w.double()).sum().backward()
+    cat = lambda k: np.concatenate([res[0][1][k], res[1][1][k]], 0)
+    np.testing.assert_allclose(cat("y"), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cat("dx"), x.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(cat("dr"), r.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0][1]["dg"] + res[1][1]["dg"], gamma.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(res[0][1]["db"] + res[1][1]["db"], beta.grad.numpy(), rtol=1e-4, atol=1e-4)
+    for rr in res:
+        np.testing.assert_allclose(rr[1]["rm"], rm.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rr[1]["rv"], rv.numpy(), rtol=1e-5, atol=1e-6)

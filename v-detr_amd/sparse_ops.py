@@ -520,10 +520,77 @@ class _SpBnActFn(Function):
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
+class _SpSyncBnActFn(Function):
+    """_SpBnActFn with batch statistics over all data-parallel ranks (bn_act.set_sync; the reference converts the backbone's
+    BatchNorms to SyncBatchNorm like every other, main.py:512-514).  Ranks hold different site counts: the local (mean, M2,
+    N) triples are all-gathered and merged; the normalisation itself is the fused launch (its running-statistics path, fed
+    with the global batch statistics); the backward's two sums are all-reduced between its reduction and its element pass,
+    which therefore run as tensor expressions here."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, nbt, momentum, eps, act):
+        import torch.distributed as dist
+        from . import bn_act as BNA
+        x = x.contiguous()
+        N, C = x.shape
+        grp = BNA._sync["group"]
+        var_l, mean_l = torch.var_mean(x, 0, unbiased=False)
+        loc = torch.stack((mean_l, var_l * N, torch.full_like(mean_l, float(N))))
+        world = dist.get_world_size(grp)
+        allr = torch.empty((world, 3, C), dtype=torch.float32, device=x.device)
+        dist.all_gather(list(allr.unbind(0)), loc, group=grp)
+        cnt = allr[:, 2]
+        n = cnt.sum(0)
+        mean = (allr[:, 0] * cnt).sum(0) / n
+        m2 = (allr[:, 1] + cnt * (allr[:, 0] - mean) ** 2).sum(0)
+        var = m2 / n
+        if running_mean is not None:
+            running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_(m2 / torch.clamp(n - 1.0, min=1.0), alpha=momentum)
+        if nbt is not None:
+            nbt += 1
+        lib = L.lib()
+        d = L.SpBnDesc()
+        d.N, d.C, d.act, d.training, d.eps, d.momentum = N, C, act, 0, float(eps), float(momentum)
+        y = torch.empty_like(x)
+        res = residual.contiguous() if residual is not None else None
+        mean_c, var_c = mean.contiguous(), var.contiguous()
+        d.x, d.gamma, d.beta, d.residual = x.data_ptr(), L.ptr(gamma).value, L.ptr(beta).value, L.ptr(res).value
+        d.running_mean, d.running_var, d.y = mean_c.data_ptr(), var_c.data_ptr(), y.data_ptr()
+        L.check(lib.vdetr_sp_bn_act_fwd_f32(ctypes.byref(d), L.stream_ptr()), "sp_bn_act_fwd")
+        invstd = torch.rsqrt(var + eps)
+        ctx.save_for_backward(x, gamma, y, mean_c, invstd, (1.0 / n[:1]))
+        ctx.cfg = (act, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        from . import bn_act as BNA
+        x, gamma, y, mean, invstd, inv_n = ctx.saved_tensors
+        act, has_res = ctx.cfg
+        g = dy
+        if act == 1:
+            g = dy * (y > 0)
+        elif act == 2:
+            g = dy * torch.where(y > 0, torch.ones_like(y), y + 1.0)
+        xhat = (x - mean) * invstd
+        loc = torch.stack((g.sum(0), (g * xhat).sum(0)))
+        tot = loc.clone()
+        dist.all_reduce(tot, group=BNA._sync["group"])
+        k = invstd if gamma is None else gamma * invstd
+        dx = k * (g - tot[0] * inv_n - xhat * (tot[1] * inv_n)) if ctx.needs_input_grad[0] else None
+        return dx, (loc[1] if gamma is not None else None), (loc[0] if gamma is not None else None), \
+            (g if has_res and ctx.needs_input_grad[3] else None), None, None, None, None, None, None
+
+
 def bn_act(x, bn, act=None, residual=None):
     """act(bn(x) + residual) for an ``nn.BatchNorm1d`` module over the rows of x [N, C]: one fused HIP pass on the GPU; any
     other module type (SyncBatchNorm) or a CPU tensor goes through the module itself and plain torch ops."""
-    fused = x.is_cuda and type(bn) is torch.nn.BatchNorm1d and x.shape[1] % 4 == 0 and x.shape[0] > 0 and not _NO_FUSED_BN
+    # (sp_bn.hip holds one float4 of a row per thread, 256 threads: up to 1024 channels; momentum=None is a cumulative
+    # average, which the kernels do not do: both go through the module)
+    fused = x.is_cuda and type(bn) is torch.nn.BatchNorm1d and x.shape[1] % 4 == 0 and 0 < x.shape[1] <= 1024 and x.shape[0] > 0 \
+        and not _NO_FUSED_BN and (bn.momentum is not None or not bn.training)
     if not fused:
         y = bn(x)
         if residual is not None:
@@ -531,6 +598,11 @@ def bn_act(x, bn, act=None, residual=None):
         return torch.relu(y) if act == "relu" else torch.nn.functional.elu(y) if act == "elu" else y
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
+    if training:
+        from . import bn_act as BNA
+        if BNA.sync_active():
+            return _SpSyncBnActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                                        bn.num_batches_tracked if bn.track_running_stats else None, momentum, bn.eps, _ACT[act])
     return _SpBnActFn.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
                             bn.num_batches_tracked if bn.track_running_stats else None, training, momentum, bn.eps, _ACT[act])
 
