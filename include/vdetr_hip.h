@@ -182,6 +182,12 @@ int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k,
  * probs_out / ds_out may alias scores / dprob (element-wise in place) EXCEPT when dtable is requested: the table
  * gradient kernel lets several waves re-read the inputs, so its outputs must be separate tensors.
  * With dprob == delta == ds_out == NULL only P_drop is produced (the `attn` return value, vdetr_transformer.py:758). */
+/* The forward with q, k, v stored as bf16 (BASELINE config 4: "bf16" activations; shared-KV kinds only).  QK^T and PV run
+ * on the bf16 matrix instructions; the scores, the RPE bias, the softmax, the accumulators and every output (out, lse,
+ * scores) are fp32, so the backward entry points above apply unchanged (their GEMM operands are the caller's).  Row
+ * strides of the descriptor count ELEMENTS and must be multiples of 8; q, k, v 16-byte aligned. */
+int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, const void* k, const void* v, float* out, float* lse,
+                        float* scores, void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
 size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d);
 int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, const float* dprob, const float* lse,
                               const float* delta, float* probs_out, float* ds_out, float* dtable, void* workspace,

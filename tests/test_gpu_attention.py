@@ -328,3 +328,65 @@ def test_row_strided_kv_equals_contiguous(B):
             assert torch.equal(a, b), name  # same kernel, same arithmetic, different addresses
         else:  # library GEMMs pick other tilings for other strides; the table reduction sums its partials atomically
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()), msg=name)
+
+
+@pytest.mark.parametrize("B,nQ,nK,boxes", [(1, 64, 512, True), (2, 37, 301, False), (1, 1024, 4096, True)])
+def test_bf16_attention_core_vs_oracle(B, nQ, nK, boxes):
+    """BASELINE config 4's arithmetic: q, k, v stored as bf16, QK^T / PV on the bf16 matrix instructions, everything else
+    fp32.  Against the fp64 oracle evaluated on the SAME bf16-rounded operands the remaining error is the probabilities'
+    rounding to bf16 in front of PV (2^-9 relative per term) and the fp32 accumulation: 1e-2 of the output scale forward, 2e-2
+    of the gradients' scale backward (stated tolerance for the bf16 configuration; the fp32 path keeps 1e-3)."""
+    from oracle.attention_oracle import fused_attention_reference
+    from vdetr_amd import attention as A
+    H = 4
+    g = torch.Generator().manual_seed(nQ + nK)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 9)
+    if not boxes:
+        verts[:, ::5] += 0.05 * torch.randn(verts[:, ::5].shape, generator=g)
+    q, k, v = (torch.randn(s, generator=g).bfloat16() for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g)
+    kw = dict(num_heads=H, scale=0.125, shared_kv=True, rpe=A.RPEConfig())
+    dq, dk, dv = (x.to(DEV).requires_grad_(True) for x in (q, k, v))
+    dtb = tables.to(DEV).requires_grad_(True)
+    out = A.fused_attention(dq, dk, dv, table=dtb, vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV), **kw)
+    assert out.dtype == torch.float32 and dq.dtype == torch.bfloat16
+    (out * wout.to(DEV)).sum().backward()
+    assert dq.grad.dtype == torch.bfloat16
+    rk, rv = k.double().requires_grad_(True), v.double().requires_grad_(True)
+    rtb = tables.double().requires_grad_(True)
+    routs, rdq = [], []
+    for c in range(0, nQ, 64):
+        sl = slice(c, c + 64)
+        rq = q[:, sl].double().requires_grad_(True)
+        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
+        (o * wout[:, sl].double()).sum().backward()
+        routs.append(o.detach())
+        rdq.append(rq.grad)
+    ref = [torch.cat(routs, 1), torch.cat(rdq, 1), rk.grad, rv.grad, rtb.grad]
+    got = [out.detach(), dq.grad, dk.grad, dv.grad, dtb.grad]
+    for name, r, o in zip(["out", "dq", "dk", "dv", "dtable"], ref, got):
+        scale = float(r.abs().max())
+        tol = 1e-2 if name == "out" else 2e-2
+        assert_close(o.float(), r.numpy(), tol, tol * scale, name)
+        rel = float((o.float().cpu().double() - r).norm() / r.norm())
+        assert rel < 5e-3, f"{name}: relative L2 error {rel:.2e}"
+
+
+def test_bf16_decoder_layer_close_to_fp32():
+    """set_attention_dtype(bf16) on the cross attention module: the module's output stays within 1e-2 of the fp32 module's."""
+    from vdetr_amd.vdetr_transformer import set_attention_dtype
+    g = load_golden("cross_attn_mid")
+    mod = build_cross_attention(str(g["angle_type"]), DEV)
+    ref = {k: v.detach().clone() for k, v in run_cross_attention_case(g, mod, DEV).items() if v is not None}
+    mod.zero_grad(set_to_none=True)
+    assert set_attention_dtype(mod, torch.bfloat16) == 1
+    got = run_cross_attention_case(g, mod, DEV)
+    set_attention_dtype(mod, torch.float32)
+    assert_close(got["x"], ref["x"].detach().cpu().numpy(), 2e-2, 2e-2 * float(ref["x"].abs().max()), "x")
+    # (k.bias has a mathematically ZERO gradient — a constant added to every key shifts all scores of a row alike — so
+    #  the absolute tolerance is tied to the largest parameter gradient, not to each tensor's own)
+    gmax = max(float(ref[k].abs().max()) for k in ref if k.startswith("grad_param:"))
+    for k in ref:
+        if k.startswith("grad_"):
+            r = ref[k].cpu().numpy()
+            assert_close(got[k], r, 5e-2, 3e-2 * max(np.abs(r).max(), 0.05 * gmax) + 1e-7, k)

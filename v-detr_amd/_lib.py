@@ -175,6 +175,7 @@ _SIGNATURES = {
     "vdetr_three_interpolate_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vdetr_attn_fwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
     "vdetr_attn_fwd_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_attn_fwd_bf16": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
     "vdetr_attn_bwd_scores_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_delta_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

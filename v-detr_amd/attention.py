@@ -146,24 +146,34 @@ class _FusedAttention(Function):
         B, nQ, C = q.shape
         nK = k.shape[1]
         assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
-        _check_inputs(q=q, table=table, vertices=vertices, xyz=xyz, cos_sin=cos_sin)
+        bf16 = q.dtype == torch.bfloat16  # q, k, v stored as bf16: the bf16 matrix instructions, everything else fp32
+        if bf16:
+            if kind != L.VDETR_ATTN_SHARED_KV or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16:
+                raise RuntimeError("fused_attention: the bf16 path takes bf16 q, k AND v of a shared-KV attention")
+            _check_inputs(table=table, vertices=vertices, xyz=xyz, cos_sin=cos_sin)
+            L.require_gpu(q, "q")
+            L.require_contiguous(q, "q")
+        else:
+            _check_inputs(q=q, table=table, vertices=vertices, xyz=xyz, cos_sin=cos_sin)
         for name, t in (("k", k), ("v", v)):  # row-strided views are fine (see _kv_layout)
             L.require_gpu(t, name)
-            L.require_float(t, name)
+            if not bf16:
+                L.require_float(t, name)
         ks, vs = k.stride(1), v.stride(1)
         lib = L.lib()
         use_drop = dropout_p > 0.0
         rng = rng_state if use_drop else None  # a per-step snapshot nobody writes again (begin_step)
         d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p if use_drop else 0.0, rng,
                   salt, ks, vs)
-        out = torch.empty_like(q)
+        out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         rows = (B, nQ, H) if kind == L.VDETR_ATTN_SHARED_KV else (B, H, nQ)
         lse = torch.empty(rows, dtype=torch.float32, device=q.device)
         scores = torch.empty(rows + (nK,), dtype=torch.float32, device=q.device) if need_grad else None
         nbytes = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
         ws = L.workspace(nbytes, q.device) if nbytes else None
-        L.check(lib.vdetr_attn_fwd_f32(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse),
-                                       L.ptr(scores), L.ptr(ws), nbytes, L.stream_ptr()), "attn_fwd")
+        fwd = lib.vdetr_attn_fwd_bf16 if bf16 else lib.vdetr_attn_fwd_f32
+        L.check(fwd(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse),
+                    L.ptr(scores), L.ptr(ws), nbytes, L.stream_ptr()), "attn_fwd")
         if need_grad:
             ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
             ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
@@ -173,6 +183,9 @@ class _FusedAttention(Function):
     def backward(ctx, dout):
         q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng = ctx.saved_tensors
         kind, H, scale, rpe, dropout_p, salt = ctx.cfg
+        in_dtype = q.dtype
+        if in_dtype == torch.bfloat16:  # the gradient GEMMs run in fp32 on the stored bf16 operands (1 MB each): what is
+            q, k, v = q.float(), k.float().contiguous(), v.float().contiguous()  # 67 MB per layer stays fp32 anyway
         B, nQ, C = q.shape
         nK = k.shape[1]
         lib = L.lib()
@@ -229,6 +242,8 @@ class _FusedAttention(Function):
                 dv = torch.bmm(p_r.transpose(1, 2), do_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
                 dk = torch.bmm(ds_r.transpose(1, 2), q_r).view(B, H, nK, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nK, C)
                 dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
+        if in_dtype == torch.bfloat16:
+            dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
         return (dq, dk, dv, dtable) + (None,) * 12
 
 
@@ -236,7 +251,8 @@ def _kv_layout(t, B, nK):
     """K / V as the kernel can read them: rows of contiguous floats at a constant row stride (a multiple of 4 floats,
     16-B aligned base, batches nK rows apart) — e.g. a 64-wide column block of a wider projection output.  Anything
     else is made contiguous."""
-    ok = (t.dim() == 3 and t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(1) >= t.shape[2] and
+    mult = 8 if t.dtype == torch.bfloat16 else 4
+    ok = (t.dim() == 3 and t.stride(2) == 1 and t.stride(1) % mult == 0 and t.stride(1) >= t.shape[2] and
           t.data_ptr() % 16 == 0 and (B == 1 or t.stride(0) == nK * t.stride(1)))
     return t if ok else t.contiguous()
 

@@ -29,8 +29,17 @@ constexpr int kPPad = 20;  // floats per row of the P transpose pad (16 + 4: kee
 // BOX (RPE only): this instantiation handles the workgroups whose four queries are axis-aligned boxes (6 axis taps per
 // pair, attn_common.h), the BOX = false one all the others; both are launched over the same grid and a workgroup exits
 // at once when it belongs to the other kind (the two paths in one kernel needed > 256 VGPRs).
-template <bool PERHEAD, bool RPE, bool BOX = false>
+// BF16 (shared-KV kinds): q, k, v are bf16 in memory and QK^T / PV run on the bf16 matrix instructions
+// (v_mfma_f32_16x16x32_bf16: one instruction per 32 of the 64 head dims; v_mfma_f32_16x16x16_bf16 for the 16 keys of a
+// tile); scores, RPE bias, softmax, accumulators and the output stay fp32 (BASELINE config 4).  Same tiling, same lane
+// layouts: the operand of lane (row/col = lane & 15, k-group = lane >> 4) is 8 (resp. 4) consecutive k instead of one.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+template <bool PERHEAD, bool RPE, bool BOX = false, bool BF16 = false>
 __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
+  static_assert(!(BF16 && PERHEAD), "the bf16 path is built for the shared-KV kinds");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   attn_load_rng(P);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -63,16 +72,22 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   if (RPE) rpe_stage_table(P, tab, tid, kFwdThreads);
 
   // ---- A operand of QK^T: row i = c ---------------------------------------------------------------
-  float qa[16];
+  float qa[BF16 ? 1 : 16];
+  bf16x8 qa8[2];
   {
     const int qi = PERHEAD ? min(q0 + c, nQ - 1) : min(q0 + (c >> 2), nQ - 1);
     const int hoff = PERHEAD ? head * kDh : (c & 3) * kDh;
-    const f32x4* src = reinterpret_cast<const f32x4*>(P.q + ((size_t)b * nQ + qi) * qstride + hoff + 16 * g);
+    if (BF16) {  // 16 bf16 of the row: d = 16 g + 8 m + e for instruction m; the scale goes onto the fp32 scores
+      const bf16x8* src = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.q) + ((size_t)b * nQ + qi) * qstride + hoff + 16 * g);
+      qa8[0] = src[0]; qa8[1] = src[1];
+    } else {
+      const f32x4* src = reinterpret_cast<const f32x4*>(P.q + ((size_t)b * nQ + qi) * qstride + hoff + 16 * g);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const f32x4 v = src[s4];
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 v = src[s4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
+        for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
+      }
     }
   }
   // query index of accumulator register r
@@ -95,19 +110,31 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   // use every tile step exposed 2-3 full memory latencies (vmcnt is in-order on gfx950, so a V load also waits
   // for the score stores issued before it).
   struct TileOps {
-    f32x4 kb[4], vb[4];
+    f32x4 kb[BF16 ? 1 : 4], vb[BF16 ? 1 : 4];
+    bf16x8 kb8[2];
+    bf16x4 vb4[4];
     float kx, ky, kz;
   };
   auto fetch = [&](int tile, TileOps& t) {
     const int key0 = tile << 4;
     const int keyc = min(key0 + c, nK - 1);
-    const f32x4* kp = reinterpret_cast<const f32x4*>(P.k + ((size_t)b * nK + keyc) * P.k_stride + kvoff + 16 * g);
+    if (BF16) {
+      const bf16x8* kp = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.k) + ((size_t)b * nK + keyc) * P.k_stride + kvoff + 16 * g);
+      t.kb8[0] = kp[0]; t.kb8[1] = kp[1];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
+      for (int s = 0; s < 4; ++s) {
+        const int kk = min(key0 + 4 * g + s, nK - 1);
+        t.vb4[s] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(P.v) + ((size_t)b * nK + kk) * P.v_stride + kvoff + 4 * c);
+      }
+    } else {
+      const f32x4* kp = reinterpret_cast<const f32x4*>(P.k + ((size_t)b * nK + keyc) * P.k_stride + kvoff + 16 * g);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int kk = min(key0 + 4 * g + s, nK - 1);
-      t.vb[s] = *reinterpret_cast<const f32x4*>(P.v + ((size_t)b * nK + kk) * P.v_stride + kvoff + 4 * c);
+      for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = min(key0 + 4 * g + s, nK - 1);
+        t.vb[s] = *reinterpret_cast<const f32x4*>(P.v + ((size_t)b * nK + kk) * P.v_stride + kvoff + 4 * c);
+      }
     }
     if (RPE) {
       const float* xp = P.xyz + ((size_t)b * nK + keyc) * 3;
@@ -125,9 +152,15 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
     if (tile + kFwdWaves < tile_end) fetch(tile + kFwdWaves, nxt);
     // ---- S = Q K^T --------------------------------------------------------------------------------
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (BF16) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa8[0], ops.kb8[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa8[1], ops.kb8[1], acc, 0, 0, 0);
+      acc *= P.scale;
+    } else {
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
+      for (int s = 0; s < 16; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
+    }
     float sc[4] = {acc[0], acc[1], acc[2], acc[3]};
     // ---- + RPE bias -------------------------------------------------------------------------------
     if (RPE) {
@@ -193,10 +226,19 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
     const f32x4 pa = *reinterpret_cast<const f32x4*>(ppad + c * kPPad + 4 * g);
     __builtin_amdgcn_wave_barrier();
     // ---- O += P V ------------------------------------------------------------------------------------
+    if (BF16) {
+      const bf16x4 pb = {(__bf16)pa[0], (__bf16)pa[1], (__bf16)pa[2], (__bf16)pa[3]};  // P[row c][keys 4g..4g+3]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        const bf16x4 vt = {ops.vb4[0][t], ops.vb4[1][t], ops.vb4[2][t], ops.vb4[3][t]};  // V[keys 4g..4g+3][d = 4c + t]
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, pb), __builtin_bit_cast(short4v, vt), o[t], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], ops.vb[s][t], o[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], ops.vb[s][t], o[t], 0, 0, 0);
+    }
     ops = nxt;
   }
 
@@ -453,6 +495,59 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
     }
   }
   if (int e = check_launch("attn_fwd")) return e;
+  if (ks > 1) {
+    const size_t elems = (size_t)d->B * d->nQ * d->H * kDh;
+    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, P);
+    return check_launch("attn_fwd_combine");
+  }
+  return VDETR_OK;
+}
+
+// q, k, v bf16 (k_row_stride / v_row_stride in ELEMENTS, multiples of 8: 16-B aligned operand loads); out, lse, scores fp32
+extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, const void* k, const void* v, float* out, float* lse,
+                                   float* scores, void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+  AttnParams P;
+  if (int e = attn_fill_params(d, &P, "attn_fwd_bf16")) return e;
+  VDETR_REQUIRE(d->kind == VDETR_ATTN_SHARED_KV, "attn_fwd_bf16: built for the shared-KV kinds");
+  VDETR_REQUIRE(q && k && v && out && lse, "attn_fwd_bf16: null pointer");
+  VDETR_REQUIRE(P.k_stride % 8 == 0 && P.v_stride % 8 == 0, "attn_fwd_bf16: K / V row strides %d / %d must be multiples of 8", P.k_stride, P.v_stride);
+  VDETR_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "attn_fwd_bf16: operands must be 16-B aligned");
+  P.q = (const float*)q; P.k = (const float*)k; P.v = (const float*)v; P.out = out; P.lse = lse; P.scores = scores;
+  const bool rpe = d->table != nullptr;
+  const int ks = choose_ksplit(d);
+  if (ks > 1) {
+    const size_t need = vdetr_attn_fwd_workspace_bytes(d);
+    if (!workspace || workspace_bytes < need) {
+      set_error("attn_fwd_bf16: workspace %zu B < required %zu B", workspace_bytes, need);
+      return VDETR_ERR_WORKSPACE;
+    }
+    const size_t rows = (size_t)d->B * d->nQ * d->H;
+    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    P.part_o = (float*)base;
+    P.part_lse = P.part_o + (size_t)ks * rows * kDh;
+    P.ksplit = ks;
+    P.tiles_per_split = ((d->nK + 15) / 16 + ks - 1) / ks;
+  }
+  const size_t lds_table = rpe ? (size_t)kRpeVerts * P.T * P.T * P.T * 16 : 0;
+  const size_t lds = lds_table + (size_t)kFwdWaves * 16 * kPPad * 4 > (size_t)kFwdWaves * kWave * 24 * 4
+                         ? lds_table + (size_t)kFwdWaves * 16 * kPPad * 4
+                         : (size_t)kFwdWaves * kWave * 24 * 4;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((d->nQ + 3) / 4, ks, d->B);
+  if (rpe) {
+    static const int box_env = [] { const char* e = getenv("VDETR_FWD_BOX"); return e ? atoi(e) : 1; }();
+    P.box_path = box_env && !d->cos_sin;
+    if (int e = set_lds(attn_fwd_kernel<false, true, false, true>, lds, "attn_fwd_bf16")) return e;
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true>), grid, dim3(kFwdThreads), lds, st, P);
+    if (P.box_path) {
+      if (int e = set_lds(attn_fwd_kernel<false, true, true, true>, lds, "attn_fwd_bf16")) return e;
+      hipLaunchKernelGGL((attn_fwd_kernel<false, true, true, true>), grid, dim3(kFwdThreads), lds, st, P);
+    }
+  } else {
+    if (int e = set_lds(attn_fwd_kernel<false, false, false, true>, lds, "attn_fwd_bf16")) return e;
+    hipLaunchKernelGGL((attn_fwd_kernel<false, false, false, true>), grid, dim3(kFwdThreads), lds, st, P);
+  }
+  if (int e = check_launch("attn_fwd_bf16")) return e;
   if (ks > 1) {
     const size_t elems = (size_t)d->B * d->nQ * d->H * kDh;
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, P);

@@ -114,6 +114,17 @@ def rotz_batch_tensor(t):
 # =====================================================================================================
 # attention modules
 # =====================================================================================================
+def set_attention_dtype(module, dtype):
+    """storage type of q / k / v in every 3DV-RPE cross attention under `module` (torch.float32 | torch.bfloat16)"""
+    assert dtype in (torch.float32, torch.bfloat16)
+    n = 0
+    for m in module.modules():
+        if isinstance(m, GlobalShareCrossAttention):
+            m.core_dtype = dtype
+            n += 1
+    return n
+
+
 class GlobalShareCrossAttention(nn.Module):
     """3D-vertex-RPE cross attention (reference :656-758).
 
@@ -154,6 +165,9 @@ class GlobalShareCrossAttention(nn.Module):
         self.rpe_cfg = A.RPEConfig(num_points, self.log_scale, max_value)
         self.return_attn = False
         self.defer_proj_drop = False
+        # storage type of the projected q / k / v handed to the attention core: torch.bfloat16 = BASELINE config 4 (the bf16
+        # matrix instructions for QK^T / PV; scores, RPE, softmax, accumulators, output fp32); set_attention_dtype() below
+        self.core_dtype = torch.float32
         self._salt = next(_salt_counter)
 
     def __deepcopy__(self, memo):
@@ -189,6 +203,8 @@ class GlobalShareCrossAttention(nn.Module):
         w = cat_params([t for m in mods for t in (m.k.weight, m.v.weight)])
         b = cat_params([t for m in mods for t in (m.k.bias, m.v.bias)]) if mods[0].k.bias is not None else None
         kv = linear(key_b, w, b)                                                   # [B,nK,n*128]
+        if mods[0].core_dtype != torch.float32 and kv.is_cuda:
+            kv = kv.to(mods[0].core_dtype)  # one cast for the K / V of every layer
         parts = kv.view(kv.shape[0], kv.shape[1], 2 * n, -1).unbind(2)
         mlps = [mm for m in mods for mm in m.cpb_mlps]
         w1 = stack_params([mm[0].weight for mm in mlps])
@@ -219,12 +235,15 @@ class GlobalShareCrossAttention(nn.Module):
         if p > 0 and rng is None:
             rng = A.begin_step(q.device)
         tables = self.rpe_tables() if cache is None else cache[2]
+        q32, k32 = q, k
+        if self.core_dtype != torch.float32 and q.is_cuda:
+            q, k, v = (t if t.dtype == self.core_dtype else t.to(self.core_dtype) for t in (q, k, v))
         x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, table=tables,
                               rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
                               attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt)
         attn = None
         if self.return_attn:
-            attn = A.attention_probabilities(q, k, num_heads=self.num_heads, scale=self.scale, shared_kv=True,
+            attn = A.attention_probabilities(q32.float(), k32.float(), num_heads=self.num_heads, scale=self.scale, shared_kv=True,
                                              table=tables, rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz,
                                              cos_sin=cos_sin, attn_mask=attn_mask, dropout_p=p, rng_state=rng,
                                              salt=self._salt)
