@@ -150,10 +150,10 @@ typedef struct vdetr_attn_desc {
          (vdetr_transformer.py:733-735 runs self.k / self.v per layer on the same `key`). --- */
   int32_t k_row_stride, v_row_stride;
   /* --- backward only: EIGHT zero-initialised device words {max |dO row|^2, max |V row|^2, query counters of the two
-         vertex halves, number of queries whose RPE vertices are not an axis-aligned box, 3 spare}.
-         vdetr_attn_delta_f32 fills words 0, 1 and 4, vdetr_attn_bwd_scores_f32 then distributes the queries dynamically
+         vertex halves, number of queries whose RPE vertices are not an axis-aligned box, "word 4 was filled" flag, 2 spare}.
+         vdetr_attn_delta_f32 fills words 0, 1, 4 and 5 (4 and 5 only when the descriptor carries the RPE operands), vdetr_attn_bwd_scores_f32 then distributes the queries dynamically
          over its workgroups (a CU busy with other work costs 1/8 of a round, not a whole one), takes the fixed-point
-         scale from the Cauchy-Schwarz bound and, when word 4 is 0 (and there is no rotation operand), runs the
+         scale from the Cauchy-Schwarz bound and, when word 4 is 0 and word 5 is set (and there is no rotation operand), runs the
          axis-aligned-box kernel (attn_bwd_box.hip) instead of the general one.  NULL: static distribution. --- */
   uint32_t* bwd_aux;
 } vdetr_attn_desc;

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
   constexpr int kSplit = kRpeVerts / VERTS;  // workgroups per query
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [dTable copy VERTS*T^3*4][strips]
   // every query is an axis-aligned box (count of the others left by the delta launch): attn_bwd_box_kernel does this launch
-  if (P.box_path && P.bwd_aux[4] == 0) return;
+  if (P.box_path && P.bwd_aux[4] == 0 && P.bwd_aux[5] != 0) return;  // (word 5: the delta launch did look at the vertices)
   attn_load_rng(P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -657,6 +657,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
         if (aux) n2max = fmaxf(n2max, wave_allsum_f32(g * g));
         if (lane == 0) delta[perhead ? ((size_t)b * H + h) * nQ + q : (size_t)row * H + h] = s;
       }
+      if (aux && vertices && row == 0 && lane == 0) aux[5] = 1u;  // "word 4 is meaningful": without it the box kernels stay off
       if (aux && vertices) {  // aux[4] += 1 for a query whose 8 RPE vertices are not an axis-aligned box (attn_common.h)
         const float* vp = vertices + (size_t)row * 24;
         const int i = lane & 7;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBoxWaves * kWave) void attn_bwd_box_kernel(AttnPar
   constexpr int kBoxThreads = kBoxWaves * kWave;
   constexpr int T = kBoxT, TT = T * T, T3 = TT * T;
   constexpr int table_words = 4 * T3 * 4;  // 4 vertex tables x cells x heads
-  if (P.bwd_aux[4] != 0) return;            // a query is not an axis-aligned box: the general kernel runs instead
+  if (P.bwd_aux[4] != 0 || P.bwd_aux[5] == 0) return;            // a query is not an axis-aligned box: the general kernel runs instead
   extern __shared__ __attribute__((aligned(16))) float smem[];
   attn_load_rng(P);
   int* tab = reinterpret_cast<int*>(smem);

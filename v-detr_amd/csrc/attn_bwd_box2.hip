@@ -39,7 +39,7 @@ size_t attn_bwd_box2_lds_bytes() { return (size_t)4 * kB2T * kB2T * kB2T * 4 * 4
 __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P) {
   constexpr int T = kB2T, TT = T * T, T3 = TT * T;
   constexpr int table_words = 4 * T3 * 4;
-  if (P.bwd_aux[4] != 0) return;  // a query is not an axis-aligned box: the general kernel runs instead
+  if (P.bwd_aux[4] != 0 || P.bwd_aux[5] == 0) return;  // a query is not an axis-aligned box: the general kernel runs instead
   extern __shared__ __attribute__((aligned(16))) float smem[];
   attn_load_rng(P);
   int* tab = reinterpret_cast<int*>(smem);

@@ -20,6 +20,7 @@
 // the whole chip.
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 #include "common.h"
 
 namespace vdetr {
@@ -661,12 +662,22 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
     static const int persistent = getenv("VDETR_SP_PERSISTENT") ? atoi(getenv("VDETR_SP_PERSISTENT")) : 2;
     const int ksub = persistent == 2 && CA % 64 == 0 ? 2 : 1;
     if (persistent && CA % 32 == 0) {
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      // per-device state (CU count, work-counter ring), created under a lock on the device's first launch: a process may
+      // drive several GPUs from several threads
+      struct DevState { int cus = 0; int* ring = nullptr; std::atomic<unsigned> next{0}; };
+      static DevState devs[64];
+      static std::mutex dev_mu;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+      DevState& D = devs[dev];
+      if (!D.cus) {
+        std::lock_guard<std::mutex> lock(dev_mu);
+        if (!D.cus) {
+          hipDeviceProp_t prop;
+          D.cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        }
       }
+      const int cus = D.cus;
       const int per_cu = ksub == 2 ? 1 : 2;
       const int nwork = ntiles * ceil_div(CB, 128);
       // `spare` CUs are left to whatever else is running (A/B switch): with a grid of exactly one workgroup per CU, a CU that is
@@ -679,17 +690,25 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
       int* ticket = nullptr;
       static const int use_ticket = getenv("VDETR_SP_TICKET") ? atoi(getenv("VDETR_SP_TICKET")) : 1;  // A/B switch
       if (use_ticket) {  // a (work counter, exit counter) pair per launch out of a ring: launches of different streams may overlap
-        static int* ring = nullptr;
-        static std::atomic<unsigned> ring_next{0};
         constexpr unsigned kRing = 4096;
-        if (!ring) {  // zeroed once; every launch leaves its pair zeroed again (the kernel's last workgroup resets it)
-          if (hipMalloc(&ring, 2 * kRing * sizeof(int)) != hipSuccess || hipMemset(ring, 0, 2 * kRing * sizeof(int)) != hipSuccess) {
-            set_error("sp_pairs_gemm: cannot allocate the work counters");
-            ring = nullptr;
-            return VDETR_ERR_LAUNCH;
+        if (!D.ring) {  // zeroed once; every launch leaves its pair zeroed again (the kernel's last workgroup resets it)
+          std::lock_guard<std::mutex> lock(dev_mu);
+          if (!D.ring) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+              set_error("sp_pairs_gemm: the first launch on a device allocates its work counters and cannot be captured into a "
+                        "hipGraph: run the layer once eagerly first");
+              return VDETR_ERR_LAUNCH;
+            }
+            int* r = nullptr;
+            if (hipMalloc(&r, 2 * kRing * sizeof(int)) != hipSuccess || hipMemset(r, 0, 2 * kRing * sizeof(int)) != hipSuccess) {
+              set_error("sp_pairs_gemm: cannot allocate the work counters");
+              return VDETR_ERR_LAUNCH;
+            }
+            D.ring = r;
           }
         }
-        ticket = ring + 2 * (ring_next.fetch_add(1) % kRing);
+        ticket = D.ring + 2 * (D.next.fetch_add(1) % kRing);
       }
       hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, x, arow, w, tiles, ntiles, CA, CB, cin * cout, y, ticket);
       return check_launch("sp_pairs_gemm");
