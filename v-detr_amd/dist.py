@@ -158,8 +158,11 @@ class FlatParams:
         dev = self.grad.device
         return {"static": tab, "block_entry": torch.tensor(be, dtype=torch.int32, device=dev),
                       "block_chunk": torch.tensor(bc, dtype=torch.int32, device=dev), "nblocks": len(be),
-                      "dev": torch.empty((n, 3), dtype=torch.int64, device=dev), "host": tab.clone().pin_memory(),
-                      "event": None, "captured": [],
+                      "dev": torch.empty((n, 3), dtype=torch.int64, device=dev),
+                      # eager launches: a ring of pinned tables, so that the host only waits for the upload of THREE steps ago
+                      # (one table = the launching thread can never be more than one step ahead of the device)
+                      "hosts": [tab.clone().pin_memory() for _ in range(3)], "events": [None, None, None], "tick": 0,
+                      "captured": [],
                       # pinned tables for hipGraph captures, allocated up front (no host allocation while capturing)
                       "spare": [tab.clone().pin_memory() for _ in range(4)]}
 
@@ -180,9 +183,11 @@ class FlatParams:
             host = P["spare"].pop()
             P["captured"].append(host)
         else:
-            host = P["host"]
-            if P["event"] is not None:
-                P["event"].synchronize()  # the previous upload has left the pinned table
+            slot = P["tick"] % 3
+            P["tick"] += 1
+            host = P["hosts"][slot]
+            if P["events"][slot] is not None:
+                P["events"][slot].synchronize()  # the upload that last used this pinned table has left it
         keep, ptrs = [], []
         for g in src:
             if g is None:
@@ -197,8 +202,8 @@ class FlatParams:
         L.check(L.lib().vdetr_pack_f32(L.ptr(P["dev"]), L.ptr(P["block_entry"]), L.ptr(P["block_chunk"]), P["nblocks"],
                                        L.ptr(self.grad), L.stream_ptr()), "pack")
         if not capturing:
-            P["event"] = torch.cuda.Event()
-            P["event"].record()
+            P["events"][slot] = torch.cuda.Event()
+            P["events"][slot].record()
         for g in keep:
             g.record_stream(torch.cuda.current_stream())
 
