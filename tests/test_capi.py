@@ -44,7 +44,8 @@ def test_argument_errors_do_not_exit():
     assert b"negative" in lib.vdetr_last_error()
     assert lib.vdetr_furthest_point_sampling_f32(None, 1, 0, 4, None, None, 0, None) == 1
     assert lib.vdetr_furthest_point_sampling_f32(None, 1, 10, 0, None, None, 0, None) == 0  # m <= 0: no-op
-    assert 40000 * 20 + 256 <= lib.vdetr_fps_workspace_bytes(1, 40000) <= 40128 * 20 + 256  # + the bucket padding
+    # the sorted cloud in 64-slot segments of tree-leaf buckets: at most 2 ceil(n / 64) + 64 of them
+    assert 40000 * 20 + 256 <= lib.vdetr_fps_workspace_bytes(1, 40000) <= (2 * 625 + 64) * 64 * 20 + 256
     d = _lib.AttnDesc()
     d.kind, d.B, d.H, d.nQ, d.nK = 0, 1, 3, 4, 4
     assert lib.vdetr_attn_fwd_f32(ctypes.byref(d), None, None, None, None, None, None, None, 0, None) == 1

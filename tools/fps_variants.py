@@ -63,13 +63,15 @@ def main():
     variants = [("v2", {"VDETR_FPS_IMPL": "2"})]
     for wv in (16, 8, 4):
         variants.append((f"rows W={wv}", {"VDETR_FPS_WAVES": str(wv)}))
+    for tr in (0, 2):
+        variants.append((f"rows tree={tr}", {"VDETR_FPS_TREE": str(tr)}))
     variants.append(("default", {}))
     if "--only" in sys.argv:
         keep = sys.argv[sys.argv.index("--only") + 1].split(";")
         variants = [v for v in variants if v[0] in keep]
     for name, env in variants:
         e = dict(os.environ)
-        for k in ("VDETR_FPS_IMPL", "VDETR_FPS_WAVES", "VDETR_FPS_DEBUG"):
+        for k in ("VDETR_FPS_IMPL", "VDETR_FPS_WAVES", "VDETR_FPS_DEBUG", "VDETR_FPS_TREE"):
             e.pop(k, None)
         e.update(env)
         if debug:

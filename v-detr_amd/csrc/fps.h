@@ -39,7 +39,7 @@ struct RowsScene {
   const float* xyz;  // (n,3)
   int32_t* idx;      // (m)
   long ws_off;       // first workspace element (point) of this scene
-  int n, nbuckets, ref_block, ref_log2;
+  int n, cap_buckets, ref_block, ref_log2;  // cap_buckets: 64-slot segments this scene owns in the workspace
 };
 
 struct RowsParams {
@@ -56,8 +56,16 @@ struct RowsPlan {  // geometry chosen on the host for one launch
 
 // false: the cloud is too large for the row kernel (the caller uses fps.hip's kernel)
 bool fps_rows_plan(int nmax, RowsPlan* plan);
-inline long fps_rows_npad(int n, const RowsPlan& pl) { return ((long)n + pl.bucket_pts - 1) / pl.bucket_pts * pl.bucket_pts; }
-// launches one workgroup per scene; P.scenes[0..b) filled by the caller except nbuckets
+// Buckets of a scene: leaves of the Z-curve's binary tree with <= 64 points take up to ~1.65 n / 64 segments of 64
+// slots on uniform clouds; the workspace holds 2 n / 64 + 64 (capped by what the owner lanes can hold), and a cloud that
+// needs more falls back to plain runs of 64 sorted points (n / 64 segments) inside the kernel.
+inline long fps_rows_cap(int n, int waves = 16) {
+  const long runs = ((long)n + 63) / 64, most = (long)kRowsSlots * 64 * waves;
+  const long want = 2 * runs + 64;
+  return want < most ? want : (runs > most ? runs : most);
+}
+inline long fps_rows_npad(int n, const RowsPlan& pl) { return fps_rows_cap(n, pl.waves) * pl.bucket_pts; }
+// launches one workgroup per scene; P.scenes[0..b) filled by the caller except cap_buckets
 int fps_rows_launch(RowsParams& P, int b, const RowsPlan& plan, hipStream_t stream);
 
 }  // namespace vdetr

@@ -369,7 +369,7 @@ static int ref_log2_of(int n) { return fps_ref_log2_of(n); }
 static size_t ws_points(int n) {
   int npad, bp, nb;
   fps_geometry(n, &npad, &bp, &nb);
-  const size_t rows = n > 0 ? (size_t)n + kWave : 0;  // fps_rows.hip pads to a multiple of 16/32/64
+  const size_t rows = n > 0 ? (size_t)fps_rows_cap(n) * 64 : 0;  // fps_rows.hip: 64-slot segments of its tree-leaf buckets
   return rows > (size_t)npad ? rows : (size_t)npad;
 }
 

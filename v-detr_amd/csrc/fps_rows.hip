@@ -34,9 +34,9 @@
 
 namespace vdetr {
 
-constexpr int kRowsCellBits = 15;
+constexpr int kRowsCellBits = 14;
 constexpr int kRowsCells = 1 << kRowsCellBits;
-constexpr int kRowsHistWords = kRowsCells + (kRowsCells >> 5);  // one pad word per 32 cells
+constexpr int kRowsHistWords = kRowsCells + (kRowsCells >> 5) + 4;  // one pad word per 32 cells + the end sentinel
 __device__ __forceinline__ int hidx(int c) { return c + (c >> 5); }
 
 template <int BP>
@@ -92,7 +92,8 @@ template <int W, int NS, bool DEBUG>
 __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   constexpr int T = W * kWave;
   extern __shared__ __align__(16) unsigned char smem[];
-  int* const s_hist = reinterpret_cast<int*>(smem);        // prologue
+  int* const s_hist = reinterpret_cast<int*>(smem);        // prologue: cell starts, then per-leaf fill counters
+  int* const s_leaf = s_hist + kRowsHistWords;             // prologue: slot offset and first bucket of the cell's tree leaf
   float4* const s_cand = reinterpret_cast<float4*>(smem);  // rounds: (x,y,z,key) of every bucket's max
   __shared__ int s_wsum[W];
   __shared__ float s_red[W][6];
@@ -105,7 +106,8 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   int32_t* __restrict__ out = S.idx;
   float4* __restrict__ pts = Pin.pts + S.ws_off;
   uint32_t* __restrict__ keys = Pin.keys + S.ws_off;
-  const int n = S.n, nb = S.nbuckets, npad = nb * kBP, m = Pin.m;
+  const int n = S.n, m = Pin.m;
+  int nb = 0;  // buckets of this scene: decided in prologue 2
   const unsigned rb = (unsigned)S.ref_block;
 
   // ---- prologue 1: bounding box of the cloud, the split sequence of the cell grid ------------------------------
@@ -167,8 +169,9 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
   // ---- prologue 2: histogram, exclusive scan, scatter ------------------------------------------------------------
   for (int k = tid; k < n; k += T) atomicAdd(&s_hist[hidx(cell_of(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2]))], 1);
   __syncthreads();
+  constexpr int kPer = kRowsCells / T;  // consecutive cells per thread
+  __shared__ int s_total;
   {
-    constexpr int kPer = kRowsCells / T;  // consecutive cells per thread
     int sum = 0;
     for (int i = 0; i < kPer; ++i) sum += s_hist[hidx(tid * kPer + i)];
     int incl = sum;
@@ -187,22 +190,95 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
       s_hist[hidx(tid * kPer + i)] = run;
       run += v;
     }
+    if (tid == T - 1) s_hist[hidx(kRowsCells)] = run;  // = n: the end sentinel of the prefix
+  }
+  __syncthreads();
+  // ---- buckets = leaves of the Z-curve's binary tree ------------------------------------------------------------------
+  // A run of 64 consecutive sorted points straddles octant boundaries of the curve at random, and its box is then far
+  // larger than its points' share of space; a tree node is an aligned box.  On the host model (tools/fps_model.py, 40k
+  // points): 8.5 instead of 14.0 surviving buckets per round, 1.5 instead of 2.3 on the busiest wave.
+  // The leaf of cell c is the shallowest node [c & ~(size-1), +size), size = 2^(bits-d), that holds <= 64 K points; it
+  // takes ceil(count / 64) buckets, filled in cell order.  K = 1 costs ~1.6x the buckets of plain runs; the first of
+  // K = 1, 2, 4, 8 whose buckets fit the owner lanes' slots (cap_buckets) is used, plain runs (K = inf) otherwise.
+  // s_leaf[c] = (first slot of the leaf - first sorted position of the leaf) << 13 | first bucket of the leaf (at its head)
+  auto head_of = [&](int c, int limit, int& cnt) -> int {
+    int dlo = 0, dhi = kRowsCellBits;
+    while (dlo < dhi) {
+      const int mid = (dlo + dhi) >> 1, size = 1 << (kRowsCellBits - mid), st = c & ~(size - 1);
+      if (s_hist[hidx(st + size)] - s_hist[hidx(st)] <= limit) dhi = mid; else dlo = mid + 1;
+    }
+    const int size = 1 << (kRowsCellBits - dlo), head = c & ~(size - 1);
+    cnt = s_hist[hidx(head + size)] - s_hist[hidx(head)];
+    return head;
+  };
+  bool tree = false;
+  int limit = kBP;
+  for (int ks = 0; ks < 4 && S.cap_buckets > 0; ++ks, limit *= 2) {
+    int sum = 0;
+    for (int i = 0; i < kPer; ++i) {
+      const int c = tid * kPer + i;
+      int cnt;
+      const int head = head_of(c, limit, cnt);
+      const int nbk = c == head ? (cnt + kBP - 1) / kBP : 0;
+      s_leaf[c] = nbk;
+      sum += nbk;
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    __syncthreads();  // s_wsum and s_total of the pass before have been read by everybody
+    if (lane == kWave - 1) s_wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int ww = 0; ww < w; ++ww) base += s_wsum[ww];
+    int run = base + incl - sum;
+    for (int i = 0; i < kPer; ++i) {
+      const int c = tid * kPer + i;
+      const int v = s_leaf[c];
+      s_leaf[c] = min(run, 8191);
+      run += v;
+    }
+    if (tid == T - 1) s_total = run;
+    __syncthreads();
+    if (s_total <= S.cap_buckets) { tree = true; break; }
+  }
+  const float p0x = xyz[0], p0y = xyz[1], p0z = xyz[2];
+  nb = tree ? s_total : (n + kBP - 1) / kBP;
+  const int npad = nb * kBP;
+  if (tree) {
+    for (int i = 0; i < kPer; ++i) {
+      const int c = tid * kPer + i;
+      int cnt;
+      const int head = head_of(c, limit, cnt);
+      const int delta = (s_leaf[head] & 8191) * kBP - s_hist[hidx(head)];  // >= 0: the leaves before hold all the points before
+      s_leaf[c] |= (int)((unsigned)delta << 13);  // (readers of this word want its low 13 bits only: unchanged)
+    }
+    // every slot starts as padding (rank 0: never a candidate)
+    for (int k = tid; k < npad; k += T) {
+      pts[k] = make_float4(p0x, p0y, p0z, -INFINITY);
+      keys[k] = 0xFFFFFFFFu;
+    }
+  } else {
+    for (int c = tid; c < kRowsCells; c += T) s_leaf[c] = 0;
+    for (int k = n + tid; k < npad; k += T) {
+      pts[k] = make_float4(p0x, p0y, p0z, -INFINITY);
+      keys[k] = 0xFFFFFFFFu;
+    }
   }
   __syncthreads();
   for (int k = tid; k < n; k += T) {
     const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-    const int pos = atomicAdd(&s_hist[hidx(cell_of(x, y, z))], 1);
+    const int cell = cell_of(x, y, z);
+    const int pos = atomicAdd(&s_hist[hidx(cell)], 1) + (int)((unsigned)s_leaf[cell] >> 13);
     // origin-skip rule: `if (mag <= 1e-3) continue;` compares the float mag against a DOUBLE literal
     // (sampling_gpu.cu:103-104); mag in the same contraction order as the distance.
     const float mag = __fmaf_rn(z, z, __fmaf_rn(x, x, __fmul_rn(y, y)));
     const bool skip = (double)mag <= 1e-3;
     pts[pos] = make_float4(x, y, z, skip ? -INFINITY : 1e10f);
     keys[pos] = fps_tie_key((unsigned)k, rb, S.ref_log2);
-  }
-  const float p0x = xyz[0], p0y = xyz[1], p0z = xyz[2];
-  for (int k = n + tid; k < npad; k += T) {
-    pts[k] = make_float4(p0x, p0y, p0z, -INFINITY);
-    keys[k] = 0xFFFFFFFFu;
   }
   __syncthreads();  // the sorted cloud is visible to every wave; s_hist is dead, s_cand may be written
 
@@ -478,14 +554,29 @@ static int launch_rows(RowsParams& P, int b, size_t lds, bool debug, hipStream_t
 
 int fps_rows_launch(RowsParams& P, int b, const RowsPlan& pl, hipStream_t stream) {
   static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
-  int nbmax = 0;
+  // VDETR_FPS_TREE: 0 = runs of 64 sorted points always; 1 (default) = tree leaves in the slots the runs need (a
+  // second slot per owner lane costs more in the box test than the tighter boxes win: 4.92 vs 4.28 ms at 40k points);
+  // 2 = room for 2 n / 64 + 64 leaves
+  static const int env_tree = getenv("VDETR_FPS_TREE") ? atoi(getenv("VDETR_FPS_TREE")) : 1;
+  long capmax = 0, runmax = 0;
   for (int i = 0; i < b; ++i) {
-    P.scenes[i].nbuckets = (int)(((long)P.scenes[i].n + kBP - 1) / kBP);
-    nbmax = nbmax > P.scenes[i].nbuckets ? nbmax : P.scenes[i].nbuckets;
+    const long runs = ((long)P.scenes[i].n + kBP - 1) / kBP;
+    runmax = runmax > runs ? runmax : runs;
   }
-  size_t lds = (size_t)kRowsHistWords * sizeof(int);
-  if ((size_t)nbmax * sizeof(float4) > lds) lds = (size_t)nbmax * sizeof(float4);
-  const int ns = (nbmax + pl.waves * kWave - 1) / (pl.waves * kWave);
+  const long per_slot = (long)pl.waves * kWave;
+  const long run_slots = (runmax + per_slot - 1) / per_slot * per_slot;
+  for (int i = 0; i < b; ++i) {
+    const long runs = ((long)P.scenes[i].n + kBP - 1) / kBP;
+    long cap = fps_rows_cap(P.scenes[i].n, pl.waves);  // what the workspace holds
+    if (env_tree == 0) cap = 0;
+    else if (env_tree == 1) cap = cap < run_slots ? cap : run_slots;
+    P.scenes[i].cap_buckets = (int)cap;
+    const long most = cap > runs ? cap : runs;
+    capmax = capmax > most ? capmax : most;
+  }
+  size_t lds = (size_t)(kRowsHistWords + kRowsCells) * sizeof(int);
+  if ((size_t)capmax * sizeof(float4) > lds) lds = (size_t)capmax * sizeof(float4);
+  const int ns = (int)((capmax + per_slot - 1) / per_slot);
   switch (pl.waves) {
     case 16:
       if (ns <= 1) return launch_rows<16, 1>(P, b, lds, debug, stream);
