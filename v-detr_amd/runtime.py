@@ -27,43 +27,57 @@ def _default_cache_dir():
 def enable_gemm_tuning(rank=0, cache_dir=None):
     """Turn TunableOp on for this process.  Returns the path of the results file in use.  The file lives in a private
     (0700) per-user, per-version directory and is unique to this process (rank AND pid: concurrent jobs of one user do not
-    share it); it is seeded from the committed MI355X measurements through a temp file + atomic rename."""
+    share it); it is seeded through a temp file + atomic rename from what earlier runs learned, else from the committed
+    MI355X measurements, and rank 0 publishes what this run added when the process exits."""
     import torch.cuda.tunable as tn
     d = cache_dir or _default_cache_dir()
+    scratch_dir = None
     try:
         os.makedirs(d, mode=0o700, exist_ok=True)
         if os.path.islink(d) or os.stat(d).st_uid != os.getuid():
             raise OSError("cache directory is a symlink or owned by someone else")
     except OSError:
-        d = tempfile.mkdtemp(prefix="vdetr_tunableop_")  # private by construction
+        d = scratch_dir = tempfile.mkdtemp(prefix="vdetr_tunableop_")  # private by construction; removed at exit
     path = os.path.join(d, f"tunableop_rank{rank}_pid{os.getpid()}.csv")
-    if os.path.exists(SEED_RESULTS):
+    # start from what earlier runs of this user / library version measured (shapes outside the committed seed are then
+    # tuned once, not on every run and every rank), else from the committed MI355X measurements
+    learned = os.path.join(d, "tunableop_learned.csv")
+    seed = learned if os.path.exists(learned) and not os.path.islink(learned) else SEED_RESULTS
+    if os.path.exists(seed):
         fd, tmp = tempfile.mkstemp(dir=d, prefix=".seed_")
-        with os.fdopen(fd, "wb") as dst, open(SEED_RESULTS, "rb") as src:
+        with os.fdopen(fd, "wb") as dst, open(seed, "rb") as src:
             shutil.copyfileobj(src, dst)
-        os.replace(tmp, path)  # always start from the committed measurements, never from a stale file
+        os.replace(tmp, path)
     tn.set_filename(path)
     tn.enable(True)
     tn.tuning_enable(True)
-    # the per-process file is scratch: removed at exit; VDETR_TUNABLEOP_SAVE=<file> keeps a copy of what this run tuned
-    # (how tuning/gfx950_tunableop.csv is refreshed on the GPU box)
+    # the per-process file is scratch; at exit rank 0 publishes it as the learned file of this cache directory (temp file
+    # + atomic rename: concurrent jobs of one user never see a half-written file).  VDETR_TUNABLEOP_SAVE=<file> keeps a
+    # copy as well (how tuning/gfx950_tunableop.csv is refreshed on the GPU box).
     if hasattr(tn, "write_file_on_exit"):  # older torch: results written at exit; newer: appended as they are found
         tn.write_file_on_exit(False)
     import atexit
 
     def _finish(path=path):
         try:
+            if hasattr(tn, "write_file"):
+                tn.write_file(path)
             keep = os.environ.get("VDETR_TUNABLEOP_SAVE")
             if keep:
-                if hasattr(tn, "write_file"):
-                    tn.write_file(path)
                 shutil.copy(path, keep)
+            if rank == 0 and scratch_dir is None and os.path.getsize(path) > 0:
+                fd, tmp = tempfile.mkstemp(dir=d, prefix=".learned_")
+                with os.fdopen(fd, "wb") as dst, open(path, "rb") as src:
+                    shutil.copyfileobj(src, dst)
+                os.replace(tmp, learned)
         except Exception:
             pass
         try:
             os.remove(path)
         except OSError:
             pass
+        if scratch_dir is not None:
+            shutil.rmtree(scratch_dir, ignore_errors=True)
 
     atexit.register(_finish)
     return path
