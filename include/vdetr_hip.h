@@ -193,6 +193,22 @@ int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, con
                               const float* delta, float* probs_out, float* ds_out, float* dtable, void* workspace,
                               size_t workspace_bytes, vdetr_stream_t stream);
 
+/* The key side of the shared-KV backward in one pass over the stored scores (autograd of vdetr_transformer.py:739-753;
+ * replaces torch.bmm(dO, V^T), the element-wise stage above and the two GEMMs dV = P_drop^T dO, dK = scale dS^T q):
+ *   q, dout [B,nQ,4*64];  v [B,nK,64] (row stride d->v_row_stride);  scores, lse, delta as saved / produced above
+ *   ds_out [B,nQ,4,nK]  UNSCALED dS (input of vdetr_attn_bwd_table_f32 and of dQ = scale * ds_out K)
+ *   dk, dv [B,nK,64]    written (not accumulated); 16-B aligned
+ * Shared-KV kind with 4 heads only.  fp32 operands pass through the bf16 matrix unit as hi + lo halves (three cross
+ * terms: relative error of a product <= 2^-16); results are bit-reproducible from run to run. */
+size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d);
+int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* scores,
+                          const float* lse, const float* delta, float* ds_out, float* dk, float* dv, void* workspace,
+                          size_t workspace_bytes, vdetr_stream_t stream);
+/* The RPE table gradient alone, from the dS that vdetr_attn_bwd_kv_f32 wrote (same kernels, workspace and bwd_aux contract
+ * as vdetr_attn_bwd_scores_f32 with a dtable; d->bwd_aux is required).  dtable [8,T,T,T,4]: caller zero-fills. */
+int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* ds, float* dtable, void* workspace,
+                             size_t workspace_bytes, vdetr_stream_t stream);
+
 /* delta = rowsum(dO * O) over the 64 channels of a head, in the row order of the kind (see vdetr_attn_fwd_f32);
  * dout / out [B,nQ,H*64].  The softmax-backward term the score stage subtracts.  With d->bwd_aux (shared-KV kind, `v` as
  * passed to the forward) the launch also produces the two norm maxima described at vdetr_attn_desc.bwd_aux. */

@@ -165,12 +165,57 @@ def test_full_size_forward_backward_vs_oracle(boxes):
             assert_close(o, r.numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
-def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant):
+@pytest.mark.parametrize("case", ["rpe_boxes", "rpe_general", "plain_dropout_mask", "ragged"])
+def test_fused_key_side_backward_equals_gemm_path(monkeypatch, case):
+    """attn_bwd_kv.hip (dO V^T, softmax backward, dV, dK in one pass; dS handed to the table kernels) against the library
+    GEMM path on the same launch: dq, dk, dv within 2e-5 of the largest entry (split-bf16 products, 2^-16 each, against
+    fp32 GEMMs), the table gradient within the fixed-point resolution, and the fused path bit-identical run to run (its
+    reduction tree is fixed and two commutative adds meet in memory)."""
+    from vdetr_amd import attention as A
+    g = torch.Generator().manual_seed(31)
+    if case == "ragged":
+        B, nQ, nK = 2, 37, 301  # partial row tiles, partial key tiles, idle row slots
+    else:
+        B, nQ, nK = 1, 256, 1536
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 5)
+    if case == "rpe_general":
+        verts[:, ::7] += 0.05 * torch.randn(verts[:, ::7].shape, generator=g)
+    q, k, v = (torch.randn(s, generator=g).to(DEV) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g).to(DEV)
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True)
+    rpe = case != "plain_dropout_mask"
+    if rpe:
+        kw.update(rpe=A.RPEConfig(), vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV))
+    else:
+        kw.update(dropout_p=0.1, rng_state=A.new_rng_state(DEV, 5), attn_mask=(torch.rand((B, nQ, nK), generator=g) < 0.1).to(DEV))
+
+    def run():
+        args = [x.clone().requires_grad_(True) for x in (q, k, v)]
+        tb = tables.to(DEV).requires_grad_(True) if rpe else None
+        (A.fused_attention(*args, table=tb, **kw) * wout).sum().backward()
+        return [a.grad for a in args] + ([tb.grad] if rpe else [])
+
+    monkeypatch.setattr(A, "FUSED_KV_BWD", False)
+    ref = run()
+    monkeypatch.setattr(A, "FUSED_KV_BWD", True)
+    got = run()
+    again = run()
+    for name, r, o, o2 in zip(["dq", "dk", "dv", "dtable"], ref, got, again):
+        scale = float(r.abs().max())
+        tol = 3e-4 if name == "dtable" else 2e-5
+        err = float((o - r).abs().max())
+        assert err <= tol * scale, f"{case} {name}: max |diff| {err:.3e} vs scale {scale:.3e}"
+        assert torch.equal(o, o2), f"{case} {name}: not reproducible"
+
+
+@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True)])
+def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
     """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
     where every wave of every workgroup is busy (the size at which a packed-math code-generation problem once showed):
-    P~ and dS bit-identical (same element-wise code), table gradient within the fixed-point resolution, three times."""
+    P~ and dS bit-identical (same element-wise code), table gradient within the fixed-point resolution, three times.
+    fused: the kernels read the dS that attn_bwd_kv.hip wrote instead of forming it (dq, dk, dv are then that pass's)."""
     from vdetr_amd import attention as A
+    monkeypatch.setattr(A, "FUSED_KV_BWD", fused)
     B, nQ, nK = 1, 192, 2048
     g = torch.Generator().manual_seed(11)
     xyz, verts, tables, _ = _scene(B, nQ, nK, 5)

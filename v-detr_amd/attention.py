@@ -9,7 +9,8 @@ Everything outside the core (q/k/v/out projections, the cpb MLP that produces th
 that parameters, their names and their gradients flow exactly as in the reference modules.
 
 Forward saves the biased scores S [rows, nK] and the row log-sum-exp; backward is
-  dP~ = dO V^T (GEMM) -> kernel: P~, dS, dTable -> dV = P~^T dO, dK = dS^T q, dQ = dS K (GEMMs).
+  shared K/V, 4 heads: one pass over S (attn_bwd_kv.hip: dP~ = dO V^T, P~, dS, dV, dK) -> dTable from dS -> dQ = dS K (GEMM);
+  otherwise: dP~ = dO V^T (GEMM) -> kernel: P~, dS, dTable -> dV = P~^T dO, dK = dS^T q, dQ = dS K (GEMMs).
 """
 import ctypes
 import os
@@ -48,6 +49,18 @@ def new_rng_state(device, seed=None):
 # the same captured hipGraph therefore draws fresh dropout masks on every replay.  Modules that share a snapshot
 # stay independent through their per-module ``salt`` (the by-value seed of the descriptor).
 DYNAMIC_BWD = os.environ.get("VDETR_BWD_DYNAMIC", "1") != "0"
+# shared-KV backward: dO V^T, the softmax backward, dV and dK in one pass over the scores (attn_bwd_kv.hip) instead of
+# three library GEMMs around an element-wise kernel.  VDETR_BWD_FUSED=0 keeps the GEMM path (A/B measurements, parity).
+FUSED_KV_BWD = os.environ.get("VDETR_BWD_FUSED", "1") != "0"
+
+
+def _fused_kv_ok(want_table):
+    if not FUSED_KV_BWD:
+        return False
+    if want_table:  # the table gradient then reads the dS the fused kernel wrote: default kernel variants only
+        return (DYNAMIC_BWD and os.environ.get("VDETR_BWD_VARIANT", "9") == "9" and
+                os.environ.get("VDETR_BWD_BOX", "2") != "1")
+    return True
 _master = {}
 _current = {}
 
@@ -199,6 +212,27 @@ class _FusedAttention(Function):
         delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
         L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),
                 "attn_delta")
+        if shared and H == 4 and _fused_kv_ok(want_table):
+            ds = torch.empty_like(scores)  # [B, nQ, H, nK], unscaled
+            dkv = torch.empty((2, B, nK, HEAD_DIM), dtype=torch.float32, device=q.device)
+            nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
+            ws = L.workspace(nbytes, q.device)
+            L.check(lib.vdetr_attn_bwd_kv_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(scores), L.ptr(lse),
+                                              L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws), nbytes,
+                                              L.stream_ptr()), "attn_bwd_kv")
+            dtable = None
+            if want_table:
+                dtable = _take_zeros(table, tuple(table.shape), table.dtype)
+                nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
+                ws = L.workspace(nbytes, q.device)
+                L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws), nbytes,
+                                                     L.stream_ptr()), "attn_bwd_table")
+            dq = q.new_empty((B, nQ * H, HEAD_DIM))
+            torch.baddbmm(dq, ds.view(B, nQ * H, nK), k, beta=0.0, alpha=float(scale), out=dq)
+            dq, dk, dv = dq.view(B, nQ, C), dkv[0], dkv[1]
+            if in_dtype == torch.bfloat16:
+                dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
+            return (dq, dk, dv, dtable) + (None,) * 12
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)

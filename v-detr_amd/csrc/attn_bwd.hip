@@ -346,11 +346,12 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
   };
   const int rowbytes = P.nK * 4;
+  const bool dsg = P.ds_given != 0;  // `dprob` holds dS already (attn_bwd_kv.hip): one stream to read, nothing to store
   auto fetch = [&](rsrc_t rs, rsrc_t rd, rsrc_t rx, rsrc_t rm, bool has_mask, int chunk, ChunkOps& o) {
     const int key = chunk * kWave + lane;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      o.s[h] = ldf(rs, key * 4, h * rowbytes);
+      if (!dsg) o.s[h] = ldf(rs, key * 4, h * rowbytes);
       o.d[h] = ldf(rd, key * 4, h * rowbytes);
     }
     o.kx = ldf(rx, key * 12, 0); o.ky = ldf(rx, key * 12 + 4, 0); o.kz = ldf(rx, key * 12 + 8, 0);
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
     auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
     float lse[4], delta[4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lse[h] = uni(P.lse[row0 + h]); delta[h] = uni(P.delta[row0 + h]); }
+    for (int h = 0; h < 4; ++h) { lse[h] = P.ds_given ? 0.f : uni(P.lse[row0 + h]); delta[h] = P.ds_given ? 0.f : uni(P.delta[row0 + h]); }
     constexpr int kVL = VLOOP ? VERTS : 1;
     const float* vp = P.vertices + ((size_t)b * P.nQ + q) * 24 + w * 3;
     float vxs[kVL], vys[kVL], vzs[kVL];
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
     const rsrc_t rsc = make_rsrc(P.scores + row0 * P.nK, 4u * rowbytes), rd = make_rsrc(P.dprob + row0 * P.nK, 4u * rowbytes);
     const rsrc_t rp = make_rsrc(P.probs_out + row0 * P.nK, 4u * rowbytes), rg = make_rsrc(P.ds_out + row0 * P.nK, 4u * rowbytes);
     const rsrc_t rx = make_rsrc(P.xyz + (size_t)b * P.nK * 3, 3u * rowbytes);
-    const bool has_mask = P.mask_kind == VDETR_MASK_BOOL;
+    const bool has_mask = P.mask_kind == VDETR_MASK_BOOL && !dsg;
     const rsrc_t rm = make_rsrc(has_mask ? reinterpret_cast<const unsigned char*>(P.mask) + ((size_t)b * P.nQ + q) * P.nK
                                          : reinterpret_cast<const unsigned char*>(P.xyz), has_mask ? (unsigned)P.nK : 0u);
     ChunkOps ops, nxt;
@@ -396,7 +397,10 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
       const int key = chunk * kWave + lane;
       const bool valid = key < P.nK;
       float ds[4];
-      {
+      if (dsg) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ds[h] = valid ? ops.d[h] * fix_scale : 0.f;
+      } else {
         uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
         if (P.drop_thresh) rnd = attn_rand4(P, b, q, key, 0);
 #pragma unroll
@@ -724,22 +728,26 @@ static int launch_mm(const AttnParams& P, int grid, size_t lds, hipStream_t st) 
   return VDETR_OK;
 }
 
-extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, const float* dprob,
-                                         const float* lse, const float* delta, float* probs_out, float* ds_out,
-                                         float* dtable, void* workspace, size_t workspace_bytes,
-                                         vdetr_stream_t stream) {
+static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, const float* dprob, const float* lse,
+                                const float* delta, float* probs_out, float* ds_out, float* dtable, void* workspace,
+                                size_t workspace_bytes, vdetr_stream_t stream, bool ds_given) {
   AttnParams P;
   if (int e = attn_fill_params(d, &P, "attn_bwd_scores")) return e;
-  VDETR_REQUIRE(scores && lse && probs_out, "attn_bwd_scores: null pointer");
-  VDETR_REQUIRE((dprob == nullptr) == (delta == nullptr) && (dprob == nullptr) == (ds_out == nullptr),
-                "attn_bwd_scores: dprob, delta and ds_out go together");
-  VDETR_REQUIRE(!dtable || (d->table && dprob), "attn_bwd_scores: dtable needs an RPE descriptor and dprob");
-  VDETR_REQUIRE(!dtable || (probs_out != scores && ds_out != dprob),
-                "attn_bwd_scores: with a table gradient the outputs must not alias the inputs "
-                "(several waves re-read the scores)");
+  if (ds_given) {
+    VDETR_REQUIRE(dprob && dtable && d->table && d->bwd_aux, "attn_bwd_table: needs dS, dtable, the RPE operands and bwd_aux");
+  } else {
+    VDETR_REQUIRE(scores && lse && probs_out, "attn_bwd_scores: null pointer");
+    VDETR_REQUIRE((dprob == nullptr) == (delta == nullptr) && (dprob == nullptr) == (ds_out == nullptr),
+                  "attn_bwd_scores: dprob, delta and ds_out go together");
+    VDETR_REQUIRE(!dtable || (d->table && dprob), "attn_bwd_scores: dtable needs an RPE descriptor and dprob");
+    VDETR_REQUIRE(!dtable || (probs_out != scores && ds_out != dprob),
+                  "attn_bwd_scores: with a table gradient the outputs must not alias the inputs "
+                  "(several waves re-read the scores)");
+  }
   P.scores = const_cast<float*>(scores); P.dprob = const_cast<float*>(dprob);
   P.lse = const_cast<float*>(lse); P.delta = delta;
   P.probs_out = probs_out; P.ds_out = ds_out;
+  P.ds_given = ds_given ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (!d->table) {
     const size_t total = (size_t)d->B * d->H * d->nQ * d->nK;
@@ -748,6 +756,7 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     return check_launch("attn_bwd_scores");
   }
   const int variant = bwd_variant();
+  VDETR_REQUIRE(!ds_given || variant == 9, "attn_bwd_table: built into kernel variant 9 (VDETR_BWD_VARIANT=%d)", variant);
   const int table_floats = kRpeVerts * P.T * P.T * P.T * 4;
   const bool mm = dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16;
   const int split = mm && (variant == 8 || variant == 9 || variant == 11 || variant == 12) ? 2 : 1;  // workgroups per query
@@ -766,6 +775,8 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
   // only, 406 us.  Read per call: the parity test runs the kernels side by side in one process.
   const char* box_var = getenv("VDETR_BWD_BOX");
   const int box_env = box_var ? atoi(box_var) : 2;
+  VDETR_REQUIRE(!ds_given || box_env != 1, "attn_bwd_table: not built into the first box kernel (VDETR_BWD_BOX=1)");
+  VDETR_REQUIRE(!ds_given || P.T * P.T * P.T <= kWave * 16, "attn_bwd_table: table edge %d too large for the matrix-unit kernel", P.T);
   const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && P.T == 10;
   P.box_path = box ? 1 : 0;
   if (mm) {
@@ -800,6 +811,18 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
     return check_launch("attn_bwd_table_reduce");
   }
   return VDETR_OK;
+}
+
+extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, const float* dprob,
+                                         const float* lse, const float* delta, float* probs_out, float* ds_out,
+                                         float* dtable, void* workspace, size_t workspace_bytes,
+                                         vdetr_stream_t stream) {
+  return attn_bwd_scores_impl(d, scores, dprob, lse, delta, probs_out, ds_out, dtable, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* ds, float* dtable, void* workspace,
+                                        size_t workspace_bytes, vdetr_stream_t stream) {
+  return attn_bwd_scores_impl(d, nullptr, ds, nullptr, nullptr, nullptr, nullptr, dtable, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, const float* v,

@@ -91,11 +91,12 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
   };
   const int rowbytes = P.nK * 4;
+  const bool dsg = P.ds_given != 0;  // dS comes from attn_bwd_kv.hip: one stream to read, no exp, no hash, no stores
   auto fetch = [&](rsrc_t rs, rsrc_t rd, rsrc_t rx, rsrc_t rm, bool has_mask, int chunk, ChunkOps& o) {
     const int key = chunk * kWave + lane;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      o.s[h] = ldf(rs, key * 4, h * rowbytes);
+      if (!dsg) o.s[h] = ldf(rs, key * 4, h * rowbytes);
       o.d[h] = ldf(rd, key * 4, h * rowbytes);
     }
     o.kx = ldf(rx, key * 12, 0); o.ky = ldf(rx, key * 12 + 4, 0); o.kz = ldf(rx, key * 12 + 8, 0);
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
     auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
     float lse[4], delta[4];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { lse[h] = uni(P.lse[row0 + h]); delta[h] = uni(P.delta[row0 + h]); }
+    for (int h = 0; h < 4; ++h) { lse[h] = P.ds_given ? 0.f : uni(P.lse[row0 + h]); delta[h] = P.ds_given ? 0.f : uni(P.delta[row0 + h]); }
     const float* vp = P.vertices + ((size_t)b * P.nQ + q) * 24;
     const float X0 = uni(vp[0]), X1 = uni(vp[6]), Y0 = uni(vp[1]), Y1 = uni(vp[4]), Zp = uni(vp[part * 12 + 2]);
     const rsrc_t rsc = make_rsrc(P.scores + row0 * P.nK, 4u * rowbytes), rd = make_rsrc(P.dprob + row0 * P.nK, 4u * rowbytes);
     const rsrc_t rp = make_rsrc(P.probs_out + row0 * P.nK, 4u * rowbytes), rg = make_rsrc(P.ds_out + row0 * P.nK, 4u * rowbytes);
     const rsrc_t rx = make_rsrc(P.xyz + (size_t)b * P.nK * 3, 3u * rowbytes);
-    const bool has_mask = P.mask_kind == VDETR_MASK_BOOL;
+    const bool has_mask = P.mask_kind == VDETR_MASK_BOOL && !dsg;
     const rsrc_t rm = make_rsrc(has_mask ? reinterpret_cast<const unsigned char*>(P.mask) + ((size_t)b * P.nQ + q) * P.nK
                                          : reinterpret_cast<const unsigned char*>(P.xyz), has_mask ? (unsigned)P.nK : 0u);
     ChunkOps ops, nxt;
@@ -134,7 +135,10 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
       const int key = chunk * kWave + lane;
       const bool valid = key < P.nK;
       float ds[4];
-      {
+      if (dsg) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ds[h] = valid ? ops.d[h] * fix_scale : 0.f;
+      } else {
         uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
         if (P.drop_thresh) rnd = attn_rand4(P, b, q, key, 0);
 #pragma unroll

@@ -1,0 +1,361 @@
+// attn_bwd_kv.hip — the key side of the shared-KV attention backward as ONE pass over the stored scores (gfx950).
+//
+// Autograd of vdetr_transformer.py:739-753 (attn = softmax(q k^T * scale + rpe); x = dropout(attn) v) needs, per layer,
+//     dP~ = dO V^T,   P~ / dS = softmax + dropout backward,   dV = P~^T dO,   dK = scale dS^T q,   dQ = scale dS K
+// over a [4 nQ x nK] score matrix (4 heads share K and V: rows are (query, head)).  As library GEMMs around an
+// element-wise kernel that is 67 MB written for dP~, 67 + 67 MB read and 67 + 67 MB written element-wise, and 67 MB read
+// by each of the three contractions (4096 x 4096 at C2): ~540 MB of HBM traffic, and fp32 matrix instructions that run at
+// 1/16 of the bf16 rate.  Here a wave owns 32 keys and walks 32-row tiles of the scores:
+//     S tile (the only big read) -> dP~ tile on the matrix unit (dO tile x the wave's V operand, resident in registers)
+//     -> P~, dS in registers -> dS stored once (the table gradient and the dQ GEMM read it) -> dV^T += dO^T P~,
+//     dK^T += q^T dS with the tile as the B operand exactly as the matrix unit left it (the accumulator layout of
+//     v_mfma_f32_32x32x16_bf16 IS its B-operand layout up to a permutation of the 16 contraction slots, which the
+//     pre-packed A operands follow).
+// fp32 operands go through the bf16 unit as hi + lo (round-to-nearest) with the three leading cross terms: relative
+// error of a product <= 2^-16, far below the 1e-3 parity tolerance and summed over thousands of terms of mixed sign.
+// Determinism: the 16 row slots of a key tile (2 workgroups x 8 waves) are reduced by a fixed tree in LDS, and the two
+// workgroups add their sums onto a zeroed output — two commutative float adds, the same bits in either order.
+#include "attn_common.h"
+
+namespace vdetr {
+
+int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKvWaves = 8;
+constexpr int kKvThreads = kKvWaves * kWave;
+constexpr int kKvSlots = 2 * kKvWaves;          // row slots per key tile: 2 workgroups x 8 waves
+constexpr int kKvOperandUnits = 2 * kWave;      // one packed operand: (hi, lo) x 64 lanes, 16 B each
+constexpr int kKvTileUnits = 3 * 4 * kKvOperandUnits;
+
+struct KvParams {
+  AttnParams A;
+  const float* dout;  // [B][R][64], R = 4 nQ rows (query, head)
+  float* dk;          // [B][nK][64]
+  float* dv;
+  uint4* pack;        // [B][NT][3 kinds][4][hi, lo][64 lanes] operand images of dO and q
+  int R, NT;          // rows, 32-row tiles
+};
+
+// row (inside a 32 x 32 tile) of accumulator register v in lane group g = lane >> 5
+__device__ __forceinline__ constexpr int kv_row(int v, int g) { return (v & 3) + 8 * (v >> 2) + 4 * g; }
+
+__device__ __forceinline__ void kv_split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)x[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(x[e] - (float)h);
+  }
+}
+
+__device__ __forceinline__ f32x16 kv_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// a b with a = ah + al, b = bh + bl: the three leading terms
+__device__ __forceinline__ f32x16 kv_mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+  c = kv_mfma(al, bh, c);
+  c = kv_mfma(ah, bl, c);
+  return kv_mfma(ah, bh, c);
+}
+
+// ---- operand images ----------------------------------------------------------------------------------------------------
+// kind 0 (sub = s):         A of dP~ = dO V^T:   lane (row = l & 31, g)  e -> dO[r0 + row][16 s + 8 g + e]
+// kind 1 (sub = 2 mt + t):  A of dV^T = dO^T P~: lane (d = 32 mt + (l & 31), g)  e -> dO[r0 + kv_row(8 t + e, g)][d]
+// kind 2:                   A of dK^T = q^T dS:  as kind 1 with q
+// (the contraction slot (g, e) of instruction t is the tile row kv_row(8 t + e, g): what accumulator register 8 t + e of
+// lane group g holds).  Also zero-fills dK / dV, which the main kernel accumulates into.
+__global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K) {
+  const AttnParams& P = K.A;
+  const int R = K.R, NT = K.NT;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+  const long nunits = (long)P.B * NT * 12 * kWave;
+  for (long u = gid; u < nunits; u += stride) {
+    const int lane = (int)(u & 63);
+    long r = u >> 6;
+    const int sub = (int)(r & 3);
+    r >>= 2;
+    const int kind = (int)(r % 3);
+    const long bt = r / 3;
+    const int b = (int)(bt / NT), tile = (int)(bt - (long)b * NT), r0 = tile * 32;
+    const int l31 = lane & 31, g = lane >> 5;
+    const float* src = (kind == 2 ? P.q : K.dout) + (size_t)b * R * kDh;
+    float x[8];
+    if (kind == 0) {
+      const int row = r0 + l31;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = row < R ? src[(size_t)row * kDh + 16 * sub + 8 * g + e] : 0.f;
+    } else {
+      const int d = 32 * (sub >> 1) + l31, t = sub & 1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = r0 + kv_row(8 * t + e, g);
+        x[e] = row < R ? src[(size_t)row * kDh + d] : 0.f;
+      }
+    }
+    bf16x8 hi, lo;
+    kv_split8(x, hi, lo);
+    uint4* dst = K.pack + ((bt * 3 + kind) * 4 + sub) * kKvOperandUnits;
+    dst[lane] = __builtin_bit_cast(uint4, hi);
+    dst[kWave + lane] = __builtin_bit_cast(uint4, lo);
+  }
+  const long nz = (long)P.B * P.nK * kDh / 4;
+  f32x4* zk = reinterpret_cast<f32x4*>(K.dk);
+  f32x4* zv = reinterpret_cast<f32x4*>(K.dv);
+  for (long i = gid; i < nz; i += stride) {
+    zk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    zv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// grid (2 x key tiles, B); workgroup (key tile kt, half hf): wave w walks the row tiles hf * 8 + w, + 16, ...
+//
+// One tile step, written as phases so that every load is in flight long before its use (with 2 waves per SIMD nothing
+// else hides a round trip; a first version that let the compiler place the loads ran 8 + 8 + 8 dependent L2 round trips
+// per tile: 70 us instead of 40):
+//   0  issue: dO operands of dP~ (8 x 16 B), dO^T / q^T operands of contraction step t = 0 (8), lse / delta of queries 0-1
+//   1  dP~ = 12 matrix instructions (V operand from the wave's LDS strip)
+//   2  issue: operands of step t = 1 into the registers phase 1 freed, lse / delta of queries 2-3, then the NEXT tile's
+//      scores (16 dwords; last, because vmcnt retires in order: nothing this tile waits for sits behind them)
+//   3  softmax backward of queries 0-1, dS stores, step t = 0: 12 matrix instructions
+//   4  the same for queries 2-3 and t = 1
+// Scores and dS go through buffer instructions whose range check does the masking: a lane whose key is past nK carries
+// offset 2^31, a row past the end is past num_records, so there is no branch around any load or store.
+__global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
+  AttnParams P = K.A;
+  attn_load_rng(P);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const int kt = blockIdx.x >> 1, hf = blockIdx.x & 1, b = blockIdx.y;
+  const int R = K.R, NT = K.NT, nK = P.nK;
+  const int key = kt * 32 + l31;
+  const bool kvalid = key < nK;
+
+  // B operand of dP~: V[key][16 s + 8 g + e] as (hi, lo), in the wave's LDS strip: [s][hi, lo][lane] 16-B units
+  uint4* vstrip = reinterpret_cast<uint4*>(smem) + w * (8 * kWave) + lane;
+  {
+    const float* vrow = P.v + ((size_t)b * nK + (kvalid ? key : 0)) * P.v_stride + 8 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(vrow + 16 * s), c = *reinterpret_cast<const f32x4*>(vrow + 16 * s + 4);
+      float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+      if (!kvalid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+      }
+      bf16x8 hi, lo;
+      kv_split8(x, hi, lo);
+      vstrip[(2 * s) * kWave] = __builtin_bit_cast(uint4, hi);
+      vstrip[(2 * s + 1) * kWave] = __builtin_bit_cast(uint4, lo);
+    }
+  }
+  f32x16 accV[2], accK[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { accV[0][i] = 0.f; accV[1][i] = 0.f; accK[0][i] = 0.f; accK[1][i] = 0.f; }
+
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  const unsigned recs = (unsigned)((size_t)R * nK * 4);  // the whole offset goes into the VGPR: it is what the range check sees
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(P.scores + (size_t)b * R * nK, 0, (int)recs, 0x00020000);
+  const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(P.ds_out + (size_t)b * R * nK, 0, (int)recs, 0x00020000);
+  const int rowbytes = nK * 4;
+  const unsigned lane_off = kvalid ? (unsigned)(4 * g * rowbytes + key * 4) : 0x80000000u;
+  const float* lse_b = P.lse + (size_t)b * R;
+  const float* delta_b = P.delta + (size_t)b * R;
+  const bool has_mask = P.mask_kind == VDETR_MASK_BOOL;
+  const unsigned char* mask_b = reinterpret_cast<const unsigned char*>(P.mask) + (size_t)b * P.nQ * nK + (kvalid ? key : 0);
+
+  auto load_scores = [&](int tile, float (&sv)[16]) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const unsigned voff = lane_off + (unsigned)((tile * 32 + 8 * a) * rowbytes);
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        sv[4 * a + h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + (unsigned)(h * rowbytes)), 0, 0));
+    }
+  };
+  const int first = hf * kKvWaves + w;
+  float sv[16], sn[16];
+  if (first < NT) load_scores(first, sn);
+
+  for (int tile = first; tile < NT; tile += kKvSlots) {
+    const int r0 = tile * 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sv[i] = sn[i];
+    const uint4* pk = K.pack + ((size_t)b * NT + tile) * kKvTileUnits + lane;
+    auto operand = [&](int kind, int sub, int hl) { return pk[((kind * 4 + sub) * 2 + hl) * kWave]; };
+    auto row_consts = [&](int a, f32x4& l4, f32x4& d4) {  // lse / delta of the 4 heads of query (r0 + 8 a + 4 g) / 4
+      const int rb = min(r0 + 8 * a + 4 * g, R - 4);
+      l4 = *reinterpret_cast<const f32x4*>(lse_b + rb);
+      d4 = *reinterpret_cast<const f32x4*>(delta_b + rb);
+    };
+    // ---- phase 0 ------------------------------------------------------------------------------------------------------
+    uint4 opA[8], opB[8];  // [2 sub + hl]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { opA[2 * s] = operand(0, s, 0); opA[2 * s + 1] = operand(0, s, 1); }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      opB[2 * mt] = operand(1, 2 * mt, 0); opB[2 * mt + 1] = operand(1, 2 * mt, 1);
+      opB[4 + 2 * mt] = operand(2, 2 * mt, 0); opB[4 + 2 * mt + 1] = operand(2, 2 * mt, 1);
+    }
+    f32x4 l4[2], d4[2];
+    row_consts(0, l4[0], d4[0]);
+    row_consts(1, l4[1], d4[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 1: dP~ tile = dO tile x V^T --------------------------------------------------------------------------------
+    f32x16 dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 vh = __builtin_bit_cast(bf16x8, vstrip[(2 * s) * kWave]), vl = __builtin_bit_cast(bf16x8, vstrip[(2 * s + 1) * kWave]);
+      dp = kv_mfma3(__builtin_bit_cast(bf16x8, opA[2 * s]), __builtin_bit_cast(bf16x8, opA[2 * s + 1]), vh, vl, dp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2 ------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      opA[2 * mt] = operand(1, 2 * mt + 1, 0); opA[2 * mt + 1] = operand(1, 2 * mt + 1, 1);
+      opA[4 + 2 * mt] = operand(2, 2 * mt + 1, 0); opA[4 + 2 * mt + 1] = operand(2, 2 * mt + 1, 1);
+    }
+    f32x4 l4b[2], d4b[2];
+    row_consts(2, l4b[0], d4b[0]);
+    row_consts(3, l4b[1], d4b[1]);
+    if (tile + kKvSlots < NT) load_scores(tile + kKvSlots, sn);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phases 3, 4: softmax + dropout backward of 2 queries x 4 heads, then their contraction step -----------------------
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float xp[8], xs[8];
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2) {
+        const int a = 2 * t + a2;
+        const int rb = r0 + 8 * a + 4 * g;  // rows rb .. rb + 3 = the 4 heads of query rb / 4 (R is a multiple of 4)
+        const bool ok = rb < R && kvalid;
+        const int qi = min(rb, R - 4) >> 2;
+        const f32x4 lv = t ? l4b[a2] : l4[a2], dv = t ? d4b[a2] : d4[a2];
+        uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+        if (P.drop_thresh) rnd = attn_rand4(P, b, qi, key, 0);
+        bool masked = false;
+        if (has_mask) masked = mask_b[(size_t)qi * nK] != 0;
+        const unsigned voff = lane_off + (unsigned)((r0 + 8 * a) * rowbytes);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const int v = 4 * a + h;
+          const bool keep = pick4(rnd, h) >= P.drop_thresh;
+          const ScoreGrad gr = score_grad(sv[v], lv[h], keep, P.drop_scale, true, dp[v], dv[h], masked);
+          xp[4 * a2 + h] = ok ? gr.p_drop : 0.f;
+          xs[4 * a2 + h] = ok ? gr.ds : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(gr.ds), rd, (int)(voff + (unsigned)(h * rowbytes)), 0, 0);
+        }
+      }
+      bf16x8 ph, pl, sh, sl;
+      kv_split8(xp, ph, pl);
+      kv_split8(xs, sh, sl);
+      const uint4* op = t ? opA : opB;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        accV[mt] = kv_mfma3(__builtin_bit_cast(bf16x8, op[2 * mt]), __builtin_bit_cast(bf16x8, op[2 * mt + 1]), ph, pl, accV[mt]);
+        accK[mt] = kv_mfma3(__builtin_bit_cast(bf16x8, op[4 + 2 * mt]), __builtin_bit_cast(bf16x8, op[4 + 2 * mt + 1]), sh, sl, accK[mt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();  // the V strips are dead: the reduction reuses the memory
+
+  // ---- the 8 waves' sums: fixed tree through LDS ([slot][register][lane]), then key-major rows for the global adds ---------
+  auto put = [&](int slot) {
+    float* dst = smem + (size_t)slot * 64 * kWave + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      dst[i * kWave] = accV[0][i]; dst[(16 + i) * kWave] = accV[1][i];
+      dst[(32 + i) * kWave] = accK[0][i]; dst[(48 + i) * kWave] = accK[1][i];
+    }
+  };
+  auto add = [&](int slot) {
+    const float* src = smem + (size_t)slot * 64 * kWave + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      accV[0][i] += src[i * kWave]; accV[1][i] += src[(16 + i) * kWave];
+      accK[0][i] += src[(32 + i) * kWave]; accK[1][i] += src[(48 + i) * kWave];
+    }
+  };
+  if (w >= 4) put(w - 4);
+  __syncthreads();
+  if (w < 4) add(w);
+  __syncthreads();
+  if (w == 2 || w == 3) put(w - 2);
+  __syncthreads();
+  if (w < 2) add(w);
+  __syncthreads();
+  if (w == 1) put(0);
+  __syncthreads();
+  if (w == 0) add(0);
+  __syncthreads();
+  constexpr int kFinStride = kDh + 1;
+  if (w == 0) {  // fin[which][key 32][d 64 (+1)]: accumulator (d = 32 mt + kv_row(i, g), key = l31)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = 32 * mt + kv_row(i, g);
+        smem[l31 * kFinStride + d] = accV[mt][i];
+        smem[(32 + l31) * kFinStride + d] = accK[mt][i] * P.scale;
+      }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * 32 * kDh; idx += kKvThreads) {
+    const int which = idx >> 11, kl = (idx >> 6) & 31, d = idx & 63;
+    const int kg = kt * 32 + kl;
+    if (kg < nK) unsafeAtomicAdd((which ? K.dk : K.dv) + ((size_t)b * nK + kg) * kDh + d, smem[(which * 32 + kl) * kFinStride + d]);
+  }
+}
+
+}  // namespace vdetr
+
+using namespace vdetr;
+
+static bool kv_supported(const vdetr_attn_desc* d) { return d && d->kind == VDETR_ATTN_SHARED_KV && d->H == 4; }
+
+extern "C" size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d) {
+  if (!kv_supported(d) || d->B <= 0 || d->nQ <= 0) return 0;
+  const size_t nt = ((size_t)d->nQ * 4 + 31) / 32;
+  return (size_t)d->B * nt * kKvTileUnits * sizeof(uint4) + 256;
+}
+
+extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout,
+                                     const float* scores, const float* lse, const float* delta, float* ds_out, float* dk,
+                                     float* dv, void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+  KvParams K;
+  if (int e = attn_fill_params(d, &K.A, "attn_bwd_kv")) return e;
+  VDETR_REQUIRE(kv_supported(d), "attn_bwd_kv: built for the shared-KV kind with 4 heads (kind %d, H %d)", d->kind, d->H);
+  VDETR_REQUIRE(q && v && dout && scores && lse && delta && ds_out && dk && dv, "attn_bwd_kv: null pointer");
+  VDETR_REQUIRE(K.A.v_stride % 4 == 0 && (((uintptr_t)v | (uintptr_t)lse | (uintptr_t)delta | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                "attn_bwd_kv: v rows, lse, delta, dk and dv must be 16-B aligned");
+  VDETR_REQUIRE((size_t)d->nQ * 4 * d->nK * 4 < ((size_t)1 << 31), "attn_bwd_kv: a scene's score matrix (%d x %d x 4 heads) must stay below 2 GB", d->nQ, d->nK);
+  const size_t need = vdetr_attn_bwd_kv_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need) {
+    set_error("attn_bwd_kv: workspace %zu B < required %zu B", workspace_bytes, need);
+    return VDETR_ERR_WORKSPACE;
+  }
+  K.A.q = q; K.A.v = v;
+  K.A.scores = const_cast<float*>(scores); K.A.lse = const_cast<float*>(lse); K.A.delta = delta; K.A.ds_out = ds_out;
+  K.dout = dout; K.dk = dk; K.dv = dv;
+  K.pack = reinterpret_cast<uint4*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  K.R = d->nQ * 4;
+  K.NT = (K.R + 31) / 32;
+  hipStream_t st = (hipStream_t)stream;
+  const long units = (long)d->B * K.NT * 12 * kWave;
+  const long zero4 = (long)d->B * d->nK * kDh / 4;
+  const long work = units > zero4 ? units : zero4;
+  hipLaunchKernelGGL(attn_bwd_kv_pack_kernel, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)), dim3(256), 0, st, K);
+  if (int e = check_launch("attn_bwd_kv_pack")) return e;
+  const size_t lds = (size_t)4 * 64 * kWave * sizeof(float);
+  if (int e = set_lds(attn_bwd_kv_kernel, lds, "attn_bwd_kv")) return e;
+  const int nkt = (d->nK + 31) / 32;
+  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(2 * nkt, d->B), dim3(kKvThreads), lds, st, K);
+  return check_launch("attn_bwd_kv");
+}

@@ -51,6 +51,7 @@ struct AttnParams {
   float* probs_out;
   float* ds_out;
   float* dtable_part;  // [gridDim.x][8*T^3*H]
+  int ds_given;        // table-gradient kernels: `dprob` already holds dS (attn_bwd_kv.hip wrote it); nothing else is read or stored
 };
 
 // ---- dropout random numbers: counter-based (stateless), so forward and backward regenerate the same keep-mask
