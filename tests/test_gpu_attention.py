@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from helpers import (assert_close, build_cross_attention, build_decoder, build_share_self_attention,
+from helpers import (assert_close, grad_atol, build_cross_attention, build_decoder, build_share_self_attention,
                      run_cross_attention_case, run_decoder_case, t)
 
 pytestmark = pytest.mark.gpu
@@ -165,7 +165,7 @@ def test_full_size_forward_backward_vs_oracle(boxes):
             assert_close(o, r.numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
-@pytest.mark.parametrize("case", ["rpe_boxes", "rpe_general", "plain_dropout_mask", "ragged"])
+@pytest.mark.parametrize("case", ["rpe_boxes", "rpe_general", "plain_dropout_mask", "ragged", "per_head", "per_head_ragged"])
 def test_fused_key_side_backward_equals_gemm_path(monkeypatch, case):
     """attn_bwd_kv.hip (dO V^T, softmax backward, dV, dK in one pass; dS handed to the table kernels) against the library
     GEMM path on the same launch: dq, dk, dv within 2e-5 of the largest entry (split-bf16 products, 2^-16 each, against
@@ -173,17 +173,23 @@ def test_fused_key_side_backward_equals_gemm_path(monkeypatch, case):
     reduction tree is fixed and two commutative adds meet in memory)."""
     from vdetr_amd import attention as A
     g = torch.Generator().manual_seed(31)
+    per_head = case.startswith("per_head")
     if case == "ragged":
         B, nQ, nK = 2, 37, 301  # partial row tiles, partial key tiles, idle row slots
+    elif case == "per_head":
+        B, nQ, nK = 1, 1024, 1024  # the decoder's query self-attention
+    elif case == "per_head_ragged":
+        B, nQ, nK = 3, 77, 45
     else:
         B, nQ, nK = 1, 256, 1536
     xyz, verts, tables, _ = _scene(B, nQ, nK, 5)
     if case == "rpe_general":
         verts[:, ::7] += 0.05 * torch.randn(verts[:, ::7].shape, generator=g)
-    q, k, v = (torch.randn(s, generator=g).to(DEV) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    kvc = 256 if per_head else 64
+    q, k, v = (torch.randn(s, generator=g).to(DEV) for s in ((B, nQ, 256), (B, nK, kvc), (B, nK, kvc)))
     wout = torch.randn((B, nQ, 256), generator=g).to(DEV)
-    kw = dict(num_heads=4, scale=0.125, shared_kv=True)
-    rpe = case != "plain_dropout_mask"
+    kw = dict(num_heads=4, scale=0.125, shared_kv=not per_head)
+    rpe = case not in ("plain_dropout_mask", "per_head", "per_head_ragged")
     if rpe:
         kw.update(rpe=A.RPEConfig(), vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV))
     else:
@@ -308,7 +314,7 @@ def test_cross_attention_module_vs_reference_vectors(case):
     assert_close(res["attn"], g["attn"], 1e-3, 1e-7, "attn")
     for k in g.files:
         if k.startswith("grad_"):
-            assert_close(res[k], g[k], 1e-3, max(2e-4 * np.abs(g[k]).max(), 2e-6), k)
+            assert_close(res[k], g[k], 1e-3, grad_atol(g, k, 2e-4), k)
 
 
 def test_share_self_attention_module_vs_reference_vectors():
@@ -318,9 +324,10 @@ def test_share_self_attention_module_vs_reference_vectors():
     x, _ = mod(tgt + pos, tgt + pos, value=tgt)
     (x * t(g["wout"], DEV)).sum().backward()
     assert_close(x, g["x"], 1e-3, 1e-5, "x")
-    assert_close(tgt.grad, g["grad_tgt"], 1e-3, 1e-6, "grad_tgt")
+    # (2e-5 of the largest entry: the key-side contractions run on split-bf16 products, 2^-17 per product; measured 6e-6)
+    assert_close(tgt.grad, g["grad_tgt"], 1e-3, 2e-5 * float(np.abs(g["grad_tgt"]).max()), "grad_tgt")
     for pname, p in mod.named_parameters():
-        assert_close(p.grad, g["grad_param:" + pname], 1e-3, max(2e-4 * np.abs(g["grad_param:" + pname]).max(), 2e-6), pname)
+        assert_close(p.grad, g["grad_param:" + pname], 1e-3, grad_atol(g, "grad_param:" + pname, 2e-4), pname)
 
 
 @pytest.mark.parametrize("case,nl,share", [("decoder_c1_l2", 2, False), ("decoder_c1_l3", 3, False),
@@ -340,7 +347,7 @@ def test_decoder_vs_reference_vectors(case, nl, share):
     params = dict(dec.named_parameters())
     for k in g.files:
         if k.startswith("grad_param:"):
-            assert_close(params[k[11:]].grad, g[k], 1e-3, max(1e-4 * np.abs(g[k]).max(), 2e-6), k)
+            assert_close(params[k[11:]].grad, g[k], 1e-3, grad_atol(g, k, 1e-4), k)
 
 
 @pytest.mark.parametrize("B", [1, 2])

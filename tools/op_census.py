@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--top", type=int, default=80)
     ap.add_argument("--stacks", action="store_true", help="group forward operators by Python call site instead")
     ap.add_argument("--parents", action="store_true", help="group by the enclosing autograd node / operator chain instead")
+    ap.add_argument("--timeline", default=None, help="write every device kernel of the step in launch order to this file")
     a = ap.parse_args()
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -36,6 +37,25 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=a.stacks) as prof:
         tr.step()
         torch.cuda.synchronize()
+    if a.timeline:
+        items = []
+        for ev in prof.events():
+            if ev.device_type != torch.autograd.DeviceType.CPU or not ev.kernels:
+                continue
+            if ev.cpu_children and any(c.kernels for c in ev.cpu_children):
+                continue
+            chain, q = [], ev.cpu_parent
+            while q is not None and len(chain) < 3:
+                chain.append(q.name.replace("autograd::engine::evaluate_function: ", "bwd:"))
+                q = q.cpu_parent
+            for k in ev.kernels:
+                items.append((ev.time_range.start, k.duration, k.name[:70], ev.name, str(ev.input_shapes)[:70], " < ".join(chain)[:90]))
+        items.sort()
+        os.makedirs(os.path.dirname(os.path.abspath(a.timeline)), exist_ok=True)
+        with open(a.timeline, "w") as f:
+            for i, (t, dur, kn, op, shp, ch) in enumerate(items):
+                f.write(f"{i:4d} {dur:8.1f} us  {kn:70s} | {op:28s} {shp:70s} | {ch}\n")
+        print(f"# wrote {len(items)} kernels to {a.timeline}")
     rows = collections.defaultdict(lambda: [0, 0.0, 0])
     for ev in prof.events():
         if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith("aten::"):

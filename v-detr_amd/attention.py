@@ -212,9 +212,11 @@ class _FusedAttention(Function):
         delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
         L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),
                 "attn_delta")
-        if shared and H == 4 and _fused_kv_ok(want_table):
-            ds = torch.empty_like(scores)  # [B, nQ, H, nK], unscaled
-            dkv = torch.empty((2, B, nK, HEAD_DIM), dtype=torch.float32, device=q.device)
+        if _fused_kv_ok(want_table) and ((shared and H == 4) or (not shared and not want_table)):
+            # one pass over the scores: dP~ = dO V^T, softmax / dropout backward, dV, dK; dS (unscaled) comes back for the
+            # table gradient and the dQ GEMM (attn_bwd_kv.hip)
+            ds = torch.empty_like(scores)  # [B, nQ, H, nK] (shared K/V) / [B, H, nQ, nK] (per head)
+            dkv = torch.empty((2, B, nK, k.shape[2]), dtype=torch.float32, device=q.device)
             nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
             ws = L.workspace(nbytes, q.device)
             L.check(lib.vdetr_attn_bwd_kv_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(scores), L.ptr(lse),
@@ -227,9 +229,21 @@ class _FusedAttention(Function):
                 ws = L.workspace(nbytes, q.device)
                 L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws), nbytes,
                                                      L.stream_ptr()), "attn_bwd_table")
-            dq = q.new_empty((B, nQ * H, HEAD_DIM))
-            torch.baddbmm(dq, ds.view(B, nQ * H, nK), k, beta=0.0, alpha=float(scale), out=dq)
-            dq, dk, dv = dq.view(B, nQ, C), dkv[0], dkv[1]
+            if shared:
+                dq = q.new_empty((B, nQ * H, HEAD_DIM))
+                torch.baddbmm(dq, ds.view(B, nQ * H, nK), k, beta=0.0, alpha=float(scale), out=dq)
+                dq = dq.view(B, nQ, C)
+            else:
+                ds_r = ds.view(B * H, nQ, nK)
+                k4 = k.reshape(B, nK, H, HEAD_DIM).permute(0, 2, 1, 3)
+                if B == 1:  # the GEMM reads the per-head K views and writes the [nQ, H*64] layout in place
+                    dq = q.new_empty((1, nQ, C))
+                    dq_r = dq.view(nQ, H, HEAD_DIM).permute(1, 0, 2)
+                    torch.baddbmm(dq_r, ds_r, k4[0], beta=0.0, alpha=float(scale), out=dq_r)
+                else:
+                    dq = torch.bmm(ds_r, k4.reshape(B * H, nK, HEAD_DIM)).mul_(float(scale))
+                    dq = dq.view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
+            dk, dv = dkv[0], dkv[1]
             if in_dtype == torch.bfloat16:
                 dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
             return (dq, dk, dv, dtable) + (None,) * 12

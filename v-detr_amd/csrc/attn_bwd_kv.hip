@@ -32,12 +32,54 @@ constexpr int kKvTileUnits = 3 * 4 * kKvOperandUnits;
 
 struct KvParams {
   AttnParams A;
-  const float* dout;  // [B][R][64], R = 4 nQ rows (query, head)
-  float* dk;          // [B][nK][64]
+  const float* dout;  // [B][nQ][H * 64]
+  float* dk;          // [B][nK][64] (shared K/V) or [B][nK][H * 64] (per head)
   float* dv;
-  uint4* pack;        // [B][NT][3 kinds][4][hi, lo][64 lanes] operand images of dO and q
-  int R, NT;          // rows, 32-row tiles
+  uint4* pack;        // [problems][NT][3 kinds][4][hi, lo][64 lanes] operand images of dO and q
+  int R, NT;          // rows of a problem, 32-row tiles
 };
+
+// One problem = one score matrix [R x nK] with its own 64-wide K / V:
+//   shared K/V (4 heads):  one per scene, rows r = (query, head) = 4 q + h, R = 4 nQ
+//   per-head K/V:          one per (scene, head), rows = queries, R = nQ
+struct KvProblem {
+  const float* q;      // row r at q + r * rstride
+  const float* dout;
+  const float* v;      // key k at v + k * A.v_stride
+  float* dk;           // key k at dk + k * ostride
+  float* dv;
+  size_t score_off;    // first element of the problem in scores / ds_out
+  size_t row_off;      // first element in lse / delta
+  int rstride, ostride, b, head;
+};
+template <bool PERHEAD>
+__device__ __forceinline__ KvProblem kv_problem(const KvParams& K, int prob) {
+  const AttnParams& P = K.A;
+  KvProblem p;
+  if (PERHEAD) {
+    const int b = prob / P.H, hh = prob - b * P.H, C = P.H * kDh;
+    p.b = b; p.head = hh;
+    p.q = P.q + (size_t)b * P.nQ * C + hh * kDh;
+    p.dout = K.dout + (size_t)b * P.nQ * C + hh * kDh;
+    p.rstride = C;
+    p.v = P.v + (size_t)b * P.nK * P.v_stride + hh * kDh;
+    p.dk = K.dk + (size_t)b * P.nK * C + hh * kDh;
+    p.dv = K.dv + (size_t)b * P.nK * C + hh * kDh;
+    p.ostride = C;
+  } else {
+    p.b = prob; p.head = 0;
+    p.q = P.q + (size_t)prob * K.R * kDh;
+    p.dout = K.dout + (size_t)prob * K.R * kDh;
+    p.rstride = kDh;
+    p.v = P.v + (size_t)prob * P.nK * P.v_stride;
+    p.dk = K.dk + (size_t)prob * P.nK * kDh;
+    p.dv = K.dv + (size_t)prob * P.nK * kDh;
+    p.ostride = kDh;
+  }
+  p.score_off = (size_t)prob * K.R * P.nK;
+  p.row_off = (size_t)prob * K.R;
+  return p;
+}
 
 // row (inside a 32 x 32 tile) of accumulator register v in lane group g = lane >> 5
 __device__ __forceinline__ constexpr int kv_row(int v, int g) { return (v & 3) + 8 * (v >> 2) + 4 * g; }
@@ -67,11 +109,13 @@ __device__ __forceinline__ f32x16 kv_mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16
 // kind 2:                   A of dK^T = q^T dS:  as kind 1 with q
 // (the contraction slot (g, e) of instruction t is the tile row kv_row(8 t + e, g): what accumulator register 8 t + e of
 // lane group g holds).  Also zero-fills dK / dV, which the main kernel accumulates into.
+template <bool PERHEAD>
 __global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K) {
   const AttnParams& P = K.A;
   const int R = K.R, NT = K.NT;
+  const int nprob = PERHEAD ? P.B * P.H : P.B;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
-  const long nunits = (long)P.B * NT * 12 * kWave;
+  const long nunits = (long)nprob * NT * 12 * kWave;
   for (long u = gid; u < nunits; u += stride) {
     const int lane = (int)(u & 63);
     long r = u >> 6;
@@ -79,20 +123,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K) {
     r >>= 2;
     const int kind = (int)(r % 3);
     const long bt = r / 3;
-    const int b = (int)(bt / NT), tile = (int)(bt - (long)b * NT), r0 = tile * 32;
+    const int prob = (int)(bt / NT), tile = (int)(bt - (long)prob * NT), r0 = tile * 32;
     const int l31 = lane & 31, g = lane >> 5;
-    const float* src = (kind == 2 ? P.q : K.dout) + (size_t)b * R * kDh;
+    const KvProblem pb = kv_problem<PERHEAD>(K, prob);
+    const float* src = kind == 2 ? pb.q : pb.dout;
     float x[8];
     if (kind == 0) {
       const int row = r0 + l31;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = row < R ? src[(size_t)row * kDh + 16 * sub + 8 * g + e] : 0.f;
+      for (int e = 0; e < 8; ++e) x[e] = row < R ? src[(size_t)row * pb.rstride + 16 * sub + 8 * g + e] : 0.f;
     } else {
       const int d = 32 * (sub >> 1) + l31, t = sub & 1;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int row = r0 + kv_row(8 * t + e, g);
-        x[e] = row < R ? src[(size_t)row * kDh + d] : 0.f;
+        x[e] = row < R ? src[(size_t)row * pb.rstride + d] : 0.f;
       }
     }
     bf16x8 hi, lo;
@@ -101,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K) {
     dst[lane] = __builtin_bit_cast(uint4, hi);
     dst[kWave + lane] = __builtin_bit_cast(uint4, lo);
   }
-  const long nz = (long)P.B * P.nK * kDh / 4;
+  const long nz = (long)P.B * P.nK * (PERHEAD ? P.H : 1) * kDh / 4;
   f32x4* zk = reinterpret_cast<f32x4*>(K.dk);
   f32x4* zv = reinterpret_cast<f32x4*>(K.dv);
   for (long i = gid; i < nz; i += stride) {
@@ -123,6 +168,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K) {
 //   4  the same for queries 2-3 and t = 1
 // Scores and dS go through buffer instructions whose range check does the masking: a lane whose key is past nK carries
 // offset 2^31, a row past the end is past num_records, so there is no branch around any load or store.
+template <bool PERHEAD>
 __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
   AttnParams P = K.A;
   attn_load_rng(P);
@@ -130,7 +176,9 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
-  const int kt = blockIdx.x >> 1, hf = blockIdx.x & 1, b = blockIdx.y;
+  const int kt = blockIdx.x >> 1, hf = blockIdx.x & 1, prob = blockIdx.y;
+  const KvProblem pb = kv_problem<PERHEAD>(K, prob);
+  const int b = pb.b;
   const int R = K.R, NT = K.NT, nK = P.nK;
   const int key = kt * 32 + l31;
   const bool kvalid = key < nK;
@@ -138,7 +186,7 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
   // B operand of dP~: V[key][16 s + 8 g + e] as (hi, lo), in the wave's LDS strip: [s][hi, lo][lane] 16-B units
   uint4* vstrip = reinterpret_cast<uint4*>(smem) + w * (8 * kWave) + lane;
   {
-    const float* vrow = P.v + ((size_t)b * nK + (kvalid ? key : 0)) * P.v_stride + 8 * g;
+    const float* vrow = pb.v + (size_t)(kvalid ? key : 0) * P.v_stride + 8 * g;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(vrow + 16 * s), c = *reinterpret_cast<const f32x4*>(vrow + 16 * s + 4);
@@ -159,12 +207,12 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
 
   using rsrc_t = __amdgpu_buffer_rsrc_t;
   const unsigned recs = (unsigned)((size_t)R * nK * 4);  // the whole offset goes into the VGPR: it is what the range check sees
-  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(P.scores + (size_t)b * R * nK, 0, (int)recs, 0x00020000);
-  const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(P.ds_out + (size_t)b * R * nK, 0, (int)recs, 0x00020000);
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(P.scores + pb.score_off, 0, (int)recs, 0x00020000);
+  const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(P.ds_out + pb.score_off, 0, (int)recs, 0x00020000);
   const int rowbytes = nK * 4;
   const unsigned lane_off = kvalid ? (unsigned)(4 * g * rowbytes + key * 4) : 0x80000000u;
-  const float* lse_b = P.lse + (size_t)b * R;
-  const float* delta_b = P.delta + (size_t)b * R;
+  const float* lse_b = P.lse + pb.row_off;
+  const float* delta_b = P.delta + pb.row_off;
   const bool has_mask = P.mask_kind == VDETR_MASK_BOOL;
   const unsigned char* mask_b = reinterpret_cast<const unsigned char*>(P.mask) + (size_t)b * P.nQ * nK + (kvalid ? key : 0);
 
@@ -185,12 +233,27 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
     const int r0 = tile * 32;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sv[i] = sn[i];
-    const uint4* pk = K.pack + ((size_t)b * NT + tile) * kKvTileUnits + lane;
+    const uint4* pk = K.pack + ((size_t)prob * NT + tile) * kKvTileUnits + lane;
     auto operand = [&](int kind, int sub, int hl) { return pk[((kind * 4 + sub) * 2 + hl) * kWave]; };
-    auto row_consts = [&](int a, f32x4& l4, f32x4& d4) {  // lse / delta of the 4 heads of query (r0 + 8 a + 4 g) / 4
-      const int rb = min(r0 + 8 * a + 4 * g, R - 4);
-      l4 = *reinterpret_cast<const f32x4*>(lse_b + rb);
-      d4 = *reinterpret_cast<const f32x4*>(delta_b + rb);
+    // lse / delta of the 8 rows of contraction step t (accumulator registers 8 t .. 8 t + 7 of this lane group)
+    auto row_consts = [&](int t, float (&lv)[8], float (&dv)[8]) {
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2) {
+        const int rb = r0 + 8 * (2 * t + a2) + 4 * g;
+        if (PERHEAD) {  // 4 consecutive queries, any nQ
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int row = min(rb + h, R - 1);
+            lv[4 * a2 + h] = lse_b[row];
+            dv[4 * a2 + h] = delta_b[row];
+          }
+        } else {        // the 4 heads of one query: one aligned 16-B load (R is a multiple of 4)
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_b + min(rb, R - 4));
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta_b + min(rb, R - 4));
+#pragma unroll
+          for (int h = 0; h < 4; ++h) { lv[4 * a2 + h] = l4[h]; dv[4 * a2 + h] = d4[h]; }
+        }
+      }
     };
     // ---- phase 0 ------------------------------------------------------------------------------------------------------
     uint4 opA[8], opB[8];  // [2 sub + hl]
@@ -201,9 +264,8 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
       opB[2 * mt] = operand(1, 2 * mt, 0); opB[2 * mt + 1] = operand(1, 2 * mt, 1);
       opB[4 + 2 * mt] = operand(2, 2 * mt, 0); opB[4 + 2 * mt + 1] = operand(2, 2 * mt, 1);
     }
-    f32x4 l4[2], d4[2];
-    row_consts(0, l4[0], d4[0]);
-    row_consts(1, l4[1], d4[1]);
+    float lv0[8], dv0[8];
+    row_consts(0, lv0, dv0);
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 1: dP~ tile = dO tile x V^T --------------------------------------------------------------------------------
     f32x16 dp;
@@ -221,9 +283,8 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
       opA[2 * mt] = operand(1, 2 * mt + 1, 0); opA[2 * mt + 1] = operand(1, 2 * mt + 1, 1);
       opA[4 + 2 * mt] = operand(2, 2 * mt + 1, 0); opA[4 + 2 * mt + 1] = operand(2, 2 * mt + 1, 1);
     }
-    f32x4 l4b[2], d4b[2];
-    row_consts(2, l4b[0], d4b[0]);
-    row_consts(3, l4b[1], d4b[1]);
+    float lv1[8], dv1[8];
+    row_consts(1, lv1, dv1);
     if (tile + kKvSlots < NT) load_scores(tile + kKvSlots, sn);
     __builtin_amdgcn_sched_barrier(0);
     // ---- phases 3, 4: softmax + dropout backward of 2 queries x 4 heads, then their contraction step -----------------------
@@ -233,22 +294,30 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
 #pragma unroll
       for (int a2 = 0; a2 < 2; ++a2) {
         const int a = 2 * t + a2;
-        const int rb = r0 + 8 * a + 4 * g;  // rows rb .. rb + 3 = the 4 heads of query rb / 4 (R is a multiple of 4)
-        const bool ok = rb < R && kvalid;
-        const int qi = min(rb, R - 4) >> 2;
-        const f32x4 lv = t ? l4b[a2] : l4[a2], dv = t ? d4b[a2] : d4[a2];
-        uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
-        if (P.drop_thresh) rnd = attn_rand4(P, b, qi, key, 0);
-        bool masked = false;
-        if (has_mask) masked = mask_b[(size_t)qi * nK] != 0;
+        const int rb = r0 + 8 * a + 4 * g;  // shared K/V: rows rb .. rb + 3 are the 4 heads of query rb / 4
         const unsigned voff = lane_off + (unsigned)((r0 + 8 * a) * rowbytes);
+        uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+        bool masked = false;
+        if (!PERHEAD) {
+          const int qi = min(rb, R - 4) >> 2;
+          if (P.drop_thresh) rnd = attn_rand4(P, b, qi, key, 0);
+          if (has_mask) masked = mask_b[(size_t)qi * nK] != 0;
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const int v = 4 * a + h;
-          const bool keep = pick4(rnd, h) >= P.drop_thresh;
-          const ScoreGrad gr = score_grad(sv[v], lv[h], keep, P.drop_scale, true, dp[v], dv[h], masked);
-          xp[4 * a2 + h] = ok ? gr.p_drop : 0.f;
-          xs[4 * a2 + h] = ok ? gr.ds : 0.f;
+          const int v = 4 * a + h, e = 4 * a2 + h;
+          const bool ok = rb + h < R && kvalid;
+          int pick = h;
+          if (PERHEAD) {
+            const int qi = min(rb + h, R - 1);
+            if (P.drop_thresh) rnd = attn_rand4(P, b, qi, key, pb.head >> 2);
+            if (has_mask) masked = mask_b[(size_t)qi * nK] != 0;
+            pick = pb.head & 3;
+          }
+          const bool keep = pick4(rnd, pick) >= P.drop_thresh;
+          const ScoreGrad gr = score_grad(sv[v], t ? lv1[e] : lv0[e], keep, P.drop_scale, true, dp[v], t ? dv1[e] : dv0[e], masked);
+          xp[e] = ok ? gr.p_drop : 0.f;
+          xs[e] = ok ? gr.ds : 0.f;
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(gr.ds), rd, (int)(voff + (unsigned)(h * rowbytes)), 0, 0);
         }
       }
@@ -310,7 +379,7 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
   for (int idx = tid; idx < 2 * 32 * kDh; idx += kKvThreads) {
     const int which = idx >> 11, kl = (idx >> 6) & 31, d = idx & 63;
     const int kg = kt * 32 + kl;
-    if (kg < nK) unsafeAtomicAdd((which ? K.dk : K.dv) + ((size_t)b * nK + kg) * kDh + d, smem[(which * 32 + kl) * kFinStride + d]);
+    if (kg < nK) unsafeAtomicAdd((which ? pb.dk : pb.dv) + (size_t)kg * pb.ostride + d, smem[(which * 32 + kl) * kFinStride + d]);
   }
 }
 
@@ -318,12 +387,27 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
 
 using namespace vdetr;
 
-static bool kv_supported(const vdetr_attn_desc* d) { return d && d->kind == VDETR_ATTN_SHARED_KV && d->H == 4; }
+static bool kv_supported(const vdetr_attn_desc* d) {
+  return d && ((d->kind == VDETR_ATTN_SHARED_KV && d->H == 4) || d->kind == VDETR_ATTN_PER_HEAD);
+}
+static size_t kv_rows(const vdetr_attn_desc* d) { return d->kind == VDETR_ATTN_PER_HEAD ? (size_t)d->nQ : (size_t)d->nQ * 4; }
+static size_t kv_problems(const vdetr_attn_desc* d) { return d->kind == VDETR_ATTN_PER_HEAD ? (size_t)d->B * d->H : (size_t)d->B; }
 
 extern "C" size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d) {
-  if (!kv_supported(d) || d->B <= 0 || d->nQ <= 0) return 0;
-  const size_t nt = ((size_t)d->nQ * 4 + 31) / 32;
-  return (size_t)d->B * nt * kKvTileUnits * sizeof(uint4) + 256;
+  if (!kv_supported(d) || d->B <= 0 || d->nQ <= 0 || d->H <= 0) return 0;
+  const size_t nt = (kv_rows(d) + 31) / 32;
+  return kv_problems(d) * nt * kKvTileUnits * sizeof(uint4) + 256;
+}
+
+template <bool PERHEAD>
+static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, hipStream_t st) {
+  hipLaunchKernelGGL(attn_bwd_kv_pack_kernel<PERHEAD>, dim3((unsigned)((pack_work + 255) / 256 < 2048 ? (pack_work + 255) / 256 : 2048)),
+                     dim3(256), 0, st, K);
+  if (int e = check_launch("attn_bwd_kv_pack")) return e;
+  const size_t lds = (size_t)4 * 64 * kWave * sizeof(float);
+  if (int e = set_lds(attn_bwd_kv_kernel<PERHEAD>, lds, "attn_bwd_kv")) return e;
+  hipLaunchKernelGGL(attn_bwd_kv_kernel<PERHEAD>, dim3(2 * nkt, nprob), dim3(kKvThreads), lds, st, K);
+  return check_launch("attn_bwd_kv");
 }
 
 extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout,
@@ -331,11 +415,13 @@ extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, c
                                      float* dv, void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
   KvParams K;
   if (int e = attn_fill_params(d, &K.A, "attn_bwd_kv")) return e;
-  VDETR_REQUIRE(kv_supported(d), "attn_bwd_kv: built for the shared-KV kind with 4 heads (kind %d, H %d)", d->kind, d->H);
+  VDETR_REQUIRE(kv_supported(d), "attn_bwd_kv: built for shared K/V with 4 heads and for per-head K/V (kind %d, H %d)", d->kind, d->H);
   VDETR_REQUIRE(q && v && dout && scores && lse && delta && ds_out && dk && dv, "attn_bwd_kv: null pointer");
   VDETR_REQUIRE(K.A.v_stride % 4 == 0 && (((uintptr_t)v | (uintptr_t)lse | (uintptr_t)delta | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
                 "attn_bwd_kv: v rows, lse, delta, dk and dv must be 16-B aligned");
-  VDETR_REQUIRE((size_t)d->nQ * 4 * d->nK * 4 < ((size_t)1 << 31), "attn_bwd_kv: a scene's score matrix (%d x %d x 4 heads) must stay below 2 GB", d->nQ, d->nK);
+  const size_t rows = kv_rows(d), nprob = kv_problems(d);
+  VDETR_REQUIRE(rows * d->nK * 4 < ((size_t)1 << 31), "attn_bwd_kv: a score matrix (%zu x %d) must stay below 2 GB", rows, d->nK);
+  VDETR_REQUIRE(nprob <= 65535, "attn_bwd_kv: %zu score matrices > 65535", nprob);
   const size_t need = vdetr_attn_bwd_kv_workspace_bytes(d);
   if (!workspace || workspace_bytes < need) {
     set_error("attn_bwd_kv: workspace %zu B < required %zu B", workspace_bytes, need);
@@ -345,17 +431,12 @@ extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, c
   K.A.scores = const_cast<float*>(scores); K.A.lse = const_cast<float*>(lse); K.A.delta = delta; K.A.ds_out = ds_out;
   K.dout = dout; K.dk = dk; K.dv = dv;
   K.pack = reinterpret_cast<uint4*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  K.R = d->nQ * 4;
+  K.R = (int)rows;
   K.NT = (K.R + 31) / 32;
-  hipStream_t st = (hipStream_t)stream;
-  const long units = (long)d->B * K.NT * 12 * kWave;
-  const long zero4 = (long)d->B * d->nK * kDh / 4;
+  const long units = (long)nprob * K.NT * 12 * kWave;
+  const long zero4 = (long)d->B * d->nK * (d->kind == VDETR_ATTN_PER_HEAD ? d->H : 1) * kDh / 4;
   const long work = units > zero4 ? units : zero4;
-  hipLaunchKernelGGL(attn_bwd_kv_pack_kernel, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)), dim3(256), 0, st, K);
-  if (int e = check_launch("attn_bwd_kv_pack")) return e;
-  const size_t lds = (size_t)4 * 64 * kWave * sizeof(float);
-  if (int e = set_lds(attn_bwd_kv_kernel, lds, "attn_bwd_kv")) return e;
   const int nkt = (d->nK + 31) / 32;
-  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(2 * nkt, d->B), dim3(kKvThreads), lds, st, K);
-  return check_launch("attn_bwd_kv");
+  return d->kind == VDETR_ATTN_PER_HEAD ? kv_launch<true>(K, nkt, (int)nprob, work, (hipStream_t)stream)
+                                         : kv_launch<false>(K, nkt, (int)nprob, work, (hipStream_t)stream);
 }
