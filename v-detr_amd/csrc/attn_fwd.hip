@@ -38,7 +38,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
 template <bool PERHEAD, bool RPE, bool BOX = false, bool BF16 = false>
-__global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
+__device__ __forceinline__ void attn_fwd_body(AttnParams P) {
   static_assert(!(BF16 && PERHEAD), "the bf16 path is built for the shared-KV kinds");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   attn_load_rng(P);
@@ -295,6 +295,28 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   }
 }
 
+template <bool PERHEAD, bool RPE, bool BOX = false, bool BF16 = false>
+__global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
+  attn_fwd_body<PERHEAD, RPE, BOX, BF16>(P);
+}
+
+// The RPE attention with the instantiation chosen per workgroup IN the kernel (its 4 queries are axis-aligned boxes or not:
+// the test attn_fwd_body repeats).  Launching the two instantiations side by side cost a 1024-workgroup launch of
+// immediate exits per layer (6 us with the 133 KB LDS reservation); both bodies use the same register budget.
+template <bool BF16>
+__global__ __launch_bounds__(kFwdThreads) void attn_fwd_rpe_auto_kernel(AttnParams P) {
+  const int g = (threadIdx.x & 63) >> 4;
+  const int q_pair = min((int)blockIdx.x * 4 + g, P.nQ - 1);
+  const float* vp = P.vertices + ((size_t)blockIdx.z * P.nQ + q_pair) * 24;
+  float vx[8], vy[8], vz[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
+  const bool box = P.cos_sin == nullptr && P.box_path && __all(rpe_box_pattern(vx, vy, vz));
+  if (box) attn_fwd_body<false, true, true, BF16>(P);
+  else attn_fwd_body<false, true, false, BF16>(P);
+}
+
+
 // merge of key-split partials: out = sum_s exp(lse_s - LSE) * o_s
 __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(AttnParams P) {
   const size_t rows = (size_t)P.B * P.nQ * P.H;
@@ -483,11 +505,17 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
     if (rpe) {
       static const int box_env = [] { const char* v = getenv("VDETR_FWD_BOX"); return v ? atoi(v) : 1; }();
       P.box_path = box_env && !d->cos_sin;  // rotated boxes never take it: skip the launch
-      if (int e = set_lds(attn_fwd_kernel<false, true, false>, lds, "attn_fwd")) return e;
-      hipLaunchKernelGGL((attn_fwd_kernel<false, true, false>), grid, dim3(kFwdThreads), lds, st, P);
-      if (P.box_path) {
-        if (int e = set_lds(attn_fwd_kernel<false, true, true>, lds, "attn_fwd")) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<false, true, true>), grid, dim3(kFwdThreads), lds, st, P);
+      static const int auto_env = [] { const char* v = getenv("VDETR_FWD_AUTO"); return v ? atoi(v) : 1; }();
+      if (P.box_path && auto_env) {  // one launch, the box / general body chosen per workgroup on the device
+        if (int e = set_lds(attn_fwd_rpe_auto_kernel<false>, lds, "attn_fwd")) return e;
+        hipLaunchKernelGGL((attn_fwd_rpe_auto_kernel<false>), grid, dim3(kFwdThreads), lds, st, P);
+      } else {
+        if (int e = set_lds(attn_fwd_kernel<false, true, false>, lds, "attn_fwd")) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<false, true, false>), grid, dim3(kFwdThreads), lds, st, P);
+        if (P.box_path) {
+          if (int e = set_lds(attn_fwd_kernel<false, true, true>, lds, "attn_fwd")) return e;
+          hipLaunchKernelGGL((attn_fwd_kernel<false, true, true>), grid, dim3(kFwdThreads), lds, st, P);
+        }
       }
     } else {
       if (int e = set_lds(attn_fwd_kernel<false, false>, lds, "attn_fwd")) return e;
@@ -537,11 +565,18 @@ extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, cons
   if (rpe) {
     static const int box_env = [] { const char* e = getenv("VDETR_FWD_BOX"); return e ? atoi(e) : 1; }();
     P.box_path = box_env && !d->cos_sin;
-    if (int e = set_lds(attn_fwd_kernel<false, true, false, true>, lds, "attn_fwd_bf16")) return e;
-    hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true>), grid, dim3(kFwdThreads), lds, st, P);
-    if (P.box_path) {
-      if (int e = set_lds(attn_fwd_kernel<false, true, true, true>, lds, "attn_fwd_bf16")) return e;
-      hipLaunchKernelGGL((attn_fwd_kernel<false, true, true, true>), grid, dim3(kFwdThreads), lds, st, P);
+    // (the merged kernel of the fp32 path spills 11 registers when built for bf16 operands: opt-in only)
+    static const int auto_env = [] { const char* e = getenv("VDETR_FWD_AUTO"); return e ? atoi(e) : 0; }();
+    if (P.box_path && auto_env == 2) {
+      if (int e = set_lds(attn_fwd_rpe_auto_kernel<true>, lds, "attn_fwd_bf16")) return e;
+      hipLaunchKernelGGL((attn_fwd_rpe_auto_kernel<true>), grid, dim3(kFwdThreads), lds, st, P);
+    } else {
+      if (int e = set_lds(attn_fwd_kernel<false, true, false, true>, lds, "attn_fwd_bf16")) return e;
+      hipLaunchKernelGGL((attn_fwd_kernel<false, true, false, true>), grid, dim3(kFwdThreads), lds, st, P);
+      if (P.box_path) {
+        if (int e = set_lds(attn_fwd_kernel<false, true, true, true>, lds, "attn_fwd_bf16")) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<false, true, true, true>), grid, dim3(kFwdThreads), lds, st, P);
+      }
     }
   } else {
     if (int e = set_lds(attn_fwd_kernel<false, false, false, true>, lds, "attn_fwd_bf16")) return e;

@@ -177,6 +177,61 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearPair(torch.autograd.Function):
+    """(x W1^T + b1, x W2^T + b2) for two [E, E] blocks that sit next to each other in one parameter (the q / k blocks of an
+    in_proj_weight): ONE batched GEMM forward (both outputs contiguous), and the input gradient as a GEMM plus an
+    accumulating GEMM instead of two GEMMs and an add.  Weight / bias gradients as `_Linear` (deferred when that is on)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ctx.save_for_backward(x, w1, b1, w2, b2)
+        E_out, E_in = w1.shape
+        x2 = x.reshape(-1, E_in)
+        W = torch.as_strided(w1, (2, E_out, E_in), (w2.storage_offset() - w1.storage_offset(), w1.stride(0), w1.stride(1)))
+        Bv = torch.as_strided(b1, (2, 1, E_out), (b2.storage_offset() - b1.storage_offset(), 0, b1.stride(0)))
+        y = torch.baddbmm(Bv, x2.unsqueeze(0).expand(2, -1, -1), W.transpose(1, 2))
+        return y[0].view(x.shape[:-1] + (E_out,)), y[1].view(x.shape[:-1] + (E_out,))
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        g1 = g1.reshape(-1, g1.shape[-1])
+        g2 = g2.reshape(-1, g2.shape[-1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(g1, w1)
+            torch.addmm(dx, g2, w2, out=dx)
+            dx = dx.view(x.shape)
+        x2 = x.reshape(-1, x.shape[-1])
+        grads = [None, None, None, None]
+        for i, (w, b, g) in enumerate(((w1, b1, g1), (w2, b2, g2))):
+            need_w, need_b = ctx.needs_input_grad[1 + 2 * i], ctx.needs_input_grad[2 + 2 * i]
+            if DeferredParamGrads.enabled and (need_w or need_b):
+                DeferredParamGrads.pending.append((w if need_w else None, b if need_b else None, g, x2))
+                continue
+            if need_w:
+                grads[2 * i] = torch.mm(g.t(), x2)
+            if need_b:
+                grads[2 * i + 1] = colsum(g if g.stride(1) == 1 else g.contiguous())
+        return (dx,) + tuple(grads)
+
+
+def linear_pair(x, w1, b1, w2, b2):
+    """(linear(x, w1, b1), linear(x, w2, b2)); one batched GEMM when the two blocks are equally shaped, equally strided
+    views into one storage (e.g. unbind of a packed projection weight) on the GPU."""
+    ok = (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and w1.shape == w2.shape and w1.stride() == w2.stride()
+          and b1 is not None and b2 is not None and b1.shape == b2.shape and b1.stride() == b2.stride()
+          and w1.untyped_storage().data_ptr() == w2.untyped_storage().data_ptr()
+          and b1.untyped_storage().data_ptr() == b2.untyped_storage().data_ptr()
+          and w2.storage_offset() > w1.storage_offset() and b2.storage_offset() > b1.storage_offset())
+    if not ok:
+        return linear(x, w1, b1), linear(x, w2, b2)
+    if DeferredParamGrads.pending:
+        raise RuntimeError("runtime.defer_weight_grads() is on but runtime.flush_weight_grads() was not called after "
+                           "the last backward pass")
+    return _LinearPair.apply(x, w1, b1, w2, b2)
+
+
 def linear(x, w, b=None):
     """F.linear; on the GPU with a bias, the backward computes the bias gradient with the one-launch column sum."""
     if b is not None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and (

@@ -31,7 +31,7 @@ from . import bn_act as BNA
 from . import attention as A
 from . import box_decode
 from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
-                      PositionEmbeddingLearned, buffers_alias, cat_params, get_clones, linear, slot_stack_params,
+                      PositionEmbeddingLearned, buffers_alias, cat_params, get_clones, linear, linear_pair, slot_stack_params,
                       stack_params)
 from .pc_util import morton_argsort, scale_points, shift_scale_points
 
@@ -317,7 +317,11 @@ class MultiheadSelfAttention(nn.Module):
         # or a joint q/k output (each slice's backward is a zero-filled full-size buffer + copy)
         wq, wk, wv = self.in_proj_weight.view(3, E, E).unbind(0)
         bq, bk, bv = self.in_proj_bias.view(3, E).unbind(0)
-        q, k, v = linear(query, wq, bq), linear(key, wk, bk), linear(value, wv, bv)
+        if query is key:  # the decoder's call (q = k = tgt + pos): both projections in one batched GEMM
+            q, k = linear_pair(query, wq, bq, wk, bk)
+        else:
+            q, k = linear(query, wq, bq), linear(key, wk, bk)
+        v = linear(value, wv, bv)
         L_, B = query.shape[0], query.shape[1]
         S = key.shape[0]
         mask = None
