@@ -204,6 +204,9 @@ size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d);
 int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* scores,
                           const float* lse, const float* delta, float* ds_out, float* dk, float* dv, void* workspace,
                           size_t workspace_bytes, vdetr_stream_t stream);
+/* Workgroup shape of vdetr_attn_bwd_kv_f32: 8 waves (default, the kernel alone on the chip) or 4 (one wave per SIMD with
+ * <= 256 registers: fits next to the table-gradient kernel when the caller runs that on another stream). */
+int vdetr_attn_bwd_kv_set_waves(int waves);
 /* The RPE table gradient alone, from the dS that vdetr_attn_bwd_kv_f32 wrote (same kernels, workspace and bwd_aux contract
  * as vdetr_attn_bwd_scores_f32 with a dtable; d->bwd_aux is required).  dtable [8,T,T,T,4]: caller zero-fills. */
 int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* ds, float* dtable, void* workspace,

@@ -214,7 +214,7 @@ def test_fused_key_side_backward_equals_gemm_path(monkeypatch, case):
         assert torch.equal(o, o2), f"{case} {name}: not reproducible"
 
 
-@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True)])
+@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True), ("3", False), ("3", True)])
 def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
     """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
     where every wave of every workgroup is busy (the size at which a packed-math code-generation problem once showed):
@@ -237,7 +237,7 @@ def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
 
     monkeypatch.setenv("VDETR_BWD_BOX", "0")
     ref = run()
-    monkeypatch.setenv("VDETR_BWD_BOX", variant)  # 1: attn_bwd_box.hip, 2: attn_bwd_box2.hip
+    monkeypatch.setenv("VDETR_BWD_BOX", variant)  # 1: attn_bwd_box.hip, 2: attn_bwd_box2.hip, 3: the same with fp32 products
     for rep in range(3):
         got = run()
         for name, r, o in zip(("dq", "dk", "dv"), ref, got):

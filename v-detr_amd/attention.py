@@ -54,6 +54,55 @@ DYNAMIC_BWD = os.environ.get("VDETR_BWD_DYNAMIC", "1") != "0"
 FUSED_KV_BWD = os.environ.get("VDETR_BWD_FUSED", "1") != "0"
 
 
+# The RPE-table gradient kernel (2.9 ms of a 9.5 ms step) feeds parameters only: nothing on the backward's critical path
+# waits for it.  With VDETR_BWD_ASYNC_TABLE=1 `fused_attention(..., table_grad_async=True)` launches it on a side stream;
+# the caller wraps the table with `join_table_grad` BEFORE the layers that use it (GlobalShareCrossAttention.precompute),
+# so that autograd reaches the join — main stream waits for the side stream — only after those layers' backward.
+# OFF by default — measured (captured C2 step): 9.62 ms in line, 10.07 ms with the side stream.  The table kernel keeps
+# 16 waves and 85 KB of LDS on every CU for its whole run (its workgroups pull queries until none are left); what the
+# main chain launches next to it either does not fit on a CU (the library's dQ GEMM sat behind it for 349 us) or shares
+# the VALU issue slots of a kernel that is bound by exactly those (attn_bwd_kv_kernel 52 -> 60 us, add_ln 6.4 -> 8.4 us).
+ASYNC_TABLE_GRAD = os.environ.get("VDETR_BWD_ASYNC_TABLE", "0") != "0"
+_side_streams = {}
+_side_keep = []  # tensors the side-stream kernels read, alive until the join
+
+
+def _dev_key(device):
+    device = torch.device(device)
+    return (device.type, device.index if device.index is not None else torch.cuda.current_device())
+
+
+def _side_stream(device):
+    key = _dev_key(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+class _JoinTableGrad(Function):
+    @staticmethod
+    def forward(ctx, t):
+        ctx.dev = t.device
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        side = _side_streams.get(_dev_key(ctx.dev))
+        if side is not None:
+            torch.cuda.current_stream(ctx.dev).wait_stream(side)
+        _side_keep.clear()
+        return g
+
+
+def join_table_grad(table):
+    """Identity on `table`; in the backward pass the current stream waits for the side stream on which the gradients of the
+    tables derived from it (`fused_attention(..., table_grad_async=True)`) were computed."""
+    if ASYNC_TABLE_GRAD and table is not None and table.is_cuda and table.requires_grad and torch.is_grad_enabled():
+        _side_stream(table.device)
+        return _JoinTableGrad.apply(table)
+    return table
+
+
 def _fused_kv_ok(want_table):
     if not FUSED_KV_BWD:
         return False
@@ -155,7 +204,7 @@ def _check_inputs(**tensors):
 class _FusedAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, table, vertices, xyz, cos_sin, mask, kind, H, scale, rpe, dropout_p, rng_state,
-                need_grad, salt):
+                need_grad, salt, table_async=False):
         B, nQ, C = q.shape
         nK = k.shape[1]
         assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
@@ -190,6 +239,7 @@ class _FusedAttention(Function):
         if need_grad:
             ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
             ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
+            ctx.table_async = bool(table_async)
         return out
 
     @staticmethod
@@ -217,18 +267,14 @@ class _FusedAttention(Function):
             # table gradient and the dQ GEMM (attn_bwd_kv.hip)
             ds = torch.empty_like(scores)  # [B, nQ, H, nK] (shared K/V) / [B, H, nQ, nK] (per head)
             dkv = torch.empty((2, B, nK, k.shape[2]), dtype=torch.float32, device=q.device)
+            run_async = want_table and ctx.table_async and ASYNC_TABLE_GRAD
+            lib.vdetr_attn_bwd_kv_set_waves(4 if run_async or _side_keep else 8)  # 4: fits next to the table kernel
             nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
             ws = L.workspace(nbytes, q.device)
             L.check(lib.vdetr_attn_bwd_kv_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(scores), L.ptr(lse),
                                               L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws), nbytes,
                                               L.stream_ptr()), "attn_bwd_kv")
-            dtable = None
-            if want_table:
-                dtable = _take_zeros(table, tuple(table.shape), table.dtype)
-                nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
-                ws = L.workspace(nbytes, q.device)
-                L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws), nbytes,
-                                                     L.stream_ptr()), "attn_bwd_table")
+            # dQ first: its library GEMM does not fit next to the table kernel on a CU and would sit behind it
             if shared:
                 dq = q.new_empty((B, nQ * H, HEAD_DIM))
                 torch.baddbmm(dq, ds.view(B, nQ * H, nK), k, beta=0.0, alpha=float(scale), out=dq)
@@ -243,10 +289,26 @@ class _FusedAttention(Function):
                 else:
                     dq = torch.bmm(ds_r, k4.reshape(B * H, nK, HEAD_DIM)).mul_(float(scale))
                     dq = dq.view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
+            dtable = None
+            if want_table:
+                dtable = _take_zeros(table, tuple(table.shape), table.dtype)
+                nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
+                if run_async:
+                    side = _side_stream(q.device)
+                    side.wait_stream(torch.cuda.current_stream(q.device))  # dS, the zeroed dtable and bwd_aux are ready
+                    with torch.cuda.stream(side):
+                        ws2 = L.workspace(nbytes, q.device)
+                        L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws2), nbytes,
+                                                             L.stream_ptr()), "attn_bwd_table")
+                    _side_keep.append((ds, dtable, ws2, aux, table, vertices, xyz, mask))
+                else:
+                    ws = L.workspace(nbytes, q.device)
+                    L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws), nbytes,
+                                                         L.stream_ptr()), "attn_bwd_table")
             dk, dv = dkv[0], dkv[1]
             if in_dtype == torch.bfloat16:
                 dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-            return (dq, dk, dv, dtable) + (None,) * 12
+            return (dq, dk, dv, dtable) + (None,) * 13
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)
@@ -292,7 +354,7 @@ class _FusedAttention(Function):
                 dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         if in_dtype == torch.bfloat16:
             dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-        return (dq, dk, dv, dtable) + (None,) * 12
+        return (dq, dk, dv, dtable) + (None,) * 13
 
 
 def _kv_layout(t, B, nK):
@@ -306,7 +368,7 @@ def _kv_layout(t, B, nK):
 
 
 def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
-                    cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0):
+                    cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0, table_grad_async=False):
     """out[B,nQ,H*64] = dropout(softmax(scale * q k^T + rpe + mask)) v.
 
     q [B,nQ,H*64]; k,v [B,nK,64] (shared_kv) or [B,nK,H*64]; table [8,T,T,T,H]; vertices [B,nQ,8,3];
@@ -330,7 +392,8 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
             cos_sin = cos_sin.detach().contiguous()
     k, v = _kv_layout(k, B, nK), _kv_layout(v, B, nK)
     return _FusedAttention.apply(q.contiguous(), k, v, table, vertices, xyz, cos_sin, mask,
-                                 kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt))
+                                 kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt),
+                                 bool(table_grad_async))
 
 
 def attention_probabilities(q, k, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,

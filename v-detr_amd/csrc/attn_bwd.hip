@@ -21,7 +21,7 @@ namespace vdetr {
 
 int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
 int launch_attn_bwd_box(const AttnParams& P, int grid, hipStream_t st);   // attn_bwd_box.hip
-int launch_attn_bwd_box2(const AttnParams& P, int grid, hipStream_t st);  // attn_bwd_box2.hip
+int launch_attn_bwd_box2(const AttnParams& P, int grid, hipStream_t st, bool f32_products);  // attn_bwd_box2.hip
 
 constexpr int kBwdThreads = 1024;
 
@@ -792,7 +792,7 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
     else e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st);
     if (e) return e;
     if (box)
-      if (int e2 = box_env == 2 ? launch_attn_bwd_box2(P, grid, st) : launch_attn_bwd_box(P, grid, st)) return e2;
+      if (int e2 = box_env >= 2 ? launch_attn_bwd_box2(P, grid, st, box_env == 3) : launch_attn_bwd_box(P, grid, st)) return e2;
   } else {
     const size_t lds = dtable ? (size_t)table_floats * sizeof(float) : 16;
     if (variant == 0) {

@@ -36,7 +36,13 @@ constexpr int kB2StripWords = kWave * kB2RecStride + kB2SlotWords + 2 * kB2MaxHa
 
 size_t attn_bwd_box2_lds_bytes() { return (size_t)4 * kB2T * kB2T * kB2T * 4 * 4 + (size_t)kB2Waves * kB2StripWords * 4; }
 
+// F32: the products go through v_mfma_f32_16x16x4_f32 as they are (k-slot = one pair, 4 per instruction, 2 per stream)
+// instead of as four bf16 cross terms (8 pairs per v_mfma_f32_16x16x32_bf16).  The matrix unit then runs ~4x longer —
+// it was 3 % busy — and the VALU no longer splits: one multiply per operand element instead of multiply + mask +
+// subtract + two byte permutes, and groups are padded to pairs, not quads.  The kernel is VALU-bound.
+template <bool F32>
 __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P) {
+  constexpr int HS = F32 ? 2 : 4;  // pairs per half-slot (a stream's share of one matrix instruction)
   constexpr int T = kB2T, TT = T * T, T3 = TT * T;
   constexpr int table_words = 4 * T3 * 4;
   if (P.bwd_aux[4] != 0 || P.bwd_aux[5] == 0) return;  // a query is not an axis-aligned box: the general kernel runs instead
@@ -179,11 +185,11 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
           const int jl = __builtin_amdgcn_readlane(J, leader);
           const unsigned long long m = __ballot(J == jl);
           todo &= ~m;
-          const int hs = (__builtin_popcountll(m) + 3) >> 2;  // half-slots (4 pairs each) of this group
+          const int hs = (__builtin_popcountll(m) + HS - 1) / HS;  // half-slots of this group
           const int st = n1 < n0 ? 1 : 0;
           const int base = st ? n1 : n0;
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          if (J == jl) myslot = (base + (rank >> 2)) * 8 + st * 4 + (rank & 3);
+          if (J == jl) myslot = (base + rank / HS) * (2 * HS) + st * HS + rank % HS;
           if (lane < hs) reinterpret_cast<reci_t*>(meta)[st * kB2MaxHalf + base + lane] = jl;
           if (st) n1 += hs; else n0 += hs;
         }
@@ -195,8 +201,16 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       int Jcur = reinterpret_cast<const reci_t*>(meta)[o_gl * kB2MaxHalf];
       for (int i = 0; i < nmfma; ++i) {
-        const unsigned sp = reinterpret_cast<const recs_t*>(slot_tab)[i * 4 + kk];  // slots 8 i + 2 kk, + 1
         const int Jnext = reinterpret_cast<const reci_t*>(meta)[o_gl * kB2MaxHalf + i + 1];
+        if (F32) {  // slot 4 i + kk: one pair per lane group
+          const unsigned p = reinterpret_cast<const recb_t*>(slot_tab)[i * 4 + kk];
+          const bool occupied = p != 0xFFu;
+          const char* r = rec + (p & 63u) * (kB2RecStride * 4);
+          const float u = *reinterpret_cast<const rec1_t*>(r + a_offz) * *reinterpret_cast<const rec1_t*>(r + a_offy);
+          const float t = *reinterpret_cast<const rec1_t*>(r + b_offx) * *reinterpret_cast<const rec1_t*>(r + b_offd);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32((a_active && occupied) ? u : 0.f, occupied ? t : 0.f, acc, 0, 0, 0);
+        } else {
+        const unsigned sp = reinterpret_cast<const recs_t*>(slot_tab)[i * 4 + kk];  // slots 8 i + 2 kk, + 1
         i32x4 aw, bw;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -217,6 +231,7 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
           bw[2 * e + 1] = (int)__builtin_amdgcn_perm((unsigned)__float_as_int(tl), (unsigned)__float_as_int(tl), 0x07060706u);
         }
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw), __builtin_bit_cast(bf16x8, bw), acc, 0, 0, 0);
+        }
         // ---- a stream's group is complete when the next half-slot belongs to another group: flush its 128 sums ----------
         if (Jcur != Jnext) {
           if (Jcur >= 0) {
@@ -242,10 +257,15 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
   for (int i = tid; i < table_words; i += kB2Threads) dst[i] = (float)tab[i] * fix_inv;
 }
 
-int launch_attn_bwd_box2(const AttnParams& P, int grid, hipStream_t st) {
+int launch_attn_bwd_box2(const AttnParams& P, int grid, hipStream_t st, bool f32_products) {
   const size_t lds = attn_bwd_box2_lds_bytes();
-  if (int e = set_lds(attn_bwd_box2_kernel, lds, "attn_bwd_box2")) return e;
-  hipLaunchKernelGGL(attn_bwd_box2_kernel, dim3(grid), dim3(kB2Threads), lds, st, P);
+  if (f32_products) {
+    if (int e = set_lds(attn_bwd_box2_kernel<true>, lds, "attn_bwd_box2")) return e;
+    hipLaunchKernelGGL(attn_bwd_box2_kernel<true>, dim3(grid), dim3(kB2Threads), lds, st, P);
+  } else {
+    if (int e = set_lds(attn_bwd_box2_kernel<false>, lds, "attn_bwd_box2")) return e;
+    hipLaunchKernelGGL(attn_bwd_box2_kernel<false>, dim3(grid), dim3(kB2Threads), lds, st, P);
+  }
   return check_launch("attn_bwd_box2");
 }
 

@@ -17,6 +17,10 @@
 // workgroups add their sums onto a zeroed output — two commutative float adds, the same bits in either order.
 #include "attn_common.h"
 
+#include <stdlib.h>
+
+#include <atomic>
+
 namespace vdetr {
 
 int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
@@ -24,9 +28,8 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kKvWaves = 8;
-constexpr int kKvThreads = kKvWaves * kWave;
-constexpr int kKvSlots = 2 * kKvWaves;          // row slots per key tile: 2 workgroups x 8 waves
+// waves per workgroup: 8 (2 per SIMD) when the kernel has the chip to itself; 4 (1 per SIMD, <= 256 registers) fit NEXT to
+// the table-gradient kernel's 4 x 64 registers per SIMD when that runs on a side stream (attention.py)
 constexpr int kKvOperandUnits = 2 * kWave;      // one packed operand: (hi, lo) x 64 lanes, 16 B each
 constexpr int kKvTileUnits = 3 * 4 * kKvOperandUnits;
 
@@ -168,8 +171,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K) {
 //   4  the same for queries 2-3 and t = 1
 // Scores and dS go through buffer instructions whose range check does the masking: a lane whose key is past nK carries
 // offset 2^31, a row past the end is past num_records, so there is no branch around any load or store.
-template <bool PERHEAD>
-__global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
+template <bool PERHEAD, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void attn_bwd_kv_kernel(KvParams K) {
+  constexpr int kKvWaves = WAVES, kKvThreads = WAVES * kWave, kKvSlots = 2 * WAVES;  // row slots per key tile: 2 workgroups
   AttnParams P = K.A;
   attn_load_rng(P);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -352,18 +356,13 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
       accK[0][i] += src[(32 + i) * kWave]; accK[1][i] += src[(48 + i) * kWave];
     }
   };
-  if (w >= 4) put(w - 4);
-  __syncthreads();
-  if (w < 4) add(w);
-  __syncthreads();
-  if (w == 2 || w == 3) put(w - 2);
-  __syncthreads();
-  if (w < 2) add(w);
-  __syncthreads();
-  if (w == 1) put(0);
-  __syncthreads();
-  if (w == 0) add(0);
-  __syncthreads();
+#pragma unroll
+  for (int half = kKvWaves / 2; half >= 1; half >>= 1) {  // waves [half, 2 half) hand their sums to waves [0, half)
+    if (w >= half && w < 2 * half) put(w - half);
+    __syncthreads();
+    if (w < half) add(w);
+    __syncthreads();
+  }
   constexpr int kFinStride = kDh + 1;
   if (w == 0) {  // fin[which][key 32][d 64 (+1)]: accumulator (d = 32 mt + kv_row(i, g), key = l31)
 #pragma unroll
@@ -387,6 +386,15 @@ __global__ __launch_bounds__(kKvThreads) void attn_bwd_kv_kernel(KvParams K) {
 
 using namespace vdetr;
 
+// 8 (default; VDETR_KV_WAVES overrides) or 4 waves per workgroup, see the note at the kernel
+static std::atomic<int> g_kv_waves{[] { const char* v = getenv("VDETR_KV_WAVES"); return v && atoi(v) == 4 ? 4 : 8; }()};
+
+extern "C" int vdetr_attn_bwd_kv_set_waves(int waves) {
+  VDETR_REQUIRE(waves == 4 || waves == 8, "attn_bwd_kv_set_waves: %d (4 or 8)", waves);
+  g_kv_waves.store(waves);
+  return VDETR_OK;
+}
+
 static bool kv_supported(const vdetr_attn_desc* d) {
   return d && ((d->kind == VDETR_ATTN_SHARED_KV && d->H == 4) || d->kind == VDETR_ATTN_PER_HEAD);
 }
@@ -399,14 +407,16 @@ extern "C" size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d) {
   return kv_problems(d) * nt * kKvTileUnits * sizeof(uint4) + 256;
 }
 
-template <bool PERHEAD>
+template <bool PERHEAD, int WAVES>
 static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, hipStream_t st) {
   hipLaunchKernelGGL(attn_bwd_kv_pack_kernel<PERHEAD>, dim3((unsigned)((pack_work + 255) / 256 < 2048 ? (pack_work + 255) / 256 : 2048)),
                      dim3(256), 0, st, K);
   if (int e = check_launch("attn_bwd_kv_pack")) return e;
-  const size_t lds = (size_t)4 * 64 * kWave * sizeof(float);
-  if (int e = set_lds(attn_bwd_kv_kernel<PERHEAD>, lds, "attn_bwd_kv")) return e;
-  hipLaunchKernelGGL(attn_bwd_kv_kernel<PERHEAD>, dim3(2 * nkt, nprob), dim3(kKvThreads), lds, st, K);
+  const size_t strips = (size_t)WAVES * 8 * kWave * sizeof(uint4), tree = (size_t)(WAVES / 2) * 64 * kWave * sizeof(float);
+  const size_t fin = (size_t)2 * 32 * (kDh + 1) * sizeof(float);
+  const size_t lds = strips > tree ? (strips > fin ? strips : fin) : (tree > fin ? tree : fin);
+  if (int e = set_lds(attn_bwd_kv_kernel<PERHEAD, WAVES>, lds, "attn_bwd_kv")) return e;
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<PERHEAD, WAVES>), dim3(2 * nkt, nprob), dim3(WAVES * kWave), lds, st, K);
   return check_launch("attn_bwd_kv");
 }
 
@@ -437,6 +447,9 @@ extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, c
   const long zero4 = (long)d->B * d->nK * (d->kind == VDETR_ATTN_PER_HEAD ? d->H : 1) * kDh / 4;
   const long work = units > zero4 ? units : zero4;
   const int nkt = (d->nK + 31) / 32;
-  return d->kind == VDETR_ATTN_PER_HEAD ? kv_launch<true>(K, nkt, (int)nprob, work, (hipStream_t)stream)
-                                         : kv_launch<false>(K, nkt, (int)nprob, work, (hipStream_t)stream);
+  const bool four = g_kv_waves.load() == 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->kind == VDETR_ATTN_PER_HEAD)
+    return four ? kv_launch<true, 4>(K, nkt, (int)nprob, work, st) : kv_launch<true, 8>(K, nkt, (int)nprob, work, st);
+  return four ? kv_launch<false, 4>(K, nkt, (int)nprob, work, st) : kv_launch<false, 8>(K, nkt, (int)nprob, work, st);
 }

@@ -214,6 +214,9 @@ class GlobalShareCrossAttention(nn.Module):
         coords = mods[0].relative_coords_table.reshape(1, -1, 3).expand(8 * n, -1, -1)
         hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
         tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H).unbind(0)
+        # the table gradients are computed on a side stream (attention.py: ASYNC_TABLE_GRAD); autograd reaches these joins —
+        # they were created before any decoder layer — only after every layer's backward, and waits there
+        tables = [A.join_table_grad(t) for t in tables]
         return [(parts[2 * i], parts[2 * i + 1], tables[i]) for i in range(n)]
 
     def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None,
@@ -240,7 +243,8 @@ class GlobalShareCrossAttention(nn.Module):
             q, k, v = (t if t.dtype == self.core_dtype else t.to(self.core_dtype) for t in (q, k, v))
         x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, table=tables,
                               rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
-                              attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt)
+                              attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt,
+                              table_grad_async=cache is not None)
         attn = None
         if self.return_attn:
             attn = A.attention_probabilities(q32.float(), k32.float(), num_heads=self.num_heads, scale=self.scale, shared_kv=True,
