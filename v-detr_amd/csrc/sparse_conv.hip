@@ -340,11 +340,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP
 // memory round trips and 64 KB of stores per workgroup; a persistent workgroup pays that chain once.
 // B operand addresses are a uniform row pointer (scalar registers) + a per-lane column offset: no 64-bit vector address
 // arithmetic in the loop (the plain kernel: 16 v_lshl_add_u64 per K-step).
-template <bool TRANS, int KSUB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 1 ? 2 : 1))) void sp_pairs_gemm_persistent_kernel(
+// fp32 operands on the bf16 matrix unit: x = hi + lo (both round-to-nearest bf16), products as the three leading cross terms
+// hi hi + hi lo + lo hi: relative error of a product <= 2^-16, fp32 accumulation.  v_mfma_f32_16x16x4_f32 runs at 1/16 of
+// the bf16 rate (MI355X_MICROARCH.md): the fp32 form of these kernels sat at 45-55 % of THAT peak.
+typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void sp_split8(const f32x4& x0, const f32x4& x1, sp_bf16x8& hi, sp_bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+    hi[e] = h0; hi[4 + e] = h1;
+    lo[e] = (__bf16)(x0[e] - (float)h0); lo[4 + e] = (__bf16)(x1[e] - (float)h1);
+  }
+}
+__device__ __forceinline__ f32x4 sp_mfma3(const sp_bf16x8& ah, const sp_bf16x8& al, const sp_bf16x8& bh, const sp_bf16x8& bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+
+template <bool TRANS, int KSUB, bool SPLIT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (KSUB == 1 || SPLIT) ? 2 : 1))) void sp_pairs_gemm_persistent_kernel(
     const float* __restrict__ X, const int* __restrict__ arow, const float* __restrict__ W, const int* __restrict__ tiles,
     int ntiles, int CA, int CB, int wk_stride, float* __restrict__ Y, int* __restrict__ ticket) {
   constexpr int RT = 4, CT = 4;
+  static_assert(!SPLIT || KSUB == 2, "the split-bf16 form contracts 32 channels per step");
   // ticket != NULL (default; VDETR_SP_TICKET=0 for the static stride): work items are handed out by a device counter (the first
   // gridDim.x statically), so that a CU busy with another stream's long kernel — the next scene's 9 ms sampling — takes no
   // items instead of making its workgroup start a round late: worth 1.1-2 ms of 26.7 in the training step.  (Tried: every
@@ -450,6 +469,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 
 #pragma unroll
       for (int t = 0; t < CT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto mfma_step = [&](const f32x4 (&a)[KSUB][RT], const f32x4 (&b)[KSUB][CT]) {
+      if (SPLIT) {  // (KSUB == 2) the lane's 2 x 4 contraction values of a K-step of 32 are one bf16 operand: 3 instead of 8 MFMAs
+        sp_bf16x8 ah[RT], al[RT], bh[CT], bl[CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) sp_split8(a[0][i], a[KSUB - 1][i], ah[i], al[i]);
+#pragma unroll
+        for (int t = 0; t < CT; ++t) sp_split8(b[0][t], b[KSUB - 1][t], bh[t], bl[t]);
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[i][t] = sp_mfma3(ah[i], al[i], bh[t], bl[t], acc[i][t]);
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < KSUB; ++u)
 #pragma unroll
@@ -507,7 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSUB == 
 // The chunk's pairs are walked SB at a time: the 256 threads stage the gathered X rows (TCI channels) and dY rows (TCO
 // channels) in LDS (float4 per thread, rows of >= 256 B: coalesced), double-buffered, and the waves read their MFMA operands
 // from there (a pair is one k-slot: A[m = ci][k] = X[pair][ci], B[k][n = co] = dY[pair][co]).
-template <int WR, int WC, int RT, int CT, int SB>
+template <int WR, int WC, int RT, int CT, int SB, bool SPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP_WAVES))) void sp_pairs_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                             const int* __restrict__ pin, const int* __restrict__ pout,
                                                             const int* __restrict__ chunks, int Cin, int Cout,
@@ -580,6 +611,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, VDETR_SP
       row_load(ri, ro);
       index_load(j + 2 * SB, ri_n, ro_n);
     }
+    if (SPLIT) {  // 32 pairs per matrix instruction: lane (c, g) holds pairs 8 g .. 8 g + 7 of a group for its channel
+      static_assert(!SPLIT || SB % 32 == 0, "the split-bf16 form walks 32 pairs per step");
+#pragma unroll
+      for (int s = 0; s < SB / 32; ++s) {
+        sp_bf16x8 ah[RT], al[RT], bh[CT], bl[CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          f32x4 x0, x1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x0[e] = lx[buf][32 * s + 8 * g + e][(wr * RT + i) * 16 + c];
+            x1[e] = lx[buf][32 * s + 8 * g + 4 + e][(wr * RT + i) * 16 + c];
+          }
+          sp_split8(x0, x1, ah[i], al[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+          f32x4 y0, y1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            y0[e] = ly[buf][32 * s + 8 * g + e][(wc * CT + t) * 16 + c];
+            y1[e] = ly[buf][32 * s + 8 * g + 4 + e][(wc * CT + t) * 16 + c];
+          }
+          sp_split8(y0, y1, bh[t], bl[t]);
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[i][t] = sp_mfma3(ah[i], al[i], bh[t], bl[t], acc[i][t]);
+      }
+    } else
 #pragma unroll
     for (int s = 0; s < SB / 4; ++s) {
       float a[RT], b[CT];
@@ -678,14 +740,22 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
         }
       }
       const int cus = D.cus;
-      const int per_cu = ksub == 2 ? 1 : 2;
+      // workgroups per CU: the fp32 K-step of 32 is 1.7 us of MFMA (covers a gathered row's latency with one workgroup);
+      // the split-bf16 one is 0.4 us: two workgroups keep twice the loads in flight (VDETR_SP_PER_CU overrides)
+      static const int split_pc = getenv("VDETR_SP_SPLIT") ? atoi(getenv("VDETR_SP_SPLIT")) : 1;
+      static const int per_cu_env = getenv("VDETR_SP_PER_CU") ? atoi(getenv("VDETR_SP_PER_CU")) : 0;
+      const int per_cu = per_cu_env > 0 ? per_cu_env : (ksub == 2 && !split_pc ? 1 : 2);
       const int nwork = ntiles * ceil_div(CB, 128);
       // `spare` CUs are left to whatever else is running (A/B switch): with a grid of exactly one workgroup per CU, a CU that is
       // busy with another stream's long kernel (the next scene's 9 ms sampling) makes its workgroup start a round late
       static const int spare = getenv("VDETR_SP_SPARE_CUS") ? atoi(getenv("VDETR_SP_SPARE_CUS")) : 0;
       const int slots = per_cu * (cus - spare) > 0 ? per_cu * (cus - spare) : 1;
       dim3 grid(nwork < slots ? nwork : slots);
-      auto kern = ksub == 2 ? (transposed ? sp_pairs_gemm_persistent_kernel<true, 2> : sp_pairs_gemm_persistent_kernel<false, 2>)
+      // VDETR_SP_SPLIT=0: exact fp32 products (v_mfma_f32_16x16x4_f32) everywhere; default: split-bf16 products where the
+      // contraction is a multiple of 64 channels (the wide layers, which hold the time)
+      static const int split = getenv("VDETR_SP_SPLIT") ? atoi(getenv("VDETR_SP_SPLIT")) : 1;
+      auto kern = ksub == 2 ? (split ? (transposed ? sp_pairs_gemm_persistent_kernel<true, 2, true> : sp_pairs_gemm_persistent_kernel<false, 2, true>)
+                                     : (transposed ? sp_pairs_gemm_persistent_kernel<true, 2> : sp_pairs_gemm_persistent_kernel<false, 2>))
                             : (transposed ? sp_pairs_gemm_persistent_kernel<true, 1> : sp_pairs_gemm_persistent_kernel<false, 1>);
       int* ticket = nullptr;
       static const int use_ticket = getenv("VDETR_SP_TICKET") ? atoi(getenv("VDETR_SP_TICKET")) : 1;  // A/B switch
@@ -735,8 +805,13 @@ extern "C" int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const i
 #ifndef VDETR_SP_WGRAD_SB
 #define VDETR_SP_WGRAD_SB 16
 #endif
-    hipLaunchKernelGGL((sp_pairs_wgrad_kernel<2, 2, 4, 4, VDETR_SP_WGRAD_SB>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin,
-                       pout, chunks, cin, cout, partials);
+    static const int split = getenv("VDETR_SP_SPLIT") ? atoi(getenv("VDETR_SP_SPLIT")) : 1;
+    if (split)
+      hipLaunchKernelGGL((sp_pairs_wgrad_kernel<2, 2, 4, 4, 32, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin, pout,
+                         chunks, cin, cout, partials);
+    else
+      hipLaunchKernelGGL((sp_pairs_wgrad_kernel<2, 2, 4, 4, VDETR_SP_WGRAD_SB>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin,
+                         pout, chunks, cin, cout, partials);
   } else {
     dim3 grid(nchunks, ceil_div(cin, 64), ceil_div(cout, 64));
     hipLaunchKernelGGL((sp_pairs_wgrad_kernel<4, 1, 1, 4, 32>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin, pout, chunks,
