@@ -541,9 +541,17 @@ def kernel_rooflines(cfg_name, device, reps=20):
         d.bwd_aux = aux.data_ptr()
         L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), st), "attn_delta")
 
+    # what the step runs (attention.py): the key-side pass writes dS, the table kernels read it
+    dkv = torch.empty((2, B, nK, 64), device=device)
+    wkv = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
+    ws_kv = L.workspace(wkv, device)
+
+    def kv():
+        L.check(lib.vdetr_attn_bwd_kv_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(scores), L.ptr(lse), L.ptr(delta),
+                                          L.ptr(dscore), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws_kv), wkv, st), "attn_bwd_kv")
+
     def bwd():
-        L.check(lib.vdetr_attn_bwd_scores_f32(ctypes.byref(d), L.ptr(scores), L.ptr(dprob), L.ptr(lse), L.ptr(delta),
-                                              L.ptr(probs), L.ptr(dscore), L.ptr(dtable), L.ptr(ws), wsb, st), "attn_bwd")
+        L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(dscore), L.ptr(dtable), L.ptr(ws), wsb, st), "attn_bwd_table")
 
     def timeit(fn, prep=None):
         ts = []
@@ -560,15 +568,21 @@ def kernel_rooflines(cfg_name, device, reps=20):
         return float(np.mean(ts))
 
     t_fwd = timeit(fwd)
+    bwd_prep()
+    t_kv = timeit(kv)
     t_bwd = timeit(bwd, bwd_prep)
     pairs = B * nQ * nK
     flops = 4.0 * H * pairs * 64                       # QK^T + PV (MFMA-eligible), SURVEY.md §8d
-    bytes_bwd = 4.0 * 4 * H * pairs                    # S, dP~ read + P~, dS written (fp32)
+    bytes_bwd = 4.0 * H * pairs                        # dS read once (fp32); the kernel is VALU-bound, see valu_issue
+    bytes_kv = 2.0 * 4.0 * H * pairs                   # S read, dS written (fp32); operands and dK / dV are ~1 % of that
     fwd_obj = {"kernel": "attn_fwd_kernel<shared_kv,rpe> (3DV-RPE cross-attention forward)", "bound": "mfma",
                "achieved": flops / t_fwd / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                "frac": flops / t_fwd / 1e12 / 157.3, "traffic": None, "launch_us": t_fwd * 1e6,
                "rpe_lookups_per_s": 8.0 * pairs / t_fwd}
-    bwd_obj = {"kernel": "attn_bwd_box2_kernel (softmax backward + RPE table gradient, axis-aligned boxes)", "bound": "hbm",
+    kv_obj = {"kernel": "attn_bwd_kv_kernel (dO V^T, softmax backward, dV, dK in one pass over the scores; + its operand-packing launch)",
+              "bound": "hbm", "achieved": bytes_kv / t_kv / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": bytes_kv / t_kv / 1e9 / 8000.0,
+              "traffic": None, "launch_us": t_kv * 1e6}
+    bwd_obj = {"kernel": "attn_bwd_box2_kernel (RPE table gradient from dS, axis-aligned boxes)", "bound": "hbm",
                "achieved": bytes_bwd / t_bwd / 1e9, "peak": 8000.0, "unit": "GB/s",
                "frac": bytes_bwd / t_bwd / 1e9 / 8000.0, "traffic": None, "launch_us": t_bwd * 1e6,
                "rpe_scatter_per_s": 8.0 * pairs / t_bwd}
@@ -578,6 +592,8 @@ def kernel_rooflines(cfg_name, device, reps=20):
         if cfg_name == "c2":
             fwd_obj["traffic"] = tr["attn_fwd_kernel<false,true,true>"]["bytes"]
             bwd_obj["traffic"] = tr["attn_bwd_box2_kernel"]["bytes"]
+            if "attn_bwd_kv_kernel" in tr:
+                kv_obj["traffic"] = tr["attn_bwd_kv_kernel"]["bytes"]
             vi = tr["attn_bwd_box2_kernel"].get("valu_wave_insts")
             if vi:  # what actually bounds the kernel: VALU issue (1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction)
                 bwd_obj["valu_issue"] = {"wave_insts": vi, "limit_us": vi / 614.4e9 * 1e6, "frac": vi / 614.4e9 / t_bwd,
@@ -585,6 +601,7 @@ def kernel_rooflines(cfg_name, device, reps=20):
                                                  "the kernel is VALU-bound, the HBM fraction above is low by construction"}
     except (OSError, KeyError, IndexError, ValueError):
         pass
+    bwd_obj["key_side_pass"] = kv_obj
     return fwd_obj, bwd_obj
 
 
@@ -870,6 +887,8 @@ def main():
         "arith": {"activations": "f32" if dtype == "f32" else "f32 residual stream; q / k / v of the cross attention stored as bf16",
                   "qk_pv": "v_mfma_f32_16x16x4_f32 (exact f32)" if dtype == "f32" else "v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16, f32 accumulate (self-attention: f32)", "softmax_log2_table_lookup": "f32",
                   "dtable_products": "split-bf16 2^-15 (two bf16 terms per f32 factor)", "dtable_accum": "int32 fixed point in LDS",
+                  "backward_contractions": "dO V^T, dV = P^T dO, dK = dS^T q: f32 operands as hi + lo bf16 on v_mfma_f32_32x32x16_bf16, "
+                                           "three cross terms (2^-16 per product), f32 accumulate; dQ = dS K: library f32 GEMM",
                   "note": "dtype f32 is the arithmetic of every tensor the model sees; the RPE-table gradient alone is formed from "
                           "2-term split-bf16 products accumulated in int32 fixed point (DESIGN.md 4.4b): 4.3e-4 relative L2 against the fp64 oracle at this layer size (tests/test_gpu_attention.py::test_full_size_forward_backward_vs_oracle)"},
     }
@@ -943,7 +962,7 @@ def main():
                 "ms_per_step": ms, "scenes_per_s": world * 1e3 / ms, "n_gpus": world, "geometry_ms": bt.geometry_ms, "input_points": 40000,
                 "grad_allreduce_bytes": bt.reducer.grad_bytes() if bt.reducer.active else 0,
                 "voxels_per_stride": bt.voxels, "backbone_parameters": sum(p.numel() for p in bt.bb_params), "loss": bloss,
-                "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP kernel maps, fused pair-list convolutions on the fp32 matrix cores, fused BatchNorm; eager) -> FPS tokens -> "
+                "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP kernel maps, fused pair-list convolutions — wide layers as split-bf16 products (2^-16 each) on the bf16 matrix unit, f32 accumulate —, fused BatchNorm; eager) -> FPS tokens -> "
                         "decoder step (captured hipGraph) -> backbone backward -> clip + AdamW over all 79 M parameters; "
                         "the geometry (voxel sites, kernel maps, pair lists) and FPS indices of the scene after next are built from its "
                         "coordinates on a side stream inside every timed step (a two-scene loader queue); geometry_ms = that work alone"}
@@ -999,9 +1018,19 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             leg("cpu_baseline", cpu_leg)
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        print(json.dumps(result), flush=True)
+    # Leave in order: everybody done, the group destroyed, then the process ends without running the interpreter's teardown —
+    # captured graphs that hold RCCL nodes were seen to crash in their destructors at exit (core dump after the line above).
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        try:
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] process-group shutdown: {type(exc).__name__}: {exc}", file=sys.stderr)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/rp_kb -o kb -- python3 tools/kernel_ben
 kdb=$(find /tmp/rp_kb -name '*.db' | head -1)
 [ -n "$kdb" ] && python3 tools/rocprof_summary.py $kdb > $out/kernel_bench_rocprof.txt 2>&1
 python3 tools/kernel_bench.py c2 --indexing > $out/kernel_bench_indexing.txt 2>&1
+# one cross-attention layer's backward: library-GEMM path vs the fused key-side pass, and the pieces alone (HIP events)
+python3 tools/bwd_layer_bench.py > $out/bwd_layer_bench.txt 2>&1 < /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$c -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_$c.log 2>&1
   f=$(find /tmp/rp_$c -name '*counter_collection.csv' | head -1)
@@ -67,5 +69,8 @@ bash tools/pmc_spconv.sh $tag > /dev/null 2>&1; cat gpurun_out/pmc_sp_$tag/pmc_s
 python3 tools/pmc_traffic.py $out > $out/pmc_traffic.json 2>/dev/null
 python3 tools/fps_variants.py > $out/fps_variants.txt 2>&1 < /dev/null
 [ -x tools/probes/bin/lat_probe ] && timeout 120 tools/probes/bin/lat_probe > $out/lat_probe.txt 2>&1
+# the launcher path the driver uses for N > 1, with one rank (RCCL communicator, gradient all-reduce captured in the graph)
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-criterion-leg --no-backbone-leg --no-roofline > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "exit code $?" >> $out/bench_torchrun_1rank.err
+for c in c1 c4 c5; do python3 bench.py --config $c --no-cpu-baseline --no-criterion-leg --no-backbone-leg > $out/bench_$c.json 2> $out/bench_$c.err; done
 VDETR_PMC_TRAFFIC=$out/pmc_traffic.json python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400
