@@ -230,6 +230,18 @@ class Trainer:
 
     _capture_stream = None  # one per process: a second Trainer on the same model meets the first one's AccumulateGrad nodes
 
+    @staticmethod
+    def quiesce_collectives():
+        """Before a capture begins: nothing of the warm-up's collectives may still sit in ProcessGroupNCCL's watchdog list.
+        The watchdog thread polls the completion events of outstanding collectives every 100 ms, and an event query from
+        ANOTHER thread while this thread captures is an error under the default (global) capture mode — seen as an
+        intermittent SIGABRT of the rank ("operation not permitted when stream is capturing", 1 run in 3).  After a device
+        synchronise every collective is complete; half a second lets the watchdog see that and drop them.  The captures
+        below also run in thread-local error mode, which permits such calls from other threads."""
+        torch.cuda.synchronize()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            time.sleep(0.5)
+
     def capture(self):
         if Trainer._capture_stream is None:
             Trainer._capture_stream = torch.cuda.Stream()
@@ -242,20 +254,21 @@ class Trainer:
                     self.reducer.reduce_all()  # real updates: the replicas must stay identical
                 self._update()
         torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
+        Trainer.quiesce_collectives()
         # Capture on the stream the warm-up ran on: the warm-up's autograd graph (kept alive by tensors the modules hold)
         # owns one AccumulateGrad node per parameter, bound to the stream it was created on; under a different capture
         # stream the engine runs those nodes on the old stream and stitches cross-stream dependencies into the graph.
         same = os.environ.get("VDETR_CAPTURE_SAME_STREAM", "1") != "0"
         self.g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_main, **({"stream": s} if same else {})):
+        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local", **({"stream": s} if same else {})):
             self._fwd_bwd()
             if self.phased or not self.reducer.active:
                 self._update()
         if self.reducer.active and not self.phased:
             self.reducer.reduce_all()  # the flat gradient buffer, in slices; not captured (RCCL outside the graph)
+            Trainer.quiesce_collectives()
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, **({"stream": s} if same else {})):
+            with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local", **({"stream": s} if same else {})):
                 self._update()
 
     def _fps_lookahead(self):
@@ -387,9 +400,9 @@ class BackboneTrainer:
             for _ in range(3):
                 self._decoder_fwd_bwd()
         torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
+        Trainer.quiesce_collectives()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
             self._decoder_fwd_bwd()
 
     def step(self):

@@ -69,6 +69,26 @@ def test_round2_entry_points_reject_bad_arguments():
     assert lib.vdetr_sp_pairs_gemm_f32(None, None, None, None, 0, 16, 16, 0, None, None) == 0   # no tiles: no-op
 
 
+def test_round3_attention_backward_entry_points_reject_bad_arguments():
+    """vdetr_attn_bwd_kv_f32 / vdetr_attn_bwd_table_f32 / the workgroup-shape setter (round 3): status codes + message."""
+    from vdetr_amd import _lib
+    lib = _lib.lib()
+    d = _lib.AttnDesc()
+    d.kind, d.B, d.H, d.nQ, d.nK, d.scale = _lib.VDETR_ATTN_SHARED_KV, 1, 4, 64, 100, 0.125
+    # packed operand images: 3 kinds x 4 sub-operands x (hi, lo) x 64 lanes x 16 B per 32-row tile; rows = 4 heads x nQ
+    assert lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d)) == (64 * 4 // 32) * 3 * 4 * 2 * 64 * 16 + 256
+    assert lib.vdetr_attn_bwd_kv_f32(ctypes.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == 1
+    assert b"attn_bwd_kv" in lib.vdetr_last_error()
+    d.kind = _lib.VDETR_ATTN_PER_HEAD
+    d.H = 3  # per-head K/V: one problem per (scene, head), rows = queries
+    assert lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d)) == 3 * (64 // 32) * 3 * 4 * 2 * 64 * 16 + 256
+    d.kind, d.H = _lib.VDETR_ATTN_SHARED_KV, 4
+    assert lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), None, None, None, 0, None) == 1   # no dS, no table, no bwd_aux
+    assert b"attn_bwd_table" in lib.vdetr_last_error()
+    assert lib.vdetr_attn_bwd_kv_set_waves(5) == 1 and b"set_waves" in lib.vdetr_last_error()
+    assert lib.vdetr_attn_bwd_kv_set_waves(4) == 0 and lib.vdetr_attn_bwd_kv_set_waves(8) == 0
+
+
 def test_ops_refuse_cpu_tensors():
     """No CPU fallback: the reference asserts "CPU not supported" (sampling.cpp:36,62,84)."""
     from vdetr_amd import pointnet2_utils as PU
