@@ -37,6 +37,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
+// -DVDETR_FWD_SPLIT=1 (build option, OFF by default): fp32 operands on the bf16 matrix unit, x = hi + lo (bf16, round-to-nearest),
+// products as the three leading cross terms (2^-16 per product, fp32 accumulate): QK^T is 6 instructions of 16 cycles instead of
+// 16 of 32, PV 12 of 8 instead of 16 of 32 — and matrix time ADDS to VALU time on this chip.  Measured: forward
+// 176 -> 161 us, captured C2 step 9.55 -> 9.44 ms; every output stays within 1e-3 of the oracle, but scores that are off by 1e-5
+// instead of 1e-7 flip near-tie proposal selections downstream: the whole-model parity case with three ragged scenes then has 39
+// token rows of the feature gradient outside its tolerance (tests/test_gpu_model.py).  The forward keeps exact fp32 products.
+#ifndef VDETR_FWD_SPLIT
+#define VDETR_FWD_SPLIT 0
+#endif
+constexpr bool kFwdSplit = VDETR_FWD_SPLIT != 0;
+__device__ __forceinline__ void fwd_split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h0 = (__bf16)x0[e], h1 = (__bf16)x1[e];
+    hi[e] = h0; hi[4 + e] = h1;
+    lo[e] = (__bf16)(x0[e] - (float)h0); lo[4 + e] = (__bf16)(x1[e] - (float)h1);
+  }
+}
+__device__ __forceinline__ void fwd_split4(const f32x4& x, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h = (__bf16)x[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(x[e] - (float)h);
+  }
+}
+
 template <bool PERHEAD, bool RPE, bool BOX = false, bool BF16 = false>
 __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
   static_assert(!(BF16 && PERHEAD), "the bf16 path is built for the shared-KV kinds");
@@ -88,6 +115,15 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
       }
+    }
+  }
+  bf16x8 qh[2], ql[2];  // split form of the scaled q operand: instruction m covers d = 16 g + 8 m + e
+  if constexpr (!BF16 && kFwdSplit) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      const f32x4 x0 = {qa[8 * mm], qa[8 * mm + 1], qa[8 * mm + 2], qa[8 * mm + 3]};
+      const f32x4 x1 = {qa[8 * mm + 4], qa[8 * mm + 5], qa[8 * mm + 6], qa[8 * mm + 7]};
+      fwd_split8(x0, x1, qh[mm], ql[mm]);
     }
   }
   // query index of accumulator register r
@@ -152,10 +188,19 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
     if (tile + kFwdWaves < tile_end) fetch(tile + kFwdWaves, nxt);
     // ---- S = Q K^T --------------------------------------------------------------------------------
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (BF16) {
+    if constexpr (BF16) {
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa8[0], ops.kb8[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa8[1], ops.kb8[1], acc, 0, 0, 0);
       acc *= P.scale;
+    } else if constexpr (kFwdSplit) {
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        bf16x8 kh, kl;
+        fwd_split8(ops.kb[2 * mm], ops.kb[2 * mm + 1], kh, kl);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[mm], kh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[mm], kl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[mm], kh, acc, 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < 16; ++s)
@@ -226,12 +271,24 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
     const f32x4 pa = *reinterpret_cast<const f32x4*>(ppad + c * kPPad + 4 * g);
     __builtin_amdgcn_wave_barrier();
     // ---- O += P V ------------------------------------------------------------------------------------
-    if (BF16) {
+    if constexpr (BF16) {
       const bf16x4 pb = {(__bf16)pa[0], (__bf16)pa[1], (__bf16)pa[2], (__bf16)pa[3]};  // P[row c][keys 4g..4g+3]
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const bf16x4 vt = {ops.vb4[0][t], ops.vb4[1][t], ops.vb4[2][t], ops.vb4[3][t]};  // V[keys 4g..4g+3][d = 4c + t]
         o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, pb), __builtin_bit_cast(short4v, vt), o[t], 0, 0, 0);
+      }
+    } else if constexpr (kFwdSplit) {
+      bf16x4 ph, pl;
+      fwd_split4(pa, ph, pl);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 vt = {ops.vb[0][t], ops.vb[1][t], ops.vb[2][t], ops.vb[3][t]};  // V[keys 4g..4g+3][d = 4c + t]
+        bf16x4 vh, vl;
+        fwd_split4(vt, vh, vl);
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, pl), __builtin_bit_cast(short4v, vh), o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, ph), __builtin_bit_cast(short4v, vl), o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, ph), __builtin_bit_cast(short4v, vh), o[t], 0, 0, 0);
       }
     } else {
 #pragma unroll
