@@ -535,11 +535,10 @@ def kernel_rooflines(cfg_name, device, reps=20):
     lse = torch.empty((B, nQ, H), device=device)
     scores = torch.empty((B, nQ, H, nK), device=device)
     dout = torch.randn((B, nQ, H * 64), generator=g).to(device) * 1e-3
-    dprob = torch.bmm(dout.view(B, nQ * H, 64), v.transpose(1, 2)).view(B, nQ, H, nK).contiguous()  # dP~ = dO V^T
     delta = torch.zeros((B, nQ, H), device=device)
     aux = torch.zeros(8, dtype=torch.int32, device=device)  # norm maxima, query counters, non-box count (vdetr_hip.h)
     dtable = torch.zeros_like(table)
-    probs, dscore = torch.empty_like(scores), torch.empty_like(dprob)
+    dscore = torch.empty_like(scores)  # dS [B, nQ, H, nK], written by the key-side pass
     wsf = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
     wsb = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
     ws = L.workspace(max(wsf, wsb), device)
