@@ -60,9 +60,11 @@ def get_3d_box_batch_tensor(box_size, angle, center):
     """(.., 3) size (l,w,h), (..) yaw, (.., 3) camera-frame centre -> (.., 8, 3) corners (box_util.py:319-352)."""
     sx, sy, sz = _corner_signs(box_size)
     l, w, h = box_size[..., 0:1], box_size[..., 1:2], box_size[..., 2:3]
-    local = torch.stack((l * sx, h * sy, w * sz), dim=-1)  # (.., 8, 3)
-    R = roty_batch_tensor(angle)                            # (.., 3, 3)
-    corners = torch.matmul(local, R.transpose(-1, -2))
+    lx, ly, lz = l * sx, h * sy, w * sz                     # (.., 8) each
+    # local @ roty(angle)^T written out (R = [[c, 0, s], [0, 1, 0], [-s, 0, c]]): as a batched 8 x 3 x 3 matmul this was a
+    # 48 us library launch per call for 0.3 MFLOP, plus the 8 launches that assemble R
+    c, s = torch.cos(angle).unsqueeze(-1), torch.sin(angle).unsqueeze(-1)
+    corners = torch.stack((lx * c + lz * s, ly, lz * c - lx * s), dim=-1)
     return corners + center.unsqueeze(-2)
 
 
