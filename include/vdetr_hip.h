@@ -204,6 +204,11 @@ size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d);
 int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* scores,
                           const float* lse, const float* delta, float* ds_out, float* dk, float* dv, void* workspace,
                           size_t workspace_bytes, vdetr_stream_t stream);
+/* vdetr_attn_delta_f32 + vdetr_attn_bwd_kv_f32 with the delta / bwd_aux work done by the first workgroups of the pass's
+ * operand-packing launch (one launch less per attention backward): `out` is the forward's output, `delta` is WRITTEN. */
+int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* out,
+                                const float* scores, const float* lse, float* delta, float* ds_out, float* dk, float* dv,
+                                void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
 /* Workgroup shape of vdetr_attn_bwd_kv_f32: 8 waves (default, the kernel alone on the chip) or 4 (one wave per SIMD with
  * <= 256 registers: fits next to the table-gradient kernel when the caller runs that on another stream). */
 int vdetr_attn_bwd_kv_set_waves(int waves);

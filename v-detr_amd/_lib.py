@@ -180,6 +180,7 @@ _SIGNATURES = {
     "vdetr_attn_bwd_scores_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_kv_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
     "vdetr_attn_bwd_kv_f32": (c_int, [ctypes.POINTER(AttnDesc)] + [c_void_p] * 10 + [c_size_t, c_void_p]),
+    "vdetr_attn_bwd_kv_delta_f32": (c_int, [ctypes.POINTER(AttnDesc)] + [c_void_p] * 11 + [c_size_t, c_void_p]),
     "vdetr_attn_bwd_kv_set_waves": (c_int, [c_int]),
     "vdetr_attn_bwd_table_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_delta_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -260,9 +260,11 @@ class _FusedAttention(Function):
             aux = _take_zeros(q, (8,), torch.int32)  # 5 words used (vdetr_hip.h: bwd_aux)
             d.bwd_aux = aux.data_ptr()
         delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
-        L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),
-                "attn_delta")
-        if _fused_kv_ok(want_table) and ((shared and H == 4) or (not shared and not want_table)):
+        fused = _fused_kv_ok(want_table) and ((shared and H == 4) or (not shared and not want_table))
+        if not fused:  # (the fused pass computes delta in the first workgroups of its operand-packing launch)
+            L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),
+                    "attn_delta")
+        if fused:
             # one pass over the scores: dP~ = dO V^T, softmax / dropout backward, dV, dK; dS (unscaled) comes back for the
             # table gradient and the dQ GEMM (attn_bwd_kv.hip)
             ds = torch.empty_like(scores)  # [B, nQ, H, nK] (shared K/V) / [B, H, nQ, nK] (per head)
@@ -271,9 +273,9 @@ class _FusedAttention(Function):
             lib.vdetr_attn_bwd_kv_set_waves(4 if run_async or _side_keep else 8)  # 4: fits next to the table kernel
             nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
             ws = L.workspace(nbytes, q.device)
-            L.check(lib.vdetr_attn_bwd_kv_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(scores), L.ptr(lse),
-                                              L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws), nbytes,
-                                              L.stream_ptr()), "attn_bwd_kv")
+            L.check(lib.vdetr_attn_bwd_kv_delta_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(out), L.ptr(scores),
+                                                    L.ptr(lse), L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws),
+                                                    nbytes, L.stream_ptr()), "attn_bwd_kv")
             # dQ first: its library GEMM does not fit next to the table kernel on a CU and would sit behind it
             if shared:
                 dq = q.new_empty((B, nQ * H, HEAD_DIM))

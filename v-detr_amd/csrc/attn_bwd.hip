@@ -629,53 +629,10 @@ __global__ __launch_bounds__(512) void issue_probe_kernel(int mode, int iters, f
   if (t == -1.f) sink[0] = t;
 }
 
-// delta[row] = sum_d dO[b,q,h,d] * O[b,q,h,d]: one wave per (b, q), lane l holds element h*64 + l of the four heads.
-// With `aux` (zeroed by the caller) the launch also leaves max_row |dO row|^2 in aux[0] and, from extra workgroups that
-// walk the key rows, max_key |V row|^2 in aux[1] (bit patterns of non-negative floats under atomicMax).
-constexpr int kDeltaKeys = 16;  // keys per wave in the |V row| pass
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                        float* __restrict__ delta, int B, int nQ, int H, int perhead,
-                                                        unsigned* aux, const float* __restrict__ v, int nK, int v_stride,
-                                                        int qblocks, const float* __restrict__ vertices) {
+// delta launch: see attn_delta_body (attn_common.h); also run as the first workgroups of attn_bwd_kv.hip's preparation launch
+__global__ __launch_bounds__(256) void attn_delta_kernel(DeltaArgs A) {
   __shared__ float wmax[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float n2max = 0.f;
-  int slot = 0;
-  if ((int)blockIdx.x >= qblocks) {  // |V row|^2 (shared-KV: 64 floats per key), kDeltaKeys keys per wave
-    slot = 1;
-    const int key0 = (((int)blockIdx.x - qblocks) * 4 + wv) * kDeltaKeys;
-#pragma unroll 4
-    for (int i = 0; i < kDeltaKeys; ++i) {
-      const int key = key0 + i;
-      const float x = key < B * nK ? v[(size_t)key * v_stride + lane] : 0.f;
-      n2max = fmaxf(n2max, wave_allsum_f32(x * x));
-    }
-  } else {
-    const int row = blockIdx.x * 4 + wv;
-    if (row < B * nQ) {
-      const int b = row / nQ, q = row - b * nQ;
-      for (int h = 0; h < H; ++h) {
-        const size_t e = ((size_t)row * H + h) * 64 + lane;
-        const float g = dout[e];
-        const float s = wave_allsum_f32(g * out[e]);
-        if (aux) n2max = fmaxf(n2max, wave_allsum_f32(g * g));
-        if (lane == 0) delta[perhead ? ((size_t)b * H + h) * nQ + q : (size_t)row * H + h] = s;
-      }
-      if (aux && vertices && row == 0 && lane == 0) aux[5] = 1u;  // "word 4 is meaningful": without it the box kernels stay off
-      if (aux && vertices) {  // aux[4] += 1 for a query whose 8 RPE vertices are not an axis-aligned box (attn_common.h)
-        const float* vp = vertices + (size_t)row * 24;
-        const int i = lane & 7;
-        const bool ok = vp[i * 3] == vp[rpe_box_xi(i) ? 6 : 0] && vp[i * 3 + 1] == vp[rpe_box_yi(i) ? 4 : 1] &&
-                        vp[i * 3 + 2] == vp[rpe_box_zi(i) ? 14 : 2];
-        if (!__all(ok) && lane == 0) atomicAdd(aux + 4, 1u);
-      }
-    }
-  }
-  if (!aux) return;
-  if (lane == 0) wmax[wv] = n2max;
-  __syncthreads();  // one atomic per workgroup: thousands of atomics on one word serialise (measured 32 us per launch)
-  if (threadIdx.x == 0)
-    atomicMax(aux + slot, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+  attn_delta_body(A, (int)blockIdx.x, wmax);
 }
 
 // keep-mask dump (test hook)
@@ -833,9 +790,9 @@ extern "C" int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout,
   VDETR_REQUIRE(!norms || (v && d->kind == VDETR_ATTN_SHARED_KV), "attn_delta: bwd_aux needs v and the shared-KV kind");
   const int qblocks = ceil_div((long)d->B * d->nQ, 4);
   const int vblocks = norms ? ceil_div((long)d->B * d->nK, 4 * kDeltaKeys) : 0;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(qblocks + vblocks), dim3(256), 0, (hipStream_t)stream, dout, out, delta, d->B,
-                     d->nQ, d->H, d->kind == VDETR_ATTN_PER_HEAD ? 1 : 0, d->bwd_aux, v, d->nK,
-                     d->v_row_stride ? d->v_row_stride : 64, qblocks, d->table && !d->cos_sin ? d->vertices : nullptr);
+  DeltaArgs A;
+  attn_delta_args(d, dout, out, v, delta, &A);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(qblocks + vblocks), dim3(256), 0, (hipStream_t)stream, A);
   return check_launch("attn_delta");
 }
 

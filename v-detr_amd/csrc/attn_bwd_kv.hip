@@ -112,12 +112,19 @@ __device__ __forceinline__ f32x16 kv_mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16
 // kind 2:                   A of dK^T = q^T dS:  as kind 1 with q
 // (the contraction slot (g, e) of instruction t is the tile row kv_row(8 t + e, g): what accumulator register 8 t + e of
 // lane group g holds).  Also zero-fills dK / dV, which the main kernel accumulates into.
+// The launch's first `ndelta` workgroups compute delta = rowsum(dO * O) and the words of bwd_aux (attn_delta_body) when the
+// caller asks for it (vdetr_attn_bwd_kv_delta_f32): the two preparations are independent and 8 + 6 us apart.
 template <bool PERHEAD>
-__global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K) {
+__global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K, DeltaArgs D, int ndelta) {
+  if ((int)blockIdx.x < ndelta) {
+    __shared__ float wmax[4];
+    attn_delta_body(D, (int)blockIdx.x, wmax);
+    return;
+  }
   const AttnParams& P = K.A;
   const int R = K.R, NT = K.NT;
   const int nprob = PERHEAD ? P.B * P.H : P.B;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+  const long gid = (long)((int)blockIdx.x - ndelta) * 256 + threadIdx.x, stride = (long)((int)gridDim.x - ndelta) * 256;
   const long nunits = (long)nprob * NT * 12 * kWave;
   for (long u = gid; u < nunits; u += stride) {
     const int lane = (int)(u & 63);
@@ -408,9 +415,9 @@ extern "C" size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d) {
 }
 
 template <bool PERHEAD, int WAVES>
-static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, hipStream_t st) {
-  hipLaunchKernelGGL(attn_bwd_kv_pack_kernel<PERHEAD>, dim3((unsigned)((pack_work + 255) / 256 < 2048 ? (pack_work + 255) / 256 : 2048)),
-                     dim3(256), 0, st, K);
+static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, const DeltaArgs& D, int ndelta, hipStream_t st) {
+  const unsigned pack_blocks = (unsigned)((pack_work + 255) / 256 < 2048 ? (pack_work + 255) / 256 : 2048);
+  hipLaunchKernelGGL(attn_bwd_kv_pack_kernel<PERHEAD>, dim3(pack_blocks + (unsigned)ndelta), dim3(256), 0, st, K, D, ndelta);
   if (int e = check_launch("attn_bwd_kv_pack")) return e;
   const size_t strips = (size_t)WAVES * 8 * kWave * sizeof(uint4), tree = (size_t)(WAVES / 2) * 64 * kWave * sizeof(float);
   const size_t fin = (size_t)2 * 32 * (kDh + 1) * sizeof(float);
@@ -420,9 +427,9 @@ static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, hipS
   return check_launch("attn_bwd_kv");
 }
 
-extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout,
-                                     const float* scores, const float* lse, const float* delta, float* ds_out, float* dk,
-                                     float* dv, void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+static int kv_run(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* out,
+                  const float* scores, const float* lse, float* delta, float* ds_out, float* dk, float* dv, void* workspace,
+                  size_t workspace_bytes, vdetr_stream_t stream) {
   KvParams K;
   if (int e = attn_fill_params(d, &K.A, "attn_bwd_kv")) return e;
   VDETR_REQUIRE(kv_supported(d), "attn_bwd_kv: built for shared K/V with 4 heads and for per-head K/V (kind %d, H %d)", d->kind, d->H);
@@ -449,7 +456,27 @@ extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, c
   const int nkt = (d->nK + 31) / 32;
   const bool four = g_kv_waves.load() == 4;
   hipStream_t st = (hipStream_t)stream;
+  DeltaArgs D{};
+  int ndelta = 0;
+  if (out) {  // delta (and bwd_aux) produced by the first workgroups of the packing launch
+    VDETR_REQUIRE(!d->bwd_aux || d->kind == VDETR_ATTN_SHARED_KV, "attn_bwd_kv: bwd_aux needs the shared-KV kind");
+    attn_delta_args(d, dout, out, v, delta, &D);
+    ndelta = D.qblocks + D.vblocks;
+  }
   if (d->kind == VDETR_ATTN_PER_HEAD)
-    return four ? kv_launch<true, 4>(K, nkt, (int)nprob, work, st) : kv_launch<true, 8>(K, nkt, (int)nprob, work, st);
-  return four ? kv_launch<false, 4>(K, nkt, (int)nprob, work, st) : kv_launch<false, 8>(K, nkt, (int)nprob, work, st);
+    return four ? kv_launch<true, 4>(K, nkt, (int)nprob, work, D, ndelta, st) : kv_launch<true, 8>(K, nkt, (int)nprob, work, D, ndelta, st);
+  return four ? kv_launch<false, 4>(K, nkt, (int)nprob, work, D, ndelta, st) : kv_launch<false, 8>(K, nkt, (int)nprob, work, D, ndelta, st);
+}
+
+extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout,
+                                     const float* scores, const float* lse, const float* delta, float* ds_out, float* dk,
+                                     float* dv, void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+  return kv_run(d, q, v, dout, nullptr, scores, lse, const_cast<float*>(delta), ds_out, dk, dv, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout,
+                                           const float* out, const float* scores, const float* lse, float* delta, float* ds_out,
+                                           float* dk, float* dv, void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+  VDETR_REQUIRE(out, "attn_bwd_kv_delta: null pointer (out)");
+  return kv_run(d, q, v, dout, out, scores, lse, delta, ds_out, dk, dv, workspace, workspace_bytes, stream);
 }

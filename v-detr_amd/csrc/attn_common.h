@@ -265,4 +265,75 @@ __device__ __forceinline__ void rpe_stage_table(const AttnParams& P, f32x4* tab,
   }
 }
 
+// ---- delta[row] = sum_d dO[b,q,h,d] * O[b,q,h,d] (the softmax-backward term): one wave per (b, q), lane l holds element
+// h*64 + l of the heads.  With `aux` (zeroed by the caller) the launch also leaves max_row |dO row|^2 in aux[0] and, from extra
+// workgroups that walk the key rows, max_key |V row|^2 in aux[1] (bit patterns of non-negative floats under atomicMax),
+// counts the queries whose RPE vertices are not an axis-aligned box in aux[4] and sets aux[5].  256-thread workgroups; `block`
+// in [0, qblocks + vblocks).
+constexpr int kDeltaKeys = 16;  // keys per wave in the |V row| pass
+struct DeltaArgs {
+  const float* dout;
+  const float* out;
+  float* delta;
+  int B, nQ, H, perhead;
+  unsigned* aux;
+  const float* v;
+  int nK, v_stride, qblocks, vblocks;
+  const float* vertices;
+};
+inline void attn_delta_args(const vdetr_attn_desc* d, const float* dout, const float* out, const float* v, float* delta, DeltaArgs* A) {
+  A->dout = dout; A->out = out; A->delta = delta;
+  A->B = d->B; A->nQ = d->nQ; A->H = d->H; A->perhead = d->kind == VDETR_ATTN_PER_HEAD ? 1 : 0;
+  A->aux = d->bwd_aux; A->v = v; A->nK = d->nK;
+  A->v_stride = d->v_row_stride ? d->v_row_stride : 64;
+  A->qblocks = (int)(((long)d->B * d->nQ + 3) / 4);
+  A->vblocks = d->bwd_aux ? (int)(((long)d->B * d->nK + 4 * kDeltaKeys - 1) / (4 * kDeltaKeys)) : 0;
+  A->vertices = d->table && !d->cos_sin ? d->vertices : nullptr;
+}
+__device__ __forceinline__ void attn_delta_body(const DeltaArgs& A, int block, float* wmax) {
+  const float* __restrict__ dout = A.dout;
+  const float* __restrict__ out = A.out;
+  float* __restrict__ delta = A.delta;
+  unsigned* aux = A.aux;
+  const int B = A.B, nQ = A.nQ, H = A.H, nK = A.nK;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float n2max = 0.f;
+  int slot = 0;
+  if (block >= A.qblocks) {  // |V row|^2 (shared-KV: 64 floats per key), kDeltaKeys keys per wave
+    slot = 1;
+    const int key0 = ((block - A.qblocks) * 4 + wv) * kDeltaKeys;
+#pragma unroll 4
+    for (int i = 0; i < kDeltaKeys; ++i) {
+      const int key = key0 + i;
+      const float x = key < B * nK ? A.v[(size_t)key * A.v_stride + lane] : 0.f;
+      n2max = fmaxf(n2max, wave_allsum_f32(x * x));
+    }
+  } else {
+    const int row = block * 4 + wv;
+    if (row < B * nQ) {
+      const int b = row / nQ, q = row - b * nQ;
+      for (int h = 0; h < H; ++h) {
+        const size_t e = ((size_t)row * H + h) * 64 + lane;
+        const float g = dout[e];
+        const float s = wave_allsum_f32(g * out[e]);
+        if (aux) n2max = fmaxf(n2max, wave_allsum_f32(g * g));
+        if (lane == 0) delta[A.perhead ? ((size_t)b * H + h) * nQ + q : (size_t)row * H + h] = s;
+      }
+      if (aux && A.vertices && row == 0 && lane == 0) aux[5] = 1u;  // "word 4 is meaningful": without it the box kernels stay off
+      if (aux && A.vertices) {  // aux[4] += 1 for a query whose 8 RPE vertices are not an axis-aligned box
+        const float* vp = A.vertices + (size_t)row * 24;
+        const int i = lane & 7;
+        const bool ok = vp[i * 3] == vp[rpe_box_xi(i) ? 6 : 0] && vp[i * 3 + 1] == vp[rpe_box_yi(i) ? 4 : 1] &&
+                        vp[i * 3 + 2] == vp[rpe_box_zi(i) ? 14 : 2];
+        if (!__all(ok) && lane == 0) atomicAdd(aux + 4, 1u);
+      }
+    }
+  }
+  if (!aux) return;
+  if (lane == 0) wmax[wv] = n2max;
+  __syncthreads();  // one atomic per workgroup: thousands of atomics on one word serialise (measured 32 us per launch)
+  if (threadIdx.x == 0)
+    atomicMax(aux + slot, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
 }  // namespace vdetr
