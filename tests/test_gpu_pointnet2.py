@@ -86,6 +86,25 @@ def test_fps_degenerate_clouds_bit_exact(kind):
     assert np.array_equal(ref, got), np.nonzero(ref != got)[1][:3]
 
 
+@pytest.mark.parametrize("n,kind", [(65536, "uniform"), (50000, "uniform"), (60000, "clustered"), (126000, "uniform"), (4097, "uniform")])
+def test_fps_bucket_layouts_bit_exact(n, kind):
+    """The bucket layouts of fps_rows.hip's prologue (round 3): tree leaves of <= 64 points when they fit the owner lanes'
+    slots (4097, 40 k), nodes of <= 128 / 256 points chopped into runs when only those fit (50 k, 65,536 = exactly one full
+    slot of runs, a clustered cloud whose leaves are small), plain runs (126 k).  600 samples each against the C oracle."""
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(n)
+    if kind == "uniform":
+        x = rng.uniform(1, 9, size=(1, n, 3)).astype(np.float32)
+    else:  # 200 tight clusters + 10 % background: many nearly-empty leaves next to crowded cells
+        c = rng.uniform(1, 9, size=(200, 3))
+        x = np.concatenate([c[rng.integers(0, 200, n - n // 10)] + rng.normal(0, 0.02, (n - n // 10, 3)),
+                            rng.uniform(1, 9, size=(n // 10, 3))]).astype(np.float32)[None]
+    ref = O.furthest_point_sampling(x, 600)
+    got = PU.furthest_point_sample(cu(x), 600).cpu().numpy()
+    bad = np.nonzero(ref != got)[1]
+    assert bad.size == 0, f"first mismatch at sample {bad[:1]}: ref {ref[0, bad[:3]]} got {got[0, bad[:3]]}"
+
+
 def test_fps_200k_property():
     """Four buckets per owner lane (the largest geometry of fps_rows.hip): the defining FPS property + the oracle on a prefix."""
     from vdetr_amd import pointnet2_utils as PU
