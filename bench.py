@@ -832,30 +832,49 @@ def main():
     crit_holder = [None, None]
     trainer = make_trainer(a.loss == "criterion")
     graph_ok = False
+    def all_ranks(ok):
+        """every rank takes the same branch of the fallback chain: a rank that replays a graph with collectives inside while
+        another one issues them eagerly would wait for each other forever"""
+        if world > 1:
+            t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+            return bool(t.item())
+        return ok
+
     if use_graph:
+        err = None
         try:
             trainer.capture()
-            graph_ok = True
-            trainer = choose_fps_depth(trainer)
         except Exception as e:  # capture is an optimisation: report and fall back
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+            err = e
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
             torch.cuda.synchronize()
-            if trainer.phased:  # the collectives inside the graph are the newest part: retry with them outside
+        graph_ok = all_ranks(err is None)  # (agreed BEFORE choose_fps_depth, whose own collectives every rank must reach)
+        if graph_ok:
+            try:
+                trainer = choose_fps_depth(trainer)
+            except Exception as e:
+                print(f"[bench] rank {rank}: sampling look-ahead choice failed ({type(e).__name__}: {e}); keeping depth 1", file=sys.stderr)
+        if not graph_ok:
+            was_phased = trainer.phased
+            trainer.g_main = trainer.g_opt = None
+            if was_phased:  # the collectives inside the graph are the newest part: retry with them outside
+                err = None
                 try:
                     os.environ["VDETR_PHASED_REDUCE"] = "0"
                     trainer = make_trainer(a.loss == "criterion")
                     trainer.capture()
-                    graph_ok = True
-                    if rank == 0:
-                        print("[bench] captured with the all-reduce outside the graph", file=sys.stderr)
                 except Exception as e2:
-                    if rank == 0:
-                        print(f"[bench] second capture failed too ({type(e2).__name__}: {e2}); running eager", file=sys.stderr)
-                    trainer.g_main = trainer.g_opt = None
+                    err = e2
+                    print(f"[bench] rank {rank}: second capture failed too ({type(e2).__name__}: {e2})", file=sys.stderr)
                     torch.cuda.synchronize()
-            else:
-                trainer.g_main = trainer.g_opt = None
+                graph_ok = all_ranks(err is None)
+                if graph_ok and rank == 0:
+                    print("[bench] captured with the all-reduce outside the graph", file=sys.stderr)
+                if not graph_ok:
+                    trainer.g_main = trainer.g_opt = None
+                    if rank == 0:
+                        print("[bench] running eager", file=sys.stderr)
 
     def barrier():
         if world > 1:
