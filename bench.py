@@ -710,6 +710,51 @@ def cpu_baseline(cfg_name):
                       f"({times[2]:.1f} s, {times[3]:.1f} s), extrapolated linearly to {nl - 1} layers = {full:.1f} s/scene"}
 
 
+def self_launch(ngpus):
+    """Run this script as `ngpus` ranks of ONE node (a child `python -m torch.distributed.run`, rendezvous on 127.0.0.1 at a
+    free port), pass rank 0's JSON line through and return the children's exit code.  The parent never initialises the GPU
+    and never replaces itself (no exec): it waits for the child and leaves with its code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // ngpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] starting {ngpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        proc.wait()
+        return 130
+
+
+def launch_check(a):
+    """What the ranks of `--launch-check` run: the process group of `--backend` over the launcher's environment, one
+    all-reduce, rank 0's JSON line.  No GPU work (gloo) — it exists so that the start-up path of `--gpus N` has a CPU test."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.distributed.init_process_group(backend=a.backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if a.backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        t = t.cuda()
+    torch.distributed.all_reduce(t)
+    from vdetr_amd.dist import avg_reduce_supported
+    avg = avg_reduce_supported()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "backend": a.backend, "sum_of_ranks_plus_1": float(t.item()),
+                          "reduce_op_avg": bool(avg)}), flush=True)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -735,7 +780,16 @@ def main():
                     "(captured all-reduces on the side stream) runs on a single GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                     "the N>1 code path with several ranks on one GPU)")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, form the process group, all-reduce one "
+                    "number, print a JSON line and leave: the launcher path without a GPU (tests/test_dist_gloo.py)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` with nobody else having started the ranks: start them here, one process per GPU, as the
+        # reference's main.py:588-593 spawns its workers itself.  Nothing in this parent has touched the GPU.
+        sys.exit(self_launch(a.gpus))
+    if a.launch_check:
+        sys.exit(launch_check(a))
 
     from vdetr_amd.dist import broadcast_parameters, init_distributed
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"

@@ -214,7 +214,7 @@ def test_fused_key_side_backward_equals_gemm_path(monkeypatch, case):
         assert torch.equal(o, o2), f"{case} {name}: not reproducible"
 
 
-@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True), ("3", False), ("3", True)])
+@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True), ("3", False), ("3", True), ("4", True)])
 def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
     """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
     where every wave of every workgroup is busy (the size at which a packed-math code-generation problem once showed):
@@ -237,13 +237,44 @@ def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
 
     monkeypatch.setenv("VDETR_BWD_BOX", "0")
     ref = run()
-    monkeypatch.setenv("VDETR_BWD_BOX", variant)  # 1: attn_bwd_box.hip, 2: attn_bwd_box2.hip, 3: the same with fp32 products
+    # 1: attn_bwd_box.hip, 2: attn_bwd_box2.hip, 3: the same with fp32 products, 4: attn_bwd_box3.hip (workgroup-wide sort; dS given)
+    monkeypatch.setenv("VDETR_BWD_BOX", variant)
     for rep in range(3):
         got = run()
         for name, r, o in zip(("dq", "dk", "dv"), ref, got):
             assert torch.equal(r, o), f"{name} differs between the box and the general kernel (rep {rep})"
         scale = float(ref[3].abs().max())
         assert float((got[3] - ref[3]).abs().max()) <= 3e-4 * scale, f"dtable rep {rep}"
+
+
+@pytest.mark.parametrize("B,nQ,nK", [(1, 8, 64), (2, 33, 700), (1, 300, 1024), (1, 70, 1500), (3, 40, 2049), (1, 520, 4096)])
+def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK):
+    """attn_bwd_box3.hip (1024-key tiles sorted by cell signature across the workgroup) at sizes that leave tiles, waves and
+    quads partly filled — fewer keys than a wave, a ragged last tile, one key in the last tile, several scenes, more queries
+    than two rounds of the grid — against the general kernel on the same dS: table gradient within the fixed-point resolution,
+    and bit-identical run to run (integer sums)."""
+    from vdetr_amd import attention as A
+    monkeypatch.setattr(A, "FUSED_KV_BWD", True)
+    g = torch.Generator().manual_seed(B * 7 + nQ + nK)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 5)
+    q, k, v = (torch.randn(s, generator=g).to(DEV) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g).to(DEV)
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True, rpe=A.RPEConfig(), vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV))
+
+    def run():
+        args = [x.clone().requires_grad_(True) for x in (q, k, v)]
+        tb = tables.to(DEV).requires_grad_(True)
+        (A.fused_attention(*args, table=tb, **kw) * wout).sum().backward()
+        return tb.grad
+
+    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    ref = run()
+    monkeypatch.setenv("VDETR_BWD_BOX", "4")
+    got, again = run(), run()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 3e-4 * scale, "dtable"
+    assert float((got - ref).norm() / ref.norm()) < 1e-3, "dtable, relative L2"
+    assert torch.equal(got, again), "not reproducible"
 
 
 def test_attention_probabilities_and_dropout_statistics():

@@ -322,6 +322,8 @@ class GradientReducer:
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._handles = []
         self._hook_handles = []
+        # decided now (a collective of its own), not inside the first bucket's launch — which may be under hipGraph capture
+        self._use_avg = avg_reduce_supported(process_group, dev) if self.active else False
         if overlap and self.active and bucket_views:
             for p in self.params:
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
@@ -446,15 +448,14 @@ class GradientReducer:
         self._launched = [False] * len(self.buckets)
         self._seen.clear()
 
-    _avg_unsupported = False
-
     def _allreduce_avg(self, t, async_op=False):
-        """Average over the ranks.  RCCL averages inside the collective (ncclAvg); gloo (CPU tests) needs the division."""
-        if dist.get_backend(self.group) == "nccl" and not GradientReducer._avg_unsupported:
-            try:
-                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
-            except (RuntimeError, ValueError):  # a collective library without ncclAvg rejects the op on every rank alike,
-                GradientReducer._avg_unsupported = True  # before anything is enqueued: divide + sum from now on
+        """Average over the ranks.  RCCL averages inside the collective (ncclAvg) where every rank's library has it — a
+        COLLECTIVE decision taken once per group (avg_reduce_supported), never a per-rank try / except around a collective:
+        ranks that disagreed would pair an AVG with a SUM.  Otherwise (gloo: the CPU tests) divide, then sum."""
+        if self._use_avg is None:
+            self._use_avg = avg_reduce_supported(self.group, t.device)
+        if self._use_avg:
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
         t.div_(self.world)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
@@ -466,6 +467,33 @@ class GradientReducer:
 
     def grad_bytes(self):
         return sum(b.numel() * b.element_size() for b in self.buckets)
+
+
+_AVG_VERDICT = {}
+
+
+def avg_reduce_supported(group=None, device=None):
+    """True iff EVERY rank of the group may use ``ReduceOp.AVG`` (ncclAvg: NCCL / RCCL >= 2.10).  Each rank reads its own
+    library version (no collective is attempted to find out), the verdicts are combined with a MIN all-reduce, and the
+    result is cached per group: all ranks take the same branch in GradientReducer._allreduce_avg from the first call on."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    key = id(group) if group is not None else 0
+    if key in _AVG_VERDICT:
+        return _AVG_VERDICT[key]
+    if dist.get_backend(group) != "nccl":
+        _AVG_VERDICT[key] = False  # gloo has no AVG at all: the same answer on every rank without asking
+        return False
+    try:
+        ver = torch.cuda.nccl.version()
+        local = tuple(ver[:2]) >= (2, 10) if isinstance(ver, tuple) else int(ver) >= 21000
+    except Exception:  # noqa: BLE001
+        local = False
+    dev = device if device is not None and torch.device(device).type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if local else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    _AVG_VERDICT[key] = bool(int(t.item()))
+    return _AVG_VERDICT[key]
 
 
 def broadcast_parameters(module, src=0, process_group=None):
