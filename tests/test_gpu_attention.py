@@ -214,7 +214,7 @@ def test_fused_key_side_backward_equals_gemm_path(monkeypatch, case):
         assert torch.equal(o, o2), f"{case} {name}: not reproducible"
 
 
-@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True), ("3", False), ("3", True), ("4", True)])
+@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True), ("3", False), ("3", True), ("4", True), ("5", True)])
 def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
     """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
     where every wave of every workgroup is busy (the size at which a packed-math code-generation problem once showed):
@@ -247,9 +247,11 @@ def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
         assert float((got[3] - ref[3]).abs().max()) <= 3e-4 * scale, f"dtable rep {rep}"
 
 
-@pytest.mark.parametrize("B,nQ,nK", [(1, 8, 64), (2, 33, 700), (1, 300, 1024), (1, 70, 1500), (3, 40, 2049), (1, 520, 4096)])
-def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK):
-    """attn_bwd_box3.hip (1024-key tiles sorted by cell signature across the workgroup) at sizes that leave tiles, waves and
+@pytest.mark.parametrize("variant", ["4", "5"])
+@pytest.mark.parametrize("B,nQ,nK", [(1, 8, 64), (1, 5, 3), (2, 33, 700), (1, 300, 1024), (1, 70, 1500), (3, 40, 2049), (1, 520, 4096)])
+def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK, variant):
+    """attn_bwd_box3.hip (variant 4: 1024-key tiles sorted by cell signature across the workgroup) and attn_bwd_box4.hip (5: 64-key
+    chunks sorted inside a wave) at sizes that leave tiles, waves and
     quads partly filled — fewer keys than a wave, a ragged last tile, one key in the last tile, several scenes, more queries
     than two rounds of the grid — against the general kernel on the same dS: table gradient within the fixed-point resolution,
     and bit-identical run to run (integer sums)."""
@@ -269,7 +271,7 @@ def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK):
 
     monkeypatch.setenv("VDETR_BWD_BOX", "0")
     ref = run()
-    monkeypatch.setenv("VDETR_BWD_BOX", "4")
+    monkeypatch.setenv("VDETR_BWD_BOX", variant)
     got, again = run(), run()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 3e-4 * scale, "dtable"

@@ -23,6 +23,7 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
 int launch_attn_bwd_box(const AttnParams& P, int grid, hipStream_t st);   // attn_bwd_box.hip
 int launch_attn_bwd_box2(const AttnParams& P, int grid, hipStream_t st, bool f32_products);  // attn_bwd_box2.hip
 int launch_attn_bwd_box3(const AttnParams& P, int grid, hipStream_t st);                     // attn_bwd_box3.hip (dS given)
+int launch_attn_bwd_box4(const AttnParams& P, int grid, hipStream_t st);                     // attn_bwd_box4.hip (dS given)
 
 constexpr int kBwdThreads = 1024;
 
@@ -731,10 +732,11 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
   // general one over the same grid / partial-table layout, and the device decides which of the two does the work
   // VDETR_BWD_BOX: 2 (default) attn_bwd_box2.hip, 355 us at C2 size; 1 attn_bwd_box.hip, 465 us; 0 the general kernel
   // only, 406 us.  Read per call: the parity test runs the kernels side by side in one process.
-  // 4 (default where dS is given): attn_bwd_box3.hip, workgroup-wide sort of 1024 keys, exact fp32 products
+  // 4: attn_bwd_box3.hip, workgroup-wide sort of 1024 keys, exact fp32 products; 5 (default where dS is given):
+  // attn_bwd_box4.hip, wave-private chunks sorted by one LDS add per pair, exact fp32 products
   const char* box_var = getenv("VDETR_BWD_BOX");
-  int box_env = box_var ? atoi(box_var) : (ds_given ? 4 : 2);
-  if (box_env >= 4 && !ds_given) box_env = 2;  // the third design only exists in the dS-given form
+  int box_env = box_var ? atoi(box_var) : (ds_given ? 5 : 2);
+  if (box_env >= 4 && !ds_given) box_env = 2;  // the third and fourth designs only exist in the dS-given form
   VDETR_REQUIRE(!ds_given || box_env != 1, "attn_bwd_table: not built into the first box kernel (VDETR_BWD_BOX=1)");
   VDETR_REQUIRE(!ds_given || P.T * P.T * P.T <= kWave * 16, "attn_bwd_table: table edge %d too large for the matrix-unit kernel", P.T);
   const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && P.T == 10;
@@ -752,7 +754,8 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
     else e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st);
     if (e) return e;
     if (box)
-      if (int e2 = box_env >= 4 ? launch_attn_bwd_box3(P, grid, st)
+      if (int e2 = box_env >= 5 ? launch_attn_bwd_box4(P, grid, st)
+                   : box_env == 4 ? launch_attn_bwd_box3(P, grid, st)
                    : box_env >= 2 ? launch_attn_bwd_box2(P, grid, st, box_env == 3) : launch_attn_bwd_box(P, grid, st)) return e2;
   } else {
     const size_t lds = dtable ? (size_t)table_floats * sizeof(float) : 16;
