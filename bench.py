@@ -159,10 +159,12 @@ class Trainer:
         defer_weight_grads(defer_wg)
         self.params = [p for p in model.parameters() if p.requires_grad]
         # parameters / gradients as views of two flat buffers: one AdamW launch, one norm, slice-shaped buckets
-        self.flat = FlatParams(self.params, groups=model.flat_param_groups())
         # hooks + bucket views only pay off when they overlap communication with an EAGER backward; otherwise
         # gradients stay ordinary tensors and are packed with one multi-tensor copy before the all-reduce
         self.hooked = (world > 1 or force_dist) and overlap and not use_graph
+        # (shape-grouped layout for the parked weight gradients; reverse parameter order where bucket hooks fire during an
+        # eager backward with inline weight gradients, so that buckets complete while the backward is still running)
+        self.flat = FlatParams(self.params, groups=model.flat_param_groups(), group_shapes=defer_wg or not self.hooked)
         self.reducer = GradientReducer(self.params, bucket_mb=float(os.environ.get("VDETR_BUCKET_MB", "64")), overlap=self.hooked,
                                        bucket_views=self.hooked, flat=self.flat, force=force_dist)
         # Captured step on several ranks: the gradient buckets are all-reduced INSIDE the hipGraph, each on the side stream as
@@ -523,13 +525,22 @@ def kernel_rooflines(cfg_name, device, reps=20):
     half = (0.1 + torch.rand((B, nQ, 1, 3), generator=g)).to(device)
     signs = torch.tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]],
                          dtype=torch.float32, device=device)
-    verts = (center[:, :, None, :] + half * signs).contiguous()
+    cos_sin = None
+    if CONFIGS[cfg_name][5] == "object_coords":  # C5: rotated boxes — the corners turn about the vertical axis and the kernels
+        ang = ((torch.rand((B, nQ), generator=g) * 2 - 1) * 3.1).to(device)  # get the (cos, sin) operand: general RPE kernels
+        c, sn = torch.cos(ang)[:, :, None], torch.sin(ang)[:, :, None]
+        off = half * signs
+        off = torch.stack((off[..., 0] * c - off[..., 1] * sn, off[..., 0] * sn + off[..., 1] * c, off[..., 2]), -1)
+        verts = (center[:, :, None, :] + off).contiguous()
+        cos_sin = torch.stack((c[..., 0], sn[..., 0]), -1).contiguous()
+    else:
+        verts = (center[:, :, None, :] + half * signs).contiguous()
     q = torch.randn((B, nQ, 256), generator=g).to(device)
     k = torch.randn((B, nK, 64), generator=g).to(device)
     v = torch.randn((B, nK, 64), generator=g).to(device)
     table = torch.randn((8, 10, 10, 10, 4), generator=g).to(device)
     rng = A.begin_step(device)
-    d = A._desc(L.VDETR_ATTN_SHARED_KV, B, H, nQ, nK, 0.125, table, A.RPEConfig(), verts, kxyz, None, None, 0.1, rng, 1)
+    d = A._desc(L.VDETR_ATTN_SHARED_KV, B, H, nQ, nK, 0.125, table, A.RPEConfig(), verts, kxyz, cos_sin, None, 0.1, rng, 1)
     lib = L.lib()
     out = torch.empty_like(q)
     lse = torch.empty((B, nQ, H), device=device)
@@ -587,14 +598,21 @@ def kernel_rooflines(cfg_name, device, reps=20):
     flops = 4.0 * H * pairs * 64                       # QK^T + PV (MFMA-eligible), SURVEY.md §8d
     bytes_bwd = 4.0 * H * pairs                        # dS read once (fp32); the kernel is VALU-bound, see valu_issue
     bytes_kv = 2.0 * 4.0 * H * pairs                   # S read, dS written (fp32); operands and dK / dV are ~1 % of that
-    fwd_obj = {"kernel": "attn_fwd_kernel<shared_kv,rpe> (3DV-RPE cross-attention forward)", "bound": "mfma",
+    fwd_obj = {"kernel": "attn_fwd_kernel<shared_kv,rpe> (3DV-RPE cross-attention forward)", "bound": "mfma",  # (name completed below)
                "achieved": flops / t_fwd / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                "frac": flops / t_fwd / 1e12 / 157.3, "traffic": None, "launch_us": t_fwd * 1e6,
                "rpe_lookups_per_s": 8.0 * pairs / t_fwd}
     kv_obj = {"kernel": "attn_bwd_kv_kernel (dO V^T, softmax backward, dV, dK in one pass over the scores; + its operand-packing launch)",
               "bound": "hbm", "achieved": bytes_kv / t_kv / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": bytes_kv / t_kv / 1e9 / 8000.0,
               "traffic": None, "launch_us": t_kv * 1e6}
-    bwd_obj = {"kernel": "attn_bwd_box2_kernel (RPE table gradient from dS, axis-aligned boxes)", "bound": "hbm",
+    # the name of the kernel that did the work comes from the library and the launch's own gate word, not from a string here
+    kbox, kgen = ctypes.c_char_p(), ctypes.c_char_p()
+    L.check(lib.vdetr_attn_bwd_table_kernel_names(ctypes.byref(d), ctypes.byref(kbox), ctypes.byref(kgen)), "kernel names")
+    gate = aux.cpu()
+    ran_box = kbox.value is not None and int(gate[4]) == 0 and int(gate[5]) != 0
+    bwd_kernel = (kbox.value if ran_box else kgen.value).decode()
+    fwd_kernel = "attn_fwd_rpe_auto_kernel (box body)" if ran_box else "attn_fwd_rpe_auto_kernel (general body" + (", rotated)" if cos_sin is not None else ")")
+    bwd_obj = {"kernel": f"{bwd_kernel} (RPE table gradient from dS; " + ("axis-aligned boxes)" if ran_box else "general vertices" + (" + rotation)" if cos_sin is not None else ")")), "bound": "hbm",
                "achieved": bytes_bwd / t_bwd / 1e9, "peak": 8000.0, "unit": "GB/s",
                "frac": bytes_bwd / t_bwd / 1e9 / 8000.0, "traffic": None, "launch_us": t_bwd * 1e6,
                "rpe_scatter_per_s": 8.0 * pairs / t_bwd}
@@ -603,16 +621,18 @@ def kernel_rooflines(cfg_name, device, reps=20):
         tr = _pmc_traffic()
         if cfg_name == "c2":
             fwd_obj["traffic"] = tr["attn_fwd_kernel<false,true,true>"]["bytes"]
-            bwd_obj["traffic"] = tr["attn_bwd_box2_kernel"]["bytes"]
+            bkey = next((k for k in tr if bwd_kernel.split("<")[0] in k), None)
+            bwd_obj["traffic"] = tr[bkey]["bytes"] if bkey else None
             if "attn_bwd_kv_kernel" in tr:
                 kv_obj["traffic"] = tr["attn_bwd_kv_kernel"]["bytes"]
-            vi = tr["attn_bwd_box2_kernel"].get("valu_wave_insts")
+            vi = tr[bkey].get("valu_wave_insts") if bkey else None
             if vi:  # what actually bounds the kernel: VALU issue (1024 SIMDs x 2.4 GHz / 4 cycles per wave instruction)
                 bwd_obj["valu_issue"] = {"wave_insts": vi, "limit_us": vi / 614.4e9 * 1e6, "frac": vi / 614.4e9 / t_bwd,
                                          "note": "SQ_INSTS_VALU per launch (offline PMC pass) / chip issue rate / launch time: "
                                                  "the kernel is VALU-bound, the HBM fraction above is low by construction"}
     except (OSError, KeyError, IndexError, ValueError):
         pass
+    fwd_obj["kernel"] = f"{fwd_kernel}: 3DV-RPE cross-attention forward"
     bwd_obj["key_side_pass"] = kv_obj
     return fwd_obj, bwd_obj
 
@@ -705,6 +725,7 @@ def cpu_baseline(cfg_name):
     per_layer = max(times[3] - times[2], 1e-9)
     full = t_fps + times[2] + (nl - 2) * per_layer
     return {"value": bs / (full * bs), "unit": "scenes/s", "cores": cores, "kind": "port", "extrapolated": True,
+            "kind_note": "port, EXTRAPOLATED: timed on a bounded sample (below) and scaled linearly to the full layer count",
             "sample": f"EXTRAPOLATED from a bounded sample: FPS {npts}->{npre} pts with the C oracle on 1 thread ({t_fps:.2f} s) + decoder fwd+bwd with 1 and 2 of "
                       f"{nl - 1} RPE layers at full nQ={nq}/nK={npre} through the torch CPU oracle (RPE via F.grid_sample, as the reference) on {cores} threads "
                       f"({times[2]:.1f} s, {times[3]:.1f} s), extrapolated linearly to {nl - 1} layers = {full:.1f} s/scene"}
@@ -971,11 +992,14 @@ def main():
         "loss": loss,
         "arith": {"activations": "f32" if dtype == "f32" else "f32 residual stream; q / k / v of the cross attention stored as bf16",
                   "qk_pv": "v_mfma_f32_16x16x4_f32 (exact f32)" if dtype == "f32" else "v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16, f32 accumulate (self-attention: f32)", "softmax_log2_table_lookup": "f32",
-                  "dtable_products": "split-bf16 2^-15 (two bf16 terms per f32 factor)", "dtable_accum": "int32 fixed point in LDS",
+                  "dtable_products": ("exact f32 outer products on v_mfma_f32_16x16x4_f32 (attn_bwd_box4_kernel)" if not CONFIGS[a.config][5] else
+                                      "split-bf16 2^-15 (two bf16 terms per f32 factor; rotated boxes: the general kernel)"),
+                  "dtable_accum": "int32 fixed point in LDS",
                   "backward_contractions": "dO V^T, dV = P^T dO, dK = dS^T q: f32 operands as hi + lo bf16 on v_mfma_f32_32x32x16_bf16, "
                                            "three cross terms (2^-16 per product), f32 accumulate; dQ = dS K: library f32 GEMM",
-                  "note": "dtype f32 is the arithmetic of every tensor the model sees; the RPE-table gradient alone is formed from "
-                          "2-term split-bf16 products accumulated in int32 fixed point (DESIGN.md 4.4b): 4.3e-4 relative L2 against the fp64 oracle at this layer size (tests/test_gpu_attention.py::test_full_size_forward_backward_vs_oracle)"},
+                  "note": "dtype f32 is the arithmetic of every tensor the model sees; the RPE-table gradient's group sums are rounded "
+                          "into an int32 fixed-point histogram whose scale comes from a worst-case bound (DESIGN.md 4.4): relative L2 against the "
+                          "fp64 oracle at this layer size in tests/test_gpu_attention.py::test_full_size_forward_backward_vs_oracle"},
     }
     if a.config == "c2":  # decoder fwd+bwd = 216 GFLOP per scene at the full configuration
         result["end_to_end"] = {"gflop_per_scene": 216.0, "achieved_tflops": 216.0e-3 * result["value"],
@@ -995,12 +1019,19 @@ def main():
         fwd_obj["step_us"], bwd_obj["step_us"] = layers * fwd_obj["launch_us"], layers * bwd_obj["launch_us"]
         # one workgroup per scene: the launch time does not grow with the batch
         fps_obj["step_us"] = fps_obj["launch_us"]
-        objs = sorted((fps_obj, bwd_obj, fwd_obj), key=lambda o: -o["step_us"])
-        for o in objs:  # device time of the kernel's launches in one step / step time (the sampling runs on a side stream)
+        # `roofline` = the kernel with the largest share of the step's CRITICAL PATH: the main stream's cross-attention kernels.
+        # The sampling of the next scene runs on a side stream under them (one CU): reported as `side_stream`, with the share of
+        # the step its launch would take if it were not hidden.
+        for o in (fps_obj, bwd_obj, fwd_obj):
             o["share_of_step"] = o["step_us"] * 1e-3 / result["ms_per_step"]
-        result["roofline"] = objs[0]        # the kernel with the most device time per step
+        fps_obj["on_critical_path"] = bool(a.no_fps_prefetch)
+        objs = sorted((bwd_obj, fwd_obj) + ((fps_obj,) if a.no_fps_prefetch else ()), key=lambda o: -o["step_us"])
+        result["roofline"] = objs[0]
         result["roofline_secondary"] = objs[1]
-        result["roofline_tertiary"] = objs[2]
+        if len(objs) > 2:
+            result["roofline_tertiary"] = objs[2]
+        else:
+            result["side_stream"] = fps_obj
 
     def cpu_leg():
         result["cpu_baseline"] = cpu_baseline(a.config)
@@ -1104,18 +1135,28 @@ def main():
             leg("cpu_baseline", cpu_leg)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    # Leave in order: everybody done, the group destroyed, then the process ends without running the interpreter's teardown —
-    # captured graphs that hold RCCL nodes were seen to crash in their destructors at exit (core dump after the line above).
+    # Leave in order: everybody done, the group destroyed.  Only a process whose captured graphs hold RCCL nodes then ends
+    # without the interpreter's teardown (their destructors were seen to crash at exit, after the line above); it runs what
+    # atexit would have run first (the GEMM-tuning results), and a shutdown that failed is reported through the exit code.
     if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rc = 0
         try:
             torch.cuda.synchronize()
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         except Exception as exc:  # noqa: BLE001
             print(f"[bench] process-group shutdown: {type(exc).__name__}: {exc}", file=sys.stderr)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+            rc = 3
+        rccl_in_graph = bool(graph_ok and getattr(trainer, "phased", False) and trainer.reducer.active and a.backend == "nccl")
+        if rccl_in_graph or rc:
+            try:
+                from vdetr_amd.runtime import finish_gemm_tuning
+                finish_gemm_tuning()
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] GEMM-tuning results not published: {type(exc).__name__}: {exc}", file=sys.stderr)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(rc)
 
 
 if __name__ == "__main__":

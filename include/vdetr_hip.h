@@ -198,8 +198,11 @@ int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* scores, con
  *   q, dout [B,nQ,4*64];  v [B,nK,64] (row stride d->v_row_stride);  scores, lse, delta as saved / produced above
  *   ds_out [B,nQ,4,nK]  UNSCALED dS (input of vdetr_attn_bwd_table_f32 and of dQ = scale * ds_out K)
  *   dk, dv [B,nK,64]    written (not accumulated); 16-B aligned
- * Shared-KV kind with 4 heads only.  fp32 operands pass through the bf16 matrix unit as hi + lo halves (three cross
- * terms: relative error of a product <= 2^-16); results are bit-reproducible from run to run. */
+ * Shared-KV kind with 4 heads — and the PER-HEAD kind (nn.MultiheadAttention's core): then q, dout [B,nQ,H*64], v, dk, dv
+ * [B,nK,H*64] (row stride d->v_row_stride), scores / ds_out [B,H,nQ,nK], lse / delta [B,H,nQ], no bwd_aux.  Limits (checked,
+ * VDETR_ERR_ARG): a score matrix (4 nQ x nK resp. nQ x nK floats) below 2 GB, at most 65535 of them (B resp. B*H), v rows, lse,
+ * delta, dk, dv 16-B aligned.  fp32 operands pass through the bf16 matrix unit as hi + lo halves (three cross terms: relative
+ * error of a product <= 2^-16); results are bit-reproducible from run to run. */
 size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d);
 int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* scores,
                           const float* lse, const float* delta, float* ds_out, float* dk, float* dv, void* workspace,
@@ -210,12 +213,19 @@ int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float* q, const 
                                 const float* scores, const float* lse, float* delta, float* ds_out, float* dk, float* dv,
                                 void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
 /* Workgroup shape of vdetr_attn_bwd_kv_f32: 8 waves (default, the kernel alone on the chip) or 4 (one wave per SIMD with
- * <= 256 registers: fits next to the table-gradient kernel when the caller runs that on another stream). */
+ * <= 256 registers: fits next to the table-gradient kernel when the caller runs that on another stream).  PROCESS-WIDE state,
+ * read at launch: a tuning switch for single-threaded callers (threads or devices that set different shapes race on it; either
+ * shape computes the same values). */
 int vdetr_attn_bwd_kv_set_waves(int waves);
 /* The RPE table gradient alone, from the dS that vdetr_attn_bwd_kv_f32 wrote (same kernels, workspace and bwd_aux contract
  * as vdetr_attn_bwd_scores_f32 with a dtable; d->bwd_aux is required).  dtable [8,T,T,T,4]: caller zero-fills. */
 int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* ds, float* dtable, void* workspace,
                              size_t workspace_bytes, vdetr_stream_t stream);
+/* Names of the kernels vdetr_attn_bwd_table_f32 launches for this descriptor (static strings; for profiles and bench labels).
+ * The two table kernels share one grid and the DEVICE decides which of them works: `box_kernel` (NULL when none is launched:
+ * a rotation operand, another table edge, no bwd_aux) runs iff every query's vertices are an axis-aligned box, i.e. iff
+ * bwd_aux[4] == 0 && bwd_aux[5] != 0 after the launch; otherwise `general_kernel` does the work. */
+int vdetr_attn_bwd_table_kernel_names(const vdetr_attn_desc* d, const char** box_kernel, const char** general_kernel);
 
 /* delta = rowsum(dO * O) over the 64 channels of a head, in the row order of the kind (see vdetr_attn_fwd_f32);
  * dout / out [B,nQ,H*64].  The softmax-backward term the score stage subtracts.  With d->bwd_aux (shared-KV kind, `v` as

@@ -5,8 +5,8 @@ TEST INFRASTRUCTURE ONLY — nothing under ``v-detr_amd/`` may import this modul
 
 Pinned against the reference itself: ``oracle/make_golden.py`` imports the reference's
 ``GlobalShareCrossAttention`` / ``ShareSelfAttention`` / ``TransformerDecoder`` (models/vdetr_transformer.py) in the
-build container and stores inputs + outputs + gradients under ``tests/golden/``; ``tests/test_oracle_attention.py``
-checks this restatement against those vectors.  It deliberately does NOT call F.grid_sample: the trilinear
+build container and stores inputs + outputs + gradients under ``tests/golden/``; ``tests/test_host_vs_reference.py``
+checks this restatement (and the host modules built on it) against those vectors.  It deliberately does NOT call F.grid_sample: the trilinear
 lookup is written out so that it is an independent statement of vdetr_transformer.py:710-731.
 """
 import math

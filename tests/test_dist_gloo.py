@@ -373,3 +373,116 @@ def test_flat_layout_parts_and_forced_bucket_breaks():
     for p in params:  # (the alignment padding between parameters is not part of any span: compare the views)
         o = flat.offsets[id(p)]
         assert torch.equal(flat.grad[o:o + p.numel()], ref[o:o + p.numel()])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE / RANK in the environment starts two ranks itself (as the reference's
+    main.py:588-593 spawns its workers), passes rank 0's JSON line through and leaves with the children's exit code.  Run here
+    through the launcher's CPU path (--launch-check: process group + one all-reduce over gloo, no GPU work)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["launch_check"] and d["n_gpus"] == 2 and d["sum_of_ranks_plus_1"] == 3.0 and d["reduce_op_avg"] is False
+    # a rank that fails makes the launcher fail
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "no-such-backend", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
+
+
+def test_avg_reduce_verdict_is_collective_and_cached():
+    """dist.avg_reduce_supported: gloo has no ReduceOp.AVG -> False on every rank without a collective; GradientReducer then
+    divides and sums (the path every CPU test of this file takes)."""
+    from vdetr_amd import dist as D
+    assert D.avg_reduce_supported() is False  # no process group in this process
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vdetr_amd import bn_act as BNA
+    from vdetr_amd import sparse_ops as S
+    from vdetr_amd.dist import init_distributed
+    from vdetr_amd.helpers import GenericMLP
+    init_distributed("gloo")
+    BNA.set_sync(True)
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn((7, 6), generator=g, dtype=torch.float64) * 3 + 1     # rows of ALL ranks: rank 0 holds 7, rank 1 holds none
+    wout = torch.randn((7, 6), generator=g, dtype=torch.float64)
+    mine = slice(0, 7) if rank == 0 else slice(7, 7)
+    res = {}
+    # (1) the sparse backbone's BatchNorm on a path the fused launch does not take (CPU rows; 6 channels: not a multiple of 4),
+    #     one rank with an EMPTY tensor: it must still join the collectives
+    bn = torch.nn.BatchNorm1d(6).double().train()
+    x = full[mine].clone().requires_grad_(True)
+    y = S.bn_act(x, bn, "relu")
+    (y * wout[mine]).sum().backward()
+    res["sp"] = (y.detach().numpy(), x.grad.numpy(), bn.weight.grad.numpy(), bn.bias.grad.numpy(), bn.running_mean.numpy().copy(),
+                 bn.running_var.numpy().copy(), int(bn.num_batches_tracked))
+    # (2) a GenericMLP reached through its nn.Sequential (CPU: no fused launch): [B, C, N] with different N per rank
+    torch.manual_seed(11)
+    mlp = GenericMLP(input_dim=4, hidden_dims=[5], output_dim=3, norm_fn_name="bn1d", activation="relu", use_conv=True).double().train()
+    xin = torch.randn((1, 4, 9), generator=g, dtype=torch.float64)
+    cols = slice(0, 6) if rank == 0 else slice(6, 9)
+    xm = xin[:, :, cols].clone().requires_grad_(True)
+    ym = mlp(xm)
+    ym.square().sum().backward()
+    bnm = [m for m in mlp.layers if isinstance(m, torch.nn.BatchNorm1d)][0]
+    res["mlp"] = (ym.detach().numpy(), xm.grad.numpy(), bnm.weight.grad.numpy(), bnm.running_mean.numpy().copy(), bnm.running_var.numpy().copy())
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batch_norm_fallback_paths_match_one_big_batch():
+    """with bn_act.set_sync every BatchNorm call must use cross-replica statistics, not only the fused launches.  Two
+    gloo ranks (one holding an EMPTY tensor in the sparse case, 6 + 3 columns in the dense one) reproduce the BatchNorm of the
+    concatenated batch: outputs, input gradients, summed parameter gradients, running statistics."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process statement of the same
+    g = torch.Generator().manual_seed(5)
+    full = (torch.randn((7, 6), generator=g, dtype=torch.float64) * 3 + 1).requires_grad_(True)
+    wout = torch.randn((7, 6), generator=g, dtype=torch.float64)
+    bn = torch.nn.BatchNorm1d(6).double().train()
+    y = torch.relu(bn(full))
+    (y * wout).sum().backward()
+    sp0, sp1 = res[0]["sp"], res[1]["sp"]
+    np.testing.assert_allclose(sp0[0], y.detach().numpy(), rtol=1e-10, atol=1e-12)
+    assert sp1[0].shape == (0, 6)
+    np.testing.assert_allclose(sp0[1], full.grad.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sp0[2] + sp1[2], bn.weight.grad.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sp0[3] + sp1[3], bn.bias.grad.numpy(), rtol=1e-9, atol=1e-12)
+    for r in (sp0, sp1):  # both ranks hold the SAME running statistics: those of the whole batch
+        np.testing.assert_allclose(r[4], bn.running_mean.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r[5], bn.running_var.numpy(), rtol=1e-10, atol=1e-12)
+        assert r[6] == 1
+    from vdetr_amd.helpers import GenericMLP
+    torch.manual_seed(11)
+    mlp = GenericMLP(input_dim=4, hidden_dims=[5], output_dim=3, norm_fn_name="bn1d", activation="relu", use_conv=True).double().train()
+    xin = torch.randn((1, 4, 9), generator=g, dtype=torch.float64).requires_grad_(True)
+    ym = mlp(xin)
+    ym.square().sum().backward()
+    bnm = [m for m in mlp.layers if isinstance(m, torch.nn.BatchNorm1d)][0]
+    m0, m1 = res[0]["mlp"], res[1]["mlp"]
+    np.testing.assert_allclose(np.concatenate((m0[0], m1[0]), 2), ym.detach().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate((m0[1], m1[1]), 2), xin.grad.numpy(), rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(m0[2] + m1[2], bnm.weight.grad.numpy(), rtol=1e-8, atol=1e-11)
+    for r in (m0, m1):
+        np.testing.assert_allclose(r[3], bnm.running_mean.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(r[4], bnm.running_var.numpy(), rtol=1e-10, atol=1e-12)

@@ -114,18 +114,19 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
             assert_close(o, r.detach().numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
-@pytest.mark.parametrize("boxes", [True, False])
+@pytest.mark.parametrize("boxes", [True, False, "rotated"])
 def test_full_size_forward_backward_vs_oracle(boxes):
     """The launch bench.py times (B=1, nQ=1024, nK=4096, H=4: BASELINE config 2's layer size) against the fp64 oracle:
     out, dq, dk, dv and the RPE-table gradient within 1e-3 relative.  boxes=True: axis-aligned box vertices, i.e.
-    attn_bwd_box2_kernel with its dynamic query distribution and every wave of every workgroup busy; boxes=False: a few
-    perturbed vertices send the same launch down the general kernel.  The oracle is evaluated in chunks of 32 queries
+    the box kernel (attn_bwd_box4.hip) with its dynamic query distribution and every wave of every workgroup busy; boxes=False: a few
+    perturbed vertices send the same launch down the general kernel; "rotated": the (cos, sin) operand of angle_type
+    "object_coords" (vdetr_transformer.py:712-720, BASELINE config 5) at the full size.  The oracle is evaluated in chunks of 32 queries
     (softmax rows are independent; dk, dv and dtable are sums over the chunks)."""
     from oracle.attention_oracle import fused_attention_reference
     from vdetr_amd import attention as A
     B, nQ, nK, H = 1, 1024, 4096, 4
     g = torch.Generator().manual_seed(21)
-    xyz, verts, tables, _ = _scene(B, nQ, nK, 5)
+    xyz, verts, tables, cs = _scene(B, nQ, nK, 5, boxes == "rotated")  # "rotated": BASELINE config 5's operand (object_coords)
     if not boxes:
         verts[:, ::97] += 0.05 * torch.randn(verts[:, ::97].shape, generator=g)
     q, k, v = (torch.randn(s, generator=g) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
@@ -135,7 +136,8 @@ def test_full_size_forward_backward_vs_oracle(boxes):
     # device
     dq, dk, dv = (x.to(DEV).requires_grad_(True) for x in (q, k, v))
     dtb = tables.to(DEV).requires_grad_(True)
-    out = A.fused_attention(dq, dk, dv, table=dtb, vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV), **kw)
+    out = A.fused_attention(dq, dk, dv, table=dtb, vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV),
+                            cos_sin=None if cs is None else cs.to(DEV), **kw)
     (out * wout.to(DEV)).sum().backward()
     # oracle, 32 queries at a time
     rk, rv = k.double().requires_grad_(True), v.double().requires_grad_(True)
@@ -144,7 +146,8 @@ def test_full_size_forward_backward_vs_oracle(boxes):
     for c in range(0, nQ, 32):
         sl = slice(c, c + 32)
         rq = q[:, sl].double().requires_grad_(True)
-        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
+        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(),
+                                      cos_sin=None if cs is None else cs[:, sl].double(), **kw)
         (o * wout[:, sl].double()).sum().backward()
         routs.append(o.detach())
         rdq.append(rq.grad)
@@ -155,10 +158,10 @@ def test_full_size_forward_backward_vs_oracle(boxes):
         if name == "out":
             assert_close(o, r.numpy(), 1e-4, 1e-5 * max(scale, 1.0), name)
         elif name == "dtable":
-            # 33.5 M (query, key, vertex) contributions, formed from 2-term split-bf16 products and summed in int32 fixed
-            # point whose scale comes from a worst-case BOUND of a bin's sum (all of a query's attention mass in one bin,
-            # DESIGN.md 4.4); real bins hold ~1e-3 of that, so single contributions keep ~10 bits.  The rounding is
-            # unbiased and absolute: measured 2.0e-4 of the largest entry whatever the entry's size, 4.3e-4 relative L2.
+            # 33.5 M (query, key, vertex) contributions (exact fp32 products in the box kernel, 2-term split-bf16 in the general
+            # one) summed in int32 fixed point whose scale comes from a worst-case BOUND of a bin's sum (all of a query's
+            # attention mass in one bin); real bins hold ~1e-3 of that, so a group's sum keeps ~10 bits.  The
+            # rounding is unbiased and absolute: ~2e-4 of the largest entry whatever the entry's size, ~4e-4 relative L2.
             assert_close(o, r.numpy(), 1e-3, 3e-4 * scale, name)
             assert float((o.cpu().double() - r).norm() / r.norm()) < 1e-3, "dtable, relative L2 error"
         else:
@@ -443,7 +446,8 @@ def test_bf16_attention_core_vs_oracle(B, nQ, nK, boxes):
     for c in range(0, nQ, 64):
         sl = slice(c, c + 64)
         rq = q[:, sl].double().requires_grad_(True)
-        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
+        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(),
+                                      cos_sin=None if cs is None else cs[:, sl].double(), **kw)
         (o * wout[:, sl].double()).sum().backward()
         routs.append(o.detach())
         rdq.append(rq.grad)

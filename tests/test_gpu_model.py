@@ -52,12 +52,16 @@ def _loss(out):
                for o in out["aux_outputs"] + [out["outputs"]])
 
 
-@pytest.mark.parametrize("angle_type,batch,ragged", [("", 1, False), ("", 2, False), ("object_coords", 2, False), ("", 3, True)])
-def test_model_forward_backward_vs_cpu_oracle(angle_type, batch, ragged, monkeypatch):
+@pytest.mark.parametrize("angle_type,batch,ragged,npoints", [("", 1, False, 4000), ("", 2, False, 4000), ("object_coords", 2, False, 4000),
+                                                             ("", 3, True, 4000), ("object_coords", 4, True, 20000)])
+def test_model_forward_backward_vs_cpu_oracle(angle_type, batch, ragged, npoints, monkeypatch):
     """BASELINE config 1 shape (4k-point scene, 64 queries, 2 RPE layers): whole post-backbone path, HIP vs the CPU
-    oracle on identical weights and inputs; seed indices bit-exact, boxes / logits within 1e-3 relative."""
-    model = _make_model(angle_type=angle_type).eval()
-    inp_cpu = _inputs(4000, 3, "cpu", batch, ragged)
+    oracle on identical weights and inputs; seed indices bit-exact, boxes / logits within 1e-3 relative.  The last case is
+    BASELINE config 5's input shape — four 20k-point scenes of different voxel counts per step, rotated boxes (12 angle bins,
+    the (cos, sin) RPE operand) — with a decoder the CPU oracle finishes in seconds (1024 keys, 128 queries, 2 RPE layers)."""
+    big = npoints > 4000
+    model = (_make_model(nq=128, npre=1024, angle_type=angle_type) if big else _make_model(angle_type=angle_type)).eval()
+    inp_cpu = _inputs(npoints, 3, "cpu", batch, ragged)
     ref_model = model
     # ---- GPU (HIP kernels) first, before anything is patched
     import copy

@@ -58,10 +58,11 @@ def main():
     kw = dict(num_heads=H, scale=0.125, shared_kv=True, rpe=A.RPEConfig(), vertices=verts, xyz=kxyz, dropout_p=0.1)
     res = {}
     grads = {}
+    rng_once = A.new_rng_state(dev, 1234)  # ONE dropout state for both paths: their gradients are then comparable
     for name, fused in (("gemm_path", False), ("fused_path", True)):
         A.FUSED_KV_BWD = fused
         A.begin_step(dev)
-        out = A.fused_attention(q, k, v, table=table, **kw)
+        out = A.fused_attention(q, k, v, table=table, rng_state=rng_once.clone(), **kw)
 
         def bwd():
             torch.autograd.grad(out, (q, k, v, table), dout, retain_graph=True)

@@ -260,7 +260,12 @@ class _FusedAttention(Function):
             aux = _take_zeros(q, (8,), torch.int32)  # 5 words used (vdetr_hip.h: bwd_aux)
             d.bwd_aux = aux.data_ptr()
         delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=q.device)
-        fused = _fused_kv_ok(want_table) and ((shared and H == 4) or (not shared and not want_table))
+        # the fused key-side pass where it is built AND inside its limits (attn_bwd_kv.hip:kv_run: a score matrix below 2 GB,
+        # at most 65535 of them, 16-B aligned operands); everything else takes the library-GEMM composition as before
+        rows_kv, nprob_kv = (4 * nQ, B) if shared else (nQ, B * H)
+        fused = (_fused_kv_ok(want_table) and ((shared and H == 4) or (not shared and not want_table))
+                 and rows_kv * nK * 4 < (1 << 31) and nprob_kv <= 65535 and v.stride(1) % 4 == 0
+                 and all(t.data_ptr() % 16 == 0 for t in (v, lse)))
         if not fused:  # (the fused pass computes delta in the first workgroups of its operand-packing launch)
             L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(out), L.ptr(v), L.ptr(delta), L.stream_ptr()),
                     "attn_delta")

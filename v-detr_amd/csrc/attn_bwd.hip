@@ -668,6 +668,15 @@ static int bwd_variant() {
   static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 9; }();
   return variant;
 }
+// VDETR_BWD_BOX (read per call: the parity test runs the kernels side by side in one process): which axis-aligned-box kernel
+// is launched next to the general one.  0 none, 1 attn_bwd_box.hip, 2 / 3 attn_bwd_box2.hip (split-bf16 / fp32 products),
+// 4 attn_bwd_box3.hip, 5 attn_bwd_box4.hip (default where dS is given; 2 otherwise: 4 and 5 only exist in the dS-given form)
+static int bwd_box_variant(bool ds_given) {
+  const char* box_var = getenv("VDETR_BWD_BOX");
+  int box_env = box_var ? atoi(box_var) : (ds_given ? 5 : 2);
+  if (box_env >= 4 && !ds_given) box_env = 2;
+  return box_env;
+}
 static int bwd_grid(const vdetr_attn_desc* d, int split) {
   const long wgs = (long)d->B * d->nQ * split;
   return (int)(wgs < 256 ? wgs : 256);
@@ -734,9 +743,7 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
   // only, 406 us.  Read per call: the parity test runs the kernels side by side in one process.
   // 4: attn_bwd_box3.hip, workgroup-wide sort of 1024 keys, exact fp32 products; 5 (default where dS is given):
   // attn_bwd_box4.hip, wave-private chunks sorted by one LDS add per pair, exact fp32 products
-  const char* box_var = getenv("VDETR_BWD_BOX");
-  int box_env = box_var ? atoi(box_var) : (ds_given ? 5 : 2);
-  if (box_env >= 4 && !ds_given) box_env = 2;  // the third and fourth designs only exist in the dS-given form
+  const int box_env = bwd_box_variant(ds_given);
   VDETR_REQUIRE(!ds_given || box_env != 1, "attn_bwd_table: not built into the first box kernel (VDETR_BWD_BOX=1)");
   VDETR_REQUIRE(!ds_given || P.T * P.T * P.T <= kWave * 16, "attn_bwd_table: table edge %d too large for the matrix-unit kernel", P.T);
   const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && P.T == 10;
@@ -787,6 +794,20 @@ extern "C" int vdetr_attn_bwd_scores_f32(const vdetr_attn_desc* d, const float* 
 extern "C" int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* ds, float* dtable, void* workspace,
                                         size_t workspace_bytes, vdetr_stream_t stream) {
   return attn_bwd_scores_impl(d, nullptr, ds, nullptr, nullptr, nullptr, nullptr, dtable, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int vdetr_attn_bwd_table_kernel_names(const vdetr_attn_desc* d, const char** box_kernel, const char** general_kernel) {
+  VDETR_REQUIRE(d && box_kernel && general_kernel, "attn_bwd_table_kernel_names: null pointer");
+  VDETR_REQUIRE(d->table, "attn_bwd_table_kernel_names: no RPE table in the descriptor");
+  static const char* const kBox[] = {nullptr, "attn_bwd_box_kernel", "attn_bwd_box2_kernel<false>", "attn_bwd_box2_kernel<true>",
+                                     "attn_bwd_box3_kernel", "attn_bwd_box4_kernel"};
+  const int variant = bwd_variant(), box_env = bwd_box_variant(true);
+  const int T = d->table_size;
+  const bool mm = variant != 0 && variant != 1 && T * T * T <= kWave * 16;
+  const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && T == 10;
+  *box_kernel = box ? kBox[box_env > 5 ? 5 : box_env] : nullptr;
+  *general_kernel = mm ? "attn_bwd_scores_rpe_mm_kernel" : "attn_bwd_scores_rpe_kernel";
+  return VDETR_OK;
 }
 
 extern "C" int vdetr_attn_delta_f32(const vdetr_attn_desc* d, const float* dout, const float* out, const float* v,

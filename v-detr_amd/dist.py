@@ -55,16 +55,22 @@ class FlatParams:
     one tensor and rides into the optimizer launch as its ``grad_scale``, and the all-reduce buckets are plain slices of
     the gradient buffer.  ``p.data`` of every parameter is re-pointed at its slice (state_dict / load_state_dict keep
     working, they copy in place); calling ``module.to()`` afterwards would detach the views again.
-    Layout = the model's adjacency groups first, then REVERSE parameter order, so that slices complete roughly
-    front-to-back during backward."""
+    Layout = the model's adjacency groups first, then the rest: shape by shape (``group_shapes=True``, for loops that park
+    their weight gradients) or in plain REVERSE parameter order (``group_shapes=False``: the hooked eager path, whose slices
+    then complete roughly front-to-back during backward)."""
 
-    def __init__(self, params, groups=None, first=None):
+    def __init__(self, params, groups=None, first=None, group_shapes=True):
         """``groups``: optional list of (parameters, slot) — parameters a model wants ADJACENT in memory, in this order
         (see helpers.cat_params).  slot = None packs them back to back; slot = n gives every parameter a zero-padded
         slab of n elements (helpers.slot_stack_params).  Everything else follows in reverse parameter order.
         ``first``: parameters to lay out before all others of the ungrouped rest (e.g. the part of a model whose gradients
         are final first, so that its gradient buckets are contiguous and can be all-reduced while the rest is still in
-        its backward pass)."""
+        its backward pass).  ``group_shapes`` (default): the ungrouped matrices are laid out shape by shape — for loops that
+        park their weight gradients and compute them per shape in batched GEMMs (runtime.defer_weight_grads, reduce_phased);
+        False keeps plain REVERSE parameter order, the layout for the hooked eager path (GradientReducer with
+        bucket_views=True), whose buckets then complete roughly back to front while the backward pass is still running.
+        (A flat optimizer state saved under one layout does not line up with the other: persist it per parameter —
+        ``state_dict_per_parameter`` — not as the flat tensor.)"""
         plist = [p for p in params if p.requires_grad]
         first_ids = {id(p) for p in (first or [])}
         assert plist, "no trainable parameters"
@@ -85,10 +91,13 @@ class FlatParams:
         # groups lets reduce_phased() finish and send it without splitting such a batch
         rest = [p for p in reversed(plist) if id(p) not in placed]
         order = {}
-        for p in rest:
-            if p.ndim == 2:
-                order.setdefault((p.shape[1], p.shape[0] % p.shape[1] == 0), len(order))  # [k*C, C] stacks go with [C, C]
-        rest.sort(key=lambda p: order[(p.shape[1], p.shape[0] % p.shape[1] == 0)] if p.ndim == 2 else len(order))  # stable
+        def shape_key(p):  # [k*C, C] stacks go with [C, C]; an empty matrix is its own kind
+            return (p.shape[1], p.shape[1] > 0 and p.shape[0] % p.shape[1] == 0)
+        if group_shapes:
+            for p in rest:
+                if p.ndim == 2:
+                    order.setdefault(shape_key(p), len(order))
+            rest.sort(key=lambda p: order[shape_key(p)] if p.ndim == 2 else len(order))  # stable
         rest.sort(key=lambda p: 0 if id(p) in first_ids else 1)  # stable: keeps the shape runs inside each part
         for p in rest:
             if id(p) not in placed:

@@ -445,7 +445,8 @@ class PositionEmbeddingLearned(nn.Module):
         x = xyz.transpose(1, 2)  # [B, C_in, N]; the 1x1 convolution reads the transposed operand in place
         bn = head[1]
         if not (self.training and x.is_cuda and type(bn) is nn.BatchNorm1d and bn.momentum is not None and bn.track_running_stats):
-            return head(x.contiguous())
+            from . import bn_act as BNA  # (cross-replica statistics on this path too while bn_act.set_sync is on)
+            return BNA.run_sequential(head, x.contiguous())
         if DeferredParamGrads.enabled and DeferredParamGrads.direct and not x.requires_grad and torch.is_grad_enabled() \
                 and head[3].bias is not None:
             return _PosEmbedDeferred.apply(self, x, head[0].weight, head[1].weight, head[1].bias, head[3].weight,
@@ -507,7 +508,8 @@ class GenericMLP(nn.Module):
     def forward(self, x):
         mods = list(self.layers)
         if not (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and torch.is_grad_enabled()):
-            return self.layers(x)
+            from . import bn_act as BNA
+            return BNA.run_sequential(self.layers, x)
         # Conv1d(k=1) -> BatchNorm1d -> ReLU [-> Dropout] blocks as GEMM + ONE fused launch (bn_act.py: statistics, affine,
         # ReLU, dropout and the running-statistics bookkeeping; the convolution's bias only enters the running mean)
         from . import bn_act as BNA
@@ -528,7 +530,7 @@ class GenericMLP(nn.Module):
                                counters=[bn.num_batches_tracked])
                 i += 3 if drop is None else 4
             else:
-                x = m(x)
+                x = BNA.batch_norm_module(m, x) if isinstance(m, nn.modules.batchnorm._BatchNorm) else m(x)
                 i += 1
         return x
 

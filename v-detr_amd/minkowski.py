@@ -143,12 +143,15 @@ class CoordinateManager:
         stream = stream or torch.cuda.current_stream()
         if torch.cuda.is_current_stream_capturing():
             return self
+        # the memo holds the recorded tensors THEMSELVES (keyed by storage + stream): an id() of a freed tensor could be
+        # handed to a new one, which would then be skipped and its block recycled under the training stream's kernels
         done = self.__dict__.setdefault("_recorded", {})
         for t in self.device_tensors():
-            key = (id(t), stream.cuda_stream)
-            if key not in done:
+            key = (t.untyped_storage().data_ptr(), stream.cuda_stream)
+            held = done.get(key)
+            if held is None or held is not t:
                 t.record_stream(stream)
-                done[key] = True
+                done[key] = t
         return self
 
     def finalize(self):

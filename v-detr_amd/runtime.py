@@ -80,7 +80,24 @@ def enable_gemm_tuning(rank=0, cache_dir=None):
             shutil.rmtree(scratch_dir, ignore_errors=True)
 
     atexit.register(_finish)
+    _FINISHERS.append(_finish)
     return path
+
+
+_FINISHERS = []
+
+
+def finish_gemm_tuning():
+    """Publish what this run tuned and remove the per-process scratch NOW.  For callers that leave through ``os._exit`` (which
+    skips atexit handlers): bench.py after a distributed run whose captured graphs hold RCCL nodes.  Idempotent."""
+    import atexit
+    while _FINISHERS:
+        fn = _FINISHERS.pop()
+        try:
+            atexit.unregister(fn)
+        except Exception:  # noqa: BLE001
+            pass
+        fn()
 
 
 def defer_weight_grads(enable=True):

@@ -592,7 +592,10 @@ def bn_act(x, bn, act=None, residual=None):
     fused = x.is_cuda and type(bn) is torch.nn.BatchNorm1d and x.shape[1] % 4 == 0 and 0 < x.shape[1] <= 1024 and x.shape[0] > 0 \
         and not _NO_FUSED_BN and (bn.momentum is not None or not bn.training)
     if not fused:
-        y = bn(x)
+        from . import bn_act as BNA
+        # (with bn_act.set_sync this is still a cross-replica BatchNorm — as tensor expressions — and a rank whose tensor is
+        # EMPTY joins its collectives with a count of zero instead of leaving the other ranks waiting)
+        y = BNA.batch_norm_module(bn, x, channel_last=True)
         if residual is not None:
             y = y + residual
         return torch.relu(y) if act == "relu" else torch.nn.functional.elu(y) if act == "elu" else y

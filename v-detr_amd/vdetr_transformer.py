@@ -697,7 +697,10 @@ class TransformerDecoder(nn.Module):
         if not inplace:
             rm = torch.cat([b.running_mean for b in bns])
             rv = torch.cat([b.running_var for b in bns])
-        y = F.batch_norm(x, rm, rv, w, bias, training, bns[0].momentum, bns[0].eps)
+        if training and BNA.sync_active():  # cross-replica statistics on this path too (incl. the first call of a device)
+            y = BNA.sync_batch_norm(x, w, bias, rm, rv, None, bns[0].momentum, bns[0].eps)
+        else:
+            y = F.batch_norm(x, rm, rv, w, bias, training, bns[0].momentum, bns[0].eps)
         if training:
             with torch.no_grad():
                 if not inplace:  # hand the updated statistics back to the modules that own them
