@@ -141,6 +141,28 @@ def loss_fn(out):
                            for k in ("sem_cls_logits", "center_normalized", "size_normalized")])
 
 
+def allreduce_bucket_model(grad_bytes, world):
+    """How many gradient buckets the captured decoder step should use, from a model instead of a 1-rank timing (where the
+    collective is free).  Ring all-reduce over the node's xGMI mesh: every GPU sends and receives 2 (W-1)/W x S bytes, RCCL
+    spreads its rings over the W-1 direct links (MI355X: 7 links x 153.6 GB/s bidirectional = 76.8 GB/s per direction and
+    link; VDETR_XGMI_GBPS / VDETR_XGMI_EFF override), so t(S) = 2 (W-1)/W x S / (links x 76.8 GB/s x eff) + latency.  With k
+    buckets all but the last all-reduce hide under the next bucket's batched weight-gradient GEMMs, but every extra phase
+    splits those batches: +0.33 ms per extra phase (measured).  exposed(k) = t(S / k) + (k - 1) x 0.33 ms."""
+    if world < 2:
+        return {"buckets": 1, "bucket_mb": 64.0, "note": "1 rank: nothing to overlap"}
+    per_dir = float(os.environ.get("VDETR_XGMI_GBPS", "76.8"))
+    eff = float(os.environ.get("VDETR_XGMI_EFF", "0.7"))
+    links = min(world - 1, 7)
+    busbw = per_dir * links * eff * 1e9
+    t = lambda nbytes: 2.0 * (world - 1) / world * nbytes / busbw * 1e3 + 0.03  # ms  # noqa: E731
+    split_ms = float(os.environ.get("VDETR_SPLIT_COST_MS", "0.33"))
+    exposed = {k: t(grad_bytes / k) + (k - 1) * split_ms for k in (1, 2, 3, 4)}
+    k = min(exposed, key=exposed.get)
+    return {"buckets": k, "bucket_mb": grad_bytes / k / (1 << 20) + 1.0, "bus_GBps_assumed": busbw / 1e9, "allreduce_ms_model": t(grad_bytes),
+            "exposed_ms_model": {str(kk): round(v, 3) for kk, v in exposed.items()},
+            "note": "bucket count = argmin of the modelled exposed time (allreduce_bucket_model in bench.py); VDETR_BUCKET_MB overrides"}
+
+
 class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
@@ -165,7 +187,10 @@ class Trainer:
         # (shape-grouped layout for the parked weight gradients; reverse parameter order where bucket hooks fire during an
         # eager backward with inline weight gradients, so that buckets complete while the backward is still running)
         self.flat = FlatParams(self.params, groups=model.flat_param_groups(), group_shapes=defer_wg or not self.hooked)
-        self.reducer = GradientReducer(self.params, bucket_mb=float(os.environ.get("VDETR_BUCKET_MB", "64")), overlap=self.hooked,
+        grad_bytes = sum(p.numel() for p in self.params) * 4
+        self.bucket_model = allreduce_bucket_model(grad_bytes, world)
+        bucket_mb = float(os.environ.get("VDETR_BUCKET_MB", self.bucket_model["bucket_mb"]))
+        self.reducer = GradientReducer(self.params, bucket_mb=bucket_mb, overlap=self.hooked,
                                        bucket_views=self.hooked, flat=self.flat, force=force_dist)
         # Captured step on several ranks: the gradient buckets are all-reduced INSIDE the hipGraph, each on the side stream as
         # soon as its slice of the flat buffer is packed, while the parked weight gradients of the next bucket are computed
@@ -351,7 +376,9 @@ class BackboneTrainer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.dec_params = [p for n, p in model.named_parameters() if n.startswith(("decoder.", "encoder_to_decoder"))]
         self.bb_params = [p for n, p in model.named_parameters() if not n.startswith(("decoder.", "encoder_to_decoder"))]
-        self.flat = FlatParams(self.params, groups=model.flat_param_groups(), first=self.dec_params)
+        # (the decoder's part shape by shape for its batched weight gradients, the backbone's in REVERSE parameter order: its
+        # gradient buckets then complete one after the other while its eager backward pass is still running)
+        self.flat = FlatParams(self.params, groups=model.flat_param_groups(), first=self.dec_params, group_shapes="first")
         # data parallel: the decoder's gradients (47 MB) are final after its captured backward and are all-reduced on the side
         # stream while the backbone's backward (the larger half of the step) runs; the backbone's 268 MB follow in 64 MB buckets
         first_bb = next(p for p in self.flat.params if any(p is q for q in self.bb_params))
@@ -360,6 +387,11 @@ class BackboneTrainer:
         self.dec_buckets = self.reducer.buckets_of(self.dec_params)
         self.bb_buckets = [k for k in range(len(self.reducer.buckets)) if k not in self.dec_buckets]
         assert not set(self.reducer.buckets_of(self.bb_params)) & set(self.dec_buckets), "decoder / backbone gradients share a bucket"
+        # every backbone bucket leaves as soon as its last gradient has arrived, under the rest of the backbone's backward
+        # (DistributedDataParallel's bucket hooks in the reference, main.py:515-517); VDETR_BB_OVERLAP=0: all of them after it
+        self.bb_overlap = self.reducer.active and os.environ.get("VDETR_BB_OVERLAP", "1") != "0"
+        if self.bb_overlap:
+            self.reducer.launch_when_complete(self.bb_buckets)
         self.opt = torch.optim.AdamW([self.flat.param], lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
         self.graph, self.loss = None, None
         # the NEXT scene's geometry and FPS indices are built on a side stream while this scene trains (the synthetic bench
@@ -450,10 +482,12 @@ class BackboneTrainer:
             self._worker.start()
         if self.reducer.active:
             self.reducer.pack_and_launch(self.dec_buckets)  # overlaps the backbone's backward
-        enc_rows.backward(self.static_feat.grad.permute(1, 0, 2))
+            if self.bb_overlap:
+                self.reducer.begin_watch()
+        enc_rows.backward(self.static_feat.grad.permute(1, 0, 2))  # (backbone buckets are packed and sent from its hooks)
         mark()
         if self.reducer.active:
-            self.reducer.pack_and_launch(self.bb_buckets)
+            self.reducer.pack_and_launch(self.reducer.pending_watched() if self.bb_overlap else self.bb_buckets)
             self.reducer.finish()
         else:
             self.flat.pack_grads()
@@ -984,7 +1018,8 @@ def main():
                    "step": "FPS+gather, projection, decoder fwd, loss, backward, grad all-reduce (N>1), clip, AdamW",
                    "hip_graph": graph_ok, "sync_bn": bool(a.sync_bn), "fps_prefetch": not a.no_fps_prefetch,
                    "fps_lookahead": 2 if getattr(trainer, "fps_depth2", False) and graph_ok else (1 if not a.no_fps_prefetch else 0),
-                   "grad_allreduce_bytes": trainer.reducer.grad_bytes(),
+                   "grad_allreduce_bytes": trainer.reducer.grad_bytes(), "grad_allreduce_buckets": len(trainer.reducer.buckets),
+                   "grad_allreduce_model": trainer.bucket_model,
                    "grad_allreduce": ("none (1 rank)" if not trainer.reducer.active else
                                       "inside the hipGraph, bucket by bucket on a side stream while the next bucket's weight gradients are computed"
                                       if trainer.phased and graph_ok else
@@ -1077,6 +1112,10 @@ def main():
             result["with_backbone"] = {
                 "ms_per_step": ms, "scenes_per_s": world * 1e3 / ms, "n_gpus": world, "geometry_ms": bt.geometry_ms, "input_points": 40000,
                 "grad_allreduce_bytes": bt.reducer.grad_bytes() if bt.reducer.active else 0,
+                "grad_allreduce": ("decoder bucket(s) on the side stream under the backbone's backward; backbone buckets of 64 MB sent from "
+                                   "post-accumulate hooks while that backward is still running" if getattr(bt, "bb_overlap", False) else
+                                   "after the backbone's backward" if bt.reducer.active else "none (1 rank)"),
+                "grad_allreduce_buckets": len(bt.reducer.buckets) if bt.reducer.active else 0,
                 "voxels_per_stride": bt.voxels, "backbone_parameters": sum(p.numel() for p in bt.bb_params), "loss": bloss,
                 "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP kernel maps, fused pair-list convolutions — wide layers as split-bf16 products (2^-16 each) on the bf16 matrix unit, f32 accumulate —, fused BatchNorm; eager) -> FPS tokens -> "
                         "decoder step (captured hipGraph) -> backbone backward -> clip + AdamW over all 79 M parameters; "

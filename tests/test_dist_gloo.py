@@ -486,3 +486,78 @@ def test_sync_batch_norm_fallback_paths_match_one_big_batch():
     for r in (m0, m1):
         np.testing.assert_allclose(r[3], bnm.running_mean.numpy(), rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(r[4], bnm.running_var.numpy(), rtol=1e-10, atol=1e-12)
+
+
+def _watch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vdetr_amd.dist import FlatParams, GradientReducer, broadcast_parameters, init_distributed
+    init_distributed("gloo")
+    torch.manual_seed(3)
+    bb = torch.nn.Sequential(*[torch.nn.Linear(8, 8) for _ in range(6)])      # "backbone": eager backward, watched buckets
+    dec = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 2))   # "decoder": gradients final first
+    unused = torch.nn.Linear(8, 8)                                            # never receives a gradient: its bucket is flushed after
+    params = list(bb.parameters()) + list(unused.parameters()) + list(dec.parameters())
+    broadcast_parameters(torch.nn.ModuleList([bb, dec, unused]))
+    flat = FlatParams(params, first=list(dec.parameters()), group_shapes="first")
+    # the backbone part lies in REVERSE parameter order behind the decoder part
+    offs = [flat.offsets[id(p)] for p in bb.parameters()]
+    assert offs == sorted(offs, reverse=True)
+    first_bb = next(p for p in flat.params if not any(p is d for d in dec.parameters()))
+    red = GradientReducer(params, bucket_mb=0.0004, overlap=False, bucket_views=False, flat=flat, break_before=[first_bb])
+    dec_b = red.buckets_of(list(dec.parameters()))
+    bb_b = [k for k in range(len(red.buckets)) if k not in dec_b]
+    assert len(bb_b) >= 3
+    launched_in_backward = []
+    orig = red._launch
+    red._launch = lambda k: (launched_in_backward.append(k), orig(k))[1]
+    red.launch_when_complete(bb_b)
+    torch.manual_seed(10 + rank)
+    x = torch.randn(5, 8)
+    out = []
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        launched_in_backward.clear()
+        red.begin_watch()
+        dec(bb(x)).square().sum().backward()
+        during = list(launched_in_backward)
+        red.pack_and_launch(dec_b)
+        pend = red.pending_watched()
+        red.pack_and_launch(pend)
+        red.finish()
+        out.append((during, pend, flat.grad.numpy().copy()))
+    # reference: local gradients, to be averaged by the parent
+    for p in params:
+        p.grad = None
+    dec(bb(x)).square().sum().backward()
+    q.put((rank, out, [(flat.offsets[id(p)], (torch.zeros_like(p) if p.grad is None else p.grad).numpy().copy()) for p in params], bb_b))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_watched_buckets_leave_during_the_backward_pass():
+    """GradientReducer.launch_when_complete (the backbone's gradient buckets in BackboneTrainer): with the backbone part of the
+    flat buffer in reverse parameter order, every watched bucket whose parameters all receive a gradient is packed and its
+    all-reduce started from a post-accumulate hook INSIDE backward(), in the order the backward pass completes them; a bucket
+    with an unused parameter is left for pending_watched(); the flat gradient equals the average of the ranks' gradients."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_watch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, _, bb_b in res:
+        for during, pend, _ in out:
+            assert len(during) >= 2 and set(during) <= set(bb_b), (during, bb_b)   # sent while backward() was still running
+            assert during == sorted(during)                                         # back to front = ascending bucket index
+            assert len(pend) >= 1 and not set(pend) & set(during)                   # the bucket of the unused parameter
+    for (off, g0), (_, g1) in zip(res[0][2], res[1][2]):
+        avg = ((g0 + g1) / 2).reshape(-1)
+        for rank, out, _, _ in res:
+            for _, _, flatgrad in out:
+                np.testing.assert_allclose(flatgrad[off:off + avg.size], avg, rtol=1e-6, atol=1e-7)

@@ -446,8 +446,7 @@ def test_bf16_attention_core_vs_oracle(B, nQ, nK, boxes):
     for c in range(0, nQ, 64):
         sl = slice(c, c + 64)
         rq = q[:, sl].double().requires_grad_(True)
-        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(),
-                                      cos_sin=None if cs is None else cs[:, sl].double(), **kw)
+        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
         (o * wout[:, sl].double()).sum().backward()
         routs.append(o.detach())
         rdq.append(rq.grad)

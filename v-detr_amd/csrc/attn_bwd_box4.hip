@@ -206,29 +206,58 @@ __global__ __launch_bounds__(kB4Threads) void attn_bwd_box4_kernel(AttnParams P)
       // register quad, where scalar branches make it copy the four registers behind the wait states of a matrix result at every
       // merge —, 319 us; the matrix instruction as asm with the accumulator tied in place: the compiler still copies it right
       // behind the asm, where nothing pads the hazard.  The form below is the one with the fewest instructions: 299 us.)
+      if (ns == kWave) {  // a full chunk (every chunk when nK is a multiple of 64): no bounds in the walk
 #pragma unroll
-      for (int i = 0; i < kWave / 4; ++i) {
-        if (4 * i < ns) {
-          unsigned eb = (unsigned)(emask >> (4 * i)) & 0xFu;
+        for (int i = 0; i < kWave / 4; ++i) {
+          const unsigned eb = (unsigned)(emask >> (4 * i)) & 0xFu;
           if (eb == 0u) {  // the quad lies inside one group: one matrix instruction, nothing else
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i], t[i], acc, 0, 0, 0);
           } else if (eb == 8u) {  // ... or ends one with its last slot
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(u[i], t[i], acc, 0, 0, 0);
             flush(4 * i + 3);
-          } else {  // a group ends inside: one instruction per segment, the other slots' rows zeroed
-            const int nq = min(4, ns - 4 * i);
-            int s = 0;
-            do {
-              const int e = eb ? __builtin_ctz(eb) : 3;
-              const bool on = kk >= s && kk <= e;
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(on ? u[i] : 0.f, t[i], acc, 0, 0, 0);
-              if (eb) {
-                flush(4 * i + e);
-                eb &= eb - 1;
-              }
-              s = e + 1;
-            } while (s < nq);
+          } else {
+            // a group ends inside the quad (slot e0 < 3): its slots' rows first, flush, then the rows of the slots behind it —
+            // which belong to the next group(s).  One more end at slot 3 or none: straight-line; two ends inside: the loop.
+            const int e0 = __builtin_ctz(eb);
+            const bool head = kk <= e0;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(head ? u[i] : 0.f, t[i], acc, 0, 0, 0);
+            flush(4 * i + e0);
+            unsigned rest = eb & (eb - 1u);
+            if ((rest & 7u) == 0u) {
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(head ? 0.f : u[i], t[i], acc, 0, 0, 0);
+              if (rest) flush(4 * i + 3);
+            } else {
+              int s = e0 + 1;
+              do {
+                const int e = rest ? __builtin_ctz(rest) : 3;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk >= s && kk <= e ? u[i] : 0.f, t[i], acc, 0, 0, 0);
+                if (rest) {
+                  flush(4 * i + e);
+                  rest &= rest - 1u;
+                }
+                s = e + 1;
+              } while (s < 4);
+            }
           }
+        }
+      } else {  // the last, partly filled chunk of a key count that is not a multiple of 64
+        for (int i = 0; 4 * i < ns; ++i) {
+          unsigned eb = (unsigned)(emask >> (4 * i)) & 0xFu;
+          const int nq = min(4, ns - 4 * i);
+          // (u / t of quad i: re-read, this loop is not unrolled)
+          const float ui = *reinterpret_cast<const b4_rec1_t*>(rq + i * 4 * kB4RecBytes + a_off);
+          const float ti = *reinterpret_cast<const b4_rec1_t*>(rq + i * 4 * kB4RecBytes + b_offx) *
+                           *reinterpret_cast<const b4_rec1_t*>(rq + i * 4 * kB4RecBytes + b_offd);
+          int s = 0;
+          do {
+            const int e = eb ? __builtin_ctz(eb) : 3;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kk >= s && kk <= e ? ui : 0.f, ti, acc, 0, 0, 0);
+            if (eb) {
+              flush(4 * i + e);
+              eb &= eb - 1u;
+            }
+            s = e + 1;
+          } while (s < nq);
         }
       }
     }

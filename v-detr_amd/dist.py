@@ -68,7 +68,8 @@ class FlatParams:
         its backward pass).  ``group_shapes`` (default): the ungrouped matrices are laid out shape by shape — for loops that
         park their weight gradients and compute them per shape in batched GEMMs (runtime.defer_weight_grads, reduce_phased);
         False keeps plain REVERSE parameter order, the layout for the hooked eager path (GradientReducer with
-        bucket_views=True), whose buckets then complete roughly back to front while the backward pass is still running.
+        bucket_views=True), whose buckets then complete roughly back to front while the backward pass is still running;
+        "first" groups the shapes of the ``first`` part only (a captured decoder in front of an eager backbone).
         (A flat optimizer state saved under one layout does not line up with the other: persist it per parameter —
         ``state_dict_per_parameter`` — not as the flat tensor.)"""
         plist = [p for p in params if p.requires_grad]
@@ -93,11 +94,16 @@ class FlatParams:
         order = {}
         def shape_key(p):  # [k*C, C] stacks go with [C, C]; an empty matrix is its own kind
             return (p.shape[1], p.shape[1] > 0 and p.shape[0] % p.shape[1] == 0)
-        if group_shapes:
+        if group_shapes:  # ("first": only the `first` part is shape-grouped, the rest keeps reverse parameter order)
+            grouped = (lambda p: id(p) in first_ids) if group_shapes == "first" else (lambda p: True)
             for p in rest:
-                if p.ndim == 2:
+                if p.ndim == 2 and grouped(p):
                     order.setdefault(shape_key(p), len(order))
-            rest.sort(key=lambda p: order[shape_key(p)] if p.ndim == 2 else len(order))  # stable
+            if group_shapes == "first":
+                rest = sorted((p for p in rest if grouped(p)), key=lambda p: order[shape_key(p)] if p.ndim == 2 else len(order)) + \
+                    [p for p in rest if not grouped(p)]
+            else:
+                rest.sort(key=lambda p: order[shape_key(p)] if p.ndim == 2 else len(order))  # stable
         rest.sort(key=lambda p: 0 if id(p) in first_ids else 1)  # stable: keeps the shape runs inside each part
         for p in rest:
             if id(p) not in placed:
@@ -416,6 +422,45 @@ class GradientReducer:
             self.flat.pack_grads_span(*self._spans[k])
             if self.active:
                 self._launch(k)
+
+    def launch_when_complete(self, buckets):
+        """flat-buffer, plain-gradient mode, EAGER backward: watch the parameters of these buckets; as soon as every one of a
+        bucket has received its gradient (post-accumulate hooks, whatever runtime.defer_weight_grads says: the caller vouches
+        that these parameters' gradients are final when they arrive), its slice is packed and its all-reduce starts on the
+        side stream — while the backward pass that is still producing the other buckets' gradients keeps running.  What the
+        reference gets from DistributedDataParallel's bucket hooks (main.py:515-517).  Call ``begin_watch()`` before every
+        backward pass, ``pack_and_launch(pending_watched())`` + ``finish()`` after it."""
+        assert self.flat is not None and not self.bucket_views
+        self._watched = {k: 0 for k in buckets}
+        self._watch_need = {k: 0 for k in buckets}
+        self._watch_seen = set()
+        for p in self.flat.params:
+            k = self._bucket_of.get(id(p))
+            if k in self._watched:
+                self._watch_need[k] += 1
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(self._watch_hook))
+
+    def begin_watch(self):
+        for k in self._watched:
+            self._watched[k] = 0
+        self._watch_seen.clear()
+
+    def _watch_hook(self, p):
+        if id(p) in self._watch_seen:
+            return
+        self._watch_seen.add(id(p))
+        k = self._bucket_of[id(p)]
+        self._watched[k] += 1
+        if self._watched[k] == self._watch_need[k] and not self._launched[k]:
+            self.flat.pack_grads_span(*self._spans[k])
+            if self.active:
+                self._launch(k)
+            else:
+                self._launched[k] = True
+
+    def pending_watched(self):
+        """watched buckets that did not complete during the backward pass (a parameter without gradient)"""
+        return [k for k in getattr(self, "_watched", {}) if not self._launched[k]]
 
     def buckets_of(self, params):
         """indices of the buckets that hold these parameters"""
