@@ -35,9 +35,11 @@ def allreduce_window(path):
     print(f"# all-reduce kernels inside the backward window: {ok}, after it: {bad}")
 
 
+
 if len(sys.argv) > 2 and sys.argv[1] == "--allreduce":
     allreduce_window(sys.argv[2])
     sys.exit(0)
+
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 win = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0

@@ -79,18 +79,37 @@ def check_code_objects(lib, verbose=False):
             nobj += 1
             asm = subprocess.run([objdump, "-d", os.path.join(tmp, f)], capture_output=True, text=True).stdout
             kernel = "?"
+            pending = None  # (register number, kernel) of an asm `global_atomic_add vN, v[a:b], vM, off` whose result is in flight
             for line in asm.splitlines():
                 m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
                 if m:
-                    kernel = m.group(1)
-                else:
-                    m = re.search(_PACKED, line)
-                    if m and _hi_broadcast(m.group(2)):
-                        hits.append(f"{kernel}: {m.group(1)}{m.group(2).rstrip()}")
+                    kernel, pending = m.group(1), None
+                    continue
+                m = re.search(_PACKED, line)
+                if m and _hi_broadcast(m.group(2)):
+                    hits.append(f"{kernel}: {m.group(1)}{m.group(2).rstrip()}")
+                # The table-gradient kernels draw their next query with a returning atomic written as asm, so that nothing waits
+                # for it at once (attn_bwd_box4.hip).  The compiler does not know that its destination register is still in flight:
+                # nothing may touch that register before the `s_waitcnt vmcnt(0)` that precedes its one use.
+                a = re.search(r"\bglobal_atomic_add\s+v(\d+),\s*v\[\d+:\d+\],\s*v\d+,\s*off", line)
+                if a:
+                    pending = int(a.group(1))
+                elif pending is not None:
+                    if re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", line):
+                        pending = None
+                    else:
+                        body = line.split("//")[0]
+                        regs = {int(r) for r in re.findall(r"\bv(\d+)\b", body)}
+                        for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", body):
+                            regs.update(range(int(lo), int(hi) + 1))
+                        if pending in regs:
+                            hits.append(f"{kernel}: v{pending} (result of an asm atomic still in flight) touched by: {body.strip()[:80]}")
+                            pending = None
     if nobj == 0:
         raise RuntimeError(f"no {ARCH} code object found in {lib}")
     if hits:
-        raise RuntimeError("packed fp32 multiply with a high-broadcast second source (DESIGN.md 4.4b) in:\n  " + "\n  ".join(hits[:20]))
+        raise RuntimeError("code-object check failed (packed fp32 multiply with a high-broadcast second source, DESIGN.md 4.4b; or a "
+                           "register of an in-flight asm atomic touched early, attn_bwd_box4.hip):\n  " + "\n  ".join(hits[:20]))
     if verbose:
         print(f"checked {nobj} {ARCH} code objects: no v_pk_mul/fma_f32 with a high-broadcast second source")
     return nobj

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kB3Threads) void attn_bwd_box3_kernel(AttnParams P)
       // the query's LAST tile, behind a wait that then has nothing left to wait for.
       if (tile == 0 && tid == 0) {
         drawn = items;
-        if (taken < cap) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(drawn) : "v"(counter), "v"(1) : "memory");
+        if (taken < cap) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_nop 3" : "=&v"(drawn) : "v"(counter), "v"(1) : "memory");  // (the nop: nobody may overwrite the address / data registers before the instruction has read them)
       }
       b3_barrier();
       if (valid && (wv & 1)) seen = __hip_atomic_fetch_add(&cnt[gid], pair_one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kB4Threads) void attn_bwd_box4_kernel(AttnParams P)
   int slot_of_next = 1;  // misc[1] / misc[2] alternate as the hand-over word of the next query
   while (item < items) {
     int drawn = items;  // the query after this one: drawn now by one lane (asm: nothing waits for it), handed over below
-    if (tid == 0 && taken < cap) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(drawn) : "v"(counter), "v"(1) : "memory");
+    if (tid == 0 && taken < cap) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_nop 3" : "=&v"(drawn) : "v"(counter), "v"(1) : "memory");  // (the nop: nobody may overwrite the address / data registers before the instruction has read them)
     const int b = item / P.nQ;
     const float* vp = P.vertices + (size_t)item * 24;
     const float X0 = uni(vp[0]), X1 = uni(vp[6]), Y0 = uni(vp[1]), Y1 = uni(vp[4]), Zp = uni(vp[part * 12 + 2]);
