@@ -487,7 +487,9 @@ class BackboneTrainer:
         enc_rows.backward(self.static_feat.grad.permute(1, 0, 2))  # (backbone buckets are packed and sent from its hooks)
         mark()
         if self.reducer.active:
-            self.reducer.pack_and_launch(self.reducer.pending_watched() if self.bb_overlap else self.bb_buckets)
+            pending = self.reducer.pending_watched() if self.bb_overlap else self.bb_buckets
+            self.sent_in_backward = len(self.bb_buckets) - len(pending)  # buckets whose all-reduce started under the backward pass
+            self.reducer.pack_and_launch(pending)
             self.reducer.finish()
         else:
             self.flat.pack_grads()
@@ -1116,6 +1118,7 @@ def main():
                                    "post-accumulate hooks while that backward is still running" if getattr(bt, "bb_overlap", False) else
                                    "after the backbone's backward" if bt.reducer.active else "none (1 rank)"),
                 "grad_allreduce_buckets": len(bt.reducer.buckets) if bt.reducer.active else 0,
+                "backbone_buckets_sent_during_backward": getattr(bt, "sent_in_backward", 0),
                 "voxels_per_stride": bt.voxels, "backbone_parameters": sum(p.numel() for p in bt.bb_params), "loss": bloss,
                 "note": "raw points -> voxels -> MinkResNet34 + FPN (HIP kernel maps, fused pair-list convolutions — wide layers as split-bf16 products (2^-16 each) on the bf16 matrix unit, f32 accumulate —, fused BatchNorm; eager) -> FPS tokens -> "
                         "decoder step (captured hipGraph) -> backbone backward -> clip + AdamW over all 79 M parameters; "
@@ -1187,7 +1190,7 @@ def main():
             print(f"[bench] process-group shutdown: {type(exc).__name__}: {exc}", file=sys.stderr)
             rc = 3
         rccl_in_graph = bool(graph_ok and getattr(trainer, "phased", False) and trainer.reducer.active and a.backend == "nccl")
-        if rccl_in_graph or rc:
+        if (rccl_in_graph and os.environ.get("VDETR_BENCH_NORMAL_EXIT") != "1") or rc:  # (NORMAL_EXIT: under a profiler that writes its trace at exit)
             try:
                 from vdetr_amd.runtime import finish_gemm_tuning
                 finish_gemm_tuning()
