@@ -120,7 +120,8 @@ __global__ __launch_bounds__(kB4Threads) void attn_bwd_box4_kernel(AttnParams P)
   auto fetch = [&](rsrc_t rd, rsrc_t rx, int chunk, Ops& o) {  // dS of the 4 heads + the key's position (out-of-range keys read 0)
     const int key = chunk * kWave + lane;
 #pragma unroll
-    for (int h = 0; h < 4; ++h) o.d[h] = ldf(rd, key * 4, h * rowbytes);
+    for (int h = 0; h < 4; ++h)
+      o.d[h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, key * 4, h * rowbytes, kStreamAux));  // dS: read once
     o.kx = ldf(rx, key * 12, 0); o.ky = ldf(rx, key * 12 + 4, 0); o.kz = ldf(rx, key * 12 + 8, 0);
   };
 

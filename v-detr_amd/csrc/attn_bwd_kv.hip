@@ -233,7 +233,7 @@ __global__ __launch_bounds__(WAVES * kWave) void attn_bwd_kv_kernel(KvParams K) 
       const unsigned voff = lane_off + (unsigned)((tile * 32 + 8 * a) * rowbytes);
 #pragma unroll
       for (int h = 0; h < 4; ++h)
-        sv[4 * a + h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + (unsigned)(h * rowbytes)), 0, 0));
+        sv[4 * a + h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + (unsigned)(h * rowbytes)), 0, kStreamAux));
     }
   };
   const int first = hf * kKvWaves + w;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WAVES * kWave) void attn_bwd_kv_kernel(KvParams K) 
           const ScoreGrad gr = score_grad(sv[v], t ? lv1[e] : lv0[e], keep, P.drop_scale, true, dp[v], t ? dv1[e] : dv0[e], masked);
           xp[e] = ok ? gr.p_drop : 0.f;
           xs[e] = ok ? gr.ds : 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(gr.ds), rd, (int)(voff + (unsigned)(h * rowbytes)), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(gr.ds), rd, (int)(voff + (unsigned)(h * rowbytes)), 0, kStreamAux);
         }
       }
       bf16x8 ph, pl, sh, sl;

@@ -11,6 +11,12 @@ constexpr int kDh = 64;          // head dim (reference: dec_dim 256 / dec_nhead
 constexpr int kRpeHeads = 4;     // the RPE lane layout carries the heads of one (query,key) pair in 4 registers
 constexpr int kRpeVerts = 8;     // 8 box vertices (vdetr_transformer.py:710)
 constexpr float kNegBig = -1e30f;
+// Cache policy of the score-sized streams (S, dS: 67 MB per layer and direction at C2, twice the 32 MB of L2): `nt` keeps them
+// from evicting what the small kernels between the attention kernels re-use (weights, activations).  -DVDETR_STREAM_NT=0: off.
+#ifndef VDETR_STREAM_NT
+#define VDETR_STREAM_NT 1
+#endif
+constexpr int kStreamAux = VDETR_STREAM_NT ? 2 : 0;  // raw buffer aux bits: 2 = nt (slc)
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct AttnParams {

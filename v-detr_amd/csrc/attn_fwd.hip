@@ -230,7 +230,8 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
       for (int r = 0; r < 4; ++r) {
         if (qrow[r] < nQ) {
           const size_t row = PERHEAD ? (((size_t)b * H + head) * nQ + qrow[r]) : (((size_t)b * nQ + qrow[r]) * H + r);
-          P.scores[row * nK + key] = sc[r];
+          if (VDETR_STREAM_NT) __builtin_nontemporal_store(sc[r], &P.scores[row * nK + key]);  // 67 MB per layer: past L2
+          else P.scores[row * nK + key] = sc[r];
         }
       }
     }
