@@ -566,7 +566,9 @@ def kernel_rooflines(cfg_name, device, reps=20):
         ang = ((torch.rand((B, nQ), generator=g) * 2 - 1) * 3.1).to(device)  # get the (cos, sin) operand: general RPE kernels
         c, sn = torch.cos(ang)[:, :, None], torch.sin(ang)[:, :, None]
         off = half * signs
-        off = torch.stack((off[..., 0] * c - off[..., 1] * sn, off[..., 0] * sn + off[..., 1] * c, off[..., 2]), -1)
+        # corners = centre + R(angle)^T (+-half): what the box decode writes, so that the kernels' turn by the angle (rpe_rotate)
+        # brings them back onto the axes
+        off = torch.stack((off[..., 0] * c + off[..., 1] * sn, -off[..., 0] * sn + off[..., 1] * c, off[..., 2]), -1)
         verts = (center[:, :, None, :] + off).contiguous()
         cos_sin = torch.stack((c[..., 0], sn[..., 0]), -1).contiguous()
     else:
@@ -1029,8 +1031,8 @@ def main():
         "loss": loss,
         "arith": {"activations": "f32" if dtype == "f32" else "f32 residual stream; q / k / v of the cross attention stored as bf16",
                   "qk_pv": "v_mfma_f32_16x16x4_f32 (exact f32)" if dtype == "f32" else "v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16, f32 accumulate (self-attention: f32)", "softmax_log2_table_lookup": "f32",
-                  "dtable_products": ("exact f32 outer products on v_mfma_f32_16x16x4_f32 (attn_bwd_box4_kernel)" if not CONFIGS[a.config][5] else
-                                      "split-bf16 2^-15 (two bf16 terms per f32 factor; rotated boxes: the general kernel)"),
+                  "dtable_products": "exact f32 outer products on v_mfma_f32_16x16x4_f32 (attn_bwd_box4_kernel: axis-aligned and rotated boxes; "
+                                     "arbitrary vertices take the general kernel: split-bf16 2^-15)",
                   "dtable_accum": "int32 fixed point in LDS",
                   "backward_contractions": "dO V^T, dV = P^T dO, dK = dS^T q: f32 operands as hi + lo bf16 on v_mfma_f32_32x32x16_bf16, "
                                            "three cross terms (2^-16 per product), f32 accumulate; dQ = dS K: library f32 GEMM",

@@ -282,6 +282,66 @@ def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK, variant):
     assert torch.equal(got, again), "not reproducible"
 
 
+def _rotated_boxes(B, nQ, nK, seed):
+    """keys, the corners of ROTATED boxes (centre + R(angle)^T (+-half), as box_decode writes them), tables, (cos, sin)"""
+    xyz, verts, tables, _ = _scene(B, nQ, nK, seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    ang = (torch.rand((B, nQ), generator=g) * 2 - 1) * 3.1
+    c, s_ = torch.cos(ang)[:, :, None], torch.sin(ang)[:, :, None]
+    centre = verts.mean(2, keepdim=True)
+    off = verts - centre
+    # corners = centre + R^T off, so that rpe_rotate (x' = x c - y s, y' = x s + y c) turns them back onto the axes
+    rot = torch.stack((off[..., 0] * c + off[..., 1] * s_, -off[..., 0] * s_ + off[..., 1] * c, off[..., 2]), -1)
+    return xyz, (centre + rot).contiguous(), tables, torch.stack((c[..., 0], s_[..., 0]), -1).contiguous()
+
+
+@pytest.mark.parametrize("B,nQ,nK", [(1, 40, 640), (2, 33, 700), (1, 300, 1024)])
+def test_rotated_boxes_take_the_box_backward_kernel(monkeypatch, B, nQ, nK):
+    """angle_type "object_coords" (BASELINE config 5): the corners of a rotated box are an axis-aligned box in the frame the
+    look-up is turned into, so the sorted box kernel (attn_bwd_box4.hip) does their table gradient too.  Against the fp64 oracle
+    (1e-3 of the scale, as every gradient), against the general kernel on the same launch (the box kernel looks up at
+    R (P_0 - X) + edge instead of R (P_i - X): a few ulps of the coordinates), and: vertices that are NOT a rotated box keep
+    the general kernel (the gate counts them)."""
+    from oracle.attention_oracle import fused_attention_reference
+    from vdetr_amd import attention as A
+    monkeypatch.setattr(A, "FUSED_KV_BWD", True)
+    g = torch.Generator().manual_seed(nQ + nK)
+    xyz, verts, tables, cs = _rotated_boxes(B, nQ, nK, 7)
+    q, k, v = (torch.randn(s, generator=g) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g)
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True, rpe=A.RPEConfig())
+
+    def run(vv):
+        args = [x.to(DEV).requires_grad_(True) for x in (q, k, v)]
+        tb = tables.to(DEV).requires_grad_(True)
+        out = A.fused_attention(*args, table=tb, vertices=vv.to(DEV).contiguous(), xyz=xyz.to(DEV), cos_sin=cs.to(DEV), **kw)
+        (out * wout.to(DEV)).sum().backward()
+        return out.detach(), tb.grad
+
+    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    _, gen = run(verts)
+    monkeypatch.setenv("VDETR_BWD_BOX", "5")
+    out, box = run(verts)
+    _, again = run(verts)
+    rq, rk, rv = (x.double().requires_grad_(True) for x in (q, k, v))
+    rtb = tables.double().requires_grad_(True)
+    ro = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts.double(), xyz=xyz.double(), cos_sin=cs.double(), **kw)
+    (ro * wout.double()).sum().backward()
+    scale = float(rtb.grad.abs().max())
+    assert_close(out, ro.detach().numpy(), 1e-4, 1e-5 * max(float(ro.abs().max()), 1.0), "out")
+    assert_close(box, rtb.grad.numpy(), 1e-3, 3e-4 * scale, "dtable (box kernel) vs oracle")
+    assert float((box - gen).abs().max()) <= 3e-4 * scale, "box kernel vs general kernel"
+    assert not torch.equal(box, gen), "the box kernel did not run"   # (different arithmetic: equal bits would mean the same kernel)
+    assert torch.equal(box, again), "not reproducible"
+    bent = verts.clone()
+    bent[:, nQ // 3, 5] += 0.01   # one corner of one query off its box: the whole launch goes down the general path
+    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    _, gen2 = run(bent)
+    monkeypatch.setenv("VDETR_BWD_BOX", "5")
+    _, box2 = run(bent)
+    assert torch.equal(gen2, box2), "a non-box query must keep the general kernel"
+
+
 def test_attention_probabilities_and_dropout_statistics():
     from oracle.attention_oracle import fused_attention_reference
     from vdetr_amd import attention as A

@@ -746,7 +746,8 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
   const int box_env = bwd_box_variant(ds_given);
   VDETR_REQUIRE(!ds_given || box_env != 1, "attn_bwd_table: not built into the first box kernel (VDETR_BWD_BOX=1)");
   VDETR_REQUIRE(!ds_given || P.T * P.T * P.T <= kWave * 16, "attn_bwd_table: table edge %d too large for the matrix-unit kernel", P.T);
-  const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && P.T == 10;
+  // (rotated boxes, the cos / sin operand of angle_type "object_coords": attn_bwd_box4.hip only)
+  const bool box = mm && variant == 9 && box_env && (!d->cos_sin || box_env >= 5) && d->bwd_aux && P.T == 10;
   P.box_path = box ? 1 : 0;
   if (mm) {
     const size_t lds = (size_t)table_floats / split * sizeof(float) + (size_t)8 * split * kMmStripFloats * sizeof(float);
@@ -804,7 +805,7 @@ extern "C" int vdetr_attn_bwd_table_kernel_names(const vdetr_attn_desc* d, const
   const int variant = bwd_variant(), box_env = bwd_box_variant(true);
   const int T = d->table_size;
   const bool mm = variant != 0 && variant != 1 && T * T * T <= kWave * 16;
-  const bool box = mm && variant == 9 && box_env && !d->cos_sin && d->bwd_aux && T == 10;
+  const bool box = mm && variant == 9 && box_env && (!d->cos_sin || box_env >= 5) && d->bwd_aux && T == 10;
   *box_kernel = box ? kBox[box_env > 5 ? 5 : box_env] : nullptr;
   *general_kernel = mm ? "attn_bwd_scores_rpe_mm_kernel" : "attn_bwd_scores_rpe_kernel";
   return VDETR_OK;

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kB4Threads) void attn_bwd_box4_kernel(AttnParams P)
   };
   auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
   const int rowbytes = P.nK * 4;
+  const bool rot = P.cos_sin != nullptr;
   const int nchunks = (P.nK + kWave - 1) / kWave;
   struct Ops { float d[4], kx, ky, kz; };
   auto fetch = [&](rsrc_t rd, rsrc_t rx, int chunk, Ops& o) {  // dS of the 4 heads + the key's position (out-of-range keys read 0)
@@ -130,19 +131,37 @@ __global__ __launch_bounds__(kB4Threads) void attn_bwd_box4_kernel(AttnParams P)
     int drawn = items;  // the query after this one: drawn now by one lane (asm: nothing waits for it), handed over below
     if (tid == 0 && taken < cap) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_nop 3" : "=&v"(drawn) : "v"(counter), "v"(1) : "memory");  // (the nop: nobody may overwrite the address / data registers before the instruction has read them)
     const int b = item / P.nQ;
-    const float* vp = P.vertices + (size_t)item * 24;
-    const float X0 = uni(vp[0]), X1 = uni(vp[6]), Y0 = uni(vp[1]), Y1 = uni(vp[4]), Zp = uni(vp[part * 12 + 2]);
     const rsrc_t rd = make_rsrc(P.dprob + (size_t)item * 4 * P.nK, 4u * rowbytes);
     const rsrc_t rx = make_rsrc(P.xyz + (size_t)b * P.nK * 3, 3u * rowbytes);
     Ops ops;
-    fetch(rd, rx, wv, ops);
+    fetch(rd, rx, wv, ops);  // (first: the box's coordinates below are one more round trip, not two, behind the hand-over)
+    const float* vp = P.vertices + (size_t)item * 24;
+    const float bx0 = vp[0], bx1 = vp[6], by0 = vp[1], by1 = vp[4], bz = vp[part * 12 + 2];
+    float X0 = uni(bx0), X1 = uni(bx1), Y0 = uni(by0), Y1 = uni(by1), Zp = uni(bz);
+    // rotated boxes (angle_type "object_coords", the cos / sin operand): the look-up frame is turned by the query's angle, where
+    // the corners are an axis-aligned box again (attn_common.h: attn_delta_body checks that).  A pair's offset is then
+    // R (P_0 - X) + (xi EX, yi EY, zi EZ): X0 / Y0 hold P_0, X1 / Y1 the edge lengths EX / EY in the turned frame.
+    float rc = 1.f, rs = 0.f;
+    if (rot) {
+      rc = uni(P.cos_sin[(size_t)item * 2]); rs = uni(P.cos_sin[(size_t)item * 2 + 1]);
+      float ex = uni(vp[9]) - X0, ey = uni(vp[10]) - Y0;     // vertex 3: xi = 1, yi = 0
+      rpe_rotate(ex, ey, rc, rs);
+      float fx = uni(vp[3]) - X0, fy = uni(vp[4]) - Y0;      // vertex 1: xi = 0, yi = 1
+      rpe_rotate(fx, fy, rc, rs);
+      X1 = ex; Y1 = fy;  // (z is not turned: Zp stays the z of this half's vertices)
+    }
     for (int chunk = wv; chunk < nchunks; chunk += kB4Waves) {
       // ---- taps, signature, products of this lane's pair ---------------------------------------------------------------------
       const int ns = min(kWave, P.nK - chunk * kWave);   // valid pairs of this chunk: the low lanes
       const bool valid = lane < ns;
+      float dx0 = X0 - ops.kx, dy0 = Y0 - ops.ky, dx1 = X1 - ops.kx, dy1 = Y1 - ops.ky;
+      if (rot) {
+        rpe_rotate(dx0, dy0, rc, rs);
+        dx1 = dx0 + X1; dy1 = dy0 + Y1;
+      }
       const AxisTap az = rpe_axis(Zp - ops.kz, P);
-      const AxisTap ay0 = rpe_axis(Y0 - ops.ky, P), ay1 = rpe_axis(Y1 - ops.ky, P);
-      const AxisTap ax0 = rpe_axis(X0 - ops.kx, P), ax1 = rpe_axis(X1 - ops.kx, P);
+      const AxisTap ay0 = rpe_axis(dy0, P), ay1 = rpe_axis(dy1, P);
+      const AxisTap ax0 = rpe_axis(dx0, P), ax1 = rpe_axis(dx1, P);
       // signature = the cell numbers the flush needs: (z T + y0) T | (z T + y1) T << 10 | x0 << 20 | x1 << 24
       const int zrow = az.base * (T * T);
       const int J = (zrow + ay0.base * T) | ((zrow + ay1.base * T) << 10) | (ax0.base << 20) | (ax1.base << 24);

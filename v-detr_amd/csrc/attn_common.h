@@ -286,6 +286,7 @@ struct DeltaArgs {
   const float* v;
   int nK, v_stride, qblocks, vblocks;
   const float* vertices;
+  const float* cos_sin;
 };
 inline void attn_delta_args(const vdetr_attn_desc* d, const float* dout, const float* out, const float* v, float* delta, DeltaArgs* A) {
   A->dout = dout; A->out = out; A->delta = delta;
@@ -294,7 +295,8 @@ inline void attn_delta_args(const vdetr_attn_desc* d, const float* dout, const f
   A->v_stride = d->v_row_stride ? d->v_row_stride : 64;
   A->qblocks = (int)(((long)d->B * d->nQ + 3) / 4);
   A->vblocks = d->bwd_aux ? (int)(((long)d->B * d->nK + 4 * kDeltaKeys - 1) / (4 * kDeltaKeys)) : 0;
-  A->vertices = d->table && !d->cos_sin ? d->vertices : nullptr;
+  A->vertices = d->table ? d->vertices : nullptr;
+  A->cos_sin = d->table ? d->cos_sin : nullptr;
 }
 __device__ __forceinline__ void attn_delta_body(const DeltaArgs& A, int block, float* wmax) {
   const float* __restrict__ dout = A.dout;
@@ -326,11 +328,27 @@ __device__ __forceinline__ void attn_delta_body(const DeltaArgs& A, int block, f
         if (lane == 0) delta[A.perhead ? ((size_t)b * H + h) * nQ + q : (size_t)row * H + h] = s;
       }
       if (aux && A.vertices && row == 0 && lane == 0) aux[5] = 1u;  // "word 4 is meaningful": without it the box kernels stay off
-      if (aux && A.vertices) {  // aux[4] += 1 for a query whose 8 RPE vertices are not an axis-aligned box
+      if (aux && A.vertices) {  // aux[4] += 1 for a query whose 8 RPE vertices are not a box (in the frame the kernels look up in)
         const float* vp = A.vertices + (size_t)row * 24;
         const int i = lane & 7;
-        const bool ok = vp[i * 3] == vp[rpe_box_xi(i) ? 6 : 0] && vp[i * 3 + 1] == vp[rpe_box_yi(i) ? 4 : 1] &&
-                        vp[i * 3 + 2] == vp[rpe_box_zi(i) ? 14 : 2];
+        bool ok;
+        if (!A.cos_sin) {  // no rotation operand: an axis-aligned box, bit for bit
+          ok = vp[i * 3] == vp[rpe_box_xi(i) ? 6 : 0] && vp[i * 3 + 1] == vp[rpe_box_yi(i) ? 4 : 1] &&
+               vp[i * 3 + 2] == vp[rpe_box_zi(i) ? 14 : 2];
+        } else {
+          // angle_type "object_coords": the offsets are turned by the query's angle before the look-up (rpe_rotate), and the
+          // corners of a ROTATED box are an axis-aligned box in that frame: R (P_i - P_0) = (xi EX, yi EY, zi EZ) with the edge
+          // vectors of vertices 3, 1 and 4.  The corners come out of fp32 arithmetic (box_decode), so the test has a tolerance
+          // of a few ulps of the coordinates; the box kernel then looks up at R (P_0 - X) + (xi EX, yi EY, zi EZ), which
+          // differs from the forward's R (P_i - X) by that much: a shift of the trilinear weights far below the 1e-3 budget.
+          float ex = vp[i * 3] - vp[0], ey = vp[i * 3 + 1] - vp[1];
+          const float ez = vp[i * 3 + 2] - vp[2];
+          rpe_rotate(ex, ey, A.cos_sin[(size_t)row * 2], A.cos_sin[(size_t)row * 2 + 1]);
+          const float EX = readlane_f32(ex, 3), EY = readlane_f32(ey, 1), EZ = readlane_f32(ez, 4);
+          const float tol = 1e-5f * (1.f + fabsf(vp[0]) + fabsf(vp[1]) + fabsf(vp[2]));
+          ok = fabsf(ex - (rpe_box_xi(i) ? EX : 0.f)) <= tol && fabsf(ey - (rpe_box_yi(i) ? EY : 0.f)) <= tol &&
+               fabsf(ez - (rpe_box_zi(i) ? EZ : 0.f)) <= tol;
+        }
         if (!__all(ok) && lane == 0) atomicAdd(aux + 4, 1u);
       }
     }
