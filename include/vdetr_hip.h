@@ -217,6 +217,13 @@ int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float* q, const 
  * read at launch: a tuning switch for single-threaded callers (threads or devices that set different shapes race on it; either
  * shape computes the same values). */
 int vdetr_attn_bwd_kv_set_waves(int waves);
+/* Workgroups of the table-gradient launches (vdetr_attn_bwd_table_f32 / vdetr_attn_bwd_scores_f32 with a table): 0 = the
+ * default, one per CU (256); an even count in 2..256 otherwise.  The persistent workgroups take every register and ~150 KB
+ * of LDS of their CU, so a caller that runs the table gradient on a side stream (it feeds parameters only) lowers the count
+ * to leave WHOLE CUs to the kernels of the main chain.  PROCESS-WIDE state read at launch, like the switch above; the
+ * fixed-point scale of the histogram follows the queries per workgroup, so results are reproducible per count, and equal
+ * across counts to the rounding of that scale. */
+int vdetr_attn_bwd_table_set_grid(int workgroups);
 /* The RPE table gradient alone, from the dS that vdetr_attn_bwd_kv_f32 wrote (same kernels, workspace and bwd_aux contract
  * as vdetr_attn_bwd_scores_f32 with a dtable; d->bwd_aux is required).  dtable [8,T,T,T,4]: caller zero-fills. */
 int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* ds, float* dtable, void* workspace,

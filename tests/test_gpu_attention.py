@@ -282,6 +282,44 @@ def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK, variant):
     assert torch.equal(got, again), "not reproducible"
 
 
+@pytest.mark.parametrize("grid,tol", [(192, 3e-4), (64, 3e-4), (16, 1e-3)])
+def test_table_gradient_on_fewer_workgroups(monkeypatch, grid, tol):
+    """vdetr_attn_bwd_table_set_grid: the table-gradient launches on fewer (persistent) workgroups than CUs — what a caller
+    does who runs them on a side stream next to the main chain — give the default grid's gradient to the rounding of the
+    histogram's fixed-point scale (which follows the queries per workgroup: measured 0 / 1.5e-4 / 3.5e-4 / 2.4e-3 of the largest
+    entry at 192 / 64 / 16 / 2 workgroups), are reproducible per count, and the default comes back with 0."""
+    from vdetr_amd import _lib as L
+    from vdetr_amd import attention as A
+    monkeypatch.setattr(A, "FUSED_KV_BWD", True)
+    B, nQ, nK = 1, 300, 1024
+    g = torch.Generator().manual_seed(grid)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 9)
+    q, k, v = (torch.randn(s, generator=g).to(DEV) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g).to(DEV)
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True, rpe=A.RPEConfig(), vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV))
+
+    def run():
+        args = [x.clone().requires_grad_(True) for x in (q, k, v)]
+        tb = tables.to(DEV).requires_grad_(True)
+        (A.fused_attention(*args, table=tb, **kw) * wout).sum().backward()
+        return tb.grad, args[0].grad
+
+    ref, dq_ref = run()
+    try:
+        L.check(L.lib().vdetr_attn_bwd_table_set_grid(grid), "set_grid")
+        got, dq = run()
+        again, _ = run()
+    finally:
+        L.check(L.lib().vdetr_attn_bwd_table_set_grid(0), "set_grid")
+    back, _ = run()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= tol * scale and float((got - ref).norm() / ref.norm()) < 1e-3
+    assert torch.equal(got, again), "not reproducible"
+    assert torch.equal(dq, dq_ref), "the other gradients do not depend on the grid"
+    assert torch.equal(back, ref), "default grid not restored"
+    assert L.lib().vdetr_attn_bwd_table_set_grid(3) != 0 and L.lib().vdetr_attn_bwd_table_set_grid(258) != 0
+
+
 def _rotated_boxes(B, nQ, nK, seed):
     """keys, the corners of ROTATED boxes (centre + R(angle)^T (+-half), as box_decode writes them), tables, (cos, sin)"""
     xyz, verts, tables, _ = _scene(B, nQ, nK, seed)

@@ -240,7 +240,7 @@ def test_full_model_with_sparse_backbone_runs():
     model.zero_grad(set_to_none=True)
     feats = model.backbone_forward(dict(inputs, geometry=geo2))
     held = geo2.device_tensors()
-    assert len(held) > 20 and all(geo2._recorded.get((t.untyped_storage().data_ptr(), main)) is t for t in held)
+    assert len(held) > 20 and all((t.untyped_storage().data_ptr(), main) in geo2._recorded for t in held)
     del geo2
     with torch.cuda.stream(side):  # the loader's next scene allocates on its own stream while the step is still queued
         geo3 = model.prepare_geometry(inputs)

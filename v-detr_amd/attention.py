@@ -54,15 +54,28 @@ DYNAMIC_BWD = os.environ.get("VDETR_BWD_DYNAMIC", "1") != "0"
 FUSED_KV_BWD = os.environ.get("VDETR_BWD_FUSED", "1") != "0"
 
 
-# The RPE-table gradient kernel (2.9 ms of a 9.5 ms step) feeds parameters only: nothing on the backward's critical path
-# waits for it.  With VDETR_BWD_ASYNC_TABLE=1 `fused_attention(..., table_grad_async=True)` launches it on a side stream;
-# the caller wraps the table with `join_table_grad` BEFORE the layers that use it (GlobalShareCrossAttention.precompute),
-# so that autograd reaches the join — main stream waits for the side stream — only after those layers' backward.
-# OFF by default — measured (captured C2 step): 9.62 ms in line, 10.07 ms with the side stream.  The table kernel keeps
-# 16 waves and 85 KB of LDS on every CU for its whole run (its workgroups pull queries until none are left); what the
-# main chain launches next to it either does not fit on a CU (the library's dQ GEMM sat behind it for 349 us) or shares
-# the VALU issue slots of a kernel that is bound by exactly those (attn_bwd_kv_kernel 52 -> 60 us, add_ln 6.4 -> 8.4 us).
-ASYNC_TABLE_GRAD = os.environ.get("VDETR_BWD_ASYNC_TABLE", "0") != "0"
+# The RPE-table gradient kernel (2.3 ms of a 9 ms step) feeds parameters only: nothing on the backward's critical path waits
+# for it.  `fused_attention(..., table_grad_async=True)` launches it on a side stream; the caller wraps the table with
+# `join_table_grad` BEFORE the layers that use it (GlobalShareCrossAttention.precompute), so that autograd reaches the join —
+# main stream waits for the side stream — only after those layers' backward.
+# Round 3 measured this SLOWER (10.07 vs 9.62 ms): the kernel's persistent workgroups keep every register and 150 KB of LDS of
+# every CU for its whole run, so whatever the main chain launched next to it waited for a CU.  Round 4: the side-stream launch
+# takes ASYNC_TABLE_GRID of the 256 CUs (vdetr_attn_bwd_table_set_grid) and leaves the others to the main chain, whose ~40
+# small launches per layer cannot fill the chip anyway: 9.02 -> 8.60 ms at 192 (224: 8.84, 176: 8.67, 160: 8.71, 128: 9.11),
+# C5 27.7 -> 26.7, C4 9.42 -> 9.08; C1 (64 queries) 2.14 -> 2.31, hence the size gate.  DESIGN.md 4.4e.
+#   VDETR_BWD_ASYNC_TABLE = auto (default: launches of >= 2^21 query-key pairs) | 1 (always) | 0 (never)
+_ASYNC_ENV = os.environ.get("VDETR_BWD_ASYNC_TABLE", "auto")
+ASYNC_TABLE_GRAD = _ASYNC_ENV != "0"
+ASYNC_MIN_PAIRS = 1 << 21
+# workgroups (= CUs) of the table kernel when it runs on the side stream: the remaining CUs are the main chain's
+ASYNC_TABLE_GRID = int(os.environ.get("VDETR_BWD_ASYNC_GRID", "192"))
+_ASYNC_KV4 = os.environ.get("VDETR_BWD_ASYNC_KV_WAVES", "8") == "4"
+
+
+def _async_wanted(B, nQ, nK):
+    return ASYNC_TABLE_GRAD and (_ASYNC_ENV == "1" or B * nQ * nK >= ASYNC_MIN_PAIRS)
+
+
 _side_streams = {}
 _side_keep = []  # tensors the side-stream kernels read, alive until the join
 
@@ -88,10 +101,69 @@ class _JoinTableGrad(Function):
     @staticmethod
     def backward(ctx, g):
         side = _side_streams.get(_dev_key(ctx.dev))
-        if side is not None:
+        if side is not None and _side_keep:  # (only if something was launched there: a capture must not wait for a stream outside it)
             torch.cuda.current_stream(ctx.dev).wait_stream(side)
         _side_keep.clear()
         return g
+
+
+class _ParkTableGrad(Function):
+    """identity on `table` (already cut from its graph); the gradient that arrives is parked, nothing flows on"""
+
+    @staticmethod
+    def forward(ctx, anchor, table, slot):
+        ctx.slot = slot
+        return table.view_as(table)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.slot[1] = g
+        return None, None, None
+
+
+class DeferredTableGrads:
+    """The gradient of the RPE tables' MLPs, run AFTER the backward pass and the other parked parameter gradients
+    (runtime.flush_weight_grads): the side stream's last table kernel then also overlaps the weight-gradient GEMMs instead of
+    being waited for inside the backward.  Only with runtime.defer_weight_grads() (the training loop promises a flush)."""
+    pending = []   # [tables as computed (with their graph), [slot = [index, grad] per layer]]
+    _anchor = {}
+
+    @classmethod
+    def park(cls, tables):
+        """tables [n, ...] (requires grad) -> n tensors for the n layers, cut from the graph"""
+        key = _dev_key(tables.device)
+        if key not in cls._anchor:  # a leaf that makes the outputs require grad; it never receives one
+            cls._anchor[key] = torch.zeros(1, device=tables.device, requires_grad=True)
+        cut = tables.detach()
+        slots = [[i, None] for i in range(tables.shape[0])]
+        cls.pending.append((tables, slots))
+        return [_ParkTableGrad.apply(cls._anchor[key], cut[i], slots[i]) for i in range(tables.shape[0])]
+
+    @classmethod
+    def flush(cls):
+        items, cls.pending = cls.pending, []
+        for tables, slots in items:
+            if all(g is None for _, g in slots):
+                continue
+            dev = tables.device
+            side = _side_streams.get(_dev_key(dev))
+            if side is not None and _side_keep:
+                torch.cuda.current_stream(dev).wait_stream(side)
+            _side_keep.clear()
+            g = torch.stack([g if g is not None else torch.zeros_like(tables[i]) for i, g in slots])
+            torch.autograd.backward([tables], [g])
+
+
+def park_table_grads(tables):
+    """[n, 8, T, T, T, H] tables of n layers -> list of n per-layer tables.  With the table gradient on the side stream and
+    parked weight gradients (runtime.defer_weight_grads) the tables are cut from their graph and their MLPs' backward runs at
+    the flush; otherwise each table passes through `join_table_grad`."""
+    from .helpers import DeferredParamGrads
+    if (ASYNC_TABLE_GRAD and DeferredParamGrads.enabled and tables.is_cuda and tables.requires_grad and torch.is_grad_enabled()
+            and os.environ.get("VDETR_BWD_ASYNC_PARK", "1") != "0"):
+        _side_stream(tables.device)
+        return DeferredTableGrads.park(tables)
+    return [join_table_grad(t) for t in tables.unbind(0)]
 
 
 def join_table_grad(table):
@@ -101,6 +173,30 @@ def join_table_grad(table):
         _side_stream(table.device)
         return _JoinTableGrad.apply(table)
     return table
+
+
+def _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork=None, dtable=None):
+    """the table-gradient launches of one layer on the side stream, behind everything the current stream has queued (dS, the
+    zeroed accumulator and bwd_aux are ready then); returns the accumulator, which `join_table_grad`'s backward makes final"""
+    if dtable is None:
+        dtable = _take_zeros(table, tuple(table.shape), table.dtype)
+    nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
+    side = _side_stream(q.device)
+    if fork is not None:
+        side.wait_event(fork)
+    else:
+        side.wait_stream(torch.cuda.current_stream(q.device))
+    with torch.cuda.stream(side):
+        ws2 = L.workspace(nbytes, q.device)
+        grid = ASYNC_TABLE_GRID if 2 <= ASYNC_TABLE_GRID < 256 else 0
+        L.check(lib.vdetr_attn_bwd_table_set_grid(grid), "attn_bwd_table_set_grid")  # (process-wide, read at launch)
+        try:
+            L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws2), nbytes, L.stream_ptr()),
+                    "attn_bwd_table")
+        finally:
+            lib.vdetr_attn_bwd_table_set_grid(0)
+    _side_keep.append((ds, dtable, ws2, aux, table, vertices, xyz, mask))
+    return dtable
 
 
 def _fused_kv_ok(want_table):
@@ -274,13 +370,23 @@ class _FusedAttention(Function):
             # table gradient and the dQ GEMM (attn_bwd_kv.hip)
             ds = torch.empty_like(scores)  # [B, nQ, H, nK] (shared K/V) / [B, H, nQ, nK] (per head)
             dkv = torch.empty((2, B, nK, k.shape[2]), dtype=torch.float32, device=q.device)
-            run_async = want_table and ctx.table_async and ASYNC_TABLE_GRAD
-            lib.vdetr_attn_bwd_kv_set_waves(4 if run_async or _side_keep else 8)  # 4: fits next to the table kernel
+            run_async = want_table and ctx.table_async and _async_wanted(B, nQ, nK)
+            # 4 waves fit NEXT TO a table kernel that holds every CU; with CUs left free for the main chain the default shape
+            lib.vdetr_attn_bwd_kv_set_waves(4 if (run_async or _side_keep) and (ASYNC_TABLE_GRID >= 256 or _ASYNC_KV4) else 8)
             nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
             ws = L.workspace(nbytes, q.device)
             L.check(lib.vdetr_attn_bwd_kv_delta_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(out), L.ptr(scores),
                                                     L.ptr(lse), L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws),
                                                     nbytes, L.stream_ptr()), "attn_bwd_kv")
+            dtable = fork = None
+            if run_async:
+                # The side stream's launches depend on the key-side pass only, but are CAPTURED behind the main chain's next
+                # kernel: a captured graph's executor keeps the FIRST edge of a node on the node's queue and moves every
+                # further edge to the next one (round robin over 4) - the main chain must stay where it is, or it hops a
+                # queue per layer and lands behind the table kernel every fourth time (measured: DESIGN.md 4.4e)
+                dtable = _take_zeros(table, tuple(table.shape), table.dtype)  # (a fill, if any, is in front of the event)
+                fork = torch.cuda.Event()
+                fork.record(torch.cuda.current_stream(q.device))
             # dQ first: its library GEMM does not fit next to the table kernel on a CU and would sit behind it
             if shared:
                 dq = q.new_empty((B, nQ * H, HEAD_DIM))
@@ -296,19 +402,12 @@ class _FusedAttention(Function):
                 else:
                     dq = torch.bmm(ds_r, k4.reshape(B * H, nK, HEAD_DIM)).mul_(float(scale))
                     dq = dq.view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
-            dtable = None
             if want_table:
-                dtable = _take_zeros(table, tuple(table.shape), table.dtype)
-                nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
                 if run_async:
-                    side = _side_stream(q.device)
-                    side.wait_stream(torch.cuda.current_stream(q.device))  # dS, the zeroed dtable and bwd_aux are ready
-                    with torch.cuda.stream(side):
-                        ws2 = L.workspace(nbytes, q.device)
-                        L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws2), nbytes,
-                                                             L.stream_ptr()), "attn_bwd_table")
-                    _side_keep.append((ds, dtable, ws2, aux, table, vertices, xyz, mask))
+                    dtable = _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable)
                 else:
+                    dtable = _take_zeros(table, tuple(table.shape), table.dtype)
+                    nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
                     ws = L.workspace(nbytes, q.device)
                     L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws), nbytes,
                                                          L.stream_ptr()), "attn_bwd_table")

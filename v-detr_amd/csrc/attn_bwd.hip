@@ -276,7 +276,7 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
   // in aux[0..1] by vdetr_attn_delta_f32, and a workgroup stops after `cap` queries.
   const bool dynamic = P.bwd_aux != nullptr;
   const int per_wg = (items + nwg - 1) / nwg;
-  const int cap = dynamic ? 2 * per_wg : per_wg;
+  const int cap = dynamic ? bwd_query_cap(per_wg) : per_wg;
   if (FIXED && dynamic) {
     const float dmax = sqrtf(__uint_as_float(P.bwd_aux[0]) * __uint_as_float(P.bwd_aux[1]));
     const float bound = 2.f * P.drop_scale * dmax * (float)cap;
@@ -677,15 +677,26 @@ static int bwd_box_variant(bool ds_given) {
   if (box_env >= 4 && !ds_given) box_env = 2;
   return box_env;
 }
+// workgroups of the table-gradient launches: one per CU by default; vdetr_attn_bwd_table_set_grid() lowers it so that a caller
+// who runs the table gradient on a side stream leaves whole CUs to the main chain (the persistent workgroups hold every
+// register and 150 KB of LDS of their CU: nothing else fits next to one)
+static int g_bwd_table_grid = [] { const char* v = getenv("VDETR_BWD_GRID"); const int n = v ? atoi(v) : 0; return n >= 2 && n <= 256 ? n & ~1 : 256; }();
 static int bwd_grid(const vdetr_attn_desc* d, int split) {
   const long wgs = (long)d->B * d->nQ * split;
-  return (int)(wgs < 256 ? wgs : 256);
+  return (int)(wgs < g_bwd_table_grid ? wgs : g_bwd_table_grid);
+}
+extern "C" int vdetr_attn_bwd_table_set_grid(int workgroups) {
+  VDETR_REQUIRE(workgroups == 0 || (workgroups >= 2 && workgroups <= 256 && workgroups % 2 == 0),
+                "attn_bwd_table_set_grid: %d (0 = default, or an even count in 2..256)", workgroups);
+  g_bwd_table_grid = workgroups ? workgroups : 256;
+  return VDETR_OK;
 }
 
 extern "C" size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d || !d->table) return 0;
   const size_t table_floats = (size_t)kRpeVerts * d->table_size * d->table_size * d->table_size * 4;
-  return (size_t)bwd_grid(d, 1) * table_floats * sizeof(float) + 256;  // partial tables (any variant) + alignment
+  const long wgs = (long)d->B * d->nQ;  // (sized for the default grid: independent of vdetr_attn_bwd_table_set_grid)
+  return (size_t)(wgs < 256 ? wgs : 256) * table_floats * sizeof(float) + 256;  // partial tables (any variant) + alignment
 }
 
 template <bool FIXED, int VERTS, int WPV, bool SPLIT16, bool VLOOP>

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kBoxWaves * kWave) void attn_bwd_box_kernel(AttnPar
   for (int i = tid; i < table_words; i += kBoxThreads) tab[i] = 0;
   // fixed-point scale of the histogram: |dP~| <= |dO row| |V row| (maxima from the delta launch), at most `cap` queries
   const int per_wg = (items + nwg - 1) / nwg;
-  const int cap = 2 * per_wg;
+  const int cap = bwd_query_cap(per_wg);
   float fix_scale = 1.f, fix_inv = 1.f;
   {
     const float dmax = sqrtf(__uint_as_float(P.bwd_aux[0]) * __uint_as_float(P.bwd_aux[1]));

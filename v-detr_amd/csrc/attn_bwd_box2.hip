@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kB2Threads) void attn_bwd_box2_kernel(AttnParams P)
   const int items = P.B * P.nQ;
   for (int i = tid; i < table_words; i += kB2Threads) tab[i] = 0;
   const int per_wg = (items + nwg - 1) / nwg;
-  const int cap = 2 * per_wg;
+  const int cap = bwd_query_cap(per_wg);
   float fix_scale = 1.f, fix_inv = 1.f;
   {
     const float dmax = sqrtf(__uint_as_float(P.bwd_aux[0]) * __uint_as_float(P.bwd_aux[1]));

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kB3Threads) void attn_bwd_box3_kernel(AttnParams P)
   for (int i = tid; i < kB3GidSlots; i += kB3Threads) cnt[i] = 0ull;
   for (int i = tid; i < kB3Tile * kB3RecBytes / 4; i += kB3Threads) reinterpret_cast<b3_rec1_t*>(rec)[i] = 0.f;  // a partly filled quad multiplies 0 x (whatever the slot held): must be finite
   const int per_wg = (items + nwg - 1) / nwg;
-  const int cap = 2 * per_wg;
+  const int cap = bwd_query_cap(per_wg);
   float fix_scale = 1.f, fix_inv = 1.f;
   {  // the bound of attn_bwd_box2.hip: |bin sum| <= queries of this workgroup x 2 drop_scale max|dO row| max|V row|
     const float dmax = sqrtf(__uint_as_float(P.bwd_aux[0]) * __uint_as_float(P.bwd_aux[1]));

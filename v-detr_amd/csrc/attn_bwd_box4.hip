@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kB4Threads) void attn_bwd_box4_kernel(AttnParams P)
   for (int i = tid; i < kB4TableWords; i += kB4Threads) tab[i] = 0;
   for (int i = lane; i < kB4StripBytes / 4; i += kWave) reinterpret_cast<b4_recu_t*>(rec)[i] = 0u;  // finite records, zero counters
   const int per_wg = (items + nwg - 1) / nwg;
-  const int cap = 2 * per_wg;
+  const int cap = bwd_query_cap(per_wg);
   float fix_scale = 1.f, fix_inv = 1.f;
   {  // the bound of attn_bwd_box2.hip: |bin sum| <= queries of this workgroup x 2 drop_scale max|dO row| max|V row|
     const float dmax = sqrtf(__uint_as_float(P.bwd_aux[0]) * __uint_as_float(P.bwd_aux[1]));

@@ -17,6 +17,13 @@ constexpr float kNegBig = -1e30f;
 #define VDETR_STREAM_NT 1
 #endif
 constexpr int kStreamAux = VDETR_STREAM_NT ? 2 : 0;  // raw buffer aux bits: 2 = nt (slc)
+
+// Table-gradient kernels, dynamic query distribution: the most queries one persistent workgroup may take, given the even share
+// `per_wg`.  The int32 histogram's fixed-point scale is sized for this many queries (a power of two below 2^30 / bound), so the
+// cap trades resolution against slack for uneven progress: 1.5x the share (it was 2x until round 4: 16 queries at 1024 queries
+// on 128 workgroups per z-half; 1.5x keeps those 16 at the 96 workgroups per half a side-stream launch uses and gives the
+// default grid one more bit).  Workgroups x cap >= queries, so every query is taken whatever the workgroups' pace.
+__host__ __device__ __forceinline__ constexpr int bwd_query_cap(int per_wg) { return per_wg + (per_wg + 1) / 2; }
 constexpr float kLog2e = 1.4426950408889634f;
 
 struct AttnParams {

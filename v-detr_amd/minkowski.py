@@ -143,13 +143,13 @@ class CoordinateManager:
         stream = stream or torch.cuda.current_stream()
         if torch.cuda.is_current_stream_capturing():
             return self
-        # the memo holds the recorded tensors THEMSELVES (keyed by storage + stream): an id() of a freed tensor could be
-        # handed to a new one, which would then be skipped and its block recycled under the training stream's kernels
+        # keyed by storage + stream (views of one buffer are one allocator block), and the memo HOLDS a tensor of every
+        # recorded storage: while it does, the address cannot be handed to a new allocation that would then be skipped
+        # and have its block recycled under the training stream's kernels
         done = self.__dict__.setdefault("_recorded", {})
         for t in self.device_tensors():
             key = (t.untyped_storage().data_ptr(), stream.cuda_stream)
-            held = done.get(key)
-            if held is None or held is not t:
+            if key not in done:
                 t.record_stream(stream)
                 done[key] = t
         return self

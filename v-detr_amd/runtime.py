@@ -111,6 +111,8 @@ def defer_weight_grads(enable=True):
         DeferredParamGrads.pending.clear()
         DeferredLnGrads.pending.clear()
         DeferredPosEmbedGrads.pending.clear()
+        from .attention import DeferredTableGrads
+        DeferredTableGrads.pending.clear()
 
 
 def weight_grads_deferred():
@@ -126,6 +128,8 @@ def flush_weight_grads():
     DeferredParamGrads.flush()
     DeferredLnGrads.flush()
     DeferredPosEmbedGrads.flush()
+    from .attention import DeferredTableGrads
+    DeferredTableGrads.flush()  # last: it waits for the side stream's table kernels, which run under the launches above
 
 
 def flush_weight_grads_phased(phase_of_param, nphases, after_phase):
@@ -138,6 +142,8 @@ def flush_weight_grads_phased(phase_of_param, nphases, after_phase):
     from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
     DeferredLnGrads.flush()        # a handful of launches whose parameters may sit in any bucket: before the first one leaves
     DeferredPosEmbedGrads.flush()
+    from .attention import DeferredTableGrads
+    DeferredTableGrads.flush()     # (likewise: the table MLPs' parameters may sit in the first bucket)
 
     def phase(it):
         ph = nphases - 1

@@ -213,10 +213,11 @@ class GlobalShareCrossAttention(nn.Module):
         T, H = mods[0].relative_coords_table.shape[1], mods[0].num_heads
         coords = mods[0].relative_coords_table.reshape(1, -1, 3).expand(8 * n, -1, -1)
         hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
-        tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H).unbind(0)
-        # the table gradients are computed on a side stream (attention.py: ASYNC_TABLE_GRAD); autograd reaches these joins —
-        # they were created before any decoder layer — only after every layer's backward, and waits there
-        tables = [A.join_table_grad(t) for t in tables]
+        tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H)
+        # the table gradients are computed on a side stream (attention.py: ASYNC_TABLE_GRAD); autograd reaches the joins —
+        # they were created before any decoder layer — only after every layer's backward, and waits there; with parked weight
+        # gradients the tables' own backward moves behind the flush and the wait with it
+        tables = A.park_table_grads(tables)
         return [(parts[2 * i], parts[2 * i + 1], tables[i]) for i in range(n)]
 
     def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None,
