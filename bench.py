@@ -350,6 +350,11 @@ class BackboneTrainer:
         global flush_weight_grads
         from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
         _, bs, npre, nq, nl, angle_type, _ = CONFIGS[cfg_name]
+        # The decoder's table gradient stays in line here: this step already keeps a loader stream (next scene's geometry, a
+        # 5 ms one-CU sampling kernel) next to the eager backbone, and a further queue for the captured step's side branch lands
+        # behind one of them (tools/backbone_step_probe.py: thread 22.0 -> 22.7 ms, inline 22.0 -> 26.4 with it on)
+        from vdetr_amd import attention as _A
+        self._async_table_mode = _A.set_async_table_grad(os.environ.get("VDETR_BENCH_BB_ASYNC_TABLE", "0"))
         torch.manual_seed(seed)
         self.model = model = build_vdetr(default_args(dec_nlayers=nl, nqueries=nq, preenc_npoints=npre, angle_type=angle_type),
                                          ScannetDatasetConfig(), "minkowski").to(device).train()
@@ -533,6 +538,10 @@ class BackboneTrainer:
             self._worker.join()
             self._worker = None
         torch.cuda.synchronize()
+        if self._async_table_mode is not None:
+            from vdetr_amd import attention as _A
+            _A.set_async_table_grad(self._async_table_mode)
+            self._async_table_mode = None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -631,7 +640,15 @@ def kernel_rooflines(cfg_name, device, reps=20):
     t_fwd = timeit(fwd)
     bwd_prep()
     t_kv = timeit(kv)
-    t_bwd = timeit(bwd, bwd_prep)
+    # the launch as the step issues it: on the side stream the table gradient takes ASYNC_TABLE_GRID of the 256 CUs
+    side = A._async_wanted(B, nQ, nK) and 2 <= A.ASYNC_TABLE_GRID < 256
+    if side:
+        L.check(lib.vdetr_attn_bwd_table_set_grid(A.ASYNC_TABLE_GRID), "attn_bwd_table_set_grid")
+    try:
+        t_bwd = timeit(bwd, bwd_prep)
+    finally:
+        lib.vdetr_attn_bwd_table_set_grid(0)
+    t_bwd_full = timeit(bwd, bwd_prep) if side else t_bwd
     pairs = B * nQ * nK
     flops = 4.0 * H * pairs * 64                       # QK^T + PV (MFMA-eligible), SURVEY.md §8d
     bytes_bwd = 4.0 * H * pairs                        # dS read once (fp32); the kernel is VALU-bound, see valu_issue
@@ -653,7 +670,10 @@ def kernel_rooflines(cfg_name, device, reps=20):
     bwd_obj = {"kernel": f"{bwd_kernel} (RPE table gradient from dS; " + ("axis-aligned boxes)" if ran_box else "general vertices" + (" + rotation)" if cos_sin is not None else ")")), "bound": "hbm",
                "achieved": bytes_bwd / t_bwd / 1e9, "peak": 8000.0, "unit": "GB/s",
                "frac": bytes_bwd / t_bwd / 1e9 / 8000.0, "traffic": None, "launch_us": t_bwd * 1e6,
-               "rpe_scatter_per_s": 8.0 * pairs / t_bwd}
+               "rpe_scatter_per_s": 8.0 * pairs / t_bwd,
+               "placement": (f"side stream of the captured step, {A.ASYNC_TABLE_GRID} persistent workgroups = CUs, concurrent with the "
+                             f"backward chain on the other {256 - A.ASYNC_TABLE_GRID} (launch alone on all 256 CUs: {t_bwd_full * 1e6:.1f} us)")
+                            if side else "in line on the main stream, 256 workgroups"}
     # HBM traffic per launch measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/README.md)
     try:
         tr = _pmc_traffic()
@@ -1064,6 +1084,10 @@ def main():
         for o in (fps_obj, bwd_obj, fwd_obj):
             o["share_of_step"] = o["step_us"] * 1e-3 / result["ms_per_step"]
         fps_obj["on_critical_path"] = bool(a.no_fps_prefetch)
+        # (round 4: the table gradient runs on a side branch of the captured step over 192 of the 256 CUs, NEXT TO the backward
+        # chain — not hidden like the one-CU sampling: it takes three quarters of the chip from the chain while it runs, and the
+        # two are about balanced, so it stays the kernel this line's `roofline` describes)
+        bwd_obj["on_critical_path"] = "shares the chip with the backward chain" if "side stream" in bwd_obj.get("placement", "") else True
         objs = sorted((bwd_obj, fwd_obj) + ((fps_obj,) if a.no_fps_prefetch else ()), key=lambda o: -o["step_us"])
         result["roofline"] = objs[0]
         result["roofline_secondary"] = objs[1]

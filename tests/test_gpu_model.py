@@ -283,8 +283,10 @@ def test_colsum_and_linear_backward(rows, cols):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
 
 
-def test_captured_step_equals_eager_step():
-    """Three training steps (forward, backward, gradient pack, clip, fused AdamW) as replays of the captured hipGraph
+@pytest.mark.parametrize("table_mode", ["auto", "1"])
+def test_captured_step_equals_eager_step(table_mode):
+    """("1": the table gradients on the side stream inside both the eager and the captured step - forked by an event, joined
+    behind the parked weight gradients.)  Three training steps (forward, backward, gradient pack, clip, fused AdamW) as replays of the captured hipGraph
     leave the same parameters as three eager steps: every custom launch of the step (attention, box decode, residual +
     LayerNorm, BatchNorm, column sums, pack with its pinned-table upload, dynamic-backward counters) is capture-safe.
     Dropout is switched off so that both runs see the same arithmetic."""
@@ -310,8 +312,13 @@ def test_captured_step_equals_eager_step():
         torch.cuda.synchronize()
         return {n: p.detach().clone() for n, p in model.named_parameters()}, float(tr.loss)
 
-    pe, le = run(False)
-    pg, lg = run(True)
+    from vdetr_amd import attention as A
+    prev = A.set_async_table_grad(table_mode)
+    try:
+        pe, le = run(False)
+        pg, lg = run(True)
+    finally:
+        A.set_async_table_grad(prev)
     assert np.isfinite(le) and np.isfinite(lg)
     worst = 0.0
     for n in pe:
@@ -398,6 +405,52 @@ def test_deferred_weight_gradients_equal_inline_ones(batch):
     assert res[True].keys() == res[False].keys()
     for n, g in res[False].items():
         assert float((res[True][n] - g).abs().max()) <= 2e-4 * (float(g.abs().max()) + 1e-12), n
+
+
+@pytest.mark.parametrize("defer", [True, False])
+def test_side_stream_table_gradient_equals_the_inline_one(defer):
+    """attention.set_async_table_grad("1"): the RPE-table gradient of every decoder layer on a side stream over 192 of the
+    256 CUs, joined behind the layers' backward (`join_table_grad`) or, with parked weight gradients, behind the flush
+    (`DeferredTableGrads`: the cpb MLPs' own backward runs there) — against the in-line launches ("0"): every gradient but
+    the cpb MLPs' bit-identical, theirs within the rounding of the histogram's fixed-point scale (it follows the grid)."""
+    from vdetr_amd import attention as A
+    from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
+    model = _make_model(nq=64, npre=512, nl=4).to(DEV).train()
+    inp = _inputs(3000, 5, DEV, 1)
+    model(inp)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    prev = A.set_async_table_grad("0")
+    try:
+        for mode in ("0", "1"):
+            A.set_async_table_grad(mode)
+            defer_weight_grads(defer)
+            A.reset_rng()
+            torch.manual_seed(0)
+            with torch.no_grad():
+                for k, v in model.state_dict().items():
+                    v.copy_(state[k])
+            model.zero_grad(set_to_none=True)
+            for f in inp["backbone_features"]:
+                f.grad = None
+            _loss(model(inp)).backward()
+            if defer:
+                if mode == "1":
+                    assert A.DeferredTableGrads.pending, "the tables' backward is parked until the flush"
+                    assert all(p.grad is None for n, p in model.named_parameters() if "cpb_mlps" in n)
+                flush_weight_grads()
+                assert not A.DeferredTableGrads.pending
+            torch.cuda.synchronize()
+            res[mode] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        A.set_async_table_grad(prev)
+        defer_weight_grads(False)
+    assert res["0"].keys() == res["1"].keys() and any("cpb_mlps" in n for n in res["0"])
+    for n, g in res["0"].items():
+        if "cpb_mlps" in n:
+            assert float((res["1"][n] - g).abs().max()) <= 1e-3 * float(g.abs().max()), n
+        else:
+            assert torch.equal(res["1"][n], g), n
 
 
 @pytest.mark.parametrize("B,N", [(1, 4096), (3, 1000), (2, 1), (1, 8192), (2, 9000), (1, 77)])

@@ -128,3 +128,42 @@ def test_decoder_plain_composition_paths(cpu_oracle_backend, monkeypatch):
             assert_close(st[k], g[f"s{s}:{k}"], 1e-3, 1e-4, f"stage {s} {k}")
     assert_close(loss, g["loss"], 1e-4, 1e-3, "loss")
     assert_close(gfeats, g["grad_feats"], 2e-3, 1e-4 * np.abs(g["grad_feats"]).max(), "grad_feats")
+
+
+def test_parked_table_gradients_reach_the_mlps_at_the_flush():
+    """attention.DeferredTableGrads (host logic of the side-stream table gradient): tables cut from their graph, the layers'
+    gradients parked by `_ParkTableGrad`, the tables' own backward run by flush() — the same parameter gradients as the
+    plain graph, nothing before the flush, a layer without a gradient counts as zero."""
+    from vdetr_amd import attention as A
+    torch.manual_seed(0)
+    w1, w2 = torch.randn(5, 3, requires_grad=True), torch.randn(7, 5, requires_grad=True)
+    coords, wl = torch.randn(3, 11, 3), torch.randn(3, 11, 7)
+
+    def tables():
+        return torch.relu(coords @ w1.t()) @ w2.t()  # [3 layers, 11, 7]
+
+    ((tables()[0] * wl[0]).sum() + 2.0 * (tables()[2] * wl[2]).sum()).backward()
+    ref = (w1.grad.clone(), w2.grad.clone())
+    w1.grad = w2.grad = None
+    parts = A.DeferredTableGrads.park(tables())
+    assert len(parts) == 3 and all(p.requires_grad for p in parts)
+    ((parts[0] * wl[0]).sum() + 2.0 * (parts[2] * wl[2]).sum()).backward()  # layer 1 unused
+    assert w1.grad is None and w2.grad is None and len(A.DeferredTableGrads.pending) == 1
+    A.DeferredTableGrads.flush()
+    assert not A.DeferredTableGrads.pending
+    assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6) and torch.allclose(w2.grad, ref[1], rtol=1e-6, atol=1e-6)
+    # nothing parked, nothing to do; a pass whose layers received no gradient at all leaves the parameters untouched
+    A.DeferredTableGrads.flush()
+    A.DeferredTableGrads.park(tables())
+    A.DeferredTableGrads.flush()
+    assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6)
+    # modes: "0" never, "1" always, "auto" from 2^21 query-key pairs on
+    prev = A.set_async_table_grad("auto")
+    try:
+        assert A._async_wanted(1, 1024, 4096) and not A._async_wanted(1, 64, 4096)
+        A.set_async_table_grad("1")
+        assert A._async_wanted(1, 1, 1)
+        A.set_async_table_grad("0")
+        assert not A._async_wanted(4, 1024, 4096) and not A.ASYNC_TABLE_GRAD
+    finally:
+        A.set_async_table_grad(prev)

@@ -72,6 +72,15 @@ ASYNC_TABLE_GRID = int(os.environ.get("VDETR_BWD_ASYNC_GRID", "192"))
 _ASYNC_KV4 = os.environ.get("VDETR_BWD_ASYNC_KV_WAVES", "8") == "4"
 
 
+def set_async_table_grad(mode):
+    """"auto" | "1" | "0" (the VDETR_BWD_ASYNC_TABLE values) from here on; returns the previous mode.  A caller whose own side
+    streams already fill the hardware queues (bench.BackboneTrainer: loader stream + sampling kernel) turns it off."""
+    global _ASYNC_ENV, ASYNC_TABLE_GRAD
+    prev, _ASYNC_ENV = _ASYNC_ENV, str(mode)
+    ASYNC_TABLE_GRAD = _ASYNC_ENV != "0"
+    return prev
+
+
 def _async_wanted(B, nQ, nK):
     return ASYNC_TABLE_GRAD and (_ASYNC_ENV == "1" or B * nQ * nK >= ASYNC_MIN_PAIRS)
 
@@ -82,6 +91,8 @@ _side_keep = []  # tensors the side-stream kernels read, alive until the join
 
 def _dev_key(device):
     device = torch.device(device)
+    if device.type != "cuda":
+        return (device.type, 0)
     return (device.type, device.index if device.index is not None else torch.cuda.current_device())
 
 
