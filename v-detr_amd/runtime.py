@@ -143,7 +143,6 @@ def flush_weight_grads_phased(phase_of_param, nphases, after_phase):
     DeferredLnGrads.flush()        # a handful of launches whose parameters may sit in any bucket: before the first one leaves
     DeferredPosEmbedGrads.flush()
     from .attention import DeferredTableGrads
-    DeferredTableGrads.flush()     # (likewise: the table MLPs' parameters may sit in the first bucket)
 
     def phase(it):
         ph = nphases - 1
@@ -157,4 +156,6 @@ def flush_weight_grads_phased(phase_of_param, nphases, after_phase):
 
     for k in range(nphases):
         DeferredParamGrads.flush(select=(lambda it, k=k: phase(it) <= k) if k < nphases - 1 else None)
+        if k == 0:  # the table MLPs' parameters may sit in the first bucket: their backward (and the wait for the side stream's
+            DeferredTableGrads.flush()  # table kernels, which ran under the GEMMs above) before that bucket leaves
         after_phase(k)
