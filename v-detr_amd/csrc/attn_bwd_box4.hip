@@ -34,7 +34,10 @@ typedef float __attribute__((may_alias)) b4_rec1_t;
 typedef int __attribute__((may_alias)) b4_reci_t;
 typedef unsigned __attribute__((may_alias)) b4_recu_t;
 
-constexpr int kB4Waves = 16;
+#ifndef VDETR_B4_WAVES
+#define VDETR_B4_WAVES 16
+#endif
+constexpr int kB4Waves = VDETR_B4_WAVES;  // (-DVDETR_B4_WAVES=8: half a CU's registers per workgroup - an experiment)
 constexpr int kB4Threads = kB4Waves * kWave;
 constexpr int kB4T = 10;                                     // table edge ("bilinear_4_10")
 constexpr int kB4RecBytes = 64;                              // U[8] = wz wy | wx[4] | dS[4]; 16-byte parts at 16 (p ^ (slot & 3))
@@ -58,7 +61,11 @@ __device__ __forceinline__ int b4_round(float x) {  // floor(x + 0.5): one instr
   return r;
 }
 
-__global__ __launch_bounds__(kB4Threads) void attn_bwd_box4_kernel(AttnParams P) {
+__global__ __launch_bounds__(kB4Threads)
+#if VDETR_B4_WAVES < 16
+__attribute__((amdgpu_waves_per_eu(4, 4)))  // <= 128 registers per lane also with fewer waves: other kernels fit next to it
+#endif
+void attn_bwd_box4_kernel(AttnParams P) {
   constexpr int T = kB4T, T3 = T * T * T;
   if (P.bwd_aux[4] != 0 || P.bwd_aux[5] == 0) return;  // a query is not an axis-aligned box: the general kernel runs instead
   extern __shared__ __attribute__((aligned(16))) float smem[];
