@@ -96,6 +96,8 @@ def test_box_corners_and_lidar():
     assert_close(c, g["corners"], 1e-5, 1e-6, "corners")
     c0 = cfg.box_parametrization_to_corners(t(g["center"]), t(g["size"]), torch.zeros_like(t(g["angle"])))
     assert_close(c0, g["corners_zero_angle"], 1e-6, 1e-7, "corners0")
+    # angle=None: the one-launch form ModelVDETR.forward uses for the (yaw 0) encoder proposals == the general form on zeros
+    assert torch.equal(cfg.box_parametrization_to_corners(t(g["center"]), t(g["size"]), None), c0)
     assert_close(convert_corners_camera2lidar(c), g["lidar"], 1e-5, 1e-6, "lidar")
 
 

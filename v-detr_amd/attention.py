@@ -136,8 +136,9 @@ class DeferredTableGrads:
     """The gradient of the RPE tables' MLPs, run AFTER the backward pass and the other parked parameter gradients
     (runtime.flush_weight_grads): the side stream's last table kernel then also overlaps the weight-gradient GEMMs instead of
     being waited for inside the backward.  Only with runtime.defer_weight_grads() (the training loop promises a flush)."""
-    pending = []   # [tables as computed (with their graph), [slot = [index, grad] per layer]]
+    pending = []   # [tables as computed (with their graph), [slot = [index, grad] per layer], stacked accumulator or None]
     _anchor = {}
+    buffers = {}   # data_ptr of a layer's (cut) table -> its slice of the stacked accumulator, for the attention backward
 
     @classmethod
     def park(cls, tables):
@@ -145,15 +146,29 @@ class DeferredTableGrads:
         key = _dev_key(tables.device)
         if key not in cls._anchor:  # a leaf that makes the outputs require grad; it never receives one
             cls._anchor[key] = torch.zeros(1, device=tables.device, requires_grad=True)
+        if cls.pending:
+            if any(g is not None for _, slots, _ in cls.pending for _, g in slots):
+                raise RuntimeError("runtime.defer_weight_grads() is on but runtime.flush_weight_grads() was not called after "
+                                   "the last backward pass (parked RPE-table gradients)")
+            cls.pending.clear()  # forward passes that were never differentiated
+            cls.buffers.clear()
         cut = tables.detach()
         slots = [[i, None] for i in range(tables.shape[0])]
-        cls.pending.append((tables, slots))
+        # the layers' accumulators as slices of ONE zeroed buffer in layer order: the flush hands it to the tables' backward
+        # as it is (a stack of 8 separately placed tensors is 8 copy nodes of ~9 us each in a captured step)
+        acc = None
+        if tables.is_cuda and tables.dtype == torch.float32:
+            acc = _take_zeros(tables, tuple(tables.shape), tables.dtype)
+            for i in range(tables.shape[0]):
+                cls.buffers[cut[i].data_ptr()] = acc[i]
+        cls.pending.append((tables, slots, acc))
         return [_ParkTableGrad.apply(cls._anchor[key], cut[i], slots[i]) for i in range(tables.shape[0])]
 
     @classmethod
     def flush(cls):
         items, cls.pending = cls.pending, []
-        for tables, slots in items:
+        cls.buffers.clear()
+        for tables, slots, acc in items:
             if all(g is None for _, g in slots):
                 continue
             dev = tables.device
@@ -161,7 +176,10 @@ class DeferredTableGrads:
             if side is not None and _side_keep:
                 torch.cuda.current_stream(dev).wait_stream(side)
             _side_keep.clear()
-            g = torch.stack([g if g is not None else torch.zeros_like(tables[i]) for i, g in slots])
+            if acc is not None and all(g is None or g.data_ptr() == acc[i].data_ptr() for i, g in slots):
+                g = acc  # every layer accumulated in place (a layer without a gradient left its slice zero)
+            else:
+                g = torch.stack([g if g is not None else torch.zeros_like(tables[i]) for i, g in slots])
             torch.autograd.backward([tables], [g])
 
 
@@ -184,6 +202,14 @@ def join_table_grad(table):
         _side_stream(table.device)
         return _JoinTableGrad.apply(table)
     return table
+
+
+def _table_accumulator(table):
+    """zeroed gradient accumulator of one layer's table: its slice of the parked tables' stacked buffer where there is one"""
+    buf = DeferredTableGrads.buffers.pop(table.data_ptr(), None)
+    if buf is not None and buf.shape == table.shape:
+        return buf
+    return _take_zeros(table, tuple(table.shape), table.dtype)
 
 
 def _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork=None, dtable=None):
@@ -395,7 +421,7 @@ class _FusedAttention(Function):
                 # kernel: a captured graph's executor keeps the FIRST edge of a node on the node's queue and moves every
                 # further edge to the next one (round robin over 4) - the main chain must stay where it is, or it hops a
                 # queue per layer and lands behind the table kernel every fourth time (measured: DESIGN.md 4.4e)
-                dtable = _take_zeros(table, tuple(table.shape), table.dtype)  # (a fill, if any, is in front of the event)
+                dtable = _table_accumulator(table)  # (a fill, if any, is in front of the event)
                 fork = torch.cuda.Event()
                 fork.record(torch.cuda.current_stream(q.device))
             # dQ first: its library GEMM does not fit next to the table kernel on a CU and would sit behind it
@@ -417,7 +443,7 @@ class _FusedAttention(Function):
                 if run_async:
                     dtable = _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable)
                 else:
-                    dtable = _take_zeros(table, tuple(table.shape), table.dtype)
+                    dtable = _table_accumulator(table)
                     nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
                     ws = L.workspace(nbytes, q.device)
                     L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws), nbytes,

@@ -249,7 +249,7 @@ class ModelVDETR(nn.Module):
             "size_normalized": convert_unnorm2norm(size_unnormalized, point_cloud_dims, with_offset=False),
         }
         enc_box_predictions["box_corners"] = self.decoder.box_processor.box_parametrization_to_corners(
-            query_xyz, size_unnormalized, query_xyz.new_zeros((bs, npoints)))
+            query_xyz, size_unnormalized, None)  # (yaw 0, as the reference's zero tensor: pc_util.get_3d_box_batch_tensor)
         tgt = None if self.querypos_mlp else torch.zeros_like(query_embed)
         box_predictions = self.decoder(tgt, enc_features, query_xyz, enc_xyz, point_cloud_dims, query_pos=query_embed,
                                        enc_box_predictions=enc_box_predictions, enc_box_features=enc_features)[0]

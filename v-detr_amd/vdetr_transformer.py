@@ -188,9 +188,22 @@ class GlobalShareCrossAttention(nn.Module):
         b1 = torch.stack([m[0].bias for m in self.cpb_mlps])    # [8,hid]
         w2 = torch.stack([m[2].weight for m in self.cpb_mlps])  # [8,H,hid]
         T = self.relative_coords_table.shape[1]
-        coords = self.relative_coords_table.reshape(1, -1, 3).expand(8, -1, -1)
-        hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
+        hid = self._cpb_hidden(self, w1, b1, 8)
         return torch.bmm(hid, w2.transpose(1, 2)).view(8, T, T, T, self.num_heads)
+
+    @staticmethod
+    def _cpb_hidden(mod, w1, b1, n):
+        """relu(coords W1^T + b1) of n cpb MLPs ([n,hid,3], [n,hid]) on the coordinate grid.  The bias rides in the GEMM as a
+        fourth contraction row against a column of ones: `baddbmm` first copies the broadcast bias into the [n, T^3, hid]
+        output (22 us for 32 MB at n = 64) and its backward reduces that tensor again for the bias gradient (21 us); here the
+        weight gradient's GEMM yields the bias gradient as its fourth row."""
+        tab = mod.relative_coords_table
+        c1 = mod.__dict__.get("_coords1")
+        if c1 is None or c1.device != tab.device or c1.dtype != tab.dtype:
+            flat = tab.reshape(-1, 3)
+            c1 = mod.__dict__["_coords1"] = torch.cat((flat, torch.ones_like(flat[:, :1])), dim=1)  # [T^3, 4]
+        w1b = torch.cat((w1, b1.unsqueeze(-1)), dim=2)                                           # [n, hid, 4]
+        return torch.relu(torch.bmm(c1.unsqueeze(0).expand(n, -1, -1), w1b.transpose(1, 2)))
 
     @staticmethod
     def precompute(mods, key):
@@ -211,8 +224,7 @@ class GlobalShareCrossAttention(nn.Module):
         b1 = stack_params([mm[0].bias for mm in mlps])
         w2 = stack_params([mm[2].weight for mm in mlps])
         T, H = mods[0].relative_coords_table.shape[1], mods[0].num_heads
-        coords = mods[0].relative_coords_table.reshape(1, -1, 3).expand(8 * n, -1, -1)
-        hid = torch.relu(torch.baddbmm(b1.unsqueeze(1), coords, w1.transpose(1, 2)))
+        hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
         tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H)
         # the table gradients are computed on a side stream (attention.py: ASYNC_TABLE_GRAD); autograd reaches the joins —
         # they were created before any decoder layer — only after every layer's backward, and waits there; with parked weight
