@@ -9,6 +9,13 @@ rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py -
 db=$(find /tmp/rp_eager -name '*.db' | head -1); csv=$(find /tmp/rp_eager -name '*kernel_trace.csv' | head -1)
 python3 tools/rocprof_summary.py ${db:-$csv} 5 3 > $out/eager_kernel_summary.txt 2>&1
 python3 tools/kernel_bench.py c2 > $out/kernel_bench_c2.txt 2>&1
+# the CAPTURED step under the kernel trace: which hardware queue the chain and the table-gradient branch run on.
+# NOTE: the tracer delays the cross-queue start of the side branch (the traced step is ~1.5 ms longer than the untraced one and
+# shows the table kernels back to back behind the chain); the untraced sweep (profiles/*_async_table_sweep.txt) is the timing evidence.
+rm -rf /tmp/rp_graph
+VDETR_BENCH_NORMAL_EXIT=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_graph -o graph -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-criterion-leg --no-backbone-leg > $out/bench_graph_traced.log 2>&1
+gcsv=$(find /tmp/rp_graph -name '*kernel_trace.csv' | head -1)
+[ -n "$gcsv" ] && python3 tools/async_timeline.py $gcsv attn_bwd_box4 > $out/graph_timeline.txt 2>&1
 # the step with the device criterion as its loss: kernel trace + the solver's scan counts
 rocprofv3 --kernel-trace --stats -d /tmp/rp_crit -o crit -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-backbone-leg --loss criterion > $out/bench_criterion_eager.log 2>&1 < /dev/null
 cdb=$(find /tmp/rp_crit -name '*.db' | head -1)
