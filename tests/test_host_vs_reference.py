@@ -159,6 +159,30 @@ def test_parked_table_gradients_reach_the_mlps_at_the_flush():
     A.DeferredTableGrads.park(tables())
     A.DeferredTableGrads.flush()
     assert torch.allclose(w1.grad, ref[0], rtol=1e-6, atol=1e-6)
+    # tables parked WITH their MLP's operands (computed without a graph): begin_flush writes the backward out as three GEMMs
+    n8, T3, hd, H = 6, 50, 16, 4
+    c1 = torch.cat((torch.randn(T3, 3), torch.ones(T3, 1)), 1)
+    v1, c_1, v2 = (torch.randn(n8, hd, 3, requires_grad=True), torch.randn(n8, hd, requires_grad=True),
+                   torch.randn(n8, H, hd, requires_grad=True))
+    wt = torch.randn(3, 2, T3, H)
+
+    def mlp(grad):
+        with torch.enable_grad() if grad else torch.no_grad():
+            hid = torch.relu(torch.bmm(c1.unsqueeze(0).expand(n8, -1, -1), torch.cat((v1, c_1.unsqueeze(-1)), 2).transpose(1, 2)))
+            return torch.bmm(hid, v2.transpose(1, 2)).view(3, 2, T3, H), hid
+
+    (mlp(True)[0] * wt).sum().backward()
+    ref2 = [p.grad.clone() for p in (v1, c_1, v2)]
+    v1.grad = c_1.grad = v2.grad = None
+    tabs, hid = mlp(False)
+    parts = A.DeferredTableGrads.park(tabs, mlp=(c1, v1, c_1, v2, hid))
+    sum((parts[i] * wt[i]).sum() for i in range(3)).backward()
+    assert v1.grad is None
+    A.DeferredTableGrads.begin_flush()
+    assert not A.DeferredTableGrads.pending and len(A.DeferredTableGrads._begun) == 1
+    A.DeferredTableGrads.flush()
+    for p, r in zip((v1, c_1, v2), ref2):
+        assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-5)
     # modes: "0" never, "1" always, "auto" from 2^21 query-key pairs on
     prev = A.set_async_table_grad("auto")
     try:

@@ -12,6 +12,7 @@ Forward saves the biased scores S [rows, nK] and the row log-sum-exp; backward i
   shared K/V, 4 heads: one pass over S (attn_bwd_kv.hip: dP~ = dO V^T, P~, dS, dV, dK) -> dTable from dS -> dQ = dS K (GEMM);
   otherwise: dP~ = dO V^T (GEMM) -> kernel: P~, dS, dTable -> dV = P~^T dO, dK = dS^T q, dQ = dS K (GEMMs).
 """
+import contextlib
 import ctypes
 import os
 
@@ -136,18 +137,22 @@ class DeferredTableGrads:
     """The gradient of the RPE tables' MLPs, run AFTER the backward pass and the other parked parameter gradients
     (runtime.flush_weight_grads): the side stream's last table kernel then also overlaps the weight-gradient GEMMs instead of
     being waited for inside the backward.  Only with runtime.defer_weight_grads() (the training loop promises a flush)."""
-    pending = []   # [tables as computed (with their graph), [slot = [index, grad] per layer], stacked accumulator or None]
+    pending = []   # [tables as computed (with their graph), [slot = [index, grad] per layer], stacked accumulator or None, mlp]
     _anchor = {}
+    _begun = []    # results of begin_flush(): (parameter alias, gradient) pairs computed on the side stream
     buffers = {}   # data_ptr of a layer's (cut) table -> its slice of the stacked accumulator, for the attention backward
 
     @classmethod
-    def park(cls, tables):
-        """tables [n, ...] (requires grad) -> n tensors for the n layers, cut from the graph"""
+    def park(cls, tables, mlp=None):
+        """tables [n, ...] (requires grad) -> n tensors for the n layers, cut from the graph.
+        ``mlp`` = (c1 [T^3, 4], w1 [8n, hid, 3], b1 [8n, hid], w2 [8n, H, hid], hidden [8n, T^3, hid]): the tables were computed
+        WITHOUT a graph as relu([coords, 1] [w1, b1]^T) w2^T; their backward is then three GEMMs that `begin_flush` puts on
+        the side stream right behind the last table kernel, so nothing of it sits on the main stream."""
         key = _dev_key(tables.device)
         if key not in cls._anchor:  # a leaf that makes the outputs require grad; it never receives one
             cls._anchor[key] = torch.zeros(1, device=tables.device, requires_grad=True)
         if cls.pending:
-            if any(g is not None for _, slots, _ in cls.pending for _, g in slots):
+            if any(g is not None for _, slots, _, _ in cls.pending for _, g in slots):
                 raise RuntimeError("runtime.defer_weight_grads() is on but runtime.flush_weight_grads() was not called after "
                                    "the last backward pass (parked RPE-table gradients)")
             cls.pending.clear()  # forward passes that were never differentiated
@@ -161,16 +166,65 @@ class DeferredTableGrads:
             acc = _take_zeros(tables, tuple(tables.shape), tables.dtype)
             for i in range(tables.shape[0]):
                 cls.buffers[cut[i].data_ptr()] = acc[i]
-        cls.pending.append((tables, slots, acc))
+        cls.pending.append((tables, slots, acc, mlp))
         return [_ParkTableGrad.apply(cls._anchor[key], cut[i], slots[i]) for i in range(tables.shape[0])]
 
     @classmethod
+    def begin_flush(cls):
+        """First thing of runtime.flush_weight_grads: for tables parked with their MLP's operands, the MLPs' backward (three
+        batched GEMMs + the ReLU mask) is enqueued on the side stream behind the table kernels it reads; flush() joins."""
+        keep = []
+        for item in cls.pending:
+            tables, slots, acc, mlp = item
+            if mlp is None or all(g is None for _, g in slots):
+                keep.append(item)
+                continue
+            dev = tables.device
+            # on the side stream only where this step's table kernels ran there (a fork and a join just for these launches
+            # cost a small step more than they hide: C1 2.08 -> 2.29 ms)
+            side = _side_streams.get(_dev_key(dev)) if (tables.is_cuda and _side_keep) else None
+            cur = torch.cuda.current_stream(dev) if tables.is_cuda else None
+            if acc is None or not all(g is None or g.data_ptr() == acc[i].data_ptr() for i, g in slots):
+                # a layer's backward did not accumulate in place (e.g. the GEMM composition of the attention backward)
+                if side is not None and _side_keep:
+                    cur.wait_stream(side)
+                acc = torch.stack([g if g is not None else torch.zeros_like(tables[i]) for i, g in slots])
+                if side is not None:
+                    side.wait_stream(cur)
+            c1, w1, b1, w2, hid = mlp
+            n8 = hid.shape[0]
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), torch.no_grad():
+                dT = acc.reshape(n8, hid.shape[1], -1)                                # [8n, T^3, H]
+                dW2 = torch.bmm(dT.transpose(1, 2), hid)                              # [8n, H, hid]
+                dhid = torch.ops.aten.threshold_backward(torch.bmm(dT, w2.detach()), hid, 0.0)
+                dW1b = torch.bmm(dhid.transpose(1, 2), c1.unsqueeze(0).expand(n8, -1, -1))   # [8n, hid, 4]: weights | bias
+            cls._begun.append((dev if side is not None else None, ((w1, dW1b[..., :3]), (b1, dW1b[..., 3]), (w2, dW2)),
+                               (acc, dT, dhid, hid)))
+        cls.pending = keep
+
+    @classmethod
     def flush(cls):
+        from .helpers import DeferredParamGrads
+        begun, cls._begun = cls._begun, []
+        for dev, pairs, _alive in begun:
+            side = _side_streams.get(_dev_key(dev)) if dev is not None else None  # (None: computed on the current stream)
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+            _side_keep.clear()
+            roots, grads = [], []
+            with torch.no_grad():
+                for p, g in pairs:
+                    if p.requires_grad:
+                        DeferredParamGrads._deliver(p, g, roots, grads)
+            if roots:
+                torch.autograd.backward(roots, grads)
         items, cls.pending = cls.pending, []
         cls.buffers.clear()
-        for tables, slots, acc in items:
+        for tables, slots, acc, _mlp in items:
             if all(g is None for _, g in slots):
                 continue
+            if not tables.requires_grad:
+                raise RuntimeError("tables parked with their MLP's operands can only be flushed through begin_flush()")
             dev = tables.device
             side = _side_streams.get(_dev_key(dev))
             if side is not None and _side_keep:
@@ -183,15 +237,21 @@ class DeferredTableGrads:
             torch.autograd.backward([tables], [g])
 
 
-def park_table_grads(tables):
+def table_grads_parkable(ref):
+    """True where `park_table_grads` parks: side-stream table gradients + parked weight gradients, on the GPU, under grad mode"""
+    from .helpers import DeferredParamGrads
+    return bool(ASYNC_TABLE_GRAD and DeferredParamGrads.enabled and ref.is_cuda and ref.requires_grad and torch.is_grad_enabled()
+                and os.environ.get("VDETR_BWD_ASYNC_PARK", "1") != "0")
+
+
+def park_table_grads(tables, mlp=None):
     """[n, 8, T, T, T, H] tables of n layers -> list of n per-layer tables.  With the table gradient on the side stream and
     parked weight gradients (runtime.defer_weight_grads) the tables are cut from their graph and their MLPs' backward runs at
-    the flush; otherwise each table passes through `join_table_grad`."""
-    from .helpers import DeferredParamGrads
-    if (ASYNC_TABLE_GRAD and DeferredParamGrads.enabled and tables.is_cuda and tables.requires_grad and torch.is_grad_enabled()
-            and os.environ.get("VDETR_BWD_ASYNC_PARK", "1") != "0"):
+    the flush (`mlp`: see DeferredTableGrads.park — the caller checked `table_grads_parkable` and computed the tables without
+    a graph); otherwise each table passes through `join_table_grad`."""
+    if mlp is not None or table_grads_parkable(tables):
         _side_stream(tables.device)
-        return DeferredTableGrads.park(tables)
+        return DeferredTableGrads.park(tables, mlp)
     return [join_table_grad(t) for t in tables.unbind(0)]
 
 

@@ -113,6 +113,7 @@ def defer_weight_grads(enable=True):
         DeferredPosEmbedGrads.pending.clear()
         from .attention import DeferredTableGrads
         DeferredTableGrads.pending.clear()
+        DeferredTableGrads._begun.clear()
 
 
 def weight_grads_deferred():
@@ -125,10 +126,11 @@ def weight_grads_deferred():
 def flush_weight_grads():
     from .add_ln import DeferredLnGrads
     from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
+    from .attention import DeferredTableGrads
+    DeferredTableGrads.begin_flush()  # (the table MLPs' backward onto the side stream, behind the table kernels it reads)
     DeferredParamGrads.flush()
     DeferredLnGrads.flush()
     DeferredPosEmbedGrads.flush()
-    from .attention import DeferredTableGrads
     DeferredTableGrads.flush()  # last: it waits for the side stream's table kernels, which run under the launches above
 
 
@@ -140,9 +142,10 @@ def flush_weight_grads_phased(phase_of_param, nphases, after_phase):
     The shape-batched GEMMs split into at most ``nphases`` smaller batches; the values are those of the one-shot flush."""
     from .add_ln import DeferredLnGrads
     from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
+    from .attention import DeferredTableGrads
+    DeferredTableGrads.begin_flush()  # (onto the side stream; joined before the first bucket leaves)
     DeferredLnGrads.flush()        # a handful of launches whose parameters may sit in any bucket: before the first one leaves
     DeferredPosEmbedGrads.flush()
-    from .attention import DeferredTableGrads
 
     def phase(it):
         ph = nphases - 1

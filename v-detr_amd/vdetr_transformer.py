@@ -16,6 +16,7 @@ the box heads are library GEMMs / element-wise ops and stay in PyTorch with the 
 import copy
 import itertools
 import math
+import os
 from functools import partial
 from typing import Optional
 
@@ -23,8 +24,6 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
-
-import os
 
 from . import add_ln as ALN
 from . import bn_act as BNA
@@ -224,12 +223,18 @@ class GlobalShareCrossAttention(nn.Module):
         b1 = stack_params([mm[0].bias for mm in mlps])
         w2 = stack_params([mm[2].weight for mm in mlps])
         T, H = mods[0].relative_coords_table.shape[1], mods[0].num_heads
-        hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
-        tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H)
         # the table gradients are computed on a side stream (attention.py: ASYNC_TABLE_GRAD); autograd reaches the joins —
         # they were created before any decoder layer — only after every layer's backward, and waits there; with parked weight
-        # gradients the tables' own backward moves behind the flush and the wait with it
-        tables = A.park_table_grads(tables)
+        # gradients the tables' own backward (three GEMMs, written out in DeferredTableGrads.begin_flush) follows the last
+        # table kernel ON that stream, next to the flush
+        if A.table_grads_parkable(w1) and os.environ.get("VDETR_BWD_ASYNC_MLP", "1") != "0":
+            with torch.no_grad():
+                hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
+                tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H)
+            tables = A.park_table_grads(tables, mlp=(mods[0].__dict__["_coords1"], w1, b1, w2, hid))
+        else:
+            hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
+            tables = A.park_table_grads(torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H))
         return [(parts[2 * i], parts[2 * i + 1], tables[i]) for i in range(n)]
 
     def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None,
