@@ -73,6 +73,37 @@ ASYNC_TABLE_GRID = int(os.environ.get("VDETR_BWD_ASYNC_GRID", "192"))
 _ASYNC_KV4 = os.environ.get("VDETR_BWD_ASYNC_KV_WAVES", "8") == "4"
 
 
+_step_side = {}  # device key -> this step's forward ran a cross-attention whose table gradient will go to the side stream
+
+
+def side_branch_in_use(device):
+    """True when the current step's backward will launch table-gradient kernels on the side stream of `device`: other
+    parameter-only work (the box heads' weight gradients) may then go there too and is joined at the flush (SideResults)."""
+    return bool(_step_side.get(_dev_key(device)))
+
+
+class SideResults:
+    """Parameter gradients other modules computed on the side stream: [(device, [(parameter or alias, gradient)], tensors
+    kept alive)]; delivered after the join at runtime.flush_weight_grads (DeferredTableGrads.flush)."""
+    pending = []
+
+    @classmethod
+    def flush(cls):
+        from .helpers import DeferredParamGrads
+        items, cls.pending = cls.pending, []
+        for dev, pairs, _alive in items:
+            side = _side_streams.get(_dev_key(dev))
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+            roots, grads = [], []
+            with torch.no_grad():
+                for p, g in pairs:
+                    if p is not None and p.requires_grad:
+                        DeferredParamGrads._deliver(p, g, roots, grads)
+            if roots:
+                torch.autograd.backward(roots, grads)
+
+
 def set_async_table_grad(mode):
     """"auto" | "1" | "0" (the VDETR_BWD_ASYNC_TABLE values) from here on; returns the previous mode.  A caller whose own side
     streams already fill the hardware queues (bench.BackboneTrainer: loader stream + sampling kernel) turns it off."""
@@ -205,6 +236,7 @@ class DeferredTableGrads:
     @classmethod
     def flush(cls):
         from .helpers import DeferredParamGrads
+        SideResults.flush()
         begun, cls._begun = cls._begun, []
         for dev, pairs, _alive in begun:
             side = _side_streams.get(_dev_key(dev)) if dev is not None else None  # (None: computed on the current stream)
@@ -315,6 +347,7 @@ def begin_step(device):
     snap = _master[key].clone()
     _master[key][1] += 1
     _current[key] = snap
+    _step_side[key] = False
     _zero_pool[key] = None  # a fresh pool of zeros for this step's backward passes (allocated on first use)
     return snap
 
@@ -433,6 +466,8 @@ class _FusedAttention(Function):
             ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
             ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
             ctx.table_async = bool(table_async)
+            if table_async and table is not None and table.requires_grad and _async_wanted(q.shape[0], q.shape[1], k.shape[1]):
+                _step_side[_dev_key(q.device)] = True
         return out
 
     @staticmethod

@@ -114,6 +114,8 @@ def defer_weight_grads(enable=True):
         from .attention import DeferredTableGrads
         DeferredTableGrads.pending.clear()
         DeferredTableGrads._begun.clear()
+        from .attention import SideResults
+        SideResults.pending.clear()
 
 
 def weight_grads_deferred():

@@ -518,6 +518,9 @@ class FFNLayer(nn.Module):
 # decoder
 # =====================================================================================================
 _DEFER_HEADS = os.environ.get("VDETR_DEFER_HEADS", "1") != "0"  # A/B switch (read once)
+# the heads' weight gradients on the side branch: OFF - measured C2 8.376 -> 8.33 ms, but C5 (4 scenes: the GEMMs are 4 x larger and
+# hold the table kernels up) 26.15 -> 26.61 ms
+_HEADS_SIDE = os.environ.get("VDETR_HEADS_SIDE", "0") != "0"
 
 
 class _DeferredHeads(torch.autograd.Function):
@@ -577,30 +580,57 @@ class _DeferredHeads(torch.autograd.Function):
         w3 = stack_params([r["w3"].detach().reshape(G, rows, C) for r in recs])  # [S,G,rows,C]
         w2 = stack_params([r["w2"].detach().reshape(G, C, C) for r in recs])
         w1 = stack_params([r["w1"].detach().reshape(G * C, C) for r in recs])    # [S,G*C,C]
+        # The three weight-gradient GEMMs and the output bias sum feed parameters only.  Where this step's table gradients run on
+        # a side branch (attention.side_branch_in_use) and parameter gradients are delivered at the flush anyway, they go to that
+        # branch - it is idle until the first decoder layer's key-side pass - behind ONE fork after the last input-gradient
+        # operand exists: 180 us of GEMMs leave the chain (VDETR_HEADS_SIDE=1; off by default, see _HEADS_SIDE)
+        from .helpers import DeferredParamGrads
+        on_side = (_HEADS_SIDE and dY.is_cuda and DeferredParamGrads.enabled and DeferredParamGrads.direct
+                   and A.side_branch_in_use(dev))
+
+        def weight_grads(dx2, dx1):
+            db3 = dY.sum(dim=(1, 4))                                                               # [S,G,rows]
+            dw3 = torch.bmm(fold(dY, rows), fold(h2, C).transpose(1, 2)).view(S, G, rows, C)
+            dw2 = torch.bmm(fold(dx2, C), fold(h1, C).transpose(1, 2)).view(S, G, C, C)
+            if one:
+                dw1 = torch.bmm(dx1.view(S, G * C, N), f.view(S, C, N).transpose(1, 2))           # [S,G*C,C]
+            else:
+                dw1 = torch.bmm(dx1.permute(0, 2, 1, 3).reshape(S, G * C, Bsz * N),
+                                f.permute(0, 2, 1, 3).reshape(S, C, Bsz * N).transpose(1, 2))
+            return db3, dw3, dw2, dw1
+
         # ---- output layer
-        db3 = dY.sum(dim=(1, 4))                                                                   # [S,G,rows]
-        dYf = fold(dY, rows)
-        dw3 = torch.bmm(dYf, fold(h2, C).transpose(1, 2)).view(S, G, rows, C)
         dh2 = torch.matmul(w3.transpose(2, 3).unsqueeze(1), dY).view(S, Bsz, G * C, N)             # [S,B,G*C,N]
         # ---- second hidden block
         dx2 = torch.empty_like(dh2)
         dbn2 = BNA.backward_from_records([r["bn2"] for r in recs], [dh2[s] for s in range(S)], [dx2[s] for s in range(S)])
-        dw2 = torch.bmm(fold(dx2, C), fold(h1, C).transpose(1, 2)).view(S, G, C, C)
         dh1 = torch.matmul(w2.transpose(2, 3).unsqueeze(1), dx2.view(S, Bsz, G, C, N)).view(S, Bsz, G * C, N)
         # ---- first hidden block
         dx1 = torch.empty_like(dh1)
         dbn1 = BNA.backward_from_records([r["bn1"] for r in recs], [dh1[s] for s in range(S)], [dx1[s] for s in range(S)])
-        if one:
-            dw1 = torch.bmm(dx1.view(S, G * C, N), f.view(S, C, N).transpose(1, 2))               # [S,G*C,C]
-        else:
-            dw1 = torch.bmm(dx1.permute(0, 2, 1, 3).reshape(S, G * C, Bsz * N),
-                            f.permute(0, 2, 1, 3).reshape(S, C, Bsz * N).transpose(1, 2))
+        fork = None
+        if on_side:  # (recorded here, waited for behind the chain's next launch: the captured graph keeps the chain's queue)
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(dev))
         if one:  # the transposed product: rows = queries, i.e. the [nQ,B,C] layout the layers want (no permuted view to copy)
             dft = torch.bmm(dx1.view(S, G * C, N).transpose(1, 2), w1)                             # [S,N,C]
             out = [dft[s].view(N, 1, C) for s in range(S)]
         else:
             df = torch.matmul(w1.transpose(1, 2).unsqueeze(1), dx1)                                # [S,B,C,N]
             out = [df[s].permute(2, 0, 1) for s in range(S)]                                       # as [nQ,B,C]
+        if on_side:
+            side = A._side_stream(dev)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                db3, dw3, dw2, dw1 = weight_grads(dx2, dx1)
+            pairs = []
+            for s, r in enumerate(recs):
+                pairs += [(r["w1"], dw1[s].reshape(r["w1"].shape)), (r["w2"], dw2[s].reshape(r["w2"].shape)),
+                          (r["w3"], dw3[s].reshape(r["w3"].shape)), (r["b3"], db3[s].reshape(r["b3"].shape))]
+                out += [None, dbn1[s][1], dbn1[s][2], None, dbn2[s][1], dbn2[s][2], None, None]
+            A.SideResults.pending.append((dev, pairs, (dY, h2, h1, f, dx2, dx1)))
+            return (None, None, *out)
+        db3, dw3, dw2, dw1 = weight_grads(dx2, dx1)
         for s, r in enumerate(recs):
             out += [dw1[s].reshape(r["w1"].shape), dbn1[s][1], dbn1[s][2], dw2[s].reshape(r["w2"].shape), dbn2[s][1],
                     dbn2[s][2], dw3[s].reshape(r["w3"].shape), db3[s].reshape(r["b3"].shape)]
