@@ -212,6 +212,13 @@ int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float*
 int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* out,
                                 const float* scores, const float* lse, float* delta, float* ds_out, float* dk, float* dv,
                                 void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
+/* dq [B,nQ,H*64] = scale * dS K from the UNSCALED dS that vdetr_attn_bwd_kv_f32 wrote ([B,nQ,H,nK] for shared K/V, [B,H,nQ,nK]
+ * per head), k as in the forward (k_row_stride honoured): a row-owner kernel with exact fp32 products (attn_bwd_dq.hip) in place
+ * of the batched library GEMM the host composition used (`torch.baddbmm(..., alpha=scale)`: N = 64 is a poor shape for it).
+ * Replaces the matmul autograd of vdetr_transformer.py:733-757 / nn.MultiheadAttention (:468) for dQ.  16-byte aligned operands.
+ * Measured at the model's size (alone): per head 4 x 1024 x 1024 11.7 us (library 19.2), shared K/V 4096 x 4096 31 us (library
+ * 26); the host module keeps the library by default (attention.py: VDETR_BWD_DQ). */
+int vdetr_attn_bwd_dq_f32(const vdetr_attn_desc* d, const float* ds, const float* k, float* dq, vdetr_stream_t stream);
 /* Workgroup shape of vdetr_attn_bwd_kv_f32: 8 waves (default, the kernel alone on the chip) or 4 (one wave per SIMD with
  * <= 256 registers: fits next to the table-gradient kernel when the caller runs that on another stream).  PROCESS-WIDE state,
  * read at launch: a tuning switch for single-threaded callers (threads or devices that set different shapes race on it; either

@@ -320,6 +320,34 @@ def test_table_gradient_on_fewer_workgroups(monkeypatch, grid, tol):
     assert L.lib().vdetr_attn_bwd_table_set_grid(3) != 0 and L.lib().vdetr_attn_bwd_table_set_grid(258) != 0
 
 
+@pytest.mark.parametrize("kind,B,nQ,nK,kstride", [("shared", 1, 1024, 4096, 1024), ("shared", 2, 33, 700, 64), ("shared", 1, 5, 3, 64),
+                                                 ("shared", 3, 40, 2049, 128), ("perhead", 1, 1024, 1024, 256), ("perhead", 2, 50, 77, 256),
+                                                 ("perhead", 1, 17, 130, 256), ("shared", 1, 64, 63, 64)])
+def test_dq_row_owner_kernel_equals_matmul(kind, B, nQ, nK, kstride):
+    """vdetr_attn_bwd_dq_f32 (attn_bwd_dq.hip): dQ = scale * dS K with exact fp32 products against the fp64 matmul, for both
+    kinds, keys that do not fill a 64-key chunk or a 16-byte load, rows that do not fill a tile, several scenes and K as a
+    column block of a wider projection (k_row_stride)."""
+    import ctypes
+    from vdetr_amd import _lib as L
+    from vdetr_amd import attention as A
+    H = 4
+    g = torch.Generator().manual_seed(nQ * 7 + nK)
+    shared = kind == "shared"
+    ds = torch.randn((B, nQ, H, nK) if shared else (B, H, nQ, nK), generator=g).to(DEV)
+    wide = torch.randn((B, nK, kstride), generator=g).to(DEV)
+    k = wide[:, :, :64] if shared else wide[:, :, :256]
+    d = A._desc(L.VDETR_ATTN_SHARED_KV if shared else L.VDETR_ATTN_PER_HEAD, B, H, nQ, nK, 0.125, None, None, None, None, None, None,
+                0.0, None, 0, kstride, 0)
+    dq = torch.full((B, nQ, H * 64), float("nan"), device=DEV)
+    L.check(L.lib().vdetr_attn_bwd_dq_f32(ctypes.byref(d), L.ptr(ds), L.ptr(k), L.ptr(dq), L.stream_ptr()), "attn_bwd_dq")
+    if shared:
+        ref = 0.125 * torch.einsum("bqhk,bkd->bqhd", ds.double(), k.double()).reshape(B, nQ, H * 64)
+    else:
+        ref = 0.125 * torch.einsum("bhqk,bkhd->bqhd", ds.double(), k.double().reshape(B, nK, H, 64)).reshape(B, nQ, H * 64)
+    assert torch.isfinite(dq).all()
+    assert float((dq.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, (nK / 64) ** 0.5)
+
+
 def _rotated_boxes(B, nQ, nK, seed):
     """keys, the corners of ROTATED boxes (centre + R(angle)^T (+-half), as box_decode writes them), tables, (cos, sin)"""
     xyz, verts, tables, _ = _scene(B, nQ, nK, seed)

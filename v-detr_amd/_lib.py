@@ -182,6 +182,7 @@ _SIGNATURES = {
     "vdetr_attn_bwd_kv_f32": (c_int, [ctypes.POINTER(AttnDesc)] + [c_void_p] * 10 + [c_size_t, c_void_p]),
     "vdetr_attn_bwd_kv_delta_f32": (c_int, [ctypes.POINTER(AttnDesc)] + [c_void_p] * 11 + [c_size_t, c_void_p]),
     "vdetr_attn_bwd_kv_set_waves": (c_int, [c_int]),
+    "vdetr_attn_bwd_dq_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     "vdetr_attn_bwd_table_set_grid": (c_int, [c_int]),
     "vdetr_attn_bwd_table_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_table_kernel_names": (c_int, [ctypes.POINTER(AttnDesc), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p)]),

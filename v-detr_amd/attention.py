@@ -53,6 +53,13 @@ DYNAMIC_BWD = os.environ.get("VDETR_BWD_DYNAMIC", "1") != "0"
 # shared-KV backward: dO V^T, the softmax backward, dV and dK in one pass over the scores (attn_bwd_kv.hip) instead of
 # three library GEMMs around an element-wise kernel.  VDETR_BWD_FUSED=0 keeps the GEMM path (A/B measurements, parity).
 FUSED_KV_BWD = os.environ.get("VDETR_BWD_FUSED", "1") != "0"
+# dQ by attn_bwd_dq.hip (row-owner, exact fp32) instead of the library's batched GEMM.  OFF: alone it wins for per-head K/V (the
+# query self-attention: 11.7 against 19.2 us) and loses for shared K/V (31 against 26 us: every 16-row workgroup re-reads all of
+# K), but in the step these launches run NEXT TO the table-gradient branch on a quarter of the CUs, where a kernel bound by
+# matrix time pays 4x: C2 8.34 ms with the library, 8.37-8.41 with the kernel for the self-attention (VDETR_BWD_DQ=1), 8.45-8.48
+# for both (=2).
+_DQ_KERNEL = os.environ.get("VDETR_BWD_DQ", "0") != "0"
+_DQ_KERNEL_SHARED = os.environ.get("VDETR_BWD_DQ", "0") == "2"
 
 
 # The RPE-table gradient kernel (2.3 ms of a 9 ms step) feeds parameters only: nothing on the backward's critical path waits
@@ -519,8 +526,20 @@ class _FusedAttention(Function):
                 dtable = _table_accumulator(table)  # (a fill, if any, is in front of the event)
                 fork = torch.cuda.Event()
                 fork.record(torch.cuda.current_stream(q.device))
-            # dQ first: its library GEMM does not fit next to the table kernel on a CU and would sit behind it
-            if shared:
+            # dQ = scale dS K: the row-owner kernel (attn_bwd_dq.hip; exact fp32 products) for per-head K/V where K is as the
+            # kernel reads it — rows of contiguous floats at a constant stride —, the library's batched GEMM otherwise
+            kd = k if shared else k.reshape(B, nK, C)
+            if (_DQ_KERNEL and (not shared or _DQ_KERNEL_SHARED) and k.dtype == torch.float32 and ds.dtype == torch.float32 and kd.stride(2) == 1
+                    and kd.stride(1) % 4 == 0 and (B == 1 or kd.stride(0) == nK * kd.stride(1))
+                    and kd.data_ptr() % 16 == 0 and ds.data_ptr() % 16 == 0 and B * (1 if shared else H) <= 65535):
+                dq = q.new_empty((B, nQ, C))
+                keep = d.k_row_stride
+                d.k_row_stride = kd.stride(1)
+                try:
+                    L.check(lib.vdetr_attn_bwd_dq_f32(ctypes.byref(d), L.ptr(ds), L.ptr(kd), L.ptr(dq), L.stream_ptr()), "attn_bwd_dq")
+                finally:
+                    d.k_row_stride = keep
+            elif shared:
                 dq = q.new_empty((B, nQ * H, HEAD_DIM))
                 torch.baddbmm(dq, ds.view(B, nQ * H, nK), k, beta=0.0, alpha=float(scale), out=dq)
                 dq = dq.view(B, nQ, C)
