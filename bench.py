@@ -648,7 +648,9 @@ def kernel_rooflines(cfg_name, device, reps=20):
         t_bwd = timeit(bwd, bwd_prep)
     finally:
         lib.vdetr_attn_bwd_table_set_grid(0)
-    t_bwd_full = timeit(bwd, bwd_prep) if side else t_bwd
+    # (VDETR_ROOFLINE_STEP_GRID_ONLY=1: only the launch the step issues — so that a rocprofv3 run of tools/kernel_bench.py averages
+    # ONE configuration of the kernel, the one `launch_us` reports)
+    t_bwd_full = timeit(bwd, bwd_prep) if side and os.environ.get("VDETR_ROOFLINE_STEP_GRID_ONLY") != "1" else t_bwd
     pairs = B * nQ * nK
     flops = 4.0 * H * pairs * 64                       # QK^T + PV (MFMA-eligible), SURVEY.md §8d
     bytes_bwd = 4.0 * H * pairs                        # dS read once (fp32); the kernel is VALU-bound, see valu_issue

@@ -22,14 +22,14 @@ cdb=$(find /tmp/rp_crit -name '*.db' | head -1)
 [ -n "$cdb" ] && python3 tools/rocprof_summary.py $cdb 5 3 > $out/criterion_eager_kernel_summary.txt 2>&1
 python3 tools/criterion_bench.py > $out/criterion_bench.txt 2>&1 < /dev/null
 # the same micro-benchmark under the kernel trace: the per-kernel averages bench.py's `roofline` objects must agree with
-rocprofv3 --kernel-trace --stats -d /tmp/rp_kb -o kb -- python3 tools/kernel_bench.py c2 > /dev/null 2>&1
+VDETR_ROOFLINE_STEP_GRID_ONLY=1 rocprofv3 --kernel-trace --stats -d /tmp/rp_kb -o kb -- python3 tools/kernel_bench.py c2 > /dev/null 2>&1
 kdb=$(find /tmp/rp_kb -name '*.db' | head -1)
 [ -n "$kdb" ] && python3 tools/rocprof_summary.py $kdb > $out/kernel_bench_rocprof.txt 2>&1
 python3 tools/kernel_bench.py c2 --indexing > $out/kernel_bench_indexing.txt 2>&1
 # one cross-attention layer's backward: library-GEMM path vs the fused key-side pass, and the pieces alone (HIP events)
 python3 tools/bwd_layer_bench.py > $out/bwd_layer_bench.txt 2>&1 < /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$c -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_$c.log 2>&1
+  VDETR_ROOFLINE_STEP_GRID_ONLY=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$c -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_$c.log 2>&1
   f=$(find /tmp/rp_$c -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python3 - "$f" $c > $out/pmc_$c.txt <<'PY'
 import csv, sys
@@ -47,7 +47,7 @@ done
 pass=1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS"; do
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/rp_sq$pass -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_sq$pass.log 2>&1
+  VDETR_ROOFLINE_STEP_GRID_ONLY=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/rp_sq$pass -o pmc -- python3 tools/kernel_bench.py c2 > $out/pmc_sq$pass.log 2>&1
   f=$(find /tmp/rp_sq$pass -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python3 - "$f" > $out/pmc_sq_pass$pass.txt <<'PY'
 import csv, sys
