@@ -510,12 +510,13 @@ class BackboneTrainer:
             self._queue.append(self._prepare_next(self.sides[self._tick & 1]))
             self._tick += 1
 
-    def calibrate_side_stream(self, candidates=4, steps=4):
+    def calibrate_side_stream(self, candidates=5, steps=6):
         """HIP maps the streams of a process onto 4 hardware queues; a side stream that lands on the queue of the step's own
         streams puts the next scene's 9 ms sampling kernel IN FRONT of the step's kernels (25 -> 29-33 ms per step, depending on
         how many streams the process created before: measured in this file's own process).  Which queue a stream gets cannot be
         asked, but it can be measured: a few steps with each of several candidate streams, keep the fastest.  Once per process."""
         best = (None, float("inf"))
+        self.calibration_ms = []
         for cand in [self.side] + [torch.cuda.Stream() for _ in range(candidates - 1)]:
             self.close()
             self.side = cand
@@ -527,6 +528,7 @@ class BackboneTrainer:
                 self.step()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / steps * 1e3
+            self.calibration_ms.append(round(ms, 2))
             if ms < best[1]:
                 best = (cand, ms)
         self.close()
@@ -1141,6 +1143,7 @@ def main():
             assert np.isfinite(bloss), "non-finite loss with the backbone"
             result["with_backbone"] = {
                 "ms_per_step": ms, "scenes_per_s": world * 1e3 / ms, "n_gpus": world, "geometry_ms": bt.geometry_ms, "input_points": 40000,
+                "loader_stream_calibration_ms": getattr(bt, "calibration_ms", None),
                 "grad_allreduce_bytes": bt.reducer.grad_bytes() if bt.reducer.active else 0,
                 "grad_allreduce": ("decoder bucket(s) on the side stream under the backbone's backward; backbone buckets of 64 MB sent from "
                                    "post-accumulate hooks while that backward is still running" if getattr(bt, "bb_overlap", False) else
