@@ -111,6 +111,37 @@ class SideResults:
                 torch.autograd.backward(roots, grads)
 
 
+_FLUSH_SIDE = os.environ.get("VDETR_FLUSH_SIDE", "1") != "0"
+_tick = {}
+
+
+def flush_layer_params_on_side(ref, rows):
+    """Called from the backward pass when every decoder layer's backward has run (vdetr_transformer._LayersDone): the parked
+    weight / bias gradients of the layers' linear maps (the items with `rows` rows: 64 of them at the model's size) are computed
+    on the side branch — behind the last table kernel — while the main stream goes on with the first layer's and the
+    projection's backward; runtime.flush_weight_grads joins and delivers (SideResults).  Only where that branch is in use."""
+    from .helpers import DeferredParamGrads
+    if not (_FLUSH_SIDE and ref.is_cuda and DeferredParamGrads.enabled and DeferredParamGrads.direct and side_branch_in_use(ref.device)):
+        return
+    dev = ref.device
+    key = _dev_key(dev)
+    cur = torch.cuda.current_stream(dev)
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    # the chain's next captured launch comes BEFORE the branch's: a captured graph keeps a node's first successor on the node's
+    # queue (see _FusedAttention.backward); nothing of the chain is launched between here and the return, hence this 2 us kernel
+    if key not in _tick:
+        _tick[key] = torch.zeros(4, device=dev)
+    _tick[key].add_(0.0)
+    side = _side_stream(dev)
+    side.wait_event(fork)
+    pairs, keep = [], []
+    with torch.cuda.stream(side):
+        DeferredParamGrads.flush(select=lambda it: it[2].shape[0] == rows, collect=pairs, keepalive=keep)
+    if pairs:
+        SideResults.pending.append((dev, pairs, keep))
+
+
 def set_async_table_grad(mode):
     """"auto" | "1" | "0" (the VDETR_BWD_ASYNC_TABLE values) from here on; returns the previous mode.  A caller whose own side
     streams already fill the hardware queues (bench.BackboneTrainer: loader stream + sampling kernel) turns it off."""

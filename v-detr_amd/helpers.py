@@ -88,9 +88,12 @@ class DeferredParamGrads:
         return None
 
     @classmethod
-    def flush(cls, select=None):
+    def flush(cls, select=None, collect=None, keepalive=None):
         """``select(item) -> bool``: flush only those parked items now (the others stay parked): gradient buckets of a
-        data-parallel step complete one after the other that way (runtime.flush_weight_grads_phased)."""
+        data-parallel step complete one after the other that way (runtime.flush_weight_grads_phased).
+        ``collect``: a list that receives the (parameter or view, gradient) pairs INSTEAD of their delivery — a caller that
+        computes them on another stream delivers after joining it (attention.SideResults); ``keepalive`` then receives the
+        parked operands, which that stream's launches still read after this call returns."""
         if select is None:
             items, cls.pending = cls.pending, []
         else:
@@ -98,6 +101,8 @@ class DeferredParamGrads:
             cls.pending = [it for it in cls.pending if not select(it)]
         if not items:
             return
+        if keepalive is not None:
+            keepalive.extend(items)
         groups = {}
         for it in items:
             groups.setdefault((tuple(it[2].shape), tuple(it[3].shape)), []).append(it)
@@ -140,11 +145,17 @@ class DeferredParamGrads:
                                 group[i + j][which].shape == p.shape and
                                 group[i + j][which].storage_offset() == base.storage_offset() + j * p.numel() for j in range(k))
                             if tiles:
-                                cls._deliver(base, R[i:i + k].view(base.shape), roots, grads)
+                                if collect is not None:
+                                    collect.append((base, R[i:i + k].view(base.shape)))
+                                else:
+                                    cls._deliver(base, R[i:i + k].view(base.shape), roots, grads)
                                 i += k
                                 continue
                             k = 1
-                        cls._deliver(p, R[i], roots, grads)
+                        if collect is not None:
+                            collect.append((p, R[i]))
+                        else:
+                            cls._deliver(p, R[i], roots, grads)
                         i += 1
         if roots:
             torch.autograd.backward(roots, grads)

@@ -638,6 +638,21 @@ class _DeferredHeads(torch.autograd.Function):
 
 
 
+class _LayersDone(torch.autograd.Function):
+    """identity on the decoder layers' input; its backward runs when the backward of every layer has (all their parked weight
+    gradients exist then) and hands them to the side branch (attention.flush_layer_params_on_side)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.rows = x.shape[0] * x.shape[1]
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        A.flush_layer_params_on_side(g, ctx.rows)
+        return g
+
+
 class TransformerDecoder(nn.Module):
     """FFN stage on all tokens -> top-k proposals -> num_layers x GlobalDecoderLayer with per-stage box heads and
     iterative box refinement (reference :105-452).  Constructor arguments as in the reference."""
@@ -1015,6 +1030,8 @@ class TransformerDecoder(nn.Module):
                                     topk.unsqueeze(-1).expand(-1, -1, output.shape[-1])).permute(1, 0, 2).contiguous()
             output = gathered + self.query_embed.weight.unsqueeze(1) if self.q_content == "random_add" else gathered
 
+        if output.requires_grad and output.is_cuda:
+            output = _LayersDone.apply(output)
         # ---- keys in Morton order for the RPE kernels (memory / enc_xyz feed only the cross attention) -----------
         key_order = None
         if self.sort_keys and memory_mask is None and memory_key_padding_mask is None and pos is None:
