@@ -214,13 +214,13 @@ __device__ __forceinline__ bool rpe_box_pattern(const float (&vx)[8], const floa
     ok = ok && vx[i] == vx[rpe_box_xi(i) ? 2 : 0] && vy[i] == vy[rpe_box_yi(i) ? 1 : 0] && vz[i] == vz[rpe_box_zi(i) ? 4 : 0];
   return ok;
 }
-__device__ __forceinline__ void rpe_pair_bias_box(const AttnParams& P, const f32x4* tab, const float (&X)[2],
-                                                  const float (&Y)[2], const float (&Z)[2], float kx, float ky, float kz,
-                                                  float (&acc)[4]) {
+// the two offsets per axis given directly (dx[a] = x value a of the box minus the key, in the frame the table is looked up in)
+__device__ __forceinline__ void rpe_pair_bias_box_d(const AttnParams& P, const f32x4* tab, const float (&dx)[2],
+                                                    const float (&dy)[2], const float (&dz)[2], float (&acc)[4]) {
   const int T = P.T, TT = T * T, T3 = TT * T;
-  const AxisTap ax[2] = {rpe_axis(X[0] - kx, P), rpe_axis(X[1] - kx, P)};
-  const AxisTap ay[2] = {rpe_axis(Y[0] - ky, P), rpe_axis(Y[1] - ky, P)};
-  const AxisTap az[2] = {rpe_axis(Z[0] - kz, P), rpe_axis(Z[1] - kz, P)};
+  const AxisTap ax[2] = {rpe_axis(dx[0], P), rpe_axis(dx[1], P)};
+  const AxisTap ay[2] = {rpe_axis(dy[0], P), rpe_axis(dy[1], P)};
+  const AxisTap az[2] = {rpe_axis(dz[0], P), rpe_axis(dz[1], P)};
   float w00[2][2], w01[2][2], w10[2][2], w11[2][2];
   int zy[2][2];
 #pragma unroll
@@ -239,7 +239,12 @@ __device__ __forceinline__ void rpe_pair_bias_box(const AttnParams& P, const f32
     const f32x4 c100 = t[TT], c101 = t[TT + 1], c110 = t[TT + T], c111 = t[TT + T + 1];
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 axw = {ax[xi].wa, ax[xi].wb};  // packed fp32: two corner weights per v_pk_mul_f32
-    const f32x2 p0 = axw * w00[zi][yi], p1 = axw * w01[zi][yi], p2 = axw * w10[zi][yi], p3 = axw * w11[zi][yi];
+    // (the four scalar factors pass through an empty asm: the compiler then cannot know that one of them is the HIGH half of a
+    // register pair it built, which is what made it emit the second-source high-broadcast form of v_pk_mul_f32 that the build
+    // check refuses, build.py; as opaque 32-bit registers they are read with op_sel_hi, the low-half broadcast)
+    float s00 = w00[zi][yi], s01 = w01[zi][yi], s10 = w10[zi][yi], s11 = w11[zi][yi];
+    asm volatile("" : "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11));
+    const f32x2 p0 = axw * s00, p1 = axw * s01, p2 = axw * s10, p3 = axw * s11;
     const float w000 = p0[0], w001 = p0[1], w010 = p1[0], w011 = p1[1], w100 = p2[0], w101 = p2[1], w110 = p3[0], w111 = p3[1];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -255,6 +260,34 @@ __device__ __forceinline__ void rpe_pair_bias_box(const AttnParams& P, const f32
       acc[h] = s;
     }
   }
+}
+
+__device__ __forceinline__ void rpe_pair_bias_box(const AttnParams& P, const f32x4* tab, const float (&X)[2],
+                                                  const float (&Y)[2], const float (&Z)[2], float kx, float ky, float kz,
+                                                  float (&acc)[4]) {
+  const float dx[2] = {X[0] - kx, X[1] - kx}, dy[2] = {Y[0] - ky, Y[1] - ky}, dz[2] = {Z[0] - kz, Z[1] - kz};
+  rpe_pair_bias_box_d(P, tab, dx, dy, dz, acc);
+}
+// angle_type "object_coords": in the frame the offsets are turned into (rpe_rotate by the query's angle) the corners of a ROTATED
+// box are an axis-aligned box: R (P_i - P_0) = (xi EX, yi EY, zi EZ) with the edges of vertices 3, 1 and 4 — the test of
+// attn_delta_body (a few ulps of the coordinates: the corners come out of fp32 arithmetic).  The box body then looks up at
+// R (P_0 - X) + (xi EX, yi EY, zi EZ): one rotation per pair instead of eight, 6 axis taps instead of 24.
+__device__ __forceinline__ bool rpe_box_pattern_rot(const float (&vx)[8], const float (&vy)[8], const float (&vz)[8], float rc,
+                                                    float rs, float& EX, float& EY, float& EZ) {
+  float ex[8], ey[8], ez[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    ex[i] = vx[i] - vx[0]; ey[i] = vy[i] - vy[0]; ez[i] = vz[i] - vz[0];
+    rpe_rotate(ex[i], ey[i], rc, rs);
+  }
+  EX = ex[3]; EY = ey[1]; EZ = ez[4];
+  const float tol = 1e-5f * (1.f + fabsf(vx[0]) + fabsf(vy[0]) + fabsf(vz[0]));
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    ok = ok && fabsf(ex[i] - (rpe_box_xi(i) ? EX : 0.f)) <= tol && fabsf(ey[i] - (rpe_box_yi(i) ? EY : 0.f)) <= tol &&
+         fabsf(ez[i] - (rpe_box_zi(i) ? EZ : 0.f)) <= tol;
+  return ok;
 }
 
 // cooperative copy of the [8][T^3][4] table into LDS: all of a thread's loads are issued before its first store (a plain

@@ -84,7 +84,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
   f32x4* tab = reinterpret_cast<f32x4*>(smem);
   float* ppad = smem + table_floats + w * (16 * kPPad);
   // ---- per-lane pair geometry (RPE): query g of the tile; decides which instantiation owns this workgroup ---------
-  float vx[8], vy[8], vz[8], rc = 1.f, rs = 0.f;
+  float vx[8], vy[8], vz[8], rc = 1.f, rs = 0.f, eX = 0.f, eY = 0.f, eZ = 0.f;
   const bool rot = RPE && P.cos_sin != nullptr;
   const int q_pair = min(q0 + g, nQ - 1);
   if (RPE) {
@@ -92,7 +92,8 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
     if (rot) { rc = P.cos_sin[((size_t)b * nQ + q_pair) * 2]; rs = P.cos_sin[((size_t)b * nQ + q_pair) * 2 + 1]; }
-    const bool box = !rot && P.box_path && __all(rpe_box_pattern(vx, vy, vz));  // same for the 8 waves: same 4 queries
+    // same for the 8 waves: same 4 queries.  With the rotation operand: the corners of rotated boxes (attn_common.h)
+    const bool box = P.box_path && (rot ? __all(rpe_box_pattern_rot(vx, vy, vz, rc, rs, eX, eY, eZ)) : __all(rpe_box_pattern(vx, vy, vz)));
     if (box != BOX) return;
   }
   const float bX[2] = {vx[0], vx[2]}, bY[2] = {vy[0], vy[1]}, bZ[2] = {vz[0], vz[4]};
@@ -209,8 +210,19 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
     float sc[4] = {acc[0], acc[1], acc[2], acc[3]};
     // ---- + RPE bias -------------------------------------------------------------------------------
     if (RPE) {
-      if (BOX) rpe_pair_bias_box(P, tab, bX, bY, bZ, ops.kx, ops.ky, ops.kz, sc);
-      else rpe_pair_bias(P, tab, vx, vy, vz, ops.kx, ops.ky, ops.kz, rot, rc, rs, sc);
+      if (BOX) {
+        if (rot) {  // one rotation per pair: R (P_0 - X), then the box's edges along the turned axes
+          float d0x = vx[0] - ops.kx, d0y = vy[0] - ops.ky;
+          const float d0z = vz[0] - ops.kz;
+          rpe_rotate(d0x, d0y, rc, rs);
+          const float dx[2] = {d0x, d0x + eX}, dy[2] = {d0y, d0y + eY}, dz[2] = {d0z, d0z + eZ};
+          rpe_pair_bias_box_d(P, tab, dx, dy, dz, sc);
+        } else {
+          rpe_pair_bias_box(P, tab, bX, bY, bZ, ops.kx, ops.ky, ops.kz, sc);
+        }
+      } else {
+        rpe_pair_bias(P, tab, vx, vy, vz, ops.kx, ops.ky, ops.kz, rot, rc, rs, sc);
+      }
     }
     // ---- mask, tail ------------------------------------------------------------------------------
 #pragma unroll
@@ -369,7 +381,14 @@ __global__ __launch_bounds__(kFwdThreads) void attn_fwd_rpe_auto_kernel(AttnPara
   float vx[8], vy[8], vz[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
-  const bool box = P.cos_sin == nullptr && P.box_path && __all(rpe_box_pattern(vx, vy, vz));
+  bool box;
+  if (P.cos_sin == nullptr) {
+    box = P.box_path && __all(rpe_box_pattern(vx, vy, vz));
+  } else {  // rotated boxes (the body repeats the test and keeps the edges)
+    const float rc = P.cos_sin[((size_t)blockIdx.z * P.nQ + q_pair) * 2], rs = P.cos_sin[((size_t)blockIdx.z * P.nQ + q_pair) * 2 + 1];
+    float ex, ey, ez;
+    box = P.box_path && __all(rpe_box_pattern_rot(vx, vy, vz, rc, rs, ex, ey, ez));
+  }
   if (box) attn_fwd_body<false, true, true, BF16>(P);
   else attn_fwd_body<false, true, false, BF16>(P);
 }
@@ -562,7 +581,8 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
     dim3 grid((d->nQ + 3) / 4, ks, d->B);
     if (rpe) {
       static const int box_env = [] { const char* v = getenv("VDETR_FWD_BOX"); return v ? atoi(v) : 1; }();
-      P.box_path = box_env && !d->cos_sin;  // rotated boxes never take it: skip the launch
+      static const int box_rot = [] { const char* v = getenv("VDETR_FWD_BOX_ROT"); return v ? atoi(v) : 1; }();
+      P.box_path = box_env && (!d->cos_sin || box_rot);  // (VDETR_FWD_BOX_ROT=0: rotated boxes take the general body)
       static const int auto_env = [] { const char* v = getenv("VDETR_FWD_AUTO"); return v ? atoi(v) : 1; }();
       if (P.box_path && auto_env) {  // one launch, the box / general body chosen per workgroup on the device
         if (int e = set_lds(attn_fwd_rpe_auto_kernel<false>, lds, "attn_fwd")) return e;
@@ -622,7 +642,8 @@ extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, cons
   dim3 grid((d->nQ + 3) / 4, ks, d->B);
   if (rpe) {
     static const int box_env = [] { const char* e = getenv("VDETR_FWD_BOX"); return e ? atoi(e) : 1; }();
-    P.box_path = box_env && !d->cos_sin;
+    static const int box_rot = [] { const char* v = getenv("VDETR_FWD_BOX_ROT"); return v ? atoi(v) : 1; }();
+    P.box_path = box_env && (!d->cos_sin || box_rot);
     // (the merged kernel of the fp32 path spills 11 registers when built for bf16 operands: opt-in only)
     static const int auto_env = [] { const char* e = getenv("VDETR_FWD_AUTO"); return e ? atoi(e) : 0; }();
     if (P.box_path && auto_env == 2) {
