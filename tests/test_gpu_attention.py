@@ -114,19 +114,23 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
             assert_close(o, r.detach().numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
-@pytest.mark.parametrize("boxes", [True, False, "rotated"])
+@pytest.mark.parametrize("boxes", [True, False, "rotated", "rotated_boxes"])
 def test_full_size_forward_backward_vs_oracle(boxes):
     """The launch bench.py times (B=1, nQ=1024, nK=4096, H=4: BASELINE config 2's layer size) against the fp64 oracle:
     out, dq, dk, dv and the RPE-table gradient within 1e-3 relative.  boxes=True: axis-aligned box vertices, i.e.
     the box kernel (attn_bwd_box4.hip) with its dynamic query distribution and every wave of every workgroup busy; boxes=False: a few
     perturbed vertices send the same launch down the general kernel; "rotated": the (cos, sin) operand of angle_type
-    "object_coords" (vdetr_transformer.py:712-720, BASELINE config 5) at the full size.  The oracle is evaluated in chunks of 32 queries
+    "object_coords" (vdetr_transformer.py:712-720, BASELINE config 5) at the full size on arbitrary vertices (general kernels);
+    "rotated_boxes": the same operand with the corners of rotated boxes (forward: one rotation per pair + the box body,
+    backward: attn_bwd_box4.hip).  The oracle is evaluated in chunks of 32 queries
     (softmax rows are independent; dk, dv and dtable are sums over the chunks)."""
     from oracle.attention_oracle import fused_attention_reference
     from vdetr_amd import attention as A
     B, nQ, nK, H = 1, 1024, 4096, 4
     g = torch.Generator().manual_seed(21)
     xyz, verts, tables, cs = _scene(B, nQ, nK, 5, boxes == "rotated")  # "rotated": BASELINE config 5's operand (object_coords)
+    if boxes == "rotated_boxes":  # corners of ROTATED boxes, as box_decode writes them: the box bodies of forward and backward
+        xyz, verts, tables, cs = _rotated_boxes(B, nQ, nK, 5)
     if not boxes:
         verts[:, ::97] += 0.05 * torch.randn(verts[:, ::97].shape, generator=g)
     q, k, v = (torch.randn(s, generator=g) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
