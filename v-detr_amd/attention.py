@@ -98,8 +98,12 @@ class SideResults:
     def flush(cls):
         from .helpers import DeferredParamGrads
         items, cls.pending = cls.pending, []
+        late, side_late[:] = list(side_late), []
+        for fn, alive in late:  # handed over for the end of the backward, but nobody ran them there: here, on this stream
+            with torch.no_grad():
+                items.append((None, fn(), alive))
         for dev, pairs, _alive in items:
-            side = _side_streams.get(_dev_key(dev))
+            side = _side_streams.get(_dev_key(dev)) if dev is not None else None
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)
             roots, grads = [], []
@@ -113,6 +117,7 @@ class SideResults:
 
 _FLUSH_SIDE = os.environ.get("VDETR_FLUSH_SIDE", "1") != "0"
 _tick = {}
+side_late = []  # parameter-only work other modules hand over for the END of the backward: callables -> [(parameter, gradient)], keep-alive
 
 
 def flush_layer_params_on_side(ref, rows):
@@ -136,8 +141,12 @@ def flush_layer_params_on_side(ref, rows):
     side = _side_stream(dev)
     side.wait_event(fork)
     pairs, keep = [], []
+    late, side_late[:] = list(side_late), []
     with torch.cuda.stream(side):
         DeferredParamGrads.flush(select=lambda it: it[2].shape[0] == rows, collect=pairs, keepalive=keep)
+        for fn, alive in late:  # (e.g. the box heads' weight gradients: vdetr_transformer._DeferredHeads)
+            pairs += fn()
+            keep.append(alive)
     if pairs:
         SideResults.pending.append((dev, pairs, keep))
 

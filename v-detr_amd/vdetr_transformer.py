@@ -518,9 +518,12 @@ class FFNLayer(nn.Module):
 # decoder
 # =====================================================================================================
 _DEFER_HEADS = os.environ.get("VDETR_DEFER_HEADS", "1") != "0"  # A/B switch (read once)
-# the heads' weight gradients on the side branch: OFF - measured C2 8.376 -> 8.33 ms, but C5 (4 scenes: the GEMMs are 4 x larger and
-# hold the table kernels up) 26.15 -> 26.61 ms
-_HEADS_SIDE = os.environ.get("VDETR_HEADS_SIDE", "0") != "0"
+# the heads' weight gradients on the side branch (VDETR_HEADS_SIDE): 1 = at once, at the BEGINNING of the backward, where the branch
+# is idle - measured C2 8.376 -> 8.33 ms, but C5 (4 scenes: the GEMMs are 4 x larger and hold the first table kernels up) 26.15 ->
+# 26.61 ms; 2 (default) = at the END of the backward with the layers' weight gradients (attention.flush_layer_params_on_side):
+# C2 8.33 -> 8.26 ms (two runs each), C5 25.01 -> 24.80; 0 = on the main stream inside the heads' backward
+_HEADS_SIDE = os.environ.get("VDETR_HEADS_SIDE", "2") != "0"
+_HEADS_SIDE_LATE = os.environ.get("VDETR_HEADS_SIDE", "2") == "2"
 
 
 class _DeferredHeads(torch.autograd.Function):
@@ -619,15 +622,21 @@ class _DeferredHeads(torch.autograd.Function):
             df = torch.matmul(w1.transpose(1, 2).unsqueeze(1), dx1)                                # [S,B,C,N]
             out = [df[s].permute(2, 0, 1) for s in range(S)]                                       # as [nQ,B,C]
         if on_side:
+            def pairs_of(db3, dw3, dw2, dw1):
+                pairs = []
+                for s, r in enumerate(recs):
+                    pairs += [(r["w1"], dw1[s].reshape(r["w1"].shape)), (r["w2"], dw2[s].reshape(r["w2"].shape)),
+                              (r["w3"], dw3[s].reshape(r["w3"].shape)), (r["b3"], db3[s].reshape(r["b3"].shape))]
+                return pairs
+            for s in range(S):
+                out += [None, dbn1[s][1], dbn1[s][2], None, dbn2[s][1], dbn2[s][2], None, None]
+            if _HEADS_SIDE_LATE:  # at the END of the backward, behind the last table kernel (attention.flush_layer_params_on_side)
+                A.side_late.append((lambda: pairs_of(*weight_grads(dx2, dx1)), (dY, h2, h1, f, dx2, dx1)))
+                return (None, None, *out)
             side = A._side_stream(dev)
             side.wait_event(fork)
             with torch.cuda.stream(side):
-                db3, dw3, dw2, dw1 = weight_grads(dx2, dx1)
-            pairs = []
-            for s, r in enumerate(recs):
-                pairs += [(r["w1"], dw1[s].reshape(r["w1"].shape)), (r["w2"], dw2[s].reshape(r["w2"].shape)),
-                          (r["w3"], dw3[s].reshape(r["w3"].shape)), (r["b3"], db3[s].reshape(r["b3"].shape))]
-                out += [None, dbn1[s][1], dbn1[s][2], None, dbn2[s][1], dbn2[s][2], None, None]
+                pairs = pairs_of(*weight_grads(dx2, dx1))
             A.SideResults.pending.append((dev, pairs, (dY, h2, h1, f, dx2, dx1)))
             return (None, None, *out)
         db3, dw3, dw2, dw1 = weight_grads(dx2, dx1)
