@@ -612,7 +612,7 @@ class _DeferredHeads(torch.autograd.Function):
         dx1 = torch.empty_like(dh1)
         dbn1 = BNA.backward_from_records([r["bn1"] for r in recs], [dh1[s] for s in range(S)], [dx1[s] for s in range(S)])
         fork = None
-        if on_side:  # (recorded here, waited for behind the chain's next launch: the captured graph keeps the chain's queue)
+        if on_side and not _HEADS_SIDE_LATE:  # (recorded here, waited for behind the chain's next launch: the chain keeps its queue)
             fork = torch.cuda.Event()
             fork.record(torch.cuda.current_stream(dev))
         if one:  # the transposed product: rows = queries, i.e. the [nQ,B,C] layout the layers want (no permuted view to copy)
