@@ -378,6 +378,9 @@ ACTIVATION_DICT = {"relu": nn.ReLU, "gelu": nn.GELU, "leakyrelu": partial(nn.Lea
 WEIGHT_INIT_DICT = {"xavier_uniform": nn.init.xavier_uniform_}
 
 
+_POS_TOKEN_MAJOR = os.environ.get("VDETR_POS_TOKEN_MAJOR", "1") != "0"  # A/B switch (read once), _PosEmbedDeferred.forward
+
+
 class DeferredPosEmbedGrads:
     """The learned query-position embeddings (Conv1d -> BatchNorm -> ReLU -> Conv1d on DETACHED box coordinates, one per decoder
     layer) exist only to train their own parameters: nothing upstream waits for their backward.  With
@@ -431,6 +434,12 @@ class _PosEmbedDeferred(torch.autograd.Function):
         y, rec = BNA.forward_record(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, 0.0, 0,
                                     counters=[bn.num_batches_tracked], pre_bias=conv1.bias)
         ctx.rec = (module, x, y, rec)
+        if _POS_TOKEN_MAJOR and y.shape[0] == 1 and conv2.bias is not None:
+            # one scene: the output layer as out^T [N, C] = y^T W^T + b — ONE launch (the bias rides in the GEMM's epilogue; the
+            # channel-major form is a GEMM + a broadcast add), and the [N, B, C] view the decoder adds to its queries twice per
+            # layer is then dense memory (the channel-major result reached those adds as a transposed view)
+            out_t = torch.addmm(conv2.bias, y[0].t(), conv2.weight.squeeze(-1).t())
+            return out_t.t().unsqueeze(0)
         return conv2(y)
 
     @staticmethod
