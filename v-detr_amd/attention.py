@@ -116,6 +116,7 @@ class SideResults:
 
 
 _FLUSH_SIDE = os.environ.get("VDETR_FLUSH_SIDE", "1") != "0"
+_FLUSH_SIDE_POS = os.environ.get("VDETR_FLUSH_SIDE_POS", "1") != "0"
 _tick = {}
 side_late = []  # parameter-only work other modules hand over for the END of the backward: callables -> [(parameter, gradient)], keep-alive
 
@@ -125,7 +126,7 @@ def flush_layer_params_on_side(ref, rows):
     weight / bias gradients of the layers' linear maps (the items with `rows` rows: 64 of them at the model's size) are computed
     on the side branch — behind the last table kernel — while the main stream goes on with the first layer's and the
     projection's backward; runtime.flush_weight_grads joins and delivers (SideResults).  Only where that branch is in use."""
-    from .helpers import DeferredParamGrads
+    from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
     if not (_FLUSH_SIDE and ref.is_cuda and DeferredParamGrads.enabled and DeferredParamGrads.direct and side_branch_in_use(ref.device)):
         return
     dev = ref.device
@@ -144,6 +145,8 @@ def flush_layer_params_on_side(ref, rows):
     late, side_late[:] = list(side_late), []
     with torch.cuda.stream(side):
         DeferredParamGrads.flush(select=lambda it: it[2].shape[0] == rows, collect=pairs, keepalive=keep)
+        if _FLUSH_SIDE_POS:  # the layers' learned query-position embeddings: complete as well (one per layer)
+            DeferredPosEmbedGrads.flush(collect=pairs, keepalive=keep)
         for fn, alive in late:  # (e.g. the box heads' weight gradients: vdetr_transformer._DeferredHeads)
             pairs += fn()
             keep.append(alive)

@@ -390,10 +390,14 @@ class DeferredPosEmbedGrads:
     pending = []
 
     @classmethod
-    def flush(cls):
+    def flush(cls, collect=None, keepalive=None):
+        """``collect`` / ``keepalive``: as DeferredParamGrads.flush (the launches may then run on another stream: the caller
+        delivers the pairs after joining it)."""
         items, cls.pending = cls.pending, []
         if not items:
             return
+        if keepalive is not None:
+            keepalive.extend(items)
         from . import bn_act as BNA
         groups = {}
         for it in items:
@@ -420,7 +424,10 @@ class DeferredPosEmbedGrads:
                     for p, g in ((head[3].weight, dW2[i].unsqueeze(-1)), (head[3].bias, dB2[i]), (head[1].weight, res[i][1]),
                                  (head[1].bias, res[i][2]), (head[0].weight, dW1[i].unsqueeze(-1))):
                         if p is not None and p.requires_grad:
-                            DeferredParamGrads._deliver(p, g, roots, grads)
+                            if collect is not None:
+                                collect.append((p, g))
+                            else:
+                                DeferredParamGrads._deliver(p, g, roots, grads)
         if roots:
             torch.autograd.backward(roots, grads)
 
