@@ -52,10 +52,13 @@ class DeferredLnGrads:
     pending = []
 
     @classmethod
-    def flush(cls):
+    def flush(cls, collect=None, keepalive=None):
+        """``collect`` / ``keepalive``: as DeferredParamGrads.flush (another stream's launches; the caller delivers after the join)"""
         items, cls.pending = cls.pending, []
         if not items:
             return
+        if keepalive is not None:
+            keepalive.extend(items)
         # passes that share their first LayerNorm (the decoder's output norm closes all 9 stages) next to each other: their
         # sums are then added by ONE reduction over a slice of `out` instead of one accumulation launch per pass and parameter
         items.sort(key=lambda it: id(it[3][0]))
@@ -79,15 +82,21 @@ class DeferredLnGrads:
                 while j < n and items[j][3][0] is params[0] and items[j][3][1] is params[1] and items[j][2] == C:
                     j += 1
                 first = out[0:2, i:j].sum(1) if j - i > 1 else out[0:2, i]  # [2, cmax]: d_gamma, d_beta of the shared norm
+
+                def give(p, g):
+                    if collect is not None:
+                        collect.append((p, g))
+                    else:
+                        DeferredParamGrads._deliver(p, g, roots, grads)
                 for k in range(2):
                     if params[k] is not None and params[k].requires_grad:
-                        DeferredParamGrads._deliver(params[k], first[k, :C], roots, grads)
+                        give(params[k], first[k, :C])
                 for m in range(i, j):
                     if items[m][4]:
                         for k in (2, 3):
                             p = items[m][3][k]
                             if p is not None and p.requires_grad:
-                                DeferredParamGrads._deliver(p, out[k, m, :C], roots, grads)
+                                give(p, out[k, m, :C])
                 i = j
         if roots:
             torch.autograd.backward(roots, grads)

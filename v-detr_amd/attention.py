@@ -117,6 +117,7 @@ class SideResults:
 
 _FLUSH_SIDE = os.environ.get("VDETR_FLUSH_SIDE", "1") != "0"
 _FLUSH_SIDE_POS = os.environ.get("VDETR_FLUSH_SIDE_POS", "1") != "0"
+_FLUSH_SIDE_LN = os.environ.get("VDETR_FLUSH_SIDE_LN", "1") != "0"
 _tick = {}
 side_late = []  # parameter-only work other modules hand over for the END of the backward: callables -> [(parameter, gradient)], keep-alive
 
@@ -147,6 +148,9 @@ def flush_layer_params_on_side(ref, rows):
         DeferredParamGrads.flush(select=lambda it: it[2].shape[0] == rows, collect=pairs, keepalive=keep)
         if _FLUSH_SIDE_POS:  # the layers' learned query-position embeddings: complete as well (one per layer)
             DeferredPosEmbedGrads.flush(collect=pairs, keepalive=keep)
+        if _FLUSH_SIDE_LN:   # the LayerNorm parameter sums of the layers' residual blocks (the first layer's follow at the flush)
+            from .add_ln import DeferredLnGrads
+            DeferredLnGrads.flush(collect=pairs, keepalive=keep)
         for fn, alive in late:  # (e.g. the box heads' weight gradients: vdetr_transformer._DeferredHeads)
             pairs += fn()
             keep.append(alive)
