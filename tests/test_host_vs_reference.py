@@ -193,3 +193,32 @@ def test_parked_table_gradients_reach_the_mlps_at_the_flush():
         assert not A._async_wanted(4, 1024, 4096) and not A.ASYNC_TABLE_GRAD
     finally:
         A.set_async_table_grad(prev)
+
+
+def test_parked_weight_gradients_can_be_collected_instead_of_delivered():
+    """helpers.DeferredParamGrads.flush(collect=, keepalive=, select=): what the side branch uses (attention.
+    flush_layer_params_on_side) — the (parameter, gradient) pairs of the selected items come back instead of being written, the
+    operands are handed to the caller to keep alive, the other items stay parked, and delivering the pairs afterwards
+    (attention.SideResults) gives the gradients of a plain flush."""
+    from vdetr_amd import attention as A
+    from vdetr_amd.helpers import DeferredParamGrads as D
+    torch.manual_seed(1)
+    ws = [torch.randn(6, 4, requires_grad=True) for _ in range(3)] + [torch.randn(5, 4, requires_grad=True)]
+    bs = [torch.randn(6, requires_grad=True) for _ in range(3)] + [torch.randn(5, requires_grad=True)]
+    gs = [torch.randn(10, 6) for _ in range(3)] + [torch.randn(7, 5)]
+    xs = [torch.randn(10, 4) for _ in range(3)] + [torch.randn(7, 4)]
+    ref_w = [g.t() @ x for g, x in zip(gs, xs)]
+    ref_b = [g.sum(0) for g in gs]
+    assert not D.pending
+    D.pending.extend((w, b, g, x) for w, b, g, x in zip(ws, bs, gs, xs))
+    pairs, keep = [], []
+    D.flush(select=lambda it: it[2].shape[0] == 10, collect=pairs, keepalive=keep)
+    assert len(D.pending) == 1 and D.pending[0][2].shape[0] == 7, "the 7-row item stays parked"
+    assert len(keep) == 3 and all(w.grad is None for w in ws), "nothing delivered yet"
+    assert len(pairs) == 6
+    A.SideResults.pending.append((torch.device("cpu"), pairs, keep))
+    A.SideResults.flush()
+    D.flush()
+    assert not D.pending and not A.SideResults.pending
+    for w, b, rw, rb in zip(ws, bs, ref_w, ref_b):
+        assert torch.allclose(w.grad, rw, rtol=1e-5, atol=1e-5) and torch.allclose(b.grad, rb, rtol=1e-5, atol=1e-5)
