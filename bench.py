@@ -645,11 +645,11 @@ def kernel_rooflines(cfg_name, device, reps=20):
     # the launch as the step issues it: on the side stream the table gradient takes ASYNC_TABLE_GRID of the 256 CUs
     side = A._async_wanted(B, nQ, nK) and 2 <= A.ASYNC_TABLE_GRID < 256
     if side:
-        L.check(lib.vdetr_attn_bwd_table_set_grid(A.ASYNC_TABLE_GRID), "attn_bwd_table_set_grid")
+        d.table_grid = A.side_table_grid(device)
     try:
         t_bwd = timeit(bwd, bwd_prep)
     finally:
-        lib.vdetr_attn_bwd_table_set_grid(0)
+        d.table_grid = 0
     # (VDETR_ROOFLINE_STEP_GRID_ONLY=1: only the launch the step issues — so that a rocprofv3 run of tools/kernel_bench.py averages
     # ONE configuration of the kernel, the one `launch_us` reports)
     t_bwd_full = timeit(bwd, bwd_prep) if side and os.environ.get("VDETR_ROOFLINE_STEP_GRID_ONLY") != "1" else t_bwd

@@ -37,8 +37,10 @@ extern "C" {
 typedef void* vdetr_stream_t; /* hipStream_t */
 
 /* library / diagnostics */
-int vdetr_abi_version(void); /* 2: vdetr_bnact_desc / vdetr_bnact_grads grew; attention bwd_aux is 8 words */
+int vdetr_abi_version(void); /* 3: vdetr_attn_desc carries the launch shape (table_grid, kv_waves, fwd_kernel, fwd_sched); the
+                                process-wide setters vdetr_attn_bwd_table_set_grid / vdetr_attn_bwd_kv_set_waves are gone */
 const char* vdetr_last_error(void);
+int vdetr_ab_switches(void); /* 1: a probe build that reads VDETR_* environment switches (once per process); 0: the shipped build, which reads none */
 
 /* ------------------------------------------------------------------------------------------------
  * (iii) pointnet2 ops.  One symbol per function of bindings.cpp:9-22.
@@ -156,6 +158,24 @@ typedef struct vdetr_attn_desc {
          scale from the Cauchy-Schwarz bound and, when word 4 is 0 and word 5 is set (and there is no rotation operand), runs the
          axis-aligned-box kernel (attn_bwd_box.hip) instead of the general one.  NULL: static distribution. --- */
   uint32_t* bwd_aux;
+  /* --- launch shape (ABI 3).  0 = the library's default in every field.  Per call and re-entrant: these fields replace the
+         process-wide setters of ABI 2 (vdetr_attn_bwd_table_set_grid, vdetr_attn_bwd_kv_set_waves). --- */
+  int32_t table_grid; /* workgroups of the table-gradient launches (vdetr_attn_bwd_table_f32 / _scores_f32 with a table): 0 = one
+                         per CU; an even count in 2..CUs otherwise.  The persistent workgroups take every register and ~150 KB
+                         of LDS of their CU, so a caller that runs the table gradient on a side stream (it feeds parameters only)
+                         lowers the count to leave WHOLE CUs to the kernels of its main chain.  The fixed-point scale of the
+                         histogram follows the queries per workgroup: results are reproducible per count; counts whose
+                         resolution would fall below 1e-3 of the largest entry are refused (VDETR_ERR_ARG). */
+  int32_t kv_waves;   /* workgroup shape of vdetr_attn_bwd_kv_f32: 0 or 8 = 8 waves (the kernel alone on the chip), 4 = one wave
+                         per SIMD with <= 256 registers (fits next to a table-gradient kernel on another stream); either shape
+                         computes the same values */
+  int32_t fwd_kernel; /* forward of the RPE kind: 0 = persistent workgroups (attn_fwd_pipe.hip), 1 = one workgroup per
+                         (query quad, key chunk) (attn_fwd.hip; the round-4 kernel, kept for A/B runs and parity tests) */
+  int32_t bwd_kernel; /* table gradient: 0 = the axis-aligned-box kernel where every query's vertices are a box (attn_bwd_box4.hip;
+                         decided on the device), 1 = the general kernel only (parity tests compare the two) */
+  uint32_t* fwd_sched; /* persistent forward: ONE zero device word (the item counter), left zero by the call; a word must not be
+                          shared by launches that may run concurrently.  NULL: the library clears a word at the head of
+                          `workspace` with a memset node in front of the launch. */
 } vdetr_attn_desc;
 
 /* Scratch needed by fwd (key-split partials). */
@@ -219,18 +239,6 @@ int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float* q, const 
  * Measured at the model's size (alone): per head 4 x 1024 x 1024 11.7 us (library 19.2), shared K/V 4096 x 4096 31 us (library
  * 26); the host module keeps the library by default (attention.py: VDETR_BWD_DQ). */
 int vdetr_attn_bwd_dq_f32(const vdetr_attn_desc* d, const float* ds, const float* k, float* dq, vdetr_stream_t stream);
-/* Workgroup shape of vdetr_attn_bwd_kv_f32: 8 waves (default, the kernel alone on the chip) or 4 (one wave per SIMD with
- * <= 256 registers: fits next to the table-gradient kernel when the caller runs that on another stream).  PROCESS-WIDE state,
- * read at launch: a tuning switch for single-threaded callers (threads or devices that set different shapes race on it; either
- * shape computes the same values). */
-int vdetr_attn_bwd_kv_set_waves(int waves);
-/* Workgroups of the table-gradient launches (vdetr_attn_bwd_table_f32 / vdetr_attn_bwd_scores_f32 with a table): 0 = the
- * default, one per CU (256); an even count in 2..256 otherwise.  The persistent workgroups take every register and ~150 KB
- * of LDS of their CU, so a caller that runs the table gradient on a side stream (it feeds parameters only) lowers the count
- * to leave WHOLE CUs to the kernels of the main chain.  PROCESS-WIDE state read at launch, like the switch above; the
- * fixed-point scale of the histogram follows the queries per workgroup, so results are reproducible per count, and equal
- * across counts to the rounding of that scale. */
-int vdetr_attn_bwd_table_set_grid(int workgroups);
 /* The RPE table gradient alone, from the dS that vdetr_attn_bwd_kv_f32 wrote (same kernels, workspace and bwd_aux contract
  * as vdetr_attn_bwd_scores_f32 with a dtable; d->bwd_aux is required).  dtable [8,T,T,T,4]: caller zero-fills. */
 int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* ds, float* dtable, void* workspace,

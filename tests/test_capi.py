@@ -25,13 +25,14 @@ def test_library_exports_every_symbol():
     handle = _lib.lib()
     for sym in header_symbols():
         assert hasattr(handle, sym), sym
-    assert handle.vdetr_abi_version() == 2
+    assert handle.vdetr_abi_version() == 3
 
 
 def test_descriptor_layout():
     from vdetr_amd import _lib
-    # 6x4 | ptr | 3x4 + pad | 3 ptr | ptr | 2x4 | 2x8 | ptr
-    assert ctypes.sizeof(_lib.AttnDesc) == 128
+    # 6x4 | ptr | 3x4 + pad | 3 ptr | ptr | 2x4 | 2x8 | ptr | 2x4 | ptr | 4x4 | ptr   (ABI 3: the launch-shape fields)
+    assert ctypes.sizeof(_lib.AttnDesc) == 152
+    assert _lib.AttnDesc.table_grid.offset == 128 and _lib.AttnDesc.fwd_sched.offset == 144
     assert _lib.AttnDesc.table.offset == 24 and _lib.AttnDesc.vertices.offset == 48
     assert _lib.AttnDesc.seed.offset == 88 and _lib.AttnDesc.rng_state.offset == 104
 
@@ -85,8 +86,7 @@ def test_round3_attention_backward_entry_points_reject_bad_arguments():
     d.kind, d.H = _lib.VDETR_ATTN_SHARED_KV, 4
     assert lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), None, None, None, 0, None) == 1   # no dS, no table, no bwd_aux
     assert b"attn_bwd_table" in lib.vdetr_last_error()
-    assert lib.vdetr_attn_bwd_kv_set_waves(5) == 1 and b"set_waves" in lib.vdetr_last_error()
-    assert lib.vdetr_attn_bwd_kv_set_waves(4) == 0 and lib.vdetr_attn_bwd_kv_set_waves(8) == 0
+    assert lib.vdetr_ab_switches() == 0  # the shipped build reads no environment switch
 
 
 def test_ops_refuse_cpu_tensors():

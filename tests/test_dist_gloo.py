@@ -552,10 +552,16 @@ def test_watched_buckets_leave_during_the_backward_pass():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, out, _, bb_b in res:
-        for during, pend, _ in out:
-            assert len(during) >= 2 and set(during) <= set(bb_b), (during, bb_b)   # sent while backward() was still running
+        for step, (during, pend, _) in enumerate(out):
+            assert set(during) <= set(bb_b), (during, bb_b)
             assert during == sorted(during)                                         # back to front = ascending bucket index
-            assert len(pend) >= 1 and not set(pend) & set(during)                   # the bucket of the unused parameter
+            assert len(pend) >= 1 and not set(pend) & set(during)                   # the bucket of the unused parameter (+ held back)
+        # step 0: the bucket of the unused parameter holds back what lies behind it in the fixed (ascending) issue order — every
+        # rank issues the same sequence whatever order its autograd ran in; the ranks then agree that it never completes, and
+        # from step 1 on the others leave while backward() is still running
+        during1, pend1, _ = out[1]
+        assert len(during1) >= 2, (during1, bb_b)
+        assert len(pend1) <= len(out[0][1])
     for (off, g0), (_, g1) in zip(res[0][2], res[1][2]):
         avg = ((g0 + g1) / 2).reshape(-1)
         for rank, out, _, _ in res:

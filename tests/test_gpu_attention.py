@@ -221,9 +221,8 @@ def test_fused_key_side_backward_equals_gemm_path(monkeypatch, case):
         assert torch.equal(o, o2), f"{case} {name}: not reproducible"
 
 
-@pytest.mark.parametrize("variant,fused", [("1", False), ("2", False), ("2", True), ("3", False), ("3", True), ("4", True), ("5", True)])
-def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
-    """The axis-aligned-box backward kernel (attn_bwd_box.hip) against the general one on the same launch, at a size
+def test_box_backward_kernel_equals_general_kernel(monkeypatch, fused=True):
+    """The axis-aligned-box backward kernel (attn_bwd_box4.hip) against the general one on the same launch, at a size
     where every wave of every workgroup is busy (the size at which a packed-math code-generation problem once showed):
     P~ and dS bit-identical (same element-wise code), table gradient within the fixed-point resolution, three times.
     fused: the kernels read the dS that attn_bwd_kv.hip wrote instead of forming it (dq, dk, dv are then that pass's)."""
@@ -242,10 +241,9 @@ def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
         (A.fused_attention(*args, table=tb, **kw) * wout).sum().backward()
         return [a.grad for a in args] + [tb.grad]
 
-    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    monkeypatch.setattr(A, "BWD_KERNEL", 1)  # vdetr_attn_desc.bwd_kernel: the general kernel alone
     ref = run()
-    # 1: attn_bwd_box.hip, 2: attn_bwd_box2.hip, 3: the same with fp32 products, 4: attn_bwd_box3.hip (workgroup-wide sort; dS given)
-    monkeypatch.setenv("VDETR_BWD_BOX", variant)
+    monkeypatch.setattr(A, "BWD_KERNEL", 0)
     for rep in range(3):
         got = run()
         for name, r, o in zip(("dq", "dk", "dv"), ref, got):
@@ -254,11 +252,9 @@ def test_box_backward_kernel_equals_general_kernel(monkeypatch, variant, fused):
         assert float((got[3] - ref[3]).abs().max()) <= 3e-4 * scale, f"dtable rep {rep}"
 
 
-@pytest.mark.parametrize("variant", ["4", "5"])
 @pytest.mark.parametrize("B,nQ,nK", [(1, 8, 64), (1, 5, 3), (2, 33, 700), (1, 300, 1024), (1, 70, 1500), (3, 40, 2049), (1, 520, 4096)])
-def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK, variant):
-    """attn_bwd_box3.hip (variant 4: 1024-key tiles sorted by cell signature across the workgroup) and attn_bwd_box4.hip (5: 64-key
-    chunks sorted inside a wave) at sizes that leave tiles, waves and
+def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK):
+    """attn_bwd_box4.hip (64-key chunks sorted inside a wave) at sizes that leave chunks, waves and
     quads partly filled — fewer keys than a wave, a ragged last tile, one key in the last tile, several scenes, more queries
     than two rounds of the grid — against the general kernel on the same dS: table gradient within the fixed-point resolution,
     and bit-identical run to run (integer sums)."""
@@ -276,9 +272,9 @@ def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK, variant):
         (A.fused_attention(*args, table=tb, **kw) * wout).sum().backward()
         return tb.grad
 
-    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    monkeypatch.setattr(A, "BWD_KERNEL", 1)
     ref = run()
-    monkeypatch.setenv("VDETR_BWD_BOX", variant)
+    monkeypatch.setattr(A, "BWD_KERNEL", 0)
     got, again = run(), run()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 3e-4 * scale, "dtable"
@@ -288,7 +284,7 @@ def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK, variant):
 
 @pytest.mark.parametrize("grid,tol", [(192, 3e-4), (64, 3e-4), (16, 1e-3)])
 def test_table_gradient_on_fewer_workgroups(monkeypatch, grid, tol):
-    """vdetr_attn_bwd_table_set_grid: the table-gradient launches on fewer (persistent) workgroups than CUs — what a caller
+    """vdetr_attn_desc.table_grid: the table-gradient launches on fewer (persistent) workgroups than CUs — what a caller
     does who runs them on a side stream next to the main chain — give the default grid's gradient to the rounding of the
     histogram's fixed-point scale (which follows the queries per workgroup: measured 0 / 1.5e-4 / 3.5e-4 / 2.4e-3 of the largest
     entry at 192 / 64 / 16 / 2 workgroups), are reproducible per count, and the default comes back with 0."""
@@ -308,20 +304,23 @@ def test_table_gradient_on_fewer_workgroups(monkeypatch, grid, tol):
         (A.fused_attention(*args, table=tb, **kw) * wout).sum().backward()
         return tb.grad, args[0].grad
 
+    monkeypatch.setattr(A, "ASYNC_TABLE_GRAD", False)  # in line: the launch then takes A.TABLE_GRID
     ref, dq_ref = run()
-    try:
-        L.check(L.lib().vdetr_attn_bwd_table_set_grid(grid), "set_grid")
-        got, dq = run()
-        again, _ = run()
-    finally:
-        L.check(L.lib().vdetr_attn_bwd_table_set_grid(0), "set_grid")
+    monkeypatch.setattr(A, "TABLE_GRID", grid)
+    got, dq = run()
+    again, _ = run()
+    monkeypatch.setattr(A, "TABLE_GRID", 0)
     back, _ = run()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= tol * scale and float((got - ref).norm() / ref.norm()) < 1e-3
     assert torch.equal(got, again), "not reproducible"
     assert torch.equal(dq, dq_ref), "the other gradients do not depend on the grid"
     assert torch.equal(back, ref), "default grid not restored"
-    assert L.lib().vdetr_attn_bwd_table_set_grid(3) != 0 and L.lib().vdetr_attn_bwd_table_set_grid(258) != 0
+    for bad in (3, 258):  # odd, more than the CUs: refused per call
+        monkeypatch.setattr(A, "TABLE_GRID", bad)
+        with pytest.raises(RuntimeError, match="table_grid"):
+            run()
+    monkeypatch.setattr(A, "TABLE_GRID", 0)
 
 
 @pytest.mark.parametrize("kind,B,nQ,nK,kstride", [("shared", 1, 1024, 4096, 1024), ("shared", 2, 33, 700, 64), ("shared", 1, 5, 3, 64),
@@ -388,9 +387,9 @@ def test_rotated_boxes_take_the_box_backward_kernel(monkeypatch, B, nQ, nK):
         (out * wout.to(DEV)).sum().backward()
         return out.detach(), tb.grad
 
-    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    monkeypatch.setattr(A, "BWD_KERNEL", 1)
     _, gen = run(verts)
-    monkeypatch.setenv("VDETR_BWD_BOX", "5")
+    monkeypatch.setattr(A, "BWD_KERNEL", 0)
     out, box = run(verts)
     _, again = run(verts)
     rq, rk, rv = (x.double().requires_grad_(True) for x in (q, k, v))
@@ -405,9 +404,9 @@ def test_rotated_boxes_take_the_box_backward_kernel(monkeypatch, B, nQ, nK):
     assert torch.equal(box, again), "not reproducible"
     bent = verts.clone()
     bent[:, nQ // 3, 5] += 0.01   # one corner of one query off its box: the whole launch goes down the general path
-    monkeypatch.setenv("VDETR_BWD_BOX", "0")
+    monkeypatch.setattr(A, "BWD_KERNEL", 1)
     _, gen2 = run(bent)
-    monkeypatch.setenv("VDETR_BWD_BOX", "5")
+    monkeypatch.setattr(A, "BWD_KERNEL", 0)
     _, box2 = run(bent)
     assert torch.equal(gen2, box2), "a non-box query must keep the general kernel"
 

@@ -30,6 +30,8 @@ class AttnDesc(ctypes.Structure):
         ("rng_state", c_void_p),
         ("k_row_stride", ctypes.c_int32), ("v_row_stride", ctypes.c_int32),
         ("bwd_aux", c_void_p),
+        ("table_grid", ctypes.c_int32), ("kv_waves", ctypes.c_int32), ("fwd_kernel", ctypes.c_int32), ("bwd_kernel", ctypes.c_int32),
+        ("fwd_sched", c_void_p),
     ]
 
 
@@ -156,6 +158,7 @@ class SpBnDesc(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol of include/vdetr_hip.h (tests check this)
 _SIGNATURES = {
     "vdetr_abi_version": (c_int, []),
+    "vdetr_ab_switches": (c_int, []),
     "vdetr_last_error": (ctypes.c_char_p, []),
     "vdetr_fps_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vdetr_furthest_point_sampling_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -181,9 +184,7 @@ _SIGNATURES = {
     "vdetr_attn_bwd_kv_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
     "vdetr_attn_bwd_kv_f32": (c_int, [ctypes.POINTER(AttnDesc)] + [c_void_p] * 10 + [c_size_t, c_void_p]),
     "vdetr_attn_bwd_kv_delta_f32": (c_int, [ctypes.POINTER(AttnDesc)] + [c_void_p] * 11 + [c_size_t, c_void_p]),
-    "vdetr_attn_bwd_kv_set_waves": (c_int, [c_int]),
     "vdetr_attn_bwd_dq_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
-    "vdetr_attn_bwd_table_set_grid": (c_int, [c_int]),
     "vdetr_attn_bwd_table_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_table_kernel_names": (c_int, [ctypes.POINTER(AttnDesc), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p)]),
     "vdetr_attn_delta_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -299,3 +300,18 @@ def require_int(t, name):
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+_sched_words = {}
+
+
+def sched_word(device):
+    """The zero device word of the persistent forward's item counter (``vdetr_attn_desc.fwd_sched``): one per (device, stream),
+    allocated zeroed once; every launch leaves it zero, launches of one stream never overlap."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
+    t = _sched_words.get(key)
+    if t is None:
+        t = _sched_words[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return t

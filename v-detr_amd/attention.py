@@ -15,6 +15,7 @@ Forward saves the biased scores S [rows, nK] and the row log-sum-exp; backward i
 import contextlib
 import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -50,6 +51,13 @@ def new_rng_state(device, seed=None):
 # the same captured hipGraph therefore draws fresh dropout masks on every replay.  Modules that share a snapshot
 # stay independent through their per-module ``salt`` (the by-value seed of the descriptor).
 DYNAMIC_BWD = os.environ.get("VDETR_BWD_DYNAMIC", "1") != "0"
+# forward kernel of the 3DV-RPE attention (vdetr_attn_desc.fwd_kernel): 0 = persistent workgroups (attn_fwd_pipe.hip), 1 = the
+# round-4 grid kernel (A/B runs)
+FWD_KERNEL = int(os.environ.get("VDETR_FWD_KERNEL", "0"))
+# table-gradient kernel (vdetr_attn_desc.bwd_kernel): 0 = the box kernel where every query's vertices are a box, 1 = the general
+# kernel only (the parity tests compare the two); TABLE_GRID: workgroups of an in-line table-gradient launch, 0 = one per CU
+BWD_KERNEL = int(os.environ.get("VDETR_BWD_KERNEL", "0"))
+TABLE_GRID = 0
 # shared-KV backward: dO V^T, the softmax backward, dV and dK in one pass over the scores (attn_bwd_kv.hip) instead of
 # three library GEMMs around an element-wise kernel.  VDETR_BWD_FUSED=0 keeps the GEMM path (A/B measurements, parity).
 FUSED_KV_BWD = os.environ.get("VDETR_BWD_FUSED", "1") != "0"
@@ -226,6 +234,8 @@ class DeferredTableGrads:
     _anchor = {}
     _begun = []    # results of begin_flush(): (parameter alias, gradient) pairs computed on the side stream
     buffers = {}   # data_ptr of a layer's (cut) table -> its slice of the stacked accumulator, for the attention backward
+    _outputs = {}      # id(slots) of an entry -> weak references to the tensors park() handed out for it
+    _buffer_keys = {}  # id(slots) of an entry -> its keys in `buffers`
 
     @classmethod
     def park(cls, tables, mlp=None):
@@ -236,12 +246,23 @@ class DeferredTableGrads:
         key = _dev_key(tables.device)
         if key not in cls._anchor:  # a leaf that makes the outputs require grad; it never receives one
             cls._anchor[key] = torch.zeros(1, device=tables.device, requires_grad=True)
-        if cls.pending:
-            if any(g is not None for _, slots, _, _ in cls.pending for _, g in slots):
-                raise RuntimeError("runtime.defer_weight_grads() is on but runtime.flush_weight_grads() was not called after "
-                                   "the last backward pass (parked RPE-table gradients)")
-            cls.pending.clear()  # forward passes that were never differentiated
-            cls.buffers.clear()
+        # Earlier entries stay until the flush: two forward passes followed by one backward (micro-batches with a summed loss, a
+        # second model instance) must both deliver.  An entry is dropped here only when it is provably dead: every tensor park()
+        # handed out for it is gone and no gradient has arrived (a forward pass that was never differentiated).
+        alive = []
+        for item in cls.pending:
+            _tables, slots, _acc, _mlp = item
+            outs = cls._outputs.get(id(slots), ())
+            if all(g is None for _, g in slots) and all(r() is None for r in outs):
+                cls._outputs.pop(id(slots), None)
+                for key_ in cls._buffer_keys.pop(id(slots), ()):
+                    cls.buffers.pop(key_, None)
+                continue
+            alive.append(item)
+        cls.pending = alive
+        if sum(1 for _, slots, _, _ in alive if any(g is not None for _, g in slots)) > 32:
+            raise RuntimeError("runtime.defer_weight_grads() is on but runtime.flush_weight_grads() has not been called for 32 "
+                               "backward passes (parked RPE-table gradients pile up)")
         cut = tables.detach()
         slots = [[i, None] for i in range(tables.shape[0])]
         # the layers' accumulators as slices of ONE zeroed buffer in layer order: the flush hands it to the tables' backward
@@ -251,8 +272,11 @@ class DeferredTableGrads:
             acc = _take_zeros(tables, tuple(tables.shape), tables.dtype)
             for i in range(tables.shape[0]):
                 cls.buffers[cut[i].data_ptr()] = acc[i]
+            cls._buffer_keys[id(slots)] = [cut[i].data_ptr() for i in range(tables.shape[0])]
         cls.pending.append((tables, slots, acc, mlp))
-        return [_ParkTableGrad.apply(cls._anchor[key], cut[i], slots[i]) for i in range(tables.shape[0])]
+        outs = [_ParkTableGrad.apply(cls._anchor[key], cut[i], slots[i]) for i in range(tables.shape[0])]
+        cls._outputs[id(slots)] = [weakref.ref(o) for o in outs]
+        return outs
 
     @classmethod
     def begin_flush(cls):
@@ -306,6 +330,8 @@ class DeferredTableGrads:
                 torch.autograd.backward(roots, grads)
         items, cls.pending = cls.pending, []
         cls.buffers.clear()
+        cls._outputs.clear()
+        cls._buffer_keys.clear()
         for tables, slots, acc, _mlp in items:
             if all(g is None for _, g in slots):
                 continue
@@ -371,23 +397,30 @@ def _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork=Non
         side.wait_stream(torch.cuda.current_stream(q.device))
     with torch.cuda.stream(side):
         ws2 = L.workspace(nbytes, q.device)
-        grid = ASYNC_TABLE_GRID if 2 <= ASYNC_TABLE_GRID < 256 else 0
-        L.check(lib.vdetr_attn_bwd_table_set_grid(grid), "attn_bwd_table_set_grid")  # (process-wide, read at launch)
+        keep_grid = d.table_grid
+        d.table_grid = side_table_grid(q.device)  # the launch's own field: whole CUs stay with the main chain
         try:
             L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws2), nbytes, L.stream_ptr()),
                     "attn_bwd_table")
         finally:
-            lib.vdetr_attn_bwd_table_set_grid(0)
+            d.table_grid = keep_grid
     _side_keep.append((ds, dtable, ws2, aux, table, vertices, xyz, mask))
     return dtable
+
+
+def side_table_grid(device):
+    """workgroups of a side-stream table-gradient launch: ASYNC_TABLE_GRID of 256 CUs, scaled to the device's count (even)"""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if not 2 <= ASYNC_TABLE_GRID < 256:
+        return 0
+    return max(2, (ASYNC_TABLE_GRID * cus // 256) & ~1)
 
 
 def _fused_kv_ok(want_table):
     if not FUSED_KV_BWD:
         return False
-    if want_table:  # the table gradient then reads the dS the fused kernel wrote: default kernel variants only
-        return (DYNAMIC_BWD and os.environ.get("VDETR_BWD_VARIANT", "9") == "9" and
-                os.environ.get("VDETR_BWD_BOX", "2") != "1")
+    if want_table:  # the table gradient then reads the dS the fused kernel wrote, with the dynamic distribution's counters
+        return DYNAMIC_BWD
     return True
 _master = {}
 _current = {}
@@ -459,6 +492,11 @@ def _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, d
     d.seed = int(salt) & 0xFFFFFFFFFFFFFFFF
     if rng_state is not None:
         d.rng_state = rng_state.data_ptr()
+    if table is not None and table.is_cuda:
+        d.fwd_sched = L.sched_word(table.device).data_ptr()
+    d.fwd_kernel = FWD_KERNEL
+    d.bwd_kernel = BWD_KERNEL
+    d.table_grid = TABLE_GRID
     return d
 
 
@@ -558,7 +596,7 @@ class _FusedAttention(Function):
             dkv = torch.empty((2, B, nK, k.shape[2]), dtype=torch.float32, device=q.device)
             run_async = want_table and ctx.table_async and _async_wanted(B, nQ, nK)
             # 4 waves fit NEXT TO a table kernel that holds every CU; with CUs left free for the main chain the default shape
-            lib.vdetr_attn_bwd_kv_set_waves(4 if (run_async or _side_keep) and (ASYNC_TABLE_GRID >= 256 or _ASYNC_KV4) else 8)
+            d.kv_waves = 4 if (run_async or _side_keep) and (ASYNC_TABLE_GRID >= 256 or _ASYNC_KV4) else 8
             nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
             ws = L.workspace(nbytes, q.device)
             L.check(lib.vdetr_attn_bwd_kv_delta_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(out), L.ptr(scores),

@@ -15,17 +15,11 @@
 // no global atomics.
 #include "attn_common.h"
 
-#include <stdlib.h>
-
 namespace vdetr {
 
 int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
-int launch_attn_bwd_box(const AttnParams& P, int grid, hipStream_t st);   // attn_bwd_box.hip
-int launch_attn_bwd_box2(const AttnParams& P, int grid, hipStream_t st, bool f32_products);  // attn_bwd_box2.hip
-int launch_attn_bwd_box3(const AttnParams& P, int grid, hipStream_t st);                     // attn_bwd_box3.hip (dS given)
-int launch_attn_bwd_box4(const AttnParams& P, int grid, hipStream_t st);                     // attn_bwd_box4.hip (dS given)
+int launch_attn_bwd_box4(const AttnParams& P, int grid, hipStream_t st);  // attn_bwd_box4.hip (dS given)
 
-constexpr int kBwdThreads = 1024;
 
 // ---- generic kernel (no RPE): one thread per score element ----------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(AttnParams P) {
@@ -54,156 +48,6 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(AttnParams P) {
                                    have_grad ? P.dprob[e] : 0.f, have_grad ? P.delta[row] : 0.f, masked);
     P.probs_out[e] = g.p_drop;
     if (have_grad) P.ds_out[e] = g.ds * P.scale;
-  }
-}
-
-// ---- RPE kernel ------------------------------------------------------------------------------------------
-// One (batch, query) item at a time per workgroup; a wave takes 64 consecutive keys, one (query,key) pair per lane
-// with the 4 heads in registers.
-//
-// Table gradient.  A pair contributes w_corner * dS[h] to 8 corners x 4 heads of each of the 8 vertex tables.  The
-// log-spaced table makes far cells huge, so most of a wave's 64 (spatially neighbouring, see the Morton ordering in
-// the host module) keys hit the SAME cell — the worst case for LDS atomics (same address = serialised).  Variant 1
-// therefore aggregates inside the wave first: for each distinct base cell among the 64 lanes (usually 1-3) the 32
-// products are summed over the member lanes with a 6-stage reduce-scatter (permlane32/16 swaps + DPP), after which
-// lane 2j holds the wave total of value j and ONE ds_add_f32 instruction with 32 distinct addresses updates the
-// histogram.  Variant 0 (plain per-lane atomics) is kept for A/B measurements.
-template <int CTRL>
-__device__ __forceinline__ float dpp_recv(float v) {
-  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false));
-}
-
-// v[32] per lane -> returns, in lane l, the sum over all 64 lanes of v[l >> 1]
-__device__ __forceinline__ float wave_reduce_scatter32(float (&v)[32], int lane) {
-  float a[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {  // halves: value bit 4 <- lane bit 5
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 16]), false, false);
-    a[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  float b[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {  // row pairs: value bit 3 <- lane bit 4
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[j]), __float_as_uint(a[j + 8]), false, false);
-    b[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  float c[4];
-  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {  // lane ^ 8 (row_ror:8): value bit 2 <- lane bit 3
-    const float keep = b3 ? b[j + 4] : b[j], send = b3 ? b[j] : b[j + 4];
-    c[j] = keep + dpp_recv<0x128>(send);
-  }
-  float d[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {  // row_half_mirror (c <-> 7-c): value bit 1 <- lane bit 2
-    const float keep = b2 ? c[j + 2] : c[j], send = b2 ? c[j] : c[j + 2];
-    d[j] = keep + dpp_recv<kDppRowHalfMirror>(send);
-  }
-  const float keep = b1 ? d[1] : d[0], send = b1 ? d[0] : d[1];  // quad xor 2: value bit 0 <- lane bit 1
-  float e = keep + dpp_recv<kDppQuadXor2>(send);
-  e += dpp_recv<kDppQuadXor1>(e);  // quad xor 1: both lanes of a pair hold the total
-  return e;
-}
-
-template <int VARIANT>
-__global__ __launch_bounds__(kBwdThreads) void attn_bwd_scores_rpe_kernel(AttnParams P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // dTable copy [8][T^3][4]
-  attn_load_rng(P);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int T = P.T, TT = T * T, T3 = TT * T;
-  const int table_floats = kRpeVerts * T3 * 4;
-  const bool want_table = P.dtable_part != nullptr;
-  if (want_table) {
-    for (int i = tid; i < table_floats; i += kBwdThreads) smem[i] = 0.f;
-    __syncthreads();
-  }
-  const bool have_grad = P.dprob != nullptr;
-  const bool rot = P.cos_sin != nullptr;
-  const int items = P.B * P.nQ;
-  const int nchunks = (P.nK + kWave - 1) / kWave;
-  // lane l adds value j = l>>1 = corner*4 + h (corner = cz*4 + cy*2 + cx) when l is even
-  const int jv = lane >> 1;
-  const int my_off = (((jv >> 4) & 1) * TT + ((jv >> 3) & 1) * T + ((jv >> 2) & 1)) * 4 + (jv & 3);
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    const int b = item / P.nQ, q = item - b * P.nQ;
-    const size_t row0 = ((size_t)b * P.nQ + q) * 4;  // rows (b,q,h) for h = 0..3
-    float lse[4], delta[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) { lse[h] = P.lse[row0 + h]; delta[h] = have_grad ? P.delta[row0 + h] : 0.f; }
-    float vx[8], vy[8], vz[8];
-    const float* vp = P.vertices + ((size_t)b * P.nQ + q) * 24;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { vx[i] = vp[i * 3]; vy[i] = vp[i * 3 + 1]; vz[i] = vp[i * 3 + 2]; }
-    const float rc = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2] : 1.f;
-    const float rs = rot ? P.cos_sin[((size_t)b * P.nQ + q) * 2 + 1] : 0.f;
-
-    for (int chunk = w; chunk < nchunks; chunk += kBwdThreads / kWave) {
-      const int key = chunk * kWave + lane;
-      const bool valid = key < P.nK;
-      const int keyc = valid ? key : P.nK - 1;
-      float ds[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid) {
-        uint4 rnd = make_uint4(0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu);
-        if (P.drop_thresh) rnd = attn_rand4(P, b, q, key, 0);
-        const bool masked = P.mask_kind == VDETR_MASK_BOOL &&
-                            reinterpret_cast<const unsigned char*>(P.mask)[((size_t)b * P.nQ + q) * P.nK + key];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const size_t e = (row0 + h) * P.nK + key;
-          const bool keep = pick4(rnd, h) >= P.drop_thresh;
-          const ScoreGrad g = score_grad(P.scores[e], lse[h], keep, P.drop_scale, have_grad,
-                                         have_grad ? P.dprob[e] : 0.f, delta[h], masked);
-          P.probs_out[e] = g.p_drop;
-          if (have_grad) P.ds_out[e] = g.ds * P.scale;
-          ds[h] = g.ds;
-        }
-      }
-      if (!want_table) continue;
-      const float* xp = P.xyz + ((size_t)b * P.nK + keyc) * 3;
-      const float kx = xp[0], ky = xp[1], kz = xp[2];
-#pragma unroll
-      for (int i = 0; i < kRpeVerts; ++i) {
-        float dx = vx[i] - kx, dy = vy[i] - ky, dz = vz[i] - kz;
-        if (rot) rpe_rotate(dx, dy, rc, rs);
-        const AxisTap ax = rpe_axis(dx, P), ay = rpe_axis(dy, P), az = rpe_axis(dz, P);
-        const int cell = i * T3 + rpe_cell(ax, ay, az, T);
-        const float wz[2] = {az.wa, az.wb}, wy[2] = {ay.wa, ay.wb}, wx[2] = {ax.wa, ax.wb};
-        if (VARIANT == 0) {
-          float* t = smem + (size_t)cell * 4;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const float wgt = wz[c >> 2] * wy[(c >> 1) & 1] * wx[c & 1];
-            float* cp = t + ((c >> 2) * TT + ((c >> 1) & 1) * T + (c & 1)) * 4;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) atomicAdd(cp + h, wgt * ds[h]);
-          }
-        } else {
-          float wgt[8];
-#pragma unroll
-          for (int c = 0; c < 8; ++c) wgt[c] = wz[c >> 2] * wy[(c >> 1) & 1] * wx[c & 1];
-          unsigned long long todo = ~0ull;  // every lane takes part (out-of-range keys carry ds = 0)
-          while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int c0 = __builtin_amdgcn_readlane(cell, leader);
-            const bool member = cell == c0;
-            todo &= ~__ballot(member);
-            float v[32];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-              for (int h = 0; h < 4; ++h) v[c * 4 + h] = member ? wgt[c] * ds[h] : 0.f;
-            const float total = wave_reduce_scatter32(v, lane);
-            if (!(lane & 1)) atomicAdd(smem + (size_t)c0 * 4 + my_off, total);
-          }
-        }
-      }
-    }
-  }
-  if (want_table) {
-    __syncthreads();
-    float* dst = P.dtable_part + (size_t)blockIdx.x * table_floats;
-    for (int i = tid; i < table_floats; i += kBwdThreads) dst[i] = smem[i];
   }
 }
 
@@ -659,44 +503,33 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(AttnParams P, ui
 
 using namespace vdetr;
 
-static int bwd_variant() {
-  // 0: per-lane ds_add_f32, 1: wave-aggregated + ds_add_f32; matrix-core aggregation: 9 (default) split-bf16 product,
-  // fixed-point histogram, two 16-wave workgroups per query, a wave walks the workgroup's 4 vertices per chunk;
-  // 8: as 9 with one vertex per wave; 11 / 12: as 9 with 12 / 8 waves (no spills, measured 434 / 515 us vs 417 us);
-  // 10 / 4: one 8-wave workgroup per query with / without the vertex walk;
-  // 5 / 7: fp32 MFMA with float / fixed-point histogram (8-wave workgroups, one vertex per wave)
-  static const int variant = [] { const char* v = getenv("VDETR_BWD_VARIANT"); return v ? atoi(v) : 9; }();
-  return variant;
-}
-// VDETR_BWD_BOX (read per call: the parity test runs the kernels side by side in one process): which axis-aligned-box kernel
-// is launched next to the general one.  0 none, 1 attn_bwd_box.hip, 2 / 3 attn_bwd_box2.hip (split-bf16 / fp32 products),
-// 4 attn_bwd_box3.hip, 5 attn_bwd_box4.hip (default where dS is given; 2 otherwise: 4 and 5 only exist in the dS-given form)
-static int bwd_box_variant(bool ds_given) {
-  const char* box_var = getenv("VDETR_BWD_BOX");
-  int box_env = box_var ? atoi(box_var) : (ds_given ? 5 : 2);
-  if (box_env >= 4 && !ds_given) box_env = 2;
-  return box_env;
-}
-// workgroups of the table-gradient launches: one per CU by default; vdetr_attn_bwd_table_set_grid() lowers it so that a caller
-// who runs the table gradient on a side stream leaves whole CUs to the main chain (the persistent workgroups hold every
-// register and 150 KB of LDS of their CU: nothing else fits next to one)
-static int g_bwd_table_grid = [] { const char* v = getenv("VDETR_BWD_GRID"); const int n = v ? atoi(v) : 0; return n >= 2 && n <= 256 ? n & ~1 : 256; }();
-static int bwd_grid(const vdetr_attn_desc* d, int split) {
-  const long wgs = (long)d->B * d->nQ * split;
-  return (int)(wgs < g_bwd_table_grid ? wgs : g_bwd_table_grid);
-}
-extern "C" int vdetr_attn_bwd_table_set_grid(int workgroups) {
-  VDETR_REQUIRE(workgroups == 0 || (workgroups >= 2 && workgroups <= 256 && workgroups % 2 == 0),
-                "attn_bwd_table_set_grid: %d (0 = default, or an even count in 2..256)", workgroups);
-  g_bwd_table_grid = workgroups ? workgroups : 256;
+// Workgroups of the table-gradient launches: one per CU by default; vdetr_attn_desc.table_grid lowers it so that a caller who
+// runs the table gradient on a side stream leaves whole CUs to the main chain (the persistent workgroups hold every register
+// and 150 KB of LDS of their CU: nothing else fits next to one).  The int32 histogram's fixed-point scale is sized for the most
+// queries one workgroup may take (bwd_query_cap): a grid so small that this resolution would exceed 1e-3 of the bound is refused.
+constexpr int kBwdSplit = 2;  // workgroups per query (the two z halves)
+static int bwd_table_grid(const vdetr_attn_desc* d, int* grid) {
+  const int cus = device_cu_count();
+  int want = d->table_grid ? d->table_grid : (cus & ~1);
+  VDETR_REQUIRE(want >= 2 && want <= cus && want % 2 == 0, "attn_bwd_table: table_grid %d (0 = one workgroup per CU, or an even count in 2..%d)",
+                d->table_grid, cus);
+  const long wgs = (long)d->B * d->nQ * kBwdSplit;
+  if (wgs < want) want = (int)wgs;
+  // resolution of the histogram: bound / 2^30 with bound = cap x (2 drop_scale max|dO| max|V|), against entries of the order
+  // of ONE query's bound: cap / 2^30 must stay below 1e-3 (cap = 1.5 x queries per workgroup)
+  const long per_wg = ((long)d->B * d->nQ + want / kBwdSplit - 1) / (want / kBwdSplit);
+  VDETR_REQUIRE(bwd_query_cap((int)per_wg) <= (1 << 20), "attn_bwd_table: %d workgroups for %ld queries leave the fixed-point "
+                "histogram a resolution above 1e-3 (at most ~700k queries per workgroup)", want, (long)d->B * d->nQ);
+  *grid = want;
   return VDETR_OK;
 }
 
 extern "C" size_t vdetr_attn_bwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d || !d->table) return 0;
   const size_t table_floats = (size_t)kRpeVerts * d->table_size * d->table_size * d->table_size * 4;
-  const long wgs = (long)d->B * d->nQ;  // (sized for the default grid: independent of vdetr_attn_bwd_table_set_grid)
-  return (size_t)(wgs < 256 ? wgs : 256) * table_floats * sizeof(float) + 256;  // partial tables (any variant) + alignment
+  const long wgs = (long)d->B * d->nQ;  // (sized for the default grid: independent of d->table_grid)
+  const long cus = device_cu_count();
+  return (size_t)(wgs < cus ? wgs : cus) * table_floats * sizeof(float) + 256;  // partial tables + alignment
 }
 
 template <bool FIXED, int VERTS, int WPV, bool SPLIT16, bool VLOOP>
@@ -728,18 +561,16 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
   P.probs_out = probs_out; P.ds_out = ds_out;
   P.ds_given = ds_given ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
-  if (!d->table) {
+  if (!d->table || !dtable) {  // element-wise only: P~ and dS do not depend on the look-up geometry
     const size_t total = (size_t)d->B * d->H * d->nQ * d->nK;
     const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(attn_bwd_scores_kernel, dim3(grid), dim3(256), 0, st, P);
     return check_launch("attn_bwd_scores");
   }
-  const int variant = bwd_variant();
-  VDETR_REQUIRE(!ds_given || variant == 9, "attn_bwd_table: built into kernel variant 9 (VDETR_BWD_VARIANT=%d)", variant);
   const int table_floats = kRpeVerts * P.T * P.T * P.T * 4;
-  const bool mm = dtable && variant != 0 && variant != 1 && P.T * P.T * P.T <= kWave * 16;
-  const int split = mm && (variant == 8 || variant == 9 || variant == 11 || variant == 12) ? 2 : 1;  // workgroups per query
-  const int grid = bwd_grid(d, split);
+  VDETR_REQUIRE(P.T * P.T * P.T <= kWave * 16, "attn_bwd_scores: table edge %d too large for the matrix-unit kernel", P.T);
+  int grid = 0;
+  if (int e = bwd_table_grid(d, &grid)) return e;
   if (dtable) {
     const size_t need = vdetr_attn_bwd_workspace_bytes(d);
     if (!workspace || workspace_bytes < need) {
@@ -748,49 +579,24 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
     }
     P.dtable_part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   }
-  // axis-aligned boxes (no rotation operand, table edge 10, dynamic distribution): the box kernel is launched next to the
-  // general one over the same grid / partial-table layout, and the device decides which of the two does the work
-  // VDETR_BWD_BOX: 2 (default) attn_bwd_box2.hip, 355 us at C2 size; 1 attn_bwd_box.hip, 465 us; 0 the general kernel
-  // only, 406 us.  Read per call: the parity test runs the kernels side by side in one process.
-  // 4: attn_bwd_box3.hip, workgroup-wide sort of 1024 keys, exact fp32 products; 5 (default where dS is given):
-  // attn_bwd_box4.hip, wave-private chunks sorted by one LDS add per pair, exact fp32 products
-  const int box_env = bwd_box_variant(ds_given);
-  VDETR_REQUIRE(!ds_given || box_env != 1, "attn_bwd_table: not built into the first box kernel (VDETR_BWD_BOX=1)");
-  VDETR_REQUIRE(!ds_given || P.T * P.T * P.T <= kWave * 16, "attn_bwd_table: table edge %d too large for the matrix-unit kernel", P.T);
-  // (rotated boxes, the cos / sin operand of angle_type "object_coords": attn_bwd_box4.hip only)
-  const bool box = mm && variant == 9 && box_env && (!d->cos_sin || box_env >= 5) && d->bwd_aux && P.T == 10;
+  // Two kernels over the same grid and partial-table layout; the DEVICE decides which of them works (bwd_aux words 4 / 5):
+  //   attn_bwd_scores_rpe_mm_kernel: any eight vertices per query;
+  //   attn_bwd_box4_kernel (dS given, table edge 10, dynamic distribution): every query's vertices are an axis-aligned box, or,
+  //   with the rotation operand, a box in the frame the offsets are turned into.
+  // d->bwd_kernel = 1 keeps the general kernel alone (the parity tests compare the two).
+  const bool box = ds_given && dtable && d->bwd_kernel == 0 && d->bwd_aux && P.T == 10;
   P.box_path = box ? 1 : 0;
-  if (mm) {
-    const size_t lds = (size_t)table_floats / split * sizeof(float) + (size_t)8 * split * kMmStripFloats * sizeof(float);
-    int e;
-    if (variant == 5) e = launch_mm<false, 8, 1, false, false>(P, grid, lds, st);      // fp32 MFMA, float LDS atomics
-    else if (variant == 7) e = launch_mm<true, 8, 1, false, false>(P, grid, lds, st);  // fp32 MFMA, fixed-point histogram
-    else if (variant == 4) e = launch_mm<true, 8, 1, true, false>(P, grid, lds, st);
-    else if (variant == 8) e = launch_mm<true, 4, 4, true, false>(P, grid, lds, st);
-    else if (variant == 10) e = launch_mm<true, 8, 1, true, true>(P, grid, lds, st);
-    else if (variant == 11) e = launch_mm<true, 4, 3, true, true>(P, grid, (size_t)table_floats / 2 * sizeof(float) + (size_t)12 * kMmStripFloats * sizeof(float), st);
-    else if (variant == 12) e = launch_mm<true, 4, 2, true, true>(P, grid, (size_t)table_floats / 2 * sizeof(float) + (size_t)8 * kMmStripFloats * sizeof(float), st);
-    else e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st);
-    if (e) return e;
+  {
+    const size_t lds = (size_t)table_floats / kBwdSplit * sizeof(float) + (size_t)8 * kBwdSplit * kMmStripFloats * sizeof(float);
+    if (int e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st)) return e;
     if (box)
-      if (int e2 = box_env >= 5 ? launch_attn_bwd_box4(P, grid, st)
-                   : box_env == 4 ? launch_attn_bwd_box3(P, grid, st)
-                   : box_env >= 2 ? launch_attn_bwd_box2(P, grid, st, box_env == 3) : launch_attn_bwd_box(P, grid, st)) return e2;
-  } else {
-    const size_t lds = dtable ? (size_t)table_floats * sizeof(float) : 16;
-    if (variant == 0) {
-      if (int e = set_lds(attn_bwd_scores_rpe_kernel<0>, lds, "attn_bwd_scores")) return e;
-      hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<0>), dim3(grid), dim3(kBwdThreads), lds, st, P);
-    } else {
-      if (int e = set_lds(attn_bwd_scores_rpe_kernel<1>, lds, "attn_bwd_scores")) return e;
-      hipLaunchKernelGGL((attn_bwd_scores_rpe_kernel<1>), dim3(grid), dim3(kBwdThreads), lds, st, P);
-    }
+      if (int e2 = launch_attn_bwd_box4(P, grid, st)) return e2;
   }
   if (int e = check_launch("attn_bwd_scores_rpe")) return e;
   if (dtable) {
     hipLaunchKernelGGL(attn_bwd_table_reduce_kernel,
-                       dim3((table_floats + 255) / 256, (grid / split + kRedSlice - 1) / kRedSlice), dim3(256), 0, st,
-                       P.dtable_part, grid, split, table_floats, dtable);
+                       dim3((table_floats + 255) / 256, (grid / kBwdSplit + kRedSlice - 1) / kRedSlice), dim3(256), 0, st,
+                       P.dtable_part, grid, kBwdSplit, table_floats, dtable);
     return check_launch("attn_bwd_table_reduce");
   }
   return VDETR_OK;
@@ -811,14 +617,10 @@ extern "C" int vdetr_attn_bwd_table_f32(const vdetr_attn_desc* d, const float* d
 extern "C" int vdetr_attn_bwd_table_kernel_names(const vdetr_attn_desc* d, const char** box_kernel, const char** general_kernel) {
   VDETR_REQUIRE(d && box_kernel && general_kernel, "attn_bwd_table_kernel_names: null pointer");
   VDETR_REQUIRE(d->table, "attn_bwd_table_kernel_names: no RPE table in the descriptor");
-  static const char* const kBox[] = {nullptr, "attn_bwd_box_kernel", "attn_bwd_box2_kernel<false>", "attn_bwd_box2_kernel<true>",
-                                     "attn_bwd_box3_kernel", "attn_bwd_box4_kernel"};
-  const int variant = bwd_variant(), box_env = bwd_box_variant(true);
   const int T = d->table_size;
-  const bool mm = variant != 0 && variant != 1 && T * T * T <= kWave * 16;
-  const bool box = mm && variant == 9 && box_env && (!d->cos_sin || box_env >= 5) && d->bwd_aux && T == 10;
-  *box_kernel = box ? kBox[box_env > 5 ? 5 : box_env] : nullptr;
-  *general_kernel = mm ? "attn_bwd_scores_rpe_mm_kernel" : "attn_bwd_scores_rpe_kernel";
+  const bool box = d->bwd_kernel == 0 && d->bwd_aux && T == 10;
+  *box_kernel = box ? "attn_bwd_box4_kernel" : nullptr;
+  *general_kernel = "attn_bwd_scores_rpe_mm_kernel";
   return VDETR_OK;
 }
 

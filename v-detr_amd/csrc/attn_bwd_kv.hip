@@ -393,15 +393,6 @@ __global__ __launch_bounds__(WAVES * kWave) void attn_bwd_kv_kernel(KvParams K) 
 
 using namespace vdetr;
 
-// 8 (default; VDETR_KV_WAVES overrides) or 4 waves per workgroup, see the note at the kernel
-static std::atomic<int> g_kv_waves{[] { const char* v = getenv("VDETR_KV_WAVES"); return v && atoi(v) == 4 ? 4 : 8; }()};
-
-extern "C" int vdetr_attn_bwd_kv_set_waves(int waves) {
-  VDETR_REQUIRE(waves == 4 || waves == 8, "attn_bwd_kv_set_waves: %d (4 or 8)", waves);
-  g_kv_waves.store(waves);
-  return VDETR_OK;
-}
-
 static bool kv_supported(const vdetr_attn_desc* d) {
   return d && ((d->kind == VDETR_ATTN_SHARED_KV && d->H == 4) || d->kind == VDETR_ATTN_PER_HEAD);
 }
@@ -454,7 +445,8 @@ static int kv_run(const vdetr_attn_desc* d, const float* q, const float* v, cons
   const long zero4 = (long)d->B * d->nK * (d->kind == VDETR_ATTN_PER_HEAD ? d->H : 1) * kDh / 4;
   const long work = units > zero4 ? units : zero4;
   const int nkt = (d->nK + 31) / 32;
-  const bool four = g_kv_waves.load() == 4;
+  VDETR_REQUIRE(d->kv_waves == 0 || d->kv_waves == 4 || d->kv_waves == 8, "attn_bwd_kv: kv_waves %d (0, 4 or 8)", d->kv_waves);
+  const bool four = d->kv_waves == 4;  // (see the note at the kernel)
   hipStream_t st = (hipStream_t)stream;
   DeltaArgs D{};
   int ndelta = 0;

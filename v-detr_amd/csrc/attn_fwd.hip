@@ -505,6 +505,13 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   return VDETR_OK;
 }
 
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, hipStream_t st);  // attn_fwd_pipe.hip
+
+// the persistent forward (attn_fwd_pipe.hip) takes the 3DV-RPE attention as the model runs it: fp32, table edge 10, no mask
+static bool pipe_eligible(const vdetr_attn_desc* d) {
+  return d->kind == VDETR_ATTN_SHARED_KV && d->table && d->table_size == 10 && !d->mask && d->fwd_kernel == 0;
+}
+
 // key split so that small query counts still fill the chip (shared kinds only)
 static int choose_ksplit(const vdetr_attn_desc* d) {
   if (d->kind != VDETR_ATTN_SHARED_KV) {
@@ -514,7 +521,7 @@ static int choose_ksplit(const vdetr_attn_desc* d) {
     // costs what the second round did; kept behind VDETR_FWD_KSPLIT_PERHEAD for larger self-attentions.  Also tried: the
     // per-head instantiation compiled for 128 VGPRs (two workgroups per CU, so that the 256 workgroups fit next to a busy
     // CU): 27 spilled registers, 48.7 instead of 41.4 us inside the step)
-    static const int ph = [] { const char* v = getenv("VDETR_FWD_KSPLIT_PERHEAD"); return v ? atoi(v) : 1; }();
+    const int ph = VDETR_AB("VDETR_FWD_KSPLIT_PERHEAD", 1);
     const int ntiles = (d->nK + 15) / 16;
     return (ph > 1 && ntiles >= 2 * ph * kFwdWaves) ? ph : 1;
   }
@@ -527,7 +534,7 @@ static int choose_ksplit(const vdetr_attn_desc* d) {
   // stream (measured: 307 us instead of 181 us per launch).  Finer workgroups let the hardware dispatcher
   // balance the load over whatever CUs are free (4.02 -> 5 rounds of 1/4 size instead of 2 of full size); the price is the
   // per-workgroup prologue + merge (~6 us) and the combine kernel.
-  static const int forced = [] { const char* v = getenv("VDETR_FWD_KSPLIT"); return v ? atoi(v) : 0; }();
+  const int forced = VDETR_AB("VDETR_FWD_KSPLIT", 0);
   const int fine = forced > 0 ? forced : 4;  // step time at 1/2/4/8: 18.13 / 17.91 / 17.74 / 18.06 ms
   if (d->table && ks < fine && wgs >= 64) {
     while (ks < fine && ks * 2 * kFwdWaves <= ntiles) ks *= 2;
@@ -539,9 +546,10 @@ static int choose_ksplit(const vdetr_attn_desc* d) {
 extern "C" size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d) return 0;
   const int ks = choose_ksplit(d);
-  if (ks == 1) return 0;
+  const size_t sched = pipe_eligible(d) && !d->fwd_sched ? 256 : 0;  // the item counter, where the caller brings none
+  if (ks == 1) return sched;
   const size_t rows = (size_t)d->B * d->nQ * d->H;
-  return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256;
+  return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256 + sched;
 }
 
 extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
@@ -554,14 +562,25 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
   const bool perhead = d->kind == VDETR_ATTN_PER_HEAD;
   const bool rpe = d->table != nullptr;
   const int ks = choose_ksplit(d);
-  if (ks > 1) {
-    const size_t need = vdetr_attn_fwd_workspace_bytes(d);
-    if (!workspace || workspace_bytes < need) {
-      set_error("attn_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
-      return VDETR_ERR_WORKSPACE;
+  const bool pipe = pipe_eligible(d);
+  const size_t need = vdetr_attn_fwd_workspace_bytes(d);
+  if (need && (!workspace || workspace_bytes < need)) {
+    set_error("attn_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
+    return VDETR_ERR_WORKSPACE;
+  }
+  unsigned* sched = d->fwd_sched;
+  size_t sched_bytes = 0;
+  if (pipe && !sched) {  // head of the workspace, cleared in front of the launch (a memset node in a captured graph)
+    sched = (unsigned*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    sched_bytes = 256;
+    if (hipMemsetAsync(sched, 0, 16, (hipStream_t)stream) != hipSuccess) {
+      set_error("attn_fwd: cannot clear the item counter");
+      return VDETR_ERR_LAUNCH;
     }
+  }
+  if (ks > 1) {
     const size_t rows = (size_t)d->B * d->nQ * d->H;
-    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    uintptr_t base = ((uintptr_t)workspace + sched_bytes + 255) & ~(uintptr_t)255;
     P.part_o = (float*)base;
     P.part_lse = P.part_o + (size_t)ks * rows * kDh;
     P.ksplit = ks;
@@ -573,17 +592,21 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
                          ? lds_table + (size_t)kFwdWaves * 16 * kPPad * 4
                          : (size_t)kFwdWaves * kWave * 24 * 4;
   hipStream_t st = (hipStream_t)stream;
-  if (perhead) {
+  if (pipe) {
+    VDETR_REQUIRE((size_t)d->nK * P.k_stride < (1u << 30) && (size_t)d->nK * P.v_stride < (1u << 30) && (size_t)4 * d->nK < (1u << 30),
+                  "attn_fwd: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), st)) return e;
+  } else if (perhead) {
     dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
     if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
     hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(kFwdThreads), lds, st, P);
   } else {
     dim3 grid((d->nQ + 3) / 4, ks, d->B);
     if (rpe) {
-      static const int box_env = [] { const char* v = getenv("VDETR_FWD_BOX"); return v ? atoi(v) : 1; }();
-      static const int box_rot = [] { const char* v = getenv("VDETR_FWD_BOX_ROT"); return v ? atoi(v) : 1; }();
+      const int box_env = VDETR_AB("VDETR_FWD_BOX", 1);
+      const int box_rot = VDETR_AB("VDETR_FWD_BOX_ROT", 1);
       P.box_path = box_env && (!d->cos_sin || box_rot);  // (VDETR_FWD_BOX_ROT=0: rotated boxes take the general body)
-      static const int auto_env = [] { const char* v = getenv("VDETR_FWD_AUTO"); return v ? atoi(v) : 1; }();
+      const int auto_env = VDETR_AB("VDETR_FWD_AUTO", 1);
       if (P.box_path && auto_env) {  // one launch, the box / general body chosen per workgroup on the device
         if (int e = set_lds(attn_fwd_rpe_auto_kernel<false>, lds, "attn_fwd")) return e;
         hipLaunchKernelGGL((attn_fwd_rpe_auto_kernel<false>), grid, dim3(kFwdThreads), lds, st, P);
@@ -641,11 +664,11 @@ extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, cons
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((d->nQ + 3) / 4, ks, d->B);
   if (rpe) {
-    static const int box_env = [] { const char* e = getenv("VDETR_FWD_BOX"); return e ? atoi(e) : 1; }();
-    static const int box_rot = [] { const char* v = getenv("VDETR_FWD_BOX_ROT"); return v ? atoi(v) : 1; }();
+    const int box_env = VDETR_AB("VDETR_FWD_BOX", 1);
+    const int box_rot = VDETR_AB("VDETR_FWD_BOX_ROT", 1);
     P.box_path = box_env && (!d->cos_sin || box_rot);
     // (the merged kernel of the fp32 path spills 11 registers when built for bf16 operands: opt-in only)
-    static const int auto_env = [] { const char* e = getenv("VDETR_FWD_AUTO"); return e ? atoi(e) : 0; }();
+    const int auto_env = VDETR_AB("VDETR_FWD_AUTO", 0);
     if (P.box_path && auto_env == 2) {
       if (int e = set_lds(attn_fwd_rpe_auto_kernel<true>, lds, "attn_fwd_bf16")) return e;
       hipLaunchKernelGGL((attn_fwd_rpe_auto_kernel<true>), grid, dim3(kFwdThreads), lds, st, P);

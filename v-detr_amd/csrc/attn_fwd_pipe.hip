@@ -1,0 +1,454 @@
+// attn_fwd_pipe.hip — the 3DV-RPE cross-attention forward as PERSISTENT workgroups (round 5).
+//
+//   out = dropout(softmax(scale q k^T + rpe)) v        (vdetr_transformer.py:710-757; shared K/V, 4 heads, fp32, table edge 10)
+//
+// Same tile as attn_fwd.hip (v_mfma_f32_16x16x4_f32: 4 queries x 4 heads by 16 keys, lane = one (query, key) pair with
+// the 4 heads in 4 registers, exact fp32 products), different kernel around it.  What the round-4 counters said about
+// attn_fwd_rpe_auto_kernel (profiles/r04_b_pmc_sq_pass*.txt, per wave and 16-key tile: 10.2k cycles, of which 3.4k issuing,
+// 3.6k issue-stalled, 3.1k waiting) and what this kernel does about each item:
+//   * 1,024 workgroups of 8 tiles per wave each stage the 128 KB table image (6 us of a 41 us workgroup, 131 MB of L2 -> LDS
+//     traffic per launch).  Here: one workgroup per CU stages the table ONCE and draws (query quad, key chunk) items from a
+//     device counter until none is left — the dynamic balance of the fine grid (a CU busy with the next scene's sampling
+//     costs an item, not a round) without its prologues.
+//   * LDS bank conflicts were 44 % of the LDS cycles.  A ds_read_b128 is served in four groups of 16 lanes, and the groups are
+//     not the DPP rows: {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS), i.e. 8 keys of one query and
+//     8 keys of its neighbour row.  Two queries' cells are unrelated, so their 16-byte slots collide at random; 16 keys of ONE
+//     query (Morton-sorted neighbours) touch a 2 x 2 x 2 block of cells, which the table's strides (1, 10, 100 cells = 1, 10, 4
+//     mod 16 slots) map to distinct slots.  So lanes 4-11 of every row look up the pair of the NEIGHBOUR row (query g ^ 1,
+//     same key): every service group then belongs to one query, and the four bias values go back to their owner with one
+//     v_permlane16_swap each.
+//   * 256 v_fma_f32 per pair (8 vertices x 8 corners x 4 heads) become 128 v_pk_fma_f32 (two heads per instruction, the
+//     weight as a low-half broadcast of a single register: the form build.py's code-object check accepts).
+//   * the key loop's addressing was recomputed per tile with 64-bit multiplies (~55 VALU, quarter rate); here per-item bases
+//     and one 32-bit offset per tile.
+//   * `rot` (angle_type "object_coords") is a template parameter: the loop body is one basic block in both instantiations.
+// The queries of an item whose vertices are not an (optionally rotated) axis-aligned box take a compact general body
+// (24 axis taps per pair, vertices re-read per tile): correct for any `reference_point`, not tuned — the model only ever
+// passes box corners (vdetr_transformer.py:408-412).
+#include "attn_common.h"
+
+namespace vdetr {
+
+constexpr int kPT = 10;                   // table edge ("bilinear_4_10")
+constexpr int kPCells = kPT * kPT * kPT;  // cells per vertex table
+constexpr int kPipeThreads = 512;
+constexpr int kPipeWaves = kPipeThreads / kWave;
+constexpr int kPipePad = 20;              // floats per row of the P transpose pad (16 + 4: float4-aligned rows)
+// LDS map (bytes)
+constexpr int kLdsPad = kRpeVerts * kPCells * 16;                  // 128,000: [8 waves][16 rows][20] floats
+constexpr int kLdsMl = kLdsPad + kPipeWaves * 16 * kPipePad * 4;   // 138,240: [8 waves][4 row groups][m0..3, l0..3]
+constexpr int kLdsXch = kLdsMl + kPipeWaves * 4 * 8 * 4;           // 139,264: [8 waves][8 slots][64 lanes] floats (16 KB)
+constexpr int kLdsNext = kLdsXch + kPipeWaves * 8 * kWave * 4;     // 155,648: two item indices
+constexpr int kPipeLdsBytes = kLdsNext + 16;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct PipeArgs {
+  AttnParams P;
+  unsigned* counter;  // device word, zero before the launch; the last draw of the launch sets it back to zero
+  int nitems, qtiles; // items = B x qtiles x ksplit, qtiles = ceil(nQ / 4)
+};
+
+// ---- per-axis tap as in attn_common.h (rpe_axis), with the table edge a constant --------------------------------------
+__device__ __forceinline__ AxisTap pipe_axis(float d, float log_scale, float pix_mul, float pix_add) {
+  const float L = __log2f(__builtin_fmaf(fabsf(d), log_scale, 1.0f));
+  const float pix = __builtin_fmaf(copysignf(L, d), pix_mul, pix_add);
+  const float bf = __builtin_amdgcn_fmed3f(floorf(pix), 0.f, (float)(kPT - 2));
+  const float t = pix - bf;
+  AxisTap a;
+  a.base = (int)bf;
+  a.wa = sat01(1.f - fabsf(t));
+  a.wb = sat01(1.f - fabsf(t - 1.f));
+  return a;
+}
+
+// one vertex table's 8 corners (the 2 x 2 x 2 block of cells at `t`): read, then folded into the two head pairs (16 v_pk_fma_f32)
+struct PipeCorners {
+  f32x4 c[8];
+};
+__device__ __forceinline__ void pipe_read8(const f32x4* t, PipeCorners& C) {
+  C.c[0] = t[0]; C.c[1] = t[1]; C.c[2] = t[kPT]; C.c[3] = t[kPT + 1];
+  C.c[4] = t[kPT * kPT]; C.c[5] = t[kPT * kPT + 1]; C.c[6] = t[kPT * kPT + kPT]; C.c[7] = t[kPT * kPT + kPT + 1];
+}
+__device__ __forceinline__ void pipe_fma8(const PipeCorners& C, float axa, float axb, float w00, float w01, float w10, float w11,
+                                          f32x2& s01, f32x2& s23) {
+  // the eight weights as single registers (w_zy * w_x, the products and their order of attn_common.h:rpe_pair_bias)
+  const float w[8] = {axa * w00, axb * w00, axa * w01, axb * w01, axa * w10, axb * w10, axa * w11, axb * w11};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    s01 = __builtin_elementwise_fma(f32x2{C.c[k][0], C.c[k][1]}, f32x2{w[k], w[k]}, s01);
+    s23 = __builtin_elementwise_fma(f32x2{C.c[k][2], C.c[k][3]}, f32x2{w[k], w[k]}, s23);
+  }
+}
+
+// what a lane knows about the query whose pairs it looks up (its "role" query: the neighbour row's for lanes 4-11)
+struct PipeQuery {
+  float x0, x1, y0, y1, z0, z1;  // box: the two values per axis (ROT: vertex 0 and the three edges, see pipe_bias_box)
+  float rc, rs;                  // ROT: cos, sin of the query's angle
+};
+
+// bias of the lane's role pair for the 4 heads, axis-aligned box (6 taps); ROT: one rotation of P_0 - X, then the edges
+template <bool ROT>
+__device__ __forceinline__ void pipe_bias_box(const AttnParams& P, const f32x4* tab, const PipeQuery& Q, float kx, float ky, float kz,
+                                              f32x2& s01, f32x2& s23) {
+  float dx[2], dy[2], dz[2];
+  if (ROT) {
+    float ax0 = Q.x0 - kx, ay0 = Q.y0 - ky;
+    rpe_rotate(ax0, ay0, Q.rc, Q.rs);
+    dx[0] = ax0; dx[1] = ax0 + Q.x1;
+    dy[0] = ay0; dy[1] = ay0 + Q.y1;
+    dz[0] = Q.z0 - kz; dz[1] = dz[0] + Q.z1;
+  } else {
+    dx[0] = Q.x0 - kx; dx[1] = Q.x1 - kx;
+    dy[0] = Q.y0 - ky; dy[1] = Q.y1 - ky;
+    dz[0] = Q.z0 - kz; dz[1] = Q.z1 - kz;
+  }
+  const AxisTap ax[2] = {pipe_axis(dx[0], P.log_scale, P.pix_mul, P.pix_add), pipe_axis(dx[1], P.log_scale, P.pix_mul, P.pix_add)};
+  const AxisTap ay[2] = {pipe_axis(dy[0], P.log_scale, P.pix_mul, P.pix_add), pipe_axis(dy[1], P.log_scale, P.pix_mul, P.pix_add)};
+  const AxisTap az[2] = {pipe_axis(dz[0], P.log_scale, P.pix_mul, P.pix_add), pipe_axis(dz[1], P.log_scale, P.pix_mul, P.pix_add)};
+  float w00[2][2], w01[2][2], w10[2][2], w11[2][2];
+  int zy[2][2];
+#pragma unroll
+  for (int zi = 0; zi < 2; ++zi)
+#pragma unroll
+    for (int yi = 0; yi < 2; ++yi) {
+      w00[zi][yi] = az[zi].wa * ay[yi].wa; w01[zi][yi] = az[zi].wa * ay[yi].wb;
+      w10[zi][yi] = az[zi].wb * ay[yi].wa; w11[zi][yi] = az[zi].wb * ay[yi].wb;
+      zy[zi][yi] = __mul24(__mul24(az[zi].base, kPT) + ay[yi].base, kPT);  // (full-rate 24-bit multiplies)
+    }
+  // the corners of vertex i + 1 are requested before those of vertex i are folded: the LDS latency (8 waves queue on one LDS)
+  // hides behind 24 VALU instructions instead of standing in front of them eight times per tile
+  PipeCorners cur, nxt;
+  pipe_read8(tab + zy[rpe_box_zi(0)][rpe_box_yi(0)] + ax[rpe_box_xi(0)].base, cur);
+#pragma unroll
+  for (int i = 0; i < kRpeVerts; ++i) {
+    const int xi = rpe_box_xi(i), yi = rpe_box_yi(i), zi = rpe_box_zi(i);
+    if (i + 1 < kRpeVerts)
+      pipe_read8(tab + (i + 1) * kPCells + zy[rpe_box_zi(i + 1)][rpe_box_yi(i + 1)] + ax[rpe_box_xi(i + 1)].base, nxt);
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise pairs the vertices up and waits in front of each pair)
+    pipe_fma8(cur, ax[xi].wa, ax[xi].wb, w00[zi][yi], w01[zi][yi], w10[zi][yi], w11[zi][yi], s01, s23);
+    if (i + 1 < kRpeVerts) cur = nxt;
+  }
+}
+
+// any eight vertices (rolled: one vertex per trip, its coordinates re-read): the path of non-box `reference_point`s
+__device__ __forceinline__ void pipe_bias_general(const AttnParams& P, const f32x4* tab, const float* __restrict__ vp, bool rot, float rc,
+                                                  float rs, float kx, float ky, float kz, f32x2& s01, f32x2& s23) {
+#pragma unroll 1
+  for (int i = 0; i < kRpeVerts; ++i) {
+    float dx = vp[i * 3] - kx, dy = vp[i * 3 + 1] - ky;
+    const float dz = vp[i * 3 + 2] - kz;
+    if (rot) rpe_rotate(dx, dy, rc, rs);
+    const AxisTap ax = pipe_axis(dx, P.log_scale, P.pix_mul, P.pix_add), ay = pipe_axis(dy, P.log_scale, P.pix_mul, P.pix_add),
+                  az = pipe_axis(dz, P.log_scale, P.pix_mul, P.pix_add);
+    PipeCorners C;
+    pipe_read8(tab + i * kPCells + (az.base * kPT + ay.base) * kPT + ax.base, C);
+    pipe_fma8(C, ax.wa, ax.wb, az.wa * ay.wa, az.wa * ay.wb, az.wb * ay.wa, az.wb * ay.wb, s01, s23);
+  }
+}
+
+// value of the neighbour row (lane ^ 16) for the lanes that looked up the neighbour's pair; everybody else keeps its own
+__device__ __forceinline__ float pipe_give_back(float v, bool swapped, bool odd_row) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  // r[0] = rows [0, 0, 2, 2], r[1] = rows [1, 1, 3, 3] (wave.h:xrow16)
+  const float other = __uint_as_float(odd_row ? r[0] : r[1]);
+  return swapped ? other : v;
+}
+
+enum { kPipeBox = 0, kPipeBoxRot = 1, kPipeGeneral = 2 };
+
+struct PipeTile {  // operands of one 16-key tile
+  f32x4 kb[4], vb[4];
+  float kx, ky, kz;
+};
+
+struct PipeLane {  // per-item, per-lane bases (element offsets fit 32 bits: checked on the host)
+  const float* kp;  // K row of key c, columns 16 g ..
+  const float* vp;  // V row of key 4 g, columns 4 c ..
+  const float* xp;  // xyz of key c
+  float* sp;        // scores row (b, q0 + g, head 0) + c, or NULL
+};
+
+// Operand fetches of tile `tile` (rows past nK are clamped to the last key: only the last tile of a launch can have any, and its
+// columns are masked).  Each piece is re-filled in place for the wave's NEXT tile right after its last use in the current one —
+// K behind the QK^T instructions, the coordinates behind the taps, V behind PV — so one register set serves the whole loop and
+// every load has most of a tile's time to arrive.
+__device__ __forceinline__ void pipe_fetch_k(const AttnParams& P, const PipeLane& A, int tile, int nK, int c, PipeTile& t) {
+  const int kc = min((tile << 4) + c, nK - 1) - c;  // row offset of this lane's key against the item base
+  const f32x4* kp = reinterpret_cast<const f32x4*>(A.kp + kc * P.k_stride);
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
+}
+__device__ __forceinline__ void pipe_fetch_x(const PipeLane& A, int tile, int nK, int c, PipeTile& t) {
+  const int kc = min((tile << 4) + c, nK - 1) - c;
+  const float* xp = A.xp + kc * 3;
+  t.kx = xp[0]; t.ky = xp[1]; t.kz = xp[2];
+}
+__device__ __forceinline__ void pipe_fetch_v(const AttnParams& P, const PipeLane& A, int tile, int nK, int g, PipeTile& t) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kk = min((tile << 4) + 4 * g + s, nK - 1) - 4 * g;
+    t.vb[s] = *reinterpret_cast<const f32x4*>(A.vp + kk * P.v_stride);
+  }
+}
+
+// one 16-key tile: scores, bias, online softmax, PV
+template <int MODE, bool TAIL>
+__device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab, float* ppad, const PipeLane& A, const PipeQuery& Q,
+                                          const float* __restrict__ role_vp, const float (&qa)[16], PipeTile& ops, int tile, int next, int b,
+                                          int qrow, int g, int c, bool swapped, f32x4 (&o)[4], float (&m)[4], float (&l)[4]) {
+  const int nK = P.nK;
+  const int key = (tile << 4) + c;
+  const bool kvalid = !TAIL || key < nK;
+  // ---- S = Q K^T --------------------------------------------------------------------------------------------------------
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
+  pipe_fetch_k(P, A, next, nK, c, ops);
+  // ---- RPE bias of the role pair, handed back to the pair's owner ------------------------------------------------------
+  const float kx = ops.kx, ky = ops.ky, kz = ops.kz;
+  pipe_fetch_x(A, next, nK, c, ops);
+  f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+  if (MODE == kPipeGeneral) pipe_bias_general(P, tab, role_vp, P.cos_sin != nullptr, Q.rc, Q.rs, kx, ky, kz, s01, s23);
+  else pipe_bias_box<MODE == kPipeBoxRot>(P, tab, Q, kx, ky, kz, s01, s23);
+  const bool odd = g & 1;
+  float sc[4];
+  sc[0] = acc[0] + pipe_give_back(s01[0], swapped, odd);
+  sc[1] = acc[1] + pipe_give_back(s01[1], swapped, odd);
+  sc[2] = acc[2] + pipe_give_back(s23[0], swapped, odd);
+  sc[3] = acc[3] + pipe_give_back(s23[1], swapped, odd);
+  if (TAIL && !kvalid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = kNegBig;
+  }
+  if (A.sp && kvalid && qrow < P.nQ) {
+    float* sp = A.sp + (tile << 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (VDETR_STREAM_NT) __builtin_nontemporal_store(sc[r], sp + r * nK);  // 67 MB per layer: past L2
+      else sp[r * nK] = sc[r];
+    }
+  }
+  // ---- online softmax (a row lives across the 16 lanes of a DPP row) ----------------------------------------------------
+  float p[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float tmax = row_allmax_f32_fx(sc[r]);
+    const float mn = fmaxf(m[r], tmax);
+    const float alpha = __expf(m[r] - mn);
+    const float e = kvalid ? __expf(sc[r] - mn) : 0.f;
+    l[r] = l[r] * alpha + row_allsum_f32_fx(e);
+    m[r] = mn;
+    p[r] = e;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t][r] *= alpha;
+  }
+  if (P.drop_thresh) {  // dropout on the probabilities (the normaliser uses the undropped ones)
+    const uint4 rnd = attn_rand4(P, b, qrow, key, 0);
+    p[0] = rnd.x >= P.drop_thresh ? p[0] * P.drop_scale : 0.f;
+    p[1] = rnd.y >= P.drop_thresh ? p[1] * P.drop_scale : 0.f;
+    p[2] = rnd.z >= P.drop_thresh ? p[2] * P.drop_scale : 0.f;
+    p[3] = rnd.w >= P.drop_thresh ? p[3] * P.drop_scale : 0.f;
+  }
+  // ---- P: accumulator layout -> A-operand layout through the wave-private pad -------------------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ppad[(4 * g + r) * kPipePad + c] = p[r];
+  __builtin_amdgcn_wave_barrier();
+  const f32x4 pa = *reinterpret_cast<const f32x4*>(ppad + c * kPipePad + 4 * g);
+  __builtin_amdgcn_wave_barrier();
+  // ---- O += P V ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], ops.vb[s][t], o[t], 0, 0, 0);
+  pipe_fetch_v(P, A, next, nK, g, ops);
+}
+
+template <int MODE>
+__device__ __forceinline__ void pipe_tiles(const AttnParams& P, const f32x4* tab, float* ppad, const PipeLane& A, const PipeQuery& Q,
+                                           const float* __restrict__ role_vp, const float (&qa)[16], PipeTile& ops, int tile_begin,
+                                           int tile_end, int w, int b, int qrow, int g, int c, bool swapped, f32x4 (&o)[4],
+                                           float (&m)[4], float (&l)[4]) {
+  const int nK = P.nK;
+  const int full_end = min(tile_end, nK >> 4);  // tiles below this index have 16 keys
+  int tile = tile_begin + w;
+  for (; tile < full_end; tile += kPipeWaves) {
+    const int next = tile + kPipeWaves < tile_end ? tile + kPipeWaves : tile;  // (the wave's last tile re-reads itself: no branch)
+    pipe_tile<MODE, false>(P, tab, ppad, A, Q, role_vp, qa, ops, tile, next, b, qrow, g, c, swapped, o, m, l);
+  }
+  if (tile < tile_end)  // the last tile of the key range, cut short by nK
+    pipe_tile<MODE, true>(P, tab, ppad, A, Q, role_vp, qa, ops, tile, tile, b, qrow, g, c, swapped, o, m, l);
+}
+
+template <bool ROT>
+__global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArgs K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  AttnParams& P = K.P;
+  attn_load_rng(P);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: the key loop's control stays out of the exec mask
+  const int g = lane >> 4, c = lane & 15;
+  const bool swapped = c >= 4 && c < 12;   // this lane looks up the pair of the neighbour row
+  const int gq = swapped ? (g ^ 1) : g;    // row of the role query
+  const int nQ = P.nQ, nK = P.nK, H = 4;
+  const f32x4* tab = reinterpret_cast<const f32x4*>(smem);
+  float* ppad = smem + kLdsPad / 4 + w * (16 * kPipePad);
+  float* mlbuf = smem + kLdsMl / 4;
+  float* xch = smem + kLdsXch / 4;
+  volatile int* nextbuf = reinterpret_cast<volatile int*>(smem + kLdsNext / 4);
+
+  if (tid == 0) nextbuf[0] = (int)atomicAdd(K.counter, 1u);
+  rpe_stage_table(P, reinterpret_cast<f32x4*>(smem), tid, kPipeThreads);
+  __syncthreads();
+  int item = nextbuf[0];
+  int parity = 0;
+  const int ntiles = (nK + 15) >> 4;
+  const int qstride = H * kDh;
+
+  while (item < K.nitems) {
+    // ---- the item: batch b, query quad qt, key chunk `split` ---------------------------------------------------------------
+    int drawn = 0;
+    if (tid == 0) drawn = (int)atomicAdd(K.counter, 1u);  // the NEXT item; its latency hides behind this one
+    const int split = item % P.ksplit;
+    const int qt = (item / P.ksplit) % K.qtiles;
+    const int b = item / (P.ksplit * K.qtiles);
+    const int q0 = qt * 4;
+    const int tile_begin = split * P.tiles_per_split;
+    const int tile_end = min(ntiles, tile_begin + P.tiles_per_split);
+    const int qrow = q0 + g;                      // query of this lane's accumulator registers
+    const int q_role = min(q0 + gq, nQ - 1);      // query of the pairs this lane looks up
+    // A operand of QK^T: row c = (query c >> 2, head c & 3), d = 16 g + s
+    float qa[16];
+    {
+      const int qi = min(q0 + (c >> 2), nQ - 1);
+      const f32x4* src = reinterpret_cast<const f32x4*>(P.q + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh + 16 * g);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 v = src[s4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
+      }
+    }
+    // the role query's vertices: box test (the 4 queries of the item together), then the six numbers the box body needs
+    const float* role_vp = P.vertices + ((size_t)b * nQ + q_role) * 24;
+    PipeQuery Q;
+    Q.rc = 1.f; Q.rs = 0.f;
+    bool box;
+    {
+      float vx[8], vy[8], vz[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { vx[i] = role_vp[i * 3]; vy[i] = role_vp[i * 3 + 1]; vz[i] = role_vp[i * 3 + 2]; }
+      if (ROT) {
+        Q.rc = P.cos_sin[((size_t)b * nQ + q_role) * 2];
+        Q.rs = P.cos_sin[((size_t)b * nQ + q_role) * 2 + 1];
+        float ex, ey, ez;
+        box = __all(rpe_box_pattern_rot(vx, vy, vz, Q.rc, Q.rs, ex, ey, ez));
+        Q.x0 = vx[0]; Q.y0 = vy[0]; Q.z0 = vz[0];
+        Q.x1 = ex; Q.y1 = ey; Q.z1 = ez;
+      } else {
+        box = __all(rpe_box_pattern(vx, vy, vz));
+        Q.x0 = vx[0]; Q.x1 = vx[2]; Q.y0 = vy[0]; Q.y1 = vy[1]; Q.z0 = vz[0]; Q.z1 = vz[4];
+      }
+    }
+    PipeLane A;
+    A.kp = P.k + ((size_t)b * nK + c) * P.k_stride + 16 * g;
+    A.vp = P.v + ((size_t)b * nK + 4 * g) * P.v_stride + 4 * c;
+    A.xp = P.xyz + ((size_t)b * nK + c) * 3;
+    A.sp = P.scores ? P.scores + (((size_t)b * nQ + min(qrow, nQ - 1)) * H) * nK + c : nullptr;
+
+    f32x4 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[4] = {kNegBig, kNegBig, kNegBig, kNegBig}, l[4] = {0.f, 0.f, 0.f, 0.f};
+    PipeTile ops;
+    {
+      const int t0 = min(tile_begin + w, ntiles - 1);  // (a wave without a tile in this item fetches, but does not use)
+      pipe_fetch_k(P, A, t0, nK, c, ops);
+      pipe_fetch_x(A, t0, nK, c, ops);
+      pipe_fetch_v(P, A, t0, nK, g, ops);
+    }
+    if (box)
+      pipe_tiles<ROT ? kPipeBoxRot : kPipeBox>(P, tab, ppad, A, Q, role_vp, qa, ops, tile_begin, tile_end, w, b, qrow, g, c, swapped, o, m, l);
+    else
+      pipe_tiles<kPipeGeneral>(P, tab, ppad, A, Q, role_vp, qa, ops, tile_begin, tile_end, w, b, qrow, g, c, swapped, o, m, l);
+
+    // ---- merge of the 8 waves' online-softmax states: m / l per row (1 KB), then the accumulators in two halves of 16 KB ----
+    if (tid == 0) {
+      nextbuf[parity ^ 1] = drawn;
+      if (drawn == K.nitems + (int)gridDim.x - 1) atomicExch(K.counter, 0u);  // the launch's last draw: leave the word zero
+    }
+    __syncthreads();  // B0: everybody is past the previous item's reads of mlbuf / xch
+    if (c == 0) {
+      float* mine = mlbuf + (w * 4 + g) * 8;
+      *reinterpret_cast<f32x4*>(mine) = f32x4{m[0], m[1], m[2], m[3]};
+      *reinterpret_cast<f32x4*>(mine + 4) = f32x4{l[0], l[1], l[2], l[3]};
+    }
+    const int own_t = w >> 1, own_hi = w & 1;  // this wave finishes d-tile own_t, registers 2 own_hi + {0, 1}
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (half) __syncthreads();  // B2: half 0 has been read
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) xch[(w * 8 + t * 2 + hi) * kWave + lane] = o[t][2 * hi + half];
+      __syncthreads();  // B1 / B3
+      const int r = 2 * own_hi + half;
+      float M = kNegBig;
+      float mw[kPipeWaves], lw[kPipeWaves];
+#pragma unroll
+      for (int ww = 0; ww < kPipeWaves; ++ww) {
+        mw[ww] = mlbuf[(ww * 4 + g) * 8 + r];
+        lw[ww] = mlbuf[(ww * 4 + g) * 8 + 4 + r];
+        M = fmaxf(M, mw[ww]);
+      }
+      float L = 0.f, val = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < kPipeWaves; ++ww) {
+        const float f = __expf(mw[ww] - M);
+        L += lw[ww] * f;
+        val += xch[(ww * 8 + own_t * 2 + own_hi) * kWave + lane] * f;
+      }
+      if (qrow < nQ) {
+        const float inv = L > 0.f ? 1.f / L : 0.f;
+        const float lse = L > 0.f ? M + __logf(L) : kNegBig;
+        const int d = 4 * c + own_t;
+        const size_t row = ((size_t)b * nQ + qrow) * H + r;
+        if (P.ksplit == 1) {
+          P.out[row * kDh + d] = val * inv;
+          if (own_t == 0 && c == 0) P.lse[row] = lse;
+        } else {
+          const size_t rows = (size_t)P.B * nQ * H;
+          P.part_o[((size_t)split * rows + row) * kDh + d] = val * inv;
+          if (own_t == 0 && c == 0) P.part_lse[(size_t)split * rows + row] = lse;
+        }
+      }
+    }
+    parity ^= 1;
+    item = nextbuf[parity];  // written before B0 of this item
+  }
+}
+
+}  // namespace vdetr
+
+using namespace vdetr;
+
+namespace vdetr {
+// Launch of the persistent forward (called from attn_fwd.hip:vdetr_attn_fwd_f32 with P filled, the key split chosen and the
+// partial buffers placed).  `counter`: a zero device word (workspace head, see vdetr_attn_fwd_workspace_bytes).
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, hipStream_t st) {
+  PipeArgs K;
+  K.P = P;
+  K.counter = counter;
+  K.qtiles = (P.nQ + 3) / 4;
+  K.nitems = P.B * K.qtiles * P.ksplit;
+  const int grid = workgroups < K.nitems ? workgroups : K.nitems;
+  if (P.cos_sin) {
+    if (int e = set_lds(attn_fwd_rpe_pipe_kernel<true>, kPipeLdsBytes, "attn_fwd")) return e;
+    hipLaunchKernelGGL((attn_fwd_rpe_pipe_kernel<true>), dim3(grid), dim3(kPipeThreads), kPipeLdsBytes, st, K);
+  } else {
+    if (int e = set_lds(attn_fwd_rpe_pipe_kernel<false>, kPipeLdsBytes, "attn_fwd")) return e;
+    hipLaunchKernelGGL((attn_fwd_rpe_pipe_kernel<false>), dim3(grid), dim3(kPipeThreads), kPipeLdsBytes, st, K);
+  }
+  return check_launch("attn_fwd_pipe");
+}
+}  // namespace vdetr

@@ -34,6 +34,18 @@ inline int check_launch(const char* what) {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+int device_cu_count();  // core.hip
+
+// A/B switches.  The shipped library reads no environment variable: VDETR_AB(name, default) IS the default.  A probe build
+// (VDETR_EXTRA_HIPCC_FLAGS=-DVDETR_AB_SWITCHES, v-detr_amd/build.py) reads each switch once per process instead, which is how
+// the ladders in DESIGN.md were measured.  vdetr_ab_switches() tells a caller which build it loaded.
+#ifdef VDETR_AB_SWITCHES
+int ab_env(const char* name, int dflt);  // core.hip
+#define VDETR_AB(name, dflt) ([] { static const int v_ = vdetr::ab_env(name, dflt); return v_; }())
+#else
+#define VDETR_AB(name, dflt) (dflt)
+#endif
+
 // Raises a kernel's dynamic-LDS limit (needed above 64 KB) once per high-water mark, so that after the first
 // launches no runtime API call is left on the launch path (safe inside hipGraph capture).  core.hip.
 int reserve_lds(const void* kernel, size_t bytes, const char* op);

@@ -1,6 +1,8 @@
 // core.hip — error reporting + ABI version for libvdetr_hip.so.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <mutex>
 #include <unordered_map>
 
@@ -29,7 +31,33 @@ int reserve_lds(const void* kernel, size_t bytes, const char* op) {
   }
   return VDETR_OK;
 }
+
+// compute units of the current device (cached per device: no runtime query is left on the launch path after the first call)
+int device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+#ifdef VDETR_AB_SWITCHES
+int ab_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#endif
 }  // namespace vdetr
 
-extern "C" int vdetr_abi_version(void) { return 2; }
+extern "C" int vdetr_abi_version(void) { return 3; }
+extern "C" int vdetr_ab_switches(void) {
+#ifdef VDETR_AB_SWITCHES
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" const char* vdetr_last_error(void) { return vdetr::g_err; }

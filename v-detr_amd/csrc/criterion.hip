@@ -974,10 +974,7 @@ extern "C" int vdetr_lsa_f64(const vdetr_lsa_batch* batch, int32_t* status, vdet
   }
   // up to 4096 columns: <= 4 columns per lane in a 1024-thread workgroup; beyond: <= 8
   const bool small = nc_cap <= 4096;
-  static const int cols_per_lane = [] {
-    const char* e = getenv("VDETR_LSA_COLS");
-    return e ? atoi(e) : 4;
-  }();
+  const int cols_per_lane = VDETR_AB("VDETR_LSA_COLS", 4);
   const int cpl = cols_per_lane < 1 ? 1 : (cols_per_lane > 8 ? 8 : cols_per_lane);
   int threads = ((nc_cap + cpl - 1) / cpl + 63) & ~63;
   threads = threads > 1024 ? 1024 : threads;

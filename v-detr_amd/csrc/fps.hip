@@ -417,7 +417,7 @@ extern "C" int vdetr_furthest_point_sampling_f32(const float* xyz, int b, int n,
   P.xyz = xyz; P.idx = idx; P.n = n; P.m = m;
   P.nscenes = 0;
   P.ref_log2 = ref_log2_of(n); P.ref_block = 1 << P.ref_log2;
-  static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
+  const bool debug = VDETR_AB("VDETR_FPS_DEBUG", 0) != 0;
   if (debug) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_cyc), z, sizeof(z));

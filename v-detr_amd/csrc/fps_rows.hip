@@ -519,8 +519,8 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
 // ---- host --------------------------------------------------------------------------------------------------------
 
 bool fps_rows_plan(int nmax, RowsPlan* plan) {
-  static const int env_impl = getenv("VDETR_FPS_IMPL") ? atoi(getenv("VDETR_FPS_IMPL")) : 0;  // 2: fps.hip's kernel always
-  static const int env_waves = getenv("VDETR_FPS_WAVES") ? atoi(getenv("VDETR_FPS_WAVES")) : 0;
+  const int env_impl = VDETR_AB("VDETR_FPS_IMPL", 0);  // 2: fps.hip's kernel always
+  const int env_waves = VDETR_AB("VDETR_FPS_WAVES", 0);
   if (env_impl == 2 || nmax <= 0) return false;
   const long nb = ((long)nmax + kBP - 1) / kBP;
   int waves = (env_waves == 4 || env_waves == 8 || env_waves == 16) ? env_waves : 16;
@@ -553,11 +553,11 @@ static int launch_rows(RowsParams& P, int b, size_t lds, bool debug, hipStream_t
 }
 
 int fps_rows_launch(RowsParams& P, int b, const RowsPlan& pl, hipStream_t stream) {
-  static const bool debug = getenv("VDETR_FPS_DEBUG") != nullptr;
+  const bool debug = VDETR_AB("VDETR_FPS_DEBUG", 0) != 0;
   // VDETR_FPS_TREE: 0 = runs of 64 sorted points always; 1 (default) = tree leaves in the slots the runs need (a
   // second slot per owner lane costs more in the box test than the tighter boxes win: 4.92 vs 4.28 ms at 40k points);
   // 2 = room for 2 n / 64 + 64 leaves
-  static const int env_tree = getenv("VDETR_FPS_TREE") ? atoi(getenv("VDETR_FPS_TREE")) : 1;
+  const int env_tree = VDETR_AB("VDETR_FPS_TREE", 1);
   long capmax = 0, runmax = 0;
   for (int i = 0; i < b; ++i) {
     const long runs = ((long)P.scenes[i].n + kBP - 1) / kBP;

@@ -703,7 +703,7 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
   VDETR_REQUIRE(CA % 16 == 0, "sp_pairs_gemm: contraction width %d must be a multiple of 16", CA);
   hipStream_t st = (hipStream_t)stream;
 #ifdef VDETR_SP_PADTEST
-  static const int pad = getenv("VDETR_SP_LDS_PAD") ? atoi(getenv("VDETR_SP_LDS_PAD")) : 0;  // unused LDS: caps the workgroups per CU
+  const int pad = VDETR_AB("VDETR_SP_LDS_PAD", 0);  // unused LDS: caps the workgroups per CU
   if (pad > 0) {
     dim3 grid(ntiles, ceil_div(CB, 128));
     auto kern = transposed ? sp_pairs_gemm_kernel<true, 2, 2, 4, 4> : sp_pairs_gemm_kernel<false, 2, 2, 4, 4>;
@@ -721,7 +721,7 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
   } else {
     // persistent = 2 (default): one workgroup per CU, K-steps of 32 (the next 32 x (A, B) operands in flight under 128 MFMAs =
     // 1.7 us: covers a row fetched from HBM); 1: two workgroups per CU, K-steps of 16; 0: the plain kernel.  A/B switch.
-    static const int persistent = getenv("VDETR_SP_PERSISTENT") ? atoi(getenv("VDETR_SP_PERSISTENT")) : 2;
+    const int persistent = VDETR_AB("VDETR_SP_PERSISTENT", 2);
     const int ksub = persistent == 2 && CA % 64 == 0 ? 2 : 1;
     if (persistent && CA % 32 == 0) {
       // per-device state (CU count, work-counter ring), created under a lock on the device's first launch: a process may
@@ -742,23 +742,23 @@ extern "C" int vdetr_sp_pairs_gemm_f32(const float* x, const int32_t* arow, cons
       const int cus = D.cus;
       // workgroups per CU: the fp32 K-step of 32 is 1.7 us of MFMA (covers a gathered row's latency with one workgroup);
       // the split-bf16 one is 0.4 us: two workgroups keep twice the loads in flight (VDETR_SP_PER_CU overrides)
-      static const int split_pc = getenv("VDETR_SP_SPLIT") ? atoi(getenv("VDETR_SP_SPLIT")) : 1;
-      static const int per_cu_env = getenv("VDETR_SP_PER_CU") ? atoi(getenv("VDETR_SP_PER_CU")) : 0;
+      const int split_pc = VDETR_AB("VDETR_SP_SPLIT", 1);
+      const int per_cu_env = VDETR_AB("VDETR_SP_PER_CU", 0);
       const int per_cu = per_cu_env > 0 ? per_cu_env : (ksub == 2 && !split_pc ? 1 : 2);
       const int nwork = ntiles * ceil_div(CB, 128);
       // `spare` CUs are left to whatever else is running (A/B switch): with a grid of exactly one workgroup per CU, a CU that is
       // busy with another stream's long kernel (the next scene's 9 ms sampling) makes its workgroup start a round late
-      static const int spare = getenv("VDETR_SP_SPARE_CUS") ? atoi(getenv("VDETR_SP_SPARE_CUS")) : 0;
+      const int spare = VDETR_AB("VDETR_SP_SPARE_CUS", 0);
       const int slots = per_cu * (cus - spare) > 0 ? per_cu * (cus - spare) : 1;
       dim3 grid(nwork < slots ? nwork : slots);
       // VDETR_SP_SPLIT=0: exact fp32 products (v_mfma_f32_16x16x4_f32) everywhere; default: split-bf16 products where the
       // contraction is a multiple of 64 channels (the wide layers, which hold the time)
-      static const int split = getenv("VDETR_SP_SPLIT") ? atoi(getenv("VDETR_SP_SPLIT")) : 1;
+      const int split = VDETR_AB("VDETR_SP_SPLIT", 1);
       auto kern = ksub == 2 ? (split ? (transposed ? sp_pairs_gemm_persistent_kernel<true, 2, true> : sp_pairs_gemm_persistent_kernel<false, 2, true>)
                                      : (transposed ? sp_pairs_gemm_persistent_kernel<true, 2> : sp_pairs_gemm_persistent_kernel<false, 2>))
                             : (transposed ? sp_pairs_gemm_persistent_kernel<true, 1> : sp_pairs_gemm_persistent_kernel<false, 1>);
       int* ticket = nullptr;
-      static const int use_ticket = getenv("VDETR_SP_TICKET") ? atoi(getenv("VDETR_SP_TICKET")) : 1;  // A/B switch
+      const int use_ticket = VDETR_AB("VDETR_SP_TICKET", 1);  // A/B switch
       if (use_ticket) {  // a (work counter, exit counter) pair per launch out of a ring: launches of different streams may overlap
         constexpr unsigned kRing = 4096;
         if (!D.ring) {  // zeroed once; every launch leaves its pair zeroed again (the kernel's last workgroup resets it)
@@ -805,7 +805,7 @@ extern "C" int vdetr_sp_pairs_wgrad_f32(const float* x, const float* dy, const i
 #ifndef VDETR_SP_WGRAD_SB
 #define VDETR_SP_WGRAD_SB 16
 #endif
-    static const int split = getenv("VDETR_SP_SPLIT") ? atoi(getenv("VDETR_SP_SPLIT")) : 1;
+    const int split = VDETR_AB("VDETR_SP_SPLIT", 1);
     if (split)
       hipLaunchKernelGGL((sp_pairs_wgrad_kernel<2, 2, 4, 4, 32, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, pin, pout,
                          chunks, cin, cout, partials);

@@ -32,6 +32,7 @@ def init_distributed(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        _AVG_VERDICT.clear()  # verdicts of an earlier process group of this process do not carry over
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -431,8 +432,11 @@ class GradientReducer:
         reference gets from DistributedDataParallel's bucket hooks (main.py:515-517).  Call ``begin_watch()`` before every
         backward pass, ``pack_and_launch(pending_watched())`` + ``finish()`` after it."""
         assert self.flat is not None and not self.bucket_views
-        self._watched = {k: 0 for k in buckets}
-        self._watch_need = {k: 0 for k in buckets}
+        self._watched = {k: 0 for k in sorted(buckets)}
+        self._watch_need = {k: 0 for k in sorted(buckets)}
+        self._watch_order = sorted(buckets)   # the order the collectives are issued in, on EVERY rank
+        self._watch_skip = None               # buckets that never complete (an unused parameter), agreed by the ranks after step 1
+        self._watch_next = 0
         self._watch_seen = set()
         for p in self.flat.params:
             k = self._bucket_of.get(id(p))
@@ -444,6 +448,7 @@ class GradientReducer:
         for k in self._watched:
             self._watched[k] = 0
         self._watch_seen.clear()
+        self._watch_next = 0
 
     def _watch_hook(self, p):
         if id(p) in self._watch_seen:
@@ -451,16 +456,44 @@ class GradientReducer:
         self._watch_seen.add(id(p))
         k = self._bucket_of[id(p)]
         self._watched[k] += 1
-        if self._watched[k] == self._watch_need[k] and not self._launched[k]:
-            self.flat.pack_grads_span(*self._spans[k])
+        # A bucket leaves only when it and every EARLIER watched bucket are complete: the ranks then issue the same
+        # collectives in the same (ascending) order on the communicator whatever order autograd produced the gradients in on
+        # each of them — a rank with a parameter that got no gradient holds back the later buckets until
+        # pack_and_launch(pending_watched()), it does not reorder them (DistributedDataParallel's fixed bucket order).
+        order = self._watch_chain()
+        while self._watch_next < len(order):
+            j = order[self._watch_next]
+            if self._launched[j]:
+                self._watch_next += 1
+                continue
+            if self._watched[j] != self._watch_need[j]:
+                break
+            self.flat.pack_grads_span(*self._spans[j])
             if self.active:
-                self._launch(k)
+                self._launch(j)
             else:
-                self._launched[k] = True
+                self._launched[j] = True
+            self._watch_next += 1
+
+    def _watch_chain(self):
+        """the fixed issue order of the watched buckets: ascending, the structurally incomplete ones (agreed set) last"""
+        skip = self._watch_skip or ()
+        return [k for k in self._watch_order if k not in skip] + [k for k in self._watch_order if k in skip]
 
     def pending_watched(self):
-        """watched buckets that did not complete during the backward pass (a parameter without gradient)"""
-        return [k for k in getattr(self, "_watched", {}) if not self._launched[k]]
+        """watched buckets that did not leave during the backward pass (a parameter without gradient in one of them, or in an
+        earlier one of the chain), in chain order.  The FIRST call (every rank makes it once per step) agrees on the buckets that
+        never complete — the union over the ranks of this step's leftovers, one small MAX all-reduce: they go to the end of the
+        chain from the next step on, so that an unused parameter does not hold the buckets behind it back for good."""
+        if not hasattr(self, "_watch_order"):
+            return []
+        chain = self._watch_chain()
+        pend = [k for k in chain if not self._launched[k]]
+        if self._watch_skip is None and getattr(self, "_watch_incomplete", None) is None:
+            # incomplete HERE (not merely held back by an earlier bucket of the chain); agreed on in finish(), when every rank
+            # has issued all of this step's bucket collectives (the ranks may have issued different numbers of them so far)
+            self._watch_incomplete = [k for k in pend if self._watched[k] != self._watch_need[k]]
+        return pend
 
     def buckets_of(self, params):
         """indices of the buckets that hold these parameters"""
@@ -498,6 +531,15 @@ class GradientReducer:
             self._handles = []
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
+        if getattr(self, "_watch_incomplete", None) is not None and self._watch_skip is None:
+            mine = torch.zeros(len(self.buckets), dtype=torch.int32, device=self.buckets[0].device)
+            for k in self._watch_incomplete:
+                mine[k] = 1
+            if self.active:  # every bucket of the step is out on every rank: the same position in everybody's sequence
+                dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=self.group)
+            flags = mine.tolist()
+            self._watch_skip = {k for k in self._watch_order if flags[k]}
+            self._watch_incomplete = None
         self._pending = list(self._counts)
         self._launched = [False] * len(self.buckets)
         self._seen.clear()
@@ -526,13 +568,26 @@ class GradientReducer:
 _AVG_VERDICT = {}
 
 
+def destroy_distributed():
+    """dist.destroy_process_group() + the per-group caches of this module"""
+    _AVG_VERDICT.clear()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def avg_reduce_supported(group=None, device=None):
     """True iff EVERY rank of the group may use ``ReduceOp.AVG`` (ncclAvg: NCCL / RCCL >= 2.10).  Each rank reads its own
     library version (no collective is attempted to find out), the verdicts are combined with a MIN all-reduce, and the
     result is cached per group: all ranks take the same branch in GradientReducer._allreduce_avg from the first call on."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    key = id(group) if group is not None else 0
+    # keyed by what the verdict depends on — the backend and the ranks of the group — not by the group object's id (which
+    # a later group may reuse); init_distributed / destroy clear the cache
+    try:
+        ranks = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    except Exception:  # noqa: BLE001
+        ranks = (dist.get_world_size(group),)
+    key = (dist.get_backend(group), ranks)
     if key in _AVG_VERDICT:
         return _AVG_VERDICT[key]
     if dist.get_backend(group) != "nccl":

@@ -114,8 +114,12 @@ def defer_weight_grads(enable=True):
         from .attention import DeferredTableGrads
         DeferredTableGrads.pending.clear()
         DeferredTableGrads._begun.clear()
-        from .attention import SideResults
-        SideResults.pending.clear()
+        DeferredTableGrads.buffers.clear()
+        DeferredTableGrads._outputs.clear()
+        DeferredTableGrads._buffer_keys.clear()
+        from . import attention
+        attention.SideResults.pending.clear()
+        attention.side_late[:] = []  # closures handed over for the end of a backward pass that will not come
 
 
 def weight_grads_deferred():
