@@ -368,6 +368,72 @@ typedef struct vdetr_addln_reduce {
 int vdetr_add_ln_param_reduce_batch_f32(const vdetr_addln_reduce* items, int n, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * The decoder layer's glue between its attention cores, three launches per layer (rowblock.hip).
+ * Replaces the ~13 launches of GlobalDecoderLayer.forward_pre (models/vdetr_transformer.py:531-568) between
+ * nn.MultiheadAttention's core, GlobalShareCrossAttention's core and the next layer: the q / k / v projections (:541-542,
+ * in_proj of :468), out_proj + dropout1 + residual + norm2 + the cross attention's q projection (:543-545, :733), and
+ * proj + proj_drop + dropout2 + residual + norm3 + linear1 + relu + dropout + linear2 + dropout3 + residual (+ the norms the
+ * decoder applies to the layer output, :401 / :433) (:556-567, :755-757).  d_model = dim_feedforward = 256.
+ * Rows are numbered as the decoder's sequence-first tensors lay them out (row = q * B + b); the attention cores' operands
+ * (`a`, `qout`, `out`) are batch-first [B, nQ, 256].  Exact fp32 products (v_mfma_f32_16x16x4_f32).  The dropout masks are
+ * those of vdetr_add_ln_fwd_f32 / vdetr_relu_dropout_fwd_f32 for the same (p, seed, rng_state), and every tensor their
+ * backward entry points read is written: the backward of a fused launch is the backward of the launches it replaces.
+ * All pointers 16-B aligned.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vdetr_rb_linear {
+  const float* w; /* [256, 256] (out, in): nn.Linear.weight */
+  const float* b; /* [256] or NULL */
+} vdetr_rb_linear;
+typedef struct vdetr_rb_norm {
+  const float *gamma, *beta; /* [256] */
+  float eps;
+} vdetr_rb_norm;
+typedef struct vdetr_rb_drop {
+  float p;       /* 0 = off */
+  uint64_t seed; /* the launch's salt; offset 0; folded with rng_state as in vdetr_addln_desc */
+} vdetr_rb_drop;
+
+typedef struct vdetr_rb_qkv_desc {
+  int32_t rows, B;
+  const float* t;   /* [rows,256] norm1(tgt) */
+  const float* pos; /* [rows,256] or NULL: q and k project t + pos, v projects t (:540-542) */
+  const float* w;   /* [768,256] in_proj_weight: q | k | v blocks */
+  const float* b;   /* [768] or NULL */
+  float* x;         /* [rows,256] t + pos, written (operand of the q / k weight gradients); required with pos */
+  float* out;       /* [3][B,nQ,256] batch-first q | k | v */
+} vdetr_rb_qkv_desc;
+int vdetr_rb_qkv_f32(const vdetr_rb_qkv_desc* d, vdetr_stream_t stream);
+
+typedef struct vdetr_rb_projq_desc {
+  int32_t rows, B;
+  const uint64_t* rng_state; /* device {seed, offset} of the step, or NULL */
+  const float* a;   /* [B,nQ,256] self-attention core output */
+  const float* tgt; /* [rows,256] residual stream */
+  const float* pos; /* [rows,256] or NULL */
+  vdetr_rb_linear proj, q;
+  vdetr_rb_drop drop1;
+  vdetr_rb_norm norm2;
+  float *y, *mean_y, *rstd_y, *t2; /* y = tgt + drop1(proj a) [rows,256]; statistics of y [rows]; t2 = norm2(y) */
+  float* xq;   /* [rows,256] t2 + pos (operand of the q weight gradient); required with pos */
+  float* qout; /* [B,nQ,256] (t2 + pos) Wq^T + bq */
+} vdetr_rb_projq_desc;
+int vdetr_rb_proj_q_f32(const vdetr_rb_projq_desc* d, vdetr_stream_t stream);
+
+typedef struct vdetr_rb_ffn_desc {
+  int32_t rows, B;
+  const uint64_t* rng_state;
+  const float* a;   /* [B,nQ,256] cross-attention core output */
+  const float* tgt; /* [rows,256] residual stream */
+  vdetr_rb_linear proj, lin1, lin2;
+  vdetr_rb_drop drop2, drop_act, drop3; /* drop2: proj_drop and dropout2 as one mask (keep probability the product) */
+  vdetr_rb_norm norm3, post1, post2;    /* post2.gamma == NULL: one output norm */
+  float *y, *mean_y, *rstd_y, *t2;      /* y = tgt + drop2(proj a); statistics; t2 = norm3(y) */
+  float* h;                             /* drop_act(relu(lin1 t2)) */
+  float *z, *mean_z, *rstd_z, *o1, *o2; /* z = y + drop3(lin2 h); statistics; o1 = post1(z), o2 = post2(z) */
+} vdetr_rb_ffn_desc;
+int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * y = dropout(relu(BatchNorm1d(x))) on [B, C, N]: the hidden blocks of GenericMLP (models/helpers.py:74-141,
  * Conv1d -> BatchNorm1d -> ReLU -> Dropout; the box heads of models/vdetr_transformer.py:193-242 and
  * PositionEmbeddingLearned, helpers.py:17-33).  One launch forward, one backward.

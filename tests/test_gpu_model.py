@@ -472,3 +472,94 @@ def test_morton_order_equals_the_tensor_expression(B, N):
     codes = torch.empty((B, N), dtype=torch.int32, device="cuda")
     L.check(L.lib().vdetr_morton_order_f32(L.ptr(dev), B, N, L.ptr(codes), None, L.stream_ptr()), "morton_order")
     assert torch.equal(codes.cpu().long(), ref_codes)
+
+
+def _zero_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(m.dropout, float):   # MultiheadSelfAttention keeps its rate as a number
+            m.dropout = 0.0
+
+
+@pytest.mark.parametrize("cfg", ["c2"])
+def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
+    """What bench.py times, checked whole: BASELINE config 2 (40k-point scene, 4096 keys, 1024 queries, 8 RPE layers, 9 head
+    stages) in TRAIN mode (batch statistics in the heads; dropout rates 0 so that the two sides draw no random numbers), with the
+    step's machinery ON — fused glue launches, the table gradient on the side stream, weight gradients parked and flushed —
+    against the same model on the CPU with the native entry points routed to the oracle: the boxes / logits of all 9 stages at
+    1e-3, the gradient of the backbone features, and the gradient of EVERY parameter (RPE table MLPs included).
+    Queries are matched by the token they were proposed from: the top-1024 selection is compared as a set, so a swap of two
+    neighbours in the sorted order (objectness equal to the last bit) is not an error."""
+    import copy
+    import bench
+    from vdetr_amd import runtime
+    npts, bs, npre, nq, nl, angle_type, _ = bench.CONFIGS[cfg]
+    model = _make_model(nq=nq, npre=npre, nl=nl, angle_type=angle_type).train()
+    _zero_dropout(model)
+    inp_cpu = _inputs(npts, 3, "cpu", bs)
+    gpu_model = copy.deepcopy(model).to(DEV)
+    inp_gpu = {k: ([t.detach().to(DEV).requires_grad_(t.requires_grad) for t in v] if isinstance(v, list) else v.to(DEV))
+               for k, v in inp_cpu.items()}
+    runtime.defer_weight_grads(True)
+    try:
+        out_gpu = gpu_model(inp_gpu)
+        _loss(out_gpu).backward()
+        runtime.flush_weight_grads()
+    finally:
+        runtime.defer_weight_grads(False)
+    torch.cuda.synchronize()
+    # ---- CPU with the oracle behind the native entry points (test fixture only)
+    import vdetr_amd.attention as A
+    import vdetr_amd.pointnet2_utils as PU
+    from conftest import _OracleExt
+    from oracle.attention_oracle import fused_attention_reference
+    monkeypatch.setattr(A, "fused_attention", fused_attention_reference)
+    monkeypatch.setattr(A, "begin_step", lambda device: None)
+    monkeypatch.setattr(A, "current_rng", lambda device: None)
+    monkeypatch.setattr(PU, "_ext", _OracleExt())
+    import vdetr_amd.box_decode as BD
+    from oracle.box_oracle import decode_boxes_reference
+    monkeypatch.setattr(BD, "decode_boxes", decode_boxes_reference)
+    import vdetr_amd.add_ln as ALN
+    from oracle import add_ln_oracle
+    monkeypatch.setattr(ALN, "layer_norm", add_ln_oracle.layer_norm)
+    monkeypatch.setattr(ALN, "add_dropout_layer_norm", add_ln_oracle.add_dropout_layer_norm)
+    import os
+    torch.set_num_threads(min(32, os.cpu_count() or 1))  # (torch's intra-op pool stops scaling well before a 256-thread host is full)
+    out_cpu = model(inp_cpu)
+    _loss(out_cpu).backward()
+    assert torch.equal(out_gpu["seed_inds"].cpu(), out_cpu["seed_inds"])          # FPS: bit-exact
+    stages_g = out_gpu["aux_outputs"] + [out_gpu["outputs"]]
+    stages_c = out_cpu["aux_outputs"] + [out_cpu["outputs"]]
+    keys = ("sem_cls_logits", "center_unnormalized", "size_unnormalized", "box_corners", "angle_continuous")
+    for k in keys:  # stage 0: all 4096 tokens
+        assert_close(stages_g[0][k], stages_c[0][k].detach().numpy(), 1e-3, 2e-4, f"stage 0 {k}")
+    # the proposals: top-nq tokens by stage-0 objectness, on each side
+    top_g = torch.topk(stages_g[0]["objectness_prob"].detach().cpu(), nq, dim=1)[1]
+    top_c = torch.topk(stages_c[0]["objectness_prob"].detach(), nq, dim=1)[1]
+    same_order = torch.equal(top_g, top_c)
+    for b in range(bs):
+        sg, sc = set(top_g[b].tolist()), set(top_c[b].tolist())
+        assert len(sg & sc) >= nq - 2, f"scene {b}: the two sides propose different tokens ({nq - len(sg & sc)} of {nq})"
+        pos_c = {t: i for i, t in enumerate(top_c[b].tolist())}
+        rows_g = [i for i, t in enumerate(top_g[b].tolist()) if t in pos_c]
+        rows_c = [pos_c[top_g[b, i].item()] for i in rows_g]
+        for s in range(1, len(stages_g)):
+            for k in keys:
+                assert_close(stages_g[s][k][b][rows_g], stages_c[s][k][b][rows_c].detach().numpy(), 1e-3, 2e-4, f"stage {s} {k} (scene {b})")
+    for fg, fc in zip(inp_gpu["backbone_features"], inp_cpu["backbone_features"]):
+        assert_close(fg.grad, fc.grad.numpy(), 5e-3, 1e-3 * float(fc.grad.abs().max()), "d loss / d backbone features")
+    if same_order:  # (with a different proposal order the query embeddings' rows are permuted: the sets above already matched)
+        bad = []
+        for (n, pg), (_, pc) in zip(gpu_model.named_parameters(), model.named_parameters()):
+            if pc.grad is None:
+                assert pg.grad is None or float(pg.grad.abs().max()) == 0.0, n
+                continue
+            assert pg.grad is not None, f"{n}: no gradient on the device"
+            g, c = pg.grad.detach().cpu().double(), pc.grad.double()
+            scale = float(c.abs().max())
+            err = float((g - c).abs().max())
+            if err > 2e-3 * scale + 1e-6:
+                bad.append((n, err, scale))
+        assert not bad, "parameter gradients off: " + ", ".join(f"{n}: {e:.2e} of {s:.2e}" for n, e, s in bad[:8])

@@ -1,0 +1,131 @@
+"""The decoder layer's fused glue launches (csrc/rowblock.hip, v-detr_amd/rowblock.py) against the composition of separate
+launches they replace (helpers.linear, add_ln.add_dropout_layer_norm, bn_act.relu_dropout): same dropout streams, so values
+and gradients must agree to fp32 rounding of a different summation order."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import args_ns
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(a, b, what, rtol=2e-4, frac=2e-5):
+    a, b = a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=frac * max(np.abs(b).max(), 1e-6), err_msg=what)
+
+
+def _layer(seed=0):
+    from oracle.param_fill import fill_module
+    from vdetr_amd.vdetr_transformer import GlobalDecoderLayer
+    torch.manual_seed(seed)
+    layer = GlobalDecoderLayer(d_model=256, nhead=4, dim_feedforward=256, dropout=0.1, pos_for_key=False, args=args_ns())
+    fill_module(layer)
+    with torch.no_grad():
+        for m in layer.multihead_attn.cpb_mlps:
+            m[0].weight.mul_(2.0)
+            m[2].weight.mul_(1.5)
+        for ln in (layer.norm1, layer.norm2, layer.norm3):
+            ln.weight.add_(0.2 * torch.randn(256))
+            ln.bias.add_(0.1 * torch.randn(256))
+    return layer.to(DEV)
+
+
+def _scene(B, nQ, nK, seed):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand((B, nK, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0]) + 1.0
+    centre = xyz[:, torch.randint(0, nK, (nQ,), generator=g)]
+    half = 0.1 + torch.rand((B, nQ, 1, 3), generator=g)
+    signs = torch.tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]], dtype=torch.float32)
+    verts = centre[:, :, None, :] + half * signs
+    return xyz.to(DEV), verts.contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("B,nQ,nK,train", [(1, 64, 256, True), (1, 37, 100, True), (2, 40, 130, True), (1, 64, 256, False), (3, 17, 64, True)])
+def test_fused_layer_equals_separate_launches(monkeypatch, B, nQ, nK, train):
+    """GlobalDecoderLayer.forward_pre through rowblock.py (three launches between the attention cores) and through one launch per
+    op: output, the two output norms, and the gradients of every input and parameter."""
+    from vdetr_amd import attention as A
+    from vdetr_amd import vdetr_transformer as T
+    layer = _layer(3)
+    layer.train(train)
+    out_norm, next_norm = torch.nn.LayerNorm(256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        out_norm.weight.add_(0.1 * torch.randn(256, device=DEV))
+        next_norm.bias.add_(0.1 * torch.randn(256, device=DEV))
+    g = torch.Generator().manual_seed(B * 100 + nQ)
+    tgt0 = torch.randn((nQ, B, 256), generator=g).to(DEV)
+    mem0 = torch.randn((nK, B, 256), generator=g).to(DEV)
+    pos0 = (0.5 * torch.randn((nQ, B, 256), generator=g)).to(DEV)
+    xyz, verts = _scene(B, nQ, nK, 5)
+    wts = [torch.randn((nQ, B, 256), generator=g).to(DEV) for _ in range(3)]
+    params = list(layer.parameters()) + list(out_norm.parameters()) + list(next_norm.parameters())
+    names = [n for n, _ in layer.named_parameters()] + ["out_norm.weight", "out_norm.bias", "next_norm.weight", "next_norm.bias"]
+
+    def run(fused):
+        monkeypatch.setattr(T, "_ROWBLOCK", fused)
+        A.reset_rng()
+        torch.manual_seed(0)
+        for p in params:
+            p.grad = None
+        tgt, mem, pos = (t.clone().requires_grad_(True) for t in (tgt0, mem0, pos0))
+        layer.post_norms = (out_norm, next_norm)
+        layer.pre_normed = None
+        out, _ = layer(tgt, mem, verts, None, xyz, None, query_pos=pos)
+        o1, o2 = layer.post_normed
+        layer.post_norms = layer.post_normed = None
+        ((out * wts[0]).sum() + (o1 * wts[1]).sum() + (o2 * wts[2]).sum()).backward()
+        return [out, o1, o2, tgt.grad, mem.grad, pos.grad] + [p.grad for p in params]
+
+    ref = run(False)
+    got = run(True)
+    again = run(True)
+    for n, a, b, c in zip(["out", "norm(out)", "next norm1(out)", "d tgt", "d memory", "d query_pos"] + names, got, ref, again):
+        if b is None:
+            assert a is None, n
+            continue
+        _close(a, b, n)
+        assert torch.equal(a, c), f"{n}: not reproducible"
+
+
+def test_fused_layer_parks_weight_gradients(monkeypatch):
+    """with runtime.defer_weight_grads() the fused launches park their weight / bias / LayerNorm gradients like the separate
+    ones: after the flush every parameter holds the same gradient as without parking"""
+    from vdetr_amd import attention as A
+    from vdetr_amd import runtime
+    from vdetr_amd import vdetr_transformer as T
+    monkeypatch.setattr(T, "_ROWBLOCK", True)
+    layer = _layer(4).train()
+    out_norm = torch.nn.LayerNorm(256).to(DEV)
+    B, nQ, nK = 1, 48, 128
+    g = torch.Generator().manual_seed(7)
+    tgt0, mem0, pos0 = (torch.randn(s, generator=g).to(DEV) for s in ((nQ, B, 256), (nK, B, 256), (nQ, B, 256)))
+    xyz, verts = _scene(B, nQ, nK, 6)
+    params = list(layer.parameters()) + list(out_norm.parameters())
+
+    def run(defer):
+        runtime.defer_weight_grads(defer)
+        try:
+            A.reset_rng()
+            for p in params:
+                p.grad = None
+            tgt = tgt0.clone().requires_grad_(True)
+            layer.post_norms = (out_norm,)
+            out, _ = layer(tgt, mem0, verts, None, xyz, None, query_pos=pos0)
+            (o1,) = layer.post_normed
+            layer.post_norms = layer.post_normed = None
+            (out.sum() + (o1 * o1).sum()).backward()
+            if defer:
+                runtime.flush_weight_grads()
+            return [tgt.grad] + [p.grad.clone() if p.grad is not None else None for p in params]
+        finally:
+            runtime.defer_weight_grads(False)
+
+    ref, got = run(False), run(True)
+    for n, a, b in zip(["d tgt"] + [n for n, _ in layer.named_parameters()] + ["out_norm.weight", "out_norm.bias"], got, ref):
+        if b is None:
+            assert a is None, n
+        else:
+            _close(a, b, n)

@@ -112,6 +112,14 @@ if __name__ == "__main__":
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 20
     rng = A.begin_step(dev)
     ok = True
+    if "--only" in sys.argv:  # one kernel, `reps` launches: the process a rocprofv3 --pmc pass wraps
+        kern = 0 if sys.argv[sys.argv.index("--only") + 1] == "pipe" else 1
+        _, bs, nK, nQ, *_ = bench.CONFIGS[cfg]
+        r = Runner(make_case(bs, nQ, nK, bench.CONFIGS[cfg][5] == "object_coords", False, dev), kern, 0.1, True, rng)
+        for _ in range(reps):
+            r()
+        torch.cuda.synchronize()
+        sys.exit(0)
     if "--cases" in sys.argv:
         for (B, nQ, nK, rot, general, drop, store) in [(1, 64, 512, False, False, 0.1, True), (2, 37, 203, False, False, 0.0, True),
                                                        (2, 37, 203, True, False, 0.1, False), (1, 50, 1000, False, True, 0.0, True),
@@ -131,6 +139,8 @@ if __name__ == "__main__":
             for _ in range(12):
                 PU.furthest_point_sample(pts, 4096)
     t = time_pair(case, 0.1, reps, rng)
+    torch.cuda.synchronize()
+    ok &= compare(case, 0.1, True, rng, cfg + " (after the timed launches)")
     t.update({"config": cfg, "with_fps": "--with-fps" in sys.argv, "all_ok": bool(ok)})
     print(json.dumps(t), flush=True)
     sys.exit(0 if ok else 1)

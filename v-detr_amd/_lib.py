@@ -86,6 +86,47 @@ class AddLnReduce(ctypes.Structure):
                 ("d_gamma2", c_void_p), ("d_beta2", c_void_p)]
 
 
+class RbLinear(ctypes.Structure):
+    """Mirror of ``vdetr_rb_linear``."""
+
+    _fields_ = [("w", c_void_p), ("b", c_void_p)]
+
+
+class RbNorm(ctypes.Structure):
+    """Mirror of ``vdetr_rb_norm``."""
+
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float)]
+
+
+class RbDrop(ctypes.Structure):
+    """Mirror of ``vdetr_rb_drop``."""
+
+    _fields_ = [("p", c_float), ("seed", ctypes.c_uint64)]
+
+
+class RbQkvDesc(ctypes.Structure):
+    """Mirror of ``vdetr_rb_qkv_desc``."""
+
+    _fields_ = [("rows", ctypes.c_int32), ("B", ctypes.c_int32)] + [(n, c_void_p) for n in ("t", "pos", "w", "b", "x", "out")]
+
+
+class RbProjQDesc(ctypes.Structure):
+    """Mirror of ``vdetr_rb_projq_desc``."""
+
+    _fields_ = ([("rows", ctypes.c_int32), ("B", ctypes.c_int32)] + [(n, c_void_p) for n in ("rng_state", "a", "tgt", "pos")] +
+                [("proj", RbLinear), ("q", RbLinear), ("drop1", RbDrop), ("norm2", RbNorm)] +
+                [(n, c_void_p) for n in ("y", "mean_y", "rstd_y", "t2", "xq", "qout")])
+
+
+class RbFfnDesc(ctypes.Structure):
+    """Mirror of ``vdetr_rb_ffn_desc``."""
+
+    _fields_ = ([("rows", ctypes.c_int32), ("B", ctypes.c_int32)] + [(n, c_void_p) for n in ("rng_state", "a", "tgt")] +
+                [("proj", RbLinear), ("lin1", RbLinear), ("lin2", RbLinear), ("drop2", RbDrop), ("drop_act", RbDrop), ("drop3", RbDrop),
+                 ("norm3", RbNorm), ("post1", RbNorm), ("post2", RbNorm)] +
+                [(n, c_void_p) for n in ("y", "mean_y", "rstd_y", "t2", "h", "z", "mean_z", "rstd_z", "o1", "o2")])
+
+
 class BnActDesc(ctypes.Structure):
     """Mirror of ``vdetr_bnact_desc``."""
 
@@ -234,6 +275,9 @@ _SIGNATURES = {
     "vdetr_sp_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vdetr_sp_bn_act_fwd_f32": (c_int, [ctypes.POINTER(SpBnDesc), c_void_p]),
     "vdetr_sp_bn_act_bwd_f32": (c_int, [ctypes.POINTER(SpBnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vdetr_rb_qkv_f32": (c_int, [ctypes.POINTER(RbQkvDesc), c_void_p]),
+    "vdetr_rb_proj_q_f32": (c_int, [ctypes.POINTER(RbProjQDesc), c_void_p]),
+    "vdetr_rb_ffn_f32": (c_int, [ctypes.POINTER(RbFfnDesc), c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

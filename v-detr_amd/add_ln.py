@@ -132,41 +132,49 @@ class _AddLN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_y, d_out, d_out2):
-        rows, C, eps, p, salt, has_r = ctx.cfg
         ysrc, gamma, gamma2, mean, rstd, rng = ctx.saved_tensors
         if d_y is None and d_out is None and d_out2 is None:
             return (None,) * 10
         cont = lambda t: t.contiguous() if t is not None else None
-        d_y, d_out, d_out2 = cont(d_y), cont(d_out), cont(d_out2)
-        # the backward kernel only tests `r` for NULL; `y` / `x` carry the normalised tensor
-        d = _desc(rows, C, eps, p, salt, rng, dict(x=ysrc, r=ysrc if has_r else None, gamma=gamma, beta=gamma, gamma2=gamma2,
-                                                    beta2=gamma2, y=ysrc if has_r else None, mean=mean, rstd=rstd))
-        g = L.AddLnGrads()
-        d_x = torch.empty_like(ysrc)
-        d_r = torch.empty_like(ysrc) if (has_r and p > 0.0) else None
-        nbytes = L.lib().vdetr_add_ln_bwd_workspace_bytes(ctypes.byref(d))
-        # parameter sums after the backward, all LayerNorms in one launch (see DeferredLnGrads): the kernel only leaves
-        # its per-workgroup partial sums, in a buffer of their own
-        defer = DeferredParamGrads.enabled and DeferredParamGrads.direct and (d_out2 is not None or gamma2 is None)
-        if defer:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=ysrc.device)
-            d_gamma = d_beta = d_gamma2 = d_beta2 = None
-            DeferredLnGrads.pending.append((ws, nbytes // (16 * C), C, ctx.ln_params, d_out2 is not None))
-        else:
-            d_gamma, d_beta = torch.empty_like(gamma), torch.empty_like(gamma)
-            d_gamma2 = torch.empty_like(gamma2) if d_out2 is not None else None
-            d_beta2 = torch.empty_like(gamma2) if d_out2 is not None else None
-            ws = L.workspace(nbytes, ysrc.device)
-        for k, t in (("d_out", d_out), ("d_out2", d_out2), ("d_y", d_y), ("d_x", d_x), ("d_r", d_r), ("d_gamma", d_gamma),
-                     ("d_beta", d_beta), ("d_gamma2", d_gamma2), ("d_beta2", d_beta2), ("partials", ws)):
-            setattr(g, k, t.data_ptr() if t is not None else None)
-        L.check(L.lib().vdetr_add_ln_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "add_ln_bwd")
-        if defer:
-            return d_x, (d_r if d_r is not None else d_x) if has_r else None, None, None, None, None, None, None, None, None
-        if d_out2 is None and gamma2 is not None:
-            d_gamma2, d_beta2 = torch.zeros_like(gamma2), torch.zeros_like(gamma2)
+        has_r = ctx.cfg[5]
+        d_x, d_r, d_gamma, d_beta, d_gamma2, d_beta2 = backward_core(ctx.cfg, ysrc, gamma, gamma2, mean, rstd, rng, ctx.ln_params,
+                                                                      cont(d_y), cont(d_out), cont(d_out2))
         # without dropout the branch gradient IS the residual gradient
         return d_x, (d_r if d_r is not None else d_x) if has_r else None, d_gamma, d_beta, d_gamma2, d_beta2, None, None, None, None
+
+
+def backward_core(cfg, ysrc, gamma, gamma2, mean, rstd, rng, ln_params, d_y, d_out, d_out2):
+    """One vdetr_add_ln_bwd_f32 launch on the tensors a forward launch left (this module's, or a fused launch that writes the
+    same ones: rowblock.py).  cfg = (rows, C, eps, p, salt, has_r); gradients contiguous or None.  Returns (d_x, d_r, d_gamma,
+    d_beta, d_gamma2, d_beta2): d_r is None without dropout (the branch gradient is then d_x); the parameter sums are None when
+    they are parked for the flush (DeferredLnGrads, `ln_params` = the four parameter tensors they are delivered to)."""
+    rows, C, eps, p, salt, has_r = cfg
+    # the backward kernel only tests `r` for NULL; `y` / `x` carry the normalised tensor
+    d = _desc(rows, C, eps, p, salt, rng, dict(x=ysrc, r=ysrc if has_r else None, gamma=gamma, beta=gamma, gamma2=gamma2,
+                                                beta2=gamma2, y=ysrc if has_r else None, mean=mean, rstd=rstd))
+    g = L.AddLnGrads()
+    d_x = torch.empty_like(ysrc)
+    d_r = torch.empty_like(ysrc) if (has_r and p > 0.0) else None
+    nbytes = L.lib().vdetr_add_ln_bwd_workspace_bytes(ctypes.byref(d))
+    # parameter sums after the backward, all LayerNorms in one launch (see DeferredLnGrads): the kernel only leaves
+    # its per-workgroup partial sums, in a buffer of their own
+    defer = DeferredParamGrads.enabled and DeferredParamGrads.direct and (d_out2 is not None or gamma2 is None)
+    if defer:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=ysrc.device)
+        d_gamma = d_beta = d_gamma2 = d_beta2 = None
+        DeferredLnGrads.pending.append((ws, nbytes // (16 * C), C, ln_params, d_out2 is not None))
+    else:
+        d_gamma, d_beta = torch.empty_like(gamma), torch.empty_like(gamma)
+        d_gamma2 = torch.empty_like(gamma2) if d_out2 is not None else None
+        d_beta2 = torch.empty_like(gamma2) if d_out2 is not None else None
+        ws = L.workspace(nbytes, ysrc.device)
+    for k, t in (("d_out", d_out), ("d_out2", d_out2), ("d_y", d_y), ("d_x", d_x), ("d_r", d_r), ("d_gamma", d_gamma),
+                 ("d_beta", d_beta), ("d_gamma2", d_gamma2), ("d_beta2", d_beta2), ("partials", ws)):
+        setattr(g, k, t.data_ptr() if t is not None else None)
+    L.check(L.lib().vdetr_add_ln_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "add_ln_bwd")
+    if not defer and d_out2 is None and gamma2 is not None:
+        d_gamma2, d_beta2 = torch.zeros_like(gamma2), torch.zeros_like(gamma2)
+    return d_x, d_r, d_gamma, d_beta, d_gamma2, d_beta2
 
 
 def layer_norm(x, ln, ln2=None):

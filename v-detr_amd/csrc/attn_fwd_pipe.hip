@@ -297,7 +297,15 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
   float* xch = smem + kLdsXch / 4;
   volatile int* nextbuf = reinterpret_cast<volatile int*>(smem + kLdsNext / 4);
 
-  if (tid == 0) nextbuf[0] = (int)atomicAdd(K.counter, 1u);
+  // Every workgroup draws until it gets an index >= nitems: nitems + gridDim.x draws per launch, and whoever makes the LAST one
+  // (value nitems + gridDim.x - 1) puts the word back to zero for the next launch — also when that is a workgroup's first draw
+  // (one that got its CU only after the others had taken every item).
+  const int last_draw = K.nitems + (int)gridDim.x - 1;
+  if (tid == 0) {
+    const int first = (int)atomicAdd(K.counter, 1u);
+    nextbuf[0] = first;
+    if (first == last_draw) atomicExch(K.counter, 0u);
+  }
   rpe_stage_table(P, reinterpret_cast<f32x4*>(smem), tid, kPipeThreads);
   __syncthreads();
   int item = nextbuf[0];
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
     // ---- merge of the 8 waves' online-softmax states: m / l per row (1 KB), then the accumulators in two halves of 16 KB ----
     if (tid == 0) {
       nextbuf[parity ^ 1] = drawn;
-      if (drawn == K.nitems + (int)gridDim.x - 1) atomicExch(K.counter, 0u);  // the launch's last draw: leave the word zero
+      if (drawn == last_draw) atomicExch(K.counter, 0u);
     }
     __syncthreads();  // B0: everybody is past the previous item's reads of mlbuf / xch
     if (c == 0) {

@@ -1,0 +1,420 @@
+// rowblock.hip — the decoder layer's glue between its attention kernels as THREE launches (round 5).
+//
+// Reference: GlobalDecoderLayer.forward_pre (models/vdetr_transformer.py:531-568).  Between the self-attention core, the
+// cross-attention core and the next layer the reference (and rounds 1-4 of this library) run ~13 launches per layer on
+// [nQ, 256] tensors of 1 MB: position adds, 8 projections of [nQ x 256] x [256 x 256], three dropout + residual + LayerNorm
+// blocks, the FFN's relu + dropout.  Every one of them pays the ~4.5 us a dispatch costs whatever its size, the
+// library GEMMs 7-9 us each.  A 16-row block of the activations is 16 KB: it fits a workgroup's LDS / registers for the whole
+// chain, and each element of the chain is row-local (LayerNorm included).  So:
+//   rb_qkv_kernel   x = tgt2 + pos;  q = x Wq^T + bq,  k = x Wk^T + bk,  v = tgt2 Wv^T + bv           (the self-attention's operands)
+//   rb_proj_q_kernel   y = tgt + drop(a Wo^T + bo);  t2 = LN(y);  x = t2 + pos;  q = x Wq^T + bq         (behind the self-attention)
+//   rb_ffn_kernel   y = tgt + drop(a Wp^T + bp);  t2 = LN(y);  h = drop(relu(t2 W1^T + b1));
+//                   z = y + drop(h W2^T + b2);  o1 = LN(z; g1, b1') [, o2 = LN(z; g2, b2')]           (behind the cross-attention)
+// One workgroup = 16 rows x all 256 columns, 4 waves; wave w owns columns 64 w .. 64 w + 63 as four 16-column MFMA tiles
+// (v_mfma_f32_16x16x4_f32: exact fp32 products, an fmaf chain per output element — the library GEMMs' numerics class).
+// MFMA column j of tile nt is output column 64 w + 4 j + nt, so that a lane's four accumulators of one row are four ADJACENT
+// columns: bias, dropout quad hash (add_ln.hip / bn_act.hip key their masks by groups of 4 channels), residual, LayerNorm and
+// the stores all work on float4.  The contraction index of MFMA step s in lane group kg is 16 (s >> 2) + 4 kg + (s & 3): each
+// lane's share of a weight row is contiguous float4s, its share of the activation row comes out of LDS as float4s.
+// Everything the existing backward kernels read (y, mean, rstd, t2, h, ...) is written exactly as the separate launches wrote
+// it, with the same dropout streams: the autograd side (v-detr_amd/rowblock.py) reuses vdetr_add_ln_bwd_f32 /
+// vdetr_relu_dropout_bwd_f32 and the parked weight gradients unchanged.
+#include "attn_common.h"
+
+namespace vdetr {
+
+constexpr int kRbRows = 16;
+constexpr int kRbC = 256;
+constexpr int kRbThreads = 256;
+constexpr int kRbStride = kRbC + 4;  // floats per LDS row: 16 rows x 1040 B land on 16 different 16-byte slots
+
+struct RbDrop {  // a dropout stream (add_ln.hip: LnRng / bn_act.hip: BnRng): keep iff 16-bit draw >= thresh
+  unsigned seed_lo, seed_hi, off_lo, off_hi, thresh;
+  float scale;
+};
+__device__ __forceinline__ RbDrop rb_drop(float p, unsigned long long seed, unsigned long long offset, const uint64_t* rng) {
+  RbDrop r;
+  unsigned long long s = seed, o = offset;
+  if (rng) { s ^= rng[0]; o += rng[1]; }
+  r.seed_lo = (unsigned)s; r.seed_hi = (unsigned)(s >> 32); r.off_lo = (unsigned)o; r.off_hi = (unsigned)(o >> 32);
+  r.thresh = 0; r.scale = 1.f;
+  if (p > 0.f) {
+    int t = (int)((double)p * 65536.0 + 0.5);
+    t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
+    r.thresh = (unsigned)t;
+    r.scale = 65536.f / (float)(65536 - t);
+  }
+  return r;
+}
+// the residual blocks' mask (add_ln.hip: ln_rowkey / ln_keep4): channels 4 j .. 4 j + 3 of `row`
+__device__ __forceinline__ void rb_keep4_ln(const RbDrop& g, int row, int j, bool (&keep)[4]) {
+  if (!g.thresh) { keep[0] = keep[1] = keep[2] = keep[3] = true; return; }
+  unsigned k = fmix32(((unsigned)row * 0x9E3779B1u + g.off_lo) ^ g.seed_lo);
+  k = fmix32(k ^ (0x27D4EB2Fu + g.off_hi) ^ g.seed_hi);
+  const unsigned x = fmix32(k ^ ((unsigned)j * 0x165667B1u));
+  const unsigned y = fmix32(x + 0x9E3779B9u);
+  keep[0] = (x & 0xFFFFu) >= g.thresh; keep[1] = (x >> 16) >= g.thresh;
+  keep[2] = (y & 0xFFFFu) >= g.thresh; keep[3] = (y >> 16) >= g.thresh;
+}
+// the FFN activation's mask (bn_act.hip: relu_dropout_fwd_kernel): float4 number i of the flat tensor
+__device__ __forceinline__ void rb_keep4_act(const RbDrop& g, long i, bool (&keep)[4]) {
+  if (!g.thresh) { keep[0] = keep[1] = keep[2] = keep[3] = true; return; }
+  unsigned r0 = fmix32(((unsigned)i * 0x9E3779B1u + g.off_lo) ^ g.seed_lo ^ ((unsigned)(i >> 32) * 0x27D4EB2Fu));
+  r0 = fmix32(r0 ^ g.seed_hi ^ g.off_hi);
+  const unsigned r1 = fmix32(r0 + 0x9E3779B9u);
+  keep[0] = (r0 & 0xFFFFu) >= g.thresh; keep[1] = (r0 >> 16) >= g.thresh;
+  keep[2] = (r1 & 0xFFFFu) >= g.thresh; keep[3] = (r1 >> 16) >= g.thresh;
+}
+
+// ---- the 16 x 256 activation tile: global -> LDS (row-major, padded), LDS -> the 64 A-operand registers of a lane ----------
+// Rows are numbered as the decoder's sequence-first tensors lay them out: row = q * B + b.  The attention cores read and write
+// batch-first tensors [B, nQ, C]: `rb_bmajor` is the row of (q, b) there (identity for one scene).
+__device__ __forceinline__ int rb_bmajor(int row, int B, int nQ) { return B == 1 ? row : (row % B) * nQ + row / B; }
+__device__ __forceinline__ void rb_stage_rows(const float* __restrict__ src, int row0, int rows, int B, bool bmajor, float* xs, int tid,
+                                              const float* __restrict__ add = nullptr, float* sum_out = nullptr) {
+#pragma unroll
+  for (int u = 0; u < kRbRows * kRbC / 4 / kRbThreads; ++u) {  // 4 float4 per thread
+    const int e = tid + u * kRbThreads, r = e >> 6, c4 = e & 63;
+    const int row = min(row0 + r, rows - 1);  // rows past the end are computed on a copy of the last row and not stored
+    const int srow = bmajor ? rb_bmajor(row, B, rows / B) : row;
+    f32x4 v = reinterpret_cast<const f32x4*>(src + (size_t)srow * kRbC)[c4];
+    if (add) {  // + the position embedding (sequence-first, like the rows)
+      v += reinterpret_cast<const f32x4*>(add + (size_t)row * kRbC)[c4];
+      if (sum_out && row0 + r < rows) reinterpret_cast<f32x4*>(sum_out + (size_t)row * kRbC)[c4] = v;
+    }
+    *reinterpret_cast<f32x4*>(xs + r * kRbStride + 4 * c4) = v;
+  }
+}
+__device__ __forceinline__ void rb_load_a(const float* xs, int lane, float (&a)[64]) {
+  const int i = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xs + i * kRbStride + 16 * m + 4 * kg);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[4 * m + e] = v[e];
+  }
+}
+// acc[nt][r] += sum_k X[4 g + r][k] W[col0 + 4 c + nt][k]   (W: nn.Linear layout [out][256]); lane = (g = lane >> 4, c = lane & 15)
+__device__ __forceinline__ void rb_gemm(const float (&a)[64], const float* __restrict__ W, int col0, int lane, f32x4 (&acc)[4]) {
+  const int j = lane & 15, kg = lane >> 4;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(W + (size_t)(col0 + 4 * j) * kRbC + 4 * kg);  // + nt * 64 float4 (the next row), + 4 m
+  f32x4 b[3][4];  // weights of steps m, m + 1, m + 2 in flight (L2 latency ~ two steps of 16 matrix instructions)
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) { b[0][nt] = wp[nt * 64]; b[1][nt] = wp[nt * 64 + 4]; }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m + 2 < 16) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) b[(m + 2) % 3][nt] = wp[nt * 64 + 4 * (m + 2)];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % 3][nt][e], acc[nt], 0, 0, 0);
+  }
+}
+// accumulators -> per-row float4 of the four adjacent columns (row 4 g + r, columns col0 + 4 c ..)
+__device__ __forceinline__ f32x4 rb_row(const f32x4 (&acc)[4], int r) { return f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}; }
+
+// LayerNorm statistics of the workgroup's 16 rows from each lane's 16 values (4 rows x 4 columns): DPP row sums, then the 4
+// waves through LDS.  red: [2][4 waves][16 rows] floats.  Two-pass (mean, then centred squares), as add_ln.hip does.
+__device__ __forceinline__ void rb_row_stats(const f32x4 (&y)[4], float* red, int w, int lane, float eps, float (&mean)[4], float (&rstd)[4]) {
+  const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float s = row_allsum_f32((y[r][0] + y[r][1]) + (y[r][2] + y[r][3]));
+    if (c == 0) red[w * 16 + 4 * g + r] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    mean[r] = ((red[4 * g + r] + red[16 + 4 * g + r]) + (red[32 + 4 * g + r] + red[48 + 4 * g + r])) * (1.f / kRbC);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = y[r][e] - mean[r]; q += t * t; }
+    q = row_allsum_f32(q);
+    if (c == 0) red[64 + w * 16 + 4 * g + r] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    rstd[r] = rsqrtf(((red[64 + 4 * g + r] + red[80 + 4 * g + r]) + (red[96 + 4 * g + r] + red[112 + 4 * g + r])) * (1.f / kRbC) + eps);
+}
+
+typedef vdetr_rb_linear RbLinear;
+typedef vdetr_rb_norm RbNorm;
+typedef vdetr_rb_drop RbDropArgs;
+
+// ---- rb_ffn_kernel -------------------------------------------------------------------------------------------------------
+typedef vdetr_rb_ffn_desc RbFfnArgs;
+
+__global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A) {
+  __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
+  __shared__ float red[128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int row0 = blockIdx.x * kRbRows;
+  const int col0 = 64 * w, colq = col0 + 4 * c;  // this lane's four columns
+  const RbDrop d2 = rb_drop(A.drop2.p, A.drop2.seed, 0, A.rng_state), da = rb_drop(A.drop_act.p, A.drop_act.seed, 0, A.rng_state),
+               d3 = rb_drop(A.drop3.p, A.drop3.seed, 0, A.rng_state);
+  float a[64];
+  f32x4 acc[4];
+  f32x4 y[4];  // the residual stream of this lane's rows 4 g + r, columns colq ..
+  float mean[4], rstd[4];
+
+  rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  rb_gemm(a, A.proj.w, col0, lane, acc);
+  {
+    const f32x4 bias = A.proj.b ? *reinterpret_cast<const f32x4*>(A.proj.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+      f32x4 v = rb_row(acc, r) + bias;
+      bool keep[4];
+      rb_keep4_ln(d2, rowc, colq >> 2, keep);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(A.tgt + (size_t)rowc * kRbC + colq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = t[e] + (keep[e] ? v[e] * d2.scale : 0.f);
+      y[r] = v;
+      if (row < A.rows) *reinterpret_cast<f32x4*>(A.y + (size_t)row * kRbC + colq) = v;
+    }
+  }
+  rb_row_stats(y, red, w, lane, A.norm3.eps, mean, rstd);  // (its barriers also fence the reads of xs above)
+  {
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(A.norm3.gamma + colq), be = *reinterpret_cast<const f32x4*>(A.norm3.beta + colq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
+      *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = o;
+      if (row < A.rows) {
+        *reinterpret_cast<f32x4*>(A.t2 + (size_t)row * kRbC + colq) = o;
+        if (w == 0 && c == 0) { A.mean_y[row] = mean[r]; A.rstd_y[row] = rstd[r]; }
+      }
+    }
+  }
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  rb_gemm(a, A.lin1.w, col0, lane, acc);
+  __syncthreads();  // every wave has its A operand: the tile can be overwritten
+  {
+    const f32x4 bias = A.lin1.b ? *reinterpret_cast<const f32x4*>(A.lin1.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+      f32x4 v = rb_row(acc, r) + bias;
+      bool keep[4];
+      rb_keep4_act(da, ((long)rowc * kRbC + colq) >> 2, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f && keep[e]) ? v[e] * da.scale : 0.f;
+      *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
+      if (row < A.rows) *reinterpret_cast<f32x4*>(A.h + (size_t)row * kRbC + colq) = v;
+    }
+  }
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  rb_gemm(a, A.lin2.w, col0, lane, acc);
+  {
+    const f32x4 bias = A.lin2.b ? *reinterpret_cast<const f32x4*>(A.lin2.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+      f32x4 v = rb_row(acc, r) + bias;
+      bool keep[4];
+      rb_keep4_ln(d3, rowc, colq >> 2, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = y[r][e] + (keep[e] ? v[e] * d3.scale : 0.f);
+      y[r] = v;
+      if (row < A.rows) *reinterpret_cast<f32x4*>(A.z + (size_t)row * kRbC + colq) = v;
+    }
+  }
+  rb_row_stats(y, red, w, lane, A.post1.eps, mean, rstd);
+  {
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(A.post1.gamma + colq), be = *reinterpret_cast<const f32x4*>(A.post1.beta + colq);
+    const bool two = A.post2.gamma != nullptr;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 ga2 = two ? *reinterpret_cast<const f32x4*>(A.post2.gamma + colq) : zero, be2 = two ? *reinterpret_cast<const f32x4*>(A.post2.beta + colq) : zero;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      if (row >= A.rows) continue;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
+      *reinterpret_cast<f32x4*>(A.o1 + (size_t)row * kRbC + colq) = o;
+      if (two) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga2[e] + be2[e];
+        *reinterpret_cast<f32x4*>(A.o2 + (size_t)row * kRbC + colq) = o;
+      }
+      if (w == 0 && c == 0) { A.mean_z[row] = mean[r]; A.rstd_z[row] = rstd[r]; }
+    }
+  }
+}
+
+// ---- rb_proj_q_kernel: out-projection of the self-attention + residual block 1 + the cross-attention's query projection ------
+typedef vdetr_rb_projq_desc RbProjQArgs;
+
+__global__ __launch_bounds__(kRbThreads) void rb_proj_q_kernel(RbProjQArgs A) {
+  __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
+  __shared__ float red[128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int row0 = blockIdx.x * kRbRows;
+  const int col0 = 64 * w, colq = col0 + 4 * c;
+  const RbDrop d1 = rb_drop(A.drop1.p, A.drop1.seed, 0, A.rng_state);
+  float a[64];
+  f32x4 acc[4];
+  f32x4 y[4];
+  float mean[4], rstd[4];
+  rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  rb_gemm(a, A.proj.w, col0, lane, acc);
+  {
+    const f32x4 bias = A.proj.b ? *reinterpret_cast<const f32x4*>(A.proj.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+      f32x4 v = rb_row(acc, r) + bias;
+      bool keep[4];
+      rb_keep4_ln(d1, rowc, colq >> 2, keep);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(A.tgt + (size_t)rowc * kRbC + colq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = t[e] + (keep[e] ? v[e] * d1.scale : 0.f);
+      y[r] = v;
+      if (row < A.rows) *reinterpret_cast<f32x4*>(A.y + (size_t)row * kRbC + colq) = v;
+    }
+  }
+  rb_row_stats(y, red, w, lane, A.norm2.eps, mean, rstd);
+  {
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(A.norm2.gamma + colq), be = *reinterpret_cast<const f32x4*>(A.norm2.beta + colq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
+      if (row < A.rows) {
+        *reinterpret_cast<f32x4*>(A.t2 + (size_t)row * kRbC + colq) = o;
+        if (w == 0 && c == 0) { A.mean_y[row] = mean[r]; A.rstd_y[row] = rstd[r]; }
+      }
+      if (A.pos) {
+        o += *reinterpret_cast<const f32x4*>(A.pos + (size_t)rowc * kRbC + colq);
+        if (row < A.rows) *reinterpret_cast<f32x4*>(A.xq + (size_t)row * kRbC + colq) = o;
+      }
+      *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = o;
+    }
+  }
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  rb_gemm(a, A.q.w, col0, lane, acc);
+  {
+    const f32x4 bias = A.q.b ? *reinterpret_cast<const f32x4*>(A.q.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r;
+      if (row >= A.rows) continue;
+      *reinterpret_cast<f32x4*>(A.qout + (size_t)rb_bmajor(row, A.B, A.rows / A.B) * kRbC + colq) = rb_row(acc, r) + bias;
+    }
+  }
+}
+
+// ---- rb_qkv_kernel: the self-attention's three projections; blockIdx.y = 0 / 1 / 2 = q / k / v ---------------------------------
+typedef vdetr_rb_qkv_desc RbQkvArgs;
+
+__global__ __launch_bounds__(kRbThreads) void rb_qkv_kernel(RbQkvArgs A) {
+  __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int row0 = blockIdx.x * kRbRows, which = blockIdx.y;
+  const int col0 = 64 * w, colq = col0 + 4 * c;
+  const bool with_pos = which < 2 && A.pos != nullptr;
+  rb_stage_rows(A.t, row0, A.rows, A.B, false, xs, tid, with_pos ? A.pos : nullptr, which == 0 ? A.x : nullptr);
+  __syncthreads();
+  float a[64];
+  rb_load_a(xs, lane, a);
+  f32x4 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  rb_gemm(a, A.w + (size_t)which * kRbC * kRbC, col0, lane, acc);
+  const f32x4 bias = A.b ? *reinterpret_cast<const f32x4*>(A.b + which * kRbC + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float* out = A.out + (size_t)which * A.rows * kRbC;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    if (row >= A.rows) continue;
+    *reinterpret_cast<f32x4*>(out + (size_t)rb_bmajor(row, A.B, A.rows / A.B) * kRbC + colq) = rb_row(acc, r) + bias;
+  }
+}
+
+}  // namespace vdetr
+
+using namespace vdetr;
+
+static int rb_common(int rows, int B, const char* op) {
+  VDETR_REQUIRE(rows > 0 && B > 0 && rows % B == 0, "%s: rows=%d must be a positive multiple of B=%d", op, rows, B);
+  return VDETR_OK;
+}
+#define RB_ALIGNED(p) ((((uintptr_t)(p)) & 15) == 0)
+
+extern "C" int vdetr_rb_qkv_f32(const vdetr_rb_qkv_desc* d, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr, "rb_qkv: null descriptor");
+  if (int e = rb_common(d->rows, d->B, "rb_qkv")) return e;
+  VDETR_REQUIRE(d->t && d->w && d->out && (!d->pos || d->x), "rb_qkv: null pointer");
+  VDETR_REQUIRE(RB_ALIGNED(d->t) && RB_ALIGNED(d->pos) && RB_ALIGNED(d->w) && RB_ALIGNED(d->b) && RB_ALIGNED(d->x) && RB_ALIGNED(d->out),
+                "rb_qkv: operands must be 16-B aligned");
+  hipLaunchKernelGGL(rb_qkv_kernel, dim3(ceil_div(d->rows, kRbRows), 3), dim3(kRbThreads), 0, (hipStream_t)stream, *d);
+  return check_launch("rb_qkv");
+}
+
+extern "C" int vdetr_rb_proj_q_f32(const vdetr_rb_projq_desc* d, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr, "rb_proj_q: null descriptor");
+  if (int e = rb_common(d->rows, d->B, "rb_proj_q")) return e;
+  VDETR_REQUIRE(d->a && d->tgt && d->proj.w && d->q.w && d->norm2.gamma && d->norm2.beta && d->y && d->mean_y && d->rstd_y && d->t2 &&
+                d->qout && (!d->pos || d->xq), "rb_proj_q: null pointer");
+  VDETR_REQUIRE(d->drop1.p >= 0.f && d->drop1.p < 1.f, "rb_proj_q: dropout_p %f outside [0,1)", d->drop1.p);
+  VDETR_REQUIRE(RB_ALIGNED(d->a) && RB_ALIGNED(d->tgt) && RB_ALIGNED(d->pos) && RB_ALIGNED(d->proj.w) && RB_ALIGNED(d->proj.b) &&
+                RB_ALIGNED(d->q.w) && RB_ALIGNED(d->q.b) && RB_ALIGNED(d->norm2.gamma) && RB_ALIGNED(d->norm2.beta) && RB_ALIGNED(d->y) &&
+                RB_ALIGNED(d->t2) && RB_ALIGNED(d->xq) && RB_ALIGNED(d->qout), "rb_proj_q: operands must be 16-B aligned");
+  hipLaunchKernelGGL(rb_proj_q_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d);
+  return check_launch("rb_proj_q");
+}
+
+extern "C" int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr, "rb_ffn: null descriptor");
+  if (int e = rb_common(d->rows, d->B, "rb_ffn")) return e;
+  VDETR_REQUIRE(d->a && d->tgt && d->proj.w && d->lin1.w && d->lin2.w && d->norm3.gamma && d->norm3.beta && d->post1.gamma && d->post1.beta &&
+                d->y && d->mean_y && d->rstd_y && d->t2 && d->h && d->z && d->mean_z && d->rstd_z && d->o1, "rb_ffn: null pointer");
+  VDETR_REQUIRE((d->post2.gamma == nullptr) == (d->post2.beta == nullptr) && (d->post2.gamma == nullptr) == (d->o2 == nullptr),
+                "rb_ffn: post2.gamma, post2.beta and o2 go together");
+  for (const vdetr_rb_drop* dr : {&d->drop2, &d->drop_act, &d->drop3})
+    VDETR_REQUIRE(dr->p >= 0.f && dr->p < 1.f, "rb_ffn: dropout_p %f outside [0,1)", dr->p);
+  VDETR_REQUIRE(RB_ALIGNED(d->a) && RB_ALIGNED(d->tgt) && RB_ALIGNED(d->proj.w) && RB_ALIGNED(d->proj.b) && RB_ALIGNED(d->lin1.w) &&
+                RB_ALIGNED(d->lin1.b) && RB_ALIGNED(d->lin2.w) && RB_ALIGNED(d->lin2.b) && RB_ALIGNED(d->norm3.gamma) && RB_ALIGNED(d->norm3.beta) &&
+                RB_ALIGNED(d->post1.gamma) && RB_ALIGNED(d->post1.beta) && RB_ALIGNED(d->post2.gamma) && RB_ALIGNED(d->post2.beta) &&
+                RB_ALIGNED(d->y) && RB_ALIGNED(d->t2) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) && RB_ALIGNED(d->o1) && RB_ALIGNED(d->o2),
+                "rb_ffn: operands must be 16-B aligned");
+  hipLaunchKernelGGL(rb_ffn_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d);
+  return check_launch("rb_ffn");
+}

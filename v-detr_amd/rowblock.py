@@ -1,0 +1,288 @@
+"""The decoder layer's glue between its attention cores as three launches (csrc/rowblock.hip): autograd bindings.
+
+Reference: GlobalDecoderLayer.forward_pre (models/vdetr_transformer.py:531-568).  ``qkv`` is the self-attention's in-projection
+(:540-542 + nn.MultiheadAttention's in_proj), ``proj_q`` its out-projection with residual block 1 and the cross attention's
+query projection (:543-545, :733), ``ffn`` the cross attention's output projection with residual blocks 2 and 3, the FFN
+(:556-567, :755-757) and the norms the decoder applies to the layer output (:401, :433).
+
+Forward: one launch each.  Backward: the launches the separate modules would run (vdetr_add_ln_bwd_f32,
+vdetr_relu_dropout_bwd_f32, the input-gradient GEMMs), on the tensors the fused launch wrote for them, with the weight / bias
+gradients parked exactly as helpers._Linear parks them (runtime.defer_weight_grads).  Same dropout streams as add_ln.py /
+bn_act.py for the same salts: a layer computes the same values on either path.  No CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import add_ln as ALN
+from . import attention as A
+from .helpers import DeferredParamGrads, colsum
+
+C = 256
+
+
+def _seq_rows(t, B):
+    """batch-first [B, nQ, C] -> the rows (q, b) of the sequence-first layout, [nQ * B, C] (a view for one scene)"""
+    if B == 1:
+        return t.reshape(-1, t.shape[-1])
+    return t.transpose(0, 1).reshape(-1, t.shape[-1])
+
+
+def _batch_first(rows2d, B):
+    """[nQ * B, C] rows (q, b) -> [B, nQ, C]"""
+    if B == 1:
+        return rows2d.view(1, -1, rows2d.shape[-1])
+    return rows2d.view(-1, B, rows2d.shape[-1]).transpose(0, 1).contiguous()
+
+
+def _rng_for(p, device):
+    if p <= 0.0:
+        return None
+    rng = A.current_rng(device)
+    return rng if rng is not None else A.begin_step(device)
+
+
+def _lin(d, w, b):
+    d.w = w.data_ptr()
+    d.b = b.data_ptr() if b is not None else None
+
+
+def _norm(d, ln_w, ln_b, eps):
+    d.gamma, d.beta, d.eps = ln_w.data_ptr(), ln_b.data_ptr(), float(eps)
+
+
+def _drop(d, p, salt):
+    d.p, d.seed = float(p), int(salt) & 0xFFFFFFFFFFFFFFFF
+
+
+def _park_or_grad(w, b, dy2, x2, need_w, need_b):
+    """weight / bias gradient of y = x w^T + b from (dy, x): parked (runtime.defer_weight_grads) or computed here"""
+    if not (need_w or need_b):
+        return None, None
+    if DeferredParamGrads.enabled:
+        DeferredParamGrads.pending.append((w if need_w else None, b if need_b else None, dy2, x2))
+        return None, None
+    dw = torch.mm(dy2.t(), x2) if need_w else None
+    db = colsum(dy2 if dy2.stride(1) == 1 else dy2.contiguous()) if need_b else None
+    return dw, db
+
+
+def _check(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        L.require_gpu(t, "rowblock operand")
+        L.require_float(t, "rowblock operand")
+        if not t.is_contiguous() or t.data_ptr() % 16:
+            raise RuntimeError("rowblock operands must be contiguous and 16-B aligned")
+
+
+class _Qkv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, pos, wq, wk, wv, bq, bk, bv, B):
+        _check(t, pos, wq, wk, wv, bq, bk, bv)
+        rows = t.numel() // C
+        if not (wk.data_ptr() == wq.data_ptr() + C * C * 4 and wv.data_ptr() == wk.data_ptr() + C * C * 4 and
+                bk.data_ptr() == bq.data_ptr() + C * 4 and bv.data_ptr() == bk.data_ptr() + C * 4):
+            raise RuntimeError("rowblock.qkv: the q / k / v blocks must be adjacent rows of one in_proj parameter")
+        out = torch.empty((3, B, rows // B, C), dtype=torch.float32, device=t.device)
+        x = torch.empty((rows, C), dtype=torch.float32, device=t.device) if pos is not None else None
+        d = L.RbQkvDesc()
+        d.rows, d.B = rows, B
+        d.t, d.pos = t.data_ptr(), (pos.data_ptr() if pos is not None else None)
+        d.w, d.b = wq.data_ptr(), bq.data_ptr()
+        d.x, d.out = (x.data_ptr() if x is not None else None), out.data_ptr()
+        L.check(L.lib().vdetr_rb_qkv_f32(ctypes.byref(d), L.stream_ptr()), "rb_qkv")
+        ctx.B, ctx.shape = B, t.shape
+        ctx.save_for_backward(t, x, wq, wk, wv, bq, bk, bv)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        t, x, wq, wk, wv, bq, bk, bv = ctx.saved_tensors
+        B = ctx.B
+        t2 = t.reshape(-1, C)
+        x2 = x if x is not None else t2
+        dq2, dk2, dv2 = (_seq_rows(g.contiguous(), B) for g in (dq, dk, dv))
+        need = ctx.needs_input_grad
+        d_t = d_pos = None
+        if need[0] or need[1]:
+            d_x = torch.mm(dq2, wq)
+            d_x.addmm_(dk2, wk)                      # gradient of t + pos
+            if need[1]:
+                d_pos = d_x.view(ctx.shape)
+            if need[0]:
+                d_t = torch.addmm(d_x, dv2, wv).view(ctx.shape)
+        g = [None] * 6
+        for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
+            g[i], g[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
+        return d_t, d_pos, g[0], g[1], g[2], g[3], g[4], g[5], None
+
+
+class _ProjQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, tgt, pos, wo, bo, wq, bq, g2, b2, eps, p, salt, rng, B):
+        _check(a, tgt, pos, wo, bo, wq, bq, g2, b2)
+        rows = tgt.numel() // C
+        dev = tgt.device
+        y = torch.empty_like(tgt)
+        t2 = torch.empty_like(tgt)
+        xq = torch.empty_like(tgt) if pos is not None else None
+        mean = torch.empty(rows, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        qout = torch.empty((B, rows // B, C), dtype=torch.float32, device=dev)
+        d = L.RbProjQDesc()
+        d.rows, d.B = rows, B
+        d.rng_state = rng.data_ptr() if (rng is not None and p > 0) else None
+        d.a, d.tgt, d.pos = a.data_ptr(), tgt.data_ptr(), (pos.data_ptr() if pos is not None else None)
+        _lin(d.proj, wo, bo)
+        _lin(d.q, wq, bq)
+        _drop(d.drop1, p, salt)
+        _norm(d.norm2, g2, b2, eps)
+        d.y, d.mean_y, d.rstd_y, d.t2 = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), t2.data_ptr()
+        d.xq, d.qout = (xq.data_ptr() if xq is not None else None), qout.data_ptr()
+        L.check(L.lib().vdetr_rb_proj_q_f32(ctypes.byref(d), L.stream_ptr()), "rb_proj_q")
+        ctx.cfg = (rows, float(eps), float(p), salt, B, tgt.shape)
+        ctx.ln_params = (g2, b2, None, None)
+        ctx.save_for_backward(a, y, xq if xq is not None else t2, wo, bo, wq, bq, g2, mean, rstd, rng if p > 0 else None)
+        ctx.set_materialize_grads(False)
+        return y, qout
+
+    @staticmethod
+    def backward(ctx, d_y, d_qout):
+        rows, eps, p, salt, B, shape = ctx.cfg
+        a, y, xq, wo, bo, wq, bq, g2, mean, rstd, rng = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        d_t2 = None
+        gwq = gbq = None
+        if d_qout is not None:
+            dq2 = _seq_rows(d_qout.contiguous(), B)
+            d_t2 = torch.mm(dq2, wq)                 # gradient of t2 + pos
+            gwq, gbq = _park_or_grad(wq, bq, dq2, xq.reshape(-1, C), need[5], need[6])
+        if d_y is None and d_t2 is None:
+            return (None,) * 14
+        d_x, d_r, dg, db, _, _ = ALN.backward_core((rows, C, eps, p, salt, True), y, g2, None, mean, rstd, rng, ctx.ln_params,
+                                                   d_y.contiguous().view(rows, C) if d_y is not None else None, d_t2, None)
+        d_r2 = d_r if d_r is not None else d_x
+        a2 = _seq_rows(a, B)
+        d_a = _batch_first(torch.mm(d_r2, wo), B) if need[0] else None
+        gwo, gbo = _park_or_grad(wo, bo, d_r2, a2, need[3], need[4])
+        d_pos = d_t2.view(shape) if (need[2] and d_t2 is not None) else None
+        return d_a, d_x.view(shape), d_pos, gwo, gbo, gwq, gbq, dg, db, None, None, None, None, None
+
+
+class _Ffn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, tgt, wp, bp, w1, b1, w2, b2, g3, be3, gp1, bep1, gp2, bep2, eps3, epsp, p2, salt2, pa, salta, p3, salt3,
+                rng, B):
+        _check(a, tgt, wp, bp, w1, b1, w2, b2, g3, be3, gp1, bep1, gp2, bep2)
+        rows = tgt.numel() // C
+        dev = tgt.device
+        new = lambda: torch.empty_like(tgt)
+        y, t2, h, z, o1 = new(), new(), new(), new(), new()
+        o2 = new() if gp2 is not None else None
+        stats = torch.empty((4, rows), dtype=torch.float32, device=dev)
+        use_rng = rng is not None and (p2 > 0 or pa > 0 or p3 > 0)
+        d = L.RbFfnDesc()
+        d.rows, d.B = rows, B
+        d.rng_state = rng.data_ptr() if use_rng else None
+        d.a, d.tgt = a.data_ptr(), tgt.data_ptr()
+        _lin(d.proj, wp, bp)
+        _lin(d.lin1, w1, b1)
+        _lin(d.lin2, w2, b2)
+        _drop(d.drop2, p2, salt2)
+        _drop(d.drop_act, pa, salta)
+        _drop(d.drop3, p3, salt3)
+        _norm(d.norm3, g3, be3, eps3)
+        _norm(d.post1, gp1, bep1, epsp)
+        if gp2 is not None:
+            _norm(d.post2, gp2, bep2, epsp)
+        d.y, d.mean_y, d.rstd_y, d.t2 = y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), t2.data_ptr()
+        d.h = h.data_ptr()
+        d.z, d.mean_z, d.rstd_z, d.o1 = z.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), o1.data_ptr()
+        d.o2 = o2.data_ptr() if o2 is not None else None
+        L.check(L.lib().vdetr_rb_ffn_f32(ctypes.byref(d), L.stream_ptr()), "rb_ffn")
+        ctx.cfg = (rows, float(eps3), float(epsp), float(p2), salt2, float(pa), float(p3), salt3, B, tgt.shape)
+        ctx.ln3 = (g3, be3, None, None)
+        ctx.lnp = (gp1, bep1, gp2, bep2)
+        ctx.save_for_backward(a, y, t2, h, z, stats, wp, bp, w1, b1, w2, b2, g3, gp1, gp2, rng if use_rng else None)
+        ctx.set_materialize_grads(False)
+        return z, o1, o2
+
+    @staticmethod
+    def backward(ctx, d_z, d_o1, d_o2):
+        rows, eps3, epsp, p2, salt2, pa, p3, salt3, B, shape = ctx.cfg
+        a, y, t2, h, z, stats, wp, bp, w1, b1, w2, b2, g3, gp1, gp2, rng = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if d_z is None and d_o1 is None and d_o2 is None:
+            return (None,) * 24
+        cont = lambda t: t.contiguous().view(rows, C) if t is not None else None
+        # block 3: z = y + drop3(lin2 h); o1 = post1(z), o2 = post2(z)
+        d_y, d_r3, dgp1, dbp1, dgp2, dbp2 = ALN.backward_core((rows, C, epsp, p3, salt3, True), z, gp1, gp2, stats[2], stats[3], rng,
+                                                              ctx.lnp, cont(d_z), cont(d_o1), cont(d_o2))
+        d_r3 = d_r3 if d_r3 is not None else d_y
+        d_h = torch.mm(d_r3, w2)
+        gw2, gb2 = _park_or_grad(w2, b2, d_r3, h.view(rows, C), need[6], need[7])
+        d_pre = torch.empty_like(d_h)
+        L.check(L.lib().vdetr_relu_dropout_bwd_f32(L.ptr(h), L.ptr(d_h), L.ptr(d_pre), h.numel(), float(pa), L.stream_ptr()),
+                "relu_dropout_bwd")
+        d_t2 = torch.mm(d_pre, w1)
+        gw1, gb1 = _park_or_grad(w1, b1, d_pre, t2.view(rows, C), need[4], need[5])
+        # block 2: y = tgt + drop2(proj a); t2 = norm3(y)
+        d_tgt, d_r2, dg3, db3, _, _ = ALN.backward_core((rows, C, eps3, p2, salt2, True), y, g3, None, stats[0], stats[1], rng, ctx.ln3,
+                                                        d_y, d_t2, None)
+        d_r2 = d_r2 if d_r2 is not None else d_tgt
+        d_a = _batch_first(torch.mm(d_r2, wp), B) if need[0] else None
+        gwp, gbp = _park_or_grad(wp, bp, d_r2, _seq_rows(a, B), need[2], need[3])
+        return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 10
+
+
+# ---- module-level entry points -----------------------------------------------------------------------------------------
+def _plain_ln(m):
+    return ALN.supported(m) and m.normalized_shape[0] == C
+
+
+def usable(layer, tgt, query_pos, masks):
+    """True where GlobalDecoderLayer.forward_pre may take the three fused launches: fp32 activations on the GPU, d_model =
+    dim_feedforward = 256, nn.MultiheadAttention-style self attention, plain LayerNorms, a ReLU FFN, no masks."""
+    from .vdetr_transformer import GlobalShareCrossAttention, MultiheadSelfAttention
+    sa, ca = layer.self_attn, layer.multihead_attn
+    return bool(tgt.is_cuda and tgt.dtype == torch.float32 and tgt.dim() == 3 and tgt.shape[-1] == C and all(m is None for m in masks)
+                and type(sa) is MultiheadSelfAttention and sa.embed_dim == C and type(ca) is GlobalShareCrossAttention
+                and ca.q.weight.shape == (C, C) and ca.proj.weight.shape == (C, C) and ca.q.bias is not None
+                and layer.linear1.weight.shape == (C, C) and layer.linear2.weight.shape == (C, C)
+                and type(layer.activation) is torch.nn.ReLU and all(_plain_ln(m) for m in (layer.norm1, layer.norm2, layer.norm3))
+                and (query_pos is None or query_pos.shape == tgt.shape))
+
+
+def qkv(t, pos, sa, B):
+    """the self-attention's projected operands, batch-first [B, nQ, 256] each"""
+    E = sa.embed_dim
+    wq, wk, wv = sa.in_proj_weight.view(3, E, E).unbind(0)
+    bq, bk, bv = sa.in_proj_bias.view(3, E).unbind(0)
+    return _Qkv.apply(t.contiguous(), pos.contiguous() if pos is not None else None, wq, wk, wv, bq, bk, bv, B)
+
+
+def proj_q(a, tgt, pos, out_proj, q_lin, drop, ln, salt, B):
+    """(tgt + drop(out_proj(a)), q_lin(ln(.) + pos)): the residual stream [nQ, B, 256] and the cross attention's query [B, nQ, 256]"""
+    p = drop.p if (drop is not None and drop.training) else 0.0
+    return _ProjQ.apply(a.contiguous(), tgt.contiguous(), pos.contiguous() if pos is not None else None, out_proj.weight, out_proj.bias,
+                        q_lin.weight, q_lin.bias, ln.weight, ln.bias, ln.eps, p, salt, _rng_for(p, tgt.device), B)
+
+
+def ffn(a, tgt, layer, post_norms, salts, act_salt, B):
+    """residual blocks 2 and 3 of the layer around its FFN; returns (z, post_norms[0](z) [, post_norms[1](z)])"""
+    ca = layer.multihead_attn
+    p2 = layer.dropout2.p if layer.dropout2.training else 0.0
+    if ca.proj_drop.training and ca.proj_drop.p > 0.0:   # proj_drop and dropout2: one mask (add_ln.add_dropout_layer_norm)
+        p2 = 1.0 - (1.0 - p2) * (1.0 - ca.proj_drop.p)
+    pa = layer.dropout.p if layer.dropout.training else 0.0
+    p3 = layer.dropout3.p if layer.dropout3.training else 0.0
+    n1 = post_norms[0]
+    n2 = post_norms[1] if len(post_norms) > 1 else None
+    rng = _rng_for(max(p2, pa, p3), tgt.device)
+    return _Ffn.apply(a.contiguous(), tgt.contiguous(), ca.proj.weight, ca.proj.bias, layer.linear1.weight, layer.linear1.bias,
+                      layer.linear2.weight, layer.linear2.bias, layer.norm3.weight, layer.norm3.bias, n1.weight, n1.bias,
+                      n2.weight if n2 is not None else None, n2.bias if n2 is not None else None, layer.norm3.eps, n1.eps,
+                      p2, salts[1], pa, act_salt, p3, salts[2], rng, B)

@@ -29,6 +29,7 @@ from . import add_ln as ALN
 from . import bn_act as BNA
 from . import attention as A
 from . import box_decode
+from . import rowblock as RB
 from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
                       PositionEmbeddingLearned, buffers_alias, cat_params, get_clones, linear, linear_pair, slot_stack_params,
                       stack_params)
@@ -237,10 +238,10 @@ class GlobalShareCrossAttention(nn.Module):
             tables = A.park_table_grads(torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H))
         return [(parts[2 * i], parts[2 * i + 1], tables[i]) for i in range(n)]
 
-    def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None,
-                cache=None):
-        query_b = query.permute(1, 0, 2)
-        q = linear(query_b, self.q.weight, self.q.bias)   # [B,nQ,C]
+    def core(self, q, key, reference_point, reference_angle, xyz, attn_mask=None, cache=None):
+        """The attention between the query projection and the output projection (:733-753): q [B,nQ,C] projected queries ->
+        (x [B,nQ,C], attn or None).  `key` [nK,B,C] is projected here unless `cache` = (k, v, tables) carries the layer's share
+        of TransformerDecoder's joint projection."""
         if cache is None:
             key_b = key.permute(1, 0, 2)
             k = linear(key_b, self.k.weight, self.k.bias)     # [B,nK,C/H]
@@ -269,6 +270,13 @@ class GlobalShareCrossAttention(nn.Module):
                                              table=tables, rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz,
                                              cos_sin=cos_sin, attn_mask=attn_mask, dropout_p=p, rng_state=rng,
                                              salt=self._salt)
+        return x, attn
+
+    def forward(self, query, key, reference_point, reference_angle, xyz, attn_mask=None, key_padding_mask=None,
+                cache=None):
+        query_b = query.permute(1, 0, 2)
+        q = linear(query_b, self.q.weight, self.q.bias)   # [B,nQ,C]
+        x, attn = self.core(q, key, reference_point, reference_angle, xyz, attn_mask, cache)
         x = linear(x, self.proj.weight, self.proj.bias)
         if not self.defer_proj_drop:  # (the caller applies it together with its own residual dropout: one mask)
             x = self.proj_drop(x)
@@ -365,6 +373,10 @@ class MultiheadSelfAttention(nn.Module):
 # =====================================================================================================
 # decoder layers
 # =====================================================================================================
+# the glue between a layer's attention cores as three launches (rowblock.hip); VDETR_ROWBLOCK=0: one launch per op (A/B, parity)
+_ROWBLOCK = os.environ.get("VDETR_ROWBLOCK", "1") != "0"
+
+
 def _act_drop(mod, h):
     """``mod.dropout(mod.activation(h))`` of an FFN block (:566, :604): one launch for relu + dropout on the GPU."""
     if type(mod.activation) is nn.ReLU and h.is_cuda and h.dtype == torch.float32 and h.numel() % 4 == 0:
@@ -436,6 +448,23 @@ class GlobalDecoderLayer(nn.Module):
         if self._aln_salts is None:
             self._aln_salts = [ALN.new_salt() for _ in range(3)]
         tgt2 = self.pre_normed if self.pre_normed is not None else ALN.layer_norm(tgt, self.norm1)
+        if (_ROWBLOCK and self.post_norms and not return_attn_weights and not self.pos_for_key and
+                RB.usable(self, tgt, query_pos, (tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask))):
+            # everything between the attention cores as three launches (rowblock.hip): the same values, the same dropout
+            # streams (salts) as the composition below
+            B = tgt.shape[1]
+            sa, ca = self.self_attn, self.multihead_attn
+            q, k, v = RB.qkv(tgt2, query_pos, sa, B)
+            p = sa.dropout if sa.training else 0.0
+            core = A.fused_attention(q, k, v, num_heads=sa.num_heads, scale=sa.head_dim ** -0.5, shared_kv=False, dropout_p=p,
+                                     salt=sa._salt)
+            tgt, qc = RB.proj_q(core, tgt, query_pos, sa.out_proj, ca.q, self.dropout1, self.norm2, self._aln_salts[0], B)
+            core, _ = ca.core(qc, memory, reference_point, reference_angle, enc_xyz, None, self.cross_cache)
+            if getattr(self, "_act_salt", None) is None:
+                self._act_salt = BNA.new_salt()
+            res = RB.ffn(core, tgt, self, self.post_norms, self._aln_salts, self._act_salt, B)
+            self.post_normed = tuple(r for r in res[1:] if r is not None)
+            return res[0], None
         q = k = self.with_pos_embed(tgt2, query_pos)
         branch = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
         tgt, tgt2 = ALN.add_dropout_layer_norm(tgt, branch, self.dropout1, self.norm2, salt=self._aln_salts[0])
