@@ -433,6 +433,40 @@ typedef struct vdetr_rb_ffn_desc {
 } vdetr_rb_ffn_desc;
 int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t stream);
 
+/* Backward of the three launches: the input gradients as one launch each (same descriptors as the forward, whose saved
+ * outputs they read); they also write the dY operand of every linear map's weight gradient (the caller computes those, e.g.
+ * batched after the backward pass) and per-workgroup partial sums of the LayerNorm parameter gradients, [ceil(rows / 16)][4][256]
+ * = (dgamma, dbeta, dgamma2, dbeta2) rows in the layout vdetr_add_ln_param_reduce_batch_f32 reduces.  Gradient inputs may be
+ * NULL (= zero) where noted. */
+typedef struct vdetr_rb_qkv_grads {
+  const float *dq, *dk, *dv;           /* [B,nQ,256] gradients of the three outputs */
+  float *dq_rows, *dk_rows, *dv_rows;  /* [rows,256] the same in sequence-first row order (weight-gradient operands), or NULL */
+  float* d_x;                          /* [rows,256] gradient of t + pos (= gradient of pos), or NULL */
+  float* d_t;                          /* [rows,256] gradient of t */
+} vdetr_rb_qkv_grads;
+int vdetr_rb_qkv_bwd_f32(const vdetr_rb_qkv_desc* d, const vdetr_rb_qkv_grads* g, vdetr_stream_t stream);
+
+typedef struct vdetr_rb_projq_grads {
+  const float* d_y;     /* [rows,256] gradient of y from its later uses, or NULL */
+  const float* d_qout;  /* [B,nQ,256] gradient of qout, or NULL */
+  float* d_tgt;         /* [rows,256] gradient of tgt */
+  float* d_a;           /* [B,nQ,256] gradient of a, or NULL */
+  float* d_t2;          /* [rows,256] gradient of t2 + pos (= gradient of pos), or NULL */
+  float* dq_rows;       /* [rows,256] d_qout in sequence-first row order (operand of the q weight gradient), or NULL */
+  float* d_proj;        /* [rows,256] gradient of the out-projection's output (after the dropout mask) */
+  float* part_n2;       /* [ceil(rows/16)][4][256] */
+} vdetr_rb_projq_grads;
+int vdetr_rb_proj_q_bwd_f32(const vdetr_rb_projq_desc* d, const vdetr_rb_projq_grads* g, vdetr_stream_t stream);
+
+typedef struct vdetr_rb_ffn_grads {
+  const float *d_z, *d_o1, *d_o2;   /* [rows,256] each may be NULL */
+  float* d_tgt;                     /* [rows,256] */
+  float* d_a;                       /* [B,nQ,256] or NULL */
+  float *d_lin2, *d_lin1, *d_proj;  /* [rows,256] dY of lin2, lin1, proj */
+  float *part_post, *part_n3;       /* [ceil(rows/16)][4][256]: post1 / post2; norm3 (rows 0-1) */
+} vdetr_rb_ffn_grads;
+int vdetr_rb_ffn_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * y = dropout(relu(BatchNorm1d(x))) on [B, C, N]: the hidden blocks of GenericMLP (models/helpers.py:74-141,
  * Conv1d -> BatchNorm1d -> ReLU -> Dropout; the box heads of models/vdetr_transformer.py:193-242 and

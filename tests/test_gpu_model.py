@@ -489,8 +489,8 @@ def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
     step's machinery ON — fused glue launches, the table gradient on the side stream, weight gradients parked and flushed —
     against the same model on the CPU with the native entry points routed to the oracle: the boxes / logits of all 9 stages at
     1e-3, the gradient of the backbone features, and the gradient of EVERY parameter (RPE table MLPs included).
-    Queries are matched by the token they were proposed from: the top-1024 selection is compared as a set, so a swap of two
-    neighbours in the sorted order (objectness equal to the last bit) is not an error."""
+    A query is (rank, token): ranks at which the two sides' top-1024 selections hold different tokens (a swap of two neighbours
+    in the sorted order, objectness equal to the last bit) are left out of the per-query comparison; at most 4 may differ."""
     import copy
     import bench
     from vdetr_amd import runtime
@@ -540,14 +540,14 @@ def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
     top_c = torch.topk(stages_c[0]["objectness_prob"].detach(), nq, dim=1)[1]
     same_order = torch.equal(top_g, top_c)
     for b in range(bs):
-        sg, sc = set(top_g[b].tolist()), set(top_c[b].tolist())
-        assert len(sg & sc) >= nq - 2, f"scene {b}: the two sides propose different tokens ({nq - len(sg & sc)} of {nq})"
-        pos_c = {t: i for i, t in enumerate(top_c[b].tolist())}
-        rows_g = [i for i, t in enumerate(top_g[b].tolist()) if t in pos_c]
-        rows_c = [pos_c[top_g[b, i].item()] for i in rows_g]
+        # query i takes the i-th learned embedding (q_content "random", :401-402): a query is (rank, token).  Ranks at which the
+        # two sides hold different tokens (two objectness values equal to the last bit, swapped in the sort) are left out
+        agree = (top_g[b] == top_c[b]).nonzero().flatten().tolist()
+        assert len(agree) >= nq - 4, f"scene {b}: the two sides rank {nq - len(agree)} of {nq} proposals differently"
         for s in range(1, len(stages_g)):
             for k in keys:
-                assert_close(stages_g[s][k][b][rows_g], stages_c[s][k][b][rows_c].detach().numpy(), 1e-3, 2e-4, f"stage {s} {k} (scene {b})")
+                assert_close(stages_g[s][k][b][agree], stages_c[s][k][b][agree].detach().numpy(), 1e-3, 2e-4,
+                             f"stage {s} {k} (scene {b}, {len(agree)} of {nq} ranks hold the same token)")
     for fg, fc in zip(inp_gpu["backbone_features"], inp_cpu["backbone_features"]):
         assert_close(fg.grad, fc.grad.numpy(), 5e-3, 1e-3 * float(fc.grad.abs().max()), "d loss / d backbone features")
     if same_order:  # (with a different proposal order the query embeddings' rows are permuted: the sets above already matched)

@@ -11,10 +11,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _close(a, b, what, rtol=2e-4, frac=2e-5):
+def _close(a, b, what, rtol=2e-4, frac=2e-5, floor=0.0):
     a, b = a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
     assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=frac * max(np.abs(b).max(), 1e-6), err_msg=what)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=max(frac * max(np.abs(b).max(), 1e-6), floor), err_msg=what)
+
+
+def _floor(name, names, tensors):
+    """the key projection's bias has a zero gradient in exact arithmetic (every row of dS sums to zero): what is compared there is
+    summation noise, whose scale is the weight gradient's (tests/helpers.py: grad_atol)"""
+    if name.endswith(".k.bias"):
+        w = tensors[names.index(name[:-5] + ".weight")]
+        return 1e-4 * float(w.abs().max())
+    return 0.0
 
 
 def _layer(seed=0):
@@ -43,12 +52,17 @@ def _scene(B, nQ, nK, seed):
     return xyz.to(DEV), verts.contiguous().to(DEV)
 
 
-@pytest.mark.parametrize("B,nQ,nK,train", [(1, 64, 256, True), (1, 37, 100, True), (2, 40, 130, True), (1, 64, 256, False), (3, 17, 64, True)])
-def test_fused_layer_equals_separate_launches(monkeypatch, B, nQ, nK, train):
-    """GlobalDecoderLayer.forward_pre through rowblock.py (three launches between the attention cores) and through one launch per
-    op: output, the two output norms, and the gradients of every input and parameter."""
+@pytest.mark.parametrize("fused_bwd", [True, False])
+@pytest.mark.parametrize("B,nQ,nK,train", [(1, 64, 256, True), (1, 37, 100, True), (2, 40, 130, True), (1, 64, 256, False), (3, 17, 64, True),
+                                           (1, 1024, 512, True)])
+def test_fused_layer_equals_separate_launches(monkeypatch, B, nQ, nK, train, fused_bwd):
+    """GlobalDecoderLayer.forward_pre through rowblock.py (three launches between the attention cores, and three for their
+    backward; fused_bwd=False: the separate backward launches behind the fused forward) and through one launch per op: output,
+    the two output norms, and the gradients of every input and parameter."""
     from vdetr_amd import attention as A
+    from vdetr_amd import rowblock as RB
     from vdetr_amd import vdetr_transformer as T
+    monkeypatch.setattr(RB, "FUSED_BWD", fused_bwd)
     layer = _layer(3)
     layer.train(train)
     out_norm, next_norm = torch.nn.LayerNorm(256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
@@ -82,12 +96,16 @@ def test_fused_layer_equals_separate_launches(monkeypatch, B, nQ, nK, train):
     ref = run(False)
     got = run(True)
     again = run(True)
-    for n, a, b, c in zip(["out", "norm(out)", "next norm1(out)", "d tgt", "d memory", "d query_pos"] + names, got, ref, again):
+    all_names = ["out", "norm(out)", "next norm1(out)", "d tgt", "d memory", "d query_pos"] + names
+    for n, a, b, c in zip(all_names, got, ref, again):
         if b is None:
             assert a is None, n
             continue
-        _close(a, b, n)
-        assert torch.equal(a, c), f"{n}: not reproducible"
+        _close(a, b, n, floor=_floor(n, all_names, ref))
+        if "cpb_mlps" in n:  # behind the table gradient, whose workgroups draw their queries dynamically: partial sums regroup
+            _close(a, c, n + " (second run)", rtol=1e-5, frac=1e-6)
+        else:
+            assert torch.equal(a, c), f"{n}: not reproducible"
 
 
 def test_fused_layer_parks_weight_gradients(monkeypatch):
@@ -124,8 +142,9 @@ def test_fused_layer_parks_weight_gradients(monkeypatch):
             runtime.defer_weight_grads(False)
 
     ref, got = run(False), run(True)
-    for n, a, b in zip(["d tgt"] + [n for n, _ in layer.named_parameters()] + ["out_norm.weight", "out_norm.bias"], got, ref):
+    all_names = ["d tgt"] + [n for n, _ in layer.named_parameters()] + ["out_norm.weight", "out_norm.bias"]
+    for n, a, b in zip(all_names, got, ref):
         if b is None:
             assert a is None, n
         else:
-            _close(a, b, n)
+            _close(a, b, n, floor=_floor(n, all_names, ref))

@@ -127,6 +127,24 @@ class RbFfnDesc(ctypes.Structure):
                 [(n, c_void_p) for n in ("y", "mean_y", "rstd_y", "t2", "h", "z", "mean_z", "rstd_z", "o1", "o2")])
 
 
+class RbQkvGrads(ctypes.Structure):
+    """Mirror of ``vdetr_rb_qkv_grads``."""
+
+    _fields_ = [(n, c_void_p) for n in ("dq", "dk", "dv", "dq_rows", "dk_rows", "dv_rows", "d_x", "d_t")]
+
+
+class RbProjQGrads(ctypes.Structure):
+    """Mirror of ``vdetr_rb_projq_grads``."""
+
+    _fields_ = [(n, c_void_p) for n in ("d_y", "d_qout", "d_tgt", "d_a", "d_t2", "dq_rows", "d_proj", "part_n2")]
+
+
+class RbFfnGrads(ctypes.Structure):
+    """Mirror of ``vdetr_rb_ffn_grads``."""
+
+    _fields_ = [(n, c_void_p) for n in ("d_z", "d_o1", "d_o2", "d_tgt", "d_a", "d_lin2", "d_lin1", "d_proj", "part_post", "part_n3")]
+
+
 class BnActDesc(ctypes.Structure):
     """Mirror of ``vdetr_bnact_desc``."""
 
@@ -278,6 +296,9 @@ _SIGNATURES = {
     "vdetr_rb_qkv_f32": (c_int, [ctypes.POINTER(RbQkvDesc), c_void_p]),
     "vdetr_rb_proj_q_f32": (c_int, [ctypes.POINTER(RbProjQDesc), c_void_p]),
     "vdetr_rb_ffn_f32": (c_int, [ctypes.POINTER(RbFfnDesc), c_void_p]),
+    "vdetr_rb_qkv_bwd_f32": (c_int, [ctypes.POINTER(RbQkvDesc), ctypes.POINTER(RbQkvGrads), c_void_p]),
+    "vdetr_rb_proj_q_bwd_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), c_void_p]),
+    "vdetr_rb_ffn_bwd_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

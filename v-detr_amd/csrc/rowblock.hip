@@ -71,7 +71,7 @@ __device__ __forceinline__ void rb_keep4_act(const RbDrop& g, long i, bool (&kee
 // batch-first tensors [B, nQ, C]: `rb_bmajor` is the row of (q, b) there (identity for one scene).
 __device__ __forceinline__ int rb_bmajor(int row, int B, int nQ) { return B == 1 ? row : (row % B) * nQ + row / B; }
 __device__ __forceinline__ void rb_stage_rows(const float* __restrict__ src, int row0, int rows, int B, bool bmajor, float* xs, int tid,
-                                              const float* __restrict__ add = nullptr, float* sum_out = nullptr) {
+                                              const float* __restrict__ add = nullptr, float* sum_out = nullptr, float* copy_out = nullptr) {
 #pragma unroll
   for (int u = 0; u < kRbRows * kRbC / 4 / kRbThreads; ++u) {  // 4 float4 per thread
     const int e = tid + u * kRbThreads, r = e >> 6, c4 = e & 63;
@@ -82,6 +82,7 @@ __device__ __forceinline__ void rb_stage_rows(const float* __restrict__ src, int
       v += reinterpret_cast<const f32x4*>(add + (size_t)row * kRbC)[c4];
       if (sum_out && row0 + r < rows) reinterpret_cast<f32x4*>(sum_out + (size_t)row * kRbC)[c4] = v;
     }
+    if (copy_out && row0 + r < rows) reinterpret_cast<f32x4*>(copy_out + (size_t)row * kRbC)[c4] = v;  // the rows in sequence-first order
     *reinterpret_cast<f32x4*>(xs + r * kRbStride + 4 * c4) = v;
   }
 }
@@ -114,6 +115,29 @@ __device__ __forceinline__ void rb_gemm(const float (&a)[64], const float* __res
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % 3][nt][e], acc[nt], 0, 0, 0);
   }
 }
+// One dword of every 128-byte line of up to three [256][256] weight matrices, all requests in flight at once.  Between two uses
+// of a weight matrix the step streams hundreds of MB through the 4 MB L2s, so every launch finds its weights cold in its XCD's
+// L2: walked with a 2-step look-ahead, rb_gemm then pays a memory round trip per step (measured: 12 us per 256 x 256 product
+// instead of the 4 us its 256 matrix instructions take).  Touching everything first costs ONE round trip per launch.
+__device__ __forceinline__ float rb_touch(const float* w0, const float* w1, const float* w2, int tid) {
+  float v[24];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const size_t o = (size_t)(tid + u * kRbThreads) * 32;  // 2048 lines of 32 floats
+    v[u] = w0[o];
+    v[8 + u] = w1 ? w1[o] : 0.f;
+    v[16 + u] = w2 ? w2[o] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 24; ++u) s += v[u];
+  return s;
+}
+// (keeps the touch alive: never true for finite weights)
+__device__ __forceinline__ void rb_sink(float s, float* out) {
+  if (s == 1.2345678e-30f) out[0] = s;
+}
+
 // accumulators -> per-row float4 of the four adjacent columns (row 4 g + r, columns col0 + 4 c ..)
 __device__ __forceinline__ f32x4 rb_row(const f32x4 (&acc)[4], int r) { return f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}; }
 
@@ -166,6 +190,7 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A) {
   f32x4 y[4];  // the residual stream of this lane's rows 4 g + r, columns colq ..
   float mean[4], rstd[4];
 
+  const float touched = rb_touch(A.proj.w, A.lin1.w, A.lin2.w, tid);
   rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
   __syncthreads();
   rb_load_a(xs, lane, a);
@@ -264,6 +289,7 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A) {
       if (w == 0 && c == 0) { A.mean_z[row] = mean[r]; A.rstd_z[row] = rstd[r]; }
     }
   }
+  rb_sink(touched, A.z);
 }
 
 // ---- rb_proj_q_kernel: out-projection of the self-attention + residual block 1 + the cross-attention's query projection ------
@@ -282,6 +308,7 @@ __global__ __launch_bounds__(kRbThreads) void rb_proj_q_kernel(RbProjQArgs A) {
   f32x4 acc[4];
   f32x4 y[4];
   float mean[4], rstd[4];
+  const float touched = rb_touch(A.proj.w, A.q.w, nullptr, tid);
   rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
   __syncthreads();
   rb_load_a(xs, lane, a);
@@ -337,6 +364,7 @@ __global__ __launch_bounds__(kRbThreads) void rb_proj_q_kernel(RbProjQArgs A) {
       *reinterpret_cast<f32x4*>(A.qout + (size_t)rb_bmajor(row, A.B, A.rows / A.B) * kRbC + colq) = rb_row(acc, r) + bias;
     }
   }
+  rb_sink(touched, A.qout);
 }
 
 // ---- rb_qkv_kernel: the self-attention's three projections; blockIdx.y = 0 / 1 / 2 = q / k / v ---------------------------------
@@ -350,6 +378,7 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_kernel(RbQkvArgs A) {
   const int row0 = blockIdx.x * kRbRows, which = blockIdx.y;
   const int col0 = 64 * w, colq = col0 + 4 * c;
   const bool with_pos = which < 2 && A.pos != nullptr;
+  const float touched = rb_touch(A.w + (size_t)which * kRbC * kRbC, nullptr, nullptr, tid);
   rb_stage_rows(A.t, row0, A.rows, A.B, false, xs, tid, with_pos ? A.pos : nullptr, which == 0 ? A.x : nullptr);
   __syncthreads();
   float a[64];
@@ -366,6 +395,299 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_kernel(RbQkvArgs A) {
     if (row >= A.rows) continue;
     *reinterpret_cast<f32x4*>(out + (size_t)rb_bmajor(row, A.B, A.rows / A.B) * kRbC + colq) = rb_row(acc, r) + bias;
   }
+  rb_sink(touched, out);
+}
+
+// =====================================================================================================================================
+// Backward of the three launches: the input-gradient chains, again one launch each.  The weight / bias gradients stay what they
+// were — batched GEMMs after the backward pass (helpers.DeferredParamGrads) on the (dY, X) pairs these kernels write —, the
+// LayerNorm parameter sums leave as per-workgroup partial rows in the layout of add_ln.hip (add_ln_param_reduce_batch_kernel
+// sums them at the flush).  dX = dY W needs W "column-wise": with MFMA column j of tile nt = output column 64 w + 4 j + nt the
+// four tiles' B operands of one contraction index are ONE float4 of a weight row.
+// =====================================================================================================================================
+
+// acc[nt][r] += sum_k X[4 g + r][k] W[k][col0 + 4 c + nt]   (W [256][256] as stored: the gradient of y = x W^T with respect to x)
+__device__ __forceinline__ void rb_gemm_t(const float (&a)[64], const float* __restrict__ W, int col0, int lane, f32x4 (&acc)[4]) {
+  const int j = lane & 15, kg = lane >> 4;
+  const float* wp = W + (size_t)(4 * kg) * kRbC + col0 + 4 * j;  // + (16 m + e) rows
+  f32x4 b[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    b[0][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)e * kRbC);
+    b[1][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 + e) * kRbC);
+  }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m + 2 < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[(m + 2) % 3][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * (m + 2) + e) * kRbC);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % 3][e][nt], acc[nt], 0, 0, 0);
+  }
+}
+
+// sum over the four row groups g of a wave (lanes c, c + 16, c + 32, c + 48), result in every lane
+__device__ __forceinline__ float rb_sum_g(float v) {
+  pair_u32 p = xrow16(__float_as_uint(v));
+  v = __uint_as_float(p.a) + __uint_as_float(p.b);
+  p = xhalf32(__float_as_uint(v));
+  return __uint_as_float(p.a) + __uint_as_float(p.b);
+}
+
+// LayerNorm backward of the workgroup's 16 rows (add_ln.hip: add_ln_bwd_kernel): yv = the normalised tensor, go / go2 = the
+// gradients of its one or two affine outputs, dy_in = the gradient reaching it from elsewhere.  Returns in dx the total gradient;
+// adds the block's parameter sums to part [4][256] (dgamma, dbeta, dgamma2, dbeta2; rows past the end contribute nothing).
+// red: [2][4 waves][16 rows].
+__device__ __forceinline__ void rb_ln_bwd(const f32x4 (&yv)[4], const f32x4 (&go)[4], const f32x4 (&go2)[4], bool two, const f32x4 (&dy_in)[4],
+                                          const float (&mean)[4], const float (&rstd)[4], const bool (&live)[4], const float* gamma,
+                                          const float* gamma2, int colq, float* red, float* part, int w, int lane, f32x4 (&dx)[4]) {
+  const int g = lane >> 4, c = lane & 15;
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + colq);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 ga2 = two ? *reinterpret_cast<const f32x4*>(gamma2 + colq) : zero;
+  f32x4 xh[4], t[4];
+  f32x4 dga = zero, dbe = zero, dga2 = zero, dbe2 = zero;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float h = (yv[r][e] - mean[r]) * rstd[r];
+      const float o1 = live[r] ? go[r][e] : 0.f, o2 = (live[r] && two) ? go2[r][e] : 0.f;
+      dga[e] += o1 * h; dbe[e] += o1; dga2[e] += o2 * h; dbe2[e] += o2;
+      const float tt = o1 * ga[e] + o2 * ga2[e];
+      xh[r][e] = h; t[r][e] = tt;
+      s1 += tt; s2 += tt * h;
+    }
+    s1 = row_allsum_f32(s1); s2 = row_allsum_f32(s2);
+    if (c == 0) { red[w * 16 + 4 * g + r] = s1; red[64 + w * 16 + 4 * g + r] = s2; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * g + r;
+    const float m1 = ((red[i] + red[16 + i]) + (red[32 + i] + red[48 + i])) * (1.f / kRbC);
+    const float m2 = ((red[64 + i] + red[80 + i]) + (red[96 + i] + red[112 + i])) * (1.f / kRbC);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dx[r][e] = dy_in[r][e] + rstd[r] * (t[r][e] - m1 - xh[r][e] * m2);
+  }
+  __syncthreads();  // red may be reused
+  // parameter sums of this block: over r in the lane (done), over g across the wave; lanes g == 0 write their four columns
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { dga[e] = rb_sum_g(dga[e]); dbe[e] = rb_sum_g(dbe[e]); }
+  if (two) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dga2[e] = rb_sum_g(dga2[e]); dbe2[e] = rb_sum_g(dbe2[e]); }
+  }
+  if (g == 0) {
+    *reinterpret_cast<f32x4*>(part + colq) = dga;
+    *reinterpret_cast<f32x4*>(part + kRbC + colq) = dbe;
+    if (two) {
+      *reinterpret_cast<f32x4*>(part + 2 * kRbC + colq) = dga2;
+      *reinterpret_cast<f32x4*>(part + 3 * kRbC + colq) = dbe2;
+    }
+  }
+}
+
+__device__ __forceinline__ f32x4 rb_ld4(const float* p, int row, int colq) { return *reinterpret_cast<const f32x4*>(p + (size_t)row * kRbC + colq); }
+__device__ __forceinline__ void rb_st4(float* p, int row, int colq, const f32x4& v) { *reinterpret_cast<f32x4*>(p + (size_t)row * kRbC + colq) = v; }
+
+// ---- rb_ffn_bwd_kernel ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_desc A, vdetr_rb_ffn_grads G) {
+  __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
+  __shared__ float red[128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int row0 = blockIdx.x * kRbRows;
+  const int col0 = 64 * w, colq = col0 + 4 * c;
+  const RbDrop d2 = rb_drop(A.drop2.p, A.drop2.seed, 0, A.rng_state), da = rb_drop(A.drop_act.p, A.drop_act.seed, 0, A.rng_state),
+               d3 = rb_drop(A.drop3.p, A.drop3.seed, 0, A.rng_state);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const bool two = G.d_o2 != nullptr;
+  const float touched = rb_touch(A.lin2.w, A.lin1.w, A.proj.w, tid);
+  int rowc[4];
+  bool live[4];
+  float mean[4], rstd[4];
+  f32x4 yv[4], go[4], go2[4], din[4], dy[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    live[r] = row < A.rows;
+    rowc[r] = min(row, A.rows - 1);
+    mean[r] = A.mean_z[rowc[r]]; rstd[r] = A.rstd_z[rowc[r]];
+    yv[r] = rb_ld4(A.z, rowc[r], colq);
+    go[r] = G.d_o1 ? rb_ld4(G.d_o1, rowc[r], colq) : zero;
+    go2[r] = two ? rb_ld4(G.d_o2, rowc[r], colq) : zero;
+    din[r] = G.d_z ? rb_ld4(G.d_z, rowc[r], colq) : zero;
+  }
+  // block 3 backward: z = y + drop3(lin2 h); o1 = post1(z), o2 = post2(z)
+  rb_ln_bwd(yv, go, go2, two, din, mean, rstd, live, A.post1.gamma, A.post2.gamma, colq, red, G.part_post + (size_t)blockIdx.x * 4 * kRbC, w, lane, dy);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // d (lin2 output) = dy through the mask of dropout3
+    bool keep[4];
+    rb_keep4_ln(d3, rowc[r], colq >> 2, keep);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? dy[r][e] * d3.scale : 0.f;
+    if (live[r]) rb_st4(G.d_lin2, rowc[r], colq, v);
+    *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
+  }
+  __syncthreads();
+  float a[64];
+  f32x4 acc[4];
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
+  rb_gemm_t(a, A.lin2.w, col0, lane, acc);  // d h
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // through relu + dropout: h > 0 <=> passed both
+    const f32x4 hv = rb_ld4(A.h, rowc[r], colq);
+    f32x4 v = rb_row(acc, r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = hv[e] > 0.f ? v[e] * da.scale : 0.f;
+    if (live[r]) rb_st4(G.d_lin1, rowc[r], colq, v);
+    *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
+  }
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
+  rb_gemm_t(a, A.lin1.w, col0, lane, acc);  // d t2
+  // block 2 backward: y = tgt + drop2(proj a); t2 = norm3(y)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    mean[r] = A.mean_y[rowc[r]]; rstd[r] = A.rstd_y[rowc[r]];
+    yv[r] = rb_ld4(A.y, rowc[r], colq);
+    go[r] = rb_row(acc, r);
+    go2[r] = zero;
+    din[r] = dy[r];
+  }
+  rb_ln_bwd(yv, go, go2, false, din, mean, rstd, live, A.norm3.gamma, nullptr, colq, red, G.part_n3 + (size_t)blockIdx.x * 4 * kRbC, w, lane, dy);
+  // (rb_ln_bwd's barriers: every wave is past its reads of xs)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (live[r]) rb_st4(G.d_tgt, rowc[r], colq, dy[r]);
+    bool keep[4];
+    rb_keep4_ln(d2, rowc[r], colq >> 2, keep);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? dy[r][e] * d2.scale : 0.f;
+    if (live[r]) rb_st4(G.d_proj, rowc[r], colq, v);
+    *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
+  }
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
+  rb_gemm_t(a, A.proj.w, col0, lane, acc);  // d a
+  if (G.d_a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (live[r]) rb_st4(G.d_a, rb_bmajor(rowc[r], A.B, A.rows / A.B), colq, rb_row(acc, r));
+  }
+  rb_sink(touched, G.d_tgt);
+}
+
+// ---- rb_proj_q_bwd_kernel ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kRbThreads) void rb_proj_q_bwd_kernel(vdetr_rb_projq_desc A, vdetr_rb_projq_grads G) {
+  __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
+  __shared__ float red[128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int row0 = blockIdx.x * kRbRows;
+  const int col0 = 64 * w, colq = col0 + 4 * c;
+  const RbDrop d1 = rb_drop(A.drop1.p, A.drop1.seed, 0, A.rng_state);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const float touched = rb_touch(A.q.w, A.proj.w, nullptr, tid);
+  int rowc[4];
+  bool live[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { live[r] = row0 + 4 * g + r < A.rows; rowc[r] = min(row0 + 4 * g + r, A.rows - 1); }
+  float a[64];
+  f32x4 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
+  if (G.d_qout) {  // d (t2 + pos) = d q Wq
+    rb_stage_rows(G.d_qout, row0, A.rows, A.B, true, xs, tid, nullptr, nullptr, G.dq_rows);
+    __syncthreads();
+    rb_load_a(xs, lane, a);
+    rb_gemm_t(a, A.q.w, col0, lane, acc);
+  }
+  float mean[4], rstd[4];
+  f32x4 yv[4], go[4], go2[4], din[4], dy[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    mean[r] = A.mean_y[rowc[r]]; rstd[r] = A.rstd_y[rowc[r]];
+    yv[r] = rb_ld4(A.y, rowc[r], colq);
+    go[r] = rb_row(acc, r);
+    go2[r] = zero;
+    din[r] = G.d_y ? rb_ld4(G.d_y, rowc[r], colq) : zero;
+    if (live[r] && G.d_t2) rb_st4(G.d_t2, rowc[r], colq, go[r]);
+  }
+  rb_ln_bwd(yv, go, go2, false, din, mean, rstd, live, A.norm2.gamma, nullptr, colq, red, G.part_n2 + (size_t)blockIdx.x * 4 * kRbC, w, lane, dy);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (live[r]) rb_st4(G.d_tgt, rowc[r], colq, dy[r]);
+    bool keep[4];
+    rb_keep4_ln(d1, rowc[r], colq >> 2, keep);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? dy[r][e] * d1.scale : 0.f;
+    if (live[r]) rb_st4(G.d_proj, rowc[r], colq, v);
+    *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
+  }
+  __syncthreads();
+  rb_load_a(xs, lane, a);
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
+  rb_gemm_t(a, A.proj.w, col0, lane, acc);
+  if (G.d_a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (live[r]) rb_st4(G.d_a, rb_bmajor(rowc[r], A.B, A.rows / A.B), colq, rb_row(acc, r));
+  }
+  rb_sink(touched, G.d_tgt);
+}
+
+// ---- rb_qkv_bwd_kernel: d (t + pos) = dq Wq + dk Wk;  d t = d (t + pos) + dv Wv ------------------------------------------------------
+__global__ __launch_bounds__(kRbThreads) void rb_qkv_bwd_kernel(vdetr_rb_qkv_desc A, vdetr_rb_qkv_grads G) {
+  __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int row0 = blockIdx.x * kRbRows;
+  const int col0 = 64 * w, colq = col0 + 4 * c;
+  float a[64];
+  f32x4 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float touched = rb_touch(A.w, A.w + (size_t)kRbC * kRbC, A.w + (size_t)2 * kRbC * kRbC, tid);
+  const float* dsrc[3] = {G.dq, G.dk, G.dv};
+  float* drows[3] = {G.dq_rows, G.dk_rows, G.dv_rows};
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    if (which) __syncthreads();  // the previous operand has been read out of the tile
+    rb_stage_rows(dsrc[which], row0, A.rows, A.B, true, xs, tid, nullptr, nullptr, drows[which]);
+    __syncthreads();
+    rb_load_a(xs, lane, a);
+    rb_gemm_t(a, A.w + (size_t)which * kRbC * kRbC, col0, lane, acc);
+    if (which == 1 && G.d_x) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + 4 * g + r < A.rows) rb_st4(G.d_x, row0 + 4 * g + r, colq, rb_row(acc, r));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (row0 + 4 * g + r < A.rows) rb_st4(G.d_t, row0 + 4 * g + r, colq, rb_row(acc, r));
+  rb_sink(touched, G.d_t);
 }
 
 }  // namespace vdetr
@@ -417,4 +739,41 @@ extern "C" int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t strea
                 "rb_ffn: operands must be 16-B aligned");
   hipLaunchKernelGGL(rb_ffn_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d);
   return check_launch("rb_ffn");
+}
+
+extern "C" int vdetr_rb_qkv_bwd_f32(const vdetr_rb_qkv_desc* d, const vdetr_rb_qkv_grads* g, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr && g != nullptr, "rb_qkv_bwd: null descriptor");
+  if (int e = rb_common(d->rows, d->B, "rb_qkv_bwd")) return e;
+  VDETR_REQUIRE(d->w && g->dq && g->dk && g->dv && g->d_t, "rb_qkv_bwd: null pointer");
+  VDETR_REQUIRE(RB_ALIGNED(d->w) && RB_ALIGNED(g->dq) && RB_ALIGNED(g->dk) && RB_ALIGNED(g->dv) && RB_ALIGNED(g->dq_rows) && RB_ALIGNED(g->dk_rows) &&
+                RB_ALIGNED(g->dv_rows) && RB_ALIGNED(g->d_x) && RB_ALIGNED(g->d_t), "rb_qkv_bwd: operands must be 16-B aligned");
+  hipLaunchKernelGGL(rb_qkv_bwd_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g);
+  return check_launch("rb_qkv_bwd");
+}
+
+extern "C" int vdetr_rb_proj_q_bwd_f32(const vdetr_rb_projq_desc* d, const vdetr_rb_projq_grads* g, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr && g != nullptr, "rb_proj_q_bwd: null descriptor");
+  if (int e = rb_common(d->rows, d->B, "rb_proj_q_bwd")) return e;
+  VDETR_REQUIRE(d->proj.w && d->q.w && d->norm2.gamma && d->y && d->mean_y && d->rstd_y && g->d_tgt && g->d_proj && g->part_n2 &&
+                (g->d_y || g->d_qout), "rb_proj_q_bwd: null pointer");
+  VDETR_REQUIRE(RB_ALIGNED(d->proj.w) && RB_ALIGNED(d->q.w) && RB_ALIGNED(d->norm2.gamma) && RB_ALIGNED(d->y) && RB_ALIGNED(g->d_y) &&
+                RB_ALIGNED(g->d_qout) && RB_ALIGNED(g->d_tgt) && RB_ALIGNED(g->d_a) && RB_ALIGNED(g->d_t2) && RB_ALIGNED(g->dq_rows) &&
+                RB_ALIGNED(g->d_proj) && RB_ALIGNED(g->part_n2), "rb_proj_q_bwd: operands must be 16-B aligned");
+  hipLaunchKernelGGL(rb_proj_q_bwd_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g);
+  return check_launch("rb_proj_q_bwd");
+}
+
+extern "C" int vdetr_rb_ffn_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr && g != nullptr, "rb_ffn_bwd: null descriptor");
+  if (int e = rb_common(d->rows, d->B, "rb_ffn_bwd")) return e;
+  VDETR_REQUIRE(d->proj.w && d->lin1.w && d->lin2.w && d->norm3.gamma && d->post1.gamma && d->y && d->mean_y && d->rstd_y && d->h && d->z &&
+                d->mean_z && d->rstd_z && g->d_tgt && g->d_lin2 && g->d_lin1 && g->d_proj && g->part_post && g->part_n3 &&
+                (g->d_z || g->d_o1 || g->d_o2), "rb_ffn_bwd: null pointer");
+  VDETR_REQUIRE(!g->d_o2 || d->post2.gamma, "rb_ffn_bwd: d_o2 without a second output norm");
+  VDETR_REQUIRE(RB_ALIGNED(d->proj.w) && RB_ALIGNED(d->lin1.w) && RB_ALIGNED(d->lin2.w) && RB_ALIGNED(d->norm3.gamma) && RB_ALIGNED(d->post1.gamma) &&
+                RB_ALIGNED(d->post2.gamma) && RB_ALIGNED(d->y) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) && RB_ALIGNED(g->d_z) && RB_ALIGNED(g->d_o1) &&
+                RB_ALIGNED(g->d_o2) && RB_ALIGNED(g->d_tgt) && RB_ALIGNED(g->d_a) && RB_ALIGNED(g->d_lin2) && RB_ALIGNED(g->d_lin1) &&
+                RB_ALIGNED(g->d_proj) && RB_ALIGNED(g->part_post) && RB_ALIGNED(g->part_n3), "rb_ffn_bwd: operands must be 16-B aligned");
+  hipLaunchKernelGGL(rb_ffn_bwd_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g);
+  return check_launch("rb_ffn_bwd");
 }

@@ -11,6 +11,7 @@ gradients parked exactly as helpers._Linear parks them (runtime.defer_weight_gra
 bn_act.py for the same salts: a layer computes the same values on either path.  No CPU path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -20,6 +21,8 @@ from . import attention as A
 from .helpers import DeferredParamGrads, colsum
 
 C = 256
+# the input-gradient chains as one launch each (rb_*_bwd_kernel); VDETR_ROWBLOCK_BWD=0: the separate backward launches (A/B, parity)
+FUSED_BWD = os.environ.get("VDETR_ROWBLOCK_BWD", "1") != "0"
 
 
 def _seq_rows(t, B):
@@ -68,6 +71,28 @@ def _park_or_grad(w, b, dy2, x2, need_w, need_b):
     return dw, db
 
 
+def _ln_sums(part, nblk, ln_params, two):
+    """parameter gradients of a LayerNorm from a fused backward launch's per-workgroup partial rows [nblk][4][256]: parked for the
+    flush (add_ln.DeferredLnGrads) or summed here.  Returns (d_gamma, d_beta, d_gamma2, d_beta2)."""
+    if DeferredParamGrads.enabled and DeferredParamGrads.direct:
+        ALN.DeferredLnGrads.pending.append((part, nblk, C, ln_params, two))
+        return None, None, None, None
+    sums = part.view(nblk, 4, C).sum(0)
+    g2 = ln_params[2]
+    if two:
+        return sums[0], sums[1], sums[2], sums[3]
+    return sums[0], sums[1], (torch.zeros_like(g2) if g2 is not None else None), (torch.zeros_like(g2) if g2 is not None else None)
+
+
+def _opt(t, rows=None):
+    if t is None:
+        return None
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
 def _check(*ts):
     for t in ts:
         if t is None:
@@ -104,8 +129,32 @@ class _Qkv(torch.autograd.Function):
         B = ctx.B
         t2 = t.reshape(-1, C)
         x2 = x if x is not None else t2
-        dq2, dk2, dv2 = (_seq_rows(g.contiguous(), B) for g in (dq, dk, dv))
         need = ctx.needs_input_grad
+        if FUSED_BWD and dq is not None and dk is not None and dv is not None:
+            rows = t2.shape[0]
+            dq, dk, dv = _opt(dq), _opt(dk), _opt(dv)
+            d_t = torch.empty_like(t2)
+            d_x = torch.empty_like(t2) if (need[1] and x is not None) else None
+            if B > 1:
+                rws = torch.empty((3, rows, C), dtype=torch.float32, device=t.device)
+                dq2, dk2, dv2 = rws[0], rws[1], rws[2]
+            else:
+                dq2, dk2, dv2 = dq.view(rows, C), dk.view(rows, C), dv.view(rows, C)
+            d = L.RbQkvDesc()
+            d.rows, d.B, d.w = rows, B, wq.data_ptr()
+            g = L.RbQkvGrads()
+            g.dq, g.dk, g.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+            if B > 1:
+                g.dq_rows, g.dk_rows, g.dv_rows = dq2.data_ptr(), dk2.data_ptr(), dv2.data_ptr()
+            g.d_x = d_x.data_ptr() if d_x is not None else None
+            g.d_t = d_t.data_ptr()
+            L.check(L.lib().vdetr_rb_qkv_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_qkv_bwd")
+            gr = [None] * 6
+            for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
+                gr[i], gr[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
+            return (d_t.view(ctx.shape) if need[0] else None, d_x.view(ctx.shape) if d_x is not None else None,
+                    gr[0], gr[1], gr[2], gr[3], gr[4], gr[5], None)
+        dq2, dk2, dv2 = (_seq_rows(g.contiguous(), B) for g in (dq, dk, dv))
         d_t = d_pos = None
         if need[0] or need[1]:
             d_x = torch.mm(dq2, wq)
@@ -154,6 +203,39 @@ class _ProjQ(torch.autograd.Function):
         rows, eps, p, salt, B, shape = ctx.cfg
         a, y, xq, wo, bo, wq, bq, g2, mean, rstd, rng = ctx.saved_tensors
         need = ctx.needs_input_grad
+        if FUSED_BWD and (d_y is not None or d_qout is not None):
+            dev = y.device
+            d_y, d_qout = _opt(d_y), _opt(d_qout)
+            nblk = (rows + 15) // 16
+            d_tgt = torch.empty((rows, C), dtype=torch.float32, device=dev)
+            d_proj = torch.empty_like(d_tgt)
+            d_t2 = torch.empty_like(d_tgt) if (need[2] and d_qout is not None) else None
+            d_a = torch.empty((B, rows // B, C), dtype=torch.float32, device=dev) if need[0] else None
+            dq_rows = torch.empty_like(d_tgt) if (B > 1 and d_qout is not None) else None
+            part = torch.empty((nblk, 4, C), dtype=torch.float32, device=dev)
+            d = L.RbProjQDesc()
+            d.rows, d.B = rows, B
+            d.rng_state = rng.data_ptr() if (rng is not None and p > 0) else None
+            _lin(d.proj, wo, None)
+            _lin(d.q, wq, None)
+            _drop(d.drop1, p, salt)
+            _norm(d.norm2, g2, g2, eps)
+            d.y, d.mean_y, d.rstd_y = y.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            g = L.RbProjQGrads()
+            g.d_y = d_y.data_ptr() if d_y is not None else None
+            g.d_qout = d_qout.data_ptr() if d_qout is not None else None
+            g.d_tgt, g.d_proj, g.part_n2 = d_tgt.data_ptr(), d_proj.data_ptr(), part.data_ptr()
+            g.d_a = d_a.data_ptr() if d_a is not None else None
+            g.d_t2 = d_t2.data_ptr() if d_t2 is not None else None
+            g.dq_rows = dq_rows.data_ptr() if dq_rows is not None else None
+            L.check(L.lib().vdetr_rb_proj_q_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_proj_q_bwd")
+            gwq = gbq = None
+            if d_qout is not None:
+                gwq, gbq = _park_or_grad(wq, bq, dq_rows if dq_rows is not None else d_qout.view(rows, C), xq.reshape(-1, C), need[5], need[6])
+            gwo, gbo = _park_or_grad(wo, bo, d_proj, _seq_rows(a, B), need[3], need[4])
+            dg, db, _, _ = _ln_sums(part, nblk, ctx.ln_params, False)
+            return (d_a, d_tgt.view(shape), d_t2.view(shape) if d_t2 is not None else None, gwo, gbo, gwq, gbq, dg, db,
+                    None, None, None, None, None)
         d_t2 = None
         gwq = gbq = None
         if d_qout is not None:
@@ -164,7 +246,8 @@ class _ProjQ(torch.autograd.Function):
             return (None,) * 14
         d_x, d_r, dg, db, _, _ = ALN.backward_core((rows, C, eps, p, salt, True), y, g2, None, mean, rstd, rng, ctx.ln_params,
                                                    d_y.contiguous().view(rows, C) if d_y is not None else None, d_t2, None)
-        d_r2 = d_r if d_r is not None else d_x
+        d_x = d_x.view(rows, C)
+        d_r2 = d_r.view(rows, C) if d_r is not None else d_x
         a2 = _seq_rows(a, B)
         d_a = _batch_first(torch.mm(d_r2, wo), B) if need[0] else None
         gwo, gbo = _park_or_grad(wo, bo, d_r2, a2, need[3], need[4])
@@ -217,11 +300,50 @@ class _Ffn(torch.autograd.Function):
         need = ctx.needs_input_grad
         if d_z is None and d_o1 is None and d_o2 is None:
             return (None,) * 24
+        if FUSED_BWD:
+            dev = y.device
+            d_z, d_o1, d_o2 = _opt(d_z), _opt(d_o1), _opt(d_o2)
+            two = d_o2 is not None
+            nblk = (rows + 15) // 16
+            new = lambda: torch.empty((rows, C), dtype=torch.float32, device=dev)
+            d_tgt, d_lin2, d_lin1, d_proj = new(), new(), new(), new()
+            d_a = torch.empty((B, rows // B, C), dtype=torch.float32, device=dev) if need[0] else None
+            parts = torch.empty((2, nblk, 4, C), dtype=torch.float32, device=dev)
+            d = L.RbFfnDesc()
+            d.rows, d.B = rows, B
+            d.rng_state = rng.data_ptr() if rng is not None else None
+            _lin(d.proj, wp, None)
+            _lin(d.lin1, w1, None)
+            _lin(d.lin2, w2, None)
+            _drop(d.drop2, p2, salt2)
+            _drop(d.drop_act, pa, 0)
+            _drop(d.drop3, p3, salt3)
+            _norm(d.norm3, g3, g3, eps3)
+            _norm(d.post1, gp1, gp1, epsp)
+            if gp2 is not None:
+                _norm(d.post2, gp2, gp2, epsp)
+            d.y, d.mean_y, d.rstd_y = y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
+            d.h, d.z, d.mean_z, d.rstd_z = h.data_ptr(), z.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr()
+            g = L.RbFfnGrads()
+            g.d_z = d_z.data_ptr() if d_z is not None else None
+            g.d_o1 = d_o1.data_ptr() if d_o1 is not None else None
+            g.d_o2 = d_o2.data_ptr() if d_o2 is not None else None
+            g.d_tgt, g.d_lin2, g.d_lin1, g.d_proj = d_tgt.data_ptr(), d_lin2.data_ptr(), d_lin1.data_ptr(), d_proj.data_ptr()
+            g.d_a = d_a.data_ptr() if d_a is not None else None
+            g.part_post, g.part_n3 = parts[0].data_ptr(), parts[1].data_ptr()
+            L.check(L.lib().vdetr_rb_ffn_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_ffn_bwd")
+            gw2, gb2 = _park_or_grad(w2, b2, d_lin2, h.view(rows, C), need[6], need[7])
+            gw1, gb1 = _park_or_grad(w1, b1, d_lin1, t2.view(rows, C), need[4], need[5])
+            gwp, gbp = _park_or_grad(wp, bp, d_proj, _seq_rows(a, B), need[2], need[3])
+            dgp1, dbp1, dgp2, dbp2 = _ln_sums(parts[0], nblk, ctx.lnp, two)
+            dg3, db3, _, _ = _ln_sums(parts[1], nblk, ctx.ln3, False)
+            return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 10
         cont = lambda t: t.contiguous().view(rows, C) if t is not None else None
         # block 3: z = y + drop3(lin2 h); o1 = post1(z), o2 = post2(z)
         d_y, d_r3, dgp1, dbp1, dgp2, dbp2 = ALN.backward_core((rows, C, epsp, p3, salt3, True), z, gp1, gp2, stats[2], stats[3], rng,
                                                               ctx.lnp, cont(d_z), cont(d_o1), cont(d_o2))
-        d_r3 = d_r3 if d_r3 is not None else d_y
+        d_y = d_y.view(rows, C)
+        d_r3 = d_r3.view(rows, C) if d_r3 is not None else d_y
         d_h = torch.mm(d_r3, w2)
         gw2, gb2 = _park_or_grad(w2, b2, d_r3, h.view(rows, C), need[6], need[7])
         d_pre = torch.empty_like(d_h)
@@ -232,7 +354,8 @@ class _Ffn(torch.autograd.Function):
         # block 2: y = tgt + drop2(proj a); t2 = norm3(y)
         d_tgt, d_r2, dg3, db3, _, _ = ALN.backward_core((rows, C, eps3, p2, salt2, True), y, g3, None, stats[0], stats[1], rng, ctx.ln3,
                                                         d_y, d_t2, None)
-        d_r2 = d_r2 if d_r2 is not None else d_tgt
+        d_tgt = d_tgt.view(rows, C)
+        d_r2 = d_r2.view(rows, C) if d_r2 is not None else d_tgt
         d_a = _batch_first(torch.mm(d_r2, wp), B) if need[0] else None
         gwp, gbp = _park_or_grad(wp, bp, d_r2, _seq_rows(a, B), need[2], need[3])
         return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 10
