@@ -670,7 +670,8 @@ def kernel_rooflines(cfg_name, device, reps=20):
     gate = aux.cpu()
     ran_box = kbox.value is not None and int(gate[4]) == 0 and int(gate[5]) != 0
     bwd_kernel = (kbox.value if ran_box else kgen.value).decode()
-    fwd_kernel = ("attn_fwd_rpe_auto_kernel (box body" + (", one rotation per pair)" if cos_sin is not None else ")")) if ran_box else "attn_fwd_rpe_auto_kernel (general body" + (", rotated)" if cos_sin is not None else ")")
+    fwd_name = "attn_fwd_rpe_pipe_kernel, persistent workgroups" if A.FWD_KERNEL == 0 else "attn_fwd_rpe_auto_kernel"
+    fwd_kernel = (f"{fwd_name} (box body" + (", one rotation per pair)" if cos_sin is not None else ")")) if ran_box else f"{fwd_name} (general body" + (", rotated)" if cos_sin is not None else ")")
     bwd_obj = {"kernel": f"{bwd_kernel} (RPE table gradient from dS; " + (("rotated boxes: axis-aligned in the turned frame)" if cos_sin is not None else "axis-aligned boxes)") if ran_box else "general vertices" + (" + rotation)" if cos_sin is not None else ")")), "bound": "hbm",
                "achieved": bytes_bwd / t_bwd / 1e9, "peak": 8000.0, "unit": "GB/s",
                "frac": bytes_bwd / t_bwd / 1e9 / 8000.0, "traffic": None, "launch_us": t_bwd * 1e6,

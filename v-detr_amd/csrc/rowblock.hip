@@ -26,6 +26,7 @@ namespace vdetr {
 constexpr int kRbRows = 16;
 constexpr int kRbC = 256;
 constexpr int kRbThreads = 256;
+constexpr int kRbDepth = 6;  // weight tiles in flight per wave (steps of 16 matrix instructions): one wave per SIMD, registers to spare
 constexpr int kRbStride = kRbC + 4;  // floats per LDS row: 16 rows x 1040 B land on 16 different 16-byte slots
 
 struct RbDrop {  // a dropout stream (add_ln.hip: LnRng / bn_act.hip: BnRng): keep iff 16-bit draw >= thresh
@@ -72,18 +73,26 @@ __device__ __forceinline__ void rb_keep4_act(const RbDrop& g, long i, bool (&kee
 __device__ __forceinline__ int rb_bmajor(int row, int B, int nQ) { return B == 1 ? row : (row % B) * nQ + row / B; }
 __device__ __forceinline__ void rb_stage_rows(const float* __restrict__ src, int row0, int rows, int B, bool bmajor, float* xs, int tid,
                                               const float* __restrict__ add = nullptr, float* sum_out = nullptr, float* copy_out = nullptr) {
+  constexpr int kPer = kRbRows * kRbC / 4 / kRbThreads;  // 4 float4 per thread: all requested before the first is used
+  f32x4 v[kPer], p[kPer];
+  int rowv[kPer];
 #pragma unroll
-  for (int u = 0; u < kRbRows * kRbC / 4 / kRbThreads; ++u) {  // 4 float4 per thread
+  for (int u = 0; u < kPer; ++u) {
     const int e = tid + u * kRbThreads, r = e >> 6, c4 = e & 63;
     const int row = min(row0 + r, rows - 1);  // rows past the end are computed on a copy of the last row and not stored
+    rowv[u] = row;
     const int srow = bmajor ? rb_bmajor(row, B, rows / B) : row;
-    f32x4 v = reinterpret_cast<const f32x4*>(src + (size_t)srow * kRbC)[c4];
-    if (add) {  // + the position embedding (sequence-first, like the rows)
-      v += reinterpret_cast<const f32x4*>(add + (size_t)row * kRbC)[c4];
-      if (sum_out && row0 + r < rows) reinterpret_cast<f32x4*>(sum_out + (size_t)row * kRbC)[c4] = v;
-    }
-    if (copy_out && row0 + r < rows) reinterpret_cast<f32x4*>(copy_out + (size_t)row * kRbC)[c4] = v;  // the rows in sequence-first order
-    *reinterpret_cast<f32x4*>(xs + r * kRbStride + 4 * c4) = v;
+    v[u] = reinterpret_cast<const f32x4*>(src + (size_t)srow * kRbC)[c4];
+    p[u] = add ? reinterpret_cast<const f32x4*>(add + (size_t)row * kRbC)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};  // (sequence-first, like the rows)
+  }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + u * kRbThreads, r = e >> 6, c4 = e & 63;
+    const f32x4 t = v[u] + p[u];
+    const bool live = row0 + r < rows;
+    if (sum_out && live) reinterpret_cast<f32x4*>(sum_out + (size_t)rowv[u] * kRbC)[c4] = t;    // t + pos
+    if (copy_out && live) reinterpret_cast<f32x4*>(copy_out + (size_t)rowv[u] * kRbC)[c4] = t;  // the rows in sequence-first order
+    *reinterpret_cast<f32x4*>(xs + r * kRbStride + 4 * c4) = t;
   }
 }
 __device__ __forceinline__ void rb_load_a(const float* xs, int lane, float (&a)[64]) {
@@ -99,20 +108,27 @@ __device__ __forceinline__ void rb_load_a(const float* xs, int lane, float (&a)[
 __device__ __forceinline__ void rb_gemm(const float (&a)[64], const float* __restrict__ W, int col0, int lane, f32x4 (&acc)[4]) {
   const int j = lane & 15, kg = lane >> 4;
   const f32x4* wp = reinterpret_cast<const f32x4*>(W + (size_t)(col0 + 4 * j) * kRbC + 4 * kg);  // + nt * 64 float4 (the next row), + 4 m
-  f32x4 b[3][4];  // weights of steps m, m + 1, m + 2 in flight (L2 latency ~ two steps of 16 matrix instructions)
+  // weights of steps m + 1 .. m + kRbDepth - 1 in flight while step m's 16 matrix instructions run.  The
+  // scheduling barriers pin that order: left alone, the compiler sinks every load to just above its first use and the loop pays
+  // the round trip eight times per product (measured: 12 us instead of 4 per 256 x 256 product).
+  f32x4 b[kRbDepth][4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) { b[0][nt] = wp[nt * 64]; b[1][nt] = wp[nt * 64 + 4]; }
+  for (int d = 0; d < kRbDepth - 1; ++d)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[d][nt] = wp[nt * 64 + 4 * d];
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
-    if (m + 2 < 16) {
+    if (m + kRbDepth - 1 < 16) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) b[(m + 2) % 3][nt] = wp[nt * 64 + 4 * (m + 2)];
+      for (int nt = 0; nt < 4; ++nt) b[(m + kRbDepth - 1) % kRbDepth][nt] = wp[nt * 64 + 4 * (m + kRbDepth - 1)];
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % 3][nt][e], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % kRbDepth][nt][e], acc[nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // One dword of every 128-byte line of up to three [256][256] weight matrices, all requests in flight at once.  Between two uses
@@ -410,23 +426,25 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_kernel(RbQkvArgs A) {
 __device__ __forceinline__ void rb_gemm_t(const float (&a)[64], const float* __restrict__ W, int col0, int lane, f32x4 (&acc)[4]) {
   const int j = lane & 15, kg = lane >> 4;
   const float* wp = W + (size_t)(4 * kg) * kRbC + col0 + 4 * j;  // + (16 m + e) rows
-  f32x4 b[3][4];
+  f32x4 b[kRbDepth][4];  // (pipelined and pinned as in rb_gemm)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    b[0][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)e * kRbC);
-    b[1][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 + e) * kRbC);
-  }
+  for (int d = 0; d < kRbDepth - 1; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[d][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * d + e) * kRbC);
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
-    if (m + 2 < 16) {
+    if (m + kRbDepth - 1 < 16) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) b[(m + 2) % 3][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * (m + 2) + e) * kRbC);
+      for (int e = 0; e < 4; ++e)
+        b[(m + kRbDepth - 1) % kRbDepth][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * (m + kRbDepth - 1) + e) * kRbC);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % 3][e][nt], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % kRbDepth][e][nt], acc[nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -1042,7 +1042,12 @@ class TransformerDecoder(nn.Module):
         objectness = box_prediction["objectness_prob"].detach()
         ntok = objectness.shape[1]
         if ntok >= self.num_queries:
-            topk = torch.topk(objectness, self.num_queries, dim=1)[1]
+            # the reference takes torch.topk (:364-366), whose order among EQUAL values is the implementation's choice — and at
+            # 4096 tokens two fp32 objectness values coincide in about every scene (birthday bound: 4096^2 / 2^24), so a CPU and
+            # a GPU run of the same weights rank those two proposals differently and hand them each other's query embedding
+            # (measured: ranks 882 / 883 of BASELINE config 2's scene).  A stable descending sort is one of the orders topk may
+            # return, and the same one on every device: ties go to the lower token index.
+            topk = torch.sort(objectness, dim=1, descending=True, stable=True)[1][:, :self.num_queries]
         else:
             topk = torch.arange(ntok, device=objectness.device).unsqueeze(0).repeat(objectness.shape[0], 1)
 
