@@ -404,7 +404,12 @@ def test_deferred_weight_gradients_equal_inline_ones(batch):
     defer_weight_grads(False)
     assert res[True].keys() == res[False].keys()
     for n, g in res[False].items():
-        assert float((res[True][n] - g).abs().max()) <= 2e-4 * (float(g.abs().max()) + 1e-12), n
+        scale = float(g.abs().max())
+        if n.endswith(".bias") and n[:-4] + "weight" in res[False]:
+            # a bias in front of a batch norm (decoder.norm feeds the heads' conv + BN) has a zero gradient in exact arithmetic:
+            # what is left is summation noise on the scale of the sibling weight's gradient
+            scale = max(scale, float(res[False][n[:-4] + "weight"].abs().max()))
+        assert float((res[True][n] - g).abs().max()) <= 2e-4 * (scale + 1e-12), n
 
 
 @pytest.mark.parametrize("defer", [True, False])
@@ -536,8 +541,9 @@ def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
     for k in keys:  # stage 0: all 4096 tokens
         assert_close(stages_g[0][k], stages_c[0][k].detach().numpy(), 1e-3, 2e-4, f"stage 0 {k}")
     # the proposals: top-nq tokens by stage-0 objectness, on each side
-    top_g = torch.topk(stages_g[0]["objectness_prob"].detach().cpu(), nq, dim=1)[1]
-    top_c = torch.topk(stages_c[0]["objectness_prob"].detach(), nq, dim=1)[1]
+    # (the model's own rule: a stable descending sort, ties to the lower token index — vdetr_transformer.py, proposals)
+    top_g = torch.sort(stages_g[0]["objectness_prob"].detach().cpu(), dim=1, descending=True, stable=True)[1][:, :nq]
+    top_c = torch.sort(stages_c[0]["objectness_prob"].detach(), dim=1, descending=True, stable=True)[1][:, :nq]
     same_order = torch.equal(top_g, top_c)
     for b in range(bs):
         # query i takes the i-th learned embedding (q_content "random", :401-402): a query is (rank, token).  Ranks at which the

@@ -69,8 +69,15 @@ class Runner:
                                             L.ptr(self.lse), L.ptr(self.scores), L.ptr(self.ws), self.nws, L.stream_ptr()), "attn_fwd")
 
 
+NAMES = {0: "split", 2: "pipe", 1: "grid"}
+
+
 def compare(case, dropout, store_scores, rng, label):
-    new, old = Runner(case, 0, dropout, store_scores, rng), Runner(case, 1, dropout, store_scores, rng)
+    return all([compare_one(case, dropout, store_scores, rng, f"{label} [{NAMES[k]}]", k) for k in (0, 2)])
+
+
+def compare_one(case, dropout, store_scores, rng, label, kernel):
+    new, old = Runner(case, kernel, dropout, store_scores, rng), Runner(case, 1, dropout, store_scores, rng)
     new.out.fill_(float("nan")); new.lse.fill_(float("nan"))
     new(); old()
     torch.cuda.synchronize()
@@ -91,10 +98,10 @@ def compare(case, dropout, store_scores, rng, label):
 
 
 def time_pair(case, dropout, reps, rng):
-    new, old = Runner(case, 0, dropout, True, rng), Runner(case, 1, dropout, True, rng)
-    ts = {0: [], 1: []}
+    runners = {k: Runner(case, k, dropout, True, rng) for k in (0, 2, 1)}
+    ts = {0: [], 1: [], 2: []}
     for i in range(reps + 3):
-        for kern, r in ((0, new), (1, old)):
+        for kern, r in runners.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r()
@@ -103,7 +110,8 @@ def time_pair(case, dropout, reps, rng):
             if i >= 3:
                 ts[kern].append(e0.elapsed_time(e1) * 1e3)
     med = lambda x: sorted(x)[len(x) // 2]
-    return {"pipe_us": med(ts[0]), "pipe_min_us": min(ts[0]), "grid_us": med(ts[1]), "grid_min_us": min(ts[1])}
+    return {"split_us": med(ts[0]), "split_min_us": min(ts[0]), "pipe_us": med(ts[2]), "pipe_min_us": min(ts[2]),
+            "grid_us": med(ts[1]), "grid_min_us": min(ts[1])}
 
 
 if __name__ == "__main__":
@@ -113,7 +121,7 @@ if __name__ == "__main__":
     rng = A.begin_step(dev)
     ok = True
     if "--only" in sys.argv:  # one kernel, `reps` launches: the process a rocprofv3 --pmc pass wraps
-        kern = 0 if sys.argv[sys.argv.index("--only") + 1] == "pipe" else 1
+        kern = {"split": 0, "pipe": 2, "grid": 1}[sys.argv[sys.argv.index("--only") + 1]]
         _, bs, nK, nQ, *_ = bench.CONFIGS[cfg]
         r = Runner(make_case(bs, nQ, nK, bench.CONFIGS[cfg][5] == "object_coords", False, dev), kern, 0.1, True, rng)
         for _ in range(reps):

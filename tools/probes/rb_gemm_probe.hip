@@ -12,7 +12,7 @@ __global__ __launch_bounds__(kRbThreads) void probe_kernel(const float* x, const
   __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  rb_stage_rows(x, blockIdx.x * kRbRows, 1024, 1, false, xs, tid);
+  rb_stage_rows(x, blockIdx.x * kRbRows, 4096, 1, false, xs, tid);
   __syncthreads();
   float a[64];
   rb_load_a(xs, lane, a);
@@ -47,10 +47,10 @@ __global__ __launch_bounds__(kRbThreads) void probe_kernel(const float* x, const
 
 int main() {
   float *x, *w, *out;
-  hipMalloc(&x, 1024 * 256 * 4);
+  hipMalloc(&x, 4096 * 256 * 4);
   hipMalloc(&w, 8 * 256 * 256 * 4);
-  hipMalloc(&out, 1024 * 256 * 4);
-  hipMemset(x, 0, 1024 * 256 * 4);
+  hipMalloc(&out, 4096 * 256 * 4);
+  hipMemset(x, 0, 4096 * 256 * 4);
   hipMemset(w, 0, 8 * 256 * 256 * 4);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);

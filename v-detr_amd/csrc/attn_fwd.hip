@@ -505,12 +505,16 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   return VDETR_OK;
 }
 
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, hipStream_t st);  // attn_fwd_pipe.hip
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, hipStream_t st);  // attn_fwd_pipe.hip
+size_t attn_fwd_pipe_img_bytes(int B, int nK);
 
 // the persistent forward (attn_fwd_pipe.hip) takes the 3DV-RPE attention as the model runs it: fp32, table edge 10, no mask
 static bool pipe_eligible(const vdetr_attn_desc* d) {
-  return d->kind == VDETR_ATTN_SHARED_KV && d->table && d->table_size == 10 && !d->mask && d->fwd_kernel == 0;
+  return d->kind == VDETR_ATTN_SHARED_KV && d->table && d->table_size == 10 && !d->mask && d->fwd_kernel != 1;
 }
+// fwd_kernel 0: the persistent forward with its products on the bf16 matrix unit (three-way / two-way split operands, fp32
+// accuracy: attn_fwd_pipe.hip); 2: the same with fp32 matrix instructions; 1: the grid kernel
+static bool pipe_split(const vdetr_attn_desc* d) { return pipe_eligible(d) && d->fwd_kernel == 0; }
 
 // key split so that small query counts still fill the chip (shared kinds only)
 static int choose_ksplit(const vdetr_attn_desc* d) {
@@ -547,9 +551,10 @@ extern "C" size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d) return 0;
   const int ks = choose_ksplit(d);
   const size_t sched = pipe_eligible(d) && !d->fwd_sched ? 256 : 0;  // the item counter, where the caller brings none
-  if (ks == 1) return sched;
+  const size_t img = pipe_split(d) ? attn_fwd_pipe_img_bytes(d->B, d->nK) + 256 : 0;
+  if (ks == 1) return sched + img;
   const size_t rows = (size_t)d->B * d->nQ * d->H;
-  return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256 + sched;
+  return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256 + sched + img;
 }
 
 extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
@@ -578,15 +583,18 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
       return VDETR_ERR_LAUNCH;
     }
   }
+  uintptr_t ws_top = (uintptr_t)workspace + sched_bytes;
   if (ks > 1) {
     const size_t rows = (size_t)d->B * d->nQ * d->H;
-    uintptr_t base = ((uintptr_t)workspace + sched_bytes + 255) & ~(uintptr_t)255;
+    uintptr_t base = (ws_top + 255) & ~(uintptr_t)255;
     P.part_o = (float*)base;
     P.part_lse = P.part_o + (size_t)ks * rows * kDh;
     P.ksplit = ks;
     const int ntiles = (d->nK + 15) / 16;
     P.tiles_per_split = (ntiles + ks - 1) / ks;
+    ws_top = base + (size_t)ks * rows * (kDh + 1) * sizeof(float);
   }
+  char* kv_img = pipe_split(d) ? (char*)((ws_top + 255) & ~(uintptr_t)255) : nullptr;
   const size_t lds_table = rpe ? (size_t)kRpeVerts * P.T * P.T * P.T * 16 : 0;
   const size_t lds = lds_table + (size_t)kFwdWaves * 16 * kPPad * 4 > (size_t)kFwdWaves * kWave * 24 * 4
                          ? lds_table + (size_t)kFwdWaves * 16 * kPPad * 4
@@ -595,7 +603,7 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
   if (pipe) {
     VDETR_REQUIRE((size_t)d->nK * P.k_stride < (1u << 30) && (size_t)d->nK * P.v_stride < (1u << 30) && (size_t)4 * d->nK < (1u << 30),
                   "attn_fwd: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
-    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), st)) return e;
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, st)) return e;
   } else if (perhead) {
     dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
     if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;

@@ -47,6 +47,7 @@ struct PipeArgs {
   AttnParams P;
   unsigned* counter;  // device word, zero before the launch; the last draw of the launch sets it back to zero
   int nitems, qtiles; // items = B x qtiles x ksplit, qtiles = ceil(nQ / 4)
+  const char* kv_img; // SPLIT: [B][tiles] operand images of K and V (attn_fwd_pack_kv_kernel)
 };
 
 // ---- per-axis tap as in attn_common.h (rpe_axis), with the table edge a constant --------------------------------------
@@ -157,57 +158,115 @@ __device__ __forceinline__ float pipe_give_back(float v, bool swapped, bool odd_
 
 enum { kPipeBox = 0, kPipeBoxRot = 1, kPipeGeneral = 2 };
 
-struct PipeTile {  // operands of one 16-key tile
-  f32x4 kb[4], vb[4];
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+// SPLIT: QK^T and PV on the bf16 matrix unit.  fp32 MFMA and VALU instructions exclude each other on a SIMD, so
+// the 32 v_mfma_f32_16x16x4_f32 of a tile cost 1,024 of the ~4,500 issue cycles a wave spends on it.  With x = h + m + l (three
+// bf16, exact: 3 x 8 = 24 significant bits) a product is the six terms of order <= 2 (hh, hm, mh, mm, hl, lh: what is dropped is
+// 2^-24 of it, an fp32 rounding) on v_mfma_f32_16x16x32_bf16: 12 instructions of 16 cycles for QK^T instead of 16 of 32.  PV takes
+// P and V as two halves each (three terms, 2^-16 of a product: the output is a convex combination of V rows, nothing amplifies it):
+// 12 v_mfma_f32_16x16x16_bf16 of 8 cycles instead of 16 of 32.  K and V arrive pre-split, in operand order, from an image that a
+// small launch packs once per call (attn_fwd_pack_kv_kernel: [tile][K: 3 parts x 2 k-halves | V: 4 d-tiles][lane][16 B]).
+constexpr int kImgK = 6, kImgV = 4;                         // 16-byte pieces per lane and tile
+constexpr int kImgTileBytes = (kImgK + kImgV) * kWave * 16;  // 10,240 B per 16-key tile
+
+template <bool SPLIT>
+struct PipeTileT {  // operands of one 16-key tile
+  f32x4 kb[SPLIT ? 1 : 4], vb[SPLIT ? 1 : 4];
+  bf16x8 k8[SPLIT ? kImgK : 1];  // [2 * part + m]: part 0 / 1 / 2 = h / m / l, k = 32 m + 8 (lane >> 4) + e
+  f32x4 v8[SPLIT ? kImgV : 1];   // [t]: (4 bf16 V_h | 4 bf16 V_l) of keys 4 (lane >> 4) + e, column d = 4 (lane & 15) + t
   float kx, ky, kz;
 };
+
+// x -> three bf16 parts (round to nearest each; the residuals are exact in fp32)
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
 
 struct PipeLane {  // per-item, per-lane bases (element offsets fit 32 bits: checked on the host)
   const float* kp;  // K row of key c, columns 16 g ..
   const float* vp;  // V row of key 4 g, columns 4 c ..
   const float* xp;  // xyz of key c
   float* sp;        // scores row (b, q0 + g, head 0) + c, or NULL
+  const char* img;  // SPLIT: this lane's 16 bytes of piece 0 of the scene's tile 0
 };
 
 // Operand fetches of tile `tile` (rows past nK are clamped to the last key: only the last tile of a launch can have any, and its
 // columns are masked).  Each piece is re-filled in place for the wave's NEXT tile right after its last use in the current one —
 // K behind the QK^T instructions, the coordinates behind the taps, V behind PV — so one register set serves the whole loop and
 // every load has most of a tile's time to arrive.
-__device__ __forceinline__ void pipe_fetch_k(const AttnParams& P, const PipeLane& A, int tile, int nK, int c, PipeTile& t) {
-  const int kc = min((tile << 4) + c, nK - 1) - c;  // row offset of this lane's key against the item base
-  const f32x4* kp = reinterpret_cast<const f32x4*>(A.kp + kc * P.k_stride);
+template <bool SPLIT>
+__device__ __forceinline__ void pipe_fetch_k(const AttnParams& P, const PipeLane& A, int tile, int nK, int c, PipeTileT<SPLIT>& t) {
+  if constexpr (SPLIT) {
+    const char* src = A.img + (size_t)tile * kImgTileBytes;
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
+    for (int j = 0; j < kImgK; ++j) t.k8[j] = *reinterpret_cast<const bf16x8*>(src + j * kWave * 16);
+  } else {
+    const int kc = min((tile << 4) + c, nK - 1) - c;  // row offset of this lane's key against the item base
+    const f32x4* kp = reinterpret_cast<const f32x4*>(A.kp + kc * P.k_stride);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
+  }
 }
-__device__ __forceinline__ void pipe_fetch_x(const PipeLane& A, int tile, int nK, int c, PipeTile& t) {
+template <bool SPLIT>
+__device__ __forceinline__ void pipe_fetch_x(const PipeLane& A, int tile, int nK, int c, PipeTileT<SPLIT>& t) {
   const int kc = min((tile << 4) + c, nK - 1) - c;
   const float* xp = A.xp + kc * 3;
   t.kx = xp[0]; t.ky = xp[1]; t.kz = xp[2];
 }
-__device__ __forceinline__ void pipe_fetch_v(const AttnParams& P, const PipeLane& A, int tile, int nK, int g, PipeTile& t) {
+template <bool SPLIT>
+__device__ __forceinline__ void pipe_fetch_v(const AttnParams& P, const PipeLane& A, int tile, int nK, int g, PipeTileT<SPLIT>& t) {
+  if constexpr (SPLIT) {
+    const char* src = A.img + (size_t)tile * kImgTileBytes + kImgK * kWave * 16;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int kk = min((tile << 4) + 4 * g + s, nK - 1) - 4 * g;
-    t.vb[s] = *reinterpret_cast<const f32x4*>(A.vp + kk * P.v_stride);
+    for (int j = 0; j < kImgV; ++j) t.v8[j] = *reinterpret_cast<const f32x4*>(src + j * kWave * 16);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = min((tile << 4) + 4 * g + s, nK - 1) - 4 * g;
+      t.vb[s] = *reinterpret_cast<const f32x4*>(A.vp + kk * P.v_stride);
+    }
   }
 }
 
+// the A operand of QK^T: fp32 (row c = query c >> 2, head c & 3; d = 16 g + s) or its three bf16 parts (d = 32 m + 8 g + e)
+template <bool SPLIT>
+struct PipeQT {
+  float qa[SPLIT ? 1 : 16];
+  bf16x8 q8[SPLIT ? 6 : 1];  // [2 * part + m]
+};
+
 // one 16-key tile: scores, bias, online softmax, PV
-template <int MODE, bool TAIL>
+template <int MODE, bool TAIL, bool SPLIT>
 __device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab, float* ppad, const PipeLane& A, const PipeQuery& Q,
-                                          const float* __restrict__ role_vp, const float (&qa)[16], PipeTile& ops, int tile, int next, int b,
+                                          const float* __restrict__ role_vp, const PipeQT<SPLIT>& QA, PipeTileT<SPLIT>& ops, int tile, int next, int b,
                                           int qrow, int g, int c, bool swapped, f32x4 (&o)[4], float (&m)[4], float (&l)[4]) {
   const int nK = P.nK;
   const int key = (tile << 4) + c;
   const bool kvalid = !TAIL || key < nK;
   // ---- S = Q K^T --------------------------------------------------------------------------------------------------------
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (SPLIT) {
+    // smallest terms first: (q part, k part) = (l, h), (h, l), (m, m), (m, h), (h, m), (h, h)
+    constexpr int kTerms[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
 #pragma unroll
-  for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
-  pipe_fetch_k(P, A, next, nK, c, ops);
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QA.q8[2 * kTerms[t][0] + mm], ops.k8[2 * kTerms[t][1] + mm], acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(QA.qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
+  }
+  pipe_fetch_k<SPLIT>(P, A, next, nK, c, ops);
   // ---- RPE bias of the role pair, handed back to the pair's owner ------------------------------------------------------
   const float kx = ops.kx, ky = ops.ky, kz = ops.kz;
-  pipe_fetch_x(A, next, nK, c, ops);
+  pipe_fetch_x<SPLIT>(A, next, nK, c, ops);
   f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
   if (MODE == kPipeGeneral) pipe_bias_general(P, tab, role_vp, P.cos_sin != nullptr, Q.rc, Q.rs, kx, ky, kz, s01, s23);
   else pipe_bias_box<MODE == kPipeBoxRot>(P, tab, Q, kx, ky, kz, s01, s23);
@@ -257,16 +316,36 @@ __device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab,
   const f32x4 pa = *reinterpret_cast<const f32x4*>(ppad + c * kPipePad + 4 * g);
   __builtin_amdgcn_wave_barrier();
   // ---- O += P V ---------------------------------------------------------------------------------------------------------
+  if constexpr (SPLIT) {
+    bf16x4 ph, pl;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h = (__bf16)pa[e];
+      ph[e] = h;
+      pl[e] = (__bf16)(pa[e] - (float)h);
+    }
+    const short4v ah = __builtin_bit_cast(short4v, ph), al = __builtin_bit_cast(short4v, pl);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], ops.vb[s][t], o[t], 0, 0, 0);
-  pipe_fetch_v(P, A, next, nK, g, ops);
+    for (int t = 0; t < 4; ++t) {
+      typedef short short8v __attribute__((ext_vector_type(8)));
+      const short8v vv = __builtin_bit_cast(short8v, ops.v8[t]);
+      const short4v vh = {vv[0], vv[1], vv[2], vv[3]}, vl = {vv[4], vv[5], vv[6], vv[7]};
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, vh, o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, vl, o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, vh, o[t], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s], ops.vb[s][t], o[t], 0, 0, 0);
+  }
+  pipe_fetch_v<SPLIT>(P, A, next, nK, g, ops);
 }
 
-template <int MODE>
+template <int MODE, bool SPLIT>
 __device__ __forceinline__ void pipe_tiles(const AttnParams& P, const f32x4* tab, float* ppad, const PipeLane& A, const PipeQuery& Q,
-                                           const float* __restrict__ role_vp, const float (&qa)[16], PipeTile& ops, int tile_begin,
+                                           const float* __restrict__ role_vp, const PipeQT<SPLIT>& qa, PipeTileT<SPLIT>& ops, int tile_begin,
                                            int tile_end, int w, int b, int qrow, int g, int c, bool swapped, f32x4 (&o)[4],
                                            float (&m)[4], float (&l)[4]) {
   const int nK = P.nK;
@@ -274,13 +353,13 @@ __device__ __forceinline__ void pipe_tiles(const AttnParams& P, const f32x4* tab
   int tile = tile_begin + w;
   for (; tile < full_end; tile += kPipeWaves) {
     const int next = tile + kPipeWaves < tile_end ? tile + kPipeWaves : tile;  // (the wave's last tile re-reads itself: no branch)
-    pipe_tile<MODE, false>(P, tab, ppad, A, Q, role_vp, qa, ops, tile, next, b, qrow, g, c, swapped, o, m, l);
+    pipe_tile<MODE, false, SPLIT>(P, tab, ppad, A, Q, role_vp, qa, ops, tile, next, b, qrow, g, c, swapped, o, m, l);
   }
   if (tile < tile_end)  // the last tile of the key range, cut short by nK
-    pipe_tile<MODE, true>(P, tab, ppad, A, Q, role_vp, qa, ops, tile, tile, b, qrow, g, c, swapped, o, m, l);
+    pipe_tile<MODE, true, SPLIT>(P, tab, ppad, A, Q, role_vp, qa, ops, tile, tile, b, qrow, g, c, swapped, o, m, l);
 }
 
-template <bool ROT>
+template <bool ROT, bool SPLIT>
 __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArgs K) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   AttnParams& P = K.P;
@@ -326,15 +405,30 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
     const int qrow = q0 + g;                      // query of this lane's accumulator registers
     const int q_role = min(q0 + gq, nQ - 1);      // query of the pairs this lane looks up
     // A operand of QK^T: row c = (query c >> 2, head c & 3), d = 16 g + s
-    float qa[16];
+    PipeQT<SPLIT> qa;
     {
       const int qi = min(q0 + (c >> 2), nQ - 1);
-      const f32x4* src = reinterpret_cast<const f32x4*>(P.q + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh + 16 * g);
+      const float* qrowp = P.q + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh;
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const f32x4 v = src[s4];
+        for (int mm = 0; mm < 2; ++mm) {
+          const f32x4* src = reinterpret_cast<const f32x4*>(qrowp + 32 * mm + 8 * g);
+          const f32x4 v0 = src[0], v1 = src[1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
+          for (int e = 0; e < 8; ++e) {
+            __bf16 h, md, lo;
+            split3((e < 4 ? v0[e] : v1[e - 4]) * P.scale, h, md, lo);
+            qa.q8[mm][e] = h; qa.q8[2 + mm][e] = md; qa.q8[4 + mm][e] = lo;
+          }
+        }
+      } else {
+        const f32x4* src = reinterpret_cast<const f32x4*>(qrowp + 16 * g);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const f32x4 v = src[s4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qa.qa[s4 * 4 + e] = v[e] * P.scale;
+        }
       }
     }
     // the role query's vertices: box test (the 4 queries of the item together), then the six numbers the box body needs
@@ -363,22 +457,23 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
     A.vp = P.v + ((size_t)b * nK + 4 * g) * P.v_stride + 4 * c;
     A.xp = P.xyz + ((size_t)b * nK + c) * 3;
     A.sp = P.scores ? P.scores + (((size_t)b * nQ + min(qrow, nQ - 1)) * H) * nK + c : nullptr;
+    A.img = SPLIT ? K.kv_img + ((size_t)b * ntiles) * kImgTileBytes + lane * 16 : nullptr;
 
     f32x4 o[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m[4] = {kNegBig, kNegBig, kNegBig, kNegBig}, l[4] = {0.f, 0.f, 0.f, 0.f};
-    PipeTile ops;
+    PipeTileT<SPLIT> ops;
     {
       const int t0 = min(tile_begin + w, ntiles - 1);  // (a wave without a tile in this item fetches, but does not use)
-      pipe_fetch_k(P, A, t0, nK, c, ops);
-      pipe_fetch_x(A, t0, nK, c, ops);
-      pipe_fetch_v(P, A, t0, nK, g, ops);
+      pipe_fetch_k<SPLIT>(P, A, t0, nK, c, ops);
+      pipe_fetch_x<SPLIT>(A, t0, nK, c, ops);
+      pipe_fetch_v<SPLIT>(P, A, t0, nK, g, ops);
     }
     if (box)
-      pipe_tiles<ROT ? kPipeBoxRot : kPipeBox>(P, tab, ppad, A, Q, role_vp, qa, ops, tile_begin, tile_end, w, b, qrow, g, c, swapped, o, m, l);
+      pipe_tiles<ROT ? kPipeBoxRot : kPipeBox, SPLIT>(P, tab, ppad, A, Q, role_vp, qa, ops, tile_begin, tile_end, w, b, qrow, g, c, swapped, o, m, l);
     else
-      pipe_tiles<kPipeGeneral>(P, tab, ppad, A, Q, role_vp, qa, ops, tile_begin, tile_end, w, b, qrow, g, c, swapped, o, m, l);
+      pipe_tiles<kPipeGeneral, SPLIT>(P, tab, ppad, A, Q, role_vp, qa, ops, tile_begin, tile_end, w, b, qrow, g, c, swapped, o, m, l);
 
     // ---- merge of the 8 waves' online-softmax states: m / l per row (1 KB), then the accumulators in two halves of 16 KB ----
     if (tid == 0) {
@@ -436,6 +531,45 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
   }
 }
 
+
+// K, V [B, nK, 64] fp32 (row strides as the forward's) -> the SPLIT kernels' operand images: one wave per 16-key tile.
+__global__ __launch_bounds__(kWave) void attn_fwd_pack_kv_kernel(const float* __restrict__ k, const float* __restrict__ v, int nK, int k_stride,
+                                                                 int v_stride, char* __restrict__ img) {
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int tile = blockIdx.x, b = blockIdx.y, ntiles = gridDim.x;
+  char* dst = img + ((size_t)b * ntiles + tile) * kImgTileBytes + lane * 16;
+  const int key = tile * 16 + c;
+  const float* kr = k + ((size_t)b * nK + min(key, nK - 1)) * k_stride;
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g), v1 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g + 4);
+    bf16x8 h, md, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      __bf16 a0, a1, a2;
+      split3(key < nK ? (e < 4 ? v0[e] : v1[e - 4]) : 0.f, a0, a1, a2);
+      h[e] = a0; md[e] = a1; lo[e] = a2;
+    }
+    *reinterpret_cast<bf16x8*>(dst + (0 + mm) * kWave * 16) = h;
+    *reinterpret_cast<bf16x8*>(dst + (2 + mm) * kWave * 16) = md;
+    *reinterpret_cast<bf16x8*>(dst + (4 + mm) * kWave * 16) = lo;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    bf16x4 h, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = tile * 16 + 4 * g + e;
+      const float x = kk < nK ? v[((size_t)b * nK + kk) * v_stride + 4 * c + t] : 0.f;
+      const __bf16 hh = (__bf16)x;
+      h[e] = hh;
+      lo[e] = (__bf16)(x - (float)hh);
+    }
+    bf16x8 both = {h[0], h[1], h[2], h[3], lo[0], lo[1], lo[2], lo[3]};
+    *reinterpret_cast<bf16x8*>(dst + (kImgK + t) * kWave * 16) = both;
+  }
+}
+
 }  // namespace vdetr
 
 using namespace vdetr;
@@ -443,20 +577,31 @@ using namespace vdetr;
 namespace vdetr {
 // Launch of the persistent forward (called from attn_fwd.hip:vdetr_attn_fwd_f32 with P filled, the key split chosen and the
 // partial buffers placed).  `counter`: a zero device word (workspace head, see vdetr_attn_fwd_workspace_bytes).
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, hipStream_t st) {
+size_t attn_fwd_pipe_img_bytes(int B, int nK) { return (size_t)B * ((nK + 15) / 16) * kImgTileBytes; }
+
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, hipStream_t st) {
   PipeArgs K;
   K.P = P;
   K.counter = counter;
   K.qtiles = (P.nQ + 3) / 4;
   K.nitems = P.B * K.qtiles * P.ksplit;
+  K.kv_img = kv_img;
   const int grid = workgroups < K.nitems ? workgroups : K.nitems;
-  if (P.cos_sin) {
-    if (int e = set_lds(attn_fwd_rpe_pipe_kernel<true>, kPipeLdsBytes, "attn_fwd")) return e;
-    hipLaunchKernelGGL((attn_fwd_rpe_pipe_kernel<true>), dim3(grid), dim3(kPipeThreads), kPipeLdsBytes, st, K);
-  } else {
-    if (int e = set_lds(attn_fwd_rpe_pipe_kernel<false>, kPipeLdsBytes, "attn_fwd")) return e;
-    hipLaunchKernelGGL((attn_fwd_rpe_pipe_kernel<false>), dim3(grid), dim3(kPipeThreads), kPipeLdsBytes, st, K);
+  if (kv_img) {
+    hipLaunchKernelGGL(attn_fwd_pack_kv_kernel, dim3((P.nK + 15) / 16, P.B), dim3(kWave), 0, st, P.k, P.v, P.nK, P.k_stride, P.v_stride, kv_img);
+    if (int e = check_launch("attn_fwd_pack_kv")) return e;
   }
+#define VDETR_PIPE_LAUNCH(ROT, SPLIT)                                                                                       \
+  do {                                                                                                                      \
+    if (int e = set_lds(attn_fwd_rpe_pipe_kernel<ROT, SPLIT>, kPipeLdsBytes, "attn_fwd")) return e;                        \
+    hipLaunchKernelGGL((attn_fwd_rpe_pipe_kernel<ROT, SPLIT>), dim3(grid), dim3(kPipeThreads), kPipeLdsBytes, st, K);      \
+  } while (0)
+  if (P.cos_sin) {
+    if (kv_img) VDETR_PIPE_LAUNCH(true, true); else VDETR_PIPE_LAUNCH(true, false);
+  } else {
+    if (kv_img) VDETR_PIPE_LAUNCH(false, true); else VDETR_PIPE_LAUNCH(false, false);
+  }
+#undef VDETR_PIPE_LAUNCH
   return check_launch("attn_fwd_pipe");
 }
 }  // namespace vdetr
