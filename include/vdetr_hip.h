@@ -381,8 +381,9 @@ int vdetr_add_ln_param_reduce_batch_f32(const vdetr_addln_reduce* items, int n, 
  * All pointers 16-B aligned.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vdetr_rb_linear {
-  const float* w; /* [256, 256] (out, in): nn.Linear.weight */
-  const float* b; /* [256] or NULL */
+  const float* w;  /* [256, 256] (out, in): nn.Linear.weight — read by the backward launches (dX = dY W) */
+  const float* b;  /* [256] or NULL */
+  const float* wt; /* [256, 256] (in, out): the same matrix transposed (vdetr_rb_transpose_f32) — read by the forward launches */
 } vdetr_rb_linear;
 typedef struct vdetr_rb_norm {
   const float *gamma, *beta; /* [256] */
@@ -397,12 +398,17 @@ typedef struct vdetr_rb_qkv_desc {
   int32_t rows, B;
   const float* t;   /* [rows,256] norm1(tgt) */
   const float* pos; /* [rows,256] or NULL: q and k project t + pos, v projects t (:540-542) */
-  const float* w;   /* [768,256] in_proj_weight: q | k | v blocks */
+  const float* w;   /* [768,256] in_proj_weight: q | k | v blocks (backward) */
   const float* b;   /* [768] or NULL */
+  const float* wt;  /* [3][256,256] the three blocks transposed (vdetr_rb_transpose_f32; forward) */
   float* x;         /* [rows,256] t + pos, written (operand of the q / k weight gradients); required with pos */
   float* out;       /* [3][B,nQ,256] batch-first q | k | v */
 } vdetr_rb_qkv_desc;
 int vdetr_rb_qkv_f32(const vdetr_rb_qkv_desc* d, vdetr_stream_t stream);
+/* dst[i][k][n] = src[i][n][k], i < n: the forward launches read a weight through its transposed image (four lanes of a load then
+ * share 64 contiguous bytes; out of the [out][in] layout each reads its own row and the load unit serialises them).  `src` is a
+ * DEVICE array of n device pointers to [256,256] matrices; one launch per optimiser step covers every layer. */
+int vdetr_rb_transpose_f32(const float* const* src, float* dst, int n, vdetr_stream_t stream);
 
 typedef struct vdetr_rb_projq_desc {
   int32_t rows, B;

@@ -89,7 +89,7 @@ class AddLnReduce(ctypes.Structure):
 class RbLinear(ctypes.Structure):
     """Mirror of ``vdetr_rb_linear``."""
 
-    _fields_ = [("w", c_void_p), ("b", c_void_p)]
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("wt", c_void_p)]
 
 
 class RbNorm(ctypes.Structure):
@@ -107,7 +107,7 @@ class RbDrop(ctypes.Structure):
 class RbQkvDesc(ctypes.Structure):
     """Mirror of ``vdetr_rb_qkv_desc``."""
 
-    _fields_ = [("rows", ctypes.c_int32), ("B", ctypes.c_int32)] + [(n, c_void_p) for n in ("t", "pos", "w", "b", "x", "out")]
+    _fields_ = [("rows", ctypes.c_int32), ("B", ctypes.c_int32)] + [(n, c_void_p) for n in ("t", "pos", "w", "b", "wt", "x", "out")]
 
 
 class RbProjQDesc(ctypes.Structure):
@@ -293,6 +293,7 @@ _SIGNATURES = {
     "vdetr_sp_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vdetr_sp_bn_act_fwd_f32": (c_int, [ctypes.POINTER(SpBnDesc), c_void_p]),
     "vdetr_sp_bn_act_bwd_f32": (c_int, [ctypes.POINTER(SpBnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vdetr_rb_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vdetr_rb_qkv_f32": (c_int, [ctypes.POINTER(RbQkvDesc), c_void_p]),
     "vdetr_rb_proj_q_f32": (c_int, [ctypes.POINTER(RbProjQDesc), c_void_p]),
     "vdetr_rb_ffn_f32": (c_int, [ctypes.POINTER(RbFfnDesc), c_void_p]),

@@ -263,13 +263,18 @@ __device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab,
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(QA.qa[s], ops.kb[s >> 2][s & 3], acc, 0, 0, 0);
   }
-  pipe_fetch_k<SPLIT>(P, A, next, nK, c, ops);
+  if constexpr (!SPLIT) pipe_fetch_k<SPLIT>(P, A, next, nK, c, ops);
   // ---- RPE bias of the role pair, handed back to the pair's owner ------------------------------------------------------
   const float kx = ops.kx, ky = ops.ky, kz = ops.kz;
   pipe_fetch_x<SPLIT>(A, next, nK, c, ops);
   f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
   if (MODE == kPipeGeneral) pipe_bias_general(P, tab, role_vp, P.cos_sin != nullptr, Q.rc, Q.rs, kx, ky, kz, s01, s23);
   else pipe_bias_box<MODE == kPipeBoxRot>(P, tab, Q, kx, ky, kz, s01, s23);
+  if constexpr (SPLIT) {  // (24 registers: requested behind the lookups, whose eight vertices are where the registers run out)
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_fetch_k<SPLIT>(P, A, next, nK, c, ops);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   const bool odd = g & 1;
   float sc[4];
   sc[0] = acc[0] + pipe_give_back(s01[0], swapped, odd);

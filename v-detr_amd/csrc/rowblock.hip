@@ -15,7 +15,13 @@
 // MFMA column j of tile nt is output column 64 w + 4 j + nt, so that a lane's four accumulators of one row are four ADJACENT
 // columns: bias, dropout quad hash (add_ln.hip / bn_act.hip key their masks by groups of 4 channels), residual, LayerNorm and
 // the stores all work on float4.  The contraction index of MFMA step s in lane group kg is 16 (s >> 2) + 4 kg + (s & 3): each
-// lane's share of a weight row is contiguous float4s, its share of the activation row comes out of LDS as float4s.
+// lane's share of the activation row comes out of LDS as float4s.
+// The weights of a FORWARD product y = x W^T are read from a transposed image Wt[k][n] (vdetr_rb_transpose_f32, one launch per
+// step for all layers): the four tiles' B operands of one contraction index are then ONE float4 of an image row, and the four
+// lanes the texture unit serves per cycle read 64 contiguous bytes.  Out of nn.Linear's own [n][k] layout every lane of such a quad
+// reads a different row: 64 cycles per load instruction instead of 16, 6.9 us per 256 x 256 product on one CU alone instead of
+// the 4.2 us of its 256 matrix instructions (tools/probes/rb_gemm_probe.hip, profiles/r05_rb_gemm_probe.txt).  The backward's
+// dX = dY W reads W as stored.
 // Everything the existing backward kernels read (y, mean, rstd, t2, h, ...) is written exactly as the separate launches wrote
 // it, with the same dropout streams: the autograd side (v-detr_amd/rowblock.py) reuses vdetr_add_ln_bwd_f32 /
 // vdetr_relu_dropout_bwd_f32 and the parked weight gradients unchanged.
@@ -104,55 +110,51 @@ __device__ __forceinline__ void rb_load_a(const float* xs, int lane, float (&a)[
     for (int e = 0; e < 4; ++e) a[4 * m + e] = v[e];
   }
 }
-// acc[nt][r] += sum_k X[4 g + r][k] W[col0 + 4 c + nt][k]   (W: nn.Linear layout [out][256]); lane = (g = lane >> 4, c = lane & 15)
-__device__ __forceinline__ void rb_gemm(const float (&a)[64], const float* __restrict__ W, int col0, int lane, f32x4 (&acc)[4]) {
-  const int j = lane & 15, kg = lane >> 4;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(W + (size_t)(col0 + 4 * j) * kRbC + 4 * kg);  // + nt * 64 float4 (the next row), + 4 m
-  // weights of steps m + 1 .. m + kRbDepth - 1 in flight while step m's 16 matrix instructions run.  The
-  // scheduling barriers pin that order: left alone, the compiler sinks every load to just above its first use and the loop pays
-  // the round trip eight times per product (measured: 12 us instead of 4 per 256 x 256 product).
+// acc[nt][r] += sum_k X[4 g + r][k] M[k][col0 + 4 c + nt]   (M [256][256] row-major: a W^T image for y = x W^T, W itself for
+// dX = dY W); lane = (g = lane >> 4, c = lane & 15).  The weights of steps m + 1 .. m + kRbDepth - 1 are in flight while step m's
+// 16 matrix instructions run; the scheduling barriers pin that order (left alone, the compiler sinks every load to just above its
+// first use and the loop pays a memory round trip per step).  rb_w_begin issues the first kRbDepth - 1 steps and returns: a kernel
+// calls it BEFORE the epilogue of the product in front, so that a product starts on weights that have arrived (one wave per SIMD:
+// nothing else hides that round trip).
+struct RbRing {
   f32x4 b[kRbDepth][4];
+};
+__device__ __forceinline__ const float* rb_w_ptr(const float* __restrict__ M, int col0, int lane) {
+  return M + (size_t)(4 * (lane >> 4)) * kRbC + col0 + 4 * (lane & 15);  // + (16 m + e) rows
+}
+__device__ __forceinline__ void rb_w_begin(const float* __restrict__ M, int col0, int lane, RbRing& R) {
+  const float* wp = rb_w_ptr(M, col0, lane);
 #pragma unroll
   for (int d = 0; d < kRbDepth - 1; ++d)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) b[d][nt] = wp[nt * 64 + 4 * d];
+    for (int e = 0; e < 4; ++e) R.b[d][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * d + e) * kRbC);
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void rb_w_run(const float (&a)[64], const float* __restrict__ M, int col0, int lane, RbRing& R, f32x4 (&acc)[4]) {
+  const float* wp = rb_w_ptr(M, col0, lane);
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
     if (m + kRbDepth - 1 < 16) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) b[(m + kRbDepth - 1) % kRbDepth][nt] = wp[nt * 64 + 4 * (m + kRbDepth - 1)];
+      for (int e = 0; e < 4; ++e)
+        R.b[(m + kRbDepth - 1) % kRbDepth][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * (m + kRbDepth - 1) + e) * kRbC);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % kRbDepth][nt][e], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], R.b[m % kRbDepth][e][nt], acc[nt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-// One dword of every 128-byte line of up to three [256][256] weight matrices, all requests in flight at once.  Between two uses
-// of a weight matrix the step streams hundreds of MB through the 4 MB L2s, so every launch finds its weights cold in its XCD's
-// L2: walked with a 2-step look-ahead, rb_gemm then pays a memory round trip per step (measured: 12 us per 256 x 256 product
-// instead of the 4 us its 256 matrix instructions take).  Touching everything first costs ONE round trip per launch.
-__device__ __forceinline__ float rb_touch(const float* w0, const float* w1, const float* w2, int tid) {
-  float v[24];
+__device__ __forceinline__ void rb_zero(f32x4 (&acc)[4]) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const size_t o = (size_t)(tid + u * kRbThreads) * 32;  // 2048 lines of 32 floats
-    v[u] = w0[o];
-    v[8 + u] = w1 ? w1[o] : 0.f;
-    v[16 + u] = w2 ? w2[o] : 0.f;
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int u = 0; u < 24; ++u) s += v[u];
-  return s;
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-// (keeps the touch alive: never true for finite weights)
-__device__ __forceinline__ void rb_sink(float s, float* out) {
-  if (s == 1.2345678e-30f) out[0] = s;
-}
+__device__ __forceinline__ f32x4 rb_ld4(const float* p, int row, int colq) { return *reinterpret_cast<const f32x4*>(p + (size_t)row * kRbC + colq); }
+__device__ __forceinline__ void rb_st4(float* p, int row, int colq, const f32x4& v) { *reinterpret_cast<f32x4*>(p + (size_t)row * kRbC + colq) = v; }
+__device__ __forceinline__ f32x4 rb_ldv(const float* p, int colq) { return p ? *reinterpret_cast<const f32x4*>(p + colq) : f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 // accumulators -> per-row float4 of the four adjacent columns (row 4 g + r, columns col0 + 4 c ..)
 __device__ __forceinline__ f32x4 rb_row(const f32x4 (&acc)[4], int r) { return f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}; }
@@ -189,6 +191,9 @@ typedef vdetr_rb_norm RbNorm;
 typedef vdetr_rb_drop RbDropArgs;
 
 // ---- rb_ffn_kernel -------------------------------------------------------------------------------------------------------
+// Order inside every kernel below: the first product's weights and everything the epilogues read from global memory (residual
+// rows, biases, LayerNorm parameters) are REQUESTED first; the activation tile is staged behind them; each product's successor has
+// its first weight steps requested before the epilogue in between runs.
 typedef vdetr_rb_ffn_desc RbFfnArgs;
 
 __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A) {
@@ -205,107 +210,95 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A) {
   f32x4 acc[4];
   f32x4 y[4];  // the residual stream of this lane's rows 4 g + r, columns colq ..
   float mean[4], rstd[4];
-
-  const float touched = rb_touch(A.proj.w, A.lin1.w, A.lin2.w, tid);
+  RbRing R;
+  rb_w_begin(A.proj.wt, col0, lane, R);
+  const bool two = A.post2.gamma != nullptr;
+  const f32x4 bias_p = rb_ldv(A.proj.b, colq), bias_1 = rb_ldv(A.lin1.b, colq), bias_2 = rb_ldv(A.lin2.b, colq);
+  const f32x4 ga3 = rb_ldv(A.norm3.gamma, colq), be3 = rb_ldv(A.norm3.beta, colq);
+  const f32x4 gap = rb_ldv(A.post1.gamma, colq), bep = rb_ldv(A.post1.beta, colq);
+  const f32x4 gap2 = rb_ldv(A.post2.gamma, colq), bep2 = rb_ldv(A.post2.beta, colq);
+  f32x4 tg[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tg[r] = rb_ld4(A.tgt, min(row0 + 4 * g + r, A.rows - 1), colq);
+  __builtin_amdgcn_sched_barrier(0);
   rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
   __syncthreads();
   rb_load_a(xs, lane, a);
+  rb_zero(acc);
+  rb_w_run(a, A.proj.wt, col0, lane, R, acc);
+  rb_w_begin(A.lin1.wt, col0, lane, R);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  rb_gemm(a, A.proj.w, col0, lane, acc);
-  {
-    const f32x4 bias = A.proj.b ? *reinterpret_cast<const f32x4*>(A.proj.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+    f32x4 v = rb_row(acc, r) + bias_p;
+    bool keep[4];
+    rb_keep4_ln(d2, rowc, colq >> 2, keep);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
-      f32x4 v = rb_row(acc, r) + bias;
-      bool keep[4];
-      rb_keep4_ln(d2, rowc, colq >> 2, keep);
-      const f32x4 t = *reinterpret_cast<const f32x4*>(A.tgt + (size_t)rowc * kRbC + colq);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = t[e] + (keep[e] ? v[e] * d2.scale : 0.f);
-      y[r] = v;
-      if (row < A.rows) *reinterpret_cast<f32x4*>(A.y + (size_t)row * kRbC + colq) = v;
-    }
+    for (int e = 0; e < 4; ++e) v[e] = tg[r][e] + (keep[e] ? v[e] * d2.scale : 0.f);
+    y[r] = v;
+    if (row < A.rows) rb_st4(A.y, row, colq, v);
   }
   rb_row_stats(y, red, w, lane, A.norm3.eps, mean, rstd);  // (its barriers also fence the reads of xs above)
-  {
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(A.norm3.gamma + colq), be = *reinterpret_cast<const f32x4*>(A.norm3.beta + colq);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r;
-      f32x4 o;
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
-      *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = o;
-      if (row < A.rows) {
-        *reinterpret_cast<f32x4*>(A.t2 + (size_t)row * kRbC + colq) = o;
-        if (w == 0 && c == 0) { A.mean_y[row] = mean[r]; A.rstd_y[row] = rstd[r]; }
-      }
+    for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga3[e] + be3[e];
+    *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = o;
+    if (row < A.rows) {
+      rb_st4(A.t2, row, colq, o);
+      if (w == 0 && c == 0) { A.mean_y[row] = mean[r]; A.rstd_y[row] = rstd[r]; }
     }
   }
   __syncthreads();
   rb_load_a(xs, lane, a);
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  rb_gemm(a, A.lin1.w, col0, lane, acc);
+  rb_zero(acc);
+  rb_w_run(a, A.lin1.wt, col0, lane, R, acc);
+  rb_w_begin(A.lin2.wt, col0, lane, R);
   __syncthreads();  // every wave has its A operand: the tile can be overwritten
-  {
-    const f32x4 bias = A.lin1.b ? *reinterpret_cast<const f32x4*>(A.lin1.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
-      f32x4 v = rb_row(acc, r) + bias;
-      bool keep[4];
-      rb_keep4_act(da, ((long)rowc * kRbC + colq) >> 2, keep);
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+    f32x4 v = rb_row(acc, r) + bias_1;
+    bool keep[4];
+    rb_keep4_act(da, ((long)rowc * kRbC + colq) >> 2, keep);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f && keep[e]) ? v[e] * da.scale : 0.f;
-      *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
-      if (row < A.rows) *reinterpret_cast<f32x4*>(A.h + (size_t)row * kRbC + colq) = v;
-    }
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f && keep[e]) ? v[e] * da.scale : 0.f;
+    *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
+    if (row < A.rows) rb_st4(A.h, row, colq, v);
   }
   __syncthreads();
   rb_load_a(xs, lane, a);
+  rb_zero(acc);
+  rb_w_run(a, A.lin2.wt, col0, lane, R, acc);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  rb_gemm(a, A.lin2.w, col0, lane, acc);
-  {
-    const f32x4 bias = A.lin2.b ? *reinterpret_cast<const f32x4*>(A.lin2.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+    f32x4 v = rb_row(acc, r) + bias_2;
+    bool keep[4];
+    rb_keep4_ln(d3, rowc, colq >> 2, keep);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
-      f32x4 v = rb_row(acc, r) + bias;
-      bool keep[4];
-      rb_keep4_ln(d3, rowc, colq >> 2, keep);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = y[r][e] + (keep[e] ? v[e] * d3.scale : 0.f);
-      y[r] = v;
-      if (row < A.rows) *reinterpret_cast<f32x4*>(A.z + (size_t)row * kRbC + colq) = v;
-    }
+    for (int e = 0; e < 4; ++e) v[e] = y[r][e] + (keep[e] ? v[e] * d3.scale : 0.f);
+    y[r] = v;
+    if (row < A.rows) rb_st4(A.z, row, colq, v);
   }
   rb_row_stats(y, red, w, lane, A.post1.eps, mean, rstd);
-  {
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(A.post1.gamma + colq), be = *reinterpret_cast<const f32x4*>(A.post1.beta + colq);
-    const bool two = A.post2.gamma != nullptr;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 ga2 = two ? *reinterpret_cast<const f32x4*>(A.post2.gamma + colq) : zero, be2 = two ? *reinterpret_cast<const f32x4*>(A.post2.beta + colq) : zero;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r;
-      if (row >= A.rows) continue;
-      f32x4 o;
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    if (row >= A.rows) continue;
+    f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
-      *reinterpret_cast<f32x4*>(A.o1 + (size_t)row * kRbC + colq) = o;
-      if (two) {
+    for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * gap[e] + bep[e];
+    rb_st4(A.o1, row, colq, o);
+    if (two) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga2[e] + be2[e];
-        *reinterpret_cast<f32x4*>(A.o2 + (size_t)row * kRbC + colq) = o;
-      }
-      if (w == 0 && c == 0) { A.mean_z[row] = mean[r]; A.rstd_z[row] = rstd[r]; }
+      for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * gap2[e] + bep2[e];
+      rb_st4(A.o2, row, colq, o);
     }
+    if (w == 0 && c == 0) { A.mean_z[row] = mean[r]; A.rstd_z[row] = rstd[r]; }
   }
-  rb_sink(touched, A.z);
 }
 
 // ---- rb_proj_q_kernel: out-projection of the self-attention + residual block 1 + the cross-attention's query projection ------
@@ -324,63 +317,62 @@ __global__ __launch_bounds__(kRbThreads) void rb_proj_q_kernel(RbProjQArgs A) {
   f32x4 acc[4];
   f32x4 y[4];
   float mean[4], rstd[4];
-  const float touched = rb_touch(A.proj.w, A.q.w, nullptr, tid);
+  RbRing R;
+  rb_w_begin(A.proj.wt, col0, lane, R);
+  const f32x4 bias_p = rb_ldv(A.proj.b, colq), bias_q = rb_ldv(A.q.b, colq);
+  const f32x4 ga = rb_ldv(A.norm2.gamma, colq), be = rb_ldv(A.norm2.beta, colq);
+  f32x4 tg[4], ps[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rowc = min(row0 + 4 * g + r, A.rows - 1);
+    tg[r] = rb_ld4(A.tgt, rowc, colq);
+    ps[r] = A.pos ? rb_ld4(A.pos, rowc, colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __builtin_amdgcn_sched_barrier(0);
   rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
   __syncthreads();
   rb_load_a(xs, lane, a);
+  rb_zero(acc);
+  rb_w_run(a, A.proj.wt, col0, lane, R, acc);
+  rb_w_begin(A.q.wt, col0, lane, R);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  rb_gemm(a, A.proj.w, col0, lane, acc);
-  {
-    const f32x4 bias = A.proj.b ? *reinterpret_cast<const f32x4*>(A.proj.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+    f32x4 v = rb_row(acc, r) + bias_p;
+    bool keep[4];
+    rb_keep4_ln(d1, rowc, colq >> 2, keep);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
-      f32x4 v = rb_row(acc, r) + bias;
-      bool keep[4];
-      rb_keep4_ln(d1, rowc, colq >> 2, keep);
-      const f32x4 t = *reinterpret_cast<const f32x4*>(A.tgt + (size_t)rowc * kRbC + colq);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = t[e] + (keep[e] ? v[e] * d1.scale : 0.f);
-      y[r] = v;
-      if (row < A.rows) *reinterpret_cast<f32x4*>(A.y + (size_t)row * kRbC + colq) = v;
-    }
+    for (int e = 0; e < 4; ++e) v[e] = tg[r][e] + (keep[e] ? v[e] * d1.scale : 0.f);
+    y[r] = v;
+    if (row < A.rows) rb_st4(A.y, row, colq, v);
   }
   rb_row_stats(y, red, w, lane, A.norm2.eps, mean, rstd);
-  {
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(A.norm2.gamma + colq), be = *reinterpret_cast<const f32x4*>(A.norm2.beta + colq);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
-      f32x4 o;
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
-      if (row < A.rows) {
-        *reinterpret_cast<f32x4*>(A.t2 + (size_t)row * kRbC + colq) = o;
-        if (w == 0 && c == 0) { A.mean_y[row] = mean[r]; A.rstd_y[row] = rstd[r]; }
-      }
-      if (A.pos) {
-        o += *reinterpret_cast<const f32x4*>(A.pos + (size_t)rowc * kRbC + colq);
-        if (row < A.rows) *reinterpret_cast<f32x4*>(A.xq + (size_t)row * kRbC + colq) = o;
-      }
-      *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = o;
+    for (int e = 0; e < 4; ++e) o[e] = (y[r][e] - mean[r]) * rstd[r] * ga[e] + be[e];
+    if (row < A.rows) {
+      rb_st4(A.t2, row, colq, o);
+      if (w == 0 && c == 0) { A.mean_y[row] = mean[r]; A.rstd_y[row] = rstd[r]; }
     }
+    if (A.pos) {
+      o += ps[r];
+      if (row < A.rows) rb_st4(A.xq, row, colq, o);
+    }
+    *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = o;
   }
   __syncthreads();
   rb_load_a(xs, lane, a);
+  rb_zero(acc);
+  rb_w_run(a, A.q.wt, col0, lane, R, acc);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  rb_gemm(a, A.q.w, col0, lane, acc);
-  {
-    const f32x4 bias = A.q.b ? *reinterpret_cast<const f32x4*>(A.q.b + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + 4 * g + r;
-      if (row >= A.rows) continue;
-      *reinterpret_cast<f32x4*>(A.qout + (size_t)rb_bmajor(row, A.B, A.rows / A.B) * kRbC + colq) = rb_row(acc, r) + bias;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    if (row >= A.rows) continue;
+    rb_st4(A.qout, rb_bmajor(row, A.B, A.rows / A.B), colq, rb_row(acc, r) + bias_q);
   }
-  rb_sink(touched, A.qout);
 }
 
 // ---- rb_qkv_kernel: the self-attention's three projections; blockIdx.y = 0 / 1 / 2 = q / k / v ---------------------------------
@@ -394,24 +386,39 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_kernel(RbQkvArgs A) {
   const int row0 = blockIdx.x * kRbRows, which = blockIdx.y;
   const int col0 = 64 * w, colq = col0 + 4 * c;
   const bool with_pos = which < 2 && A.pos != nullptr;
-  const float touched = rb_touch(A.w + (size_t)which * kRbC * kRbC, nullptr, nullptr, tid);
+  const float* Wt = A.wt + (size_t)which * kRbC * kRbC;
+  RbRing R;
+  rb_w_begin(Wt, col0, lane, R);
+  const f32x4 bias = rb_ldv(A.b ? A.b + which * kRbC : nullptr, colq);
+  __builtin_amdgcn_sched_barrier(0);
   rb_stage_rows(A.t, row0, A.rows, A.B, false, xs, tid, with_pos ? A.pos : nullptr, which == 0 ? A.x : nullptr);
   __syncthreads();
   float a[64];
   rb_load_a(xs, lane, a);
   f32x4 acc[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  rb_gemm(a, A.w + (size_t)which * kRbC * kRbC, col0, lane, acc);
-  const f32x4 bias = A.b ? *reinterpret_cast<const f32x4*>(A.b + which * kRbC + colq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  rb_zero(acc);
+  rb_w_run(a, Wt, col0, lane, R, acc);
   float* out = A.out + (size_t)which * A.rows * kRbC;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = row0 + 4 * g + r;
     if (row >= A.rows) continue;
-    *reinterpret_cast<f32x4*>(out + (size_t)rb_bmajor(row, A.B, A.rows / A.B) * kRbC + colq) = rb_row(acc, r) + bias;
+    rb_st4(out, rb_bmajor(row, A.B, A.rows / A.B), colq, rb_row(acc, r) + bias);
   }
-  rb_sink(touched, out);
+}
+
+// ---- vdetr_rb_transpose_f32: dst[i][k][n] = src[i][n][k] for n matrices of 256 x 256 (the forward launches' weight images) ----
+__global__ __launch_bounds__(256) void rb_transpose_kernel(const float* const* __restrict__ src, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const float* S = src[blockIdx.y];
+  float* D = dst + (size_t)blockIdx.y * kRbC * kRbC;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int n0 = (blockIdx.x >> 3) * 32, k0 = (blockIdx.x & 7) * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = S[(size_t)(n0 + ty + 8 * i) * kRbC + k0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) D[(size_t)(k0 + ty + 8 * i) * kRbC + n0 + tx] = tile[tx][ty + 8 * i];
 }
 
 // =====================================================================================================================================
@@ -421,32 +428,6 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_kernel(RbQkvArgs A) {
 // sums them at the flush).  dX = dY W needs W "column-wise": with MFMA column j of tile nt = output column 64 w + 4 j + nt the
 // four tiles' B operands of one contraction index are ONE float4 of a weight row.
 // =====================================================================================================================================
-
-// acc[nt][r] += sum_k X[4 g + r][k] W[k][col0 + 4 c + nt]   (W [256][256] as stored: the gradient of y = x W^T with respect to x)
-__device__ __forceinline__ void rb_gemm_t(const float (&a)[64], const float* __restrict__ W, int col0, int lane, f32x4 (&acc)[4]) {
-  const int j = lane & 15, kg = lane >> 4;
-  const float* wp = W + (size_t)(4 * kg) * kRbC + col0 + 4 * j;  // + (16 m + e) rows
-  f32x4 b[kRbDepth][4];  // (pipelined and pinned as in rb_gemm)
-#pragma unroll
-  for (int d = 0; d < kRbDepth - 1; ++d)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[d][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * d + e) * kRbC);
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    if (m + kRbDepth - 1 < 16) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        b[(m + kRbDepth - 1) % kRbDepth][e] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * (m + kRbDepth - 1) + e) * kRbC);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b[m % kRbDepth][e][nt], acc[nt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 
 // sum over the four row groups g of a wave (lanes c, c + 16, c + 32, c + 48), result in every lane
 __device__ __forceinline__ float rb_sum_g(float v) {
@@ -511,8 +492,6 @@ __device__ __forceinline__ void rb_ln_bwd(const f32x4 (&yv)[4], const f32x4 (&go
   }
 }
 
-__device__ __forceinline__ f32x4 rb_ld4(const float* p, int row, int colq) { return *reinterpret_cast<const f32x4*>(p + (size_t)row * kRbC + colq); }
-__device__ __forceinline__ void rb_st4(float* p, int row, int colq, const f32x4& v) { *reinterpret_cast<f32x4*>(p + (size_t)row * kRbC + colq) = v; }
 
 // ---- rb_ffn_bwd_kernel ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_desc A, vdetr_rb_ffn_grads G) {
@@ -527,11 +506,11 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_des
                d3 = rb_drop(A.drop3.p, A.drop3.seed, 0, A.rng_state);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const bool two = G.d_o2 != nullptr;
-  const float touched = rb_touch(A.lin2.w, A.lin1.w, A.proj.w, tid);
   int rowc[4];
   bool live[4];
-  float mean[4], rstd[4];
-  f32x4 yv[4], go[4], go2[4], din[4], dy[4];
+  float mean[4], rstd[4], mean2[4], rstd2[4];
+  f32x4 yv[4], go[4], go2[4], din[4], dy[4], hv[4], yv2[4];
+  RbRing R;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = row0 + 4 * g + r;
@@ -543,6 +522,14 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_des
     go2[r] = two ? rb_ld4(G.d_o2, rowc[r], colq) : zero;
     din[r] = G.d_z ? rb_ld4(G.d_z, rowc[r], colq) : zero;
   }
+  rb_w_begin(A.lin2.w, col0, lane, R);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // what the later blocks read: requested now
+    hv[r] = rb_ld4(A.h, rowc[r], colq);
+    yv2[r] = rb_ld4(A.y, rowc[r], colq);
+    mean2[r] = A.mean_y[rowc[r]]; rstd2[r] = A.rstd_y[rowc[r]];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   // block 3 backward: z = y + drop3(lin2 h); o1 = post1(z), o2 = post2(z)
   rb_ln_bwd(yv, go, go2, two, din, mean, rstd, live, A.post1.gamma, A.post2.gamma, colq, red, G.part_post + (size_t)blockIdx.x * 4 * kRbC, w, lane, dy);
 #pragma unroll
@@ -559,29 +546,28 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_des
   float a[64];
   f32x4 acc[4];
   rb_load_a(xs, lane, a);
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
-  rb_gemm_t(a, A.lin2.w, col0, lane, acc);  // d h
+  rb_zero(acc);
+  rb_w_run(a, A.lin2.w, col0, lane, R, acc);  // d h
+  rb_w_begin(A.lin1.w, col0, lane, R);
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {  // through relu + dropout: h > 0 <=> passed both
-    const f32x4 hv = rb_ld4(A.h, rowc[r], colq);
     f32x4 v = rb_row(acc, r);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = hv[e] > 0.f ? v[e] * da.scale : 0.f;
+    for (int e = 0; e < 4; ++e) v[e] = hv[r][e] > 0.f ? v[e] * da.scale : 0.f;
     if (live[r]) rb_st4(G.d_lin1, rowc[r], colq, v);
     *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = v;
   }
   __syncthreads();
   rb_load_a(xs, lane, a);
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
-  rb_gemm_t(a, A.lin1.w, col0, lane, acc);  // d t2
+  rb_zero(acc);
+  rb_w_run(a, A.lin1.w, col0, lane, R, acc);  // d t2
+  rb_w_begin(A.proj.w, col0, lane, R);
   // block 2 backward: y = tgt + drop2(proj a); t2 = norm3(y)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    mean[r] = A.mean_y[rowc[r]]; rstd[r] = A.rstd_y[rowc[r]];
-    yv[r] = rb_ld4(A.y, rowc[r], colq);
+    mean[r] = mean2[r]; rstd[r] = rstd2[r];
+    yv[r] = yv2[r];
     go[r] = rb_row(acc, r);
     go2[r] = zero;
     din[r] = dy[r];
@@ -601,15 +587,13 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_des
   }
   __syncthreads();
   rb_load_a(xs, lane, a);
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
-  rb_gemm_t(a, A.proj.w, col0, lane, acc);  // d a
+  rb_zero(acc);
+  rb_w_run(a, A.proj.w, col0, lane, R, acc);  // d a
   if (G.d_a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (live[r]) rb_st4(G.d_a, rb_bmajor(rowc[r], A.B, A.rows / A.B), colq, rb_row(acc, r));
   }
-  rb_sink(touched, G.d_tgt);
 }
 
 // ---- rb_proj_q_bwd_kernel ------------------------------------------------------------------------------------------------------------
@@ -623,30 +607,35 @@ __global__ __launch_bounds__(kRbThreads) void rb_proj_q_bwd_kernel(vdetr_rb_proj
   const int col0 = 64 * w, colq = col0 + 4 * c;
   const RbDrop d1 = rb_drop(A.drop1.p, A.drop1.seed, 0, A.rng_state);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const float touched = rb_touch(A.q.w, A.proj.w, nullptr, tid);
   int rowc[4];
   bool live[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { live[r] = row0 + 4 * g + r < A.rows; rowc[r] = min(row0 + 4 * g + r, A.rows - 1); }
   float a[64];
   f32x4 acc[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
-  if (G.d_qout) {  // d (t2 + pos) = d q Wq
-    rb_stage_rows(G.d_qout, row0, A.rows, A.B, true, xs, tid, nullptr, nullptr, G.dq_rows);
-    __syncthreads();
-    rb_load_a(xs, lane, a);
-    rb_gemm_t(a, A.q.w, col0, lane, acc);
-  }
+  rb_zero(acc);
+  RbRing R;
   float mean[4], rstd[4];
   f32x4 yv[4], go[4], go2[4], din[4], dy[4];
+  rb_w_begin(G.d_qout ? A.q.w : A.proj.w, col0, lane, R);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     mean[r] = A.mean_y[rowc[r]]; rstd[r] = A.rstd_y[rowc[r]];
     yv[r] = rb_ld4(A.y, rowc[r], colq);
+    din[r] = G.d_y ? rb_ld4(G.d_y, rowc[r], colq) : zero;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (G.d_qout) {  // d (t2 + pos) = d q Wq
+    rb_stage_rows(G.d_qout, row0, A.rows, A.B, true, xs, tid, nullptr, nullptr, G.dq_rows);
+    __syncthreads();
+    rb_load_a(xs, lane, a);
+    rb_w_run(a, A.q.w, col0, lane, R, acc);
+    rb_w_begin(A.proj.w, col0, lane, R);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
     go[r] = rb_row(acc, r);
     go2[r] = zero;
-    din[r] = G.d_y ? rb_ld4(G.d_y, rowc[r], colq) : zero;
     if (live[r] && G.d_t2) rb_st4(G.d_t2, rowc[r], colq, go[r]);
   }
   rb_ln_bwd(yv, go, go2, false, din, mean, rstd, live, A.norm2.gamma, nullptr, colq, red, G.part_n2 + (size_t)blockIdx.x * 4 * kRbC, w, lane, dy);
@@ -663,15 +652,13 @@ __global__ __launch_bounds__(kRbThreads) void rb_proj_q_bwd_kernel(vdetr_rb_proj
   }
   __syncthreads();
   rb_load_a(xs, lane, a);
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = zero;
-  rb_gemm_t(a, A.proj.w, col0, lane, acc);
+  rb_zero(acc);
+  rb_w_run(a, A.proj.w, col0, lane, R, acc);
   if (G.d_a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (live[r]) rb_st4(G.d_a, rb_bmajor(rowc[r], A.B, A.rows / A.B), colq, rb_row(acc, r));
   }
-  rb_sink(touched, G.d_tgt);
 }
 
 // ---- rb_qkv_bwd_kernel: d (t + pos) = dq Wq + dk Wk;  d t = d (t + pos) + dv Wv ------------------------------------------------------
@@ -684,9 +671,9 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_bwd_kernel(vdetr_rb_qkv_des
   const int col0 = 64 * w, colq = col0 + 4 * c;
   float a[64];
   f32x4 acc[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float touched = rb_touch(A.w, A.w + (size_t)kRbC * kRbC, A.w + (size_t)2 * kRbC * kRbC, tid);
+  rb_zero(acc);
+  RbRing R;
+  rb_w_begin(A.w, col0, lane, R);
   const float* dsrc[3] = {G.dq, G.dk, G.dv};
   float* drows[3] = {G.dq_rows, G.dk_rows, G.dv_rows};
 #pragma unroll
@@ -695,7 +682,8 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_bwd_kernel(vdetr_rb_qkv_des
     rb_stage_rows(dsrc[which], row0, A.rows, A.B, true, xs, tid, nullptr, nullptr, drows[which]);
     __syncthreads();
     rb_load_a(xs, lane, a);
-    rb_gemm_t(a, A.w + (size_t)which * kRbC * kRbC, col0, lane, acc);
+    rb_w_run(a, A.w + (size_t)which * kRbC * kRbC, col0, lane, R, acc);
+    if (which < 2) rb_w_begin(A.w + (size_t)(which + 1) * kRbC * kRbC, col0, lane, R);
     if (which == 1 && G.d_x) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -705,7 +693,6 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_bwd_kernel(vdetr_rb_qkv_des
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     if (row0 + 4 * g + r < A.rows) rb_st4(G.d_t, row0 + 4 * g + r, colq, rb_row(acc, r));
-  rb_sink(touched, G.d_t);
 }
 
 }  // namespace vdetr
@@ -718,11 +705,18 @@ static int rb_common(int rows, int B, const char* op) {
 }
 #define RB_ALIGNED(p) ((((uintptr_t)(p)) & 15) == 0)
 
+extern "C" int vdetr_rb_transpose_f32(const float* const* src, float* dst, int n, vdetr_stream_t stream) {
+  VDETR_REQUIRE(src && dst && n > 0 && n <= 65535, "rb_transpose: null pointer or n=%d outside [1, 65535]", n);
+  VDETR_REQUIRE(RB_ALIGNED(dst), "rb_transpose: dst must be 16-B aligned");
+  hipLaunchKernelGGL(rb_transpose_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, src, dst);
+  return check_launch("rb_transpose");
+}
+
 extern "C" int vdetr_rb_qkv_f32(const vdetr_rb_qkv_desc* d, vdetr_stream_t stream) {
   VDETR_REQUIRE(d != nullptr, "rb_qkv: null descriptor");
   if (int e = rb_common(d->rows, d->B, "rb_qkv")) return e;
-  VDETR_REQUIRE(d->t && d->w && d->out && (!d->pos || d->x), "rb_qkv: null pointer");
-  VDETR_REQUIRE(RB_ALIGNED(d->t) && RB_ALIGNED(d->pos) && RB_ALIGNED(d->w) && RB_ALIGNED(d->b) && RB_ALIGNED(d->x) && RB_ALIGNED(d->out),
+  VDETR_REQUIRE(d->t && d->wt && d->out && (!d->pos || d->x), "rb_qkv: null pointer (wt: the W^T images, vdetr_rb_transpose_f32)");
+  VDETR_REQUIRE(RB_ALIGNED(d->t) && RB_ALIGNED(d->pos) && RB_ALIGNED(d->wt) && RB_ALIGNED(d->b) && RB_ALIGNED(d->x) && RB_ALIGNED(d->out),
                 "rb_qkv: operands must be 16-B aligned");
   hipLaunchKernelGGL(rb_qkv_kernel, dim3(ceil_div(d->rows, kRbRows), 3), dim3(kRbThreads), 0, (hipStream_t)stream, *d);
   return check_launch("rb_qkv");
@@ -731,11 +725,11 @@ extern "C" int vdetr_rb_qkv_f32(const vdetr_rb_qkv_desc* d, vdetr_stream_t strea
 extern "C" int vdetr_rb_proj_q_f32(const vdetr_rb_projq_desc* d, vdetr_stream_t stream) {
   VDETR_REQUIRE(d != nullptr, "rb_proj_q: null descriptor");
   if (int e = rb_common(d->rows, d->B, "rb_proj_q")) return e;
-  VDETR_REQUIRE(d->a && d->tgt && d->proj.w && d->q.w && d->norm2.gamma && d->norm2.beta && d->y && d->mean_y && d->rstd_y && d->t2 &&
-                d->qout && (!d->pos || d->xq), "rb_proj_q: null pointer");
+  VDETR_REQUIRE(d->a && d->tgt && d->proj.wt && d->q.wt && d->norm2.gamma && d->norm2.beta && d->y && d->mean_y && d->rstd_y && d->t2 &&
+                d->qout && (!d->pos || d->xq), "rb_proj_q: null pointer (proj.wt / q.wt: the W^T images, vdetr_rb_transpose_f32)");
   VDETR_REQUIRE(d->drop1.p >= 0.f && d->drop1.p < 1.f, "rb_proj_q: dropout_p %f outside [0,1)", d->drop1.p);
-  VDETR_REQUIRE(RB_ALIGNED(d->a) && RB_ALIGNED(d->tgt) && RB_ALIGNED(d->pos) && RB_ALIGNED(d->proj.w) && RB_ALIGNED(d->proj.b) &&
-                RB_ALIGNED(d->q.w) && RB_ALIGNED(d->q.b) && RB_ALIGNED(d->norm2.gamma) && RB_ALIGNED(d->norm2.beta) && RB_ALIGNED(d->y) &&
+  VDETR_REQUIRE(RB_ALIGNED(d->a) && RB_ALIGNED(d->tgt) && RB_ALIGNED(d->pos) && RB_ALIGNED(d->proj.wt) && RB_ALIGNED(d->proj.b) &&
+                RB_ALIGNED(d->q.wt) && RB_ALIGNED(d->q.b) && RB_ALIGNED(d->norm2.gamma) && RB_ALIGNED(d->norm2.beta) && RB_ALIGNED(d->y) &&
                 RB_ALIGNED(d->t2) && RB_ALIGNED(d->xq) && RB_ALIGNED(d->qout), "rb_proj_q: operands must be 16-B aligned");
   hipLaunchKernelGGL(rb_proj_q_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d);
   return check_launch("rb_proj_q");
@@ -744,14 +738,15 @@ extern "C" int vdetr_rb_proj_q_f32(const vdetr_rb_projq_desc* d, vdetr_stream_t 
 extern "C" int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t stream) {
   VDETR_REQUIRE(d != nullptr, "rb_ffn: null descriptor");
   if (int e = rb_common(d->rows, d->B, "rb_ffn")) return e;
-  VDETR_REQUIRE(d->a && d->tgt && d->proj.w && d->lin1.w && d->lin2.w && d->norm3.gamma && d->norm3.beta && d->post1.gamma && d->post1.beta &&
-                d->y && d->mean_y && d->rstd_y && d->t2 && d->h && d->z && d->mean_z && d->rstd_z && d->o1, "rb_ffn: null pointer");
+  VDETR_REQUIRE(d->a && d->tgt && d->proj.wt && d->lin1.wt && d->lin2.wt && d->norm3.gamma && d->norm3.beta && d->post1.gamma && d->post1.beta &&
+                d->y && d->mean_y && d->rstd_y && d->t2 && d->h && d->z && d->mean_z && d->rstd_z && d->o1,
+                "rb_ffn: null pointer (proj.wt / lin1.wt / lin2.wt: the W^T images, vdetr_rb_transpose_f32)");
   VDETR_REQUIRE((d->post2.gamma == nullptr) == (d->post2.beta == nullptr) && (d->post2.gamma == nullptr) == (d->o2 == nullptr),
                 "rb_ffn: post2.gamma, post2.beta and o2 go together");
   for (const vdetr_rb_drop* dr : {&d->drop2, &d->drop_act, &d->drop3})
     VDETR_REQUIRE(dr->p >= 0.f && dr->p < 1.f, "rb_ffn: dropout_p %f outside [0,1)", dr->p);
-  VDETR_REQUIRE(RB_ALIGNED(d->a) && RB_ALIGNED(d->tgt) && RB_ALIGNED(d->proj.w) && RB_ALIGNED(d->proj.b) && RB_ALIGNED(d->lin1.w) &&
-                RB_ALIGNED(d->lin1.b) && RB_ALIGNED(d->lin2.w) && RB_ALIGNED(d->lin2.b) && RB_ALIGNED(d->norm3.gamma) && RB_ALIGNED(d->norm3.beta) &&
+  VDETR_REQUIRE(RB_ALIGNED(d->a) && RB_ALIGNED(d->tgt) && RB_ALIGNED(d->proj.wt) && RB_ALIGNED(d->proj.b) && RB_ALIGNED(d->lin1.wt) &&
+                RB_ALIGNED(d->lin1.b) && RB_ALIGNED(d->lin2.wt) && RB_ALIGNED(d->lin2.b) && RB_ALIGNED(d->norm3.gamma) && RB_ALIGNED(d->norm3.beta) &&
                 RB_ALIGNED(d->post1.gamma) && RB_ALIGNED(d->post1.beta) && RB_ALIGNED(d->post2.gamma) && RB_ALIGNED(d->post2.beta) &&
                 RB_ALIGNED(d->y) && RB_ALIGNED(d->t2) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) && RB_ALIGNED(d->o1) && RB_ALIGNED(d->o2),
                 "rb_ffn: operands must be 16-B aligned");

@@ -46,9 +46,57 @@ def _rng_for(p, device):
     return rng if rng is not None else A.begin_step(device)
 
 
-def _lin(d, w, b):
+def _lin(d, w, b, wt=None):
     d.w = w.data_ptr()
     d.b = b.data_ptr() if b is not None else None
+    d.wt = wt.data_ptr() if wt is not None else None
+
+
+# ---- the forward launches' weight images (W^T, csrc/rowblock.hip) ---------------------------------------------------------
+# One [8, 256, 256] buffer per layer: in_proj q | k | v, the self-attention's out_proj, the cross attention's q and proj, linear1,
+# linear2.  Weights change in place at every optimiser step, so the images are rewritten at the start of every decoder forward —
+# ONE launch for all layers (a node of the captured step like any other); a layer called on its own rewrites its own.
+_IMG_SLOTS = 8
+_tables = {}   # (layer ids) -> (pointer ints, device table of source pointers, [n_layers, 8, 256, 256] images)
+
+
+def _sources(layer):
+    sa, ca = layer.self_attn, layer.multihead_attn
+    wq, wk, wv = sa.in_proj_weight.view(3, C, C).unbind(0)
+    return [wq, wk, wv, sa.out_proj.weight, ca.q.weight, ca.proj.weight, layer.linear1.weight, layer.linear2.weight]
+
+
+def refresh(layers):
+    """rewrite the W^T images of `layers` (one launch) and hand each layer its [8, 256, 256] slice (consumed by its next forward)"""
+    layers = list(layers)
+    srcs = [w for l in layers for w in _sources(l)]
+    dev = srcs[0].device
+    ptrs = tuple(w.data_ptr() for w in srcs)
+    key = tuple(id(l) for l in layers)
+    ent = _tables.get(key)
+    if ent is None or ent[0] != ptrs or ent[2].device != dev:
+        for w in srcs:
+            _check(w)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("rowblock.refresh: the weight pointers changed inside a stream capture (run one step eagerly first)")
+        table = torch.tensor(ptrs, dtype=torch.int64).to(dev)
+        ent = (ptrs, table, torch.empty((len(layers), _IMG_SLOTS, C, C), dtype=torch.float32, device=dev))
+        if len(_tables) > 64:
+            _tables.clear()
+        _tables[key] = ent
+    L.check(L.lib().vdetr_rb_transpose_f32(ent[1].data_ptr(), ent[2].data_ptr(), len(srcs), L.stream_ptr()), "rb_transpose")
+    for i, l in enumerate(layers):
+        l.__dict__["_rb_images"] = ent[2][i]
+    return ent[2]
+
+
+def images(layer):
+    """the layer's fresh images: those a decoder-level refresh() left for this forward, or rewritten now"""
+    img = layer.__dict__.pop("_rb_images", None)
+    if img is None or img.device != layer.linear1.weight.device:
+        refresh([layer])
+        img = layer.__dict__.pop("_rb_images")
+    return img
 
 
 def _norm(d, ln_w, ln_b, eps):
@@ -105,8 +153,8 @@ def _check(*ts):
 
 class _Qkv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, pos, wq, wk, wv, bq, bk, bv, B):
-        _check(t, pos, wq, wk, wv, bq, bk, bv)
+    def forward(ctx, t, pos, wq, wk, wv, bq, bk, bv, B, wt):
+        _check(t, pos, wq, wk, wv, bq, bk, bv, wt)
         rows = t.numel() // C
         if not (wk.data_ptr() == wq.data_ptr() + C * C * 4 and wv.data_ptr() == wk.data_ptr() + C * C * 4 and
                 bk.data_ptr() == bq.data_ptr() + C * 4 and bv.data_ptr() == bk.data_ptr() + C * 4):
@@ -116,7 +164,7 @@ class _Qkv(torch.autograd.Function):
         d = L.RbQkvDesc()
         d.rows, d.B = rows, B
         d.t, d.pos = t.data_ptr(), (pos.data_ptr() if pos is not None else None)
-        d.w, d.b = wq.data_ptr(), bq.data_ptr()
+        d.w, d.b, d.wt = wq.data_ptr(), bq.data_ptr(), wt.data_ptr()
         d.x, d.out = (x.data_ptr() if x is not None else None), out.data_ptr()
         L.check(L.lib().vdetr_rb_qkv_f32(ctypes.byref(d), L.stream_ptr()), "rb_qkv")
         ctx.B, ctx.shape = B, t.shape
@@ -153,7 +201,7 @@ class _Qkv(torch.autograd.Function):
             for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
                 gr[i], gr[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
             return (d_t.view(ctx.shape) if need[0] else None, d_x.view(ctx.shape) if d_x is not None else None,
-                    gr[0], gr[1], gr[2], gr[3], gr[4], gr[5], None)
+                    gr[0], gr[1], gr[2], gr[3], gr[4], gr[5], None, None)
         dq2, dk2, dv2 = (_seq_rows(g.contiguous(), B) for g in (dq, dk, dv))
         d_t = d_pos = None
         if need[0] or need[1]:
@@ -166,13 +214,13 @@ class _Qkv(torch.autograd.Function):
         g = [None] * 6
         for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
             g[i], g[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
-        return d_t, d_pos, g[0], g[1], g[2], g[3], g[4], g[5], None
+        return d_t, d_pos, g[0], g[1], g[2], g[3], g[4], g[5], None, None
 
 
 class _ProjQ(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, tgt, pos, wo, bo, wq, bq, g2, b2, eps, p, salt, rng, B):
-        _check(a, tgt, pos, wo, bo, wq, bq, g2, b2)
+    def forward(ctx, a, tgt, pos, wo, bo, wq, bq, g2, b2, eps, p, salt, rng, B, wot, wqt):
+        _check(a, tgt, pos, wo, bo, wq, bq, g2, b2, wot, wqt)
         rows = tgt.numel() // C
         dev = tgt.device
         y = torch.empty_like(tgt)
@@ -185,8 +233,8 @@ class _ProjQ(torch.autograd.Function):
         d.rows, d.B = rows, B
         d.rng_state = rng.data_ptr() if (rng is not None and p > 0) else None
         d.a, d.tgt, d.pos = a.data_ptr(), tgt.data_ptr(), (pos.data_ptr() if pos is not None else None)
-        _lin(d.proj, wo, bo)
-        _lin(d.q, wq, bq)
+        _lin(d.proj, wo, bo, wot)
+        _lin(d.q, wq, bq, wqt)
         _drop(d.drop1, p, salt)
         _norm(d.norm2, g2, b2, eps)
         d.y, d.mean_y, d.rstd_y, d.t2 = y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), t2.data_ptr()
@@ -235,7 +283,7 @@ class _ProjQ(torch.autograd.Function):
             gwo, gbo = _park_or_grad(wo, bo, d_proj, _seq_rows(a, B), need[3], need[4])
             dg, db, _, _ = _ln_sums(part, nblk, ctx.ln_params, False)
             return (d_a, d_tgt.view(shape), d_t2.view(shape) if d_t2 is not None else None, gwo, gbo, gwq, gbq, dg, db,
-                    None, None, None, None, None)
+                    None, None, None, None, None, None, None)
         d_t2 = None
         gwq = gbq = None
         if d_qout is not None:
@@ -243,7 +291,7 @@ class _ProjQ(torch.autograd.Function):
             d_t2 = torch.mm(dq2, wq)                 # gradient of t2 + pos
             gwq, gbq = _park_or_grad(wq, bq, dq2, xq.reshape(-1, C), need[5], need[6])
         if d_y is None and d_t2 is None:
-            return (None,) * 14
+            return (None,) * 16
         d_x, d_r, dg, db, _, _ = ALN.backward_core((rows, C, eps, p, salt, True), y, g2, None, mean, rstd, rng, ctx.ln_params,
                                                    d_y.contiguous().view(rows, C) if d_y is not None else None, d_t2, None)
         d_x = d_x.view(rows, C)
@@ -252,14 +300,14 @@ class _ProjQ(torch.autograd.Function):
         d_a = _batch_first(torch.mm(d_r2, wo), B) if need[0] else None
         gwo, gbo = _park_or_grad(wo, bo, d_r2, a2, need[3], need[4])
         d_pos = d_t2.view(shape) if (need[2] and d_t2 is not None) else None
-        return d_a, d_x.view(shape), d_pos, gwo, gbo, gwq, gbq, dg, db, None, None, None, None, None
+        return d_a, d_x.view(shape), d_pos, gwo, gbo, gwq, gbq, dg, db, None, None, None, None, None, None, None
 
 
 class _Ffn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, tgt, wp, bp, w1, b1, w2, b2, g3, be3, gp1, bep1, gp2, bep2, eps3, epsp, p2, salt2, pa, salta, p3, salt3,
-                rng, B):
-        _check(a, tgt, wp, bp, w1, b1, w2, b2, g3, be3, gp1, bep1, gp2, bep2)
+                rng, B, wpt, w1t, w2t):
+        _check(a, tgt, wp, bp, w1, b1, w2, b2, g3, be3, gp1, bep1, gp2, bep2, wpt, w1t, w2t)
         rows = tgt.numel() // C
         dev = tgt.device
         new = lambda: torch.empty_like(tgt)
@@ -271,9 +319,9 @@ class _Ffn(torch.autograd.Function):
         d.rows, d.B = rows, B
         d.rng_state = rng.data_ptr() if use_rng else None
         d.a, d.tgt = a.data_ptr(), tgt.data_ptr()
-        _lin(d.proj, wp, bp)
-        _lin(d.lin1, w1, b1)
-        _lin(d.lin2, w2, b2)
+        _lin(d.proj, wp, bp, wpt)
+        _lin(d.lin1, w1, b1, w1t)
+        _lin(d.lin2, w2, b2, w2t)
         _drop(d.drop2, p2, salt2)
         _drop(d.drop_act, pa, salta)
         _drop(d.drop3, p3, salt3)
@@ -299,7 +347,7 @@ class _Ffn(torch.autograd.Function):
         a, y, t2, h, z, stats, wp, bp, w1, b1, w2, b2, g3, gp1, gp2, rng = ctx.saved_tensors
         need = ctx.needs_input_grad
         if d_z is None and d_o1 is None and d_o2 is None:
-            return (None,) * 24
+            return (None,) * 27
         if FUSED_BWD:
             dev = y.device
             d_z, d_o1, d_o2 = _opt(d_z), _opt(d_o1), _opt(d_o2)
@@ -337,7 +385,7 @@ class _Ffn(torch.autograd.Function):
             gwp, gbp = _park_or_grad(wp, bp, d_proj, _seq_rows(a, B), need[2], need[3])
             dgp1, dbp1, dgp2, dbp2 = _ln_sums(parts[0], nblk, ctx.lnp, two)
             dg3, db3, _, _ = _ln_sums(parts[1], nblk, ctx.ln3, False)
-            return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 10
+            return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 13
         cont = lambda t: t.contiguous().view(rows, C) if t is not None else None
         # block 3: z = y + drop3(lin2 h); o1 = post1(z), o2 = post2(z)
         d_y, d_r3, dgp1, dbp1, dgp2, dbp2 = ALN.backward_core((rows, C, epsp, p3, salt3, True), z, gp1, gp2, stats[2], stats[3], rng,
@@ -358,7 +406,7 @@ class _Ffn(torch.autograd.Function):
         d_r2 = d_r2.view(rows, C) if d_r2 is not None else d_tgt
         d_a = _batch_first(torch.mm(d_r2, wp), B) if need[0] else None
         gwp, gbp = _park_or_grad(wp, bp, d_r2, _seq_rows(a, B), need[2], need[3])
-        return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 10
+        return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 13
 
 
 # ---- module-level entry points -----------------------------------------------------------------------------------------
@@ -379,22 +427,22 @@ def usable(layer, tgt, query_pos, masks):
                 and (query_pos is None or query_pos.shape == tgt.shape))
 
 
-def qkv(t, pos, sa, B):
-    """the self-attention's projected operands, batch-first [B, nQ, 256] each"""
+def qkv(t, pos, sa, B, img):
+    """the self-attention's projected operands, batch-first [B, nQ, 256] each; img: the layer's images (images())"""
     E = sa.embed_dim
     wq, wk, wv = sa.in_proj_weight.view(3, E, E).unbind(0)
     bq, bk, bv = sa.in_proj_bias.view(3, E).unbind(0)
-    return _Qkv.apply(t.contiguous(), pos.contiguous() if pos is not None else None, wq, wk, wv, bq, bk, bv, B)
+    return _Qkv.apply(t.contiguous(), pos.contiguous() if pos is not None else None, wq, wk, wv, bq, bk, bv, B, img[0:3])
 
 
-def proj_q(a, tgt, pos, out_proj, q_lin, drop, ln, salt, B):
+def proj_q(a, tgt, pos, out_proj, q_lin, drop, ln, salt, B, img):
     """(tgt + drop(out_proj(a)), q_lin(ln(.) + pos)): the residual stream [nQ, B, 256] and the cross attention's query [B, nQ, 256]"""
     p = drop.p if (drop is not None and drop.training) else 0.0
     return _ProjQ.apply(a.contiguous(), tgt.contiguous(), pos.contiguous() if pos is not None else None, out_proj.weight, out_proj.bias,
-                        q_lin.weight, q_lin.bias, ln.weight, ln.bias, ln.eps, p, salt, _rng_for(p, tgt.device), B)
+                        q_lin.weight, q_lin.bias, ln.weight, ln.bias, ln.eps, p, salt, _rng_for(p, tgt.device), B, img[3], img[4])
 
 
-def ffn(a, tgt, layer, post_norms, salts, act_salt, B):
+def ffn(a, tgt, layer, post_norms, salts, act_salt, B, img):
     """residual blocks 2 and 3 of the layer around its FFN; returns (z, post_norms[0](z) [, post_norms[1](z)])"""
     ca = layer.multihead_attn
     p2 = layer.dropout2.p if layer.dropout2.training else 0.0
@@ -408,4 +456,4 @@ def ffn(a, tgt, layer, post_norms, salts, act_salt, B):
     return _Ffn.apply(a.contiguous(), tgt.contiguous(), ca.proj.weight, ca.proj.bias, layer.linear1.weight, layer.linear1.bias,
                       layer.linear2.weight, layer.linear2.bias, layer.norm3.weight, layer.norm3.bias, n1.weight, n1.bias,
                       n2.weight if n2 is not None else None, n2.bias if n2 is not None else None, layer.norm3.eps, n1.eps,
-                      p2, salts[1], pa, act_salt, p3, salts[2], rng, B)
+                      p2, salts[1], pa, act_salt, p3, salts[2], rng, B, img[5], img[6], img[7])

@@ -373,6 +373,12 @@ class MultiheadSelfAttention(nn.Module):
 # =====================================================================================================
 # decoder layers
 # =====================================================================================================
+def _proposal_order(objectness, n):
+    """indices [B, n] of the n highest objectness values, ties to the lower token index (see the proposals in
+    GlobalTransformer.forward: a stable sort is one of the orders torch.topk may return, and the same one on every device)"""
+    return torch.sort(objectness, dim=1, descending=True, stable=True)[1][:, :n]
+
+
 # the glue between a layer's attention cores as three launches (rowblock.hip); VDETR_ROWBLOCK=0: one launch per op (A/B, parity)
 _ROWBLOCK = os.environ.get("VDETR_ROWBLOCK", "1") != "0"
 
@@ -454,15 +460,16 @@ class GlobalDecoderLayer(nn.Module):
             # streams (salts) as the composition below
             B = tgt.shape[1]
             sa, ca = self.self_attn, self.multihead_attn
-            q, k, v = RB.qkv(tgt2, query_pos, sa, B)
+            img = RB.images(self)   # the projections' W^T images: the decoder rewrites all layers' in one launch per forward
+            q, k, v = RB.qkv(tgt2, query_pos, sa, B, img)
             p = sa.dropout if sa.training else 0.0
             core = A.fused_attention(q, k, v, num_heads=sa.num_heads, scale=sa.head_dim ** -0.5, shared_kv=False, dropout_p=p,
                                      salt=sa._salt)
-            tgt, qc = RB.proj_q(core, tgt, query_pos, sa.out_proj, ca.q, self.dropout1, self.norm2, self._aln_salts[0], B)
+            tgt, qc = RB.proj_q(core, tgt, query_pos, sa.out_proj, ca.q, self.dropout1, self.norm2, self._aln_salts[0], B, img)
             core, _ = ca.core(qc, memory, reference_point, reference_angle, enc_xyz, None, self.cross_cache)
             if getattr(self, "_act_salt", None) is None:
                 self._act_salt = BNA.new_salt()
-            res = RB.ffn(core, tgt, self, self.post_norms, self._aln_salts, self._act_salt, B)
+            res = RB.ffn(core, tgt, self, self.post_norms, self._aln_salts, self._act_salt, B, img)
             self.post_normed = tuple(r for r in res[1:] if r is not None)
             return res[0], None
         q = k = self.with_pos_embed(tgt2, query_pos)
@@ -1047,7 +1054,7 @@ class TransformerDecoder(nn.Module):
             # a GPU run of the same weights rank those two proposals differently and hand them each other's query embedding
             # (measured: ranks 882 / 883 of BASELINE config 2's scene).  A stable descending sort is one of the orders topk may
             # return, and the same one on every device: ties go to the lower token index.
-            topk = torch.sort(objectness, dim=1, descending=True, stable=True)[1][:, :self.num_queries]
+            topk = _proposal_order(objectness, self.num_queries)
         else:
             topk = torch.arange(ntok, device=objectness.device).unsqueeze(0).repeat(objectness.shape[0], 1)
 
@@ -1094,6 +1101,9 @@ class TransformerDecoder(nn.Module):
             isinstance(l, GlobalDecoderLayer) and l.normalize_before and ALN.supported(self.norm, l.norm1, l.norm2, l.norm3)
             for l in self.layers)
         carried = None  # norm1 of the next layer, produced by the previous layer's last launch
+        if (fuse_ln and _ROWBLOCK and output.is_cuda and memory_mask is None and
+                all(RB.usable(l, output, None, ()) and not l.pos_for_key for l in self.layers)):
+            RB.refresh(self.layers)  # the fused glue launches' weight images of all layers: one launch (rowblock.py)
         defer = _DEFER_HEADS and self.mlp_sep and self.return_intermediate and len(self.layers) > 1
         deferred, stacked = [], {}
         for idx, layer in enumerate(self.layers):
