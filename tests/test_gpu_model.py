@@ -567,7 +567,10 @@ def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
         assert_close(stages_g[0][k], stages_c[0][k].detach().numpy(), 1e-3, 2e-4, f"stage 0 {k}")
     for s_ in range(1, len(stages_g)):  # the decoder stages: all nq queries (same token at every rank, see above)
         for k in keys:
-            assert_close(stages_g[s_][k], stages_c[s_][k].detach().numpy(), 1e-3, 2e-4,
+            # 1e-3 relative (BASELINE.json north_star); entries near zero are held to 2e-4 of the tensor's largest entry (the
+            # stages feed their boxes back into the next layer's RPE: fp32 rounding of 8 layers accumulates on that scale)
+            ref = stages_c[s_][k].detach().numpy()
+            assert_close(stages_g[s_][k], ref, 1e-3, 2e-4 * max(1.0, float(np.abs(ref).max())),
                          f"stage {s_} {k} ({order['differ']} ranks differed before pinning)")
     for fg, fc in zip(inp_gpu["backbone_features"], inp_cpu["backbone_features"]):
         assert_close(fg.grad, fc.grad.numpy(), 5e-3, 1e-3 * float(fc.grad.abs().max()), "d loss / d backbone features")

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Where does the captured step's time go between its main chain and the table-gradient branch?  Three runs of bench.py's step
+(separate processes, selected by argv[1]):
+  normal    the step as benched
+  notable   the RPE-table gradient launches left out (NOT a valid step: the lower bound the main chain alone would reach)
+  inline    the table gradient on the main stream, all 256 CUs (VDETR_BWD_ASYNC_TABLE=0)
+  grid=N    the side-stream launch on N workgroups
+    for m in normal notable inline; do python tools/probes/step_bounds.py $m | tail -1; done"""
+import json
+import os
+import sys
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "normal"
+if mode == "inline":
+    os.environ["VDETR_BWD_ASYNC_TABLE"] = "0"
+if mode.startswith("grid="):
+    os.environ["VDETR_BWD_ASYNC_GRID"] = mode[5:]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+import vdetr_amd.attention as A  # noqa: E402
+
+if mode == "notable":
+    A._launch_table_async = lambda lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable: dtable
+sys.argv = ["bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-criterion-leg", "--no-backbone-leg"] + sys.argv[2:]
+import io
+import contextlib
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    bench.main()
+line = [l for l in buf.getvalue().splitlines() if l.startswith("{")][-1]
+d = json.loads(line)
+print(json.dumps({"mode": mode, "ms_per_step": d["ms_per_step"], "scenes_per_s": d["value"]}))
