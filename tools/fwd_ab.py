@@ -115,6 +115,8 @@ def time_pair(case, dropout, reps, rng):
 
 
 if __name__ == "__main__":
+    if "--lib" in sys.argv:  # a variant build of the library (experiments): before the first call loads the default one
+        L.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
     dev = torch.device("cuda")
     cfg = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "c2"
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 20

@@ -163,12 +163,17 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 
 // SPLIT: QK^T and PV on the bf16 matrix unit.  fp32 MFMA and VALU instructions exclude each other on a SIMD, so
-// the 32 v_mfma_f32_16x16x4_f32 of a tile cost 1,024 of the ~4,500 issue cycles a wave spends on it.  With x = h + m + l (three
-// bf16, exact: 3 x 8 = 24 significant bits) a product is the six terms of order <= 2 (hh, hm, mh, mm, hl, lh: what is dropped is
-// 2^-24 of it, an fp32 rounding) on v_mfma_f32_16x16x32_bf16: 12 instructions of 16 cycles for QK^T instead of 16 of 32.  PV takes
-// P and V as two halves each (three terms, 2^-16 of a product: the output is a convex combination of V rows, nothing amplifies it):
-// 12 v_mfma_f32_16x16x16_bf16 of 8 cycles instead of 16 of 32.  K and V arrive pre-split, in operand order, from an image that a
-// small launch packs once per call (attn_fwd_pack_kv_kernel: [tile][K: 3 parts x 2 k-halves | V: 4 d-tiles][lane][16 B]).
+// the 32 v_mfma_f32_16x16x4_f32 of a tile cost 1,024 of the ~4,500 issue cycles a wave spends on it.
+//   QK^T (the scores go through exp: kept at fp32 accuracy): x = h + m + l, three bf16 parts (3 x 8 = 24 significant bits, the
+//     residuals are exact in fp32), and the six terms of order <= 2 (hh, hm, mh, mm, hl, lh: what is dropped is 2^-24 of a product,
+//     an fp32 rounding) on v_mfma_f32_16x16x32_bf16: 12 instructions of 16 cycles instead of 16 of 32.  Scores against the fp32
+//     kernel: max |diff| 5.7e-6 at |s| <= 10.8, the same as between the two fp32 kernels (tools/fwd_ab.py).
+//   PV (a convex combination of V rows: nothing downstream amplifies its rounding): P and V as two bf16 parts each (16 significant
+//     bits), three terms, 12 v_mfma_f32_16x16x16_bf16 of 8 cycles instead of 16 of 32: the output is 8e-6 relative off the fp32
+//     kernel's (1.6e-5 at |out| <= 1.9; fp32 accumulation over 4096 keys itself: 1.3e-6).  Measured alternative, three parts each and
+//     six terms (output 1.5e-6 off): +5 % launch time (profiles/r05_fwd_split_variants.txt) for nothing the 1e-3 contract can see.
+// K and V arrive pre-split, in operand order, from an image that a small launch packs once per call (attn_fwd_pack_kv_kernel:
+// [tile][K: 3 parts x 2 k-halves | V: 4 d-tiles][lane][16 B]).
 constexpr int kImgK = 6, kImgV = 4;                         // 16-byte pieces per lane and tile
 constexpr int kImgTileBytes = (kImgK + kImgV) * kWave * 16;  // 10,240 B per 16-key tile
 
