@@ -257,17 +257,20 @@ class Trainer:
 
     _capture_stream = None  # one per process: a second Trainer on the same model meets the first one's AccumulateGrad nodes
 
-    @staticmethod
-    def quiesce_collectives():
+    def quiesce_collectives(self):
         """Before a capture begins: nothing of the warm-up's collectives may still sit in ProcessGroupNCCL's watchdog list.
         The watchdog thread polls the completion events of outstanding collectives every 100 ms, and an event query from
         ANOTHER thread while this thread captures is an error under the default (global) capture mode — seen as an
         intermittent SIGABRT of the rank ("operation not permitted when stream is capturing", 1 run in 3).  After a device
-        synchronise every collective is complete; half a second lets the watchdog see that and drop them.  The captures
-        below also run in thread-local error mode, which permits such calls from other threads."""
+        synchronise the warm-up's collectives are polled until each reports completion (Work.is_completed()), then ONE watchdog
+        period lets that thread drop them.  The captures below also run in thread-local error mode, which permits such calls
+        from other threads."""
         torch.cuda.synchronize()
         if torch.distributed.is_available() and torch.distributed.is_initialized():
-            time.sleep(0.5)
+            deadline = time.time() + 5.0
+            while not self.reducer.collectives_done() and time.time() < deadline:
+                time.sleep(0.005)
+            time.sleep(0.12)
 
     def capture(self):
         if Trainer._capture_stream is None:
@@ -281,7 +284,7 @@ class Trainer:
                     self.reducer.reduce_all()  # real updates: the replicas must stay identical
                 self._update()
         torch.cuda.current_stream().wait_stream(s)
-        Trainer.quiesce_collectives()
+        self.quiesce_collectives()
         # Capture on the stream the warm-up ran on: the warm-up's autograd graph (kept alive by tensors the modules hold)
         # owns one AccumulateGrad node per parameter, bound to the stream it was created on; under a different capture
         # stream the engine runs those nodes on the old stream and stitches cross-stream dependencies into the graph.
@@ -293,7 +296,7 @@ class Trainer:
                 self._update()
         if self.reducer.active and not self.phased:
             self.reducer.reduce_all()  # the flat gradient buffer, in slices; not captured (RCCL outside the graph)
-            Trainer.quiesce_collectives()
+            self.quiesce_collectives()
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local", **({"stream": s} if same else {})):
                 self._update()
@@ -439,7 +442,7 @@ class BackboneTrainer:
             for _ in range(3):
                 self._decoder_fwd_bwd()
         torch.cuda.current_stream().wait_stream(s)
-        Trainer.quiesce_collectives()
+        self.quiesce_collectives()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
             self._decoder_fwd_bwd()
@@ -911,7 +914,12 @@ def main():
     if dtype == "bf16":  # BASELINE config 4: q / k / v of the 3DV-RPE cross attention stored as bf16, QK^T / PV on the bf16 matrix cores
         from vdetr_amd.vdetr_transformer import set_attention_dtype
         set_attention_dtype(model, torch.bfloat16)
-    use_graph = not a.no_graph
+    # the fallback chain of the captured step (see relaunch() below): level 0 = one graph with the gradient all-reduce inside,
+    # 1 = the all-reduce outside the graph (two graphs per step), 2 = no graph.  A level above 0 is always a child process.
+    fallback = int(os.environ.get("VDETR_BENCH_FALLBACK", "0"))
+    if fallback >= 1:
+        os.environ["VDETR_PHASED_REDUCE"] = "0"
+    use_graph = not a.no_graph and fallback < 2
     if world > 1:
         broadcast_parameters(model)
     if a.sync_bn:  # batch statistics over all ranks inside the fused BatchNorm launches (bn_act.set_sync), graph-capturable
@@ -989,40 +997,62 @@ def main():
             return bool(t.item())
         return ok
 
+    def any_rank_failed(failed, tag):
+        """Did the capture fail on ANY rank?  Agreed through the process group's key-value store (CPU only): a process whose
+        capture failed cannot issue device work any more — the HIP runtime leaves the capture's streams in capture state and
+        refuses every later attempt to end it ("attempt to terminate a thread-local capture sequence from another thread";
+        tools/probes/capture_recovery.py) — so neither a device all-reduce nor a retry in this process is possible."""
+        if world == 1:
+            return failed
+        store = torch.distributed.distributed_c10d._get_default_store()
+        store.add(f"bench_{tag}_failed", 1 if failed else 0)
+        store.add(f"bench_{tag}_seen", 1)
+        deadline = time.time() + 600
+        while store.add(f"bench_{tag}_seen", 0) < world:
+            if time.time() > deadline:
+                raise RuntimeError("bench: the ranks did not all report their capture within 10 minutes")
+            time.sleep(0.01)
+        return store.add(f"bench_{tag}_failed", 0) > 0
+
+    def relaunch(level):
+        """The next form of the step — level 1: collectives outside the graph, level 2: no graph — in a CHILD process per rank
+        (same RANK / WORLD_SIZE, rendezvous one port further; the parent only waits and leaves with the child's exit code: it
+        never replaces itself).  The child writes the JSON line."""
+        import subprocess
+        env = dict(os.environ)
+        env["VDETR_BENCH_FALLBACK"] = str(level)
+        if "MASTER_PORT" in env:
+            env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
+        env.pop("TORCHELASTIC_RUN_ID", None)
+        for k in ("TORCHELASTIC_USE_AGENT_STORE",):  # the child forms its own store on the new port
+            env[k] = "False"
+        if rank == 0:
+            print(f"[bench] capture failed on at least one rank: every rank restarts the step in a child process at fallback level {level} "
+                  f"({'collectives outside the graph' if level == 1 else 'no graph'})", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env)
+        code = proc.wait()
+        os._exit(code)  # (no interpreter shutdown: the failed capture's graph object cannot be destroyed)
+
     if use_graph:
         err = None
         try:
             trainer.capture()
         except Exception as e:  # capture is an optimisation: report and fall back
             err = e
-            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
-            torch.cuda.synchronize()
-        graph_ok = all_ranks(err is None)  # (agreed BEFORE choose_fps_depth, whose own collectives every rank must reach)
-        if graph_ok:
-            try:
-                trainer = choose_fps_depth(trainer)
-            except Exception as e:
-                print(f"[bench] rank {rank}: sampling look-ahead choice failed ({type(e).__name__}: {e}); keeping depth 1", file=sys.stderr)
-        if not graph_ok:
-            was_phased = trainer.phased
-            trainer.g_main = trainer.g_opt = None
-            if was_phased:  # the collectives inside the graph are the newest part: retry with them outside
-                err = None
-                try:
-                    os.environ["VDETR_PHASED_REDUCE"] = "0"
-                    trainer = make_trainer(a.loss == "criterion")
-                    trainer.capture()
-                except Exception as e2:
-                    err = e2
-                    print(f"[bench] rank {rank}: second capture failed too ({type(e2).__name__}: {e2})", file=sys.stderr)
-                    torch.cuda.synchronize()
-                graph_ok = all_ranks(err is None)
-                if graph_ok and rank == 0:
-                    print("[bench] captured with the all-reduce outside the graph", file=sys.stderr)
-                if not graph_ok:
-                    trainer.g_main = trainer.g_opt = None
-                    if rank == 0:
-                        print("[bench] running eager", file=sys.stderr)
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {str(e).splitlines()[0]})", file=sys.stderr, flush=True)
+        if any_rank_failed(err is not None, "capture"):
+            relaunch(fallback + 1)
+        graph_ok = True
+        try:
+            trainer = choose_fps_depth(trainer)
+        except Exception as e:  # (a capture inside the choice failed: the same dead end, the child keeps depth 1)
+            print(f"[bench] rank {rank}: sampling look-ahead choice failed ({type(e).__name__}: {str(e).splitlines()[0]})", file=sys.stderr, flush=True)
+            os.environ["VDETR_FPS_DEPTH"] = "1"
+            err = e
+        if any_rank_failed(err is not None, "depth"):
+            os.environ["VDETR_FPS_DEPTH"] = "1"
+            relaunch(fallback)
 
     def barrier():
         if world > 1:
@@ -1061,7 +1091,7 @@ def main():
         "config": {"workload": desc, "global_batch": world * bs, "voxels_per_scene": int(inputs["backbone_xyz"][0].shape[0]),
                    "keys": npre, "queries": nq, "rpe_layers": nl - 1, "parallelism": f"dp{world}",
                    "step": "FPS+gather, projection, decoder fwd, loss, backward, grad all-reduce (N>1), clip, AdamW",
-                   "hip_graph": graph_ok, "settle_steps": settle, "sync_bn": bool(a.sync_bn), "fps_prefetch": not a.no_fps_prefetch,
+                   "hip_graph": graph_ok, "fallback_level": fallback, "settle_steps": settle, "sync_bn": bool(a.sync_bn), "fps_prefetch": not a.no_fps_prefetch,
                    "fps_lookahead": 2 if getattr(trainer, "fps_depth2", False) and graph_ok else (1 if not a.no_fps_prefetch else 0),
                    "grad_allreduce_bytes": trainer.reducer.grad_bytes(), "grad_allreduce_buckets": len(trainer.reducer.buckets),
                    "grad_allreduce_model": trainer.bucket_model,
@@ -1071,7 +1101,9 @@ def main():
                                       "bucket hooks on a side stream during backward" if trainer.hooked else "after the replayed backward")},
         "loss": loss,
         "arith": {"activations": "f32" if dtype == "f32" else "f32 residual stream; q / k / v of the cross attention stored as bf16",
-                  "qk_pv": "v_mfma_f32_16x16x4_f32 (exact f32)" if dtype == "f32" else "v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16, f32 accumulate (self-attention: f32)", "softmax_log2_table_lookup": "f32",
+                  "qk_pv": ("3DV-RPE cross attention forward: f32 operands as bf16 parts on the bf16 matrix unit, f32 accumulate — QK^T three parts, "
+                            "six terms (2^-24 per product: f32 accuracy), PV two parts, three terms (2^-16 per product, output 8e-6 relative); "
+                            "query self-attention and VDETR_FWD_KERNEL=2: v_mfma_f32_16x16x4_f32 (exact f32)") if dtype == "f32" else "v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16, f32 accumulate (self-attention: f32)", "softmax_log2_table_lookup": "f32",
                   "dtable_products": "exact f32 outer products on v_mfma_f32_16x16x4_f32 (attn_bwd_box4_kernel: axis-aligned and rotated boxes; "
                                      "arbitrary vertices take the general kernel: split-bf16 2^-15)",
                   "dtable_accum": "int32 fixed point in LDS",

@@ -591,15 +591,39 @@ def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
         assert rows.size <= 0.02 * live and all(x <= 0.10 for x in rel) and fro <= 1e-2, (
             f"d loss / d backbone features: {rows.size} of {live} rows off (allowed {int(0.02 * live)}), largest deviation "
             f"{max(rel, default=0.0):.3f} of the row's scale (allowed 0.10), Frobenius {fro:.2e} (allowed 1e-2); first rows {rows[:8].tolist()}")
-    bad = []
-    for (n, pg), (_, pc) in zip(gpu_model.named_parameters(), model.named_parameters()):
+    # Every parameter's gradient.  The same chaos as above bounds what two correct fp32 implementations can agree on here: two
+    # DEVICE runs of this very step that differ only in the first call's GEMM selection are 7e-4 apart in the stage-7 outputs and
+    # up to 7 % (max-abs over the parameter's largest entry; median over the parameters 6e-4) apart in the heads' weight
+    # gradients (tools/probes/diag_repro.py, profiles/r05_diag_repro.txt).  Criterion: relative Frobenius error <= 5e-2 and cosine
+    # >= 0.998 for every parameter, and the MEDIAN relative error over the parameters <= 2e-3.  (A wrong scale, a dropped term
+    # or a missed accumulation is an O(1) error in at least one parameter; the kernels and layers are held to 1e-3 .. 1e-4 on
+    # their own inputs in test_gpu_attention.py / test_gpu_rowblock.py / the decoder fixtures.)
+    bad, rels = [], []
+    cpu_params = dict(model.named_parameters())
+    for n, pg in gpu_model.named_parameters():
+        pc = cpu_params[n]
         if pc.grad is None:
             assert pg.grad is None or float(pg.grad.abs().max()) == 0.0, n
             continue
-        assert pg.grad is not None, f"{n}: no gradient on the device"
-        g, c = pg.grad.detach().cpu().double(), pc.grad.double()
-        scale = float(c.abs().max())
-        err = float((g - c).abs().max())
-        if err > 2e-3 * scale + 1e-6:
-            bad.append((n, err, scale))
-    assert not bad, "parameter gradients off: " + ", ".join(f"{n}: {e:.2e} of {s:.2e}" for n, e, s in bad[:8])
+        if pg.grad is None:
+            # the bias of a convolution in front of a batch norm in train mode cancels in the normalisation: the device never
+            # forms its gradient (vdetr_bnact_desc.pre_bias), the CPU's is summation noise of the sibling weight's
+            sib = cpu_params.get(n[:-4] + "weight") if n.endswith(".bias") else None
+            assert sib is not None and sib.grad is not None and float(pc.grad.abs().max()) <= 1e-5 * float(sib.grad.abs().max()), \
+                f"{n}: no gradient on the device"
+            continue
+        g, c = pg.grad.detach().cpu().double().flatten(), pc.grad.double().flatten()
+        scale = float(c.norm())
+        sib = cpu_params.get(n[:-4] + "weight") if n.endswith(".bias") else None
+        if sib is not None and sib.grad is not None:
+            # (a bias whose gradient is zero in exact arithmetic — the key projections', a bias in front of a norm — has no scale
+            # of its own: judged on the sibling weight's, as tests/helpers.py: grad_atol)
+            w = sib.grad.double()
+            scale = max(scale, 1e-2 * float(w.norm()) * (c.numel() / w.numel()) ** 0.5)
+        rel = float((g - c).norm()) / max(scale, 1e-30)
+        cos = float(torch.dot(g, c)) / max(float(g.norm()) * float(c.norm()), 1e-30)
+        rels.append(rel)
+        if rel > 5e-2 or (cos < 0.998 and float(c.norm()) >= scale):
+            bad.append((n, rel, cos))
+    assert not bad, "parameter gradients off: " + ", ".join(f"{n}: rel {e:.2e} cos {cs:.4f}" for n, e, cs in bad[:8])
+    assert float(np.median(rels)) <= 2e-3, f"median relative error of the parameter gradients {np.median(rels):.2e}"

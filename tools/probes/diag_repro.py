@@ -42,7 +42,9 @@ runs = [run(False, 1) for _ in range(4)]
 for i in range(1, 4):
     g0, g1 = runs[0][0], runs[i][0]
     fwd = [float((a - b).abs().max()) for a, b in zip(runs[0][1], runs[i][1])]
-    worst = sorted(((float((runs[0][2][n] - runs[i][2][n]).abs().max() / (runs[0][2][n].abs().max() + 1e-30)), n) for n in runs[0][2]), reverse=True)[:3]
+    allrel = sorted(((float((runs[0][2][n] - runs[i][2][n]).abs().max() / (runs[0][2][n].abs().max() + 1e-30)), n) for n in runs[0][2]
+                     if not n.endswith(".k.bias")), reverse=True)
+    worst = allrel[:6] + [allrel[len(allrel) // 2]]
     print(f"run 0 vs run {i}: forward stages max |diff| {['%.1e' % x for x in fwd]}; feature grad max |diff| {np.abs(g1 - g0).max():.3e}; "
           f"param grads worst rel {[(n, '%.1e' % e) for e, n in worst]}", flush=True)
 g1, g2 = runs[1][0], runs[2][0]

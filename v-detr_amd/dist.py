@@ -528,6 +528,7 @@ class GradientReducer:
                     self._launch(gi)
             for h in self._handles:
                 h.wait()
+            self._last_works = self._handles  # (kept for collectives_done(): what a capture has to see finished first)
             self._handles = []
             if self._side is not None:
                 torch.cuda.current_stream().wait_stream(self._side)
@@ -543,6 +544,17 @@ class GradientReducer:
         self._pending = list(self._counts)
         self._launched = [False] * len(self.buckets)
         self._seen.clear()
+
+    def collectives_done(self):
+        """True when every collective of the last finished step has completed on the device (Work.is_completed(); a handle that
+        cannot be asked counts as done after the caller's device synchronise)."""
+        for h in getattr(self, "_last_works", ()):
+            try:
+                if not h.is_completed():
+                    return False
+            except RuntimeError:
+                pass
+        return True
 
     def _allreduce_avg(self, t, async_op=False):
         """Average over the ranks.  RCCL averages inside the collective (ncclAvg) where every rank's library has it — a
