@@ -170,12 +170,14 @@ def flush_weight_grads_phased(phase_of_param, nphases, after_phase):
         after_phase(k)
 
 
-# ---- a failed stream capture must not leave streams behind in capture state -------------------------------------------------
-# torch.cuda.graph ends the capture on its ORIGIN stream when the captured region raises.  Streams the region had forked to (the
-# table-gradient side stream, a reducer's side stream, sampling streams) and not yet joined can stay in capture state after that
-# (seen with two gloo ranks: the all-reduce inside the region invalidates the capture, and the next pageable host-to-device copy
-# of the process fails with "operation not permitted when stream is capturing").  end_stray_captures() asks the HIP runtime for
-# each known stream's capture status and ends what is still open.
+# ---- capture state of a stream ------------------------------------------------------------------------------------------------------
+# torch.cuda.graph ends the capture on its origin stream when the captured region raises — and on this HIP runtime that attempt
+# fails when a forked stream has not joined ("capturing stream has unjoined work") or the capture was invalidated, after which the
+# origin AND the forked streams stay in capture state for good: a second hipStreamEndCapture (from the same thread, through torch
+# or directly) is refused with "attempt to terminate a thread-local capture sequence from another thread", and every pageable
+# host-to-device copy of the process fails with "operation not permitted when stream is capturing"
+# (tools/probes/capture_recovery.py, profiles/r05_capture_recovery.txt).  A process whose capture failed therefore cannot fall back
+# in place: bench.py restarts the step in a child process.  capture_status() is what the probe and that decision read.
 _hip = None
 
 
@@ -195,10 +197,6 @@ def _hip_runtime():
         _hip = ctypes.CDLL(path)
         _hip.hipStreamIsCapturing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         _hip.hipStreamIsCapturing.restype = ctypes.c_int
-        _hip.hipStreamEndCapture.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
-        _hip.hipStreamEndCapture.restype = ctypes.c_int
-        _hip.hipGraphDestroy.argtypes = [ctypes.c_void_p]
-        _hip.hipGraphDestroy.restype = ctypes.c_int
         _hip.hipGetLastError.restype = ctypes.c_int
     return _hip
 
@@ -212,42 +210,3 @@ def capture_status(stream):
         _hip_runtime().hipGetLastError()
         return 2  # (the query itself fails on an invalidated capture)
     return st.value
-
-
-def end_stray_captures(origin, streams=()):
-    """After a failed capture on `origin` (a torch.cuda.Stream): bring `origin`, `streams` and this package's own side streams out
-    of capture state.  The HIP runtime refuses to end a capture whose forked streams have not joined ("capturing stream has
-    unjoined work") and then leaves ALL of them capturing: so every stream that still captures is joined into the origin first
-    (an event recorded on it, waited for by the origin), then the origin's capture is ended and its graph dropped.  Returns the
-    number of streams that were still capturing."""
-    import ctypes
-    import torch
-    from . import attention as A
-    hip = _hip_runtime()
-    sides = [st for st in list(streams) + list(getattr(A, "_side_streams", {}).values())
-             if isinstance(st, torch.cuda.Stream) and st != origin]
-    stray = [st for st in sides if capture_status(st) != 0]
-    n = len(stray) + (1 if capture_status(origin) != 0 else 0)
-    if capture_status(origin) != 0:
-        for st in stray:
-            try:
-                ev = torch.cuda.Event()
-                ev.record(st)
-                origin.wait_event(ev)
-            except RuntimeError:
-                hip.hipGetLastError()
-        g = ctypes.c_void_p()
-        rc = hip.hipStreamEndCapture(ctypes.c_void_p(origin.cuda_stream), ctypes.byref(g))  # (may return the capture's error: expected)
-        if os.environ.get("VDETR_DEBUG_CAPTURE"):
-            print(f"[runtime] hipStreamEndCapture(origin) -> {rc}, graph {g.value}", flush=True)
-        hip.hipGetLastError()
-        if g.value:
-            hip.hipGraphDestroy(g)
-    for st in stray:  # whatever the origin's end did not take along
-        if capture_status(st) != 0:
-            g = ctypes.c_void_p()
-            hip.hipStreamEndCapture(ctypes.c_void_p(st.cuda_stream), ctypes.byref(g))
-            hip.hipGetLastError()
-            if g.value:
-                hip.hipGraphDestroy(g)
-    return n
