@@ -169,10 +169,16 @@ typedef struct vdetr_attn_desc {
   int32_t kv_waves;   /* workgroup shape of vdetr_attn_bwd_kv_f32: 0 or 8 = 8 waves (the kernel alone on the chip), 4 = one wave
                          per SIMD with <= 256 registers (fits next to a table-gradient kernel on another stream); either shape
                          computes the same values */
-  int32_t fwd_kernel; /* forward of the RPE kind: 0 = persistent workgroups (attn_fwd_pipe.hip), 1 = one workgroup per
-                         (query quad, key chunk) (attn_fwd.hip; the round-4 kernel, kept for A/B runs and parity tests) */
+  int32_t fwd_kernel; /* forward of the RPE kind: 0 = persistent workgroups, QK^T / PV on the bf16 matrix unit from split f32
+                         operands (attn_fwd_pipe.hip: scores at f32 accuracy, output 8e-6 relative); 2 = the same with f32
+                         matrix instructions; 1 = one workgroup per (query quad, key chunk) (attn_fwd.hip; the round-4 kernel,
+                         kept for A/B runs and parity tests) */
   int32_t bwd_kernel; /* table gradient: 0 = the axis-aligned-box kernel where every query's vertices are a box (attn_bwd_box4.hip;
                          decided on the device), 1 = the general kernel only (parity tests compare the two) */
+  int32_t kv_halves;  /* vdetr_attn_bwd_kv_f32: workgroups per key tile.  0 or 2 = two (each walks every other group of row tiles:
+                         twice the workgroups, the shape for a launch alone on the chip), 1 = one (half the workgroups, each twice
+                         as long: next to a table-gradient kernel that holds most CUs, 256 one-per-CU workgroups would run four
+                         rounds on the CUs left).  Same values either way up to the order of the row-tile sums. */
   uint32_t* fwd_sched; /* persistent forward: ONE zero device word (the item counter), left zero by the call; a word must not be
                           shared by launches that may run concurrently.  NULL: the library clears a word at the head of
                           `workspace` with a memset node in front of the launch. */

@@ -30,7 +30,7 @@ class AttnDesc(ctypes.Structure):
         ("rng_state", c_void_p),
         ("k_row_stride", ctypes.c_int32), ("v_row_stride", ctypes.c_int32),
         ("bwd_aux", c_void_p),
-        ("table_grid", ctypes.c_int32), ("kv_waves", ctypes.c_int32), ("fwd_kernel", ctypes.c_int32), ("bwd_kernel", ctypes.c_int32),
+        ("table_grid", ctypes.c_int32), ("kv_waves", ctypes.c_int32), ("fwd_kernel", ctypes.c_int32), ("bwd_kernel", ctypes.c_int32), ("kv_halves", ctypes.c_int32),
         ("fwd_sched", c_void_p),
     ]
 

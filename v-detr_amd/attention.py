@@ -86,6 +86,9 @@ ASYNC_MIN_PAIRS = 1 << 21
 # workgroups (= CUs) of the table kernel when it runs on the side stream: the remaining CUs are the main chain's
 ASYNC_TABLE_GRID = int(os.environ.get("VDETR_BWD_ASYNC_GRID", "192"))
 _ASYNC_KV4 = os.environ.get("VDETR_BWD_ASYNC_KV_WAVES", "8") == "4"
+# 1: the per-head pass only (step 7.36 -> 7.33 ms); 2: the shared-K/V pass as well (measured: 7.41 ms, it is bandwidth bound and
+# wants the workgroups); 0: never
+KV_ONE_WG = int(os.environ.get("VDETR_BWD_KV_ONE_WG", "1"))
 
 
 _step_side = {}  # device key -> this step's forward ran a cross-attention whose table gradient will go to the side stream
@@ -597,6 +600,9 @@ class _FusedAttention(Function):
             run_async = want_table and ctx.table_async and _async_wanted(B, nQ, nK)
             # 4 waves fit NEXT TO a table kernel that holds every CU; with CUs left free for the main chain the default shape
             d.kv_waves = 4 if (run_async or _side_keep) and (ASYNC_TABLE_GRID >= 256 or _ASYNC_KV4) else 8
+            # the query self-attention's pass (256 one-per-CU workgroups at the model's size) next to a live table kernel: one
+            # workgroup per key tile
+            d.kv_halves = 1 if (_side_keep and (KV_ONE_WG >= 2 or (KV_ONE_WG == 1 and not shared))) else 2
             nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
             ws = L.workspace(nbytes, q.device)
             L.check(lib.vdetr_attn_bwd_kv_delta_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(out), L.ptr(scores),

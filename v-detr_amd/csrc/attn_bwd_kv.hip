@@ -178,16 +178,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_pack_kernel(KvParams K, Delta
 //   4  the same for queries 2-3 and t = 1
 // Scores and dS go through buffer instructions whose range check does the masking: a lane whose key is past nK carries
 // offset 2^31, a row past the end is past num_records, so there is no branch around any load or store.
-template <bool PERHEAD, int WAVES>
+// HALVES workgroups per key tile (2: the launch alone on the chip; 1: half the workgroups, each twice as long — the per-head pass
+// of the query self-attention, 256 one-per-CU workgroups at the model's size, ran four rounds on the 64 CUs a live table-gradient
+// kernel leaves: 79 us instead of 24)
+template <bool PERHEAD, int WAVES, int HALVES = 2>
 __global__ __launch_bounds__(WAVES * kWave) void attn_bwd_kv_kernel(KvParams K) {
-  constexpr int kKvWaves = WAVES, kKvThreads = WAVES * kWave, kKvSlots = 2 * WAVES;  // row slots per key tile: 2 workgroups
+  constexpr int kKvWaves = WAVES, kKvThreads = WAVES * kWave, kKvSlots = HALVES * WAVES;  // row slots per key tile
   AttnParams P = K.A;
   attn_load_rng(P);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
-  const int kt = blockIdx.x >> 1, hf = blockIdx.x & 1, prob = blockIdx.y;
+  const int kt = blockIdx.x / HALVES, hf = blockIdx.x % HALVES, prob = blockIdx.y;
   const KvProblem pb = kv_problem<PERHEAD>(K, prob);
   const int b = pb.b;
   const int R = K.R, NT = K.NT, nK = P.nK;
@@ -405,7 +408,7 @@ extern "C" size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d) {
   return kv_problems(d) * nt * kKvTileUnits * sizeof(uint4) + 256;
 }
 
-template <bool PERHEAD, int WAVES>
+template <bool PERHEAD, int WAVES, int HALVES = 2>
 static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, const DeltaArgs& D, int ndelta, hipStream_t st) {
   const unsigned pack_blocks = (unsigned)((pack_work + 255) / 256 < 2048 ? (pack_work + 255) / 256 : 2048);
   hipLaunchKernelGGL(attn_bwd_kv_pack_kernel<PERHEAD>, dim3(pack_blocks + (unsigned)ndelta), dim3(256), 0, st, K, D, ndelta);
@@ -413,8 +416,8 @@ static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, cons
   const size_t strips = (size_t)WAVES * 8 * kWave * sizeof(uint4), tree = (size_t)(WAVES / 2) * 64 * kWave * sizeof(float);
   const size_t fin = (size_t)2 * 32 * (kDh + 1) * sizeof(float);
   const size_t lds = strips > tree ? (strips > fin ? strips : fin) : (tree > fin ? tree : fin);
-  if (int e = set_lds(attn_bwd_kv_kernel<PERHEAD, WAVES>, lds, "attn_bwd_kv")) return e;
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<PERHEAD, WAVES>), dim3(2 * nkt, nprob), dim3(WAVES * kWave), lds, st, K);
+  if (int e = set_lds(attn_bwd_kv_kernel<PERHEAD, WAVES, HALVES>, lds, "attn_bwd_kv")) return e;
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<PERHEAD, WAVES, HALVES>), dim3(HALVES * nkt, nprob), dim3(WAVES * kWave), lds, st, K);
   return check_launch("attn_bwd_kv");
 }
 
@@ -446,7 +449,9 @@ static int kv_run(const vdetr_attn_desc* d, const float* q, const float* v, cons
   const long work = units > zero4 ? units : zero4;
   const int nkt = (d->nK + 31) / 32;
   VDETR_REQUIRE(d->kv_waves == 0 || d->kv_waves == 4 || d->kv_waves == 8, "attn_bwd_kv: kv_waves %d (0, 4 or 8)", d->kv_waves);
+  VDETR_REQUIRE(d->kv_halves == 0 || d->kv_halves == 1 || d->kv_halves == 2, "attn_bwd_kv: kv_halves %d (0, 1 or 2)", d->kv_halves);
   const bool four = d->kv_waves == 4;  // (see the note at the kernel)
+  const bool one = d->kv_halves == 1 && !four;
   hipStream_t st = (hipStream_t)stream;
   DeltaArgs D{};
   int ndelta = 0;
@@ -455,8 +460,11 @@ static int kv_run(const vdetr_attn_desc* d, const float* q, const float* v, cons
     attn_delta_args(d, dout, out, v, delta, &D);
     ndelta = D.qblocks + D.vblocks;
   }
-  if (d->kind == VDETR_ATTN_PER_HEAD)
+  if (d->kind == VDETR_ATTN_PER_HEAD) {
+    if (one) return kv_launch<true, 8, 1>(K, nkt, (int)nprob, work, D, ndelta, st);
     return four ? kv_launch<true, 4>(K, nkt, (int)nprob, work, D, ndelta, st) : kv_launch<true, 8>(K, nkt, (int)nprob, work, D, ndelta, st);
+  }
+  if (one) return kv_launch<false, 8, 1>(K, nkt, (int)nprob, work, D, ndelta, st);
   return four ? kv_launch<false, 4>(K, nkt, (int)nprob, work, D, ndelta, st) : kv_launch<false, 8>(K, nkt, (int)nprob, work, D, ndelta, st);
 }
 
