@@ -1,0 +1,12 @@
+mkdir -p gpurun_out/r5b
+F="--no-cpu-baseline --no-criterion-leg --no-backbone-leg --no-roofline"
+python bench.py --config c1 $F > gpurun_out/r5b/bench_c1.json 2> gpurun_out/r5b/bench_c1.err
+python bench.py --config c4 --dtype bf16 $F > gpurun_out/r5b/bench_c4_bf16.json 2> gpurun_out/r5b/bench_c4_bf16.err
+python bench.py --config c4 --dtype f32 $F > gpurun_out/r5b/bench_c4_f32.json 2> gpurun_out/r5b/bench_c4_f32.err
+python bench.py --config c5 $F > gpurun_out/r5b/bench_c5.json 2> gpurun_out/r5b/bench_c5.err
+for f in c1 c4_bf16 c4_f32 c5; do python - "$f" <<'PY'
+import json, sys
+d = json.loads(open(f"gpurun_out/r5b/bench_{sys.argv[1]}.json").read().strip().splitlines()[-1])
+print(sys.argv[1], d["value"], d["ms_per_step"], d["dtype"])
+PY
+done

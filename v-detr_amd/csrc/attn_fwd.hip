@@ -505,8 +505,8 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   return VDETR_OK;
 }
 
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, hipStream_t st);  // attn_fwd_pipe.hip
-size_t attn_fwd_pipe_img_bytes(int B, int nK);
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, hipStream_t st);  // attn_fwd_pipe.hip
+size_t attn_fwd_pipe_img_bytes(int B, int nK, int split);
 
 // the persistent forward (attn_fwd_pipe.hip) takes the 3DV-RPE attention as the model runs it: fp32, table edge 10, no mask
 static bool pipe_eligible(const vdetr_attn_desc* d) {
@@ -551,7 +551,7 @@ extern "C" size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d) return 0;
   const int ks = choose_ksplit(d);
   const size_t sched = pipe_eligible(d) && !d->fwd_sched ? 256 : 0;  // the item counter, where the caller brings none
-  const size_t img = pipe_split(d) ? attn_fwd_pipe_img_bytes(d->B, d->nK) + 256 : 0;
+  const size_t img = pipe_split(d) ? attn_fwd_pipe_img_bytes(d->B, d->nK, 3) + 256 : 0;  // (the bf16 forward's image is smaller: same bound)
   if (ks == 1) return sched + img;
   const size_t rows = (size_t)d->B * d->nQ * d->H;
   return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256 + sched + img;
@@ -603,7 +603,7 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
   if (pipe) {
     VDETR_REQUIRE((size_t)d->nK * P.k_stride < (1u << 30) && (size_t)d->nK * P.v_stride < (1u << 30) && (size_t)4 * d->nK < (1u << 30),
                   "attn_fwd: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
-    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, st)) return e;
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, kv_img ? 3 : 0, st)) return e;
   } else if (perhead) {
     dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
     if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
@@ -652,18 +652,42 @@ extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, cons
   P.q = (const float*)q; P.k = (const float*)k; P.v = (const float*)v; P.out = out; P.lse = lse; P.scores = scores;
   const bool rpe = d->table != nullptr;
   const int ks = choose_ksplit(d);
-  if (ks > 1) {
-    const size_t need = vdetr_attn_fwd_workspace_bytes(d);
-    if (!workspace || workspace_bytes < need) {
-      set_error("attn_fwd_bf16: workspace %zu B < required %zu B", workspace_bytes, need);
-      return VDETR_ERR_WORKSPACE;
+  const bool pipe = pipe_split(d);  // the persistent forward, bf16 operands re-laid into its images (attn_fwd_pipe.hip, SPLIT = 1)
+  const size_t need = vdetr_attn_fwd_workspace_bytes(d);
+  if (need && (!workspace || workspace_bytes < need)) {
+    set_error("attn_fwd_bf16: workspace %zu B < required %zu B", workspace_bytes, need);
+    return VDETR_ERR_WORKSPACE;
+  }
+  unsigned* sched = d->fwd_sched;
+  size_t sched_bytes = 0;
+  if (pipe && !sched) {
+    sched = (unsigned*)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+    sched_bytes = 256;
+    if (hipMemsetAsync(sched, 0, 16, (hipStream_t)stream) != hipSuccess) {
+      set_error("attn_fwd_bf16: cannot clear the item counter");
+      return VDETR_ERR_LAUNCH;
     }
+  }
+  uintptr_t ws_top = (uintptr_t)workspace + sched_bytes;
+  if (ks > 1) {
     const size_t rows = (size_t)d->B * d->nQ * d->H;
-    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    uintptr_t base = (ws_top + 255) & ~(uintptr_t)255;
     P.part_o = (float*)base;
     P.part_lse = P.part_o + (size_t)ks * rows * kDh;
     P.ksplit = ks;
     P.tiles_per_split = ((d->nK + 15) / 16 + ks - 1) / ks;
+    ws_top = base + (size_t)ks * rows * (kDh + 1) * sizeof(float);
+  }
+  if (pipe) {
+    VDETR_REQUIRE((size_t)4 * d->nK < (1u << 30), "attn_fwd_bf16: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
+    char* kv_img = (char*)((ws_top + 255) & ~(uintptr_t)255);
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, 1, (hipStream_t)stream)) return e;
+    if (ks > 1) {
+      const size_t elems = (size_t)d->B * d->nQ * d->H * kDh;
+      hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+      return check_launch("attn_fwd_combine");
+    }
+    return VDETR_OK;
   }
   const size_t lds_table = rpe ? (size_t)kRpeVerts * P.T * P.T * P.T * 16 : 0;
   const size_t lds = lds_table + (size_t)kFwdWaves * 16 * kPPad * 4 > (size_t)kFwdWaves * kWave * 24 * 4

@@ -174,14 +174,18 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 //     six terms (output 1.5e-6 off): +5 % launch time (profiles/r05_fwd_split_variants.txt) for nothing the 1e-3 contract can see.
 // K and V arrive pre-split, in operand order, from an image that a small launch packs once per call (attn_fwd_pack_kv_kernel:
 // [tile][K: 3 parts x 2 k-halves | V: 4 d-tiles][lane][16 B]).
-constexpr int kImgK = 6, kImgV = 4;                         // 16-byte pieces per lane and tile
-constexpr int kImgTileBytes = (kImgK + kImgV) * kWave * 16;  // 10,240 B per 16-key tile
+// SPLIT = 3: f32 q / k / v split as above; SPLIT = 1: q / k / v stored as bf16 (vdetr_attn_fwd_bf16, BASELINE config 4): one part each,
+// 2 + 4 matrix instructions per tile (P rounded to bf16, as the grid kernel's bf16 instantiation); SPLIT = 0: f32 matrix instructions
+constexpr int pipe_k_pieces(int split) { return split == 1 ? 2 : 6; }  // 16-byte pieces per lane and tile
+constexpr int pipe_v_pieces(int split) { return split == 1 ? 2 : 4; }
+constexpr int pipe_tile_bytes(int split) { return (pipe_k_pieces(split) + pipe_v_pieces(split)) * kWave * 16; }  // 10,240 B (4,096 B for bf16)
 
-template <bool SPLIT>
+template <int SPLIT>
 struct PipeTileT {  // operands of one 16-key tile
   f32x4 kb[SPLIT ? 1 : 4], vb[SPLIT ? 1 : 4];
-  bf16x8 k8[SPLIT ? kImgK : 1];  // [2 * part + m]: part 0 / 1 / 2 = h / m / l, k = 32 m + 8 (lane >> 4) + e
-  f32x4 v8[SPLIT ? kImgV : 1];   // [t]: (4 bf16 V_h | 4 bf16 V_l) of keys 4 (lane >> 4) + e, column d = 4 (lane & 15) + t
+  bf16x8 k8[SPLIT ? pipe_k_pieces(SPLIT) : 1];  // [2 * part + m]: part 0 / 1 / 2 = h / m / l, k = 32 m + 8 (lane >> 4) + e
+  f32x4 v8[SPLIT ? pipe_v_pieces(SPLIT) : 1];   // SPLIT 3: [t] = (4 bf16 V_h | 4 bf16 V_l) of keys 4 (lane >> 4) + e, column d = 4 (lane & 15) + t;
+                                                 // SPLIT 1: [t >> 1] = (column t even | t odd)
   float kx, ky, kz;
 };
 
@@ -205,12 +209,12 @@ struct PipeLane {  // per-item, per-lane bases (element offsets fit 32 bits: che
 // columns are masked).  Each piece is re-filled in place for the wave's NEXT tile right after its last use in the current one —
 // K behind the QK^T instructions, the coordinates behind the taps, V behind PV — so one register set serves the whole loop and
 // every load has most of a tile's time to arrive.
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ void pipe_fetch_k(const AttnParams& P, const PipeLane& A, int tile, int nK, int c, PipeTileT<SPLIT>& t) {
   if constexpr (SPLIT) {
-    const char* src = A.img + (size_t)tile * kImgTileBytes;
+    const char* src = A.img + (size_t)tile * pipe_tile_bytes(SPLIT);
 #pragma unroll
-    for (int j = 0; j < kImgK; ++j) t.k8[j] = *reinterpret_cast<const bf16x8*>(src + j * kWave * 16);
+    for (int j = 0; j < pipe_k_pieces(SPLIT); ++j) t.k8[j] = *reinterpret_cast<const bf16x8*>(src + j * kWave * 16);
   } else {
     const int kc = min((tile << 4) + c, nK - 1) - c;  // row offset of this lane's key against the item base
     const f32x4* kp = reinterpret_cast<const f32x4*>(A.kp + kc * P.k_stride);
@@ -218,18 +222,18 @@ __device__ __forceinline__ void pipe_fetch_k(const AttnParams& P, const PipeLane
     for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = kp[s4];
   }
 }
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ void pipe_fetch_x(const PipeLane& A, int tile, int nK, int c, PipeTileT<SPLIT>& t) {
   const int kc = min((tile << 4) + c, nK - 1) - c;
   const float* xp = A.xp + kc * 3;
   t.kx = xp[0]; t.ky = xp[1]; t.kz = xp[2];
 }
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ void pipe_fetch_v(const AttnParams& P, const PipeLane& A, int tile, int nK, int g, PipeTileT<SPLIT>& t) {
   if constexpr (SPLIT) {
-    const char* src = A.img + (size_t)tile * kImgTileBytes + kImgK * kWave * 16;
+    const char* src = A.img + (size_t)tile * pipe_tile_bytes(SPLIT) + pipe_k_pieces(SPLIT) * kWave * 16;
 #pragma unroll
-    for (int j = 0; j < kImgV; ++j) t.v8[j] = *reinterpret_cast<const f32x4*>(src + j * kWave * 16);
+    for (int j = 0; j < pipe_v_pieces(SPLIT); ++j) t.v8[j] = *reinterpret_cast<const f32x4*>(src + j * kWave * 16);
   } else {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -240,14 +244,14 @@ __device__ __forceinline__ void pipe_fetch_v(const AttnParams& P, const PipeLane
 }
 
 // the A operand of QK^T: fp32 (row c = query c >> 2, head c & 3; d = 16 g + s) or its three bf16 parts (d = 32 m + 8 g + e)
-template <bool SPLIT>
+template <int SPLIT>
 struct PipeQT {
   float qa[SPLIT ? 1 : 16];
-  bf16x8 q8[SPLIT ? 6 : 1];  // [2 * part + m]
+  bf16x8 q8[SPLIT ? pipe_k_pieces(SPLIT) : 1];  // [2 * part + m]
 };
 
 // one 16-key tile: scores, bias, online softmax, PV
-template <int MODE, bool TAIL, bool SPLIT>
+template <int MODE, bool TAIL, int SPLIT>
 __device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab, float* ppad, const PipeLane& A, const PipeQuery& Q,
                                           const float* __restrict__ role_vp, const PipeQT<SPLIT>& QA, PipeTileT<SPLIT>& ops, int tile, int next, int b,
                                           int qrow, int g, int c, bool swapped, f32x4 (&o)[4], float (&m)[4], float (&l)[4]) {
@@ -256,7 +260,11 @@ __device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab,
   const bool kvalid = !TAIL || key < nK;
   // ---- S = Q K^T --------------------------------------------------------------------------------------------------------
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT == 1) {  // bf16 operands: exact products; the scale goes onto the f32 scores
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QA.q8[0], ops.k8[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QA.q8[1], ops.k8[1], acc, 0, 0, 0);
+    acc *= P.scale;
+  } else if constexpr (SPLIT) {
     // smallest terms first: (q part, k part) = (l, h), (h, l), (m, m), (m, h), (h, m), (h, h)
     constexpr int kTerms[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
 #pragma unroll
@@ -326,7 +334,17 @@ __device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab,
   const f32x4 pa = *reinterpret_cast<const f32x4*>(ppad + c * kPipePad + 4 * g);
   __builtin_amdgcn_wave_barrier();
   // ---- O += P V ---------------------------------------------------------------------------------------------------------
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT == 1) {
+    const bf16x4 pb = {(__bf16)pa[0], (__bf16)pa[1], (__bf16)pa[2], (__bf16)pa[3]};  // P[row c][keys 4 g .. 4 g + 3]
+    const short4v ab = __builtin_bit_cast(short4v, pb);
+    typedef short short8v __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const short8v vv = __builtin_bit_cast(short8v, ops.v8[t >> 1]);
+      const short4v vt = (t & 1) ? short4v{vv[4], vv[5], vv[6], vv[7]} : short4v{vv[0], vv[1], vv[2], vv[3]};
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, vt, o[t], 0, 0, 0);
+    }
+  } else if constexpr (SPLIT) {
     bf16x4 ph, pl;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -353,7 +371,7 @@ __device__ __forceinline__ void pipe_tile(const AttnParams& P, const f32x4* tab,
   pipe_fetch_v<SPLIT>(P, A, next, nK, g, ops);
 }
 
-template <int MODE, bool SPLIT>
+template <int MODE, int SPLIT>
 __device__ __forceinline__ void pipe_tiles(const AttnParams& P, const f32x4* tab, float* ppad, const PipeLane& A, const PipeQuery& Q,
                                            const float* __restrict__ role_vp, const PipeQT<SPLIT>& qa, PipeTileT<SPLIT>& ops, int tile_begin,
                                            int tile_end, int w, int b, int qrow, int g, int c, bool swapped, f32x4 (&o)[4],
@@ -369,7 +387,7 @@ __device__ __forceinline__ void pipe_tiles(const AttnParams& P, const f32x4* tab
     pipe_tile<MODE, true, SPLIT>(P, tab, ppad, A, Q, role_vp, qa, ops, tile, tile, b, qrow, g, c, swapped, o, m, l);
 }
 
-template <bool ROT, bool SPLIT>
+template <bool ROT, int SPLIT>
 __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArgs K) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   AttnParams& P = K.P;
@@ -419,7 +437,11 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
     {
       const int qi = min(q0 + (c >> 2), nQ - 1);
       const float* qrowp = P.q + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh;
-      if constexpr (SPLIT) {
+      if constexpr (SPLIT == 1) {
+        const __bf16* qb = reinterpret_cast<const __bf16*>(P.q) + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh;
+        qa.q8[0] = *reinterpret_cast<const bf16x8*>(qb + 8 * g);
+        qa.q8[1] = *reinterpret_cast<const bf16x8*>(qb + 32 + 8 * g);
+      } else if constexpr (SPLIT) {
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
           const f32x4* src = reinterpret_cast<const f32x4*>(qrowp + 32 * mm + 8 * g);
@@ -467,7 +489,7 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
     A.vp = P.v + ((size_t)b * nK + 4 * g) * P.v_stride + 4 * c;
     A.xp = P.xyz + ((size_t)b * nK + c) * 3;
     A.sp = P.scores ? P.scores + (((size_t)b * nQ + min(qrow, nQ - 1)) * H) * nK + c : nullptr;
-    A.img = SPLIT ? K.kv_img + ((size_t)b * ntiles) * kImgTileBytes + lane * 16 : nullptr;
+    A.img = SPLIT ? K.kv_img + ((size_t)b * ntiles) * pipe_tile_bytes(SPLIT) + lane * 16 : nullptr;
 
     f32x4 o[4];
 #pragma unroll
@@ -542,41 +564,68 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
 }
 
 
-// K, V [B, nK, 64] fp32 (row strides as the forward's) -> the SPLIT kernels' operand images: one wave per 16-key tile.
-__global__ __launch_bounds__(kWave) void attn_fwd_pack_kv_kernel(const float* __restrict__ k, const float* __restrict__ v, int nK, int k_stride,
+// K, V [B, nK, 64] (row strides as the forward's) -> the SPLIT kernels' operand images: one wave per 16-key tile.  SPLIT 3: f32
+// inputs in three / two bf16 parts; SPLIT 1: bf16 inputs, re-laid only.
+template <int SPLIT>
+__global__ __launch_bounds__(kWave) void attn_fwd_pack_kv_kernel(const void* __restrict__ kin, const void* __restrict__ vin, int nK, int k_stride,
                                                                  int v_stride, char* __restrict__ img) {
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int tile = blockIdx.x, b = blockIdx.y, ntiles = gridDim.x;
-  char* dst = img + ((size_t)b * ntiles + tile) * kImgTileBytes + lane * 16;
+  char* dst = img + ((size_t)b * ntiles + tile) * pipe_tile_bytes(SPLIT) + lane * 16;
   const int key = tile * 16 + c;
-  const float* kr = k + ((size_t)b * nK + min(key, nK - 1)) * k_stride;
+  constexpr int kK = pipe_k_pieces(SPLIT);
+  if constexpr (SPLIT == 1) {
+    const __bf16* k = reinterpret_cast<const __bf16*>(kin);
+    const __bf16* v = reinterpret_cast<const __bf16*>(vin);
+    const __bf16* kr = k + ((size_t)b * nK + min(key, nK - 1)) * k_stride;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int mm = 0; mm < 2; ++mm) {
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g), v1 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g + 4);
-    bf16x8 h, md, lo;
+    for (int mm = 0; mm < 2; ++mm)
+      *reinterpret_cast<bf16x8*>(dst + mm * kWave * 16) = key < nK ? *reinterpret_cast<const bf16x8*>(kr + 32 * mm + 8 * g) : zero8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      __bf16 a0, a1, a2;
-      split3(key < nK ? (e < 4 ? v0[e] : v1[e - 4]) : 0.f, a0, a1, a2);
-      h[e] = a0; md[e] = a1; lo[e] = a2;
+    for (int tp = 0; tp < 2; ++tp) {
+      bf16x8 both;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = tile * 16 + 4 * g + e;
+        const __bf16* vr = v + ((size_t)b * nK + min(kk, nK - 1)) * v_stride + 4 * c + 2 * tp;
+        both[e] = kk < nK ? vr[0] : (__bf16)0.f;
+        both[4 + e] = kk < nK ? vr[1] : (__bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(dst + (kK + tp) * kWave * 16) = both;
     }
-    *reinterpret_cast<bf16x8*>(dst + (0 + mm) * kWave * 16) = h;
-    *reinterpret_cast<bf16x8*>(dst + (2 + mm) * kWave * 16) = md;
-    *reinterpret_cast<bf16x8*>(dst + (4 + mm) * kWave * 16) = lo;
-  }
+  } else {
+    const float* k = reinterpret_cast<const float*>(kin);
+    const float* v = reinterpret_cast<const float*>(vin);
+    const float* kr = k + ((size_t)b * nK + min(key, nK - 1)) * k_stride;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    bf16x4 h, lo;
+    for (int mm = 0; mm < 2; ++mm) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g), v1 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g + 4);
+      bf16x8 h, md, lo;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int kk = tile * 16 + 4 * g + e;
-      const float x = kk < nK ? v[((size_t)b * nK + kk) * v_stride + 4 * c + t] : 0.f;
-      const __bf16 hh = (__bf16)x;
-      h[e] = hh;
-      lo[e] = (__bf16)(x - (float)hh);
+      for (int e = 0; e < 8; ++e) {
+        __bf16 a0, a1, a2;
+        split3(key < nK ? (e < 4 ? v0[e] : v1[e - 4]) : 0.f, a0, a1, a2);
+        h[e] = a0; md[e] = a1; lo[e] = a2;
+      }
+      *reinterpret_cast<bf16x8*>(dst + (0 + mm) * kWave * 16) = h;
+      *reinterpret_cast<bf16x8*>(dst + (2 + mm) * kWave * 16) = md;
+      *reinterpret_cast<bf16x8*>(dst + (4 + mm) * kWave * 16) = lo;
     }
-    bf16x8 both = {h[0], h[1], h[2], h[3], lo[0], lo[1], lo[2], lo[3]};
-    *reinterpret_cast<bf16x8*>(dst + (kImgK + t) * kWave * 16) = both;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bf16x4 h, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = tile * 16 + 4 * g + e;
+        const float x = kk < nK ? v[((size_t)b * nK + kk) * v_stride + 4 * c + t] : 0.f;
+        const __bf16 hh = (__bf16)x;
+        h[e] = hh;
+        lo[e] = (__bf16)(x - (float)hh);
+      }
+      bf16x8 both = {h[0], h[1], h[2], h[3], lo[0], lo[1], lo[2], lo[3]};
+      *reinterpret_cast<bf16x8*>(dst + (kK + t) * kWave * 16) = both;
+    }
   }
 }
 
@@ -585,11 +634,12 @@ __global__ __launch_bounds__(kWave) void attn_fwd_pack_kv_kernel(const float* __
 using namespace vdetr;
 
 namespace vdetr {
-// Launch of the persistent forward (called from attn_fwd.hip:vdetr_attn_fwd_f32 with P filled, the key split chosen and the
-// partial buffers placed).  `counter`: a zero device word (workspace head, see vdetr_attn_fwd_workspace_bytes).
-size_t attn_fwd_pipe_img_bytes(int B, int nK) { return (size_t)B * ((nK + 15) / 16) * kImgTileBytes; }
+// Launch of the persistent forward (called from attn_fwd.hip with P filled, the key split chosen and the partial buffers placed).
+// `counter`: a zero device word (workspace head, see vdetr_attn_fwd_workspace_bytes).  split: 0 = f32 matrix instructions on f32
+// q / k / v (kv_img unused), 3 = split f32 operands, 1 = bf16 q / k / v (both: kv_img = attn_fwd_pipe_img_bytes of scratch).
+size_t attn_fwd_pipe_img_bytes(int B, int nK, int split) { return (size_t)B * ((nK + 15) / 16) * (split == 1 ? pipe_tile_bytes(1) : pipe_tile_bytes(3)); }
 
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, hipStream_t st) {
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, hipStream_t st) {
   PipeArgs K;
   K.P = P;
   K.counter = counter;
@@ -597,8 +647,10 @@ int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups,
   K.nitems = P.B * K.qtiles * P.ksplit;
   K.kv_img = kv_img;
   const int grid = workgroups < K.nitems ? workgroups : K.nitems;
-  if (kv_img) {
-    hipLaunchKernelGGL(attn_fwd_pack_kv_kernel, dim3((P.nK + 15) / 16, P.B), dim3(kWave), 0, st, P.k, P.v, P.nK, P.k_stride, P.v_stride, kv_img);
+  if (split) {
+    const dim3 pg((P.nK + 15) / 16, P.B);
+    if (split == 1) hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<1>, pg, dim3(kWave), 0, st, P.k, P.v, P.nK, P.k_stride, P.v_stride, kv_img);
+    else hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<3>, pg, dim3(kWave), 0, st, P.k, P.v, P.nK, P.k_stride, P.v_stride, kv_img);
     if (int e = check_launch("attn_fwd_pack_kv")) return e;
   }
 #define VDETR_PIPE_LAUNCH(ROT, SPLIT)                                                                                       \
@@ -607,9 +659,9 @@ int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups,
     hipLaunchKernelGGL((attn_fwd_rpe_pipe_kernel<ROT, SPLIT>), dim3(grid), dim3(kPipeThreads), kPipeLdsBytes, st, K);      \
   } while (0)
   if (P.cos_sin) {
-    if (kv_img) VDETR_PIPE_LAUNCH(true, true); else VDETR_PIPE_LAUNCH(true, false);
+    if (split == 1) VDETR_PIPE_LAUNCH(true, 1); else if (split) VDETR_PIPE_LAUNCH(true, 3); else VDETR_PIPE_LAUNCH(true, 0);
   } else {
-    if (kv_img) VDETR_PIPE_LAUNCH(false, true); else VDETR_PIPE_LAUNCH(false, false);
+    if (split == 1) VDETR_PIPE_LAUNCH(false, 1); else if (split) VDETR_PIPE_LAUNCH(false, 3); else VDETR_PIPE_LAUNCH(false, 0);
   }
 #undef VDETR_PIPE_LAUNCH
   return check_launch("attn_fwd_pipe");
