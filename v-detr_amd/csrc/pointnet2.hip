@@ -118,34 +118,42 @@ __global__ __launch_bounds__(kThreads) void group_points_kernel(const float* __r
 }
 
 // group_points_grad: grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k] (group_points_gpu.cu:46-67)
-// Duplicates are the norm here (ball_query pads a row with its first hit), and equal addresses inside one atomic
-// instruction serialise.  One thread walks the nsample entries of a (channel, point) row and only issues an atomic
-// when the index changes: a padded row costs 2 atomics instead of nsample.  Lanes run along the points j.
+// One WAVE per (point j, strip of 16 channels); lane k owns sample k of the row, so a channel's 64 gradients are ONE coalesced
+// 256-byte load (round 1's thread-per-row walk read them at a 256-byte lane stride: 67 MB at 0.25 TB/s, 273 us).  Duplicates are
+// the norm here — ball_query pads a row with its first hit, and equal addresses inside one atomic instruction serialise — so the
+// lanes whose index equals the row's first one (the first hit and all the padding) are summed across the wave and leave as a
+// single atomic of lane 0; every other lane adds its own value.  Correct for any index row (other duplicates meet in the atomics).
+constexpr int kGgStrip = 16;
 __global__ __launch_bounds__(kThreads) void group_points_grad_kernel(
     const float* __restrict__ grad_out, const int32_t* __restrict__ idx, float* __restrict__ grad_points,
     int c, int n, int npoints, int nsample) {
-  const int j = blockIdx.x * kThreads + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int j = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
   const int bi = blockIdx.z;
   if (j >= npoints) return;
   const int32_t* row = idx + ((size_t)bi * npoints + j) * nsample;
-  const int l0 = blockIdx.y * kChanStrip;
-  for (int dl = 0; dl < kChanStrip; ++dl) {
-    const int l = l0 + dl;
-    if (l >= c) break;
-    const float* g = grad_out + (((size_t)bi * c + l) * npoints + j) * nsample;
-    float* gp = grad_points + ((size_t)bi * c + l) * n;
-    int cur = row[0];
-    float acc = 0.f;
-    for (int k = 0; k < nsample; ++k) {
-      const int a = row[k];
-      if (a != cur) {
-        unsafeAtomicAdd(gp + cur, acc);
-        acc = 0.f;
-        cur = a;
-      }
-      acc += g[k];
+  const int a0 = row[0];
+  const int l0 = blockIdx.y * kGgStrip;
+  for (int k0 = 0; k0 < nsample; k0 += kWave) {
+    const int k = k0 + lane;
+    const bool live = k < nsample;
+    const int a = live ? row[k] : a0;
+    const bool first = a == a0;  // the first hit or padding
+    float g[kGgStrip];
+#pragma unroll
+    for (int dl = 0; dl < kGgStrip; ++dl) {
+      const int l = l0 + dl;
+      g[dl] = (live && l < c) ? grad_out[(((size_t)bi * c + l) * npoints + j) * nsample + k] : 0.f;
     }
-    unsafeAtomicAdd(gp + cur, acc);
+#pragma unroll
+    for (int dl = 0; dl < kGgStrip; ++dl) {
+      const int l = l0 + dl;
+      if (l >= c) break;
+      float* gp = grad_points + ((size_t)bi * c + l) * n;
+      const float s = wave_allsum_f32(first ? g[dl] : 0.f);
+      if (lane == 0) unsafeAtomicAdd(gp + a0, s);
+      if (live && !first) unsafeAtomicAdd(gp + a, g[dl]);
+    }
   }
 }
 
@@ -345,7 +353,7 @@ extern "C" int vdetr_group_points_grad_f32(const float* grad_out, const int32_t*
   const long ne = (long)npoints * nsample;
   if (b == 0 || c == 0 || ne == 0) return VDETR_OK;
   VDETR_REQUIRE(grad_out && idx && grad_points, "group_points_grad: null pointer");
-  dim3 grid(ceil_div(npoints, kThreads), ceil_div(c, kChanStrip), b);
+  dim3 grid(ceil_div(npoints, kThreads / kWave), ceil_div(c, kGgStrip), b);
   hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out, idx,
                      grad_points, c, n, npoints, nsample);
   return check_launch("group_points_grad");
