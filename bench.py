@@ -163,6 +163,22 @@ def allreduce_bucket_model(grad_bytes, world):
             "note": "bucket count = argmin of the modelled exposed time (allreduce_bucket_model in bench.py); VDETR_BUCKET_MB overrides"}
 
 
+def quiesce_collectives(self):
+    """Before a capture begins: nothing of the warm-up's collectives may still sit in ProcessGroupNCCL's watchdog list.
+    The watchdog thread polls the completion events of outstanding collectives every 100 ms, and an event query from
+    ANOTHER thread while this thread captures is an error under the default (global) capture mode — seen as an
+    intermittent SIGABRT of the rank ("operation not permitted when stream is capturing", 1 run in 3).  After a device
+    synchronise the warm-up's collectives are polled until each reports completion (Work.is_completed()), then ONE watchdog
+    period lets that thread drop them.  The captures below also run in thread-local error mode, which permits such calls
+    from other threads."""
+    torch.cuda.synchronize()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        deadline = time.time() + 5.0
+        while not self.reducer.collectives_done() and time.time() < deadline:
+            time.sleep(0.005)
+        time.sleep(0.12)
+
+
 class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
@@ -255,22 +271,8 @@ class Trainer:
         self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
         self.opt.step()
 
+    quiesce_collectives = quiesce_collectives  # (module-level: BackboneTrainer takes it too)
     _capture_stream = None  # one per process: a second Trainer on the same model meets the first one's AccumulateGrad nodes
-
-    def quiesce_collectives(self):
-        """Before a capture begins: nothing of the warm-up's collectives may still sit in ProcessGroupNCCL's watchdog list.
-        The watchdog thread polls the completion events of outstanding collectives every 100 ms, and an event query from
-        ANOTHER thread while this thread captures is an error under the default (global) capture mode — seen as an
-        intermittent SIGABRT of the rank ("operation not permitted when stream is capturing", 1 run in 3).  After a device
-        synchronise the warm-up's collectives are polled until each reports completion (Work.is_completed()), then ONE watchdog
-        period lets that thread drop them.  The captures below also run in thread-local error mode, which permits such calls
-        from other threads."""
-        torch.cuda.synchronize()
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            deadline = time.time() + 5.0
-            while not self.reducer.collectives_done() and time.time() < deadline:
-                time.sleep(0.005)
-            time.sleep(0.12)
 
     def capture(self):
         if Trainer._capture_stream is None:
@@ -343,6 +345,8 @@ class BackboneTrainer:
     backward of that part as ONE captured hipGraph (fixed sizes) -> backbone backward (eager) -> pack, clip, AdamW.
     What depends on the point coordinates only — voxel sites, kernel maps, compacted row lists, FPS indices — is built
     ahead of time (`geometry_ms`), as a data loader / side stream would for the next scene."""
+    quiesce_collectives = quiesce_collectives
+
 
     def __init__(self, cfg_name, device, npoints=40000, seed=0, force_dist=False, scene_seed=None):
         from vdetr_amd import pointnet2_utils as PU

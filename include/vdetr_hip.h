@@ -179,13 +179,22 @@ typedef struct vdetr_attn_desc {
                          twice the workgroups, the shape for a launch alone on the chip), 1 = one (half the workgroups, each twice
                          as long: next to a table-gradient kernel that holds most CUs, 256 one-per-CU workgroups would run four
                          rounds on the CUs left).  Same values either way up to the order of the row-tile sums. */
+  const void* kv_img; /* vdetr_attn_fwd_f32 with fwd_kernel 0: the K / V operand images of this call, packed ahead by
+                         vdetr_attn_pack_kv_f32 (one launch for the K / V of all decoder layers); NULL: the call packs its own into
+                         `workspace` (one more launch) */
   uint32_t* fwd_sched; /* persistent forward: ONE zero device word (the item counter), left zero by the call; a word must not be
                           shared by launches that may run concurrently.  NULL: the library clears a word at the head of
                           `workspace` with a memset node in front of the launch. */
 } vdetr_attn_desc;
 
-/* Scratch needed by fwd (key-split partials). */
+/* Scratch needed by fwd (key-split partials, the item counter, the operand images where the caller brings none). */
 size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d);
+/* K / V [B, nK, 64] f32 (row strides in floats) of `nlayers` attention calls, `layer_stride` floats apart (the layers' column blocks
+ * of one joint projection) -> their operand images for vdetr_attn_desc.kv_img, vdetr_attn_kv_image_bytes(B, nK) bytes each, one
+ * after the other in `img`.  Reference: the k / v projections of models/vdetr_transformer.py:735-739. */
+size_t vdetr_attn_kv_image_bytes(int B, int nK);
+int vdetr_attn_pack_kv_f32(const float* k, const float* v, int B, int nK, int k_row_stride, int v_row_stride, int nlayers,
+                           int64_t layer_stride, void* img, vdetr_stream_t stream);
 
 /* Fused forward: out = dropout(softmax(scale*q k^T + rpe + mask)) v.
  *   q      [B,nQ,H*64]

@@ -31,8 +31,8 @@ def test_library_exports_every_symbol():
 def test_descriptor_layout():
     from vdetr_amd import _lib
     # 6x4 | ptr | 3x4 + pad | 3 ptr | ptr | 2x4 | 2x8 | ptr | 2x4 | ptr | 4x4 | ptr   (ABI 3: the launch-shape fields)
-    assert ctypes.sizeof(_lib.AttnDesc) == 160
-    assert _lib.AttnDesc.table_grid.offset == 128 and _lib.AttnDesc.kv_halves.offset == 144 and _lib.AttnDesc.fwd_sched.offset == 152
+    assert ctypes.sizeof(_lib.AttnDesc) == 168
+    assert _lib.AttnDesc.table_grid.offset == 128 and _lib.AttnDesc.kv_halves.offset == 144 and _lib.AttnDesc.kv_img.offset == 152 and _lib.AttnDesc.fwd_sched.offset == 160
     assert _lib.AttnDesc.table.offset == 24 and _lib.AttnDesc.vertices.offset == 48
     assert _lib.AttnDesc.seed.offset == 88 and _lib.AttnDesc.rng_state.offset == 104
 

@@ -611,3 +611,23 @@ def test_bf16_decoder_layer_close_to_fp32():
         if k.startswith("grad_"):
             r = ref[k].cpu().numpy()
             assert_close(got[k], r, 5e-2, 3e-2 * max(np.abs(r).max(), 0.05 * gmax) + 1e-7, k)
+
+
+@pytest.mark.parametrize("B,nQ,nK,n", [(1, 64, 512, 3), (2, 37, 203, 2), (1, 1024, 4096, 8)])
+def test_kv_images_packed_ahead_equal_the_forwards_own(B, nQ, nK, n):
+    """vdetr_attn_pack_kv_f32 (the K / V operand images of n layers' forwards in one launch, from their joint projection
+    [B, nK, n * 128]) + vdetr_attn_desc.kv_img: every layer's forward returns the bits it returns when it packs its own."""
+    from vdetr_amd import attention as A
+    g = torch.Generator().manual_seed(B * 1000 + nK)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 9)
+    kv = torch.randn((B, nK, n * 128), generator=g).to(DEV)
+    q = torch.randn((B, nQ, 256), generator=g).to(DEV)
+    imgs = A.pack_kv_images(kv, n)
+    assert imgs is not None and imgs.shape[0] == n
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True, table=tables.to(DEV), rpe=A.RPEConfig(), vertices=verts.to(DEV).contiguous(),
+              xyz=xyz.to(DEV))
+    parts = kv.view(B, nK, 2 * n, 64).unbind(2)
+    for i in range(n):
+        own = A.fused_attention(q, parts[2 * i], parts[2 * i + 1], **kw)
+        ahead = A.fused_attention(q, parts[2 * i], parts[2 * i + 1], kv_img=imgs[i], **kw)
+        assert torch.equal(own, ahead), f"layer {i}"

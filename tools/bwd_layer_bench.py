@@ -114,7 +114,7 @@ def main():
 
     prep()
     res["kv_pass_us (pack + attn_bwd_kv_kernel)"] = timeit(kv)
-    res["table_from_ds_us (box2 + reduce)"] = timeit(tb, prep=prep)
+    res["table_from_ds_us (box4 + reduce)"] = timeit(tb, prep=prep)
     res["dq_gemm_us"] = timeit(dqg)
     res["delta_us"] = timeit(lambda: L.check(lib.vdetr_attn_delta_f32(ctypes.byref(d), L.ptr(dout), L.ptr(o), L.ptr(vd), L.ptr(delta), st), "delta"),
                              prep=lambda: aux.zero_())

@@ -30,7 +30,7 @@ class AttnDesc(ctypes.Structure):
         ("rng_state", c_void_p),
         ("k_row_stride", ctypes.c_int32), ("v_row_stride", ctypes.c_int32),
         ("bwd_aux", c_void_p),
-        ("table_grid", ctypes.c_int32), ("kv_waves", ctypes.c_int32), ("fwd_kernel", ctypes.c_int32), ("bwd_kernel", ctypes.c_int32), ("kv_halves", ctypes.c_int32),
+        ("table_grid", ctypes.c_int32), ("kv_waves", ctypes.c_int32), ("fwd_kernel", ctypes.c_int32), ("bwd_kernel", ctypes.c_int32), ("kv_halves", ctypes.c_int32), ("kv_img", c_void_p),
         ("fwd_sched", c_void_p),
     ]
 
@@ -236,6 +236,8 @@ _SIGNATURES = {
     "vdetr_three_interpolate_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vdetr_three_interpolate_grad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vdetr_attn_fwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
+    "vdetr_attn_kv_image_bytes": (c_size_t, [c_int, c_int]),
+    "vdetr_attn_pack_kv_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     "vdetr_attn_fwd_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_fwd_bf16": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),

@@ -525,7 +525,7 @@ def _check_inputs(**tensors):
 class _FusedAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, table, vertices, xyz, cos_sin, mask, kind, H, scale, rpe, dropout_p, rng_state,
-                need_grad, salt, table_async=False):
+                need_grad, salt, table_async=False, kv_img=None):
         B, nQ, C = q.shape
         nK = k.shape[1]
         assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
@@ -552,6 +552,8 @@ class _FusedAttention(Function):
         rows = (B, nQ, H) if kind == L.VDETR_ATTN_SHARED_KV else (B, H, nQ)
         lse = torch.empty(rows, dtype=torch.float32, device=q.device)
         scores = torch.empty(rows + (nK,), dtype=torch.float32, device=q.device) if need_grad else None
+        if kv_img is not None and not bf16 and FWD_KERNEL == 0:
+            d.kv_img = kv_img.data_ptr()  # this call's K / V operand images (pack_kv_images)
         nbytes = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
         ws = L.workspace(nbytes, q.device) if nbytes else None
         fwd = lib.vdetr_attn_fwd_bf16 if bf16 else lib.vdetr_attn_fwd_f32
@@ -656,7 +658,7 @@ class _FusedAttention(Function):
             dk, dv = dkv[0], dkv[1]
             if in_dtype == torch.bfloat16:
                 dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-            return (dq, dk, dv, dtable) + (None,) * 13
+            return (dq, dk, dv, dtable) + (None,) * 14
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)
@@ -702,7 +704,7 @@ class _FusedAttention(Function):
                 dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         if in_dtype == torch.bfloat16:
             dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-        return (dq, dk, dv, dtable) + (None,) * 13
+        return (dq, dk, dv, dtable) + (None,) * 14
 
 
 def _kv_layout(t, B, nK):
@@ -716,8 +718,9 @@ def _kv_layout(t, B, nK):
 
 
 def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
-                    cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0, table_grad_async=False):
+                    cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0, table_grad_async=False, kv_img=None):
     """out[B,nQ,H*64] = dropout(softmax(scale * q k^T + rpe + mask)) v.
+    kv_img: this call's slice of pack_kv_images() (optional: the forward packs its own otherwise).
 
     q [B,nQ,H*64]; k,v [B,nK,64] (shared_kv) or [B,nK,H*64]; table [8,T,T,T,H]; vertices [B,nQ,8,3];
     xyz [B,nK,3]; cos_sin [B,nQ,2] or None; attn_mask [B,nQ,nK] bool (-100 fill) / float (additive) or None.
@@ -741,7 +744,23 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
     k, v = _kv_layout(k, B, nK), _kv_layout(v, B, nK)
     return _FusedAttention.apply(q.contiguous(), k, v, table, vertices, xyz, cos_sin, mask,
                                  kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt),
-                                 bool(table_grad_async))
+                                 bool(table_grad_async), kv_img)
+
+
+def pack_kv_images(kv, n):
+    """kv [B, nK, n * 128] f32, the joint K | V projection of n cross-attention layers (layer i: columns 128 i .. + 63 = K,
+    + 64 .. + 127 = V) -> uint8 [n, bytes]: each layer's operand images for the persistent forward (fused_attention(kv_img=)),
+    one launch for all layers.  None where the forward would not use them."""
+    if (FWD_KERNEL != 0 or not kv.is_cuda or kv.dtype != torch.float32 or not kv.is_contiguous() or kv.shape[2] != n * 2 * HEAD_DIM
+            or kv.data_ptr() % 16):
+        return None
+    B, nK = kv.shape[0], kv.shape[1]
+    lib = L.lib()
+    nbytes = lib.vdetr_attn_kv_image_bytes(B, nK)
+    img = torch.empty((n, nbytes), dtype=torch.uint8, device=kv.device)
+    L.check(lib.vdetr_attn_pack_kv_f32(kv.data_ptr(), kv.data_ptr() + 4 * HEAD_DIM, B, nK, kv.shape[2], kv.shape[2], n, 2 * HEAD_DIM,
+                                       img.data_ptr(), L.stream_ptr()), "attn_pack_kv")
+    return img
 
 
 def attention_probabilities(q, k, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,

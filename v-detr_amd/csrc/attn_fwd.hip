@@ -505,7 +505,9 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   return VDETR_OK;
 }
 
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, hipStream_t st);  // attn_fwd_pipe.hip
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, bool packed, hipStream_t st);  // attn_fwd_pipe.hip
+int attn_fwd_pack_launch(const void* k, const void* v, int B, int nK, int k_stride, int v_stride, int nlayers, long layer_stride, char* img,
+                         int split, hipStream_t st);
 size_t attn_fwd_pipe_img_bytes(int B, int nK, int split);
 
 // the persistent forward (attn_fwd_pipe.hip) takes the 3DV-RPE attention as the model runs it: fp32, table edge 10, no mask
@@ -551,10 +553,21 @@ extern "C" size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d) {
   if (!d) return 0;
   const int ks = choose_ksplit(d);
   const size_t sched = pipe_eligible(d) && !d->fwd_sched ? 256 : 0;  // the item counter, where the caller brings none
-  const size_t img = pipe_split(d) ? attn_fwd_pipe_img_bytes(d->B, d->nK, 3) + 256 : 0;  // (the bf16 forward's image is smaller: same bound)
+  const size_t img = pipe_split(d) && !d->kv_img ? attn_fwd_pipe_img_bytes(d->B, d->nK, 3) + 256 : 0;  // (the bf16 forward's image is smaller: same bound)
   if (ks == 1) return sched + img;
   const size_t rows = (size_t)d->B * d->nQ * d->H;
   return (size_t)ks * rows * (kDh + 1) * sizeof(float) + 256 + sched + img;
+}
+
+extern "C" size_t vdetr_attn_kv_image_bytes(int B, int nK) { return B > 0 && nK > 0 ? attn_fwd_pipe_img_bytes(B, nK, 3) : 0; }
+
+extern "C" int vdetr_attn_pack_kv_f32(const float* k, const float* v, int B, int nK, int k_row_stride, int v_row_stride, int nlayers,
+                                      int64_t layer_stride, void* img, vdetr_stream_t stream) {
+  VDETR_REQUIRE(k && v && img, "attn_pack_kv: null pointer");
+  VDETR_REQUIRE(B > 0 && nK > 0 && nlayers > 0 && nlayers <= 65535 && B <= 65535, "attn_pack_kv: B=%d nK=%d nlayers=%d", B, nK, nlayers);
+  VDETR_REQUIRE(k_row_stride >= kDh && v_row_stride >= kDh && k_row_stride % 4 == 0 && v_row_stride % 4 == 0 && layer_stride % 4 == 0 &&
+                (((uintptr_t)k | (uintptr_t)v | (uintptr_t)img) & 15) == 0, "attn_pack_kv: rows of >= 64 floats, strides multiples of 4, 16-B aligned");
+  return attn_fwd_pack_launch(k, v, B, nK, k_row_stride, v_row_stride, nlayers, (long)layer_stride, (char*)img, 3, (hipStream_t)stream);
 }
 
 extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
@@ -594,7 +607,8 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
     P.tiles_per_split = (ntiles + ks - 1) / ks;
     ws_top = base + (size_t)ks * rows * (kDh + 1) * sizeof(float);
   }
-  char* kv_img = pipe_split(d) ? (char*)((ws_top + 255) & ~(uintptr_t)255) : nullptr;
+  char* kv_img = pipe_split(d) ? (d->kv_img ? (char*)d->kv_img : (char*)((ws_top + 255) & ~(uintptr_t)255)) : nullptr;
+  VDETR_REQUIRE(!d->kv_img || (((uintptr_t)d->kv_img) & 15) == 0, "attn_fwd: kv_img must be 16-B aligned");
   const size_t lds_table = rpe ? (size_t)kRpeVerts * P.T * P.T * P.T * 16 : 0;
   const size_t lds = lds_table + (size_t)kFwdWaves * 16 * kPPad * 4 > (size_t)kFwdWaves * kWave * 24 * 4
                          ? lds_table + (size_t)kFwdWaves * 16 * kPPad * 4
@@ -603,7 +617,7 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
   if (pipe) {
     VDETR_REQUIRE((size_t)d->nK * P.k_stride < (1u << 30) && (size_t)d->nK * P.v_stride < (1u << 30) && (size_t)4 * d->nK < (1u << 30),
                   "attn_fwd: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
-    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, kv_img ? 3 : 0, st)) return e;
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, kv_img ? 3 : 0, d->kv_img != nullptr, st)) return e;
   } else if (perhead) {
     dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
     if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
@@ -681,7 +695,7 @@ extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, cons
   if (pipe) {
     VDETR_REQUIRE((size_t)4 * d->nK < (1u << 30), "attn_fwd_bf16: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
     char* kv_img = (char*)((ws_top + 255) & ~(uintptr_t)255);
-    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, 1, (hipStream_t)stream)) return e;
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, 1, false, (hipStream_t)stream)) return e;
     if (ks > 1) {
       const size_t elems = (size_t)d->B * d->nQ * d->H * kDh;
       hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);

@@ -566,11 +566,19 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
 
 // K, V [B, nK, 64] (row strides as the forward's) -> the SPLIT kernels' operand images: one wave per 16-key tile.  SPLIT 3: f32
 // inputs in three / two bf16 parts; SPLIT 1: bf16 inputs, re-laid only.
+// blockIdx.z = layer: the decoder layers' K / V are column blocks of ONE joint projection, `layer_stride` elements apart, and their
+// images follow each other (vdetr_attn_pack_kv_f32: one launch for all layers instead of one in front of every forward).
 template <int SPLIT>
 __global__ __launch_bounds__(kWave) void attn_fwd_pack_kv_kernel(const void* __restrict__ kin, const void* __restrict__ vin, int nK, int k_stride,
-                                                                 int v_stride, char* __restrict__ img) {
+                                                                 int v_stride, char* __restrict__ img, long layer_stride, int nB) {
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int tile = blockIdx.x, b = blockIdx.y, ntiles = gridDim.x;
+  {
+    const size_t esz = SPLIT == 1 ? 2 : 4;
+    kin = reinterpret_cast<const char*>(kin) + (size_t)blockIdx.z * layer_stride * esz;
+    vin = reinterpret_cast<const char*>(vin) + (size_t)blockIdx.z * layer_stride * esz;
+    img += (size_t)blockIdx.z * nB * ntiles * pipe_tile_bytes(SPLIT);
+  }
   char* dst = img + ((size_t)b * ntiles + tile) * pipe_tile_bytes(SPLIT) + lane * 16;
   const int key = tile * 16 + c;
   constexpr int kK = pipe_k_pieces(SPLIT);
@@ -639,7 +647,16 @@ namespace vdetr {
 // q / k / v (kv_img unused), 3 = split f32 operands, 1 = bf16 q / k / v (both: kv_img = attn_fwd_pipe_img_bytes of scratch).
 size_t attn_fwd_pipe_img_bytes(int B, int nK, int split) { return (size_t)B * ((nK + 15) / 16) * (split == 1 ? pipe_tile_bytes(1) : pipe_tile_bytes(3)); }
 
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, hipStream_t st) {
+int attn_fwd_pack_launch(const void* k, const void* v, int B, int nK, int k_stride, int v_stride, int nlayers, long layer_stride, char* img,
+                         int split, hipStream_t st) {
+  const dim3 pg((nK + 15) / 16, B, nlayers);
+  if (split == 1) hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<1>, pg, dim3(kWave), 0, st, k, v, nK, k_stride, v_stride, img, layer_stride, B);
+  else hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<3>, pg, dim3(kWave), 0, st, k, v, nK, k_stride, v_stride, img, layer_stride, B);
+  return check_launch("attn_fwd_pack_kv");
+}
+
+// packed: kv_img already holds the images (vdetr_attn_desc.kv_img)
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, bool packed, hipStream_t st) {
   PipeArgs K;
   K.P = P;
   K.counter = counter;
@@ -647,11 +664,8 @@ int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups,
   K.nitems = P.B * K.qtiles * P.ksplit;
   K.kv_img = kv_img;
   const int grid = workgroups < K.nitems ? workgroups : K.nitems;
-  if (split) {
-    const dim3 pg((P.nK + 15) / 16, P.B);
-    if (split == 1) hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<1>, pg, dim3(kWave), 0, st, P.k, P.v, P.nK, P.k_stride, P.v_stride, kv_img);
-    else hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<3>, pg, dim3(kWave), 0, st, P.k, P.v, P.nK, P.k_stride, P.v_stride, kv_img);
-    if (int e = check_launch("attn_fwd_pack_kv")) return e;
+  if (split && !packed) {
+    if (int e = attn_fwd_pack_launch(P.k, P.v, P.B, P.nK, P.k_stride, P.v_stride, 1, 0, kv_img, split, st)) return e;
   }
 #define VDETR_PIPE_LAUNCH(ROT, SPLIT)                                                                                       \
   do {                                                                                                                      \

@@ -216,8 +216,11 @@ class GlobalShareCrossAttention(nn.Module):
         w = cat_params([t for m in mods for t in (m.k.weight, m.v.weight)])
         b = cat_params([t for m in mods for t in (m.k.bias, m.v.bias)]) if mods[0].k.bias is not None else None
         kv = linear(key_b, w, b)                                                   # [B,nK,n*128]
+        imgs = None
         if mods[0].core_dtype != torch.float32 and kv.is_cuda:
             kv = kv.to(mods[0].core_dtype)  # one cast for the K / V of every layer
+        elif kv.is_cuda and mods[0].rpe_cfg.table_size == 10:
+            imgs = A.pack_kv_images(kv.detach(), n)  # the forward kernels' K / V operand images of all layers: one launch
         parts = kv.view(kv.shape[0], kv.shape[1], 2 * n, -1).unbind(2)
         mlps = [mm for m in mods for mm in m.cpb_mlps]
         w1 = stack_params([mm[0].weight for mm in mlps])
@@ -236,7 +239,7 @@ class GlobalShareCrossAttention(nn.Module):
         else:
             hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
             tables = A.park_table_grads(torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H))
-        return [(parts[2 * i], parts[2 * i + 1], tables[i]) for i in range(n)]
+        return [(parts[2 * i], parts[2 * i + 1], tables[i], imgs[i] if imgs is not None else None) for i in range(n)]
 
     def core(self, q, key, reference_point, reference_angle, xyz, attn_mask=None, cache=None):
         """The attention between the query projection and the output projection (:733-753): q [B,nQ,C] projected queries ->
@@ -263,7 +266,8 @@ class GlobalShareCrossAttention(nn.Module):
         x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, table=tables,
                               rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
                               attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt,
-                              table_grad_async=cache is not None)
+                              table_grad_async=cache is not None,
+                              **({"kv_img": cache[3]} if (cache is not None and len(cache) > 3 and cache[3] is not None) else {}))
         attn = None
         if self.return_attn:
             attn = A.attention_probabilities(q32.float(), k32.float(), num_heads=self.num_heads, scale=self.scale, shared_kv=True,
