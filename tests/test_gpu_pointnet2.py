@@ -248,3 +248,30 @@ def test_gather_rows_and_grad(c):
         torch.testing.assert_close(r.grad, ref, rtol=1e-5, atol=1e-6)
     ref_np = O.gather_rows([r.detach().cpu().numpy() for r in rows], idx.cpu().numpy())
     assert np.array_equal(out.detach().cpu().numpy(), ref_np)
+
+
+@pytest.mark.parametrize("b,c,m,n", [(1, 256, 1024, 2048), (2, 37, 700, 1500), (1, 16, 1024, 1024)])
+def test_three_interpolate_through_lds(b, c, m, n):
+    """known-point sets whose channel rows fit in LDS take the staged kernel (pointnet2.hip: three_interpolate_lds_kernel): bit-equal to
+    the oracle (same contraction order), full and partial channel strips, n not a multiple of the workgroup"""
+    from oracle import pointnet2_oracle as O
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(b * 100 + c)
+    pts = rng.normal(size=(b, c, m)).astype(np.float32)
+    iidx = rng.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.random(size=(b, n, 3)).astype(np.float32)
+    out = PU.three_interpolate(torch.from_numpy(pts).cuda(), torch.from_numpy(iidx).cuda(), torch.from_numpy(w).cuda())
+    assert np.array_equal(out.cpu().numpy(), O.three_interpolate(pts, iidx, w))
+
+
+@pytest.mark.parametrize("b,c,n,m", [(1, 256, 39642, 4096), (2, 70, 2503, 300), (1, 64, 20481, 1024), (3, 33, 1000, 1000)])
+def test_gather_points_through_lds(b, c, n, m):
+    """rows streamed through LDS in 80 KB chunks (pointnet2.hip: gather_points_lds_kernel): bit-equal to the oracle, rows that are
+    not 16-byte aligned (odd n), one / two / three chunks, duplicates in idx"""
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(n)
+    pts = rng.normal(size=(b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    idx[:, :3] = np.array([0, n - 1, n - 1])
+    out = PU._ext.gather_points(torch.from_numpy(pts).cuda(), torch.from_numpy(idx).cuda())
+    assert np.array_equal(out.cpu().numpy(), O.gather_points(pts, idx))

@@ -34,6 +34,37 @@ __global__ __launch_bounds__(kThreads) void gather_points_kernel(const float* __
   }
 }
 
+// The same with the channel row streamed through LDS: one workgroup per (channel, batch element) reads its row of n floats ONCE,
+// coalesced, in chunks of 80 KB (one workgroup each), and serves the m sampled positions that fall into the chunk out of LDS.  The form above reads one
+// 128-byte line per sampled element: 134 MB of lines for 4 MB of values at c = 256, n = 40k, m = 4096 (17.6 us); the rows themselves
+// are 41 MB.  Worth it when the samples are a fair share of the row (m >= n / 32) and there are workgroups enough to fill the chip.
+constexpr int kGpThreads = 512;
+constexpr int kGpChunk = 20480;  // floats per LDS chunk (80 KB: two workgroups per CU)
+__global__ __launch_bounds__(kGpThreads) void gather_points_lds_kernel(const float* __restrict__ points, const int32_t* __restrict__ idx,
+                                                                       float* __restrict__ out, int c, int n, int m) {
+  extern __shared__ __attribute__((aligned(16))) float chunk[];
+  const int l = blockIdx.x, bi = blockIdx.z;
+  const float* row = points + ((size_t)bi * c + l) * n;
+  const int32_t* ix = idx + (size_t)bi * m;
+  float* orow = out + ((size_t)bi * c + l) * m;
+  const bool vec = ((((uintptr_t)row) & 15) == 0);
+  const int off = blockIdx.y * kGpChunk;  // one workgroup per chunk of the row: two of them share a CU, one stages while the other serves
+  const int len = min(kGpChunk, n - off);
+  if (vec) {
+    const float4* s4 = reinterpret_cast<const float4*>(row + off);
+    float4* c4 = reinterpret_cast<float4*>(chunk);
+    for (int e = threadIdx.x; e < (len >> 2); e += kGpThreads) c4[e] = s4[e];
+    for (int e = (len & ~3) + threadIdx.x; e < len; e += kGpThreads) chunk[e] = row[off + e];
+  } else {
+    for (int e = threadIdx.x; e < len; e += kGpThreads) chunk[e] = row[off + e];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < m; j += kGpThreads) {
+    const int a = ix[j] - off;
+    if (a >= 0 && a < len) orow[j] = chunk[a];
+  }
+}
+
 // gather_points_grad: grad_points[b,c,idx[b,j]] += grad_out[b,c,j]       (sampling_gpu.cu:37-50)
 __global__ __launch_bounds__(kThreads) void gather_points_grad_kernel(
     const float* __restrict__ grad_out, const int32_t* __restrict__ idx, float* __restrict__ grad_points,
@@ -184,6 +215,41 @@ __global__ __launch_bounds__(kThreads) void three_interpolate_kernel(
   }
 }
 
+// The same through LDS, for known-point sets whose channel rows fit: a workgroup stages kTiStrip channel rows of `points` (m floats
+// each, read coalesced ONCE) and every thread then interpolates its point j in all of them out of LDS.  The global form above reads
+// 4 bytes per (channel, neighbour) at a stride of m floats (one 128-B line per element: 14 us at c = 256, n = 2048, m = 1024 for
+// 3 MB of tensors).  Same contraction order.
+constexpr int kTiStrip = 16;
+__global__ __launch_bounds__(kThreads) void three_interpolate_lds_kernel(
+    const float* __restrict__ points, const int32_t* __restrict__ idx, const float* __restrict__ weight,
+    float* __restrict__ out, int c, int m, int n) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [kTiStrip][m]
+  const int bi = blockIdx.z, l0 = blockIdx.y * kTiStrip;
+  const int nl = min(kTiStrip, c - l0);
+  const float* src = points + ((size_t)bi * c + l0) * m;  // the strip's rows are contiguous
+  if ((((uintptr_t)src) & 15) == 0 && ((nl * m) & 3) == 0) {  // 16 bytes per lane: a strip is 64 KB
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* r4 = reinterpret_cast<float4*>(rows);
+    for (int e = threadIdx.x; e < (nl * m) >> 2; e += kThreads) r4[e] = s4[e];
+  } else {
+    for (int e = threadIdx.x; e < nl * m; e += kThreads) rows[e] = src[e];
+  }
+  __syncthreads();
+  for (int j = blockIdx.x * kThreads + threadIdx.x; j < n; j += gridDim.x * kThreads) {
+    const size_t r = ((size_t)bi * n + j) * 3;
+    const int i1 = idx[r], i2 = idx[r + 1], i3 = idx[r + 2];
+    const float w1 = weight[r], w2 = weight[r + 1], w3 = weight[r + 2];
+#pragma unroll 4
+    for (int dl = 0; dl < nl; ++dl) {
+      const float* p = rows + dl * m;
+      float t = __fmul_rn(p[i2], w2);
+      t = __fmaf_rn(p[i1], w1, t);
+      t = __fmaf_rn(p[i3], w3, t);
+      out[((size_t)bi * c + l0 + dl) * n + j] = t;
+    }
+  }
+}
+
 // three_interpolate_grad: grad_points[b,c,i_t] += grad_out[b,c,j]*w_t (interpolate_gpu.cu:119-146)
 __global__ __launch_bounds__(kThreads) void three_interpolate_grad_kernel(
     const float* __restrict__ grad_out, const int32_t* __restrict__ idx, const float* __restrict__ weight,
@@ -315,6 +381,12 @@ extern "C" int vdetr_gather_points_f32(const float* points, const int32_t* idx, 
   if (int e = check_bcnm("gather_points", b, c, n, m)) return e;
   if (b == 0 || c == 0 || m == 0) return VDETR_OK;
   VDETR_REQUIRE(points && idx && out, "gather_points: null pointer");
+  if ((long)m * 32 >= n && (long)c * b >= 64 && b <= 65535) {  // the rows through LDS (see the kernel)
+    const size_t lds = (size_t)(n < kGpChunk ? n : kGpChunk) * sizeof(float);
+    if (int e = set_lds(gather_points_lds_kernel, lds, "gather_points")) return e;
+    hipLaunchKernelGGL(gather_points_lds_kernel, dim3(c, ceil_div(n, kGpChunk), b), dim3(kGpThreads), lds, (hipStream_t)stream, points, idx, out, c, n, m);
+    return check_launch("gather_points");
+  }
   dim3 grid(ceil_div(m, kThreads), ceil_div(c, kChanStrip), b);
   hipLaunchKernelGGL(gather_points_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, points, idx, out,
                      c, n, m);
@@ -375,6 +447,14 @@ extern "C" int vdetr_three_interpolate_f32(const float* points, const int32_t* i
   if (int e = check_bcnm("three_interpolate", b, c, n, m)) return e;
   if (b == 0 || c == 0 || n == 0) return VDETR_OK;
   VDETR_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
+  const size_t lds = (size_t)kTiStrip * m * sizeof(float);
+  if (lds <= 64 * 1024 && n >= 4 * kThreads) {  // the rows of a strip fit in LDS and there are points enough to pay for staging them
+    const int jblocks = ceil_div(n, kThreads) < 8 ? ceil_div(n, kThreads) : 8;  // (each workgroup stages 64 KB: few, fat workgroups per strip)
+    dim3 grid(jblocks, ceil_div(c, kTiStrip), b);
+    if (int e = set_lds(three_interpolate_lds_kernel, lds, "three_interpolate")) return e;
+    hipLaunchKernelGGL(three_interpolate_lds_kernel, grid, dim3(kThreads), lds, (hipStream_t)stream, points, idx, weight, out, c, m, n);
+    return check_launch("three_interpolate");
+  }
   dim3 grid(ceil_div(n, kThreads), ceil_div(c, kChanStrip), b);
   hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, points, idx,
                      weight, out, c, m, n);
