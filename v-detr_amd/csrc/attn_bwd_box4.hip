@@ -125,7 +125,10 @@ void attn_bwd_box4_kernel(AttnParams P) {
   const bool rot = P.cos_sin != nullptr;
   const int nchunks = (P.nK + kWave - 1) / kWave;
   struct Ops { float d[4], kx, ky, kz; };
-  auto fetch = [&](rsrc_t rd, rsrc_t rx, int chunk, Ops& o) {  // dS of the 4 heads + the key's position (out-of-range keys read 0)
+  // dS of the 4 heads + the key's position.  Of a key past nK only the POSITION reads 0 (its resource ends with the keys); the dS
+  // resource spans the 4 head rows, so d[h] of such a lane holds the next head's row for h < 3: lanes past the end never write a
+  // record or bump a counter below, and nothing may use their d[]
+  auto fetch = [&](rsrc_t rd, rsrc_t rx, int chunk, Ops& o) {
     const int key = chunk * kWave + lane;
 #pragma unroll
     for (int h = 0; h < 4; ++h)
