@@ -667,7 +667,11 @@ def kernel_rooflines(cfg_name, device, reps=20):
     fwd_obj = {"kernel": "attn_fwd_kernel<shared_kv,rpe> (3DV-RPE cross-attention forward)", "bound": "mfma",  # (name completed below)
                "achieved": flops / t_fwd / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                "frac": flops / t_fwd / 1e12 / 157.3, "traffic": None, "launch_us": t_fwd * 1e6,
-               "rpe_lookups_per_s": 8.0 * pairs / t_fwd}
+               "rpe_lookups_per_s": 8.0 * pairs / t_fwd,
+               "note": "algorithmic QK^T + PV flops over the launch time (incl. the K/V operand pack and the key-split combine launches) against "
+                       "the dense f32 matrix peak: the contract is f32 arithmetic.  The default kernel forms the products on the bf16 matrix "
+                       "unit from split f32 operands (18 instructions per 16-key tile instead of 32 f32 ones); most of the launch is the "
+                       "RPE look-up (VALU + LDS), see DESIGN.md 4.1"}
     kv_obj = {"kernel": "attn_bwd_kv_kernel (dO V^T, softmax backward, dV, dK in one pass over the scores; + its operand-packing launch)",
               "bound": "hbm", "achieved": bytes_kv / t_kv / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": bytes_kv / t_kv / 1e9 / 8000.0,
               "traffic": None, "launch_us": t_kv * 1e6}
