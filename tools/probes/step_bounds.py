@@ -18,6 +18,9 @@ if mode.startswith("grid="):
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 import vdetr_amd.attention as A  # noqa: E402
+if os.environ.get("VDETR_PROBE_LIB"):  # a variant build of the library (experiments)
+    import vdetr_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["VDETR_PROBE_LIB"])
 
 if mode == "notable":
     A._launch_table_async = lambda lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable: dtable
