@@ -286,7 +286,7 @@ def test_sorted_box_backward_kernel_shapes(monkeypatch, B, nQ, nK):
     assert torch.equal(got, again), "not reproducible"
 
 
-@pytest.mark.parametrize("grid,tol", [(192, 3e-4), (64, 3e-4), (16, 1e-3)])
+@pytest.mark.parametrize("grid,tol", [(192, 3e-4), (190, 3e-4), (64, 3e-4), (16, 1e-3)])
 def test_table_gradient_on_fewer_workgroups(monkeypatch, grid, tol):
     """vdetr_attn_desc.table_grid: the table-gradient launches on fewer (persistent) workgroups than CUs — what a caller
     does who runs them on a side stream next to the main chain — give the default grid's gradient to the rounding of the

@@ -24,7 +24,7 @@ if os.environ.get("VDETR_PROBE_LIB"):  # a variant build of the library (experim
 
 if mode == "notable":
     A._launch_table_async = lambda lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable: dtable
-sys.argv = ["bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-criterion-leg", "--no-backbone-leg"] + sys.argv[2:]
+sys.argv = ["bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-criterion-leg", "--no-backbone-leg"] + sys.argv[2:]  # (e.g. --config c5)
 import io
 import contextlib
 buf = io.StringIO()

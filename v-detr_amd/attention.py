@@ -83,12 +83,16 @@ _DQ_KERNEL_SHARED = os.environ.get("VDETR_BWD_DQ", "0") == "2"
 _ASYNC_ENV = os.environ.get("VDETR_BWD_ASYNC_TABLE", "auto")
 ASYNC_TABLE_GRAD = _ASYNC_ENV != "0"
 ASYNC_MIN_PAIRS = 1 << 21
-# workgroups (= CUs) of the table kernel when it runs on the side stream: the remaining CUs are the main chain's
-ASYNC_TABLE_GRID = int(os.environ.get("VDETR_BWD_ASYNC_GRID", "192"))
+# workgroups (= CUs) of the table kernel when it runs on the side stream: the remaining CUs are the main chain's.  Round 5: 190,
+# not 192 — the row-block launches of the backward chain (csrc/rowblock.hip) are 64 workgroups for 1024 queries, and the next
+# scene's sampling kernel holds one CU for the first ~4.7 ms of a step: on 64 - 1 CUs every such launch took two rounds.
+# Step 7.31 ms at 192, 7.01 at 190, 7.06 at 188, 7.09 at 184, 7.26 at 176 (profiles/r05_step_bounds.txt).
+ASYNC_TABLE_GRID = int(os.environ.get("VDETR_BWD_ASYNC_GRID", "190"))
 _ASYNC_KV4 = os.environ.get("VDETR_BWD_ASYNC_KV_WAVES", "8") == "4"
-# 1: the per-head pass only (step 7.36 -> 7.33 ms); 2: the shared-K/V pass as well (measured: 7.41 ms, it is bandwidth bound and
-# wants the workgroups); 0: never
-KV_ONE_WG = int(os.environ.get("VDETR_BWD_KV_ONE_WG", "1"))
+# vdetr_attn_desc.kv_halves = 1 (one workgroup per key tile) while a table kernel is live — 1: the per-head pass only; 2: the
+# shared-K/V pass as well; 0 (default): never.  With the side grid at 192 the per-head form won 0.03 ms (7.36 -> 7.33; the
+# shared-K/V form lost: 7.41); at 190 the default shape is as fast or faster (7.01 / 7.03-7.05 / 7.18 for 0 / 1 / 2).
+KV_ONE_WG = int(os.environ.get("VDETR_BWD_KV_ONE_WG", "0"))
 
 
 _step_side = {}  # device key -> this step's forward ran a cross-attention whose table gradient will go to the side stream
