@@ -463,6 +463,8 @@ typedef struct vdetr_rb_qkv_grads {
   const float *dq, *dk, *dv;           /* [B,nQ,256] gradients of the three outputs */
   float *dq_rows, *dk_rows, *dv_rows;  /* [rows,256] the same in sequence-first row order (weight-gradient operands), or NULL */
   float* d_x;                          /* [rows,256] gradient of t + pos (= gradient of pos), or NULL */
+  const float* d_x_add;                /* [rows,256] or NULL: added into d_x only (a gradient that reached pos through another consumer:
+                                          one launch less than summing the two afterwards) */
   float* d_t;                          /* [rows,256] gradient of t */
 } vdetr_rb_qkv_grads;
 int vdetr_rb_qkv_bwd_f32(const vdetr_rb_qkv_desc* d, const vdetr_rb_qkv_grads* g, vdetr_stream_t stream);

@@ -130,7 +130,7 @@ class RbFfnDesc(ctypes.Structure):
 class RbQkvGrads(ctypes.Structure):
     """Mirror of ``vdetr_rb_qkv_grads``."""
 
-    _fields_ = [(n, c_void_p) for n in ("dq", "dk", "dv", "dq_rows", "dk_rows", "dv_rows", "d_x", "d_t")]
+    _fields_ = [(n, c_void_p) for n in ("dq", "dk", "dv", "dq_rows", "dk_rows", "dv_rows", "d_x", "d_x_add", "d_t")]
 
 
 class RbProjQGrads(ctypes.Structure):

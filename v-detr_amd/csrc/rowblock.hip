@@ -684,10 +684,12 @@ __global__ __launch_bounds__(kRbThreads) void rb_qkv_bwd_kernel(vdetr_rb_qkv_des
     rb_load_a(xs, lane, a);
     rb_w_run(a, A.w + (size_t)which * kRbC * kRbC, col0, lane, R, acc);
     if (which < 2) rb_w_begin(A.w + (size_t)(which + 1) * kRbC * kRbC, col0, lane, R);
-    if (which == 1 && G.d_x) {
+    if (which == 1 && G.d_x) {  // the gradient of pos: + what reached pos through its other consumer (d_x_add; not part of d t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (row0 + 4 * g + r < A.rows) rb_st4(G.d_x, row0 + 4 * g + r, colq, rb_row(acc, r));
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * g + r;
+        if (row < A.rows) rb_st4(G.d_x, row, colq, G.d_x_add ? rb_row(acc, r) + rb_ld4(G.d_x_add, row, colq) : rb_row(acc, r));
+      }
     }
   }
 #pragma unroll
@@ -759,7 +761,8 @@ extern "C" int vdetr_rb_qkv_bwd_f32(const vdetr_rb_qkv_desc* d, const vdetr_rb_q
   if (int e = rb_common(d->rows, d->B, "rb_qkv_bwd")) return e;
   VDETR_REQUIRE(d->w && g->dq && g->dk && g->dv && g->d_t, "rb_qkv_bwd: null pointer");
   VDETR_REQUIRE(RB_ALIGNED(d->w) && RB_ALIGNED(g->dq) && RB_ALIGNED(g->dk) && RB_ALIGNED(g->dv) && RB_ALIGNED(g->dq_rows) && RB_ALIGNED(g->dk_rows) &&
-                RB_ALIGNED(g->dv_rows) && RB_ALIGNED(g->d_x) && RB_ALIGNED(g->d_t), "rb_qkv_bwd: operands must be 16-B aligned");
+                RB_ALIGNED(g->dv_rows) && RB_ALIGNED(g->d_x) && RB_ALIGNED(g->d_x_add) && RB_ALIGNED(g->d_t), "rb_qkv_bwd: operands must be 16-B aligned");
+  VDETR_REQUIRE(!g->d_x_add || g->d_x, "rb_qkv_bwd: d_x_add without d_x");
   hipLaunchKernelGGL(rb_qkv_bwd_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g);
   return check_launch("rb_qkv_bwd");
 }

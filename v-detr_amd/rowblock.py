@@ -169,16 +169,26 @@ class _Qkv(torch.autograd.Function):
         L.check(L.lib().vdetr_rb_qkv_f32(ctypes.byref(d), L.stream_ptr()), "rb_qkv")
         ctx.B, ctx.shape = B, t.shape
         ctx.save_for_backward(t, x, wq, wk, wv, bq, bk, bv)
-        return out[0], out[1], out[2]
+        ctx.set_materialize_grads(False)
+        # The fourth output is `pos` again: the layer hands THIS tensor to the position's second consumer (proj_q), whose gradient
+        # then arrives here as d_alias and is added to the q / k share inside the backward launch — autograd would otherwise sum the
+        # two [rows, 256] gradients with a launch of its own per layer.
+        alias = pos.view_as(pos) if pos is not None else None
+        if alias is not None and not pos.requires_grad:
+            ctx.mark_non_differentiable(alias)
+        return out[0], out[1], out[2], alias
 
     @staticmethod
-    def backward(ctx, dq, dk, dv):
+    def backward(ctx, dq, dk, dv, d_alias=None):
         t, x, wq, wk, wv, bq, bk, bv = ctx.saved_tensors
         B = ctx.B
         t2 = t.reshape(-1, C)
         x2 = x if x is not None else t2
         need = ctx.needs_input_grad
-        if FUSED_BWD and dq is not None and dk is not None and dv is not None:
+        if dq is None and dk is None and dv is None:
+            return (None, d_alias if need[1] else None) + (None,) * 8
+        dq, dk, dv = (g if g is not None else torch.zeros((B, t2.shape[0] // B, C), dtype=torch.float32, device=t.device) for g in (dq, dk, dv))
+        if FUSED_BWD:
             rows = t2.shape[0]
             dq, dk, dv = _opt(dq), _opt(dk), _opt(dv)
             d_t = torch.empty_like(t2)
@@ -195,6 +205,9 @@ class _Qkv(torch.autograd.Function):
             if B > 1:
                 g.dq_rows, g.dk_rows, g.dv_rows = dq2.data_ptr(), dk2.data_ptr(), dv2.data_ptr()
             g.d_x = d_x.data_ptr() if d_x is not None else None
+            if d_alias is not None and d_x is not None:
+                d_alias = _opt(d_alias)
+                g.d_x_add = d_alias.data_ptr()
             g.d_t = d_t.data_ptr()
             L.check(L.lib().vdetr_rb_qkv_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_qkv_bwd")
             gr = [None] * 6
@@ -207,10 +220,10 @@ class _Qkv(torch.autograd.Function):
         if need[0] or need[1]:
             d_x = torch.mm(dq2, wq)
             d_x.addmm_(dk2, wk)                      # gradient of t + pos
-            if need[1]:
-                d_pos = d_x.view(ctx.shape)
             if need[0]:
                 d_t = torch.addmm(d_x, dv2, wv).view(ctx.shape)
+            if need[1]:
+                d_pos = (d_x if d_alias is None else d_x + d_alias.reshape(d_x.shape)).view(ctx.shape)
         g = [None] * 6
         for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
             g[i], g[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
@@ -428,11 +441,13 @@ def usable(layer, tgt, query_pos, masks):
 
 
 def qkv(t, pos, sa, B, img):
-    """the self-attention's projected operands, batch-first [B, nQ, 256] each; img: the layer's images (images())"""
+    """the self-attention's projected operands, batch-first [B, nQ, 256] each, and `pos` again — hand THAT tensor to proj_q so that
+    the position's gradient is summed inside qkv's backward launch; img: the layer's images (images())"""
     E = sa.embed_dim
     wq, wk, wv = sa.in_proj_weight.view(3, E, E).unbind(0)
     bq, bk, bv = sa.in_proj_bias.view(3, E).unbind(0)
-    return _Qkv.apply(t.contiguous(), pos.contiguous() if pos is not None else None, wq, wk, wv, bq, bk, bv, B, img[0:3])
+    q, k, v, pos_alias = _Qkv.apply(t.contiguous(), pos.contiguous() if pos is not None else None, wq, wk, wv, bq, bk, bv, B, img[0:3])
+    return q, k, v, pos_alias
 
 
 def proj_q(a, tgt, pos, out_proj, q_lin, drop, ln, salt, B, img):

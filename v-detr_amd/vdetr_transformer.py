@@ -465,11 +465,11 @@ class GlobalDecoderLayer(nn.Module):
             B = tgt.shape[1]
             sa, ca = self.self_attn, self.multihead_attn
             img = RB.images(self)   # the projections' W^T images: the decoder rewrites all layers' in one launch per forward
-            q, k, v = RB.qkv(tgt2, query_pos, sa, B, img)
+            q, k, v, pos2 = RB.qkv(tgt2, query_pos, sa, B, img)  # (pos2 = query_pos, routed through qkv for its gradient)
             p = sa.dropout if sa.training else 0.0
             core = A.fused_attention(q, k, v, num_heads=sa.num_heads, scale=sa.head_dim ** -0.5, shared_kv=False, dropout_p=p,
                                      salt=sa._salt)
-            tgt, qc = RB.proj_q(core, tgt, query_pos, sa.out_proj, ca.q, self.dropout1, self.norm2, self._aln_salts[0], B, img)
+            tgt, qc = RB.proj_q(core, tgt, pos2, sa.out_proj, ca.q, self.dropout1, self.norm2, self._aln_salts[0], B, img)
             core, _ = ca.core(qc, memory, reference_point, reference_angle, enc_xyz, None, self.cross_cache)
             if getattr(self, "_act_salt", None) is None:
                 self._act_salt = BNA.new_salt()
