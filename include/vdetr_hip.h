@@ -173,8 +173,10 @@ typedef struct vdetr_attn_desc {
                          operands (attn_fwd_pipe.hip: scores at f32 accuracy, output 8e-6 relative); 2 = the same with f32
                          matrix instructions; 1 = one workgroup per (query quad, key chunk) (attn_fwd.hip; the round-4 kernel,
                          kept for A/B runs and parity tests) */
-  int32_t bwd_kernel; /* table gradient: 0 = the axis-aligned-box kernel where every query's vertices are a box (attn_bwd_box4.hip;
-                         decided on the device), 1 = the general kernel only (parity tests compare the two) */
+  int32_t bwd_kernel; /* table gradient: 0 = the box kernel where every query's vertices are a box (attn_bwd_box4.hip), the general
+                         kernel otherwise — both are launched, the device decides; 1 = the general kernel only (parity tests compare
+                         the two); 2 = the box kernel only: the caller vouches for boxes (vertices out of a box decode) and saves the
+                         general kernel's launch; a query that is not a box then poisons dtable with NaN */
   int32_t kv_halves;  /* vdetr_attn_bwd_kv_f32: workgroups per key tile.  0 or 2 = two (each walks every other group of row tiles:
                          twice the workgroups, the shape for a launch alone on the chip), 1 = one (half the workgroups, each twice
                          as long: next to a table-gradient kernel that holds most CUs, 256 one-per-CU workgroups would run four

@@ -72,7 +72,7 @@ def rpe_bias_grid_sample(tables, vertices, xyz, log_scale=512.0, max_value=4.0, 
 
 def fused_attention_reference(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None,
                               xyz=None, cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0,
-                              keep_mask=None, return_probs=False, rpe_impl="explicit", table_grad_async=False, kv_img=None):
+                              keep_mask=None, return_probs=False, rpe_impl="explicit", table_grad_async=False, kv_img=None, vertices_are_boxes=False):
     """Same contract as ``vdetr_amd.attention.fused_attention`` (q [B,nQ,H*64]; k,v [B,nK,64] or [B,nK,H*64]).
 
     shared_kv: vdetr_transformer.py:733-753 (cross attention) / :638-648 (ShareSelfAttention);

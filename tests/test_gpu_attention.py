@@ -631,3 +631,29 @@ def test_kv_images_packed_ahead_equal_the_forwards_own(B, nQ, nK, n):
         own = A.fused_attention(q, parts[2 * i], parts[2 * i + 1], **kw)
         ahead = A.fused_attention(q, parts[2 * i], parts[2 * i + 1], kv_img=imgs[i], **kw)
         assert torch.equal(own, ahead), f"layer {i}"
+
+
+def test_table_gradient_with_boxes_vouched_for():
+    """fused_attention(vertices_are_boxes=True) -> vdetr_attn_desc.bwd_kernel = 2: the box kernel alone (the general kernel's launch
+    is saved).  Same table gradient, bit for bit, as the default for boxes; NaN — not a silently wrong gradient — where a query is
+    not a box after all."""
+    from vdetr_amd import attention as A
+    B, nQ, nK = 1, 96, 700
+    g = torch.Generator().manual_seed(12)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 21)
+    q, k, v = (torch.randn(s, generator=g).to(DEV) for s in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g).to(DEV)
+
+    def run(vv, vouch):
+        tb = tables.to(DEV).requires_grad_(True)
+        out = A.fused_attention(q, k, v, num_heads=4, scale=0.125, shared_kv=True, table=tb, rpe=A.RPEConfig(),
+                                vertices=vv.to(DEV).contiguous(), xyz=xyz.to(DEV), vertices_are_boxes=vouch)
+        (out * wout).sum().backward()
+        return tb.grad
+
+    ref, got = run(verts, False), run(verts, True)
+    assert torch.isfinite(got).all() and torch.equal(ref, got)
+    bent = verts.clone()
+    bent[0, 5, 3, 0] += 0.01  # one vertex of one query off its box
+    assert torch.isfinite(run(bent, False)).all()
+    assert torch.isnan(run(bent, True)).all()

@@ -529,7 +529,7 @@ def _check_inputs(**tensors):
 class _FusedAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, table, vertices, xyz, cos_sin, mask, kind, H, scale, rpe, dropout_p, rng_state,
-                need_grad, salt, table_async=False, kv_img=None):
+                need_grad, salt, table_async=False, kv_img=None, boxes=False):
         B, nQ, C = q.shape
         nK = k.shape[1]
         assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
@@ -567,6 +567,7 @@ class _FusedAttention(Function):
             ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
             ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
             ctx.table_async = bool(table_async)
+            ctx.boxes = bool(boxes)
             if table_async and table is not None and table.requires_grad and _async_wanted(q.shape[0], q.shape[1], k.shape[1]):
                 _step_side[_dev_key(q.device)] = True
         return out
@@ -585,6 +586,10 @@ class _FusedAttention(Function):
         shared = kind == L.VDETR_ATTN_SHARED_KV
         want_table = table is not None and ctx.needs_input_grad[3]
         d = _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, dropout_p, rng, salt, 0, v.stride(1))
+        if getattr(ctx, "boxes", False) and BWD_KERNEL == 0 and cos_sin is None:
+            # the caller vouches for axis-aligned boxes (vertices out of the box decode: exact coordinate patterns): the box kernel
+            # alone, without the general kernel's launch in front of it; a query that is not a box poisons dtable with NaN
+            d.bwd_kernel = 2
         if want_table and DYNAMIC_BWD:  # norm maxima + query counters for the dynamic distribution (see vdetr_hip.h)
             aux = _take_zeros(q, (8,), torch.int32)  # 5 words used (vdetr_hip.h: bwd_aux)
             d.bwd_aux = aux.data_ptr()
@@ -662,7 +667,7 @@ class _FusedAttention(Function):
             dk, dv = dkv[0], dkv[1]
             if in_dtype == torch.bfloat16:
                 dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-            return (dq, dk, dv, dtable) + (None,) * 14
+            return (dq, dk, dv, dtable) + (None,) * 15
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)
@@ -708,7 +713,7 @@ class _FusedAttention(Function):
                 dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         if in_dtype == torch.bfloat16:
             dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-        return (dq, dk, dv, dtable) + (None,) * 14
+        return (dq, dk, dv, dtable) + (None,) * 15
 
 
 def _kv_layout(t, B, nK):
@@ -722,9 +727,12 @@ def _kv_layout(t, B, nK):
 
 
 def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
-                    cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0, table_grad_async=False, kv_img=None):
+                    cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0, table_grad_async=False, kv_img=None,
+                    vertices_are_boxes=False):
     """out[B,nQ,H*64] = dropout(softmax(scale * q k^T + rpe + mask)) v.
     kv_img: this call's slice of pack_kv_images() (optional: the forward packs its own otherwise).
+    vertices_are_boxes: the caller vouches that every query's 8 vertices are an axis-aligned box (they come out of a box decode):
+    the table gradient then launches its box kernel alone (vdetr_attn_desc.bwd_kernel = 2).
 
     q [B,nQ,H*64]; k,v [B,nK,64] (shared_kv) or [B,nK,H*64]; table [8,T,T,T,H]; vertices [B,nQ,8,3];
     xyz [B,nK,3]; cos_sin [B,nQ,2] or None; attn_mask [B,nQ,nK] bool (-100 fill) / float (additive) or None.
@@ -748,7 +756,7 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
     k, v = _kv_layout(k, B, nK), _kv_layout(v, B, nK)
     return _FusedAttention.apply(q.contiguous(), k, v, table, vertices, xyz, cos_sin, mask,
                                  kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt),
-                                 bool(table_grad_async), kv_img)
+                                 bool(table_grad_async), kv_img, bool(vertices_are_boxes))
 
 
 def pack_kv_images(kv, n):

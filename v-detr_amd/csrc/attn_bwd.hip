@@ -392,10 +392,16 @@ __global__ __launch_bounds__(VERTS * WPV * kWave) void attn_bwd_scores_rpe_mm_ke
 // dtable[e] += sum over workgroup copies.  Workgroup p of the scores kernel wrote the `n / nsplit` floats of table
 // slice p % nsplit; blockIdx.y takes kRedSlice of the copies so that the partials are read by ~1000 blocks
 constexpr int kRedSlice = 16;
+// gate != NULL (bwd_kernel 2: the caller vouched for boxes and the general kernel was not launched): where the device found a query
+// that is not a box, nothing filled the partial tables — the gradient is poisoned with NaN instead of being left wrong.
 __global__ __launch_bounds__(256) void attn_bwd_table_reduce_kernel(const float* part, int nparts, int nsplit, int n,
-                                                                    float* dtable) {
+                                                                    float* dtable, const unsigned* gate) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  if (gate && (gate[4] != 0 || gate[5] == 0)) {
+    dtable[e] = __builtin_nanf("");
+    return;
+  }
   const int nsub = n / nsplit, sl = e / nsub, esub = e - sl * nsub;
   const int copies = nparts / nsplit;
   const int p0 = blockIdx.y * kRedSlice, p1 = min(copies, p0 + kRedSlice);
@@ -584,11 +590,16 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
   //   attn_bwd_box4_kernel (dS given, table edge 10, dynamic distribution): every query's vertices are an axis-aligned box, or,
   //   with the rotation operand, a box in the frame the offsets are turned into.
   // d->bwd_kernel = 1 keeps the general kernel alone (the parity tests compare the two).
-  const bool box = ds_given && dtable && d->bwd_kernel == 0 && d->bwd_aux && P.T == 10;
+  VDETR_REQUIRE(d->bwd_kernel >= 0 && d->bwd_kernel <= 2, "attn_bwd_table: bwd_kernel %d (0, 1 or 2)", d->bwd_kernel);
+  const bool box = ds_given && dtable && d->bwd_kernel != 1 && d->bwd_aux && P.T == 10;
+  // bwd_kernel = 2: the caller vouches that every query's vertices are a box (they come out of a box decode): the general kernel —
+  // a launch whose workgroups would all leave at once — is not put in front of the box kernel
+  const bool box_only = box && d->bwd_kernel == 2;
   P.box_path = box ? 1 : 0;
   {
     const size_t lds = (size_t)table_floats / kBwdSplit * sizeof(float) + (size_t)8 * kBwdSplit * kMmStripFloats * sizeof(float);
-    if (int e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st)) return e;
+    if (!box_only)
+      if (int e = launch_mm<true, 4, 4, true, true>(P, grid, lds, st)) return e;
     if (box)
       if (int e2 = launch_attn_bwd_box4(P, grid, st)) return e2;
   }
@@ -596,7 +607,7 @@ static int attn_bwd_scores_impl(const vdetr_attn_desc* d, const float* scores, c
   if (dtable) {
     hipLaunchKernelGGL(attn_bwd_table_reduce_kernel,
                        dim3((table_floats + 255) / 256, (grid / kBwdSplit + kRedSlice - 1) / kRedSlice), dim3(256), 0, st,
-                       P.dtable_part, grid, kBwdSplit, table_floats, dtable);
+                       P.dtable_part, grid, kBwdSplit, table_floats, dtable, box_only ? d->bwd_aux : (const unsigned*)nullptr);
     return check_launch("attn_bwd_table_reduce");
   }
   return VDETR_OK;
@@ -618,7 +629,7 @@ extern "C" int vdetr_attn_bwd_table_kernel_names(const vdetr_attn_desc* d, const
   VDETR_REQUIRE(d && box_kernel && general_kernel, "attn_bwd_table_kernel_names: null pointer");
   VDETR_REQUIRE(d->table, "attn_bwd_table_kernel_names: no RPE table in the descriptor");
   const int T = d->table_size;
-  const bool box = d->bwd_kernel == 0 && d->bwd_aux && T == 10;
+  const bool box = d->bwd_kernel != 1 && d->bwd_aux && T == 10;
   *box_kernel = box ? "attn_bwd_box4_kernel" : nullptr;
   *general_kernel = "attn_bwd_scores_rpe_mm_kernel";
   return VDETR_OK;

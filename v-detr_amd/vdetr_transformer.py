@@ -164,6 +164,9 @@ class GlobalShareCrossAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.rpe_cfg = A.RPEConfig(num_points, self.log_scale, max_value)
         self.return_attn = False
+        # set by a caller whose reference points are box corners out of its own box decode (TransformerDecoder): the table gradient
+        # then launches the box kernel alone (attention.fused_attention: vertices_are_boxes)
+        self.vertices_are_boxes = False
         self.defer_proj_drop = False
         # storage type of the projected q / k / v handed to the attention core: torch.bfloat16 = BASELINE config 4 (the bf16
         # matrix instructions for QK^T / PV; scores, RPE, softmax, accumulators, output fp32); set_attention_dtype() below
@@ -266,7 +269,7 @@ class GlobalShareCrossAttention(nn.Module):
         x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, table=tables,
                               rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
                               attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt,
-                              table_grad_async=cache is not None,
+                              table_grad_async=cache is not None, vertices_are_boxes=self.vertices_are_boxes,
                               **({"kv_img": cache[3]} if (cache is not None and len(cache) > 3 and cache[3] is not None) else {}))
         attn = None
         if self.return_attn:
@@ -1116,8 +1119,10 @@ class TransformerDecoder(nn.Module):
                 layer.pre_normed = carried
                 nxt = self.layers[idx + 1].norm1 if idx + 1 < len(self.layers) else None
                 layer.post_norms = (self.norm,) + ((nxt,) if nxt is not None else ())
+            own_boxes = False
             if idx > 0:
                 reference_point = box_prediction.pop("_reference_point_lidar", None)  # written by the fused box decode
+                own_boxes = reference_point is not None  # corners out of box_decode.hip: boxes by construction
                 if reference_point is None:
                     reference_point = convert_corners_camera2lidar(box_prediction["box_corners"].detach())
                 reference_center = box_prediction["center_unnormalized"].detach()
@@ -1129,6 +1134,8 @@ class TransformerDecoder(nn.Module):
             query_pos = self.query_pos_projection[idx](query_reference).permute(2, 0, 1)
             if self.pos_for_key:
                 pos = self.key_pos_projection[idx](enc_xyz).permute(2, 0, 1)
+            if hasattr(layer.multihead_attn, "vertices_are_boxes"):
+                layer.multihead_attn.vertices_are_boxes = own_boxes
             output, attn = layer(output, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims,
                                  tgt_mask=tgt_mask, memory_mask=memory_mask,
                                  tgt_key_padding_mask=tgt_key_padding_mask,
