@@ -339,6 +339,9 @@ typedef struct vdetr_box_decode_grads {
 int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stream);
 /* `d` as passed to the forward (inputs + the saved outputs size_unnorm, pre_size_unnorm, angle_cont, angle_class). */
 int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, vdetr_stream_t stream);
+/* n independent backward problems (HOST arrays of descriptors / gradient blocks) in one launch per 8: the stages of a decoder are
+ * differentiated together (models/vdetr_transformer.py:417-436 run their heads stage by stage; the backward of all of them is due at once). */
+int vdetr_box_decode_bwd_batch_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, int n, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Residual add + dropout + LayerNorm:  y = x + dropout(r);  out = LN(y; gamma, beta);  out2 = LN(y; gamma2, beta2).

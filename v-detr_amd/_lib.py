@@ -253,6 +253,7 @@ _SIGNATURES = {
     "vdetr_rpe_bias_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p]),
     "vdetr_box_decode_fwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), c_void_p]),
     "vdetr_box_decode_bwd_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), ctypes.POINTER(BoxDecodeGrads), c_void_p]),
+    "vdetr_box_decode_bwd_batch_f32": (c_int, [ctypes.POINTER(BoxDecodeDesc), ctypes.POINTER(BoxDecodeGrads), c_int, c_void_p]),
     "vdetr_add_ln_fwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), c_void_p]),
     "vdetr_add_ln_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AddLnDesc)]),
     "vdetr_add_ln_bwd_f32": (c_int, [ctypes.POINTER(AddLnDesc), ctypes.POINTER(AddLnGrads), c_void_p]),

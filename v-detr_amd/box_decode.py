@@ -131,8 +131,8 @@ def _joint_forward(y, chans, pre_center_norm, pre_size_norm, dims_min, dims_max,
 _JOINT_NONDIFF = ("pre_center_unnorm", "pre_size_unnorm", "objectness", "corners_lidar", "center_size", "cls_prob")
 
 
-def _joint_backward(meta, saved, gin, d_y=None):
-    """gin: {output name: gradient or None}.  One launch; returns the complete gradient of y (written into d_y if given)."""
+def _joint_backward_args(meta, saved, gin, d_y):
+    """descriptor + gradient block of one stage's backward (and the tensors they point into)"""
     B, N, A, C1, num_angle_bin, cls_kind, G, rows = meta
     y, dims_min, dims_max, size_unnorm, pre_size_unnorm, angle_cont, angle_class = saved
     slab = rows * N * 4
@@ -156,8 +156,24 @@ def _joint_backward(meta, saved, gin, d_y=None):
     g.d_cls, g.d_center, g.d_size, g.d_angle_cls, g.d_angle_res = (base, base + slab, base + 2 * slab, base + 3 * slab,
                                                                      base + 4 * slab)
     g.out_batch_stride, g.slab_rows = G * rows * N, rows
+    return d, g, keep, d_y
+
+
+def _joint_backward(meta, saved, gin, d_y=None):
+    """gin: {output name: gradient or None}.  One launch; returns the complete gradient of y (written into d_y if given)."""
+    d, g, _keep, d_y = _joint_backward_args(meta, saved, gin, d_y)
     L.check(L.lib().vdetr_box_decode_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "box_decode_bwd")
     return d_y
+
+
+def joint_backward_batch(items):
+    """items: [(meta, saved, gin, d_y)] of several stages -> their backward in one launch per 8 (vdetr_box_decode_bwd_batch_f32)"""
+    n = len(items)
+    args = [_joint_backward_args(*it) for it in items]
+    descs = (L.BoxDecodeDesc * n)(*[a[0] for a in args])
+    grads = (L.BoxDecodeGrads * n)(*[a[1] for a in args])
+    L.check(L.lib().vdetr_box_decode_bwd_batch_f32(descs, grads, n, L.stream_ptr()), "box_decode_bwd_batch")
+    return [a[3] for a in args]
 
 
 class _BoxDecodeJoint(torch.autograd.Function):

@@ -184,8 +184,7 @@ __global__ __launch_bounds__(kBoxThreads) void box_decode_fwd_kernel(vdetr_box_d
 }
 
 // Backward: every incoming gradient pointer may be NULL (that output was not used).
-__global__ __launch_bounds__(kBoxThreads) void box_decode_bwd_kernel(vdetr_box_decode_desc d, vdetr_box_decode_grads g) {
-  const int t = blockIdx.x * kBoxThreads + threadIdx.x;
+__device__ __forceinline__ void box_decode_bwd_body(const vdetr_box_decode_desc& d, const vdetr_box_decode_grads& g, int t) {
   if (t >= d.B * d.N) return;
   const int b = t / d.N, n = t - b * d.N;
   const size_t o3 = (size_t)t * 3;
@@ -274,6 +273,24 @@ __global__ __launch_bounds__(kBoxThreads) void box_decode_bwd_kernel(vdetr_box_d
   pad(g.d_angle_res, A);
 }
 
+__global__ __launch_bounds__(kBoxThreads) void box_decode_bwd_kernel(vdetr_box_decode_desc d, vdetr_box_decode_grads g) {
+  box_decode_bwd_body(d, g, blockIdx.x * kBoxThreads + threadIdx.x);
+}
+
+// Several stages' backward in one launch (vdetr_box_decode_bwd_batch_f32): blockIdx.y = stage.  The decoder's nine stages are
+// differentiated together at the head of the backward pass (vdetr_transformer._DeferredHeads): nine dependent 8-us launches there
+// were 0.1 ms of the step.
+constexpr int kBoxBatch = 8;  // (8 x 432 B of descriptors: inside the 4 KB of kernel arguments)
+struct BoxBwdBatch {
+  vdetr_box_decode_desc d[kBoxBatch];
+  vdetr_box_decode_grads g[kBoxBatch];
+};
+static_assert(sizeof(BoxBwdBatch) <= 3584, "box_decode_bwd_batch: descriptors exceed the kernel-argument budget");
+__global__ __launch_bounds__(kBoxThreads) void box_decode_bwd_batch_kernel(BoxBwdBatch Bt) {
+  const int s = blockIdx.y;
+  box_decode_bwd_body(Bt.d[s], Bt.g[s], blockIdx.x * kBoxThreads + threadIdx.x);
+}
+
 }  // namespace vdetr
 
 using namespace vdetr;
@@ -310,4 +327,33 @@ extern "C" int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vd
   VDETR_REQUIRE(g->d_center && g->d_size && g->d_angle_cls && g->d_angle_res, "box_decode_bwd: null output pointer");
   hipLaunchKernelGGL(box_decode_bwd_kernel, dim3(ceil_div((long)d->B * d->N, kBoxThreads)), dim3(kBoxThreads), 0, (hipStream_t)stream, *d, *g);
   return check_launch("box_decode_bwd");
+}
+
+static int box_bwd_check(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g) {
+  if (int e = box_check(d, "box_decode_bwd")) return e;
+  VDETR_REQUIRE(g != nullptr, "box_decode_bwd: null gradient block");
+  VDETR_REQUIRE(d->size_unnorm && d->pre_size_unnorm && d->angle_cont && d->angle_class,
+                "box_decode_bwd: the forward's size_unnorm / pre_size_unnorm / angle_cont / angle_class are required");
+  VDETR_REQUIRE(g->d_center && g->d_size && g->d_angle_cls && g->d_angle_res, "box_decode_bwd: null output pointer");
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_box_decode_bwd_batch_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, int n,
+                                              vdetr_stream_t stream) {
+  VDETR_REQUIRE(d && g && n > 0, "box_decode_bwd_batch: null pointer or n=%d", n);
+  for (int i0 = 0; i0 < n; i0 += kBoxBatch) {
+    const int m = n - i0 < kBoxBatch ? n - i0 : kBoxBatch;
+    BoxBwdBatch Bt{};
+    long rows = 0;
+    for (int i = 0; i < m; ++i) {
+      if (int e = box_bwd_check(d + i0 + i, g + i0 + i)) return e;
+      Bt.d[i] = d[i0 + i];
+      Bt.g[i] = g[i0 + i];
+      const long r = (long)d[i0 + i].B * d[i0 + i].N;
+      rows = r > rows ? r : rows;
+    }
+    hipLaunchKernelGGL(box_decode_bwd_batch_kernel, dim3(ceil_div(rows, kBoxThreads), m), dim3(kBoxThreads), 0, (hipStream_t)stream, Bt);
+    if (int e = check_launch("box_decode_bwd_batch")) return e;
+  }
+  return VDETR_OK;
 }

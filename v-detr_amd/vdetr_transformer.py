@@ -605,9 +605,8 @@ class _DeferredHeads(torch.autograd.Function):
         dev = r0["y"].device
         # ---- box decode backward of every stage, straight into one stacked buffer
         dY = torch.empty((S,) + tuple(r0["y"].shape), dtype=torch.float32, device=dev)
-        for s, rec in enumerate(recs):
-            gin = dict(zip(names, grads[s * K:(s + 1) * K]))
-            box_decode._joint_backward(rec["meta"], rec["saved"], gin, d_y=dY[s])
+        box_decode.joint_backward_batch([(rec["meta"], rec["saved"], dict(zip(names, grads[s * K:(s + 1) * K])), dY[s])
+                                         for s, rec in enumerate(recs)])  # (one launch per 8 stages)
         one = Bsz == 1
 
         def fold(t, ch):  # [S,B,G*ch or G,ch..,N] -> [S*G, ch, B*N]: the batch joins the contraction
