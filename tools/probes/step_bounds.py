@@ -5,6 +5,7 @@
   notable   the RPE-table gradient launches left out (NOT a valid step: the lower bound the main chain alone would reach)
   inline    the table gradient on the main stream, all 256 CUs (VDETR_BWD_ASYNC_TABLE=0)
   grid=N    the side-stream launch on N workgroups
+  noflush   the decoder layers' parked weight gradients dropped (not a valid step)
     for m in normal notable inline; do python tools/probes/step_bounds.py $m | tail -1; done"""
 import json
 import os
@@ -22,6 +23,16 @@ if os.environ.get("VDETR_PROBE_LIB"):  # a variant build of the library (experim
     import vdetr_amd._lib as _L
     _L.LIB_PATH = os.path.abspath(os.environ["VDETR_PROBE_LIB"])
 
+if mode == "noflush":  # the decoder layers' parked weight gradients dropped (NOT a valid step): what the flush on the side branch costs
+    from vdetr_amd.helpers import DeferredParamGrads as _D
+    _orig = _D.flush.__func__
+
+    def _drop(cls, select=None, collect=None, keepalive=None):
+        if select is not None:
+            cls.pending = [it for it in cls.pending if not select(it)]
+            return
+        return _orig(cls, select, collect, keepalive)
+    _D.flush = classmethod(_drop)
 if mode == "notable":
     A._launch_table_async = lambda lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable: dtable
 sys.argv = ["bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-criterion-leg", "--no-backbone-leg"] + sys.argv[2:]  # (e.g. --config c5)
