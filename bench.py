@@ -183,11 +183,14 @@ class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
     def __init__(self, model, inputs, world, use_graph, overlap, fps_prefetch=True, criterion=None, targets=None,
-                 defer_wg=True, fps_depth=None, force_dist=False):
+                 defer_wg=True, fps_depth=None, force_dist=False, fps_at_layer=None):
         from vdetr_amd.dist import FlatParams, GradientReducer
         global flush_weight_grads
         from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
         self.model, self.inputs, self.world = model, inputs, world
+        # the next scene's sampling launch (one CU for milliseconds) is forked in front of this decoder layer of the forward instead
+        # of at the step's start (-1); chosen by measurement in choose_fps_depth, VDETR_BENCH_FPS_AT_LAYER forces it
+        self.fps_at_layer = int(os.environ.get("VDETR_BENCH_FPS_AT_LAYER", "-1")) if fps_at_layer is None else int(fps_at_layer)
         # criterion=None: the synthetic scalar loss of SURVEY.md §8d (the headline metric); otherwise the device set
         # criterion (v-detr_amd/criterion.py) on `targets`, prepared once: their box counts do not depend on the model
         self.criterion = criterion
@@ -247,11 +250,25 @@ class Trainer:
             self.inputs["fps_inds"] = self.cur_inds  # filled by step() from the ring before the replay
         elif self.fps_prefetch:
             main = torch.cuda.current_stream()
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                next_inds = self.model.sample_indices(self.inputs)  # (the synthetic bench feeds the same scene again)
+            box, hook = {}, None
+
+            def launch_fps(*_):
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    box["inds"] = self.model.sample_indices(self.inputs)  # (the synthetic bench feeds the same scene again)
+            at = self.fps_at_layer
+            layers = getattr(getattr(self.model, "decoder", None), "layers", None)
+            if at >= 0 and layers is not None and at < len(layers):
+                # the sampling kernel holds one CU for ~4.7 ms: forked in front of decoder layer `at` instead of at the step's start
+                hook = layers[at].register_forward_pre_hook(launch_fps)
+            else:
+                launch_fps()
             self.inputs["fps_inds"] = self.cur_inds
         out = self.model(self.inputs)
+        if self.fps_prefetch and not self.fps_depth2:
+            if hook is not None:
+                hook.remove()
+            next_inds = box["inds"]
         self.loss = loss_fn(out) if self.criterion is None else self.criterion(out, self.targets)[0]
         self.loss.backward()
         if self.phased:
@@ -270,6 +287,18 @@ class Trainer:
         # applied inside the fused AdamW launch (grad_scale = 1 / coefficient)
         self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
         self.opt.step()
+
+    def reset_state(self, snap):
+        """parameters and buffers back to `snap` (model_state()), AdamW moments and step count to zero — in place, the captured
+        graphs keep their pointers.  The step's duration depends on the weights (the synthetic loss is unbounded below: the boxes
+        grow with every step, and with them the work of the box kernels): forms of the step are compared from the SAME state."""
+        with torch.no_grad():
+            for t, s0 in zip(list(self.model.parameters()) + list(self.model.buffers()), snap):
+                t.copy_(s0)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
 
     quiesce_collectives = quiesce_collectives  # (module-level: BackboneTrainer takes it too)
     _capture_stream = None  # one per process: a second Trainer on the same model meets the first one's AccumulateGrad nodes
@@ -934,7 +963,7 @@ def main():
         from vdetr_amd import bn_act as _bna
         _bna.set_sync(True, force=a.force_dist)
     inputs = make_inputs(a.config, device, rank)
-    def make_trainer(with_criterion):
+    def make_trainer(with_criterion, fps_at_layer=None):
         crit = targets = None
         if with_criterion:
             from vdetr_amd.criterion import build_criterion, default_criterion_args
@@ -942,10 +971,10 @@ def main():
             targets = make_targets(a.config, device, rank)
             crit_holder[0], crit_holder[1] = crit, targets
         return Trainer(model, inputs, world, use_graph, overlap=True, fps_prefetch=not a.no_fps_prefetch, criterion=crit,
-                       targets=targets, defer_wg=not a.no_defer_wg, force_dist=a.force_dist)
+                       targets=targets, defer_wg=not a.no_defer_wg, force_dist=a.force_dist, fps_at_layer=fps_at_layer)
 
-    def replay_ms(tr, reps=6):
-        for _ in range(3):
+    def replay_ms(tr, reps=6, settle=3):
+        for _ in range(settle):
             tr.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -954,12 +983,17 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
 
+    def model_state():
+        with torch.no_grad():
+            return [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
+
     def choose_fps_depth(tr):
         """depth 1 (the next scene's sampling as a forked branch of the captured step) or depth 2 (two scenes' samplings in
         flight on side streams outside the graph)?  Measured, not guessed: the one-CU sampling kernel takes 2.1 ms (4k points)
         to 10.7 ms (80k), the rest of the step 3 to 11 ms.  Every rank decides for itself (the graphs are rank-local)."""
         if os.environ.get("VDETR_FPS_DEPTH", "auto") != "auto" or a.no_fps_prefetch or tr.fps_depth2:
             return tr
+        snap = model_state()
         t1 = replay_ms(tr)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         model.sample_indices(inputs)
@@ -977,20 +1011,56 @@ def main():
             return float(t.item())
         t1, t_fps = over_ranks(t1), over_ranks(t_fps)
         if t_fps <= 0.8 * t1:
-            return tr
-        tr2 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=tr.criterion and crit_holder[0],
+            # One scene's sampling in flight is enough.  WHERE it is forked matters: the kernel holds a CU for t_fps, and every launch
+            # of the chain whose workgroups are one-per-CU (and most library GEMM grids at this size) pays a second round next to it
+            # — 0.55 ms of the C2 step (tools/probes/step_bounds.py nofps).  Forked in front of decoder layer k of the forward
+            # instead of at the step's start it overlaps less of the forward, as long as it still ends before the step does:
+            # largest k with (start of layer k) + 1.12 t_fps (its in-step duration) <= t1 - 1.2 ms, the forward taking ~0.37 t1.  That step is
+            # captured and timed as well; kept only if measured faster.
+            nl = len(getattr(getattr(model, "decoder", None), "layers", ()))
+            if os.environ.get("VDETR_BENCH_FPS_AT_LAYER") is not None or nl == 0 or tr.fps_at_layer >= 0:
+                return tr
+            tr.reset_state(snap)
+            t1 = over_ranks(replay_ms(tr, reps=12, settle=25))  # (the first replays after a capture run ~1.5 % slow)
+            tr.reset_state(snap)
+            k = min(int(((t1 - 1.12 * t_fps - 1.2) / t1 - 0.05) / 0.04), nl - 1)
+            if k < 1 or t_fps < 0.3 * t1:  # (no room behind a later fork / the one CU is held for a small part of the step anyway)
+                return tr
+
+            crit = tr.criterion and crit_holder[0]
+
+            def build(at):
+                # (every Trainer re-lays the parameters into flat buffers of its own: only the last one built has a live graph)
+                t = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=crit,
+                            targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=1, force_dist=a.force_dist, fps_at_layer=at)
+                t.capture()
+                t.reset_state(snap)
+                return t
+            trk = build(k)
+            tk = over_ranks(replay_ms(trk, reps=12, settle=25))
+            if rank == 0:
+                print(f"[bench] sampling {t_fps:.2f} ms alone; captured step {t1:.2f} ms with it forked at the start, {tk:.2f} ms in front "
+                      f"of decoder layer {k}: {'layer ' + str(k) if tk < 0.99 * t1 else 'start'}", file=sys.stderr)
+            if tk < 0.99 * t1:
+                trk.reset_state(snap)
+                return trk
+            return build(-1)
+        crit = tr.criterion and crit_holder[0]
+        tr2 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=crit,
                       targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=2, force_dist=a.force_dist)
         tr2.capture()
         t2 = over_ranks(replay_ms(tr2))
+        tr2.reset_state(snap)
         if rank == 0:
             print(f"[bench] sampling {t_fps:.2f} ms vs captured step {t1:.2f} ms (one scene's sampling in flight) / {t2:.2f} ms (two): "
                   f"fps_lookahead {2 if t2 < 0.97 * t1 else 1}", file=sys.stderr)
         if t2 < 0.97 * t1:  # (a tie goes to the simpler form: one side stream, no eager launches between the replays)
             return tr2
         # (tr2 has re-laid the parameters into flat buffers of its own: the first trainer's graph points at the old ones)
-        tr1 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=tr.criterion and crit_holder[0],
+        tr1 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=crit,
                       targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=1, force_dist=a.force_dist)
         tr1.capture()
+        tr1.reset_state(snap)
         return tr1
 
     crit_holder = [None, None]
@@ -1101,6 +1171,7 @@ def main():
                    "step": "FPS+gather, projection, decoder fwd, loss, backward, grad all-reduce (N>1), clip, AdamW",
                    "hip_graph": graph_ok, "fallback_level": fallback, "settle_steps": settle, "sync_bn": bool(a.sync_bn), "fps_prefetch": not a.no_fps_prefetch,
                    "fps_lookahead": 2 if getattr(trainer, "fps_depth2", False) and graph_ok else (1 if not a.no_fps_prefetch else 0),
+                   "fps_fork_layer": getattr(trainer, "fps_at_layer", -1),
                    "grad_allreduce_bytes": trainer.reducer.grad_bytes(), "grad_allreduce_buckets": len(trainer.reducer.buckets),
                    "grad_allreduce_model": trainer.bucket_model,
                    "grad_allreduce": ("none (1 rank)" if not trainer.reducer.active else
@@ -1218,7 +1289,7 @@ def main():
 
     def criterion_leg():
         # the same step with the reference's real loss: matcher + Hungarian + losses on the device
-        t2 = make_trainer(True)
+        t2 = make_trainer(True, fps_at_layer=getattr(trainer, "fps_at_layer", None))  # (forked where the headline step forks it)
         if use_graph:
             t2.capture()
         for _ in range(3):

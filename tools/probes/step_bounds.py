@@ -6,6 +6,8 @@
   inline    the table gradient on the main stream, all 256 CUs (VDETR_BWD_ASYNC_TABLE=0)
   grid=N    the side-stream launch on N workgroups
   noflush   the decoder layers' parked weight gradients dropped (not a valid step)
+  nofps     the next scene's sampling launch left out (not a valid step)
+  nomlp     the RPE tables' own backward left out (not a valid step)
     for m in normal notable inline; do python tools/probes/step_bounds.py $m | tail -1; done"""
 import json
 import os
@@ -33,6 +35,18 @@ if mode == "noflush":  # the decoder layers' parked weight gradients dropped (NO
             return
         return _orig(cls, select, collect, keepalive)
     _D.flush = classmethod(_drop)
+if mode == "nofps":  # the next scene's sampling launch left out (NOT a valid step): what its CU and its 4.7 ms cost the step
+    from vdetr_amd import model_vdetr as _M
+    _real = _M.ModelVDETR.sample_indices
+    _cache = {}
+
+    def _cached(self, inputs):
+        if "i" not in _cache:
+            _cache["i"] = _real(self, inputs)
+        return _cache["i"]
+    _M.ModelVDETR.sample_indices = _cached
+if mode == "nomlp":  # the RPE tables' own backward (three batched GEMMs at the end of the side branch) left out (not valid)
+    A.DeferredTableGrads.begin_flush = classmethod(lambda cls: None)
 if mode == "notable":
     A._launch_table_async = lambda lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable: dtable
 sys.argv = ["bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-criterion-leg", "--no-backbone-leg"] + sys.argv[2:]  # (e.g. --config c5)
