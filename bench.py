@@ -1179,10 +1179,10 @@ def main():
                                       if trainer.phased and graph_ok else
                                       "bucket hooks on a side stream during backward" if trainer.hooked else "after the replayed backward")},
         "loss": loss,
-        "arith": {"activations": "f32" if dtype == "f32" else "f32 residual stream; q / k / v of the cross attention stored as bf16",
+        "arith": {"activations": "f32" if dtype == "f32" else "f32 tensors everywhere; q / k / v of the cross attention ROUNDED to bf16 (nearest even) on the way into QK^T / PV (vdetr_attn_desc.fwd_kernel 3)",
                   "qk_pv": ("3DV-RPE cross attention forward: f32 operands as bf16 parts on the bf16 matrix unit, f32 accumulate — QK^T three parts, "
                             "six terms (2^-24 per product: f32 accuracy), PV two parts, three terms (2^-16 per product, output 8e-6 relative); "
-                            "query self-attention and VDETR_FWD_KERNEL=2: v_mfma_f32_16x16x4_f32 (exact f32)") if dtype == "f32" else "v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16, f32 accumulate (self-attention: f32)", "softmax_log2_table_lookup": "f32",
+                            "query self-attention and VDETR_FWD_KERNEL=2: v_mfma_f32_16x16x4_f32 (exact f32)") if dtype == "f32" else "v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16 on one bf16 part per operand, f32 accumulate; backward as in the f32 configuration (self-attention: f32)", "softmax_log2_table_lookup": "f32",
                   "dtable_products": "exact f32 outer products on v_mfma_f32_16x16x4_f32 (attn_bwd_box4_kernel: axis-aligned and rotated boxes; "
                                      "arbitrary vertices take the general kernel: split-bf16 2^-15)",
                   "dtable_accum": "int32 fixed point in LDS",

@@ -172,7 +172,9 @@ typedef struct vdetr_attn_desc {
   int32_t fwd_kernel; /* forward of the RPE kind: 0 = persistent workgroups, QK^T / PV on the bf16 matrix unit from split f32
                          operands (attn_fwd_pipe.hip: scores at f32 accuracy, output 8e-6 relative); 2 = the same with f32
                          matrix instructions; 1 = one workgroup per (query quad, key chunk) (attn_fwd.hip; the round-4 kernel,
-                         kept for A/B runs and parity tests) */
+                         kept for A/B runs and parity tests); 3 = the persistent kernel with q / k / v each ROUNDED to one bf16
+                         part (round to nearest even) on the way into the matrix unit: the bf16 products of BASELINE config 4 on
+                         f32 tensors — scores, softmax, RPE bias, accumulators and every stored tensor stay f32, no cast launches */
   int32_t bwd_kernel; /* table gradient: 0 = the box kernel where every query's vertices are a box (attn_bwd_box4.hip), the general
                          kernel otherwise — both are launched, the device decides; 1 = the general kernel only (parity tests compare
                          the two); 2 = the box kernel only: the caller vouches for boxes (vertices out of a box decode) and saves the
@@ -181,8 +183,8 @@ typedef struct vdetr_attn_desc {
                          twice the workgroups, the shape for a launch alone on the chip), 1 = one (half the workgroups, each twice
                          as long: next to a table-gradient kernel that holds most CUs, 256 one-per-CU workgroups would run four
                          rounds on the CUs left).  Same values either way up to the order of the row-tile sums. */
-  const void* kv_img; /* vdetr_attn_fwd_f32 with fwd_kernel 0: the K / V operand images of this call, packed ahead by
-                         vdetr_attn_pack_kv_f32 (one launch for the K / V of all decoder layers); NULL: the call packs its own into
+  const void* kv_img; /* vdetr_attn_fwd_f32 with fwd_kernel 0 / 3: the K / V operand images of this call, packed ahead by
+                         vdetr_attn_pack_kv_f32 / vdetr_attn_pack_kv_parts_f32 with the matching part count (one launch for the K / V of all decoder layers); NULL: the call packs its own into
                          `workspace` (one more launch) */
   uint32_t* fwd_sched; /* persistent forward: ONE zero device word (the item counter), left zero by the call; a word must not be
                           shared by launches that may run concurrently.  NULL: the library clears a word at the head of
@@ -197,6 +199,11 @@ size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d);
 size_t vdetr_attn_kv_image_bytes(int B, int nK);
 int vdetr_attn_pack_kv_f32(const float* k, const float* v, int B, int nK, int k_row_stride, int v_row_stride, int nlayers,
                            int64_t layer_stride, void* img, vdetr_stream_t stream);
+/* The same with the number of bf16 parts per operand chosen by the caller: 3 = vdetr_attn_pack_kv_f32 (fwd_kernel 0), 1 = operands
+ * rounded to bf16 (fwd_kernel 3; images of vdetr_attn_kv_image_parts_bytes(B, nK, 1) bytes each). */
+size_t vdetr_attn_kv_image_parts_bytes(int B, int nK, int parts);
+int vdetr_attn_pack_kv_parts_f32(const float* k, const float* v, int B, int nK, int k_row_stride, int v_row_stride, int nlayers,
+                                 int64_t layer_stride, int parts, void* img, vdetr_stream_t stream);
 
 /* Fused forward: out = dropout(softmax(scale*q k^T + rpe + mask)) v.
  *   q      [B,nQ,H*64]

@@ -593,6 +593,60 @@ def test_bf16_attention_core_vs_oracle(B, nQ, nK, boxes):
         assert rel < 5e-3, f"{name}: relative L2 error {rel:.2e}"
 
 
+@pytest.mark.parametrize("B,nQ,nK,boxes", [(1, 64, 512, True), (2, 37, 301, False), (1, 1024, 4096, True)])
+def test_rounded_operand_attention_vs_oracle(B, nQ, nK, boxes):
+    """fused_attention(operand_bf16=True) — vdetr_attn_desc.fwd_kernel 3: f32 q / k / v, rounded to bf16 inside the kernels (the
+    bf16 configuration without bf16 tensors).  Forward against the fp64 oracle on the ROUNDED operands at the bf16 path's stated
+    1e-2; gradients (the rounding's derivative taken as the identity, the backward products on the unrounded f32 operands: 2^-9
+    relative per operand next to the oracle's) at its 2e-2.  Images packed ahead with one part give the identical output."""
+    from oracle.attention_oracle import fused_attention_reference
+    from vdetr_amd import _lib as L
+    from vdetr_amd import attention as A
+    H = 4
+    g = torch.Generator().manual_seed(nQ + nK + 1)
+    xyz, verts, tables, _ = _scene(B, nQ, nK, 9)
+    if not boxes:
+        verts[:, ::5] += 0.05 * torch.randn(verts[:, ::5].shape, generator=g)
+    q = torch.randn((B, nQ, 256), generator=g)
+    kv = torch.randn((B, nK, 128), generator=g)
+    wout = torch.randn((B, nQ, 256), generator=g)
+    kw = dict(num_heads=H, scale=0.125, shared_kv=True, rpe=A.RPEConfig())
+    dq = q.to(DEV).requires_grad_(True)
+    dkv = kv.to(DEV).requires_grad_(True)
+    dtb = tables.to(DEV).requires_grad_(True)
+    dev = dict(table=dtb, vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV), operand_bf16=True, **kw)
+    out = A.fused_attention(dq, dkv[..., :64], dkv[..., 64:], **dev)
+    assert out.dtype == torch.float32
+    (out * wout.to(DEV)).sum().backward()
+    assert dq.grad.dtype == torch.float32
+    img = A.pack_kv_images(dkv.detach(), 1, parts=1)
+    assert img is not None and img.shape[1] == L.lib().vdetr_attn_kv_image_parts_bytes(B, nK, 1) < L.lib().vdetr_attn_kv_image_bytes(B, nK)
+    with torch.no_grad():
+        out_img = A.fused_attention(dq, dkv[..., :64], dkv[..., 64:], kv_img=img[0], **dev)
+        out_f32 = A.fused_attention(dq, dkv[..., :64], dkv[..., 64:], **{**dev, "operand_bf16": False})
+    assert torch.equal(out_img, out.detach())
+    assert not torch.equal(out_f32, out.detach())  # (the rounded operands are really what the kernel multiplied)
+    rk = kv[..., :64].bfloat16().double().requires_grad_(True)
+    rv = kv[..., 64:].bfloat16().double().requires_grad_(True)
+    rtb = tables.double().requires_grad_(True)
+    routs, rdq = [], []
+    for c in range(0, nQ, 64):
+        sl = slice(c, c + 64)
+        rq = q[:, sl].bfloat16().double().requires_grad_(True)
+        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
+        (o * wout[:, sl].double()).sum().backward()
+        routs.append(o.detach())
+        rdq.append(rq.grad)
+    ref = [torch.cat(routs, 1), torch.cat(rdq, 1), torch.cat((rk.grad, rv.grad), -1), rtb.grad]
+    got = [out.detach(), dq.grad, dkv.grad, dtb.grad]
+    for name, r, o in zip(["out", "dq", "dkv", "dtable"], ref, got):
+        scale = float(r.abs().max())
+        tol = 1e-2 if name == "out" else 2e-2
+        assert_close(o.float(), r.numpy(), tol, tol * scale, name)
+        rel = float((o.float().cpu().double() - r).norm() / r.norm())
+        assert rel < 5e-3, f"{name}: relative L2 error {rel:.2e}"
+
+
 def test_bf16_decoder_layer_close_to_fp32():
     """set_attention_dtype(bf16) on the cross attention module: the module's output stays within 1e-2 of the fp32 module's."""
     from vdetr_amd.vdetr_transformer import set_attention_dtype

@@ -238,6 +238,8 @@ _SIGNATURES = {
     "vdetr_attn_fwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
     "vdetr_attn_kv_image_bytes": (c_size_t, [c_int, c_int]),
     "vdetr_attn_pack_kv_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
+    "vdetr_attn_kv_image_parts_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vdetr_attn_pack_kv_parts_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_int64, c_int, c_void_p, c_void_p]),
     "vdetr_attn_fwd_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_fwd_bf16": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),

@@ -529,7 +529,7 @@ def _check_inputs(**tensors):
 class _FusedAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, table, vertices, xyz, cos_sin, mask, kind, H, scale, rpe, dropout_p, rng_state,
-                need_grad, salt, table_async=False, kv_img=None, boxes=False):
+                need_grad, salt, table_async=False, kv_img=None, boxes=False, operand_bf16=False):
         B, nQ, C = q.shape
         nK = k.shape[1]
         assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
@@ -556,8 +556,10 @@ class _FusedAttention(Function):
         rows = (B, nQ, H) if kind == L.VDETR_ATTN_SHARED_KV else (B, H, nQ)
         lse = torch.empty(rows, dtype=torch.float32, device=q.device)
         scores = torch.empty(rows + (nK,), dtype=torch.float32, device=q.device) if need_grad else None
+        if operand_bf16 and not bf16 and FWD_KERNEL == 0:
+            d.fwd_kernel = 3  # f32 tensors, q / k / v rounded to one bf16 part each inside the kernels (vdetr_hip.h)
         if kv_img is not None and not bf16 and FWD_KERNEL == 0:
-            d.kv_img = kv_img.data_ptr()  # this call's K / V operand images (pack_kv_images)
+            d.kv_img = kv_img.data_ptr()  # this call's K / V operand images (pack_kv_images, same part count)
         nbytes = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
         ws = L.workspace(nbytes, q.device) if nbytes else None
         fwd = lib.vdetr_attn_fwd_bf16 if bf16 else lib.vdetr_attn_fwd_f32
@@ -667,7 +669,7 @@ class _FusedAttention(Function):
             dk, dv = dkv[0], dkv[1]
             if in_dtype == torch.bfloat16:
                 dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-            return (dq, dk, dv, dtable) + (None,) * 15
+            return (dq, dk, dv, dtable) + (None,) * 16
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)
@@ -713,7 +715,7 @@ class _FusedAttention(Function):
                 dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         if in_dtype == torch.bfloat16:
             dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-        return (dq, dk, dv, dtable) + (None,) * 15
+        return (dq, dk, dv, dtable) + (None,) * 16
 
 
 def _kv_layout(t, B, nK):
@@ -728,9 +730,12 @@ def _kv_layout(t, B, nK):
 
 def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
                     cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0, table_grad_async=False, kv_img=None,
-                    vertices_are_boxes=False):
+                    vertices_are_boxes=False, operand_bf16=False):
     """out[B,nQ,H*64] = dropout(softmax(scale * q k^T + rpe + mask)) v.
     kv_img: this call's slice of pack_kv_images() (optional: the forward packs its own otherwise).
+    operand_bf16: f32 q / k / v whose values are rounded to bf16 on the way into QK^T and PV (BASELINE config 4's arithmetic
+    without bf16 tensors: no cast launches, the backward as for f32 operands — the rounding's derivative is the identity);
+    pack_kv_images(parts=1) for kv_img.
     vertices_are_boxes: the caller vouches that every query's 8 vertices are an axis-aligned box (they come out of a box decode):
     the table gradient then launches its box kernel alone (vdetr_attn_desc.bwd_kernel = 2).
 
@@ -756,22 +761,23 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
     k, v = _kv_layout(k, B, nK), _kv_layout(v, B, nK)
     return _FusedAttention.apply(q.contiguous(), k, v, table, vertices, xyz, cos_sin, mask,
                                  kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt),
-                                 bool(table_grad_async), kv_img, bool(vertices_are_boxes))
+                                 bool(table_grad_async), kv_img, bool(vertices_are_boxes), bool(operand_bf16))
 
 
-def pack_kv_images(kv, n):
+def pack_kv_images(kv, n, parts=3):
     """kv [B, nK, n * 128] f32, the joint K | V projection of n cross-attention layers (layer i: columns 128 i .. + 63 = K,
     + 64 .. + 127 = V) -> uint8 [n, bytes]: each layer's operand images for the persistent forward (fused_attention(kv_img=)),
-    one launch for all layers.  None where the forward would not use them."""
+    one launch for all layers.  parts: 3 = f32 accuracy (the default forward), 1 = operands rounded to bf16
+    (fused_attention(operand_bf16=True)).  None where the forward would not use them."""
     if (FWD_KERNEL != 0 or not kv.is_cuda or kv.dtype != torch.float32 or not kv.is_contiguous() or kv.shape[2] != n * 2 * HEAD_DIM
             or kv.data_ptr() % 16):
         return None
     B, nK = kv.shape[0], kv.shape[1]
     lib = L.lib()
-    nbytes = lib.vdetr_attn_kv_image_bytes(B, nK)
+    nbytes = lib.vdetr_attn_kv_image_parts_bytes(B, nK, parts)
     img = torch.empty((n, nbytes), dtype=torch.uint8, device=kv.device)
-    L.check(lib.vdetr_attn_pack_kv_f32(kv.data_ptr(), kv.data_ptr() + 4 * HEAD_DIM, B, nK, kv.shape[2], kv.shape[2], n, 2 * HEAD_DIM,
-                                       img.data_ptr(), L.stream_ptr()), "attn_pack_kv")
+    L.check(lib.vdetr_attn_pack_kv_parts_f32(kv.data_ptr(), kv.data_ptr() + 4 * HEAD_DIM, B, nK, kv.shape[2], kv.shape[2], n, 2 * HEAD_DIM,
+                                             parts, img.data_ptr(), L.stream_ptr()), "attn_pack_kv")
     return img
 
 

@@ -505,9 +505,9 @@ int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   return VDETR_OK;
 }
 
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, bool packed, hipStream_t st);  // attn_fwd_pipe.hip
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, bool packed, bool src_f32, hipStream_t st);  // attn_fwd_pipe.hip
 int attn_fwd_pack_launch(const void* k, const void* v, int B, int nK, int k_stride, int v_stride, int nlayers, long layer_stride, char* img,
-                         int split, hipStream_t st);
+                         int split, bool src_f32, hipStream_t st);
 size_t attn_fwd_pipe_img_bytes(int B, int nK, int split);
 
 // the persistent forward (attn_fwd_pipe.hip) takes the 3DV-RPE attention as the model runs it: fp32, table edge 10, no mask
@@ -515,8 +515,9 @@ static bool pipe_eligible(const vdetr_attn_desc* d) {
   return d->kind == VDETR_ATTN_SHARED_KV && d->table && d->table_size == 10 && !d->mask && d->fwd_kernel != 1;
 }
 // fwd_kernel 0: the persistent forward with its products on the bf16 matrix unit (three-way / two-way split operands, fp32
-// accuracy: attn_fwd_pipe.hip); 2: the same with fp32 matrix instructions; 1: the grid kernel
-static bool pipe_split(const vdetr_attn_desc* d) { return pipe_eligible(d) && d->fwd_kernel == 0; }
+// accuracy: attn_fwd_pipe.hip); 2: the same with fp32 matrix instructions; 1: the grid kernel; 3: the persistent forward with q / k / v
+// rounded to ONE bf16 part each (bf16 products as BASELINE config 4 names them, on f32 tensors).  Returns the parts of K (0: none).
+static int pipe_split(const vdetr_attn_desc* d) { return !pipe_eligible(d) ? 0 : d->fwd_kernel == 0 ? 3 : d->fwd_kernel == 3 ? 1 : 0; }
 
 // key split so that small query counts still fill the chip (shared kinds only)
 static int choose_ksplit(const vdetr_attn_desc* d) {
@@ -560,6 +561,9 @@ extern "C" size_t vdetr_attn_fwd_workspace_bytes(const vdetr_attn_desc* d) {
 }
 
 extern "C" size_t vdetr_attn_kv_image_bytes(int B, int nK) { return B > 0 && nK > 0 ? attn_fwd_pipe_img_bytes(B, nK, 3) : 0; }
+extern "C" size_t vdetr_attn_kv_image_parts_bytes(int B, int nK, int parts) {
+  return B > 0 && nK > 0 && (parts == 1 || parts == 3) ? attn_fwd_pipe_img_bytes(B, nK, parts) : 0;
+}
 
 extern "C" int vdetr_attn_pack_kv_f32(const float* k, const float* v, int B, int nK, int k_row_stride, int v_row_stride, int nlayers,
                                       int64_t layer_stride, void* img, vdetr_stream_t stream) {
@@ -567,7 +571,17 @@ extern "C" int vdetr_attn_pack_kv_f32(const float* k, const float* v, int B, int
   VDETR_REQUIRE(B > 0 && nK > 0 && nlayers > 0 && nlayers <= 65535 && B <= 65535, "attn_pack_kv: B=%d nK=%d nlayers=%d", B, nK, nlayers);
   VDETR_REQUIRE(k_row_stride >= kDh && v_row_stride >= kDh && k_row_stride % 4 == 0 && v_row_stride % 4 == 0 && layer_stride % 4 == 0 &&
                 (((uintptr_t)k | (uintptr_t)v | (uintptr_t)img) & 15) == 0, "attn_pack_kv: rows of >= 64 floats, strides multiples of 4, 16-B aligned");
-  return attn_fwd_pack_launch(k, v, B, nK, k_row_stride, v_row_stride, nlayers, (long)layer_stride, (char*)img, 3, (hipStream_t)stream);
+  return attn_fwd_pack_launch(k, v, B, nK, k_row_stride, v_row_stride, nlayers, (long)layer_stride, (char*)img, 3, true, (hipStream_t)stream);
+}
+
+extern "C" int vdetr_attn_pack_kv_parts_f32(const float* k, const float* v, int B, int nK, int k_row_stride, int v_row_stride, int nlayers,
+                                            int64_t layer_stride, int parts, void* img, vdetr_stream_t stream) {
+  VDETR_REQUIRE(k && v && img, "attn_pack_kv: null pointer");
+  VDETR_REQUIRE(parts == 1 || parts == 3, "attn_pack_kv: parts=%d (3 = f32 accuracy, 1 = operands rounded to bf16)", parts);
+  VDETR_REQUIRE(B > 0 && nK > 0 && nlayers > 0 && nlayers <= 65535 && B <= 65535, "attn_pack_kv: B=%d nK=%d nlayers=%d", B, nK, nlayers);
+  VDETR_REQUIRE(k_row_stride >= kDh && v_row_stride >= kDh && k_row_stride % 4 == 0 && v_row_stride % 4 == 0 && layer_stride % 4 == 0 &&
+                (((uintptr_t)k | (uintptr_t)v | (uintptr_t)img) & 15) == 0, "attn_pack_kv: rows of >= 64 floats, strides multiples of 4, 16-B aligned");
+  return attn_fwd_pack_launch(k, v, B, nK, k_row_stride, v_row_stride, nlayers, (long)layer_stride, (char*)img, parts, true, (hipStream_t)stream);
 }
 
 extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
@@ -617,7 +631,7 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
   if (pipe) {
     VDETR_REQUIRE((size_t)d->nK * P.k_stride < (1u << 30) && (size_t)d->nK * P.v_stride < (1u << 30) && (size_t)4 * d->nK < (1u << 30),
                   "attn_fwd: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
-    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, kv_img ? 3 : 0, d->kv_img != nullptr, st)) return e;
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, pipe_split(d), d->kv_img != nullptr, true, st)) return e;
   } else if (perhead) {
     dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
     if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
@@ -666,7 +680,7 @@ extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, cons
   P.q = (const float*)q; P.k = (const float*)k; P.v = (const float*)v; P.out = out; P.lse = lse; P.scores = scores;
   const bool rpe = d->table != nullptr;
   const int ks = choose_ksplit(d);
-  const bool pipe = pipe_split(d);  // the persistent forward, bf16 operands re-laid into its images (attn_fwd_pipe.hip, SPLIT = 1)
+  const bool pipe = pipe_split(d) == 3;  // (fwd_kernel 0) the persistent forward, bf16 operands re-laid into its images (attn_fwd_pipe.hip, SPLIT = 1)
   const size_t need = vdetr_attn_fwd_workspace_bytes(d);
   if (need && (!workspace || workspace_bytes < need)) {
     set_error("attn_fwd_bf16: workspace %zu B < required %zu B", workspace_bytes, need);
@@ -695,7 +709,7 @@ extern "C" int vdetr_attn_fwd_bf16(const vdetr_attn_desc* d, const void* q, cons
   if (pipe) {
     VDETR_REQUIRE((size_t)4 * d->nK < (1u << 30), "attn_fwd_bf16: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
     char* kv_img = (char*)((ws_top + 255) & ~(uintptr_t)255);
-    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, 1, false, (hipStream_t)stream)) return e;
+    if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, 1, false, false, (hipStream_t)stream)) return e;
     if (ks > 1) {
       const size_t elems = (size_t)d->B * d->nQ * d->H * kDh;
       hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);

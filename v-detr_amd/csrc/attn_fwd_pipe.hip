@@ -48,6 +48,7 @@ struct PipeArgs {
   unsigned* counter;  // device word, zero before the launch; the last draw of the launch sets it back to zero
   int nitems, qtiles; // items = B x qtiles x ksplit, qtiles = ceil(nQ / 4)
   const char* kv_img; // SPLIT: [B][tiles] operand images of K and V (attn_fwd_pack_kv_kernel)
+  int q_f32;          // SPLIT 1: q is stored as f32 and rounded to bf16 here (vdetr_attn_fwd_f32 with fwd_kernel 3); 0: stored as bf16
 };
 
 // ---- per-axis tap as in attn_common.h (rpe_axis), with the table edge a constant --------------------------------------
@@ -438,9 +439,19 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
       const int qi = min(q0 + (c >> 2), nQ - 1);
       const float* qrowp = P.q + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh;
       if constexpr (SPLIT == 1) {
-        const __bf16* qb = reinterpret_cast<const __bf16*>(P.q) + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh;
-        qa.q8[0] = *reinterpret_cast<const bf16x8*>(qb + 8 * g);
-        qa.q8[1] = *reinterpret_cast<const bf16x8*>(qb + 32 + 8 * g);
+        if (K.q_f32) {  // (uniform: f32 storage, the operand rounded to nearest-even here)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(qrowp + 32 * mm + 8 * g);
+            const f32x4 v0 = src[0], v1 = src[1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qa.q8[mm][e] = (__bf16)(e < 4 ? v0[e] : v1[e - 4]);
+          }
+        } else {
+          const __bf16* qb = reinterpret_cast<const __bf16*>(P.q) + ((size_t)b * nQ + qi) * qstride + (c & 3) * kDh;
+          qa.q8[0] = *reinterpret_cast<const bf16x8*>(qb + 8 * g);
+          qa.q8[1] = *reinterpret_cast<const bf16x8*>(qb + 32 + 8 * g);
+        }
       } else if constexpr (SPLIT) {
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) {
@@ -565,16 +576,16 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
 
 
 // K, V [B, nK, 64] (row strides as the forward's) -> the SPLIT kernels' operand images: one wave per 16-key tile.  SPLIT 3: f32
-// inputs in three / two bf16 parts; SPLIT 1: bf16 inputs, re-laid only.
+// inputs in three / two bf16 parts; SPLIT 1: bf16 inputs, re-laid only (SRC_F32: f32 inputs rounded to nearest-even bf16, one part).
 // blockIdx.z = layer: the decoder layers' K / V are column blocks of ONE joint projection, `layer_stride` elements apart, and their
 // images follow each other (vdetr_attn_pack_kv_f32: one launch for all layers instead of one in front of every forward).
-template <int SPLIT>
+template <int SPLIT, bool SRC_F32 = (SPLIT != 1)>
 __global__ __launch_bounds__(kWave) void attn_fwd_pack_kv_kernel(const void* __restrict__ kin, const void* __restrict__ vin, int nK, int k_stride,
                                                                  int v_stride, char* __restrict__ img, long layer_stride, int nB) {
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int tile = blockIdx.x, b = blockIdx.y, ntiles = gridDim.x;
   {
-    const size_t esz = SPLIT == 1 ? 2 : 4;
+    const size_t esz = SRC_F32 ? 4 : 2;
     kin = reinterpret_cast<const char*>(kin) + (size_t)blockIdx.z * layer_stride * esz;
     vin = reinterpret_cast<const char*>(vin) + (size_t)blockIdx.z * layer_stride * esz;
     img += (size_t)blockIdx.z * nB * ntiles * pipe_tile_bytes(SPLIT);
@@ -582,7 +593,31 @@ __global__ __launch_bounds__(kWave) void attn_fwd_pack_kv_kernel(const void* __r
   char* dst = img + ((size_t)b * ntiles + tile) * pipe_tile_bytes(SPLIT) + lane * 16;
   const int key = tile * 16 + c;
   constexpr int kK = pipe_k_pieces(SPLIT);
-  if constexpr (SPLIT == 1) {
+  if constexpr (SPLIT == 1 && SRC_F32) {
+    const float* k = reinterpret_cast<const float*>(kin);
+    const float* v = reinterpret_cast<const float*>(vin);
+    const float* kr = k + ((size_t)b * nK + min(key, nK - 1)) * k_stride;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g), v1 = *reinterpret_cast<const f32x4*>(kr + 32 * mm + 8 * g + 4);
+      bf16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (__bf16)(key < nK ? (e < 4 ? v0[e] : v1[e - 4]) : 0.f);
+      *reinterpret_cast<bf16x8*>(dst + mm * kWave * 16) = h;
+    }
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      bf16x8 both;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = tile * 16 + 4 * g + e;
+        const float* vr = v + ((size_t)b * nK + min(kk, nK - 1)) * v_stride + 4 * c + 2 * tp;
+        both[e] = (__bf16)(kk < nK ? vr[0] : 0.f);
+        both[4 + e] = (__bf16)(kk < nK ? vr[1] : 0.f);
+      }
+      *reinterpret_cast<bf16x8*>(dst + (kK + tp) * kWave * 16) = both;
+    }
+  } else if constexpr (SPLIT == 1) {
     const __bf16* k = reinterpret_cast<const __bf16*>(kin);
     const __bf16* v = reinterpret_cast<const __bf16*>(vin);
     const __bf16* kr = k + ((size_t)b * nK + min(key, nK - 1)) * k_stride;
@@ -644,28 +679,31 @@ using namespace vdetr;
 namespace vdetr {
 // Launch of the persistent forward (called from attn_fwd.hip with P filled, the key split chosen and the partial buffers placed).
 // `counter`: a zero device word (workspace head, see vdetr_attn_fwd_workspace_bytes).  split: 0 = f32 matrix instructions on f32
-// q / k / v (kv_img unused), 3 = split f32 operands, 1 = bf16 q / k / v (both: kv_img = attn_fwd_pipe_img_bytes of scratch).
+// q / k / v (kv_img unused), 3 = split f32 operands, 1 = bf16 q / k / v (both: kv_img = attn_fwd_pipe_img_bytes of scratch);
+// src_f32 with split 1: q / k / v are f32 tensors whose values are rounded to bf16 on the way into the operands.
 size_t attn_fwd_pipe_img_bytes(int B, int nK, int split) { return (size_t)B * ((nK + 15) / 16) * (split == 1 ? pipe_tile_bytes(1) : pipe_tile_bytes(3)); }
 
 int attn_fwd_pack_launch(const void* k, const void* v, int B, int nK, int k_stride, int v_stride, int nlayers, long layer_stride, char* img,
-                         int split, hipStream_t st) {
+                         int split, bool src_f32, hipStream_t st) {
   const dim3 pg((nK + 15) / 16, B, nlayers);
-  if (split == 1) hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<1>, pg, dim3(kWave), 0, st, k, v, nK, k_stride, v_stride, img, layer_stride, B);
+  if (split == 1 && src_f32) hipLaunchKernelGGL((attn_fwd_pack_kv_kernel<1, true>), pg, dim3(kWave), 0, st, k, v, nK, k_stride, v_stride, img, layer_stride, B);
+  else if (split == 1) hipLaunchKernelGGL((attn_fwd_pack_kv_kernel<1, false>), pg, dim3(kWave), 0, st, k, v, nK, k_stride, v_stride, img, layer_stride, B);
   else hipLaunchKernelGGL(attn_fwd_pack_kv_kernel<3>, pg, dim3(kWave), 0, st, k, v, nK, k_stride, v_stride, img, layer_stride, B);
   return check_launch("attn_fwd_pack_kv");
 }
 
 // packed: kv_img already holds the images (vdetr_attn_desc.kv_img)
-int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, bool packed, hipStream_t st) {
+int attn_fwd_pipe_launch(const AttnParams& P, unsigned* counter, int workgroups, char* kv_img, int split, bool packed, bool src_f32, hipStream_t st) {
   PipeArgs K;
   K.P = P;
   K.counter = counter;
   K.qtiles = (P.nQ + 3) / 4;
   K.nitems = P.B * K.qtiles * P.ksplit;
   K.kv_img = kv_img;
+  K.q_f32 = src_f32 ? 1 : 0;
   const int grid = workgroups < K.nitems ? workgroups : K.nitems;
   if (split && !packed) {
-    if (int e = attn_fwd_pack_launch(P.k, P.v, P.B, P.nK, P.k_stride, P.v_stride, 1, 0, kv_img, split, st)) return e;
+    if (int e = attn_fwd_pack_launch(P.k, P.v, P.B, P.nK, P.k_stride, P.v_stride, 1, 0, kv_img, split, src_f32, st)) return e;
   }
 #define VDETR_PIPE_LAUNCH(ROT, SPLIT)                                                                                       \
   do {                                                                                                                      \

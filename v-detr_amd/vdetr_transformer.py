@@ -220,10 +220,11 @@ class GlobalShareCrossAttention(nn.Module):
         b = cat_params([t for m in mods for t in (m.k.bias, m.v.bias)]) if mods[0].k.bias is not None else None
         kv = linear(key_b, w, b)                                                   # [B,nK,n*128]
         imgs = None
-        if mods[0].core_dtype != torch.float32 and kv.is_cuda:
-            kv = kv.to(mods[0].core_dtype)  # one cast for the K / V of every layer
-        elif kv.is_cuda and mods[0].rpe_cfg.table_size == 10:
-            imgs = A.pack_kv_images(kv.detach(), n)  # the forward kernels' K / V operand images of all layers: one launch
+        if kv.is_cuda and mods[0].rpe_cfg.table_size == 10:
+            # the forward kernels' K / V operand images of all layers: one launch (core_dtype bf16: one rounded part per operand)
+            imgs = A.pack_kv_images(kv.detach(), n, parts=1 if mods[0].core_dtype == torch.bfloat16 else 3)
+        if imgs is None and mods[0].core_dtype != torch.float32 and kv.is_cuda:
+            kv = kv.to(mods[0].core_dtype)  # (no image path: bf16 tensors, one cast for the K / V of every layer)
         parts = kv.view(kv.shape[0], kv.shape[1], 2 * n, -1).unbind(2)
         mlps = [mm for m in mods for mm in m.cpb_mlps]
         w1 = stack_params([mm[0].weight for mm in mlps])
@@ -264,12 +265,16 @@ class GlobalShareCrossAttention(nn.Module):
             rng = A.begin_step(q.device)
         tables = self.rpe_tables() if cache is None else cache[2]
         q32, k32 = q, k
-        if self.core_dtype != torch.float32 and q.is_cuda:
+        # bf16 arithmetic (BASELINE config 4): where the persistent forward takes the call, f32 tensors whose values are rounded to
+        # bf16 inside the kernels (no cast launches, no bf16 copies: measured 0.37 ms of the C4 step); bf16 tensors otherwise
+        rounded = (self.core_dtype == torch.bfloat16 and q.is_cuda and A.FWD_KERNEL == 0 and attn_mask is None
+                   and self.rpe_cfg.table_size == 10 and k.dtype == torch.float32)
+        if self.core_dtype != torch.float32 and q.is_cuda and not rounded:
             q, k, v = (t if t.dtype == self.core_dtype else t.to(self.core_dtype) for t in (q, k, v))
         x = A.fused_attention(q, k, v, num_heads=self.num_heads, scale=self.scale, shared_kv=True, table=tables,
                               rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
                               attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt,
-                              table_grad_async=cache is not None, vertices_are_boxes=self.vertices_are_boxes,
+                              table_grad_async=cache is not None, vertices_are_boxes=self.vertices_are_boxes, **({"operand_bf16": True} if rounded else {}),
                               **({"kv_img": cache[3]} if (cache is not None and len(cache) > 3 and cache[3] is not None) else {}))
         attn = None
         if self.return_attn:
