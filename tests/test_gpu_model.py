@@ -487,21 +487,26 @@ def _zero_dropout(model):
             m.dropout = 0.0
 
 
-@pytest.mark.parametrize("cfg", ["c2"])
-def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
+@pytest.mark.parametrize("cfg,cut", [("c2", None), ("c5", (2, 4))])
+def test_full_config_training_step_vs_cpu_oracle(cfg, cut, monkeypatch):
     """What bench.py times, checked whole: BASELINE config 2 (40k-point scene, 4096 keys, 1024 queries, 8 RPE layers, 9 head
     stages) in TRAIN mode (batch statistics in the heads; dropout rates 0 so that the two sides draw no random numbers), with the
     step's machinery ON — fused glue launches, the table gradient on the side stream, weight gradients parked and flushed —
     against the same model on the CPU with the native entry points routed to the oracle: the boxes / logits of all 9 stages at
     1e-3, the gradient of the backbone features, and the gradient of EVERY parameter (RPE table MLPs included).
     A query is (rank, token): the device's own top-1024 ranking must equal the CPU's except for at most 4 ranks whose objectness
-    values agree to rounding; the decoder then runs on the CPU's order on both sides (see check_and_pin below)."""
+    values agree to rounding; the decoder then runs on the CPU's order on both sides (see check_and_pin below).
+    c5 = BASELINE config 5 (20k-point scenes, rotated boxes: the `object_coords` RPE) CUT to 2 scenes and 3 RPE layers (4 head
+    stages): the whole configuration takes the CPU side 9.5 minutes, and at 4 scenes x 8 layers the stage-6 logits of two correct
+    fp32 implementations are already 8e-4 apart (the chaos described below; stages 0-5 inside the tolerance) — DESIGN.md 8."""
     import copy
     import os
     import bench
     from vdetr_amd import runtime
     import vdetr_amd.vdetr_transformer as T
     npts, bs, npre, nq, nl, angle_type, _ = bench.CONFIGS[cfg]
+    if cut is not None:
+        bs, nl = cut
     model = _make_model(nq=nq, npre=npre, nl=nl, angle_type=angle_type).train()
     _zero_dropout(model)
     inp_cpu = _inputs(npts, 3, "cpu", bs)
@@ -588,8 +593,10 @@ def test_full_config_training_step_vs_cpu_oracle(cfg, monkeypatch):
         live = int((np.abs(c).max(axis=-1) > 0).sum())
         rel = [float(np.abs(g[r] - c[r]).max() / max(np.abs(c[r]).max(), 1e-3 * np.abs(c).max())) for r in rows]
         fro = float(np.linalg.norm(g - c) / np.linalg.norm(c))
-        assert rows.size <= 0.02 * live and all(x <= 0.10 for x in rel) and fro <= 1e-2, (
-            f"d loss / d backbone features: {rows.size} of {live} rows off (allowed {int(0.02 * live)}), largest deviation "
+        # (several scenes share the heads' batch statistics: a gate that opens in one scene moves the rows of all of them — 3 %)
+        frac = 0.02 if bs == 1 else 0.03
+        assert rows.size <= frac * live and all(x <= 0.10 for x in rel) and fro <= 1e-2, (
+            f"d loss / d backbone features: {rows.size} of {live} rows off (allowed {int(frac * live)}), largest deviation "
             f"{max(rel, default=0.0):.3f} of the row's scale (allowed 0.10), Frobenius {fro:.2e} (allowed 1e-2); first rows {rows[:8].tolist()}")
     # Every parameter's gradient.  The same chaos as above bounds what two correct fp32 implementations can agree on here: two
     # DEVICE runs of this very step that differ only in the first call's GEMM selection are 7e-4 apart in the stage-7 outputs and

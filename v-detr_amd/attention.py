@@ -391,7 +391,7 @@ def _table_accumulator(table):
     return _take_zeros(table, tuple(table.shape), table.dtype)
 
 
-def _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork=None, dtable=None):
+def _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork=None, dtable=None, also=()):
     """the table-gradient launches of one layer on the side stream, behind everything the current stream has queued (dS, the
     zeroed accumulator and bwd_aux are ready then); returns the accumulator, which `join_table_grad`'s backward makes final"""
     if dtable is None:
@@ -411,7 +411,10 @@ def _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork=Non
                     "attn_bwd_table")
         finally:
             d.table_grid = keep_grid
-    _side_keep.append((ds, dtable, ws2, aux, table, vertices, xyz, mask))
+    # EVERY tensor the descriptor points at stays alive until the join: the launch runs later than the caller's backward() returns,
+    # and a block autograd frees then (the saved cos / sin of the rotated-box kind, the dropout state) is handed to the main stream's
+    # next allocation while this kernel still reads it — `also` (found by the cut C5 case of test_full_config_training_step_vs_cpu_oracle)
+    _side_keep.append((ds, dtable, ws2, aux, table, vertices, xyz, mask) + tuple(also))
     return dtable
 
 
@@ -659,7 +662,7 @@ class _FusedAttention(Function):
                     dq = dq.view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
             if want_table:
                 if run_async:
-                    dtable = _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable)
+                    dtable = _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable, also=(cos_sin, rng))
                 else:
                     dtable = _table_accumulator(table)
                     nbytes = lib.vdetr_attn_bwd_workspace_bytes(ctypes.byref(d))
