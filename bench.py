@@ -141,6 +141,17 @@ def loss_fn(out):
                            for k in ("sem_cls_logits", "center_normalized", "size_normalized")])
 
 
+def fps_fork_layer(t1, t_fps, nlayers):
+    """Decoder layer of the forward in front of which the next scene's sampling branch is forked, or -1 (the step's start), from the
+    measured step (t1 ms, sampling forked at the start) and the sampling alone (t_fps ms).  The one-workgroup kernel holds a CU for
+    1.12 t_fps inside the step; it must end 1.2 ms before the step does (the tail of the backward is where the chain's widest
+    launches are), layer k of the forward starts at (0.05 + 0.04 k) t1, and below 0.3 t1 the held CU is not worth a second capture."""
+    if nlayers <= 0 or t1 <= 0 or t_fps < 0.3 * t1:
+        return -1
+    k = min(int(((t1 - 1.12 * t_fps - 1.2) / t1 - 0.05) / 0.04), nlayers - 1)
+    return k if k >= 1 else -1
+
+
 def allreduce_bucket_model(grad_bytes, world):
     """How many gradient buckets the captured decoder step should use, from a model instead of a 1-rank timing (where the
     collective is free).  Ring all-reduce over the node's xGMI mesh: every GPU sends and receives 2 (W-1)/W x S bytes, RCCL
@@ -1023,8 +1034,8 @@ def main():
             tr.reset_state(snap)
             t1 = over_ranks(replay_ms(tr, reps=12, settle=25))  # (the first replays after a capture run ~1.5 % slow)
             tr.reset_state(snap)
-            k = min(int(((t1 - 1.12 * t_fps - 1.2) / t1 - 0.05) / 0.04), nl - 1)
-            if k < 1 or t_fps < 0.3 * t1:  # (no room behind a later fork / the one CU is held for a small part of the step anyway)
+            k = fps_fork_layer(t1, t_fps, nl)
+            if k < 1:  # (no room behind a later fork / the one CU is held for a small part of the step anyway)
                 return tr
 
             crit = tr.criterion and crit_holder[0]

@@ -1,6 +1,7 @@
 """N>1 path on CPU: two gloo ranks, scene-sharded gradients averaged by GradientReducer (the RCCL path on GPUs)."""
 import os
 import socket
+import sys
 
 import torch
 import torch.distributed as dist
@@ -395,6 +396,26 @@ def test_bench_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "no-such-backend", "--launch-check"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+
+
+def test_bench_sampling_fork_layer_rule():
+    """bench.fps_fork_layer: where the next scene's sampling branch is forked, from the two measured times.  The measured cases of
+    round 5 (profiles/r05_step_bounds.txt): C2 6.92 / 4.21 ms -> layer 2 (measured best: 6.78 ms; layers 1 / 3: 6.87 / 6.93); C4
+    7.41 / 5.9 -> no room, the start; C5 22.0 / 3.8 -> the held CU is a small part of the step, the start; a 1-rank communicator
+    step 7.31 / 4.2 -> layer 3 is tried (and measured slower: bench keeps the start)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    assert bench.fps_fork_layer(6.92, 4.21, 9) == 2
+    assert bench.fps_fork_layer(7.41, 5.9, 9) == -1
+    assert bench.fps_fork_layer(22.0, 3.8, 9) == -1
+    assert bench.fps_fork_layer(7.31, 4.2, 9) == 3
+    assert bench.fps_fork_layer(30.0, 10.0, 3) == 2          # never beyond the last layer
+    assert bench.fps_fork_layer(6.9, 4.2, 0) == -1 and bench.fps_fork_layer(0.0, 1.0, 9) == -1
+    for t1 in (3.0, 6.9, 12.0, 25.0):                        # the branch always ends before the step does
+        for frac in (0.3, 0.5, 0.7, 0.8):
+            k = bench.fps_fork_layer(t1, frac * t1, 9)
+            assert k == -1 or (0.05 + 0.04 * k) * t1 + 1.12 * frac * t1 <= t1 - 1.2 + 1e-9
 
 
 def test_avg_reduce_verdict_is_collective_and_cached():
