@@ -152,6 +152,22 @@ def fps_fork_layer(t1, t_fps, nlayers):
     return k if k >= 1 else -1
 
 
+def agree_any_failed(store, world, failed, tag, timeout_s=600.0):
+    """Did the capture fail on ANY rank?  Agreed through the process group's key-value store (CPU only): a process whose
+    capture failed cannot issue device work any more — the HIP runtime leaves the capture's streams in capture state and
+    refuses every later attempt to end it ("attempt to terminate a thread-local capture sequence from another thread";
+    tools/probes/capture_recovery.py) — so neither a device all-reduce nor a retry in this process is possible.
+    Every rank calls it once per `tag`; all get the same answer."""
+    store.add(f"bench_{tag}_failed", 1 if failed else 0)
+    store.add(f"bench_{tag}_seen", 1)
+    deadline = time.time() + timeout_s
+    while store.add(f"bench_{tag}_seen", 0) < world:
+        if time.time() > deadline:
+            raise RuntimeError(f"bench: the ranks did not all report their capture within {timeout_s:.0f} s")
+        time.sleep(0.01)
+    return store.add(f"bench_{tag}_failed", 0) > 0
+
+
 def allreduce_bucket_model(grad_bytes, world):
     """How many gradient buckets the captured decoder step should use, from a model instead of a 1-rank timing (where the
     collective is free).  Ring all-reduce over the node's xGMI mesh: every GPU sends and receives 2 (W-1)/W x S bytes, RCCL
@@ -1087,21 +1103,9 @@ def main():
         return ok
 
     def any_rank_failed(failed, tag):
-        """Did the capture fail on ANY rank?  Agreed through the process group's key-value store (CPU only): a process whose
-        capture failed cannot issue device work any more — the HIP runtime leaves the capture's streams in capture state and
-        refuses every later attempt to end it ("attempt to terminate a thread-local capture sequence from another thread";
-        tools/probes/capture_recovery.py) — so neither a device all-reduce nor a retry in this process is possible."""
         if world == 1:
             return failed
-        store = torch.distributed.distributed_c10d._get_default_store()
-        store.add(f"bench_{tag}_failed", 1 if failed else 0)
-        store.add(f"bench_{tag}_seen", 1)
-        deadline = time.time() + 600
-        while store.add(f"bench_{tag}_seen", 0) < world:
-            if time.time() > deadline:
-                raise RuntimeError("bench: the ranks did not all report their capture within 10 minutes")
-            time.sleep(0.01)
-        return store.add(f"bench_{tag}_failed", 0) > 0
+        return agree_any_failed(torch.distributed.distributed_c10d._get_default_store(), world, failed, tag)
 
     def relaunch(level):
         """The next form of the step — level 1: collectives outside the graph, level 2: no graph — in a CHILD process per rank

@@ -398,6 +398,43 @@ def test_bench_starts_its_own_ranks():
     assert bad.returncode != 0
 
 
+def _agree_worker(rank, world, port, fails, q):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store = dist.distributed_c10d._get_default_store()
+    out = []
+    for tag, failed_on in fails:   # one agreement per tag, as bench.py makes them ("capture", then "depth")
+        if rank == 1:
+            import time
+            time.sleep(0.2)        # the ranks do not arrive together
+        out.append(bench.agree_any_failed(store, world, rank in failed_on, tag, timeout_s=60))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_ranks_agree_on_a_failed_capture():
+    """bench.agree_any_failed: after a hipGraph capture, the ranks agree through the process group's store (no device work: a rank
+    whose capture failed cannot issue any) whether ANY of them failed — all then take the same branch of the fallback chain
+    (restart at the next level / go on).  Two ranks over gloo: nobody failed, rank 1 only, rank 0 only, both; the answers are the
+    same on both ranks and tags do not leak into each other."""
+    cases = [("capture", ()), ("depth", (1,)), ("third", (0,)), ("fourth", (0, 1)), ("fifth", ())]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, cases, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == [False, True, True, True, False]
+
+
 def test_bench_sampling_fork_layer_rule():
     """bench.fps_fork_layer: where the next scene's sampling branch is forked, from the two measured times.  The measured cases of
     round 5 (profiles/r05_step_bounds.txt): C2 6.92 / 4.21 ms -> layer 2 (measured best: 6.78 ms; layers 1 / 3: 6.87 / 6.93); C4
