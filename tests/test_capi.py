@@ -89,6 +89,30 @@ def test_round3_attention_backward_entry_points_reject_bad_arguments():
     assert lib.vdetr_ab_switches() == 0  # the shipped build reads no environment switch
 
 
+def test_round5_operand_image_entry_points():
+    """vdetr_attn_kv_image_bytes / vdetr_attn_pack_kv_f32 and their part-count forms (round 5: the forward's K / V operand images;
+    parts 3 = f32 accuracy, 1 = operands rounded to bf16): sizes by the layout (attn_fwd_pipe.hip: a 16-key tile is 6 + 4 pieces
+    of 64 lanes x 16 B with three parts, 2 + 2 with one), argument errors as status codes."""
+    from vdetr_amd import _lib
+    lib = _lib.lib()
+    tiles = (4096 + 15) // 16
+    assert lib.vdetr_attn_kv_image_bytes(1, 4096) == lib.vdetr_attn_kv_image_parts_bytes(1, 4096, 3) == tiles * 10 * 64 * 16
+    assert lib.vdetr_attn_kv_image_parts_bytes(1, 4096, 1) == tiles * 4 * 64 * 16
+    assert lib.vdetr_attn_kv_image_parts_bytes(2, 301, 1) == 2 * 19 * 4 * 64 * 16          # ragged key count: whole tiles
+    assert lib.vdetr_attn_kv_image_parts_bytes(1, 4096, 2) == 0 and lib.vdetr_attn_kv_image_parts_bytes(0, 4096, 1) == 0
+    assert lib.vdetr_attn_pack_kv_f32(None, None, 1, 4096, 64, 64, 1, 0, None, None) == 1
+    assert b"attn_pack_kv" in lib.vdetr_last_error()
+    assert lib.vdetr_attn_pack_kv_parts_f32(None, None, 1, 4096, 64, 64, 1, 0, 1, None, None) == 1
+    assert b"attn_pack_kv" in lib.vdetr_last_error()
+    buf = (ctypes.c_char * 64)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+    ptr = ctypes.c_void_p((ptr.value + 15) & ~15)
+    assert lib.vdetr_attn_pack_kv_parts_f32(ptr, ptr, 1, 4096, 64, 64, 1, 0, 2, ptr, None) == 1   # no such part count
+    assert b"parts=2" in lib.vdetr_last_error()
+    assert lib.vdetr_attn_pack_kv_parts_f32(ptr, ptr, 1, 4096, 62, 64, 1, 0, 1, ptr, None) == 1   # rows shorter than 64 floats
+    assert b"attn_pack_kv" in lib.vdetr_last_error()
+
+
 def test_ops_refuse_cpu_tensors():
     """No CPU fallback: the reference asserts "CPU not supported" (sampling.cpp:36,62,84)."""
     from vdetr_amd import pointnet2_utils as PU
