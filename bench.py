@@ -168,6 +168,20 @@ def agree_any_failed(store, world, failed, tag, timeout_s=600.0):
     return store.add(f"bench_{tag}_failed", 0) > 0
 
 
+def free_port(preferred):
+    """`preferred` if nothing listens there, otherwise a port the OS picks"""
+    import socket
+    for port in (preferred, 0):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                sock.bind(("127.0.0.1", port))
+                return sock.getsockname()[1]
+            except OSError:
+                continue
+    raise RuntimeError("bench: no free rendezvous port for the child processes")
+
+
 def allreduce_bucket_model(grad_bytes, world):
     """How many gradient buckets the captured decoder step should use, from a model instead of a 1-rank timing (where the
     collective is free).  Ring all-reduce over the node's xGMI mesh: every GPU sends and receives 2 (W-1)/W x S bytes, RCCL
@@ -1020,6 +1034,21 @@ def main():
         to 10.7 ms (80k), the rest of the step 3 to 11 ms.  Every rank decides for itself (the graphs are rank-local)."""
         if os.environ.get("VDETR_FPS_DEPTH", "auto") != "auto" or a.no_fps_prefetch or tr.fps_depth2:
             return tr
+        ncap = [0]
+
+        def captured(t):
+            """t.capture(), then the ranks agree THROUGH THE STORE whether it worked everywhere, before any of them goes on into a
+            device collective (over_ranks): a rank whose capture failed can issue no device work and would wait alone at the
+            outer agreement while the healthy ranks hang in the all-reduce until the communicator's timeout."""
+            err = None
+            try:
+                t.capture()
+            except Exception as e:
+                err = e
+            ncap[0] += 1
+            if any_rank_failed(err is not None, f"depth_capture{ncap[0]}"):
+                raise err if err is not None else RuntimeError("a capture of the sampling look-ahead choice failed on another rank")
+            return t
         snap = model_state()
         t1 = replay_ms(tr)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1060,7 +1089,7 @@ def main():
                 # (every Trainer re-lays the parameters into flat buffers of its own: only the last one built has a live graph)
                 t = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=crit,
                             targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=1, force_dist=a.force_dist, fps_at_layer=at)
-                t.capture()
+                captured(t)
                 t.reset_state(snap)
                 return t
             trk = build(k)
@@ -1075,7 +1104,7 @@ def main():
         crit = tr.criterion and crit_holder[0]
         tr2 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=crit,
                       targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=2, force_dist=a.force_dist)
-        tr2.capture()
+        captured(tr2)
         t2 = over_ranks(replay_ms(tr2))
         tr2.reset_state(snap)
         if rank == 0:
@@ -1086,7 +1115,7 @@ def main():
         # (tr2 has re-laid the parameters into flat buffers of its own: the first trainer's graph points at the old ones)
         tr1 = Trainer(model, inputs, world, True, overlap=True, fps_prefetch=True, criterion=crit,
                       targets=crit_holder[1], defer_wg=not a.no_defer_wg, fps_depth=1, force_dist=a.force_dist)
-        tr1.capture()
+        captured(tr1)
         tr1.reset_state(snap)
         return tr1
 
@@ -1107,6 +1136,18 @@ def main():
             return failed
         return agree_any_failed(torch.distributed.distributed_c10d._get_default_store(), world, failed, tag)
 
+    def child_port(parent_port, level):
+        """rendezvous port of the child processes: rank 0 asks the OS for a free one and publishes it in the parent's store (the
+        ranks of one node share 127.0.0.1); `parent_port + 1` may belong to somebody else"""
+        if world == 1:
+            return free_port(parent_port + 1)
+        store = torch.distributed.distributed_c10d._get_default_store()
+        key = f"bench_child_port_{level}"
+        if rank == 0:
+            store.set(key, str(free_port(parent_port + 1)))
+        store.wait([key])
+        return int(store.get(key))
+
     def relaunch(level):
         """The next form of the step — level 1: collectives outside the graph, level 2: no graph — in a CHILD process per rank
         (same RANK / WORLD_SIZE, rendezvous one port further; the parent only waits and leaves with the child's exit code: it
@@ -1115,7 +1156,7 @@ def main():
         env = dict(os.environ)
         env["VDETR_BENCH_FALLBACK"] = str(level)
         if "MASTER_PORT" in env:
-            env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
+            env["MASTER_PORT"] = str(child_port(int(env["MASTER_PORT"]), level))
         env.pop("TORCHELASTIC_RUN_ID", None)
         for k in ("TORCHELASTIC_USE_AGENT_STORE",):  # the child forms its own store on the new port
             env[k] = "False"

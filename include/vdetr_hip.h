@@ -156,7 +156,7 @@ typedef struct vdetr_attn_desc {
          vdetr_attn_delta_f32 fills words 0, 1, 4 and 5 (4 and 5 only when the descriptor carries the RPE operands), vdetr_attn_bwd_scores_f32 then distributes the queries dynamically
          over its workgroups (a CU busy with other work costs 1/8 of a round, not a whole one), takes the fixed-point
          scale from the Cauchy-Schwarz bound and, when word 4 is 0 and word 5 is set (and there is no rotation operand), runs the
-         axis-aligned-box kernel (attn_bwd_box.hip) instead of the general one.  NULL: static distribution. --- */
+         axis-aligned-box kernel (attn_bwd_box4.hip) instead of the general one.  NULL: static distribution. --- */
   uint32_t* bwd_aux;
   /* --- launch shape (ABI 3).  0 = the library's default in every field.  Per call and re-entrant: these fields replace the
          process-wide setters of ABI 2 (vdetr_attn_bwd_table_set_grid, vdetr_attn_bwd_kv_set_waves). --- */

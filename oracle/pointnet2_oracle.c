@@ -17,13 +17,26 @@
  *     t = b*b;  t = fma(a,a,t);  t = fma(c,c,t)
  * and is written with explicit fmaf() so that no compiler flag changes it (build with
  * -ffp-contract=off).  The HIP kernels use the same order (v-detr_amd/csrc/common.h sqdist3).
+ * ORACLE_SQ3_ORDER selects the other orders a CUDA build could have produced — 1: the first product rounded
+ * (t = a*a; t = fma(b,b,t); t = fma(c,c,t)), 2: no contraction ((a*a + b*b) + c*c, nvcc -fmad=false) — for
+ * oracle/fps_order_exposure.py, which counts the sampled indices that depend on the choice;
+ * common.h's VDETR_SQDIST_ORDER is the kernels' matching build constant.
  */
+#ifndef ORACLE_SQ3_ORDER
+#define ORACLE_SQ3_ORDER 0
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+#if ORACLE_SQ3_ORDER == 0
 static inline float sq3(float a, float b, float c) { return fmaf(c, c, fmaf(a, a, b * b)); }
+#elif ORACLE_SQ3_ORDER == 1
+static inline float sq3(float a, float b, float c) { return fmaf(c, c, fmaf(b, b, a * a)); }
+#else
+static inline float sq3(float a, float b, float c) { const float t = a * a + b * b; return t + c * c; }
+#endif
 
 /* cuda_utils.h:17-21  opt_n_threads */
 static int ref_block(int work) {

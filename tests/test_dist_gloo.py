@@ -435,6 +435,20 @@ def test_bench_ranks_agree_on_a_failed_capture():
     assert res[0] == res[1] == [False, True, True, True, False]
 
 
+def test_bench_child_rendezvous_port_is_a_free_one():
+    """bench.free_port: the children of the fallback chain rendezvous on `parent port + 1` only if nothing listens there"""
+    import socket
+    import bench
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as held:
+        held.bind(("127.0.0.1", 0))
+        held.listen(1)
+        busy = held.getsockname()[1]
+        got = bench.free_port(busy)
+        assert got != busy and got > 0
+    free = _free_port()
+    assert bench.free_port(free) == free
+
+
 def test_bench_sampling_fork_layer_rule():
     """bench.fps_fork_layer: where the next scene's sampling branch is forked, from the two measured times.  The measured cases of
     round 5 (profiles/r05_step_bounds.txt): C2 6.92 / 4.21 ms -> layer 2 (measured best: 6.78 ms; layers 1 / 3: 6.87 / 6.93); C4

@@ -677,7 +677,7 @@ def test_kv_images_packed_ahead_equal_the_forwards_own(B, nQ, nK, n):
     kv = torch.randn((B, nK, n * 128), generator=g).to(DEV)
     q = torch.randn((B, nQ, 256), generator=g).to(DEV)
     imgs = A.pack_kv_images(kv, n)
-    assert imgs is not None and imgs.shape[0] == n
+    assert imgs is not None and len(imgs) == n and all((im.parts, im.B, im.nK) == (3, B, nK) for im in imgs)
     kw = dict(num_heads=4, scale=0.125, shared_kv=True, table=tables.to(DEV), rpe=A.RPEConfig(), vertices=verts.to(DEV).contiguous(),
               xyz=xyz.to(DEV))
     parts = kv.view(B, nK, 2 * n, 64).unbind(2)
@@ -685,6 +685,17 @@ def test_kv_images_packed_ahead_equal_the_forwards_own(B, nQ, nK, n):
         own = A.fused_attention(q, parts[2 * i], parts[2 * i + 1], **kw)
         ahead = A.fused_attention(q, parts[2 * i], parts[2 * i + 1], kv_img=imgs[i], **kw)
         assert torch.equal(own, ahead), f"layer {i}"
+    # an image packed for another part count or other sizes is refused, not read
+    one_part = A.pack_kv_images(kv, n, parts=1)
+    with pytest.raises(RuntimeError, match="kv_img was packed for parts=1"):
+        A.fused_attention(q, parts[0], parts[1], kv_img=one_part[0], **kw)
+    A.fused_attention(q, parts[0], parts[1], kv_img=one_part[0], operand_bf16=True, **kw)
+    if nK > 16:
+        short = A.pack_kv_images(kv[:, :nK - 16].contiguous(), n)
+        with pytest.raises(RuntimeError, match="kv_img was packed for"):
+            A.fused_attention(q, parts[0], parts[1], kv_img=short[0], **kw)
+    with pytest.raises(TypeError):
+        A.fused_attention(q, parts[0], parts[1], kv_img=imgs[0].data, **kw)
 
 
 def test_table_gradient_with_boxes_vouched_for():

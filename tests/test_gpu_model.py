@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _make_model(nq=64, npre=512, nl=3, angle_type="", seed=0):
+def _make_model(nq=64, npre=512, nl=3, angle_type="", seed=0, rotated=None):
     from oracle.param_fill import fill_module
     from vdetr_amd.dataset_config import RotatedBoxDatasetConfig, ScannetDatasetConfig
     from vdetr_amd.model_vdetr import build_vdetr, default_args
     torch.manual_seed(seed)
     args = default_args(dec_nlayers=nl, nqueries=nq, preenc_npoints=npre, angle_type=angle_type)
-    ds = RotatedBoxDatasetConfig() if angle_type else ScannetDatasetConfig()
+    ds = RotatedBoxDatasetConfig() if (angle_type if rotated is None else rotated) else ScannetDatasetConfig()
     model = build_vdetr(args, ds)
     fill_module(model)
     with torch.no_grad():
@@ -456,6 +456,40 @@ def test_side_stream_table_gradient_equals_the_inline_one(defer):
             assert float((res["1"][n] - g).abs().max()) <= 1e-3 * float(g.abs().max()), n
         else:
             assert torch.equal(res["1"][n], g), n
+
+
+def test_rotated_boxes_in_world_coordinates_keep_the_general_table_kernel():
+    """A dataset with angle bins and the reference's DEFAULT ``angle_type = ""`` (main.py:111): the fused box decode hands the next
+    layer ROTATED corners and no (cos, sin) operand travels with the attention.  The decoder must not vouch for axis-aligned boxes
+    then (vdetr_attn_desc.bwd_kernel = 2 would let the box-only kernel poison the table gradient with NaN): every RPE-table MLP
+    gradient is finite and equals the general kernel's (VDETR_BWD_KERNEL = 1 form)."""
+    from vdetr_amd import attention as A
+    model = _make_model(nq=64, npre=512, nl=4, angle_type="", rotated=True).to(DEV).train()
+    _zero_dropout(model)
+    inp = _inputs(3000, 7, DEV, 2)
+    with torch.no_grad():  # make the angle heads speak: residual / class logits of a size that rotates the boxes visibly
+        for h in model.decoder.mlp_heads:
+            for k in ("angle_cls_head", "angle_residual_head"):
+                h[k].layers[-1].bias.add_(torch.linspace(-0.5, 0.5, h[k].layers[-1].bias.numel(), device=DEV))
+    res = {}
+    keep = A.BWD_KERNEL
+    try:
+        for kern in (0, 1):
+            A.BWD_KERNEL = kern
+            A.reset_rng()
+            model.zero_grad(set_to_none=True)
+            out = model(inp)
+            ang = torch.cat([o["angle_continuous"].flatten() for o in out["aux_outputs"][1:]])
+            assert float(ang.abs().max()) > 0.05, "the case must rotate its boxes"
+            _loss(out).backward()
+            torch.cuda.synchronize()
+            res[kern] = {n: p.grad.clone() for n, p in model.named_parameters() if "cpb_mlps" in n and p.grad is not None}
+    finally:
+        A.BWD_KERNEL = keep
+    assert res[0] and res[0].keys() == res[1].keys()
+    for n, g in res[0].items():
+        assert torch.isfinite(g).all(), n
+        assert float((g - res[1][n]).abs().max()) <= 1e-3 * float(res[1][n].abs().max()) + 1e-12, n
 
 
 @pytest.mark.parametrize("B,N", [(1, 4096), (3, 1000), (2, 1), (1, 8192), (2, 9000), (1, 77)])

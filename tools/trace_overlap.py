@@ -43,7 +43,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--allreduce":
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 win = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
-pat = sys.argv[3] if len(sys.argv) > 3 else "attn_bwd_box2"
+pat = sys.argv[3] if len(sys.argv) > 3 else "attn_bwd_box4"
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 end = max(r["e"] for r in rows)

@@ -371,18 +371,3 @@ def require_int(t, name):
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-
-
-_sched_words = {}
-
-
-def sched_word(device):
-    """The zero device word of the persistent forward's item counter (``vdetr_attn_desc.fwd_sched``): one per (device, stream),
-    allocated zeroed once; every launch leaves it zero, launches of one stream never overlap."""
-    device = torch.device(device)
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(device).cuda_stream)
-    t = _sched_words.get(key)
-    if t is None:
-        t = _sched_words[key] = torch.zeros(4, dtype=torch.int32, device=device)
-    return t

@@ -502,8 +502,6 @@ def _desc(kind, B, H, nQ, nK, scale, table, rpe, vertices, xyz, cos_sin, mask, d
     d.seed = int(salt) & 0xFFFFFFFFFFFFFFFF
     if rng_state is not None:
         d.rng_state = rng_state.data_ptr()
-    if table is not None and table.is_cuda:
-        d.fwd_sched = L.sched_word(table.device).data_ptr()
     d.fwd_kernel = FWD_KERNEL
     d.bwd_kernel = BWD_KERNEL
     d.table_grid = TABLE_GRID
@@ -562,7 +560,22 @@ class _FusedAttention(Function):
         if operand_bf16 and not bf16 and FWD_KERNEL == 0:
             d.fwd_kernel = 3  # f32 tensors, q / k / v rounded to one bf16 part each inside the kernels (vdetr_hip.h)
         if kv_img is not None and not bf16 and FWD_KERNEL == 0:
-            d.kv_img = kv_img.data_ptr()  # this call's K / V operand images (pack_kv_images, same part count)
+            # this call's K / V operand images (pack_kv_images): packed for THIS part count and THESE sizes, or the kernel reads
+            # a one-part image as three parts (or runs off its end) without any error
+            if not isinstance(kv_img, KVImage):
+                raise TypeError("fused_attention: kv_img must be an item of pack_kv_images()")
+            want = 1 if operand_bf16 else 3
+            if (kv_img.parts, kv_img.B, kv_img.nK) != (want, B, nK) or kv_img.data.device != q.device:
+                raise RuntimeError(f"fused_attention: kv_img was packed for parts={kv_img.parts}, B={kv_img.B}, nK={kv_img.nK} on "
+                                   f"{kv_img.data.device}; this call needs parts={want}, B={B}, nK={nK} on {q.device}")
+            d.kv_img = kv_img.data.data_ptr()
+        sched = None
+        if table is not None:
+            # the persistent forward's item counter: a zero word of THIS launch's own (a slice of the step's zero pool, which a
+            # captured step re-zeroes at every replay) — a word shared by a stream's launches is baked into every graph captured
+            # there, and two such graphs replayed side by side, or one launch that aborts, corrupt each other's item counts
+            sched = _take_zeros(q, (4,), torch.int32)
+            d.fwd_sched = sched.data_ptr()
         nbytes = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
         ws = L.workspace(nbytes, q.device) if nbytes else None
         fwd = lib.vdetr_attn_fwd_bf16 if bf16 else lib.vdetr_attn_fwd_f32
@@ -767,10 +780,18 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
                                  bool(table_grad_async), kv_img, bool(vertices_are_boxes), bool(operand_bf16))
 
 
+class KVImage:
+    """one attention call's K / V operand image (a row of pack_kv_images' buffer) with what it was packed for"""
+    __slots__ = ("data", "parts", "B", "nK")
+
+    def __init__(self, data, parts, B, nK):
+        self.data, self.parts, self.B, self.nK = data, int(parts), int(B), int(nK)
+
+
 def pack_kv_images(kv, n, parts=3):
     """kv [B, nK, n * 128] f32, the joint K | V projection of n cross-attention layers (layer i: columns 128 i .. + 63 = K,
-    + 64 .. + 127 = V) -> uint8 [n, bytes]: each layer's operand images for the persistent forward (fused_attention(kv_img=)),
-    one launch for all layers.  parts: 3 = f32 accuracy (the default forward), 1 = operands rounded to bf16
+    + 64 .. + 127 = V) -> n KVImage items (rows of one uint8 [n, bytes] buffer): each layer's operand images for the persistent forward
+    (fused_attention(kv_img=)), one launch for all layers.  parts: 3 = f32 accuracy (the default forward), 1 = operands rounded to bf16
     (fused_attention(operand_bf16=True)).  None where the forward would not use them."""
     if (FWD_KERNEL != 0 or not kv.is_cuda or kv.dtype != torch.float32 or not kv.is_contiguous() or kv.shape[2] != n * 2 * HEAD_DIM
             or kv.data_ptr() % 16):
@@ -781,7 +802,7 @@ def pack_kv_images(kv, n, parts=3):
     img = torch.empty((n, nbytes), dtype=torch.uint8, device=kv.device)
     L.check(lib.vdetr_attn_pack_kv_parts_f32(kv.data_ptr(), kv.data_ptr() + 4 * HEAD_DIM, B, nK, kv.shape[2], kv.shape[2], n, 2 * HEAD_DIM,
                                              parts, img.data_ptr(), L.stream_ptr()), "attn_pack_kv")
-    return img
+    return [KVImage(img[i], parts, B, nK) for i in range(n)]
 
 
 def attention_probabilities(q, k, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,

@@ -1,7 +1,7 @@
 // attn_bwd_box4.hip — 3DV-RPE table gradient for axis-aligned boxes from a given dS, fourth design (gfx950; round 4).
 //
 // Reference math: vdetr_transformer.py:710-731 backward (grid_sampler_3d_backward of the eight per-vertex tables).
-// Contract of attn_bwd_box2.hip in its dS-given mode (z-half workgroups that pull queries from a device counter, device gate
+// Contract of the round-2 box kernel (attn_bwd_box2.hip, deleted in round 5: `git log`) in its dS-given mode (z-half workgroups that pull queries from a device counter, device gate
 // on bwd_aux[4] / [5], int32 fixed-point histogram in LDS, one partial table per workgroup).
 //
 // What the two earlier designs showed: with the 64 KB histogram a CU holds ONE 16-wave workgroup, a
@@ -85,7 +85,7 @@ void attn_bwd_box4_kernel(AttnParams P) {
   const int per_wg = (items + nwg - 1) / nwg;
   const int cap = bwd_query_cap(per_wg);
   float fix_scale = 1.f, fix_inv = 1.f;
-  {  // the bound of attn_bwd_box2.hip: |bin sum| <= queries of this workgroup x 2 drop_scale max|dO row| max|V row|
+  {  // the bound of the round-2 box kernel: |bin sum| <= queries of this workgroup x 2 drop_scale max|dO row| max|V row|
     const float dmax = sqrtf(__uint_as_float(P.bwd_aux[0]) * __uint_as_float(P.bwd_aux[1]));
     const float bound = 2.f * P.drop_scale * dmax * (float)cap;
     if (bound > 0.f && bound < INFINITY) {

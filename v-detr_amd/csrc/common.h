@@ -58,8 +58,20 @@ inline int set_lds(K kernel, size_t bytes, const char* op) {
 //   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
 // (sampling_gpu.cu:106-107, ball_query_gpu.cu:34-35, interpolate_gpu.cu:36): t = dy*dy; t = fma(dx,dx,t);
 // t = fma(dz,dz,t).  The oracle (oracle/pointnet2_oracle.c) pins the same order.
+// VDETR_SQDIST_ORDER is the documented build constant for the day somebody holds this library against the CUDA binary and finds
+// nvcc chose differently: 0 (default) as above; 1: t = dx*dx; t = fma(dy,dy,t); t = fma(dz,dz,t); 2: no contraction.  How many
+// sampled indices depend on it: oracle/fps_order_exposure.py, profiles/r06_fps_order_exposure.txt.
+#ifndef VDETR_SQDIST_ORDER
+#define VDETR_SQDIST_ORDER 0
+#endif
 __device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+#if VDETR_SQDIST_ORDER == 0
   return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+#elif VDETR_SQDIST_ORDER == 1
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+#else
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+#endif
 }
 
 }  // namespace vdetr

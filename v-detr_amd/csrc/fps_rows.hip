@@ -275,7 +275,7 @@ __global__ __launch_bounds__(W * kWave) void fps_rows_kernel(RowsParams Pin) {
     const int pos = atomicAdd(&s_hist[hidx(cell)], 1) + (int)((unsigned)s_leaf[cell] >> 13);
     // origin-skip rule: `if (mag <= 1e-3) continue;` compares the float mag against a DOUBLE literal
     // (sampling_gpu.cu:103-104); mag in the same contraction order as the distance.
-    const float mag = __fmaf_rn(z, z, __fmaf_rn(x, x, __fmul_rn(y, y)));
+    const float mag = sqdist3(x, y, z);
     const bool skip = (double)mag <= 1e-3;
     pts[pos] = make_float4(x, y, z, skip ? -INFINITY : 1e10f);
     keys[pos] = fps_tie_key((unsigned)k, rb, S.ref_log2);

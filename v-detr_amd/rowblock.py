@@ -435,7 +435,9 @@ def usable(layer, tgt, query_pos, masks):
     return bool(tgt.is_cuda and tgt.dtype == torch.float32 and tgt.dim() == 3 and tgt.shape[-1] == C and all(m is None for m in masks)
                 and type(sa) is MultiheadSelfAttention and sa.embed_dim == C and type(ca) is GlobalShareCrossAttention
                 and ca.q.weight.shape == (C, C) and ca.proj.weight.shape == (C, C) and ca.q.bias is not None
+                and ca.proj.bias is not None and sa.in_proj_bias is not None and sa.out_proj.bias is not None
                 and layer.linear1.weight.shape == (C, C) and layer.linear2.weight.shape == (C, C)
+                and layer.linear1.bias is not None and layer.linear2.bias is not None  # (a bias-free layer: the unfused path)
                 and type(layer.activation) is torch.nn.ReLU and all(_plain_ln(m) for m in (layer.norm1, layer.norm2, layer.norm3))
                 and (query_pos is None or query_pos.shape == tgt.shape))
 

@@ -1126,7 +1126,11 @@ class TransformerDecoder(nn.Module):
             own_boxes = False
             if idx > 0:
                 reference_point = box_prediction.pop("_reference_point_lidar", None)  # written by the fused box decode
-                own_boxes = reference_point is not None  # corners out of box_decode.hip: boxes by construction
+                # corners out of box_decode.hip are AXIS-ALIGNED boxes only for a dataset without angle bins: with num_angle_bin > 1
+                # the decode rotates them by the predicted angle, and unless the attention works in the object's frame
+                # (angle_type "object_coords": cos / sin travel with the call and the kernels undo the rotation) the general
+                # table-gradient kernel must stay in front — vouching here would let the box-only kernel poison dtable with NaN
+                own_boxes = reference_point is not None and self.box_processor.dataset_config.num_angle_bin == 1
                 if reference_point is None:
                     reference_point = convert_corners_camera2lidar(box_prediction["box_corners"].detach())
                 reference_center = box_prediction["center_unnormalized"].detach()
