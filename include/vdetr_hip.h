@@ -809,6 +809,67 @@ int vdetr_pos_embed_fourier_f32(const float* xyz, int b, int n, const float* ran
 int vdetr_pos_embed_sine_f32(const float* xyz, int b, int n, const float* range_min, const float* range_max,
                              int num_channels, float temperature, float scale, float* out, vdetr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * The five box heads of a decoder stage as three launches (heads.hip, round 6) — reference
+ * models/vdetr_transformer.py:244-285 (five GenericMLPs on the same features) + models/helpers.py:74-141
+ * (Conv1d -> BatchNorm1d -> ReLU -> Dropout, twice, -> Conv1d); training mode (batch statistics).
+ *   launch 1   pre1 = W1 x                                   [G*256 channels] + per-32-token partial statistics
+ *   launch 2   h1 = drop(relu(bn1(pre1)));  pre2[g] = W2[g] h1[g]         + partial statistics
+ *   launch 3   h2 = drop(relu(bn2(pre2)));  y[g] = W3[g] h2[g] + b3[g]
+ * The BatchNorm statistics of a channel are merged (Chan) from the partials by every workgroup that needs them: no atomics,
+ * no grid barrier, bit-reproducible.  Everything the existing backward reads is written as the separate launches wrote it
+ * (pre1, h1, pre2, h2 as [B, G*256, N], save_mean / save_invstd, the same dropout streams: bn_common.h).
+ * Needs N % 32 == 0, G <= 8, rows <= 32, 16-B aligned operands; `workspace` of vdetr_heads_workspace_bytes(B, N, G).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vdetr_heads_desc {
+  int32_t B, N;            /* scenes, tokens per scene */
+  int32_t G, rows;         /* heads of the stage (5), rows of a head's zero-padded output slab */
+  const float* x;          /* [N, B, 256] the stage's features, sequence-first (the decoder layer's normed output) */
+  const float* w1t;        /* [G][256 in][256 out]: transposed images of the first layers (vdetr_rb_transpose_f32) */
+  const float* w2t;        /* [G][256 in][256 out]: of the second layers */
+  const float* w3;         /* [G][rows][256] */
+  const float* b3;         /* [G][rows] */
+  const float *gamma1, *beta1, *gamma2, *beta2;                 /* [G*256] */
+  float *running_mean1, *running_var1, *running_mean2, *running_var2; /* [G*256], updated in place (all four or none) */
+  int64_t* counters1[8];   /* num_batches_tracked of the G BatchNorm modules of block 1 (NULL entries are skipped): += 1 */
+  int64_t* counters2[8];
+  float eps, momentum;
+  float p1, p2;            /* dropout rates behind the two hidden blocks */
+  uint64_t salt1, salt2;   /* their streams (vdetr_bnact_desc.seed of the one-launch-per-block form) */
+  const uint64_t* rng_state;
+  float *pre1, *h1, *pre2, *h2;                                 /* [B, G*256, N] */
+  float *save_mean1, *save_invstd1, *save_mean2, *save_invstd2; /* [G*256] */
+  float* y;                /* [B, G, rows, N] */
+  void* workspace;
+} vdetr_heads_desc;
+size_t vdetr_heads_workspace_bytes(int B, int N, int G);
+int vdetr_heads_fwd_f32(const vdetr_heads_desc* d, vdetr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * PositionEmbeddingLearned (models/helpers.py:17-33: Conv1d(cin, 256) -> BatchNorm1d -> ReLU -> Conv1d(256, 256)) on DETACHED
+ * box coordinates, training mode, ONE launch (heads.hip).  The first convolution is linear in `cin` (<= 8) coordinates, so the
+ * batch statistics of its 256 outputs follow from the coordinates' mean and covariance (accumulated in fp64 by every workgroup
+ * over all B*N tokens): no second pass, no cross-workgroup exchange.
+ *   x [B, N, cin] -> hpre [B, 256, N] (first convolution WITHOUT its bias: it cancels under batch statistics and only enters
+ *   the running mean), hact [B, 256, N] = relu(bn(hpre)), out [N, B, 256] = hact^T W2^T + b2 (sequence-first, dense).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vdetr_posmlp_desc {
+  int32_t B, N, cin;
+  const float* x;          /* [B, N, cin] */
+  const float* w1;         /* [256][cin] */
+  const float* b1;         /* [256] or NULL */
+  const float *gamma, *beta;
+  float *running_mean, *running_var; /* both or none */
+  int64_t* counter;        /* num_batches_tracked or NULL */
+  float eps, momentum;
+  const float* w2t;        /* [256 in][256 out] transposed image of the second convolution */
+  const float* b2;         /* [256] or NULL */
+  float *hpre, *hact;      /* [B, 256, N] */
+  float *save_mean, *save_invstd; /* [256] */
+  float* out;              /* [N, B, 256] */
+} vdetr_posmlp_desc;
+int vdetr_pos_mlp_fwd_f32(const vdetr_posmlp_desc* d, vdetr_stream_t stream);
+
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);

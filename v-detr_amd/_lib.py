@@ -156,6 +156,27 @@ class BnActDesc(ctypes.Structure):
                                                 ("stats_given", ctypes.c_int32)]
 
 
+class HeadsDesc(ctypes.Structure):
+    """Mirror of ``vdetr_heads_desc``."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "N", "G", "rows")] + [
+        (n, c_void_p) for n in ("x", "w1t", "w2t", "w3", "b3", "gamma1", "beta1", "gamma2", "beta2", "running_mean1", "running_var1",
+                                "running_mean2", "running_var2")] + [
+        ("counters1", c_void_p * 8), ("counters2", c_void_p * 8), ("eps", c_float), ("momentum", c_float), ("p1", c_float),
+        ("p2", c_float), ("salt1", ctypes.c_uint64), ("salt2", ctypes.c_uint64), ("rng_state", c_void_p)] + [
+        (n, c_void_p) for n in ("pre1", "h1", "pre2", "h2", "save_mean1", "save_invstd1", "save_mean2", "save_invstd2", "y",
+                                "workspace")]
+
+
+class PosMlpDesc(ctypes.Structure):
+    """Mirror of ``vdetr_posmlp_desc``."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "N", "cin")] + [
+        (n, c_void_p) for n in ("x", "w1", "b1", "gamma", "beta", "running_mean", "running_var", "counter")] + [
+        ("eps", c_float), ("momentum", c_float)] + [
+        (n, c_void_p) for n in ("w2t", "b2", "hpre", "hact", "save_mean", "save_invstd", "out")]
+
+
 class BnActGrads(ctypes.Structure):
     """Mirror of ``vdetr_bnact_grads``."""
 
@@ -265,6 +286,9 @@ _SIGNATURES = {
     "vdetr_relu_dropout_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_float, c_void_p]),
     "vdetr_bn_act_fwd_f32": (c_int, [ctypes.POINTER(BnActDesc), c_void_p]),
     "vdetr_bn_stats_f32": (c_int, [ctypes.POINTER(BnActDesc), c_void_p, c_void_p, c_void_p]),
+    "vdetr_heads_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vdetr_heads_fwd_f32": (c_int, [ctypes.POINTER(HeadsDesc), c_void_p]),
+    "vdetr_pos_mlp_fwd_f32": (c_int, [ctypes.POINTER(PosMlpDesc), c_void_p]),
     "vdetr_bn_act_bwd_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_void_p]),
     "vdetr_bn_act_bwd_batch_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_int, c_void_p]),
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),

@@ -10,37 +10,9 @@
 // (momentum, unbiased variance) as nn.BatchNorm1d does; eval mode normalises with the running statistics.
 // The dropout mask is the counter-based hash of attn_common.h keyed by (channel, element): backward regenerates it.
 #include "attn_common.h"
+#include "bn_common.h"
 
 namespace vdetr {
-
-struct BnRng {
-  unsigned seed_lo, seed_hi, off_lo, off_hi, thresh;
-  float scale;
-};
-__device__ __forceinline__ BnRng bn_rng(const vdetr_bnact_desc& d) {
-  BnRng r;
-  unsigned long long s = d.seed, o = d.offset;
-  if (d.rng_state) { s ^= d.rng_state[0]; o += d.rng_state[1]; }
-  r.seed_lo = (unsigned)s; r.seed_hi = (unsigned)(s >> 32); r.off_lo = (unsigned)o; r.off_hi = (unsigned)(o >> 32);
-  r.thresh = 0; r.scale = 1.f;
-  if (d.dropout_p > 0.f) {
-    int t = (int)((double)d.dropout_p * 65536.0 + 0.5);
-    t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
-    r.thresh = (unsigned)t;
-    r.scale = 65536.f / (float)(65536 - t);
-  }
-  return r;
-}
-__device__ __forceinline__ unsigned bn_chankey(const BnRng& g, int c) {
-  const unsigned x = fmix32(((unsigned)c * 0x9E3779B1u + g.off_lo) ^ g.seed_lo);
-  return fmix32(x ^ (0x27D4EB2Fu + g.off_hi) ^ g.seed_hi);
-}
-// keep flag of element e (index within the channel's B*N elements)
-__device__ __forceinline__ bool bn_keep(const BnRng& g, unsigned chankey, int e) {
-  if (!g.thresh) return true;
-  const unsigned x = fmix32(chankey ^ ((unsigned)(e >> 1) * 0x165667B1u));
-  return ((e & 1) ? (x >> 16) : (x & 0xFFFFu)) >= g.thresh;
-}
 
 constexpr int kBnThreads = 256;  // 4 channels per workgroup
 

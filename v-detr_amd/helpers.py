@@ -436,7 +436,15 @@ class _PosEmbedDeferred(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):  # params: listed so that the output requires grad; their gradients come at the flush
         from . import bn_act as BNA
+        from . import heads as HD
         conv1, bn, _, conv2 = module.position_embedding_head
+        x_tok = x.transpose(1, 2)  # (the caller's [B, N, cin] coordinates)
+        if conv2.bias is not None and HD.pos_mlp_usable(module, x_tok):
+            # the whole block as ONE launch (csrc/heads.hip: the batch statistics of the first convolution follow from the
+            # coordinates' mean and covariance); it writes what DeferredPosEmbedGrads.flush reads
+            out, hact, rec, _ = HD.pos_mlp_forward(module, x_tok)
+            ctx.rec = (module, x, hact, rec)
+            return out.permute(1, 2, 0)  # [B, C, N] view of the dense sequence-first result
         h = PointwiseConv1d.forward_no_bias(conv1, x)
         y, rec = BNA.forward_record(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, 0.0, 0,
                                     counters=[bn.num_batches_tracked], pre_bias=conv1.bias)

@@ -29,6 +29,7 @@ from . import add_ln as ALN
 from . import bn_act as BNA
 from . import attention as A
 from . import box_decode
+from . import heads as HD
 from . import rowblock as RB
 from .helpers import (ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, GenericMLP, PointwiseConv1d,
                       PositionEmbeddingLearned, buffers_alias, cat_params, get_clones, linear, linear_pair, slot_stack_params,
@@ -932,10 +933,12 @@ class TransformerDecoder(nn.Module):
                 return False
         return True
 
-    def _run_heads_recorded(self, heads, feats, slot=None):
+    def _run_heads_recorded(self, heads, feats, slot=None, seq=None):
         """_run_heads for one stage with every launch outside autograd; returns (y [B,5,rows,N], chans, record).  ``slot`` =
         (shared dictionary, index, count): the hidden activations go straight into slice `index` of buffers stacked over
-        the `count` deferred stages, which is how the batched backward wants them."""
+        the `count` deferred stages, which is how the batched backward wants them.  ``seq``: the same features as the dense
+        sequence-first tensor [N,B,C] they are a view of — where given and the shapes fit, the stage's heads are the three
+        launches of csrc/heads.hip (same values, same records; heads.py)."""
         names = self._HEAD_NAMES
         L = [heads[n].layers for n in names]
         G, C = len(L), feats.shape[1]
@@ -958,6 +961,17 @@ class TransformerDecoder(nn.Module):
             for k in ("h1", "h2"):
                 if k not in stk:
                     stk[k] = feats.new_empty((ns, Bsz, G * C, N))
+        if seq is not None and HD.heads_usable(seq, L, rows):
+            with torch.no_grad():
+                f = feats.detach()
+                rm1, rv1 = buffers_alias([l[1].running_mean for l in L]), buffers_alias([l[1].running_var for l in L])
+                rm2, rv2 = buffers_alias([l[5].running_mean for l in L]), buffers_alias([l[5].running_var for l in L])
+                h1 = stk["h1"][si] if stk is not None else feats.new_empty((Bsz, G * C, N))
+                h2 = stk["h2"][si] if stk is not None else feats.new_empty((Bsz, G * C, N))
+                y, bn1, bn2 = HD.heads_forward(seq.detach(), L, (g1, b1, g2, b2, w3, b3), (rm1, rv1, rm2, rv2), salts, rows, h1, h2)
+            record = {"f": f, "h1": h1, "h2": h2, "bn1": bn1, "bn2": bn2, "y": y, "stack": (stk, si) if stk is not None else None,
+                      "w1": w1, "g1": g1, "b1": b1, "w2": w2, "g2": g2, "b2": b2, "w3": w3, "b3": b3}
+            return y, outs, record
         with torch.no_grad():
             f = feats.detach()  # [B,C,N] view of the [nQ,B,C] layer output: the GEMM reads it transposed, no copy
             w1d = w1.detach().squeeze(-1)
@@ -986,7 +1000,7 @@ class TransformerDecoder(nn.Module):
         feats = box_features.permute(1, 2, 0)
         if not self._heads_recordable(heads, feats):
             return None
-        ran = self._run_heads_recorded(heads, feats, slot)
+        ran = self._run_heads_recorded(heads, feats, slot, box_features if box_features.is_contiguous() else None)
         if ran is None:
             return None
         y, chans, record = ran
@@ -1115,6 +1129,8 @@ class TransformerDecoder(nn.Module):
         if (fuse_ln and _ROWBLOCK and output.is_cuda and memory_mask is None and
                 all(RB.usable(l, output, None, ()) and not l.pos_for_key for l in self.layers)):
             RB.refresh(self.layers)  # the fused glue launches' weight images of all layers: one launch (rowblock.py)
+        if self.training and output.is_cuda and torch.is_grad_enabled():
+            HD.decoder_refresh(self)  # ... and those of the stages' heads and the position MLPs (heads.py)
         defer = _DEFER_HEADS and self.mlp_sep and self.return_intermediate and len(self.layers) > 1
         deferred, stacked = [], {}
         for idx, layer in enumerate(self.layers):
@@ -1174,6 +1190,7 @@ class TransformerDecoder(nn.Module):
                     attn = torch.gather(attn, 3, inv)
                 attns.append(attn)
 
+        HD._fresh["on"] = False  # (the images are this forward's: the weights change at the next optimiser step)
         if deferred:
             self._attach_deferred([r for r, _ in deferred], [p for _, p in deferred])
         for extra in ("_reference_point_lidar", "_query_reference"):  # helpers of the loop, not part of the result
