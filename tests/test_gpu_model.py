@@ -374,12 +374,17 @@ def test_deferred_heads_backward_equals_per_stage_autograd(batch):
 
 
 @pytest.mark.parametrize("batch", [1, 2])
-def test_deferred_weight_gradients_equal_inline_ones(batch):
+def test_deferred_weight_gradients_equal_inline_ones(batch, monkeypatch):
     """runtime.defer_weight_grads: dW / db of every `linear` as shape-batched GEMMs after the backward (flush) == the
     per-layer GEMMs inside it, for plain parameters, unbound slices of a packed parameter and adjacent-parameter aliases;
     likewise the LayerNorm parameter sums (one batched launch) and the query-position embeddings' parameters."""
     from vdetr_amd import attention as A
+    from vdetr_amd import heads as HD
     from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
+    # the same FORWARD on both sides: the one-launch position MLP (csrc/heads.hip; its own test: test_gpu_heads.py) runs only with
+    # deferred gradients, and its batch statistics differ from the three-launch form's in the last bits — which this model's ReLU
+    # gates amplify past the 2e-4 this comparison of two backward SCHEDULES asserts (measured 2.9e-4 on one parameter)
+    monkeypatch.setattr(HD, "FUSED_POS", False)
     model = _make_model(nq=64, npre=512, nl=4).to(DEV).train()
     inp = _inputs(3000, 5, DEV, batch)
     model(inp)

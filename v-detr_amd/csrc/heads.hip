@@ -34,6 +34,7 @@ constexpr int kHdTok = 32;         // tokens per workgroup of the hidden layers 
 constexpr int kHdTok3 = 16;        // tokens per workgroup of the output layer / the position MLP
 constexpr int kHdStride = kHdC + 4;  // floats per LDS row: 16 rows x 1040 B land on 16 different 16-byte slots
 constexpr int kHdDepth = 4;        // weight steps (of 16 contraction indices) in flight per wave
+constexpr int kHdMergeAbove = 48;  // tiles above which the statistics partials are merged by a launch of their own
 
 struct HdRing {
   f32x4 b[kHdDepth][4];
@@ -163,11 +164,16 @@ struct HdBn {
   int64_t* counter;
 };
 __device__ __forceinline__ void hd_bn_prepare(const HdBn& S, int P, int GC, int g, int tid, float eps, float momentum, const BnRng& rg,
-                                              bool owner, float* ab, unsigned* ck) {
+                                              bool owner, float* ab, unsigned* ck, int merged) {
   const int ch = g * kHdC + tid;
   float mean, m2;
-  hd_merge(S.part, P, GC, ch, (float)kHdTok, mean, m2);
   const float n = (float)P * kHdTok;
+  if (merged) {  // heads_merge_kernel has folded the P tiles into entry 0 of the table
+    const float* p = S.part + 2 * (size_t)ch;
+    mean = p[0]; m2 = p[1];
+  } else {
+    hd_merge(S.part, P, GC, ch, (float)kHdTok, mean, m2);
+  }
   const float var = m2 / n;  // biased: what the batch is normalised with
   const float invstd = rsqrtf(var + eps);
   const float a = S.gamma[ch] * invstd, sh = S.beta[ch] - mean * a;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(kHdThreads) void heads_l1_kernel(HdArgs A) {
 }
 
 // ---- launch 2 -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kHdThreads) void heads_l2_kernel(HdArgs A) {
+__global__ __launch_bounds__(kHdThreads) void heads_l2_kernel(HdArgs A, int merged) {
   __shared__ __attribute__((aligned(16))) float xs[kHdTok * kHdStride];
   __shared__ float ab[2 * kHdC];
   __shared__ unsigned ck[kHdC];
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(kHdThreads) void heads_l2_kernel(HdArgs A) {
   for (int it = 0; it < 8; ++it) v[it] = hd_ld4(A.pre1 + base + (size_t)(64 * w + 8 * it + kk) * A.N);
   const BnRng rg = bn_rng_of(A.p1, A.salt1, 0, A.rng_state);
   const HdBn S = {hd_part(A, 0), A.gamma1, A.beta1, A.running_mean1, A.running_var1, A.save_mean1, A.save_invstd1, A.counters1[g]};
-  hd_bn_prepare(S, A.B * tps, GC, g, tid, A.eps, A.momentum, rg, blockIdx.x == 0, ab, ck);
+  hd_bn_prepare(S, A.B * tps, GC, g, tid, A.eps, A.momentum, rg, blockIdx.x == 0, ab, ck, merged);
   __syncthreads();
   const int e0 = b * A.N + q0 + 4 * tq;
 #pragma unroll
@@ -279,8 +285,19 @@ __global__ __launch_bounds__(kHdThreads) void heads_l2_kernel(HdArgs A) {
   hd_store_stats<2>(acc, A.pre2 + (size_t)b * GC * A.N, hd_part(A, 1) + (size_t)tile * GC * 2, g * kHdC + col0 + 4 * (lane & 15), q0, A.N, lane);
 }
 
+// ---- between the launches, for long sequences only: the P tile partials of every channel folded into entry 0 of the table -------
+// (every consumer workgroup merging P partials itself is P^2 work: fine at 32 tiles (1024 tokens), 335 MB of L2 reads at 128)
+__global__ __launch_bounds__(kHdThreads) void heads_merge_kernel(float* part, int P, int GC) {
+  const int ch = blockIdx.x * kHdThreads + threadIdx.x;
+  if (ch >= GC) return;
+  float mean, m2;
+  hd_merge(part, P, GC, ch, (float)kHdTok, mean, m2);
+  part[2 * (size_t)ch] = mean;       // (entry 0 is read by this thread only, and before it is written)
+  part[2 * (size_t)ch + 1] = m2;
+}
+
 // ---- launch 3 -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kHdThreads) void heads_l3_kernel(HdArgs A) {
+__global__ __launch_bounds__(kHdThreads) void heads_l3_kernel(HdArgs A, int merged) {
   __shared__ __attribute__((aligned(16))) float xs[kHdTok3 * kHdStride];
   __shared__ float ab[2 * kHdC];
   __shared__ unsigned ck[kHdC];
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(kHdThreads) void heads_l3_kernel(HdArgs A) {
   for (int it = 0; it < 4; ++it) v[it] = hd_ld4(A.pre2 + base + (size_t)(64 * w + 16 * it + kk) * A.N);
   const BnRng rg = bn_rng_of(A.p2, A.salt2, 0, A.rng_state);
   const HdBn S = {hd_part(A, 1), A.gamma2, A.beta2, A.running_mean2, A.running_var2, A.save_mean2, A.save_invstd2, A.counters2[g]};
-  hd_bn_prepare(S, A.B * (A.N / kHdTok), GC, g, tid, A.eps, A.momentum, rg, blockIdx.x == 0, ab, ck);
+  hd_bn_prepare(S, A.B * (A.N / kHdTok), GC, g, tid, A.eps, A.momentum, rg, blockIdx.x == 0, ab, ck, merged);
   __syncthreads();
   const int e0 = b * A.N + q0 + 4 * tq;
 #pragma unroll
@@ -345,104 +362,85 @@ __global__ __launch_bounds__(kHdThreads) void heads_l3_kernel(HdArgs A) {
 }
 
 // ---- the learned position embedding of a box (PositionEmbeddingLearned) -----------------------------------------------------------
+// Phases of a workgroup (16 tokens): (1) the coordinates' first and second moments over ALL B*N tokens, every workgroup for
+// itself — sums of the offsets from token 0 (the same reference everywhere: what is left to cancel in E[dd] - E[d]E[d] is the
+// spread of the boxes, not their distance from the origin), per thread in fp64, across the workgroup in fp32 (quads by DPP, one
+// lane per quad through LDS, the wave that owns a moment sums its 64 values); (2) thread = hidden channel: mean and variance of
+// w . x from the moments (fp64: 6 + 21 terms), the affine map, the channel's 16 hidden values; (3) the second convolution on the
+// matrix unit.  Everything phase 2 reads from global memory is requested before phase 1 starts.
 typedef vdetr_posmlp_desc PmArgs;
 constexpr int kPmMaxIn = 8;
-constexpr int kPmMom = kPmMaxIn + kPmMaxIn * (kPmMaxIn + 1) / 2;  // sums + upper triangle of the second moments
 
-template <int CTRL>
-__device__ __forceinline__ double hd_dpp_f64(double v) {
-  return __longlong_as_double((long long)dpp_u64<CTRL>((unsigned long long)__double_as_longlong(v)));
-}
-__device__ __forceinline__ double hd_quadsum_f64(double v) {
-  v += hd_dpp_f64<kDppQuadXor1>(v);
-  v += hd_dpp_f64<kDppQuadXor2>(v);
-  return v;
-}
-__device__ __forceinline__ double hd_wavesum_f64(double v) {  // all-reduce over the 64 lanes
-  v = hd_quadsum_f64(v);
-  v += hd_dpp_f64<kDppRowHalfMirror>(v);
-  v += hd_dpp_f64<kDppRowMirror>(v);
-  unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  {
-    const pair_u32 lo = xrow16((unsigned)u), hi = xrow16((unsigned)(u >> 32));
-    v = __longlong_as_double((long long)(((unsigned long long)hi.a << 32) | lo.a)) +
-        __longlong_as_double((long long)(((unsigned long long)hi.b << 32) | lo.b));
-    u = (unsigned long long)__double_as_longlong(v);
-  }
-  {
-    const pair_u32 lo = xhalf32((unsigned)u), hi = xhalf32((unsigned)(u >> 32));
-    v = __longlong_as_double((long long)(((unsigned long long)hi.a << 32) | lo.a)) +
-        __longlong_as_double((long long)(((unsigned long long)hi.b << 32) | lo.b));
-  }
-  return v;
-}
-
+template <int CIN>
 __global__ __launch_bounds__(kHdThreads) void pos_mlp_kernel(PmArgs A) {
+  constexpr int kMom = CIN + CIN * (CIN + 1) / 2;  // sums + upper triangle of the second moments
   __shared__ __attribute__((aligned(16))) float xs[kHdTok3 * kHdStride];
-  __shared__ double momq[kPmMom][64];
-  __shared__ double mom[kPmMom];
-  __shared__ float xt[kHdTok3][kPmMaxIn];
+  __shared__ float momq[kMom][64];
+  __shared__ float mom[kMom];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tps = A.N / kHdTok3, tile = blockIdx.x, b = tile / tps, q0 = (tile - b * tps) * kHdTok3;
-  const int col0 = 64 * w, cin = A.cin, T = A.B * A.N;
+  const int col0 = 64 * w, T = A.B * A.N;
   HdRing R;
   hd_w_begin(A.w2t, col0, lane, R);
-  // ---- first and second moments of the coordinates over ALL tokens: every workgroup computes them for itself, as fp64 sums of
-  // the coordinates' offsets from token 0 (the same reference everywhere; what is left to cancel in E[dd] - E[d]E[d] is the spread
-  // of the boxes, not their distance from the origin).  Per thread its tokens, then quads by DPP, then one lane per quad through
-  // LDS to the wave that owns the moment.
-  double s[kPmMom];
+  // what phase 2 needs: this thread's channel of the first convolution and BatchNorm, the workgroup's 16 tokens
+  const int ch = tid;
+  float wv[CIN], xt[kHdTok3][CIN], ref[CIN];
 #pragma unroll
-  for (int i = 0; i < kPmMom; ++i) s[i] = 0.0;
-  float ref[kPmMaxIn];
+  for (int i = 0; i < CIN; ++i) wv[i] = A.w1[(size_t)ch * CIN + i];
+  const float gam = A.gamma[ch], bet = A.beta[ch], bias1 = A.b1 ? A.b1[ch] : 0.f;
 #pragma unroll
-  for (int i = 0; i < kPmMaxIn; ++i) ref[i] = i < cin ? A.x[i] : 0.f;
+  for (int i = 0; i < CIN; ++i) ref[i] = A.x[i];
+#pragma unroll
+  for (int t = 0; t < kHdTok3; ++t)
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) xt[t][i] = A.x[((size_t)b * A.N + q0 + t) * CIN + i];  // (wave-uniform addresses: scalar loads)
+  // ---- phase 1 ----
+  double s[kMom];
+#pragma unroll
+  for (int i = 0; i < kMom; ++i) s[i] = 0.0;
   for (int t = tid; t < T; t += kHdThreads) {
-    double xv[kPmMaxIn];
+    float xv[CIN];
 #pragma unroll
-    for (int i = 0; i < kPmMaxIn; ++i) xv[i] = i < cin ? (double)A.x[(size_t)t * cin + i] - (double)ref[i] : 0.0;
-    int at = kPmMaxIn;
+    for (int i = 0; i < CIN; ++i) xv[i] = A.x[(size_t)t * CIN + i];
+    double dv[CIN];
 #pragma unroll
-    for (int i = 0; i < kPmMaxIn; ++i) {
-      s[i] += xv[i];
+    for (int i = 0; i < CIN; ++i) dv[i] = (double)(xv[i] - ref[i]);  // (the difference of two nearby floats: exact or nearly so)
+    int at = CIN;
 #pragma unroll
-      for (int j = i; j < kPmMaxIn; ++j) s[at++] += xv[i] * xv[j];
+    for (int i = 0; i < CIN; ++i) {
+      s[i] += dv[i];
+#pragma unroll
+      for (int j = i; j < CIN; ++j) s[at++] += dv[i] * dv[j];
     }
   }
 #pragma unroll
-  for (int i = 0; i < kPmMom; ++i) {
-    const double r = hd_quadsum_f64(s[i]);
+  for (int i = 0; i < kMom; ++i) {
+    float r = (float)s[i];
+    r += dpp_f32<kDppQuadXor1>(r);
+    r += dpp_f32<kDppQuadXor2>(r);
     if ((lane & 3) == 0) momq[i][tid >> 2] = r;
   }
   __syncthreads();
-  for (int i = w; i < kPmMom; i += 4) {
-    const double r = hd_wavesum_f64(momq[i][lane]);
+  for (int i = w; i < kMom; i += 4) {
+    const float r = wave_allsum_f32(momq[i][lane]);
     if (lane == 0) mom[i] = r;
   }
-  if (tid < kHdTok3 * kPmMaxIn) {  // this workgroup's 16 tokens
-    const int i = tid / kPmMaxIn, a = tid - i * kPmMaxIn;
-    xt[i][a] = a < cin ? A.x[((size_t)b * A.N + q0 + i) * cin + a] : 0.f;
-  }
   __syncthreads();
-  // ---- thread = hidden channel: batch statistics of w . x from the moments, then the channel's 16 hidden values ----
+  // ---- phase 2 ----
   {
-    const int ch = tid;
-    float wv[kPmMaxIn];
-#pragma unroll
-    for (int i = 0; i < kPmMaxIn; ++i) wv[i] = i < cin ? A.w1[(size_t)ch * cin + i] : 0.f;
     const double inv = 1.0 / (double)T;
-    double mu[kPmMaxIn];  // mean offset from the reference token
+    double mu[CIN];  // mean offset from the reference token
 #pragma unroll
-    for (int i = 0; i < kPmMaxIn; ++i) mu[i] = mom[i] * inv;
+    for (int i = 0; i < CIN; ++i) mu[i] = (double)mom[i] * inv;
     double mean = 0.0, var = 0.0;
-    int at = kPmMaxIn;
+    int at = CIN;
 #pragma unroll
-    for (int i = 0; i < kPmMaxIn; ++i) {
+    for (int i = 0; i < CIN; ++i) {
       mean += (double)wv[i] * (mu[i] + (double)ref[i]);
 #pragma unroll
-      for (int j = i; j < kPmMaxIn; ++j) {
-        const double cov = mom[at] * inv - mu[i] * mu[j];
+      for (int j = i; j < CIN; ++j) {
+        const double cov = (double)mom[at] * inv - mu[i] * mu[j];
         var += (i == j ? 1.0 : 2.0) * (double)wv[i] * (double)wv[j] * cov;
         ++at;
       }
@@ -450,13 +448,13 @@ __global__ __launch_bounds__(kHdThreads) void pos_mlp_kernel(PmArgs A) {
     var = var > 0.0 ? var : 0.0;
     const float meanf = (float)mean, varf = (float)var;
     const float invstd = rsqrtf(varf + A.eps);
-    const float a = A.gamma[ch] * invstd, sh = A.beta[ch] - meanf * a;
+    const float a = gam * invstd, sh = bet - meanf * a;
     if (blockIdx.x == 0) {
       A.save_mean[ch] = meanf;
       A.save_invstd[ch] = invstd;
       if (A.running_mean) {
         const float m = A.momentum, n = (float)T;
-        A.running_mean[ch] = (1.f - m) * A.running_mean[ch] + m * (meanf + (A.b1 ? A.b1[ch] : 0.f));
+        A.running_mean[ch] = (1.f - m) * A.running_mean[ch] + m * (meanf + bias1);
         A.running_var[ch] = (1.f - m) * A.running_var[ch] + m * varf * (n / (n > 1.f ? n - 1.f : 1.f));
       }
       if (tid == 0 && A.counter) A.counter[0] += 1;
@@ -466,7 +464,7 @@ __global__ __launch_bounds__(kHdThreads) void pos_mlp_kernel(PmArgs A) {
     for (int i = 0; i < kHdTok3; ++i) {
       float h = 0.f;
 #pragma unroll
-      for (int k = 0; k < kPmMaxIn; ++k) h = fmaf(xt[i][k], wv[k], h);
+      for (int k = 0; k < CIN; ++k) h = fmaf(xt[i][k], wv[k], h);
       const float act = fmaxf(h * a + sh, 0.f);
       hp[i >> 2][i & 3] = h;
       ha[i >> 2][i & 3] = act;
@@ -477,6 +475,7 @@ __global__ __launch_bounds__(kHdThreads) void pos_mlp_kernel(PmArgs A) {
     for (int i = 0; i < 4; ++i) { hd_st4(A.hpre + o + 4 * i, hp[i]); hd_st4(A.hact + o + 4 * i, ha[i]); }
   }
   __syncthreads();
+  // ---- phase 3 ----
   f32x4 acc[1][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc[0][u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -516,9 +515,14 @@ extern "C" int vdetr_heads_fwd_f32(const vdetr_heads_desc* d, vdetr_stream_t str
                     HD_ALIGNED(d->pre2) && HD_ALIGNED(d->h2) && HD_ALIGNED(d->workspace), "heads_fwd: operands must be 16-B aligned");
   hipStream_t st = (hipStream_t)stream;
   const int tiles = d->B * d->N / kHdTok;
+  const int GC = d->G * kHdC;
+  const int merged = tiles > kHdMergeAbove ? 1 : 0;
+  float* part = reinterpret_cast<float*>(d->workspace);
   hipLaunchKernelGGL(heads_l1_kernel, dim3(tiles, d->G), dim3(kHdThreads), 0, st, *d);
-  hipLaunchKernelGGL(heads_l2_kernel, dim3(tiles, d->G), dim3(kHdThreads), 0, st, *d);
-  hipLaunchKernelGGL(heads_l3_kernel, dim3(d->B * d->N / kHdTok3, d->G), dim3(kHdThreads), 0, st, *d);
+  if (merged) hipLaunchKernelGGL(heads_merge_kernel, dim3(ceil_div(GC, kHdThreads)), dim3(kHdThreads), 0, st, part, tiles, GC);
+  hipLaunchKernelGGL(heads_l2_kernel, dim3(tiles, d->G), dim3(kHdThreads), 0, st, *d, merged);
+  if (merged) hipLaunchKernelGGL(heads_merge_kernel, dim3(ceil_div(GC, kHdThreads)), dim3(kHdThreads), 0, st, part + (size_t)tiles * GC * 2, tiles, GC);
+  hipLaunchKernelGGL(heads_l3_kernel, dim3(d->B * d->N / kHdTok3, d->G), dim3(kHdThreads), 0, st, *d, merged);
   return check_launch("heads_fwd");
 }
 
@@ -529,6 +533,17 @@ extern "C" int vdetr_pos_mlp_fwd_f32(const vdetr_posmlp_desc* d, vdetr_stream_t 
   VDETR_REQUIRE(d->x && d->w1 && d->gamma && d->beta && d->w2t && d->hpre && d->hact && d->save_mean && d->save_invstd && d->out, "pos_mlp_fwd: null pointer");
   VDETR_REQUIRE((d->running_mean != nullptr) == (d->running_var != nullptr), "pos_mlp_fwd: running_mean and running_var go together");
   VDETR_REQUIRE(HD_ALIGNED(d->w2t) && HD_ALIGNED(d->b2) && HD_ALIGNED(d->hpre) && HD_ALIGNED(d->hact) && HD_ALIGNED(d->out), "pos_mlp_fwd: operands must be 16-B aligned");
-  hipLaunchKernelGGL(pos_mlp_kernel, dim3(d->B * d->N / kHdTok3), dim3(kHdThreads), 0, (hipStream_t)stream, *d);
+  const dim3 grid(d->B * d->N / kHdTok3), block(kHdThreads);
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->cin) {
+    case 1: hipLaunchKernelGGL(pos_mlp_kernel<1>, grid, block, 0, st, *d); break;
+    case 2: hipLaunchKernelGGL(pos_mlp_kernel<2>, grid, block, 0, st, *d); break;
+    case 3: hipLaunchKernelGGL(pos_mlp_kernel<3>, grid, block, 0, st, *d); break;  // (key positions: pos_for_key)
+    case 4: hipLaunchKernelGGL(pos_mlp_kernel<4>, grid, block, 0, st, *d); break;
+    case 5: hipLaunchKernelGGL(pos_mlp_kernel<5>, grid, block, 0, st, *d); break;
+    case 6: hipLaunchKernelGGL(pos_mlp_kernel<6>, grid, block, 0, st, *d); break;  // (box centre + size: the decoder's query position)
+    case 7: hipLaunchKernelGGL(pos_mlp_kernel<7>, grid, block, 0, st, *d); break;
+    default: hipLaunchKernelGGL(pos_mlp_kernel<8>, grid, block, 0, st, *d); break;
+  }
   return check_launch("pos_mlp_fwd");
 }

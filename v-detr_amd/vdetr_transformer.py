@@ -624,7 +624,7 @@ class _DeferredHeads(torch.autograd.Function):
             if k != "f" and all(x is not None and x[0] is st[0][0] and x[1] == i for i, x in enumerate(st)) and \
                     st[0][0][k].shape[0] == S:
                 return st[0][0][k]
-            return torch.stack([r[k] for r in recs])
+            return recs[0][k].unsqueeze(0) if S == 1 else torch.stack([r[k] for r in recs])
 
         h2, h1, f = stack("h2"), stack("h1"), stack("f")                      # [S,B,G*C,N] x2, [S,B,C,N]
         # (aliases of the parameter memory when dist.FlatParams laid the stages out next to each other, copies otherwise)
@@ -1063,10 +1063,21 @@ class TransformerDecoder(nn.Module):
         output = self.first_layer(enc_box_features)
         normed = self.first_layer.post_normed if fuse_ln else self.norm(output)
         self.first_layer.post_norm = self.first_layer.post_normed = None
-        box_prediction = self.get_proposal_box_predictions_refine(
-            0, query_xyz, point_cloud_dims, normed,
-            pre_center_normalized=enc_box_predictions["center_normalized"],
-            pre_size_normalized=enc_box_predictions["size_normalized"])
+        defer = _DEFER_HEADS and self.mlp_sep and self.return_intermediate and len(self.layers) > 1
+        if defer and self.training and output.is_cuda and torch.is_grad_enabled():
+            HD.decoder_refresh(self)  # the W^T images of every stage's heads and of the position MLPs: one launch (heads.py)
+        # the first stage's heads on all encoder tokens: recorded like the later stages' (the fused launches of csrc/heads.hip where
+        # the shapes fit) and differentiated by a _DeferredHeads node of its own — the last thing the backward pass reaches
+        recorded = self._stage_recorded(0, point_cloud_dims, normed, enc_box_predictions["center_normalized"],
+                                        enc_box_predictions["size_normalized"]) if defer else None
+        if recorded is not None:
+            box_prediction, rec0 = recorded
+            self._attach_deferred([rec0], [box_prediction])
+        else:
+            box_prediction = self.get_proposal_box_predictions_refine(
+                0, query_xyz, point_cloud_dims, normed,
+                pre_center_normalized=enc_box_predictions["center_normalized"],
+                pre_size_normalized=enc_box_predictions["size_normalized"])
         if self.return_intermediate:
             intermediate.append(box_prediction)
 
@@ -1129,9 +1140,8 @@ class TransformerDecoder(nn.Module):
         if (fuse_ln and _ROWBLOCK and output.is_cuda and memory_mask is None and
                 all(RB.usable(l, output, None, ()) and not l.pos_for_key for l in self.layers)):
             RB.refresh(self.layers)  # the fused glue launches' weight images of all layers: one launch (rowblock.py)
-        if self.training and output.is_cuda and torch.is_grad_enabled():
-            HD.decoder_refresh(self)  # ... and those of the stages' heads and the position MLPs (heads.py)
-        defer = _DEFER_HEADS and self.mlp_sep and self.return_intermediate and len(self.layers) > 1
+        if not defer and self.training and output.is_cuda and torch.is_grad_enabled():
+            HD.decoder_refresh(self)  # (the position MLPs' images; the stages' heads take the batched path)
         deferred, stacked = [], {}
         for idx, layer in enumerate(self.layers):
             layer.cross_cache = caches[idx]
