@@ -945,6 +945,7 @@ def main():
                     help="synthetic: scalar loss of SURVEY 8d (headline); criterion: the device set criterion on synthetic boxes")
     ap.add_argument("--no-defer-wg", action="store_true", help="weight gradients inside the backward, one GEMM per layer")
     ap.add_argument("--no-criterion-leg", action="store_true", help="skip the extra N=1 measurement with the set criterion")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the extra N=1 measurement with exact f32 products in the attention (arith.exact_f32)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-backbone-leg", action="store_true", help="skip the extra N=1 measurement with the sparse-conv backbone")
     ap.add_argument("--no-fps-prefetch", action="store_true", help="run FPS serially in front of the decoder")
@@ -1377,6 +1378,55 @@ def main():
                                "matches, 9 stages, 24 boxes/scene x repeat 5) instead of the synthetic scalar loss; "
                                "cpu_oracle_ms = the criterion alone (fwd+bwd) through oracle/criterion_oracle.py"}
 
+    def exact_leg():
+        # The label `dtype: f32`, made auditable: the same step with EXACT f32 products in the attention — the
+        # forward on v_mfma_f32_16x16x4_f32 (vdetr_attn_desc.fwd_kernel 2) and the shared-K/V backward as library f32 GEMMs around
+        # the element-wise kernel (no split-bf16 operand anywhere) — captured and timed like the headline; and what the split forms
+        # differ by from it, measured on one cross-attention layer of this configuration's size (no dropout: same masks either way).
+        from vdetr_amd import attention as _A
+        keep = (_A.FWD_KERNEL, _A.FUSED_KV_BWD)
+        try:
+            B_, nQ_, nK_ = 1, nq, npre
+            g = torch.Generator().manual_seed(11)
+            kxyz = (1 + torch.rand((B_, nK_, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0])).to(device)
+            center = kxyz[:, torch.randperm(nK_, generator=g)[:nQ_].to(device)]
+            half = (0.1 + torch.rand((B_, nQ_, 1, 3), generator=g)).to(device)
+            signs = torch.tensor([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]],
+                                 dtype=torch.float32, device=device)
+            verts = (center[:, :, None, :] + half * signs).contiguous()
+            base = [torch.randn(sh, generator=g).to(device) for sh in ((B_, nQ_, 256), (B_, nK_, 64), (B_, nK_, 64), (8, 10, 10, 10, 4))]
+            wout = torch.randn((B_, nQ_, 256), generator=g).to(device)
+            got = {}
+            for name, (fk, fused) in {"split": (0, True), "exact": (2, False)}.items():
+                _A.FWD_KERNEL, _A.FUSED_KV_BWD = fk, fused
+                ts = [t.clone().requires_grad_(True) for t in base]
+                o = _A.fused_attention(ts[0], ts[1], ts[2], num_heads=4, scale=0.125, shared_kv=True, table=ts[3], rpe=_A.RPEConfig(),
+                                       vertices=verts, xyz=kxyz)
+                (o * wout).sum().backward()
+                got[name] = [o.detach()] + [t.grad for t in ts]
+            rel = lambda x, y: float((x - y).abs().max() / y.abs().max())  # noqa: E731
+            diffs = dict(zip(("out", "dq", "dk", "dv", "dtable"), (rel(x, y) for x, y in zip(got["split"], got["exact"]))))
+            _A.FWD_KERNEL, _A.FUSED_KV_BWD = 2, False
+            t3 = make_trainer(False, fps_at_layer=getattr(trainer, "fps_at_layer", None))
+            if use_graph:
+                t3.capture()
+            for _ in range(3):
+                t3.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                t3.step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / a.steps * 1e3
+            assert np.isfinite(float(t3.loss.item())), "non-finite loss in the exact-f32 step"
+            result["arith"]["exact_f32"] = {"ms_per_step": ms, "value": bs * world / ms * 1e3,
+                                            "what": "attention forward on v_mfma_f32_16x16x4_f32 (fwd_kernel 2), shared-K/V backward as library "
+                                                    "f32 GEMMs (no split-bf16 products); everything else as in the headline step"}
+            result["arith"]["max_rel_vs_exact"] = dict(diffs, note=f"one cross-attention layer ({nQ_} queries x {nK_} keys, boxes), split forms "
+                                                       "vs exact f32 products, max |diff| / max |exact| per tensor")
+        finally:
+            _A.FWD_KERNEL, _A.FUSED_KV_BWD = keep
+
     if world > 1 and a.with_backbone_dist and a.config == "c2":
         leg("with_backbone", backbone_leg)  # collective: every rank runs it (own scene each); opt-in, it follows the headline
     if rank == 0:
@@ -1386,6 +1436,8 @@ def main():
         # (with_backbone measured 44.7 ms per step after it, 30.3 before)
         if world == 1 and a.config == "c2" and not a.no_backbone_leg:
             leg("with_backbone", backbone_leg)
+        if world == 1 and dtype == "f32" and a.loss == "synthetic" and not a.no_exact_leg:
+            leg("exact_f32_error", exact_leg)  # (writes result["arith"]["exact_f32"]; this key only appears with an error)
         if world == 1 and a.loss == "synthetic" and not a.no_criterion_leg:
             leg("criterion", criterion_leg)  # (times the criterion's CPU oracle as well: after the backbone leg for the same reason)
         if not a.no_cpu_baseline and world == 1:

@@ -5,7 +5,7 @@ tag=${1:-x}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-criterion-leg --no-backbone-leg > $out/bench_eager.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/rp_eager -o eager -- python3 bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-criterion-leg --no-exact-leg --no-backbone-leg > $out/bench_eager.log 2>&1
 db=$(find /tmp/rp_eager -name '*.db' | head -1); csv=$(find /tmp/rp_eager -name '*kernel_trace.csv' | head -1)
 python3 tools/rocprof_summary.py ${db:-$csv} 5 3 > $out/eager_kernel_summary.txt 2>&1
 python3 tools/kernel_bench.py c2 > $out/kernel_bench_c2.txt 2>&1
@@ -13,7 +13,7 @@ python3 tools/kernel_bench.py c2 > $out/kernel_bench_c2.txt 2>&1
 # NOTE: the tracer delays the cross-queue start of the side branch (the traced step is ~1.5 ms longer than the untraced one and
 # shows the table kernels back to back behind the chain); the untraced sweep (profiles/*_async_table_sweep.txt) is the timing evidence.
 rm -rf /tmp/rp_graph
-VDETR_BENCH_NORMAL_EXIT=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_graph -o graph -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-criterion-leg --no-backbone-leg > $out/bench_graph_traced.log 2>&1
+VDETR_BENCH_NORMAL_EXIT=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_graph -o graph -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-criterion-leg --no-exact-leg --no-backbone-leg > $out/bench_graph_traced.log 2>&1
 gcsv=$(find /tmp/rp_graph -name '*kernel_trace.csv' | head -1)
 [ -n "$gcsv" ] && python3 tools/async_timeline.py $gcsv attn_bwd_box4 > $out/graph_timeline.txt 2>&1
 # the step with the device criterion as its loss: kernel trace + the solver's scan counts
@@ -77,7 +77,7 @@ python3 tools/pmc_traffic.py $out > $out/pmc_traffic.json 2>/dev/null
 python3 tools/fps_variants.py > $out/fps_variants.txt 2>&1 < /dev/null
 [ -x tools/probes/bin/lat_probe ] && timeout 120 tools/probes/bin/lat_probe > $out/lat_probe.txt 2>&1
 # the launcher path the driver uses for N > 1, with one rank (RCCL communicator, gradient all-reduce captured in the graph)
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-criterion-leg --no-backbone-leg --no-roofline > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "exit code $?" >> $out/bench_torchrun_1rank.err
-for c in c1 c4 c5; do python3 bench.py --config $c --no-cpu-baseline --no-criterion-leg --no-backbone-leg > $out/bench_$c.json 2> $out/bench_$c.err; done
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-criterion-leg --no-exact-leg --no-backbone-leg --no-roofline > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "exit code $?" >> $out/bench_torchrun_1rank.err
+for c in c1 c4 c5; do python3 bench.py --config $c --no-cpu-baseline --no-criterion-leg --no-exact-leg --no-backbone-leg > $out/bench_$c.json 2> $out/bench_$c.err; done
 VDETR_PMC_TRAFFIC=$out/pmc_traffic.json python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400
