@@ -474,6 +474,34 @@ def test_multihead_self_attention_matches_torch():
         assert_close(p2.grad, p1.grad.numpy(), 1e-3, 1e-4 * float(p1.grad.abs().max()) + 1e-7, n1)
 
 
+@pytest.mark.parametrize("B,n,p", [(1, 1024, 0.0), (1, 1024, 0.1), (2, 1000, 0.0), (1, 4096, 0.0)])
+def test_per_head_attention_at_the_models_size_vs_torch(B, n, p):
+    """The query self-attention at BASELINE config 2's size (1024 queries, 4 heads: 256 workgroups = one per CU) and beyond takes
+    the four-wave workgroups of attn_fwd.hip (several per CU: they all start next to a CU that is busy elsewhere); the smaller
+    cases of this file take the eight-wave form.  Forward and gradients against softmax(q k^T / 8) v in fp64; with dropout the
+    kernel's own keep mask (dropout_keep_mask) is applied to the reference."""
+    from vdetr_amd import attention as A
+    g = torch.Generator().manual_seed(n + B)
+    q, k, v = (torch.randn((B, n, 256), generator=g).to(DEV).requires_grad_(True) for _ in range(3))
+    wout = torch.randn((B, n, 256), generator=g).to(DEV)
+    A.reset_rng()
+    rng = A.begin_step(DEV) if p > 0 else None
+    out = A.fused_attention(q, k, v, num_heads=4, scale=0.125, shared_kv=False, dropout_p=p, rng_state=rng, salt=5)
+    (out * wout).sum().backward()
+    qd, kd, vd = (t_.detach().double().view(B, n, 4, 64).transpose(1, 2).requires_grad_(True) for t_ in (q, k, v))
+    prob = torch.softmax(qd @ kd.transpose(2, 3) * 0.125, dim=-1)
+    if p > 0:
+        keep = A.dropout_keep_mask(B, 4, n, n, False, p, rng, salt=5).double()
+        assert 0.85 < float(keep.mean()) < 0.95
+        prob = prob * keep / (1.0 - round(p * 65536) / 65536.0)
+    ref = (prob @ vd).transpose(1, 2).reshape(B, n, 256)
+    (ref * wout.double()).sum().backward()
+    assert_close(out, ref.detach().cpu().numpy(), 1e-4, 1e-5, "out")
+    for name, got, want in (("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
+        want = want.transpose(1, 2).reshape(B, n, 256)
+        assert_close(got, want.cpu().numpy(), 1e-3, 2e-5 * float(want.abs().max()), name)
+
+
 @pytest.mark.parametrize("case", ["cross_attn_small", "cross_attn_rot", "cross_attn_mid"])
 def test_cross_attention_module_vs_reference_vectors(case):
     g = load_golden(case)
@@ -620,7 +648,7 @@ def test_rounded_operand_attention_vs_oracle(B, nQ, nK, boxes):
     (out * wout.to(DEV)).sum().backward()
     assert dq.grad.dtype == torch.float32
     img = A.pack_kv_images(dkv.detach(), 1, parts=1)
-    assert img is not None and img.shape[1] == L.lib().vdetr_attn_kv_image_parts_bytes(B, nK, 1) < L.lib().vdetr_attn_kv_image_bytes(B, nK)
+    assert img is not None and img[0].data.numel() == L.lib().vdetr_attn_kv_image_parts_bytes(B, nK, 1) < L.lib().vdetr_attn_kv_image_bytes(B, nK)
     with torch.no_grad():
         out_img = A.fused_attention(dq, dkv[..., :64], dkv[..., 64:], kv_img=img[0], **dev)
         out_f32 = A.fused_attention(dq, dkv[..., :64], dkv[..., 64:], **{**dev, "operand_bf16": False})

@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of the round-6 forward changes on one box: interleaved runs, the step time and the chosen sampling fork of each
+F="--steps 30 --warmup 3 --no-cpu-baseline --no-criterion-leg --no-exact-leg --no-backbone-leg --no-roofline"
+run() { env "$@" python3 bench.py $F 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3), d['config'].get('fps_fork_layer'))"; }
+for rep in 1 2; do
+  run A=0
+  run VDETR_SELF_FWD8=1
+  run VDETR_SELF_FWD8=1 VDETR_BENCH_FPS_AT_LAYER=2
+  run VDETR_BENCH_FPS_AT_LAYER=2
+  run VDETR_BENCH_FPS_AT_LAYER=1
+done

@@ -48,7 +48,7 @@ if mode == "nofps":  # the next scene's sampling launch left out (NOT a valid st
 if mode == "nomlp":  # the RPE tables' own backward (three batched GEMMs at the end of the side branch) left out (not valid)
     A.DeferredTableGrads.begin_flush = classmethod(lambda cls: None)
 if mode == "notable":
-    A._launch_table_async = lambda lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable: dtable
+    A._launch_table_async = lambda lib, d, q, ds, table, aux, vertices, xyz, mask, fork, dtable, also=(): dtable
 sys.argv = ["bench.py", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-roofline", "--no-criterion-leg", "--no-backbone-leg"] + sys.argv[2:]  # (e.g. --config c5)
 import io
 import contextlib

@@ -64,8 +64,9 @@ __device__ __forceinline__ void fwd_split4(const f32x4& x, bf16x4& hi, bf16x4& l
   }
 }
 
-template <bool PERHEAD, bool RPE, bool BOX = false, bool BF16 = false>
+template <bool PERHEAD, bool RPE, bool BOX = false, bool BF16 = false, int WAVES = kFwdWaves>
 __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
+  static_assert(WAVES == 8 || WAVES == 4, "the merge of the wave states is written for 8 or 4 waves");
   static_assert(!(BF16 && PERHEAD), "the bf16 path is built for the shared-KV kinds");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   attn_load_rng(P);
@@ -97,7 +98,7 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
     if (box != BOX) return;
   }
   const float bX[2] = {vx[0], vx[2]}, bY[2] = {vy[0], vy[1]}, bZ[2] = {vz[0], vz[4]};
-  if (RPE) rpe_stage_table(P, tab, tid, kFwdThreads);
+  if (RPE) rpe_stage_table(P, tab, tid, WAVES * kWave);
 
   // ---- A operand of QK^T: row i = c ---------------------------------------------------------------
   float qa[BF16 ? 1 : 16];
@@ -181,12 +182,12 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
   TileOps ops, nxt;
   if (tile_begin + w < tile_end) fetch(tile_begin + w, ops);
 
-  for (int tile = tile_begin + w; tile < tile_end; tile += kFwdWaves) {
+  for (int tile = tile_begin + w; tile < tile_end; tile += WAVES) {
     const int key0 = tile << 4;
     const int key = key0 + c;
     const bool kvalid = key < nK;
     const int keyc = min(key, nK - 1);
-    if (tile + kFwdWaves < tile_end) fetch(tile + kFwdWaves, nxt);
+    if (tile + WAVES < tile_end) fetch(tile + WAVES, nxt);
     // ---- S = Q K^T --------------------------------------------------------------------------------
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BF16) {
@@ -325,18 +326,18 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
     for (int r = 0; r < 4; ++r) { mine[16 + r] = m[r]; mine[20 + r] = l[r]; }
   }
   __syncthreads();
-  // wave w finishes d-tile t = w>>1 for registers r in {2*(w&1), 2*(w&1)+1}
+  // 8 waves: wave w finishes d-tile t = w>>1 for registers r in {2*(w&1), 2*(w&1)+1}; 4 waves: d-tile t = w, all four registers
   {
-    const int t = w >> 1;
+    const int t = WAVES == 8 ? (w >> 1) : w;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int r = 2 * (w & 1) + rr;
+    for (int rr = 0; rr < 16 / WAVES; ++rr) {
+      const int r = WAVES == 8 ? 2 * (w & 1) + rr : rr;
       float M = kNegBig;
 #pragma unroll
-      for (int ww = 0; ww < kFwdWaves; ++ww) M = fmaxf(M, red[((size_t)ww * kWave + lane) * 24 + 16 + r]);
+      for (int ww = 0; ww < WAVES; ++ww) M = fmaxf(M, red[((size_t)ww * kWave + lane) * 24 + 16 + r]);
       float L = 0.f, val = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < kFwdWaves; ++ww) {
+      for (int ww = 0; ww < WAVES; ++ww) {
         const float* src = red + ((size_t)ww * kWave + lane) * 24;
         const float f = __expf(src[16 + r] - M);
         L += src[20 + r] * f;
@@ -368,6 +369,14 @@ __device__ __forceinline__ void attn_fwd_body(AttnParams P) {
 template <bool PERHEAD, bool RPE, bool BOX = false, bool BF16 = false>
 __global__ __launch_bounds__(kFwdThreads) void attn_fwd_kernel(AttnParams P) {
   attn_fwd_body<PERHEAD, RPE, BOX, BF16>(P);
+}
+// The per-head kind (the query self-attention) in workgroups of FOUR waves, one per SIMD: 152 registers each, so two or three of
+// them share a CU.  At the model's size the launch is H * nQ / 16 = 256 workgroups = the chip's CU count, and in the training
+// step one CU is always held by the next scene's sampling kernel: the eight-wave form (one workgroup per CU) then runs two rounds
+// (27 -> 47 us per layer); these all start at once.  (Round 5 tried the other ways out: key halves + a combine launch, and the
+// eight-wave form squeezed into 128 registers — no gain, 27 spills.)
+__global__ __launch_bounds__(4 * kWave) void attn_fwd_perhead4_kernel(AttnParams P) {
+  attn_fwd_body<true, false, false, false, 4>(P);
 }
 
 // The RPE attention with the instantiation chosen per workgroup IN the kernel (its 4 queries are axis-aligned boxes or not:
@@ -634,8 +643,16 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
     if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, pipe_split(d), d->kv_img != nullptr, true, st)) return e;
   } else if (perhead) {
     dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
-    if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
-    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(kFwdThreads), lds, st, P);
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    const int four = VDETR_AB("VDETR_FWD_PERHEAD4", -1);  // -1: where the eight-wave workgroups would (almost) fill the chip or more
+    if (d->fwd_kernel != 1 && (four > 0 || (four < 0 && 10 * wgs > 9 * (long)device_cu_count()))) {  // (fwd_kernel 1: the eight-wave form, A/B)
+      const size_t lds4 = (size_t)4 * kWave * 24 * 4 > (size_t)4 * 16 * kPPad * 4 ? (size_t)4 * kWave * 24 * 4 : (size_t)4 * 16 * kPPad * 4;
+      if (int e = set_lds(attn_fwd_perhead4_kernel, lds4, "attn_fwd")) return e;
+      hipLaunchKernelGGL(attn_fwd_perhead4_kernel, grid, dim3(4 * kWave), lds4, st, P);
+    } else {
+      if (int e = set_lds(attn_fwd_kernel<true, false>, lds, "attn_fwd")) return e;
+      hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(kFwdThreads), lds, st, P);
+    }
   } else {
     dim3 grid((d->nQ + 3) / 4, ks, d->B);
     if (rpe) {

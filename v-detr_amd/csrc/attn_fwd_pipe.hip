@@ -414,6 +414,14 @@ __global__ __launch_bounds__(kPipeThreads) void attn_fwd_rpe_pipe_kernel(PipeArg
     nextbuf[0] = first;
     if (first == last_draw) atomicExch(K.counter, 0u);
   }
+  // A workgroup that gets its CU only when the others are done (one CU is held by the next scene's sampling kernel for most of
+  // the training step) draws an index past the last item: it must not stage 128 KB of table first — that was a ~10 us tail on
+  // every launch of the step (114 -> 131 us).  Only the workgroups the dispatcher starts last can be in that position; they
+  // look at their draw before they stage, the others keep the draw's latency behind the staging.
+  if ((int)blockIdx.x + 8 >= (int)gridDim.x) {
+    __syncthreads();
+    if (nextbuf[0] >= K.nitems) return;
+  }
   rpe_stage_table(P, reinterpret_cast<f32x4*>(smem), tid, kPipeThreads);
   __syncthreads();
   int item = nextbuf[0];
