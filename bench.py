@@ -305,29 +305,39 @@ class Trainer:
             else:
                 launch_fps()
             self.inputs["fps_inds"] = self.cur_inds
+        from vdetr_amd.runtime import ts_mark  # (no-ops unless VDETR_TS_PROBE=1: tools/probes/step_timeline.py)
+        ts_mark("step start")
         out = self.model(self.inputs)
         if self.fps_prefetch and not self.fps_depth2:
             if hook is not None:
                 hook.remove()
             next_inds = box["inds"]
+            with torch.cuda.stream(self.side):
+                ts_mark("side: sampling done")
         self.loss = loss_fn(out) if self.criterion is None else self.criterion(out, self.targets)[0]
+        ts_mark("forward + loss done")
         self.loss.backward()
+        ts_mark("backward enqueued: main chain done")
         if self.phased:
             self.reducer.reduce_phased()  # parked weight gradients, slice packs and all-reduces, bucket by bucket
         else:
             if self.defer_wg:
                 flush_weight_grads()
+            ts_mark("flush done (side branch joined)")
             if not self.hooked:
                 self.flat.pack_grads()  # one launch; (hooked eager mode accumulates straight into the flat buffer)
         if self.fps_prefetch and not self.fps_depth2:
             main.wait_stream(self.side)
             self.cur_inds.copy_(next_inds)
+        ts_mark("gradients packed, sampling joined")
 
     def _update(self):
         # clip_grad_norm_(params, 0.1) (engine.py:105-106): one norm over the flat gradient; the clip coefficient is
         # applied inside the fused AdamW launch (grad_scale = 1 / coefficient)
         self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
         self.opt.step()
+        from vdetr_amd.runtime import ts_mark
+        ts_mark("optimizer done")
 
     def reset_state(self, snap):
         """parameters and buffers back to `snap` (model_state()), AdamW moments and step count to zero — in place, the captured
@@ -1097,8 +1107,8 @@ def main():
             tk = over_ranks(replay_ms(trk, reps=12, settle=25))
             if rank == 0:
                 print(f"[bench] sampling {t_fps:.2f} ms alone; captured step {t1:.2f} ms with it forked at the start, {tk:.2f} ms in front "
-                      f"of decoder layer {k}: {'layer ' + str(k) if tk < 0.99 * t1 else 'start'}", file=sys.stderr)
-            if tk < 0.99 * t1:
+                      f"of decoder layer {k}: {'layer ' + str(k) if tk < 0.998 * t1 else 'start'}", file=sys.stderr)
+            if tk < 0.998 * t1:
                 trk.reset_state(snap)
                 return trk
             return build(-1)

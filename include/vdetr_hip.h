@@ -874,6 +874,10 @@ int vdetr_pos_mlp_fwd_f32(const vdetr_posmlp_desc* d, vdetr_stream_t stream);
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */
 int vdetr_selftest_lds_atomics(int mode, int iters, float* sink, vdetr_stream_t stream);
 
+/* Timeline probe: one wave stores the device's constant-rate clock (100 MHz ticks) to *slot, in stream order.  A captured step
+ * with a few of these between its phases shows where its streams really are (tools/probes/step_timeline.py). */
+int vdetr_probe_timestamp(uint64_t* slot, vdetr_stream_t stream);
+
 /* MFMA layout self-test: C[16,16] = A[16,64] * B[16,64]^T through v_mfma_f32_16x16x4_f32. */
 int vdetr_selftest_mfma_f32(const float* a, const float* b, float* c, vdetr_stream_t stream);
 

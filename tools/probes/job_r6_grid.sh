@@ -1,0 +1,4 @@
+#!/bin/bash
+F="--steps 40 --warmup 3 --no-cpu-baseline --no-criterion-leg --no-exact-leg --no-backbone-leg --no-roofline"
+run() { env "$@" timeout 120 python3 bench.py $F 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3), d['config'].get('fps_fork_layer'))"; }
+for g in 190 184 176 160 128 190; do run VDETR_BWD_ASYNC_GRID=$g; done

@@ -329,6 +329,7 @@ _SIGNATURES = {
     "vdetr_rb_qkv_bwd_f32": (c_int, [ctypes.POINTER(RbQkvDesc), ctypes.POINTER(RbQkvGrads), c_void_p]),
     "vdetr_rb_proj_q_bwd_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), c_void_p]),
     "vdetr_rb_ffn_bwd_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), c_void_p]),
+    "vdetr_probe_timestamp": (c_int, [c_void_p, c_void_p]),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vdetr_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -160,7 +160,10 @@ def flush_layer_params_on_side(ref, rows):
     side.wait_event(fork)
     pairs, keep = [], []
     late, side_late[:] = list(side_late), []
+    from .runtime import ts_mark
+    ts_mark("main: all layers' backward done")
     with torch.cuda.stream(side):
+        ts_mark("side: parked gradients start")
         DeferredParamGrads.flush(select=lambda it: it[2].shape[0] == rows, collect=pairs, keepalive=keep)
         if _FLUSH_SIDE_POS:  # the layers' learned query-position embeddings: complete as well (one per layer)
             DeferredPosEmbedGrads.flush(collect=pairs, keepalive=keep)
@@ -170,6 +173,57 @@ def flush_layer_params_on_side(ref, rows):
         for fn, alive in late:  # (e.g. the box heads' weight gradients: vdetr_transformer._DeferredHeads)
             pairs += fn()
             keep.append(alive)
+        ts_mark("side: parked gradients end")
+    if pairs:
+        SideResults.pending.append((dev, pairs, keep))
+
+
+# Round 6: the parked parameter gradients of a decoder layer leave for the side branch as soon as that layer's backward has
+# produced them, instead of all layers' together behind the last table kernel.  The step's real timeline (timestamp kernels in the
+# captured graph, tools/probes/step_timeline.py) showed why: during the layers' backward the MAIN chain is the critical path (330-415
+# us per layer on the 66 CUs the table kernel leaves it, against ~300 us per table kernel), so the side stream sits idle for
+# 20-113 us behind every table kernel — 470 us per step — and then ran 480 us of weight-gradient GEMMs after the last one, with
+# the main chain long done.  MEASURED AND NOT KEPT (off by default; VDETR_FLUSH_PER_LAYER=1: the layers' weight gradients, =2: the
+# LayerNorm sums and the position MLPs' as well): per layer the work is 4 / 14 launches and takes 100 / 170 us next to the chain —
+# 8 x that is more than the one batched pass at the end (480 us), the side branch stays the longer one: 6.85 -> 7.06 / 7.47 ms
+# (profiles/r06_step_timeline.txt).
+_FLUSH_PER_LAYER = os.environ.get("VDETR_FLUSH_PER_LAYER", "0") != "0"
+_FLUSH_PER_LAYER_ALL = os.environ.get("VDETR_FLUSH_PER_LAYER", "0") == "2"
+
+
+def side_flush_begin(ref):
+    """Called inside a layer's backward once its parked operands are complete and BEFORE its last launch of the chain: records
+    the fork (the chain's next launch then stays the fork node's first successor: it keeps its hardware queue, see
+    _FusedAttention.backward).  Returns a token for side_flush_end, or None where the side branch is not in use."""
+    from .helpers import DeferredParamGrads
+    if not (_FLUSH_SIDE and _FLUSH_PER_LAYER and ref.is_cuda and DeferredParamGrads.enabled and DeferredParamGrads.direct
+            and side_branch_in_use(ref.device) and _side_keep):
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(ref.device))
+    return ev
+
+
+def side_flush_end(ev, ref, rows):
+    """the parked gradients that were complete at side_flush_begin, computed on the side branch (delivered at the flush: SideResults)"""
+    if ev is None:
+        return
+    from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
+    from .runtime import ts_mark
+    dev = ref.device
+    side = _side_stream(dev)
+    side.wait_event(ev)
+    pairs, keep = [], []
+    with torch.cuda.stream(side):
+        ts_mark("side: layer's parked gradients start")
+        DeferredParamGrads.flush(select=lambda it: it[2].shape[0] == rows, collect=pairs, keepalive=keep)
+        if _FLUSH_PER_LAYER_ALL:  # (the position MLPs' and LayerNorms' parameters too: ~14 launches, 170 us per layer — too long)
+            if _FLUSH_SIDE_POS:
+                DeferredPosEmbedGrads.flush(collect=pairs, keepalive=keep)
+            if _FLUSH_SIDE_LN:
+                from .add_ln import DeferredLnGrads
+                DeferredLnGrads.flush(collect=pairs, keepalive=keep)
+        ts_mark("side: layer's parked gradients end")
     if pairs:
         SideResults.pending.append((dev, pairs, keep))
 
@@ -403,15 +457,18 @@ def _launch_table_async(lib, d, q, ds, table, aux, vertices, xyz, mask, fork=Non
         side.wait_event(fork)
     else:
         side.wait_stream(torch.cuda.current_stream(q.device))
+    from .runtime import ts_mark
     with torch.cuda.stream(side):
         ws2 = L.workspace(nbytes, q.device)
         keep_grid = d.table_grid
         d.table_grid = side_table_grid(q.device)  # the launch's own field: whole CUs stay with the main chain
+        ts_mark("side: table kernel start")
         try:
             L.check(lib.vdetr_attn_bwd_table_f32(ctypes.byref(d), L.ptr(ds), L.ptr(dtable), L.ptr(ws2), nbytes, L.stream_ptr()),
                     "attn_bwd_table")
         finally:
             d.table_grid = keep_grid
+        ts_mark("side: table kernel end")
     # EVERY tensor the descriptor points at stays alive until the join: the launch runs later than the caller's backward() returns,
     # and a block autograd frees then (the saved cos / sin of the rotated-box kind, the dropout state) is handed to the main stream's
     # next allocation while this kernel still reads it — `also` (found by the cut C5 case of test_full_config_training_step_vs_cpu_oracle)
@@ -640,6 +697,8 @@ class _FusedAttention(Function):
             L.check(lib.vdetr_attn_bwd_kv_delta_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(out), L.ptr(scores),
                                                     L.ptr(lse), L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws),
                                                     nbytes, L.stream_ptr()), "attn_bwd_kv")
+            from .runtime import ts_mark
+            ts_mark("main: key-side pass done" if shared else "main: self-attention key-side pass done")
             dtable = fork = None
             if run_async:
                 # The side stream's launches depend on the key-side pass only, but are CAPTURED behind the main chain's next

@@ -52,6 +52,17 @@ int ab_env(const char* name, int dflt) {
 #endif
 }  // namespace vdetr
 
+// One wave writes the device's constant-rate wall clock (100 MHz) to *slot: a timeline of a CAPTURED step without a tracer
+// (rocprofv3 delays the cross-queue start of the side branch; tools/probes/step_timeline.py)
+__global__ void vdetr_timestamp_kernel(unsigned long long* slot) {
+  if (threadIdx.x == 0) *slot = wall_clock64();
+}
+extern "C" int vdetr_probe_timestamp(uint64_t* slot, vdetr_stream_t stream) {
+  VDETR_REQUIRE(slot != nullptr, "probe_timestamp: null slot");
+  hipLaunchKernelGGL(vdetr_timestamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(slot));
+  return vdetr::check_launch("probe_timestamp");
+}
+
 extern "C" int vdetr_abi_version(void) { return 3; }
 extern "C" int vdetr_ab_switches(void) {
 #ifdef VDETR_AB_SWITCHES

@@ -209,10 +209,20 @@ class _Qkv(torch.autograd.Function):
                 d_alias = _opt(d_alias)
                 g.d_x_add = d_alias.data_ptr()
             g.d_t = d_t.data_ptr()
-            L.check(L.lib().vdetr_rb_qkv_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_qkv_bwd")
+            # This is the LAST launch of the layer's backward, and its own weight-gradient operands (the incoming dq / dk / dv and
+            # the saved inputs) exist already — for one scene; several scenes' row-ordered copies are written by the launch — so
+            # the layer's parked gradients can leave for the side branch from here (attention.side_flush_begin)
             gr = [None] * 6
-            for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
-                gr[i], gr[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
+            tok = None
+            if B == 1:
+                for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
+                    gr[i], gr[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
+                tok = A.side_flush_begin(t2)
+            L.check(L.lib().vdetr_rb_qkv_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_qkv_bwd")
+            if B > 1:
+                for i, (w, b, dy, xx) in enumerate(((wq, bq, dq2, x2), (wk, bk, dk2, x2), (wv, bv, dv2, t2))):
+                    gr[i], gr[3 + i] = _park_or_grad(w, b, dy, xx, need[2 + i], need[5 + i])
+            A.side_flush_end(tok, t2, rows)
             return (d_t.view(ctx.shape) if need[0] else None, d_x.view(ctx.shape) if d_x is not None else None,
                     gr[0], gr[1], gr[2], gr[3], gr[4], gr[5], None, None)
         dq2, dk2, dv2 = (_seq_rows(g.contiguous(), B) for g in (dq, dk, dv))

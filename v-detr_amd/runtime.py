@@ -210,3 +210,43 @@ def capture_status(stream):
         _hip_runtime().hipGetLastError()
         return 2  # (the query itself fails on an invalidated capture)
     return st.value
+
+
+# ---- timeline marks of a captured step (tools/probes/step_timeline.py) -----------------------------------------------------------
+# Off unless VDETR_TS_PROBE=1: `ts_mark(label)` then launches a one-wave kernel on the CURRENT stream that stores the device clock
+# into the next slot of a buffer; inside a capture the launches become nodes of the graph and every replay rewrites the slots.
+TS_PROBE = os.environ.get("VDETR_TS_PROBE", "0") == "1"
+_ts = {"buf": None, "labels": [], "frozen": False}
+
+
+def ts_mark(label):
+    if not TS_PROBE:
+        return
+    from . import _lib as L
+    if _ts["buf"] is None:
+        _ts["buf"] = torch.zeros(1024, dtype=torch.int64, device="cuda")
+    if _ts["frozen"]:
+        return
+    i = len(_ts["labels"])
+    if i >= 1024:
+        return
+    _ts["labels"].append(label)
+    L.check(L.lib().vdetr_probe_timestamp(_ts["buf"].data_ptr() + 8 * i, L.stream_ptr()), "probe_timestamp")
+
+
+def ts_reset():
+    _ts["labels"], _ts["frozen"] = [], False
+
+
+def ts_freeze():
+    """no further marks (the labels of the captured step stay as they are while it replays)"""
+    _ts["frozen"] = True
+
+
+def ts_read():
+    """[(label, microseconds since the first mark)] of the last run / replay"""
+    if _ts["buf"] is None:
+        return []
+    torch.cuda.synchronize()
+    v = _ts["buf"][:len(_ts["labels"])].cpu().tolist()
+    return [(lab, (t - v[0]) / 100.0) for lab, t in zip(_ts["labels"], v)]

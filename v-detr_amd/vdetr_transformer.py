@@ -567,6 +567,7 @@ class FFNLayer(nn.Module):
 # decoder
 # =====================================================================================================
 _DEFER_HEADS = os.environ.get("VDETR_DEFER_HEADS", "1") != "0"  # A/B switch (read once)
+_DEFER_STAGE0 = os.environ.get("VDETR_DEFER_STAGE0", "1") != "0"  # the first stage's heads recorded too (round 6; A/B switch)
 # the heads' weight gradients on the side branch (VDETR_HEADS_SIDE): 1 = at once, at the BEGINNING of the backward, where the branch
 # is idle - measured C2 8.376 -> 8.33 ms, but C5 (4 scenes: the GEMMs are 4 x larger and hold the first table kernels up) 26.15 ->
 # 26.61 ms; 2 (default) = at the END of the backward with the layers' weight gradients (attention.flush_layer_params_on_side):
@@ -636,8 +637,10 @@ class _DeferredHeads(torch.autograd.Function):
         # branch - it is idle until the first decoder layer's key-side pass - behind ONE fork after the last input-gradient
         # operand exists: 180 us of GEMMs leave the chain (VDETR_HEADS_SIDE=1; off by default, see _HEADS_SIDE)
         from .helpers import DeferredParamGrads
+        # (the first stage's node is the LAST thing the backward pass reaches: its weight gradients in line, under the side branch's
+        #  tail, not behind it)
         on_side = (_HEADS_SIDE and dY.is_cuda and DeferredParamGrads.enabled and DeferredParamGrads.direct
-                   and A.side_branch_in_use(dev))
+                   and A.side_branch_in_use(dev) and not r0.get("inline_wg", False))
 
         def weight_grads(dx2, dx1):
             db3 = dY.sum(dim=(1, 4))                                                               # [S,G,rows]
@@ -1056,6 +1059,8 @@ class TransformerDecoder(nn.Module):
                 tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
                 transpose_swap=False, return_attn_weights=False, enc_box_predictions=None, enc_box_features=None):
         A.begin_step(memory.device)  # one dropout-RNG snapshot per forward, shared by all attention modules
+        from .runtime import ts_mark  # (no-ops unless VDETR_TS_PROBE=1: tools/probes/step_timeline.py)
+        ts_mark("decoder: start")
         intermediate, attns = [], []
         fuse_ln = ALN.supported(self.norm) and isinstance(self.first_layer, FFNLayer) and \
             ALN.supported(self.first_layer.norm, self.norm)
@@ -1069,9 +1074,10 @@ class TransformerDecoder(nn.Module):
         # the first stage's heads on all encoder tokens: recorded like the later stages' (the fused launches of csrc/heads.hip where
         # the shapes fit) and differentiated by a _DeferredHeads node of its own — the last thing the backward pass reaches
         recorded = self._stage_recorded(0, point_cloud_dims, normed, enc_box_predictions["center_normalized"],
-                                        enc_box_predictions["size_normalized"]) if defer else None
+                                        enc_box_predictions["size_normalized"]) if (defer and _DEFER_STAGE0) else None
         if recorded is not None:
             box_prediction, rec0 = recorded
+            rec0["inline_wg"] = True
             self._attach_deferred([rec0], [box_prediction])
         else:
             box_prediction = self.get_proposal_box_predictions_refine(
@@ -1081,6 +1087,7 @@ class TransformerDecoder(nn.Module):
         if self.return_intermediate:
             intermediate.append(box_prediction)
 
+        ts_mark("decoder: first stage done")
         # ---- top-k proposals by objectness (:364-398) ----------------------------------------------------
         objectness = box_prediction["objectness_prob"].detach()
         ntok = objectness.shape[1]
@@ -1143,6 +1150,7 @@ class TransformerDecoder(nn.Module):
         if not defer and self.training and output.is_cuda and torch.is_grad_enabled():
             HD.decoder_refresh(self)  # (the position MLPs' images; the stages' heads take the batched path)
         deferred, stacked = [], {}
+        ts_mark("decoder: proposals, key order, K / V / tables, weight images done")
         for idx, layer in enumerate(self.layers):
             layer.cross_cache = caches[idx]
             if fuse_ln:
@@ -1194,6 +1202,7 @@ class TransformerDecoder(nn.Module):
                     pre_center_normalized=proposal_center_normalized, pre_size_normalized=proposal_size_normalized)
             if self.return_intermediate:
                 intermediate.append(box_prediction)
+            ts_mark(f"decoder: layer {idx + 1} + its stage done")
             if return_attn_weights:
                 if key_order is not None:  # back to the caller's key order
                     inv = torch.argsort(key_order, dim=1)[:, None, None, :].expand_as(attn)
