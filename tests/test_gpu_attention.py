@@ -114,6 +114,43 @@ def test_fused_attention_forward_backward(B, nQ, nK, shared, rpe, rot, mask):
             assert_close(o, r.detach().numpy(), 1e-3, 1e-4 * scale + 1e-7, name)
 
 
+def _oracle_in_chunks(q, k, v, tables, verts, xyz, wout, kw, cs=None, chunk=32, device="cpu"):
+    """fused_attention_reference in fp64, `chunk` queries at a time (softmax rows are independent; dk, dv and dtable are sums over
+    the chunks) -> [out, dq, dk, dv, dtable] as CPU tensors.  device "cpu": as always.  device = the GPU: the SAME torch code,
+    executed by ATen's fp64 kernels (none of this library's) — 6 s instead of 50-90 s for a 1024 x 4096 layer.  One full-size case
+    of every test keeps the CPU evaluation, and test_oracle_on_the_gpu_equals_the_oracle_on_the_cpu holds the two together."""
+    from oracle.attention_oracle import fused_attention_reference
+    dd = lambda t_: t_.double().to(device)  # noqa: E731
+    rk, rv, rtb = dd(k).requires_grad_(True), dd(v).requires_grad_(True), dd(tables).requires_grad_(True)
+    rxyz, rw = dd(xyz), dd(wout)
+    routs, rdq = [], []
+    nQ = q.shape[1]
+    for c in range(0, nQ, chunk):
+        sl = slice(c, c + chunk)
+        rq = dd(q[:, sl]).requires_grad_(True)
+        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=dd(verts[:, sl]).contiguous(), xyz=rxyz,
+                                      cos_sin=None if cs is None else dd(cs[:, sl]), **kw)
+        (o * rw[:, sl]).sum().backward()
+        routs.append(o.detach().cpu())
+        rdq.append(rq.grad.cpu())
+    return [torch.cat(routs, 1), torch.cat(rdq, 1), rk.grad.cpu(), rv.grad.cpu(), rtb.grad.cpu()]
+
+
+def test_oracle_on_the_gpu_equals_the_oracle_on_the_cpu():
+    """the fp64 oracle through ATen's GPU kernels against the same code on the CPU (a rotated, general-vertex case): 1e-10"""
+    from vdetr_amd import attention as A
+    B, nQ, nK = 2, 48, 640
+    g = torch.Generator().manual_seed(3)
+    xyz, verts, tables, cs = _scene(B, nQ, nK, 4, True)
+    q, k, v = (torch.randn(s_, generator=g) for s_ in ((B, nQ, 256), (B, nK, 64), (B, nK, 64)))
+    wout = torch.randn((B, nQ, 256), generator=g)
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True, rpe=A.RPEConfig())
+    a = _oracle_in_chunks(q, k, v, tables, verts, xyz, wout, kw, cs, 16, "cpu")
+    b = _oracle_in_chunks(q, k, v, tables, verts, xyz, wout, kw, cs, 48, DEV)
+    for name, x, y in zip(["out", "dq", "dk", "dv", "dtable"], a, b):
+        assert float((x - y).abs().max()) <= 1e-10 * max(1.0, float(x.abs().max())), name
+
+
 @pytest.mark.parametrize("boxes", [True, False, "rotated", "rotated_boxes"])
 def test_full_size_forward_backward_vs_oracle(boxes):
     """The launch bench.py times (B=1, nQ=1024, nK=4096, H=4: BASELINE config 2's layer size) against the fp64 oracle:
@@ -122,9 +159,7 @@ def test_full_size_forward_backward_vs_oracle(boxes):
     perturbed vertices send the same launch down the general kernel; "rotated": the (cos, sin) operand of angle_type
     "object_coords" (vdetr_transformer.py:712-720, BASELINE config 5) at the full size on arbitrary vertices (general kernels);
     "rotated_boxes": the same operand with the corners of rotated boxes (forward: one rotation per pair + the box body,
-    backward: attn_bwd_box4.hip).  The oracle is evaluated in chunks of 32 queries
-    (softmax rows are independent; dk, dv and dtable are sums over the chunks)."""
-    from oracle.attention_oracle import fused_attention_reference
+    backward: attn_bwd_box4.hip).  The oracle is evaluated in chunks of queries (_oracle_in_chunks)."""
     from vdetr_amd import attention as A
     B, nQ, nK, H = 1, 1024, 4096, 4
     g = torch.Generator().manual_seed(21)
@@ -143,19 +178,8 @@ def test_full_size_forward_backward_vs_oracle(boxes):
     out = A.fused_attention(dq, dk, dv, table=dtb, vertices=verts.to(DEV).contiguous(), xyz=xyz.to(DEV),
                             cos_sin=None if cs is None else cs.to(DEV), **kw)
     (out * wout.to(DEV)).sum().backward()
-    # oracle, 32 queries at a time
-    rk, rv = k.double().requires_grad_(True), v.double().requires_grad_(True)
-    rtb = tables.double().requires_grad_(True)
-    routs, rdq = [], []
-    for c in range(0, nQ, 32):
-        sl = slice(c, c + 32)
-        rq = q[:, sl].double().requires_grad_(True)
-        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(),
-                                      cos_sin=None if cs is None else cs[:, sl].double(), **kw)
-        (o * wout[:, sl].double()).sum().backward()
-        routs.append(o.detach())
-        rdq.append(rq.grad)
-    ref = [torch.cat(routs, 1), torch.cat(rdq, 1), rk.grad, rv.grad, rtb.grad]
+    # oracle: the axis-aligned-box case on the CPU, 32 queries at a time (52 s); the other three through ATen's fp64 kernels on the GPU
+    ref = _oracle_in_chunks(q, k, v, tables, verts, xyz, wout, kw, cs, 32 if boxes is True else 256, "cpu" if boxes is True else DEV)
     got = [out.detach(), dq.grad, dk.grad, dv.grad, dtb.grad]
     for name, r, o in zip(["out", "dq", "dk", "dv", "dtable"], ref, got):
         scale = float(r.abs().max())
@@ -601,17 +625,8 @@ def test_bf16_attention_core_vs_oracle(B, nQ, nK, boxes):
     assert out.dtype == torch.float32 and dq.dtype == torch.bfloat16
     (out * wout.to(DEV)).sum().backward()
     assert dq.grad.dtype == torch.bfloat16
-    rk, rv = k.double().requires_grad_(True), v.double().requires_grad_(True)
-    rtb = tables.double().requires_grad_(True)
-    routs, rdq = [], []
-    for c in range(0, nQ, 64):
-        sl = slice(c, c + 64)
-        rq = q[:, sl].double().requires_grad_(True)
-        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
-        (o * wout[:, sl].double()).sum().backward()
-        routs.append(o.detach())
-        rdq.append(rq.grad)
-    ref = [torch.cat(routs, 1), torch.cat(rdq, 1), rk.grad, rv.grad, rtb.grad]
+    big = nQ * nK >= (1 << 21)  # (the full-size case: the fp64 oracle through ATen's GPU kernels, see _oracle_in_chunks)
+    ref = _oracle_in_chunks(q, k, v, tables, verts, xyz, wout, kw, None, 256 if big else 64, DEV if big else "cpu")
     got = [out.detach(), dq.grad, dk.grad, dv.grad, dtb.grad]
     for name, r, o in zip(["out", "dq", "dk", "dv", "dtable"], ref, got):
         scale = float(r.abs().max())
@@ -654,18 +669,10 @@ def test_rounded_operand_attention_vs_oracle(B, nQ, nK, boxes):
         out_f32 = A.fused_attention(dq, dkv[..., :64], dkv[..., 64:], **{**dev, "operand_bf16": False})
     assert torch.equal(out_img, out.detach())
     assert not torch.equal(out_f32, out.detach())  # (the rounded operands are really what the kernel multiplied)
-    rk = kv[..., :64].bfloat16().double().requires_grad_(True)
-    rv = kv[..., 64:].bfloat16().double().requires_grad_(True)
-    rtb = tables.double().requires_grad_(True)
-    routs, rdq = [], []
-    for c in range(0, nQ, 64):
-        sl = slice(c, c + 64)
-        rq = q[:, sl].bfloat16().double().requires_grad_(True)
-        o = fused_attention_reference(rq, rk, rv, table=rtb, vertices=verts[:, sl].double().contiguous(), xyz=xyz.double(), **kw)
-        (o * wout[:, sl].double()).sum().backward()
-        routs.append(o.detach())
-        rdq.append(rq.grad)
-    ref = [torch.cat(routs, 1), torch.cat(rdq, 1), torch.cat((rk.grad, rv.grad), -1), rtb.grad]
+    big = nQ * nK >= (1 << 21)
+    r_ = _oracle_in_chunks(q.bfloat16(), kv[..., :64].bfloat16(), kv[..., 64:].bfloat16(), tables, verts, xyz, wout, kw, None,
+                           256 if big else 64, DEV if big else "cpu")
+    ref = [r_[0], r_[1], torch.cat((r_[2], r_[3]), -1), r_[4]]
     got = [out.detach(), dq.grad, dkv.grad, dtb.grad]
     for name, r, o in zip(["out", "dq", "dkv", "dtable"], ref, got):
         scale = float(r.abs().max())
