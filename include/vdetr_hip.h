@@ -346,6 +346,20 @@ typedef struct vdetr_box_decode_grads {
 int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stream);
 /* `d` as passed to the forward (inputs + the saved outputs size_unnorm, pre_size_unnorm, angle_cont, angle_class). */
 int vdetr_box_decode_bwd_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, vdetr_stream_t stream);
+/* The encoder proposals' boxes (models/model_vdetr.py:348-362, :383-390): per token the class = arg max of sigmoid(point-class logit)
+ * (first maximum), size = that class's anchor [ncls, 3], centre = the token's xyz; normalised centre / size over the scene extent;
+ * the 8 corners at yaw 0 in the camera frame (box_util.py:319-352).  logits [B, N, ncls], xyz [B, N, 3], dims [B, 3];
+ * outputs [B, N, 3] x 3 and corners [B, N, 8, 3].  One launch for ~10 tensor expressions; nothing here is differentiated. */
+int vdetr_anchor_boxes_f32(const float* logits, const float* xyz, const float* dims_min, const float* dims_max, const float* anchors,
+                           int B, int N, int ncls, float* size_unnorm, float* center_norm, float* size_norm, float* corners,
+                           vdetr_stream_t stream);
+/* The first decoder layer's box inputs (models/vdetr_transformer.py:364-398): rows topk[b, q] of a stage's corners (camera frame ->
+ * lidar (x, z, -y) when corners_are_camera, :98-102), centre, size, angle, normalised centre / size, and [centre | size] for the
+ * position MLP.  topk [B, nq] int64 indices into N; one launch for ~12 gathers / stacks / cats. */
+int vdetr_gather_proposals_f32(const long long* topk, int B, int N, int nq, int corners_are_camera, const float* corners,
+                               const float* center, const float* size, const float* angle, const float* center_norm,
+                               const float* size_norm, float* o_corners_lidar, float* o_center, float* o_size, float* o_angle,
+                               float* o_center_norm, float* o_size_norm, float* o_query_ref, vdetr_stream_t stream);
 /* n independent backward problems (HOST arrays of descriptors / gradient blocks) in one launch per 8: the stages of a decoder are
  * differentiated together (models/vdetr_transformer.py:417-436 run their heads stage by stage; the backward of all of them is due at once). */
 int vdetr_box_decode_bwd_batch_f32(const vdetr_box_decode_desc* d, const vdetr_box_decode_grads* g, int n, vdetr_stream_t stream);

@@ -98,3 +98,54 @@ def test_box_decode_joint_slabs_match_oracle(B, N, A, C1, cls_loss):
     np.testing.assert_allclose(grads["hip"], grads["ref"], rtol=1e-3, atol=1e-4 * np.abs(grads["ref"]).max())
     for i in range(5):
         assert np.abs(grads["hip"][:, i, chans[i]:]).max() == 0
+
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("B,N,ncls", [(1, 4096, 18), (3, 1000, 10), (2, 1, 18)])
+def test_anchor_boxes_launch_equals_the_tensor_expressions(B, N, ncls):
+    """vdetr_anchor_boxes_f32 (models/model_vdetr.py:348-362 as one launch) against the expressions it replaces: class by the arg max
+    of the sigmoid (saturated logits tie as there), anchor sizes, convert_unnorm2norm of centre and size, yaw-0 corners."""
+    from vdetr_amd import box_decode as BD
+    from vdetr_amd.dataset_config import ScannetDatasetConfig
+    from vdetr_amd.model_vdetr import convert_unnorm2norm
+    g = torch.Generator().manual_seed(B * 100 + N)
+    logits = (torch.randn((B, N, ncls), generator=g) * 3).to(DEV)   # (|x| < 16: no probability rounds to 1 by accident)
+    logits[:, ::7, 3:6] = 40.0   # saturated: sigmoid == 1 for several classes, the first of them wins
+    xyz = (torch.rand((B, N, 3), generator=g) * torch.tensor([8.0, 6.0, 3.0]) + 1).to(DEV)
+    dims = [xyz.min(1)[0] - 0.1, xyz.max(1)[0] + 0.2]
+    anchors = (torch.rand((ncls, 3), generator=g) + 0.3).to(DEV)
+    size, cn, sn, corners = BD.anchor_boxes(logits, xyz, dims, anchors)
+    cls = logits.sigmoid().max(dim=-1)[1]
+    want_size = anchors[cls]
+    assert torch.equal(size, want_size)
+    assert torch.allclose(cn, convert_unnorm2norm(xyz, dims), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(sn, convert_unnorm2norm(want_size, dims, with_offset=False), rtol=1e-6, atol=1e-7)
+    want = ScannetDatasetConfig().box_parametrization_to_corners(xyz, want_size, None)
+    assert torch.allclose(corners, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,nq,camera", [(1, 4096, 1024, False), (2, 300, 64, True), (3, 50, 50, False)])
+def test_gather_proposals_launch_equals_the_gathers(B, N, nq, camera):
+    """vdetr_gather_proposals_f32 (models/vdetr_transformer.py:364-398) against torch.gather + convert_corners_camera2lidar + cat"""
+    from vdetr_amd import box_decode as BD
+    from vdetr_amd.vdetr_transformer import convert_corners_camera2lidar
+    g = torch.Generator().manual_seed(N + nq)
+    pred = {"box_corners": torch.randn((B, N, 8, 3), generator=g).to(DEV), "center_unnormalized": torch.randn((B, N, 3), generator=g).to(DEV),
+            "size_unnormalized": torch.rand((B, N, 3), generator=g).to(DEV), "angle_continuous": torch.randn((B, N), generator=g).to(DEV),
+            "center_normalized": torch.rand((B, N, 3), generator=g).to(DEV), "size_normalized": torch.rand((B, N, 3), generator=g).to(DEV)}
+    if not camera:
+        pred["_reference_point_lidar"] = convert_corners_camera2lidar(pred["box_corners"]).contiguous()
+    topk = torch.stack([torch.randperm(N, generator=g)[:nq] for _ in range(B)]).to(DEV)
+    assert BD.proposals_fusable(topk, pred)
+    ref, center, size, ang, cn, sn, qref = BD.gather_proposals(topk, pred)
+
+    def take(t):
+        index = topk.view(topk.shape + (1,) * (t.dim() - 2)).expand(topk.shape + t.shape[2:])
+        return torch.gather(t, 1, index)
+    assert torch.equal(ref, convert_corners_camera2lidar(take(pred["box_corners"])))
+    assert torch.equal(center, take(pred["center_unnormalized"])) and torch.equal(size, take(pred["size_unnormalized"]))
+    assert torch.equal(ang, take(pred["angle_continuous"]))
+    assert torch.equal(cn, take(pred["center_normalized"])) and torch.equal(sn, take(pred["size_normalized"]))
+    assert torch.equal(qref, torch.cat((center, size), -1))

@@ -265,3 +265,51 @@ def decode_boxes(raw, pre_center_normalized, pre_size_normalized, point_cloud_di
         pre_center_normalized, pre_size_normalized, point_cloud_dims[0], point_cloud_dims[1], int(num_angle_bin), cls_kind)))
     return _result(o, raw["sem_cls_head"].transpose(1, 2), raw["angle_cls_head"].transpose(1, 2),
                    raw["angle_residual_head"].transpose(1, 2))
+
+
+# ---- the encoder proposals' anchor boxes / the gather of the top proposals (round 6: one launch each) ------------------------------
+def anchor_boxes(point_cls_logits, xyz, point_cloud_dims, anchors):
+    """models/model_vdetr.py:348-362 in one launch (vdetr_anchor_boxes_f32): point_cls_logits [B, N, ncls], xyz [B, N, 3] ->
+    (size_unnormalized, center_normalized, size_normalized [B, N, 3], box_corners [B, N, 8, 3]); nothing is differentiated."""
+    logits = point_cls_logits.detach().contiguous()
+    xyz = xyz.detach().contiguous()
+    B, N, ncls = logits.shape
+    dmin, dmax = point_cloud_dims[0].contiguous(), point_cloud_dims[1].contiguous()
+    anchors = anchors.contiguous()
+    for name, t in (("point_cls_logits", logits), ("xyz", xyz), ("dims_min", dmin), ("dims_max", dmax), ("anchors", anchors)):
+        L.require_gpu(t, name)
+        L.require_float(t, name)
+    out = torch.empty((3, B, N, 3), dtype=torch.float32, device=xyz.device)
+    corners = torch.empty((B, N, 8, 3), dtype=torch.float32, device=xyz.device)
+    L.check(L.lib().vdetr_anchor_boxes_f32(L.ptr(logits), L.ptr(xyz), L.ptr(dmin), L.ptr(dmax), L.ptr(anchors), B, N, ncls,
+                                           L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(corners), L.stream_ptr()), "anchor_boxes")
+    return out[0], out[1], out[2], corners
+
+
+def gather_proposals(topk, box_prediction):
+    """models/vdetr_transformer.py:364-398 in one launch (vdetr_gather_proposals_f32): rows topk [B, nq] of a stage's boxes ->
+    (reference_point in the lidar frame [B, nq, 8, 3], centre, size [B, nq, 3], angle [B, nq], normalised centre / size, [centre |
+    size] [B, nq, 6]), all detached."""
+    lidar = box_prediction.get("_reference_point_lidar")
+    corners = (lidar if lidar is not None else box_prediction["box_corners"]).detach().contiguous()
+    ts = [box_prediction[k].detach().contiguous() for k in ("center_unnormalized", "size_unnormalized", "angle_continuous",
+                                                          "center_normalized", "size_normalized")]
+    B, N = corners.shape[0], corners.shape[1]
+    nq = topk.shape[1]
+    topk = topk.contiguous()
+    dev = corners.device
+    ref = torch.empty((B, nq, 8, 3), dtype=torch.float32, device=dev)
+    vec = torch.empty((4, B, nq, 3), dtype=torch.float32, device=dev)
+    ang = torch.empty((B, nq), dtype=torch.float32, device=dev)
+    qref = torch.empty((B, nq, 6), dtype=torch.float32, device=dev)
+    L.check(L.lib().vdetr_gather_proposals_f32(L.ptr(topk), B, N, nq, 0 if lidar is not None else 1, L.ptr(corners), L.ptr(ts[0]),
+                                               L.ptr(ts[1]), L.ptr(ts[2]), L.ptr(ts[3]), L.ptr(ts[4]), L.ptr(ref), L.ptr(vec[0]),
+                                               L.ptr(vec[1]), L.ptr(ang), L.ptr(vec[2]), L.ptr(vec[3]), L.ptr(qref), L.stream_ptr()),
+            "gather_proposals")
+    return ref, vec[0], vec[1], ang, vec[2], vec[3], qref
+
+
+def proposals_fusable(topk, box_prediction):
+    ks = ("center_unnormalized", "size_unnormalized", "angle_continuous", "center_normalized", "size_normalized", "box_corners")
+    return bool(topk.is_cuda and topk.dtype == torch.int64 and all(
+        k in box_prediction and box_prediction[k].is_cuda and box_prediction[k].dtype == torch.float32 for k in ks))

@@ -307,6 +307,101 @@ static int box_check(const vdetr_box_decode_desc* d, const char* op) {
   return VDETR_OK;
 }
 
+// ---- the encoder proposals' anchor boxes and the gather of the top proposals: two launches for ~25 tensor expressions --------------
+namespace vdetr {
+// models/model_vdetr.py:348-362 — class = arg max sigmoid(point-class logit) (first maximum), size = that class's anchor, centre = the
+// token; convert_unnorm2norm (:383-390) of both; corners at yaw 0 (box_util.py:319-352 on the camera-frame centre (x, -z, y)).
+__global__ __launch_bounds__(kBoxThreads) void anchor_boxes_kernel(const float* __restrict__ logits, const float* __restrict__ xyz,
+                                                                   const float* __restrict__ dims_min, const float* __restrict__ dims_max,
+                                                                   const float* __restrict__ anchors, int B, int N, int ncls,
+                                                                   float* __restrict__ size_unnorm, float* __restrict__ center_norm,
+                                                                   float* __restrict__ size_norm, float* __restrict__ corners) {
+  const int t = blockIdx.x * kBoxThreads + threadIdx.x;
+  if (t >= B * N) return;
+  const int b = t / N;
+  const float* lg = logits + (size_t)t * ncls;
+  int cls = 0;
+  float best = -INFINITY;
+  for (int c = 0; c < ncls; ++c) {
+    const float p = 1.f / (1.f + expf(-lg[c]));  // (the probabilities, not the logits: saturated values tie as they do in the reference)
+    if (p > best) { best = p; cls = c; }
+  }
+  float su[3], cu[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = dims_min[b * 3 + a], scene = dims_max[b * 3 + a] - lo;
+    su[a] = anchors[cls * 3 + a];
+    cu[a] = xyz[(size_t)t * 3 + a];
+    size_unnorm[(size_t)t * 3 + a] = su[a];
+    center_norm[(size_t)t * 3 + a] = (cu[a] - lo) / scene;
+    size_norm[(size_t)t * 3 + a] = su[a] / scene;
+  }
+  float cor[24];
+  box_corners(su[0], su[1], su[2], 1.f, 0.f, cu[0], -cu[2], cu[1], cor);
+#pragma unroll
+  for (int i = 0; i < 24; ++i) corners[(size_t)t * 24 + i] = cor[i];
+}
+
+// models/vdetr_transformer.py:364-398 — the boxes of the nq highest-objectness tokens (indices given), as the first decoder layer reads them
+struct ProposalArgs {
+  const long long* topk;
+  int B, N, nq, camera;
+  const float *corners, *center, *size, *angle, *center_norm, *size_norm;
+  float *o_corners, *o_center, *o_size, *o_angle, *o_center_norm, *o_size_norm, *o_query_ref;
+};
+__global__ __launch_bounds__(kBoxThreads) void gather_proposals_kernel(ProposalArgs A) {
+  const int t = blockIdx.x * kBoxThreads + threadIdx.x;
+  if (t >= A.B * A.nq) return;
+  const int b = t / A.nq;
+  long long k = A.topk[t];
+  k = k < 0 ? 0 : (k >= A.N ? A.N - 1 : k);
+  const size_t src = (size_t)b * A.N + (size_t)k;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = A.corners[src * 24 + i * 3], y = A.corners[src * 24 + i * 3 + 1], z = A.corners[src * 24 + i * 3 + 2];
+    // convert_corners_camera2lidar (:98-102): (x, y, z) -> (x, z, -y)
+    A.o_corners[(size_t)t * 24 + i * 3] = x;
+    A.o_corners[(size_t)t * 24 + i * 3 + 1] = A.camera ? z : y;
+    A.o_corners[(size_t)t * 24 + i * 3 + 2] = A.camera ? -y : z;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float c = A.center[src * 3 + a], s = A.size[src * 3 + a];
+    A.o_center[(size_t)t * 3 + a] = c;
+    A.o_size[(size_t)t * 3 + a] = s;
+    A.o_query_ref[(size_t)t * 6 + a] = c;
+    A.o_query_ref[(size_t)t * 6 + 3 + a] = s;
+    A.o_center_norm[(size_t)t * 3 + a] = A.center_norm[src * 3 + a];
+    A.o_size_norm[(size_t)t * 3 + a] = A.size_norm[src * 3 + a];
+  }
+  A.o_angle[t] = A.angle[src];
+}
+}  // namespace vdetr
+
+extern "C" int vdetr_anchor_boxes_f32(const float* logits, const float* xyz, const float* dims_min, const float* dims_max, const float* anchors,
+                                      int B, int N, int ncls, float* size_unnorm, float* center_norm, float* size_norm, float* corners,
+                                      vdetr_stream_t stream) {
+  VDETR_REQUIRE(logits && xyz && dims_min && dims_max && anchors && size_unnorm && center_norm && size_norm && corners, "anchor_boxes: null pointer");
+  VDETR_REQUIRE(B > 0 && N > 0 && ncls > 0, "anchor_boxes: bad shape B=%d N=%d ncls=%d", B, N, ncls);
+  hipLaunchKernelGGL(vdetr::anchor_boxes_kernel, dim3(vdetr::ceil_div((long)B * N, vdetr::kBoxThreads)), dim3(vdetr::kBoxThreads), 0, (hipStream_t)stream,
+                     logits, xyz, dims_min, dims_max, anchors, B, N, ncls, size_unnorm, center_norm, size_norm, corners);
+  return vdetr::check_launch("anchor_boxes");
+}
+
+extern "C" int vdetr_gather_proposals_f32(const long long* topk, int B, int N, int nq, int corners_are_camera, const float* corners,
+                                          const float* center, const float* size, const float* angle, const float* center_norm,
+                                          const float* size_norm, float* o_corners_lidar, float* o_center, float* o_size, float* o_angle,
+                                          float* o_center_norm, float* o_size_norm, float* o_query_ref, vdetr_stream_t stream) {
+  VDETR_REQUIRE(topk && corners && center && size && angle && center_norm && size_norm && o_corners_lidar && o_center && o_size && o_angle &&
+                    o_center_norm && o_size_norm && o_query_ref, "gather_proposals: null pointer");
+  VDETR_REQUIRE(B > 0 && N > 0 && nq > 0, "gather_proposals: bad shape B=%d N=%d nq=%d", B, N, nq);
+  vdetr::ProposalArgs A = {topk, B, N, nq, corners_are_camera ? 1 : 0, corners, center, size, angle, center_norm, size_norm,
+                           o_corners_lidar, o_center, o_size, o_angle, o_center_norm, o_size_norm, o_query_ref};
+  hipLaunchKernelGGL(vdetr::gather_proposals_kernel, dim3(vdetr::ceil_div((long)B * nq, vdetr::kBoxThreads)), dim3(vdetr::kBoxThreads), 0,
+                     (hipStream_t)stream, A);
+  return vdetr::check_launch("gather_proposals");
+}
+
 extern "C" int vdetr_box_decode_fwd_f32(const vdetr_box_decode_desc* d, vdetr_stream_t stream) {
   if (int e = box_check(d, "box_decode_fwd")) return e;
   VDETR_REQUIRE(d->center_reg && d->size_reg && d->center_unnorm && d->center_norm && d->size_unnorm && d->size_norm &&

@@ -15,8 +15,10 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
+from . import box_decode
 from . import minkowski as ME
 from . import pointnet2_utils
+from .dataset_config import ScannetDatasetConfig
 from .helpers import GenericMLP
 from .mink_resnet import MinkResNet
 from .position_embedding import PositionEmbeddingCoordsSine
@@ -238,18 +240,27 @@ class ModelVDETR(nn.Module):
 
         point_cls_logits = self.decoder.pointcls_heads(enc_features.permute(1, 2, 0)) \
             .transpose(1, 2).reshape((bs, npoints, -1)).contiguous()
-        class_idx = point_cls_logits.sigmoid().max(dim=-1)[1]
-        size_unnormalized = self._anchor_sizes(enc_features)[class_idx]
         query_xyz, query_embed, _ = self.get_query_embeddings(enc_xyz, enc_features, point_cloud_dims)
-        enc_box_predictions = {
-            "point_cls_logits": point_cls_logits,
-            "center_unnormalized": query_xyz,
-            "center_normalized": convert_unnorm2norm(query_xyz, point_cloud_dims),
-            "size_unnormalized": size_unnormalized,
-            "size_normalized": convert_unnorm2norm(size_unnormalized, point_cloud_dims, with_offset=False),
-        }
-        enc_box_predictions["box_corners"] = self.decoder.box_processor.box_parametrization_to_corners(
-            query_xyz, size_unnormalized, None)  # (yaw 0, as the reference's zero tensor: pc_util.get_3d_box_batch_tensor)
+        if point_cls_logits.is_cuda and point_cls_logits.dtype == torch.float32 and query_xyz.dtype == torch.float32 \
+                and type(self.dataset_config).box_parametrization_to_corners is ScannetDatasetConfig.box_parametrization_to_corners:
+            # the ~10 launches below as one (box_decode.anchor_boxes: csrc/box_decode.hip); nothing of it is differentiated
+            size_unnormalized, center_normalized, size_normalized, corners = box_decode.anchor_boxes(
+                point_cls_logits, query_xyz, point_cloud_dims, self._anchor_sizes(enc_features))
+            enc_box_predictions = {"point_cls_logits": point_cls_logits, "center_unnormalized": query_xyz,
+                                   "center_normalized": center_normalized, "size_unnormalized": size_unnormalized,
+                                   "size_normalized": size_normalized, "box_corners": corners}
+        else:
+            class_idx = point_cls_logits.sigmoid().max(dim=-1)[1]
+            size_unnormalized = self._anchor_sizes(enc_features)[class_idx]
+            enc_box_predictions = {
+                "point_cls_logits": point_cls_logits,
+                "center_unnormalized": query_xyz,
+                "center_normalized": convert_unnorm2norm(query_xyz, point_cloud_dims),
+                "size_unnormalized": size_unnormalized,
+                "size_normalized": convert_unnorm2norm(size_unnormalized, point_cloud_dims, with_offset=False),
+            }
+            enc_box_predictions["box_corners"] = self.decoder.box_processor.box_parametrization_to_corners(
+                query_xyz, size_unnormalized, None)  # (yaw 0, as the reference's zero tensor: pc_util.get_3d_box_batch_tensor)
         tgt = None if self.querypos_mlp else torch.zeros_like(query_embed)
         box_predictions = self.decoder(tgt, enc_features, query_xyz, enc_xyz, point_cloud_dims, query_pos=query_embed,
                                        enc_box_predictions=enc_box_predictions, enc_box_features=enc_features)[0]

@@ -1106,13 +1106,20 @@ class TransformerDecoder(nn.Module):
             index = topk.view(topk.shape + (1,) * (t.dim() - 2)).expand(topk.shape + t.shape[2:])
             return torch.gather(t, 1, index)
 
-        reference_point = convert_corners_camera2lidar(take(box_prediction["box_corners"]))
-        reference_center = take(box_prediction["center_unnormalized"])
+        proposals_qref = None
+        if box_decode.proposals_fusable(topk, box_prediction):  # the seven gathers, the frame change and the cat as one launch
+            (reference_point, reference_center, reference_size, reference_angle, proposal_center_normalized,
+             proposal_size_normalized, proposals_qref) = box_decode.gather_proposals(topk, box_prediction)
+            box_prediction.pop("_reference_point_lidar", None)
+            box_prediction.pop("_query_reference", None)
+        else:
+            reference_point = convert_corners_camera2lidar(take(box_prediction["box_corners"]))
+            reference_center = take(box_prediction["center_unnormalized"])
+            reference_size = take(box_prediction["size_unnormalized"])
+            reference_angle = take(box_prediction["angle_continuous"])
+            proposal_center_normalized = take(box_prediction["center_normalized"])
+            proposal_size_normalized = take(box_prediction["size_normalized"])
         query_xyz = reference_center
-        reference_size = take(box_prediction["size_unnormalized"])
-        reference_angle = take(box_prediction["angle_continuous"])
-        proposal_center_normalized = take(box_prediction["center_normalized"])
-        proposal_size_normalized = take(box_prediction["size_normalized"])
         batch = output.shape[1]
         if self.q_content == "zero":
             output = output.new_zeros((topk.shape[1], batch, output.shape[-1]))
@@ -1170,7 +1177,7 @@ class TransformerDecoder(nn.Module):
                 reference_center = box_prediction["center_unnormalized"].detach()
                 reference_size = box_prediction["size_unnormalized"].detach()
                 reference_angle = box_prediction["angle_continuous"].detach()
-            query_reference = box_prediction.pop("_query_reference", None) if idx > 0 else None
+            query_reference = box_prediction.pop("_query_reference", None) if idx > 0 else proposals_qref
             if query_reference is None:
                 query_reference = torch.cat([reference_center, reference_size], dim=-1)
             query_pos = self.query_pos_projection[idx](query_reference).permute(2, 0, 1)
