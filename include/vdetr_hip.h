@@ -594,6 +594,10 @@ int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry,
  * ---------------------------------------------------------------------------------------------- */
 int vdetr_morton_sort_max(void);
 int vdetr_morton_order_f32(const float* xyz, int B, int n, int* codes, long long* order, vdetr_stream_t stream);
+/* order [B, nq] int64 = indices of the nq largest of values [B, n] per row, largest first, equal values by ascending index — what
+ * torch.sort(descending=True, stable=True) returns (one of the orders torch.topk may return, models/vdetr_transformer.py:364-366:
+ * the decoder's proposals); one workgroup per row, n <= vdetr_morton_sort_max(). */
+int vdetr_topk_order_f32(const float* values, int B, int n, int nq, long long* order, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Set criterion on the device (reference criterion.py).  Replaces, without a host round trip:

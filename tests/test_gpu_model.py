@@ -518,6 +518,23 @@ def test_morton_order_equals_the_tensor_expression(B, N):
     assert torch.equal(codes.cpu().long(), ref_codes)
 
 
+@pytest.mark.parametrize("B,N,nq", [(1, 4096, 1024), (3, 1000, 64), (2, 1, 1), (1, 8192, 8192), (2, 77, 50), (1, 512, 512)])
+def test_proposal_order_launch_equals_the_stable_sort(B, N, nq):
+    """vdetr_topk_order_f32 (one workgroup per scene, keys in registers: csrc/wgsort.h) == torch.sort(descending, stable)[:nq] —
+    the decoder's proposal order (vdetr_transformer._proposal_order) — on values with many exact ties, negative values and zeros."""
+    import vdetr_amd.vdetr_transformer as T
+    g = torch.Generator().manual_seed(N + nq)
+    v = torch.randn((B, N), generator=g)
+    v[:, ::11] = 0.0
+    v = torch.round(v * 8) / 8          # a few dozen distinct values: exact ties everywhere, +0.0 and -0.0 among them
+    v = v.to(DEV)
+    got = T._proposal_order(v, nq)
+    want = torch.sort(v, dim=1, descending=True, stable=True)[1][:, :nq]
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+    sig = torch.sigmoid(torch.randn((B, N), generator=g)).to(DEV)            # what the decoder feeds it
+    assert torch.equal(T._proposal_order(sig, nq), torch.sort(sig, dim=1, descending=True, stable=True)[1][:, :nq])
+
+
 def _zero_dropout(model):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):

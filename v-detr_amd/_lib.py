@@ -330,6 +330,7 @@ _SIGNATURES = {
     "vdetr_rb_proj_q_bwd_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), c_void_p]),
     "vdetr_rb_ffn_bwd_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), c_void_p]),
     "vdetr_probe_timestamp": (c_int, [c_void_p, c_void_p]),
+    "vdetr_topk_order_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_anchor_boxes_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 5),
     "vdetr_gather_proposals_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 14),
     "vdetr_selftest_lds_atomics": (c_int, [c_int, c_int, c_void_p, c_void_p]),

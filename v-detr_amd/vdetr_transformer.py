@@ -389,6 +389,13 @@ class MultiheadSelfAttention(nn.Module):
 def _proposal_order(objectness, n):
     """indices [B, n] of the n highest objectness values, ties to the lower token index (see the proposals in
     GlobalTransformer.forward: a stable sort is one of the orders torch.topk may return, and the same one on every device)"""
+    if objectness.is_cuda and objectness.dtype == torch.float32 and objectness.dim() == 2:
+        from . import _lib as L
+        if objectness.shape[1] <= L.lib().vdetr_morton_sort_max():  # one launch (csrc/morton.hip: topk_order_kernel), the same order
+            vals = objectness.contiguous()
+            order = torch.empty((vals.shape[0], n), dtype=torch.int64, device=vals.device)
+            L.check(L.lib().vdetr_topk_order_f32(L.ptr(vals), vals.shape[0], vals.shape[1], n, L.ptr(order), L.stream_ptr()), "topk_order")
+            return order
     return torch.sort(objectness, dim=1, descending=True, stable=True)[1][:, :n]
 
 
