@@ -78,6 +78,6 @@ python3 tools/fps_variants.py > $out/fps_variants.txt 2>&1 < /dev/null
 [ -x tools/probes/bin/lat_probe ] && timeout 120 tools/probes/bin/lat_probe > $out/lat_probe.txt 2>&1
 # the launcher path the driver uses for N > 1, with one rank (RCCL communicator, gradient all-reduce captured in the graph)
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 3 --no-cpu-baseline --no-criterion-leg --no-exact-leg --no-backbone-leg --no-roofline > $out/bench_torchrun_1rank.json 2> $out/bench_torchrun_1rank.err; echo "exit code $?" >> $out/bench_torchrun_1rank.err
-for c in c1 c4 c5; do python3 bench.py --config $c --no-cpu-baseline --no-criterion-leg --no-exact-leg --no-backbone-leg > $out/bench_$c.json 2> $out/bench_$c.err; done
-VDETR_PMC_TRAFFIC=$out/pmc_traffic.json python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
+for c in c1 c4 c5; do timeout 600 python3 bench.py --config $c --no-cpu-baseline --no-criterion-leg --no-exact-leg --no-backbone-leg > $out/bench_$c.json 2> $out/bench_$c.err; done
+VDETR_PMC_TRAFFIC=$out/pmc_traffic.json timeout 900 python3 bench.py --steps 20 --warmup 3 > $out/bench_n1.json 2> $out/bench_n1.err
 tail -1 $out/bench_n1.json | cut -c1-400
