@@ -217,6 +217,23 @@ int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k,
                        float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
                        vdetr_stream_t stream);
 
+/* The same forward with the merge of its key-split partial results LEFT TO THE CONSUMER (shared-KV kind): where the library splits the
+ * keys of a query over several workgroups (the persistent forward does, for load balance), vdetr_attn_fwd_f32 ends with a launch that
+ * merges the partial outputs — 10 us on the decoder layer's serial chain for 4 MB that the next launch reads anyway.  This entry point
+ * skips it and reports where the partials are; vdetr_rb_ffn_parts_f32 (the only consumer) merges them on its way in and writes
+ * `out` / `lse` as the merge launch would have (same arithmetic, same order: bit-identical).  `workspace` must stay untouched until
+ * that consumer has run.  parts->ksplit == 1: nothing was split, out / lse are final. */
+typedef struct vdetr_attn_parts {
+  const float* part_o;   /* [ksplit][rows][64] normalised partial outputs */
+  const float* part_lse; /* [ksplit][rows]     their log-sum-exp */
+  int32_t ksplit;
+  int32_t reserved;
+  int64_t rows;          /* B * nQ * H, in (b, q, h) order */
+} vdetr_attn_parts;
+int vdetr_attn_fwd_parts_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
+                             float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
+                             vdetr_attn_parts* parts, vdetr_stream_t stream);
+
 /* Backward, score stage (row order as above):
  *   scores  in : saved scores                         probs_out : P_drop = dropout(softmax)  (feeds dV = P_drop^T dO)
  *   dprob   in : dO V^T                               ds_out    : scale * dS                 (feeds dQ = ds_out K, dK = ds_out^T Q;
@@ -479,6 +496,11 @@ typedef struct vdetr_rb_ffn_desc {
   float *z, *mean_z, *rstd_z, *o1, *o2; /* z = y + drop3(lin2 h); statistics; o1 = post1(z), o2 = post2(z) */
 } vdetr_rb_ffn_desc;
 int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t stream);
+/* vdetr_rb_ffn_f32 whose input rows are the merge of a forward's key-split partials (vdetr_attn_fwd_parts_f32, H = 4, ksplit <= 16):
+ * d->a is not read; the merged rows are WRITTEN to attn_out [B, nQ, 256] and their log-sum-exp to attn_lse [B, nQ, 4] (what
+ * vdetr_attn_fwd_f32 would have left there), everything else as vdetr_rb_ffn_f32. */
+int vdetr_rb_ffn_parts_f32(const vdetr_rb_ffn_desc* d, const vdetr_attn_parts* parts, float* attn_out, float* attn_lse,
+                           vdetr_stream_t stream);
 
 /* Backward of the three launches: the input gradients as one launch each (same descriptors as the forward, whose saved
  * outputs they read); they also write the dY operand of every linear map's weight gradient (the caller computes those, e.g.

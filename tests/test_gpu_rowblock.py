@@ -108,6 +108,81 @@ def test_fused_layer_equals_separate_launches(monkeypatch, B, nQ, nK, train, fus
             assert torch.equal(a, c), f"{n}: not reproducible"
 
 
+@pytest.mark.parametrize("B,nQ,nK", [(1, 256, 1024), (2, 130, 1100), (1, 1024, 512), (1, 16, 4096), (1, 128, 2048), (1, 64, 256), (1, 64, 200)])
+def test_key_split_merge_inside_rb_ffn_equals_the_merge_launch(monkeypatch, B, nQ, nK):
+    """The cross-attention forward that leaves the merge of its key-split partials to rb_ffn (vdetr_attn_fwd_parts_f32 ->
+    vdetr_rb_ffn_parts_f32: 4, 2, 16 and 8 chunks, and a size that is not split at all) against the forward that ends with the merge
+    launch: the same arithmetic in the same order, so the layer's outputs, the attention's saved output / lse (through every
+    gradient) are bit-identical."""
+    from vdetr_amd import attention as A
+    from vdetr_amd import vdetr_transformer as T
+    monkeypatch.setattr(T, "_ROWBLOCK", True)
+    layer = _layer(5).train()
+    out_norm, next_norm = torch.nn.LayerNorm(256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    g = torch.Generator().manual_seed(B * 1000 + nQ)
+    tgt0 = torch.randn((nQ, B, 256), generator=g).to(DEV)
+    mem0 = torch.randn((nK, B, 256), generator=g).to(DEV)
+    pos0 = (0.5 * torch.randn((nQ, B, 256), generator=g)).to(DEV)
+    xyz, verts = _scene(B, nQ, nK, 9)
+    wts = [torch.randn((nQ, B, 256), generator=g).to(DEV) for _ in range(3)]
+    params = list(layer.parameters()) + list(out_norm.parameters()) + list(next_norm.parameters())
+    names = [n for n, _ in layer.named_parameters()] + ["out_norm.weight", "out_norm.bias", "next_norm.weight", "next_norm.bias"]
+    taken = []
+    real_take = A.take_pending_parts
+
+    def spy(out):
+        rec = real_take(out)
+        taken.append(None if rec is None else int(rec[0].ksplit))
+        return rec
+    monkeypatch.setattr(A, "take_pending_parts", spy)
+
+    def run(defer):
+        monkeypatch.setattr(A, "DEFER_COMBINE", defer)
+        A.reset_rng()
+        for p in params:
+            p.grad = None
+        tgt, mem, pos = (t.clone().requires_grad_(True) for t in (tgt0, mem0, pos0))
+        layer.post_norms = (out_norm, next_norm)
+        layer.pre_normed = None
+        out, _ = layer(tgt, mem, verts, None, xyz, None, query_pos=pos)
+        o1, o2 = layer.post_normed
+        layer.post_norms = layer.post_normed = None
+        ((out * wts[0]).sum() + (o1 * wts[1]).sum() + (o2 * wts[2]).sum()).backward()
+        return [out, o1, o2, tgt.grad, mem.grad, pos.grad] + [p.grad for p in params]
+
+    ref = run(False)
+    assert taken == [None]
+    got = run(True)
+    wgs, ntiles = B * ((nQ + 3) // 4), (nK + 15) // 16
+    assert taken[1] == {1024: 4, 1100: 4, 512: 4, 4096: 16, 2048: 8, 256: 2, 200: None}[nK], (taken, wgs, ntiles)
+    assert not A._pending_parts
+    for n, a, b in zip(["out", "norm(out)", "next norm1(out)", "d tgt", "d memory", "d query_pos"] + names, got, ref):
+        if "cpb_mlps" in n:  # (behind the table gradient's dynamically grouped partial sums)
+            _close(a, b, n, rtol=1e-5, frac=1e-6)
+        else:
+            assert torch.equal(a, b), f"{n}: max |diff| {float((a - b).abs().max())}"
+
+
+def test_a_deferred_merge_that_nobody_takes_is_an_error():
+    """fused_attention(defer_combine=True) whose output does not reach rowblock.ffn: the next step (and the next deferred forward)
+    refuse to go on instead of letting somebody read an unwritten tensor"""
+    from vdetr_amd import attention as A
+    B, nQ, nK = 1, 256, 1024
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn((B, nQ, 256), generator=g).to(DEV)
+    k, v = (torch.randn((B, nK, 64), generator=g).to(DEV) for _ in range(2))
+    table = (0.1 * torch.randn((8, 10, 10, 10, 4), generator=g)).to(DEV)
+    xyz, verts = _scene(B, nQ, nK, 2)
+    kw = dict(num_heads=4, scale=0.125, shared_kv=True, table=table, rpe=A.RPEConfig(), vertices=verts, xyz=xyz)
+    ref = A.fused_attention(q, k, v, **kw)
+    out = A.fused_attention(q, k, v, defer_combine=True, **kw)
+    assert A._pending_parts, "the forward at this size splits the keys"
+    with pytest.raises(RuntimeError, match="never ran"):
+        A.begin_step(q.device)
+    assert not A._pending_parts
+    del out, ref
+
+
 def test_fused_layer_parks_weight_gradients(monkeypatch):
     """with runtime.defer_weight_grads() the fused launches park their weight / bias / LayerNorm gradients like the separate
     ones: after the flush every parameter holds the same gradient as without parking"""

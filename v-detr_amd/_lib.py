@@ -168,6 +168,13 @@ class HeadsDesc(ctypes.Structure):
                                 "workspace")]
 
 
+class AttnParts(ctypes.Structure):
+    """Mirror of ``vdetr_attn_parts``."""
+
+    _fields_ = [("part_o", c_void_p), ("part_lse", c_void_p), ("ksplit", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("rows", ctypes.c_int64)]
+
+
 class PosMlpDesc(ctypes.Structure):
     """Mirror of ``vdetr_posmlp_desc``."""
 
@@ -263,6 +270,8 @@ _SIGNATURES = {
     "vdetr_attn_pack_kv_parts_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_int64, c_int, c_void_p, c_void_p]),
     "vdetr_attn_fwd_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_fwd_bf16": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vdetr_attn_fwd_parts_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         ctypes.POINTER(AttnParts), c_void_p]),
     "vdetr_attn_bwd_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
     "vdetr_attn_bwd_scores_f32": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vdetr_attn_bwd_kv_workspace_bytes": (c_size_t, [ctypes.POINTER(AttnDesc)]),
@@ -326,6 +335,7 @@ _SIGNATURES = {
     "vdetr_rb_qkv_f32": (c_int, [ctypes.POINTER(RbQkvDesc), c_void_p]),
     "vdetr_rb_proj_q_f32": (c_int, [ctypes.POINTER(RbProjQDesc), c_void_p]),
     "vdetr_rb_ffn_f32": (c_int, [ctypes.POINTER(RbFfnDesc), c_void_p]),
+    "vdetr_rb_ffn_parts_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(AttnParts), c_void_p, c_void_p, c_void_p]),
     "vdetr_rb_qkv_bwd_f32": (c_int, [ctypes.POINTER(RbQkvDesc), ctypes.POINTER(RbQkvGrads), c_void_p]),
     "vdetr_rb_proj_q_bwd_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), c_void_p]),
     "vdetr_rb_ffn_bwd_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), c_void_p]),

@@ -503,6 +503,7 @@ def begin_step(device):
     _master[key][1] += 1
     _current[key] = snap
     _step_side[key] = False
+    _no_pending("begin_step")
     _zero_pool[key] = None  # a fresh pool of zeros for this step's backward passes (allocated on first use)
     return snap
 
@@ -585,10 +586,30 @@ def _check_inputs(**tensors):
         L.require_float(t, name)
 
 
+# Forward calls whose key-split merge was left to their consumer (vdetr_attn_fwd_parts_f32 -> rowblock._Ffn): data_ptr of `out` ->
+# (parts, the workspace that holds the partials, lse, out).  `out` and `lse` are NOT valid until the consumer has run; the decoder
+# layer's fused path is the only caller that asks for this, directly in front of rowblock.ffn.  An entry that nobody took is a bug
+# (somebody would read an unwritten tensor): begin_step and the next deferred forward raise on it.
+_pending_parts = {}
+DEFER_COMBINE = os.environ.get("VDETR_DEFER_COMBINE", "1") != "0"
+
+
+def take_pending_parts(out):
+    """the record of a forward that left its merge to the consumer of `out` (None: `out` is final)"""
+    return _pending_parts.pop(out.data_ptr(), None) if _pending_parts else None
+
+
+def _no_pending(where):
+    if _pending_parts:
+        _pending_parts.clear()
+        raise RuntimeError(f"{where}: an attention forward left its key-split merge to a consumer that never ran "
+                           "(fused_attention(defer_combine=True) must be followed by rowblock.ffn on its output)")
+
+
 class _FusedAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, table, vertices, xyz, cos_sin, mask, kind, H, scale, rpe, dropout_p, rng_state,
-                need_grad, salt, table_async=False, kv_img=None, boxes=False, operand_bf16=False):
+                need_grad, salt, table_async=False, kv_img=None, boxes=False, operand_bf16=False, defer_combine=False):
         B, nQ, C = q.shape
         nK = k.shape[1]
         assert C == H * HEAD_DIM, f"embed dim {C} != {H} heads x {HEAD_DIM}"
@@ -638,9 +659,19 @@ class _FusedAttention(Function):
             d.fwd_sched = sched.data_ptr()
         nbytes = lib.vdetr_attn_fwd_workspace_bytes(ctypes.byref(d))
         ws = L.workspace(nbytes, q.device) if nbytes else None
-        fwd = lib.vdetr_attn_fwd_bf16 if bf16 else lib.vdetr_attn_fwd_f32
-        L.check(fwd(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse),
-                    L.ptr(scores), L.ptr(ws), nbytes, L.stream_ptr()), "attn_fwd")
+        if defer_combine and DEFER_COMBINE and not bf16 and kind == L.VDETR_ATTN_SHARED_KV and H == 4:
+            _no_pending("fused_attention")
+            parts = L.AttnParts()
+            L.check(lib.vdetr_attn_fwd_parts_f32(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse), L.ptr(scores),
+                                                 L.ptr(ws), nbytes, ctypes.byref(parts), L.stream_ptr()), "attn_fwd_parts")
+            if 2 <= parts.ksplit <= 16:
+                _pending_parts[out.data_ptr()] = (parts, ws, lse, out)
+            elif parts.ksplit != 1:
+                raise RuntimeError(f"fused_attention: {parts.ksplit} key chunks left unmerged and no consumer takes that many")
+        else:
+            fwd = lib.vdetr_attn_fwd_bf16 if bf16 else lib.vdetr_attn_fwd_f32
+            L.check(fwd(ctypes.byref(d), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(lse),
+                        L.ptr(scores), L.ptr(ws), nbytes, L.stream_ptr()), "attn_fwd")
         if need_grad:
             ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
             ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
@@ -747,7 +778,7 @@ class _FusedAttention(Function):
             dk, dv = dkv[0], dkv[1]
             if in_dtype == torch.bfloat16:
                 dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-            return (dq, dk, dv, dtable) + (None,) * 16
+            return (dq, dk, dv, dtable) + (None,) * 17
         if shared:
             # rows (b, q, h): [B, nQ*H, 64] views, K/V [B, nK, 64]
             do_r = dout.view(B, nQ * H, HEAD_DIM)
@@ -793,7 +824,7 @@ class _FusedAttention(Function):
                 dq = torch.bmm(ds_r, k_r).view(B, H, nQ, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, nQ, C)
         if in_dtype == torch.bfloat16:
             dq, dk, dv = dq.to(in_dtype), dk.to(in_dtype), dv.to(in_dtype)
-        return (dq, dk, dv, dtable) + (None,) * 16
+        return (dq, dk, dv, dtable) + (None,) * 17
 
 
 def _kv_layout(t, B, nK):
@@ -808,7 +839,7 @@ def _kv_layout(t, B, nK):
 
 def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=None, vertices=None, xyz=None,
                     cos_sin=None, attn_mask=None, dropout_p=0.0, rng_state=None, salt=0, table_grad_async=False, kv_img=None,
-                    vertices_are_boxes=False, operand_bf16=False):
+                    vertices_are_boxes=False, operand_bf16=False, defer_combine=False):
     """out[B,nQ,H*64] = dropout(softmax(scale * q k^T + rpe + mask)) v.
     kv_img: this call's slice of pack_kv_images() (optional: the forward packs its own otherwise).
     operand_bf16: f32 q / k / v whose values are rounded to bf16 on the way into QK^T and PV (BASELINE config 4's arithmetic
@@ -816,6 +847,8 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
     pack_kv_images(parts=1) for kv_img.
     vertices_are_boxes: the caller vouches that every query's 8 vertices are an axis-aligned box (they come out of a box decode):
     the table gradient then launches its box kernel alone (vdetr_attn_desc.bwd_kernel = 2).
+    defer_combine: the caller hands the result to rowblock.ffn NEXT and to nothing else: where the forward splits the keys, the merge
+    of the partial results is done by that launch on its way in (vdetr_attn_fwd_parts_f32; the returned tensor is not valid before).
 
     q [B,nQ,H*64]; k,v [B,nK,64] (shared_kv) or [B,nK,H*64]; table [8,T,T,T,H]; vertices [B,nQ,8,3];
     xyz [B,nK,3]; cos_sin [B,nQ,2] or None; attn_mask [B,nQ,nK] bool (-100 fill) / float (additive) or None.
@@ -839,7 +872,7 @@ def fused_attention(q, k, v, *, num_heads, scale, shared_kv, table=None, rpe=Non
     k, v = _kv_layout(k, B, nK), _kv_layout(v, B, nK)
     return _FusedAttention.apply(q.contiguous(), k, v, table, vertices, xyz, cos_sin, mask,
                                  kind, num_heads, float(scale), rpe, float(dropout_p), rng_state, need_grad, int(salt),
-                                 bool(table_grad_async), kv_img, bool(vertices_are_boxes), bool(operand_bf16))
+                                 bool(table_grad_async), kv_img, bool(vertices_are_boxes), bool(operand_bf16), bool(defer_combine))
 
 
 class KVImage:

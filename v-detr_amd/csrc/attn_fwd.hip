@@ -593,9 +593,9 @@ extern "C" int vdetr_attn_pack_kv_parts_f32(const float* k, const float* v, int 
   return attn_fwd_pack_launch(k, v, B, nK, k_row_stride, v_row_stride, nlayers, (long)layer_stride, (char*)img, parts, true, (hipStream_t)stream);
 }
 
-extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
-                                  float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
-                                  vdetr_stream_t stream) {
+// parts != nullptr: the key-split merge is left to the consumer (vdetr_attn_fwd_parts_f32)
+static int attn_fwd_run(const vdetr_attn_desc* d, const float* q, const float* k, const float* v, float* out, float* lse, float* scores,
+                        void* workspace, size_t workspace_bytes, vdetr_attn_parts* parts, vdetr_stream_t stream) {
   AttnParams P;
   if (int e = attn_fill_params(d, &P, "attn_fwd")) return e;
   VDETR_REQUIRE(q && k && v && out && lse, "attn_fwd: null pointer");
@@ -677,12 +677,34 @@ extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, cons
     }
   }
   if (int e = check_launch("attn_fwd")) return e;
+  if (parts) {
+    parts->part_o = ks > 1 ? P.part_o : nullptr;
+    parts->part_lse = ks > 1 ? P.part_lse : nullptr;
+    parts->ksplit = ks;
+    parts->reserved = 0;
+    parts->rows = (int64_t)d->B * d->nQ * d->H;
+    return VDETR_OK;
+  }
   if (ks > 1) {
     const size_t elems = (size_t)d->B * d->nQ * d->H * kDh;
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, P);
     return check_launch("attn_fwd_combine");
   }
   return VDETR_OK;
+}
+
+extern "C" int vdetr_attn_fwd_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
+                                  float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
+                                  vdetr_stream_t stream) {
+  return attn_fwd_run(d, q, k, v, out, lse, scores, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int vdetr_attn_fwd_parts_f32(const vdetr_attn_desc* d, const float* q, const float* k, const float* v,
+                                        float* out, float* lse, float* scores, void* workspace, size_t workspace_bytes,
+                                        vdetr_attn_parts* parts, vdetr_stream_t stream) {
+  VDETR_REQUIRE(d && parts, "attn_fwd_parts: null pointer");
+  VDETR_REQUIRE(d->kind == VDETR_ATTN_SHARED_KV, "attn_fwd_parts: built for the shared-KV kinds (rows in (b, q, h) order)");
+  return attn_fwd_run(d, q, k, v, out, lse, scores, workspace, workspace_bytes, parts, stream);
 }
 
 // q, k, v bf16 (k_row_stride / v_row_stride in ELEMENTS, multiples of 8: 16-B aligned operand loads); out, lse, scores fp32

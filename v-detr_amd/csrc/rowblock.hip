@@ -186,6 +186,74 @@ __device__ __forceinline__ void rb_row_stats(const f32x4 (&y)[4], float* red, in
     rstd[r] = rsqrtf(((red[64 + 4 * g + r] + red[80 + 4 * g + r]) + (red[96 + 4 * g + r] + red[112 + 4 * g + r])) * (1.f / kRbC) + eps);
 }
 
+// ---- the same tile out of the key-split partials of the attention forward (vdetr_attn_fwd_parts_f32) -------------------------------
+// out = sum_s exp(lse_s - M) o_s / sum_s exp(lse_s - M): attn_fwd_combine_kernel's arithmetic in its order (bit-identical), done by the
+// launch that reads the rows anyway.  Row (q, b) of the tile is attention row b * nQ + q; its 256 columns are 4 heads x 64.  The
+// merged rows and their log-sum-exp are written where the merge launch would have left them (the backward reads both).
+struct RbParts {
+  const float* part_o;    // [ks][rows4][64]
+  const float* part_lse;  // [ks][rows4]
+  float* out;             // [B, nQ, 256]
+  float* lse;             // [B, nQ, 4]
+  long rows4;
+  int ks;
+};
+template <int KS>  // > 0: that many partials, unrolled (every load in flight before the first use); 0: P.ks of them, one after the other
+__device__ __forceinline__ void rb_stage_parts(const RbParts& P, int row0, int rows, int B, float* xs, int tid) {
+  constexpr int kPer = kRbRows * kRbC / 4 / kRbThreads;
+  constexpr int kS = KS > 0 ? KS : 1;
+  f32x4 o[kPer][kS];
+  float ls[kPer][kS];
+  size_t prow[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + u * kRbThreads, r = e >> 6, c4 = e & 63;
+    const int row = min(row0 + r, rows - 1);
+    prow[u] = (size_t)rb_bmajor(row, B, rows / B) * 4 + (c4 >> 4);
+    if constexpr (KS > 0) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        ls[u][s] = P.part_lse[(size_t)s * P.rows4 + prow[u]];
+        o[u][s] = reinterpret_cast<const f32x4*>(P.part_o + ((size_t)s * P.rows4 + prow[u]) * kDh)[c4 & 15];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int e = tid + u * kRbThreads, r = e >> 6, c4 = e & 63;
+    float M = kNegBig, L = 0.f;
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KS > 0) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) M = fmaxf(M, ls[u][s]);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float f = __expf(ls[u][s] - M);
+        L += f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[i] += f * o[u][s][i];
+      }
+    } else {
+      for (int s = 0; s < P.ks; ++s) M = fmaxf(M, P.part_lse[(size_t)s * P.rows4 + prow[u]]);
+      for (int s = 0; s < P.ks; ++s) {
+        const float f = __expf(P.part_lse[(size_t)s * P.rows4 + prow[u]] - M);
+        const f32x4 ov = reinterpret_cast<const f32x4*>(P.part_o + ((size_t)s * P.rows4 + prow[u]) * kDh)[c4 & 15];
+        L += f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[i] += f * ov[i];
+      }
+    }
+    f32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = L > 0.f ? val[i] / L : 0.f;
+    if (row0 + r < rows) {
+      reinterpret_cast<f32x4*>(P.out + prow[u] * kDh)[c4 & 15] = t;  // (b, q, h) rows of 64 = [B, nQ, 256]
+      if ((c4 & 15) == 0) P.lse[prow[u]] = L > 0.f ? M + __logf(L) : kNegBig;
+    }
+    *reinterpret_cast<f32x4*>(xs + r * kRbStride + 4 * c4) = t;
+  }
+}
+
 typedef vdetr_rb_linear RbLinear;
 typedef vdetr_rb_norm RbNorm;
 typedef vdetr_rb_drop RbDropArgs;
@@ -196,7 +264,9 @@ typedef vdetr_rb_drop RbDropArgs;
 // its first weight steps requested before the epilogue in between runs.
 typedef vdetr_rb_ffn_desc RbFfnArgs;
 
-__global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A) {
+// PARTS: -1 = the rows of A.a; >= 0: the merge of key-split partials (rb_stage_parts<PARTS>)
+template <int PARTS>
+__global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A, RbParts Pp) {
   __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
   __shared__ float red[128];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -221,7 +291,8 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) tg[r] = rb_ld4(A.tgt, min(row0 + 4 * g + r, A.rows - 1), colq);
   __builtin_amdgcn_sched_barrier(0);
-  rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
+  if constexpr (PARTS < 0) rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
+  else rb_stage_parts<PARTS>(Pp, row0, A.rows, A.B, xs, tid);
   __syncthreads();
   rb_load_a(xs, lane, a);
   rb_zero(acc);
@@ -752,8 +823,35 @@ extern "C" int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t strea
                 RB_ALIGNED(d->post1.gamma) && RB_ALIGNED(d->post1.beta) && RB_ALIGNED(d->post2.gamma) && RB_ALIGNED(d->post2.beta) &&
                 RB_ALIGNED(d->y) && RB_ALIGNED(d->t2) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) && RB_ALIGNED(d->o1) && RB_ALIGNED(d->o2),
                 "rb_ffn: operands must be 16-B aligned");
-  hipLaunchKernelGGL(rb_ffn_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(rb_ffn_kernel<-1>, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, RbParts{});
   return check_launch("rb_ffn");
+}
+
+extern "C" int vdetr_rb_ffn_parts_f32(const vdetr_rb_ffn_desc* d, const vdetr_attn_parts* parts, float* attn_out, float* attn_lse,
+                                      vdetr_stream_t stream) {
+  VDETR_REQUIRE(d != nullptr && parts != nullptr, "rb_ffn_parts: null descriptor");
+  if (int e = rb_common(d->rows, d->B, "rb_ffn_parts")) return e;
+  VDETR_REQUIRE(attn_out && attn_lse && d->tgt && d->proj.wt && d->lin1.wt && d->lin2.wt && d->norm3.gamma && d->norm3.beta && d->post1.gamma &&
+                d->post1.beta && d->y && d->mean_y && d->rstd_y && d->t2 && d->h && d->z && d->mean_z && d->rstd_z && d->o1,
+                "rb_ffn_parts: null pointer (proj.wt / lin1.wt / lin2.wt: the W^T images, vdetr_rb_transpose_f32)");
+  VDETR_REQUIRE(parts->ksplit >= 2 && parts->ksplit <= 16 && parts->part_o && parts->part_lse,
+                "rb_ffn_parts: ksplit %d outside 2..16 or null partials (ksplit 1: the forward's out / lse are final, take vdetr_rb_ffn_f32)", parts->ksplit);
+  VDETR_REQUIRE(parts->rows == (int64_t)d->rows * 4, "rb_ffn_parts: %lld partial rows for %d rows of 4 heads", (long long)parts->rows, d->rows);
+  VDETR_REQUIRE((d->post2.gamma == nullptr) == (d->post2.beta == nullptr) && (d->post2.gamma == nullptr) == (d->o2 == nullptr),
+                "rb_ffn_parts: post2.gamma, post2.beta and o2 go together");
+  for (const vdetr_rb_drop* dr : {&d->drop2, &d->drop_act, &d->drop3})
+    VDETR_REQUIRE(dr->p >= 0.f && dr->p < 1.f, "rb_ffn_parts: dropout_p %f outside [0,1)", dr->p);
+  VDETR_REQUIRE(RB_ALIGNED(attn_out) && RB_ALIGNED(parts->part_o) && RB_ALIGNED(d->tgt) && RB_ALIGNED(d->proj.wt) && RB_ALIGNED(d->proj.b) &&
+                RB_ALIGNED(d->lin1.wt) && RB_ALIGNED(d->lin1.b) && RB_ALIGNED(d->lin2.wt) && RB_ALIGNED(d->lin2.b) && RB_ALIGNED(d->norm3.gamma) &&
+                RB_ALIGNED(d->norm3.beta) && RB_ALIGNED(d->post1.gamma) && RB_ALIGNED(d->post1.beta) && RB_ALIGNED(d->post2.gamma) &&
+                RB_ALIGNED(d->post2.beta) && RB_ALIGNED(d->y) && RB_ALIGNED(d->t2) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) && RB_ALIGNED(d->o1) &&
+                RB_ALIGNED(d->o2), "rb_ffn_parts: operands must be 16-B aligned");
+  RbParts P{parts->part_o, parts->part_lse, attn_out, attn_lse, (long)parts->rows, parts->ksplit};
+  const dim3 grid(ceil_div(d->rows, kRbRows));
+  if (parts->ksplit == 4) hipLaunchKernelGGL(rb_ffn_kernel<4>, grid, dim3(kRbThreads), 0, (hipStream_t)stream, *d, P);
+  else if (parts->ksplit == 2) hipLaunchKernelGGL(rb_ffn_kernel<2>, grid, dim3(kRbThreads), 0, (hipStream_t)stream, *d, P);
+  else hipLaunchKernelGGL(rb_ffn_kernel<0>, grid, dim3(kRbThreads), 0, (hipStream_t)stream, *d, P);
+  return check_launch("rb_ffn_parts");
 }
 
 extern "C" int vdetr_rb_qkv_bwd_f32(const vdetr_rb_qkv_desc* d, const vdetr_rb_qkv_grads* g, vdetr_stream_t stream) {

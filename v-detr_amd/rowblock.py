@@ -356,7 +356,15 @@ class _Ffn(torch.autograd.Function):
         d.h = h.data_ptr()
         d.z, d.mean_z, d.rstd_z, d.o1 = z.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), o1.data_ptr()
         d.o2 = o2.data_ptr() if o2 is not None else None
-        L.check(L.lib().vdetr_rb_ffn_f32(ctypes.byref(d), L.stream_ptr()), "rb_ffn")
+        pend = A.take_pending_parts(a)
+        if pend is not None:
+            # `a` is the output of an attention forward that left the merge of its key-split partials to this launch
+            # (attention.fused_attention(defer_combine=True)): rb_ffn merges them on its way in and writes `a` and its lse
+            parts, _ws, lse, _out = pend
+            L.check(L.lib().vdetr_rb_ffn_parts_f32(ctypes.byref(d), ctypes.byref(parts), a.data_ptr(), lse.data_ptr(), L.stream_ptr()),
+                    "rb_ffn_parts")
+        else:
+            L.check(L.lib().vdetr_rb_ffn_f32(ctypes.byref(d), L.stream_ptr()), "rb_ffn")
         ctx.cfg = (rows, float(eps3), float(epsp), float(p2), salt2, float(pa), float(p3), salt3, B, tgt.shape)
         ctx.ln3 = (g3, be3, None, None)
         ctx.lnp = (gp1, bep1, gp2, bep2)

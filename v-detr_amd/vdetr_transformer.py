@@ -246,7 +246,7 @@ class GlobalShareCrossAttention(nn.Module):
             tables = A.park_table_grads(torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H))
         return [(parts[2 * i], parts[2 * i + 1], tables[i], imgs[i] if imgs is not None else None) for i in range(n)]
 
-    def core(self, q, key, reference_point, reference_angle, xyz, attn_mask=None, cache=None):
+    def core(self, q, key, reference_point, reference_angle, xyz, attn_mask=None, cache=None, defer_combine=False):
         """The attention between the query projection and the output projection (:733-753): q [B,nQ,C] projected queries ->
         (x [B,nQ,C], attn or None).  `key` [nK,B,C] is projected here unless `cache` = (k, v, tables) carries the layer's share
         of TransformerDecoder's joint projection."""
@@ -276,7 +276,8 @@ class GlobalShareCrossAttention(nn.Module):
                               rpe=self.rpe_cfg, vertices=reference_point, xyz=xyz, cos_sin=cos_sin,
                               attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt,
                               table_grad_async=cache is not None, vertices_are_boxes=self.vertices_are_boxes, **({"operand_bf16": True} if rounded else {}),
-                              **({"kv_img": cache[3]} if (cache is not None and len(cache) > 3 and cache[3] is not None) else {}))
+                              **({"kv_img": cache[3]} if (cache is not None and len(cache) > 3 and cache[3] is not None) else {}),
+                              defer_combine=defer_combine and not self.return_attn)
         attn = None
         if self.return_attn:
             attn = A.attention_probabilities(q32.float(), k32.float(), num_heads=self.num_heads, scale=self.scale, shared_kv=True,
@@ -486,7 +487,8 @@ class GlobalDecoderLayer(nn.Module):
             core = A.fused_attention(q, k, v, num_heads=sa.num_heads, scale=sa.head_dim ** -0.5, shared_kv=False, dropout_p=p,
                                      salt=sa._salt)
             tgt, qc = RB.proj_q(core, tgt, pos2, sa.out_proj, ca.q, self.dropout1, self.norm2, self._aln_salts[0], B, img)
-            core, _ = ca.core(qc, memory, reference_point, reference_angle, enc_xyz, None, self.cross_cache)
+            # (defer_combine: the merge of the forward's key-split partials is done by rb_ffn, the next launch, on its way in)
+            core, _ = ca.core(qc, memory, reference_point, reference_angle, enc_xyz, None, self.cross_cache, defer_combine=True)
             if getattr(self, "_act_salt", None) is None:
                 self._act_salt = BNA.new_salt()
             res = RB.ffn(core, tgt, self, self.post_norms, self._aln_salts, self._act_salt, B, img)
