@@ -220,6 +220,26 @@ def quiesce_collectives(self):
         time.sleep(0.12)
 
 
+CLIP_NORM = 0.1  # --clip_gradient (main.py / engine.py:105-106)
+
+
+def make_optimizer(flat, reduced_after_pack):
+    """AdamW(lr 7e-4, weight decay 0.1) behind clip_grad_norm_(0.1) on the flat buffer: vdetr_amd.optim.ClipAdamW (norm out of the pack
+    launch, clip + update in one launch); VDETR_OWN_ADAMW=0: torch's fused AdamW with the clip coefficient as its grad_scale (A/B)"""
+    if os.environ.get("VDETR_OWN_ADAMW", "1") != "0" and flat.data.is_cuda:
+        from vdetr_amd.optim import ClipAdamW
+        return ClipAdamW(flat, lr=7e-4, weight_decay=0.1, max_norm=CLIP_NORM, norm_from_pack=not reduced_after_pack)
+    return torch.optim.AdamW([flat.param], lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
+
+
+def optimizer_step(opt, flat):
+    if not hasattr(opt, "max_norm"):
+        # clip_grad_norm_(params, 0.1): one norm over the flat gradient; the clip coefficient is applied inside the fused AdamW
+        # launch (grad_scale = 1 / coefficient)
+        opt.grad_scale = flat.clip_scale(CLIP_NORM)[0]
+    opt.step()
+
+
 class Trainer:
     """fwd + bwd (+ all-reduce) + clip + AdamW, eager or as captured hipGraphs."""
 
@@ -257,7 +277,7 @@ class Trainer:
         # (GradientReducer.reduce_phased); the optimizer step follows in the same graph: one replay per step, no eager gap
         # between backward, RCCL and AdamW.  VDETR_PHASED_REDUCE=0: the round-2 sequence (graph, eager all-reduce, graph).
         self.phased = use_graph and self.reducer.active and os.environ.get("VDETR_PHASED_REDUCE", "1") != "0"
-        self.opt = torch.optim.AdamW([self.flat.param], lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
+        self.opt = make_optimizer(self.flat, reduced_after_pack=self.reducer.active)
         self.use_graph = use_graph
         self.g_main = self.g_opt = None
         self.loss = None
@@ -332,10 +352,7 @@ class Trainer:
         ts_mark("gradients packed, sampling joined")
 
     def _update(self):
-        # clip_grad_norm_(params, 0.1) (engine.py:105-106): one norm over the flat gradient; the clip coefficient is
-        # applied inside the fused AdamW launch (grad_scale = 1 / coefficient)
-        self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
-        self.opt.step()
+        optimizer_step(self.opt, self.flat)
         from vdetr_amd.runtime import ts_mark
         ts_mark("optimizer done")
 
@@ -484,7 +501,7 @@ class BackboneTrainer:
         self.bb_overlap = self.reducer.active and os.environ.get("VDETR_BB_OVERLAP", "1") != "0"
         if self.bb_overlap:
             self.reducer.launch_when_complete(self.bb_buckets)
-        self.opt = torch.optim.AdamW([self.flat.param], lr=7e-4, weight_decay=0.1, capturable=True, fused=True)
+        self.opt = make_optimizer(self.flat, reduced_after_pack=self.reducer.active)
         self.graph, self.loss = None, None
         # the NEXT scene's geometry and FPS indices are built on a side stream while this scene trains (the synthetic bench
         # feeds the same cloud again, so "next" is recomputed from it every step: its cost is inside ms_per_step)
@@ -585,8 +602,7 @@ class BackboneTrainer:
             self.reducer.finish()
         else:
             self.flat.pack_grads()
-        self.opt.grad_scale = self.flat.clip_scale(0.1)[0]
-        self.opt.step()
+        optimizer_step(self.opt, self.flat)
         mark()
         if mode == "inline":
             # (A/B variant) the step is enqueued: the host builds the geometry of scene i+2 now, on a side stream (two alternate:

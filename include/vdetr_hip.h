@@ -606,6 +606,39 @@ int vdetr_colsum_f32(const float* x, float* out, int rows, int cols, long row_st
 int vdetr_pack_chunk_floats(void);
 int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk, int nblocks,
                    float* dst, vdetr_stream_t stream);
+/* The same launch, which also leaves sumsq[b] = the sum of squares of what workgroup b copied (nblocks floats): the gradient norm of
+ * clip_grad_norm_ (engine.py:105-106) costs no pass of its own (vdetr_adamw_clip_f32 adds the partials up). */
+int vdetr_pack_sumsq_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk, int nblocks,
+                         float* dst, float* sumsq, vdetr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Gradient-norm clipping + AdamW on a flat parameter buffer, one launch (csrc/optim.hip).
+ * Reference: engine.py:105-107 (clip_grad_norm_ then optimizer.step()), optimizer.py:6-26 (torch.optim.AdamW; amsgrad off).
+ *   p -= lr wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ *   g' = g / max((||g|| + norm_eps) / max_norm, 1), ||g||^2 = the sum of `sumsq` (vdetr_pack_sumsq_f32's or vdetr_sumsq_f32's
+ *   partials; NULL: no clipping).  t = *step + 1; the launch leaves *step = t (device-resident: a captured graph replays it).
+ *   `ticket`: one zero device word, left zero.  norm_out (optional): ||g||.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vdetr_adamw_desc {
+  float* param;         /* [n] */
+  const float* grad;    /* [n] */
+  float* exp_avg;       /* [n] */
+  float* exp_avg_sq;    /* [n] */
+  int64_t n;
+  float* step;
+  uint32_t* ticket;
+  const float* sumsq;
+  int32_t nsumsq;
+  float max_norm;
+  float norm_eps;       /* 1e-6 in clip_grad_norm_ */
+  float* norm_out;
+  double lr, beta1, beta2, eps, weight_decay;
+} vdetr_adamw_desc;
+int vdetr_adamw_clip_f32(const vdetr_adamw_desc* d, vdetr_stream_t stream);
+/* partial[b] = sum of squares of slice b of g [n] (npartial = vdetr_sumsq_blocks(n)): the norm's first half where the flat gradient
+ * changed after the pack (all-reduce, N > 1). */
+int vdetr_sumsq_blocks(long n);
+int vdetr_sumsq_f32(const float* g, long n, float* partial, int npartial, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Z-order permutation of a scene's key points, one launch (one workgroup per scene).  Replaces the tensor expression the

@@ -175,6 +175,15 @@ class AttnParts(ctypes.Structure):
                 ("rows", ctypes.c_int64)]
 
 
+class AdamWDesc(ctypes.Structure):
+    """Mirror of ``vdetr_adamw_desc``."""
+
+    _fields_ = [(n, c_void_p) for n in ("param", "grad", "exp_avg", "exp_avg_sq")] + [("n", ctypes.c_int64)] + [
+        (n, c_void_p) for n in ("step", "ticket", "sumsq")] + [("nsumsq", ctypes.c_int32), ("max_norm", c_float), ("norm_eps", c_float),
+                                                                ("norm_out", c_void_p)] + [
+        (n, ctypes.c_double) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
+
+
 class PosMlpDesc(ctypes.Structure):
     """Mirror of ``vdetr_posmlp_desc``."""
 
@@ -311,6 +320,10 @@ _SIGNATURES = {
     "vdetr_morton_order_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vdetr_pack_chunk_floats": (c_int, []),
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vdetr_pack_sumsq_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "vdetr_adamw_clip_f32": (c_int, [ctypes.POINTER(AdamWDesc), c_void_p]),
+    "vdetr_sumsq_blocks": (c_int, [ctypes.c_long]),
+    "vdetr_sumsq_f32": (c_int, [c_void_p, ctypes.c_long, c_void_p, c_int, c_void_p]),
     "vdetr_gt_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vdetr_match_cost_f32": (c_int, [ctypes.POINTER(MatchDesc), c_void_p]),
     "vdetr_match_cost_batch_f32": (c_int, [ctypes.POINTER(MatchDesc), c_int, c_void_p]),

@@ -11,9 +11,12 @@ namespace vdetr {
 
 constexpr int kPackChunk = 8192;  // floats per workgroup
 
+template <bool SUMSQ>
 __global__ __launch_bounds__(256) void pack_kernel(const vdetr_pack_entry* __restrict__ entries,
                                                   const uint32_t* __restrict__ block_entry,
-                                                  const uint32_t* __restrict__ block_chunk, float* __restrict__ dst) {
+                                                  const uint32_t* __restrict__ block_chunk, float* __restrict__ dst,
+                                                  float* __restrict__ sumsq) {
+  float acc = 0.f;  // SUMSQ: sum of squares of this thread's elements (the gradient norm's first half, optim.hip)
   const vdetr_pack_entry e = entries[block_entry[blockIdx.x]];
   const uint64_t begin = (uint64_t)block_chunk[blockIdx.x] * kPackChunk;
   const uint64_t end = begin + kPackChunk < e.numel ? begin + kPackChunk : e.numel;
@@ -25,10 +28,26 @@ __global__ __launch_bounds__(256) void pack_kernel(const vdetr_pack_entry* __res
     for (uint64_t i = b4 + threadIdx.x; i < e4; i += 256) {
       float4 v = src ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       reinterpret_cast<float4*>(out)[i] = v;
+      if (SUMSQ) acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
-    for (uint64_t i = (e4 << 2) + threadIdx.x; i < end; i += 256) out[i] = src ? src[i] : 0.f;
+    for (uint64_t i = (e4 << 2) + threadIdx.x; i < end; i += 256) {
+      const float x = src ? src[i] : 0.f;
+      out[i] = x;
+      if (SUMSQ) acc += x * x;
+    }
   } else {
-    for (uint64_t i = begin + threadIdx.x; i < end; i += 256) out[i] = src ? src[i] : 0.f;
+    for (uint64_t i = begin + threadIdx.x; i < end; i += 256) {
+      const float x = src ? src[i] : 0.f;
+      out[i] = x;
+      if (SUMSQ) acc += x * x;
+    }
+  }
+  if constexpr (SUMSQ) {  // fixed order: lanes by xor-shuffle, the four waves through LDS
+    __shared__ float red[4];
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -80,6 +99,14 @@ extern "C" int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* b
   VDETR_REQUIRE(nblocks >= 0, "pack: negative block count");
   if (nblocks == 0) return VDETR_OK;
   VDETR_REQUIRE(entries && block_entry && block_chunk && dst, "pack: null pointer");
-  hipLaunchKernelGGL(pack_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, entries, block_entry, block_chunk, dst);
+  hipLaunchKernelGGL(pack_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, entries, block_entry, block_chunk, dst, (float*)nullptr);
   return check_launch("pack");
+}
+
+extern "C" int vdetr_pack_sumsq_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk,
+                                    int nblocks, float* dst, float* sumsq, vdetr_stream_t stream) {
+  VDETR_REQUIRE(nblocks > 0, "pack_sumsq: no blocks");
+  VDETR_REQUIRE(entries && block_entry && block_chunk && dst && sumsq, "pack_sumsq: null pointer");
+  hipLaunchKernelGGL(pack_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, entries, block_entry, block_chunk, dst, sumsq);
+  return check_launch("pack_sumsq");
 }

@@ -215,8 +215,16 @@ class FlatParams:
             ptrs.append(g.data_ptr())
         host[:, 0] = torch.tensor(ptrs, dtype=torch.int64)  # one strided copy (an element assignment per tensor costs ~1 us each)
         P["dev"].copy_(host, non_blocking=True)
-        L.check(L.lib().vdetr_pack_f32(L.ptr(P["dev"]), L.ptr(P["block_entry"]), L.ptr(P["block_chunk"]), P["nblocks"],
-                                       L.ptr(self.grad), L.stream_ptr()), "pack")
+        if span is None and getattr(self, "want_sumsq", False):
+            # (optim.ClipAdamW asked) the same launch leaves the sum of squares of what each workgroup copied: the gradient norm
+            # costs no pass of its own.  Valid for the WHOLE buffer only, and only until something else writes the flat gradient.
+            if getattr(self, "sumsq", None) is None or self.sumsq.numel() != P["nblocks"]:
+                self.sumsq = torch.empty(P["nblocks"], dtype=torch.float32, device=self.grad.device)
+            L.check(L.lib().vdetr_pack_sumsq_f32(L.ptr(P["dev"]), L.ptr(P["block_entry"]), L.ptr(P["block_chunk"]), P["nblocks"],
+                                                 L.ptr(self.grad), L.ptr(self.sumsq), L.stream_ptr()), "pack_sumsq")
+        else:
+            L.check(L.lib().vdetr_pack_f32(L.ptr(P["dev"]), L.ptr(P["block_entry"]), L.ptr(P["block_chunk"]), P["nblocks"],
+                                           L.ptr(self.grad), L.stream_ptr()), "pack")
         if not capturing:
             P["events"][slot] = torch.cuda.Event()
             P["events"][slot].record()
