@@ -942,6 +942,11 @@ typedef struct vdetr_posmlp_desc {
   float* out;              /* [N, B, 256] */
 } vdetr_posmlp_desc;
 int vdetr_pos_mlp_fwd_f32(const vdetr_posmlp_desc* d, vdetr_stream_t stream);
+/* vdetr_rb_qkv_f32 whose `pos` rows are the position MLP of `m`, computed by the same launch (rowblock.hip: the q and k workgroups
+ * form their 16 rows of it on the way in; one launch less in front of every decoder layer).  Writes everything vdetr_pos_mlp_fwd_f32
+ * writes (m->out = the pos rows [N, B, 256], hpre, hact, the statistics) and everything vdetr_rb_qkv_f32 writes; d->pos is not read
+ * (NULL or m->out).  B * N = d->rows, a multiple of 16. */
+int vdetr_rb_qkv_pos_f32(const vdetr_rb_qkv_desc* d, const vdetr_posmlp_desc* m, vdetr_stream_t stream);
 
 /* LDS update-rate probe (mode 0 ds_add_f32, 1 ds_add_u32, 2 plain read-add-write, 3 ds_add_f32 on 8 hot bins):
  * 256 workgroups x 512 threads x `iters` updates.  Measurement hook used by tools/kernel_bench.py --lds. */

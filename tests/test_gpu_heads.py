@@ -166,10 +166,12 @@ def test_fused_position_mlp_equals_the_module(B, N):
         _close(p.grad.cpu(), q.grad, 2e-4, n)
 
 
-def test_whole_step_with_fused_heads_equals_the_unfused_step():
+def test_whole_step_with_fused_heads_equals_the_unfused_step(monkeypatch):
     """a training step of the model (4 stages, dropout on) with the heads / position MLPs fused and unfused: losses, every
     gradient, the BatchNorm buffers"""
+    from helpers import fixed_salts
     from test_gpu_model import _inputs, _loss
+    fixed_salts(monkeypatch)  # (the same dropout streams whatever ran before in this process)
     from vdetr_amd import attention as A
     from vdetr_amd import heads as HD
     from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads

@@ -163,6 +163,121 @@ def test_key_split_merge_inside_rb_ffn_equals_the_merge_launch(monkeypatch, B, n
             assert torch.equal(a, b), f"{n}: max |diff| {float((a - b).abs().max())}"
 
 
+@pytest.mark.parametrize("B,nQ,nK", [(1, 64, 256), (1, 1024, 512), (2, 48, 130), (3, 16, 64)])
+def test_position_mlp_inside_rb_qkv_equals_its_own_launch(monkeypatch, B, nQ, nK):
+    """The layer whose learned query position is computed by its q / k / v launch (vdetr_rb_qkv_pos_f32, heads.lazy_pos) against
+    the layer behind the position MLP's own launch: outputs, the MLP's saved tensors and running statistics, every gradient
+    (the MLP's through the flush).  The product's summation order differs between the two kernels: fp32 rounding apart."""
+    from vdetr_amd import attention as A
+    from vdetr_amd import heads as HD
+    from vdetr_amd import vdetr_transformer as T
+    from vdetr_amd.helpers import PositionEmbeddingLearned
+    from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
+    monkeypatch.setattr(T, "_ROWBLOCK", True)
+    layer = _layer(7).train()
+    torch.manual_seed(11)
+    posm = PositionEmbeddingLearned(6, 256).to(DEV).train()
+    with torch.no_grad():
+        posm.position_embedding_head[1].weight.uniform_(0.5, 1.5)
+        posm.position_embedding_head[1].bias.normal_(0, 0.3)
+    out_norm = torch.nn.LayerNorm(256).to(DEV)
+    g = torch.Generator().manual_seed(B * 77 + nQ)
+    tgt0 = torch.randn((nQ, B, 256), generator=g).to(DEV)
+    mem0 = torch.randn((nK, B, 256), generator=g).to(DEV)
+    boxes = torch.cat((torch.rand((B, nQ, 3), generator=g) * torch.tensor([8.0, 6.0, 0.5]) + 1.0, torch.rand((B, nQ, 3), generator=g) + 0.1), -1).to(DEV)
+    xyz, verts = _scene(B, nQ, nK, 12)
+    wts = [torch.randn((nQ, B, 256), generator=g).to(DEV) for _ in range(2)]
+    params = list(layer.parameters()) + list(out_norm.parameters()) + list(posm.parameters())
+    names = [n for n, _ in layer.named_parameters()] + ["out_norm.weight", "out_norm.bias"] + ["pos." + n for n, _ in posm.named_parameters()]
+    bn = posm.position_embedding_head[1]
+    stats0 = (bn.running_mean.clone(), bn.running_var.clone())
+    launches = []
+    real = HD.take_pending_pos
+    monkeypatch.setattr(HD, "take_pending_pos", lambda pos: launches.append(real(pos)) or launches[-1])
+
+    def run(lazy):
+        A.reset_rng()
+        with torch.no_grad():
+            bn.running_mean.copy_(stats0[0]); bn.running_var.copy_(stats0[1]); bn.num_batches_tracked.zero_()
+        for p in params:
+            p.grad = None
+        tgt, mem = (t.clone().requires_grad_(True) for t in (tgt0, mem0))
+        defer_weight_grads(True)
+        try:
+            prev = HD.lazy_pos(lazy)
+            try:
+                pos = posm(boxes).permute(2, 0, 1)
+            finally:
+                HD.lazy_pos(prev)
+            assert bool(HD._pending_pos) == lazy
+            layer.post_norms = (out_norm,)
+            layer.pre_normed = None
+            out, _ = layer(tgt, mem, verts, None, xyz, None, query_pos=pos)
+            (o1,) = layer.post_normed
+            layer.post_norms = layer.post_normed = None
+            assert not HD._pending_pos
+            ((out * wts[0]).sum() + (o1 * wts[1]).sum()).backward()
+            flush_weight_grads()
+        finally:
+            defer_weight_grads(False)
+        return [out, o1, pos.detach().clone(), bn.running_mean.clone(), bn.running_var.clone(), tgt.grad, mem.grad] + [p.grad for p in params]
+
+    ref = run(False)
+    got = run(True)
+    assert [r is not None for r in launches] == [False, True], launches
+    assert int(bn.num_batches_tracked) == 1
+    all_names = ["out", "norm(out)", "query_pos", "running_mean", "running_var", "d tgt", "d memory"] + names
+    for n, a, b in zip(all_names, got, ref):
+        if b is None:
+            assert a is None or n.endswith("head.0.bias"), n
+            continue
+        if n.endswith("position_embedding_head.0.bias"):  # cancels under batch statistics: rounding noise on both sides
+            continue
+        _close(a, b, n, floor=_floor(n, all_names, ref))
+
+
+def test_a_position_mlp_left_to_rb_qkv_is_launched_by_a_layer_that_takes_another_path(monkeypatch):
+    """heads.lazy_pos(True) and then a layer that does NOT run through rowblock.py: the layer launches the position MLP itself
+    (heads.materialize_pos) — same values as without the switch; a pending one that nothing consumed is an error at the next forward"""
+    from vdetr_amd import attention as A
+    from vdetr_amd import heads as HD
+    from vdetr_amd import vdetr_transformer as T
+    from vdetr_amd.helpers import PositionEmbeddingLearned
+    from vdetr_amd.runtime import defer_weight_grads
+    monkeypatch.setattr(T, "_ROWBLOCK", False)
+    layer = _layer(8).train()
+    torch.manual_seed(12)
+    posm = PositionEmbeddingLearned(6, 256).to(DEV).train()
+    B, nQ, nK = 1, 48, 128
+    g = torch.Generator().manual_seed(5)
+    tgt0, mem0 = (torch.randn(s, generator=g).to(DEV) for s in ((nQ, B, 256), (nK, B, 256)))
+    boxes = (torch.rand((B, nQ, 6), generator=g) + 0.2).to(DEV)
+    xyz, verts = _scene(B, nQ, nK, 13)
+    outs = []
+    defer_weight_grads(True)
+    try:
+        for lazy in (False, True):
+            A.reset_rng()
+            torch.manual_seed(0)
+            prev = HD.lazy_pos(lazy)
+            pos = posm(boxes).permute(2, 0, 1)
+            HD.lazy_pos(prev)
+            out, _ = layer(tgt0.clone().requires_grad_(True), mem0, verts, None, xyz, None, query_pos=pos)
+            assert not HD._pending_pos
+            outs.append((out.detach().clone(), pos.detach().clone()))
+        assert torch.equal(outs[0][1], outs[1][1]), "query_pos"
+        assert torch.equal(outs[0][0], outs[1][0]), "layer output"
+        HD.lazy_pos(True)
+        posm(boxes)
+        HD.lazy_pos(False)
+        with pytest.raises(RuntimeError, match="never ran"):
+            HD.no_pending_pos("test")
+    finally:
+        defer_weight_grads(False)
+        from vdetr_amd.helpers import DeferredPosEmbedGrads
+        DeferredPosEmbedGrads.pending.clear()
+
+
 def test_a_deferred_merge_that_nobody_takes_is_an_error():
     """fused_attention(defer_combine=True) whose output does not reach rowblock.ffn: the next step (and the next deferred forward)
     refuse to go on instead of letting somebody read an unwritten tensor"""

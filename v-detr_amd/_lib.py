@@ -347,6 +347,7 @@ _SIGNATURES = {
     "vdetr_rb_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vdetr_rb_qkv_f32": (c_int, [ctypes.POINTER(RbQkvDesc), c_void_p]),
     "vdetr_rb_proj_q_f32": (c_int, [ctypes.POINTER(RbProjQDesc), c_void_p]),
+    "vdetr_rb_qkv_pos_f32": (c_int, [ctypes.POINTER(RbQkvDesc), ctypes.POINTER(PosMlpDesc), c_void_p]),
     "vdetr_rb_ffn_f32": (c_int, [ctypes.POINTER(RbFfnDesc), c_void_p]),
     "vdetr_rb_ffn_parts_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(AttnParts), c_void_p, c_void_p, c_void_p]),
     "vdetr_rb_qkv_bwd_f32": (c_int, [ctypes.POINTER(RbQkvDesc), ctypes.POINTER(RbQkvGrads), c_void_p]),

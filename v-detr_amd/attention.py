@@ -369,6 +369,9 @@ class DeferredTableGrads:
                 dW2 = torch.bmm(dT.transpose(1, 2), hid)                              # [8n, H, hid]
                 dhid = torch.ops.aten.threshold_backward(torch.bmm(dT, w2.detach()), hid, 0.0)
                 dW1b = torch.bmm(dhid.transpose(1, 2), c1.unsqueeze(0).expand(n8, -1, -1))   # [8n, hid, 4]: weights | bias
+                if side is not None:
+                    from .runtime import ts_mark
+                    ts_mark("side: table MLPs' backward end")
             cls._begun.append((dev if side is not None else None, ((w1, dW1b[..., :3]), (b1, dW1b[..., 3]), (w2, dW2)),
                                (acc, dT, dhid, hid)))
         cls.pending = keep

@@ -71,6 +71,7 @@ def decoder_refresh(decoder):
     per layer the position MLP's second convolution.  Returns False (and leaves the fused paths to rewrite their own) when the
     modules are not the shapes the launches are built for."""
     _fresh["on"] = False
+    no_pending_pos("heads.decoder_refresh")
     if not (FUSED or FUSED_POS):
         return False
     ws = []
@@ -171,8 +172,42 @@ def pos_mlp_usable(module, x_tok):
                 and not BNA.sync_active())
 
 
+# Position MLPs whose launch is left to the consumer of their output (vdetr_rb_qkv_pos_f32: the decoder layer's q / k / v projection
+# computes the position rows on its way in): data_ptr of `out` -> (descriptor, tensors it points at).  The decoder turns this on for
+# the layers it runs through rowblock.py; a layer that takes another path calls materialize_pos() first.  `out`, the hidden
+# activations and the statistics are NOT valid until one of the two has run.
+_pending_pos = {}
+POS_IN_QKV = os.environ.get("VDETR_POS_IN_QKV", "1") != "0"
+_lazy_pos = {"on": False}
+
+
+def lazy_pos(on):
+    """from here on position MLPs are left to rowblock.qkv (True) or launched at once (False); returns the previous state"""
+    prev, _lazy_pos["on"] = _lazy_pos["on"], bool(on) and POS_IN_QKV
+    return prev
+
+
+def take_pending_pos(pos):
+    """the descriptor of a position MLP that was left to the consumer of `pos` (None: `pos` is final)"""
+    return _pending_pos.pop(pos.data_ptr(), None) if (_pending_pos and pos is not None) else None
+
+
+def materialize_pos(pos):
+    """launch the position MLP behind `pos` now, if it was left to a consumer that will not run"""
+    rec = take_pending_pos(pos)
+    if rec is not None:
+        L.check(L.lib().vdetr_pos_mlp_fwd_f32(ctypes.byref(rec[0]), L.stream_ptr()), "pos_mlp_fwd")
+
+
+def no_pending_pos(where):
+    if _pending_pos:
+        _pending_pos.clear()
+        raise RuntimeError(f"{where}: a position MLP was left to rowblock.qkv, which never ran on its output")
+
+
 def pos_mlp_forward(module, x_tok):
-    """One launch.  Returns (out [N, B, 256] dense, hidden activations [B, 256, N], the BatchNorm record of bn_act.forward_record)."""
+    """One launch — or none yet: with lazy_pos(True) the launch is left to rowblock.qkv (or materialize_pos) and only the outputs are
+    allocated.  Returns (out [N, B, 256] dense, hidden activations [B, 256, N], the BatchNorm record of bn_act.forward_record)."""
     conv1, bn, _, conv2 = module.position_embedding_head
     x_tok = x_tok.detach().contiguous()
     B, N, cin = x_tok.shape
@@ -195,6 +230,9 @@ def pos_mlp_forward(module, x_tok):
     d.w2t = w2t.data_ptr()
     d.b2 = conv2.bias.data_ptr() if conv2.bias is not None else None
     d.hpre, d.hact, d.save_mean, d.save_invstd, d.out = hpre.data_ptr(), hact.data_ptr(), sm[0].data_ptr(), sm[1].data_ptr(), out.data_ptr()
-    L.check(L.lib().vdetr_pos_mlp_fwd_f32(ctypes.byref(d), L.stream_ptr()), "pos_mlp_fwd")
+    if _lazy_pos["on"] and B * N % 16 == 0 and (B == 1 or N % 4 == 0):
+        _pending_pos[out.data_ptr()] = (d, (x_tok, w1, g, b, w2t, hpre, hact, sm, out))
+    else:
+        L.check(L.lib().vdetr_pos_mlp_fwd_f32(ctypes.byref(d), L.stream_ptr()), "pos_mlp_fwd")
     rec = (hpre, g, b, sm[0], sm[1], None, (float(bn.eps), float(bn.momentum), 0.0, 0), None)
     return out, hact, rec, (x_tok, w1)

@@ -18,6 +18,7 @@ import torch
 from . import _lib as L
 from . import add_ln as ALN
 from . import attention as A
+from . import heads as HD
 from .helpers import DeferredParamGrads, colsum
 
 C = 256
@@ -166,7 +167,13 @@ class _Qkv(torch.autograd.Function):
         d.t, d.pos = t.data_ptr(), (pos.data_ptr() if pos is not None else None)
         d.w, d.b, d.wt = wq.data_ptr(), bq.data_ptr(), wt.data_ptr()
         d.x, d.out = (x.data_ptr() if x is not None else None), out.data_ptr()
-        L.check(L.lib().vdetr_rb_qkv_f32(ctypes.byref(d), L.stream_ptr()), "rb_qkv")
+        pend = HD.take_pending_pos(pos)
+        if pend is not None:
+            # `pos` is the output of a position MLP whose launch was left to this one (heads.lazy_pos): the q / k workgroups compute
+            # their rows of it on the way in, the q workgroups write it (and what the MLP's backward reads)
+            L.check(L.lib().vdetr_rb_qkv_pos_f32(ctypes.byref(d), ctypes.byref(pend[0]), L.stream_ptr()), "rb_qkv_pos")
+        else:
+            L.check(L.lib().vdetr_rb_qkv_f32(ctypes.byref(d), L.stream_ptr()), "rb_qkv")
         ctx.B, ctx.shape = B, t.shape
         ctx.save_for_backward(t, x, wq, wk, wv, bq, bk, bv)
         ctx.set_materialize_grads(False)

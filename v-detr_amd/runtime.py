@@ -134,9 +134,12 @@ def flush_weight_grads():
     from .helpers import DeferredParamGrads, DeferredPosEmbedGrads
     from .attention import DeferredTableGrads
     DeferredTableGrads.begin_flush()  # (the table MLPs' backward onto the side stream, behind the table kernels it reads)
+    ts_mark("main: flush begins")
     DeferredParamGrads.flush()
+    ts_mark("main: flush, own weight gradients done")
     DeferredLnGrads.flush()
     DeferredPosEmbedGrads.flush()
+    ts_mark("main: flush, own LayerNorm / position gradients done")
     DeferredTableGrads.flush()  # last: it waits for the side stream's table kernels, which run under the launches above
 
 

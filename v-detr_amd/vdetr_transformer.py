@@ -461,6 +461,7 @@ class GlobalDecoderLayer(nn.Module):
                     memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None,
                     query_pos=None, return_attn_weights=False):
         if not ALN.supported(self.norm1, self.norm2, self.norm3):  # other norm types: the plain composition
+            HD.materialize_pos(query_pos)
             tgt2 = self.norm1(tgt)
             q = k = self.with_pos_embed(tgt2, query_pos)
             tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
@@ -475,8 +476,11 @@ class GlobalDecoderLayer(nn.Module):
         if self._aln_salts is None:
             self._aln_salts = [ALN.new_salt() for _ in range(3)]
         tgt2 = self.pre_normed if self.pre_normed is not None else ALN.layer_norm(tgt, self.norm1)
-        if (_ROWBLOCK and self.post_norms and not return_attn_weights and not self.pos_for_key and
-                RB.usable(self, tgt, query_pos, (tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask))):
+        use_rb = (_ROWBLOCK and self.post_norms and not return_attn_weights and not self.pos_for_key and
+                  RB.usable(self, tgt, query_pos, (tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask)))
+        if not use_rb:
+            HD.materialize_pos(query_pos)  # (a position MLP whose launch the decoder left to rowblock.qkv: here instead)
+        if use_rb:
             # everything between the attention cores as three launches (rowblock.hip): the same values, the same dropout
             # streams (salts) as the composition below
             B = tgt.shape[1]
@@ -518,6 +522,7 @@ class GlobalDecoderLayer(nn.Module):
     def forward_post(self, tgt, memory, reference_point, reference_angle, enc_xyz, point_cloud_dims, tgt_mask=None,
                      memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, pos=None,
                      query_pos=None, return_attn_weights=False):
+        HD.materialize_pos(query_pos)  # (never through rowblock.py)
         q = k = self.with_pos_embed(tgt, query_pos)
         tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
         tgt = self.norm1(tgt + self.dropout1(tgt2))
@@ -1160,8 +1165,9 @@ class TransformerDecoder(nn.Module):
             isinstance(l, GlobalDecoderLayer) and l.normalize_before and ALN.supported(self.norm, l.norm1, l.norm2, l.norm3)
             for l in self.layers)
         carried = None  # norm1 of the next layer, produced by the previous layer's last launch
-        if (fuse_ln and _ROWBLOCK and output.is_cuda and memory_mask is None and
-                all(RB.usable(l, output, None, ()) and not l.pos_for_key for l in self.layers)):
+        rb_layers = bool(fuse_ln and _ROWBLOCK and output.is_cuda and memory_mask is None and
+                         all(RB.usable(l, output, None, ()) and not l.pos_for_key for l in self.layers))
+        if rb_layers:
             RB.refresh(self.layers)  # the fused glue launches' weight images of all layers: one launch (rowblock.py)
         if not defer and self.training and output.is_cuda and torch.is_grad_enabled():
             HD.decoder_refresh(self)  # (the position MLPs' images; the stages' heads take the batched path)
@@ -1189,7 +1195,12 @@ class TransformerDecoder(nn.Module):
             query_reference = box_prediction.pop("_query_reference", None) if idx > 0 else proposals_qref
             if query_reference is None:
                 query_reference = torch.cat([reference_center, reference_size], dim=-1)
-            query_pos = self.query_pos_projection[idx](query_reference).permute(2, 0, 1)
+            # (rb_layers: the layer runs through rowblock.py, whose q / k / v launch computes the position rows on its way in)
+            prev_lazy = HD.lazy_pos(rb_layers and not return_attn_weights)
+            try:
+                query_pos = self.query_pos_projection[idx](query_reference).permute(2, 0, 1)
+            finally:
+                HD.lazy_pos(prev_lazy)
             if self.pos_for_key:
                 pos = self.key_pos_projection[idx](enc_xyz).permute(2, 0, 1)
             if hasattr(layer.multihead_attn, "vertices_are_boxes"):
