@@ -273,6 +273,35 @@ int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float*
 int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* out,
                                 const float* scores, const float* lse, float* delta, float* ds_out, float* dk, float* dv,
                                 void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
+/* ---- The key-side pass WITHOUT its operand-packing launch (round 6).  That launch — 8-12 us in front of every pass, 16 per step on the
+ * backward's critical chain — does two independent things.  What depends on dO (the images of dO, delta, max |dO row|^2) is left
+ * behind by the row-block kernel that PRODUCES dO (vdetr_rb_ffn_bwd_emit_f32 / vdetr_rb_proj_q_bwd_emit_f32 with a vdetr_rb_attn_emit);
+ * what depends on the forward only (the images of q, the zeroed dk / dv, bwd_aux words 1, 4, 5) is done for up to 16 attention calls
+ * by ONE launch at the head of the backward (vdetr_attn_bwd_kv_prep_f32).  vdetr_attn_bwd_kv_packed_f32 is then the pass alone:
+ * `workspace` (vdetr_attn_bwd_kv_workspace_bytes, 256-B aligned) holds the images, `delta` is read, dk / dv are accumulated into.
+ * One scene (B = 1), nQ a multiple of 32 for the emitting kernels; the prep launch has no such limits. */
+typedef struct vdetr_attn_kv_prep {
+  int32_t kind, B, H, nQ, nK, v_row_stride;   /* as in the call's vdetr_attn_desc (H = 4) */
+  const float* q;          /* [B,nQ,H*64] */
+  const float* v;          /* as the pass reads it */
+  const float* vertices;   /* [B,nQ,8,3] or NULL (no RPE table: no box test) */
+  const float* cos_sin;    /* [B,nQ,2] or NULL */
+  void* workspace;         /* the pass's workspace: the q images are written */
+  float *dk, *dv;          /* zeroed */
+  uint32_t* bwd_aux;       /* the call's 8 zero words or NULL: words 1, 4, 5 are filled */
+} vdetr_attn_kv_prep;
+int vdetr_attn_bwd_kv_prep_f32(const vdetr_attn_kv_prep* items, int n, vdetr_stream_t stream);
+int vdetr_attn_bwd_kv_packed_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* scores,
+                                 const float* lse, const float* delta, float* ds_out, float* dk, float* dv, void* workspace,
+                                 size_t workspace_bytes, vdetr_stream_t stream);
+/* what a row-block backward kernel leaves for the key-side pass of the attention whose output gradient it has just produced */
+typedef struct vdetr_rb_attn_emit {
+  void* workspace;     /* that pass's workspace (256-B aligned): the dO images are written */
+  float* delta;        /* [nQ,4] (shared K/V) or [4,nQ] (per head): written */
+  const float* out;    /* [nQ,256] the attention's forward output */
+  uint32_t* bwd_aux;   /* or NULL: max |dO row|^2 -> word 0 */
+  int32_t per_head, nQ;
+} vdetr_rb_attn_emit;
 /* dq [B,nQ,H*64] = scale * dS K from the UNSCALED dS that vdetr_attn_bwd_kv_f32 wrote ([B,nQ,H,nK] for shared K/V, [B,H,nQ,nK]
  * per head), k as in the forward (k_row_stride honoured): a row-owner kernel with exact fp32 products (attn_bwd_dq.hip) in place
  * of the batched library GEMM the host composition used (`torch.baddbmm(..., alpha=scale)`: N = 64 is a poor shape for it).
@@ -537,6 +566,11 @@ typedef struct vdetr_rb_ffn_grads {
   float *part_post, *part_n3;       /* [ceil(rows/16)][4][256]: post1 / post2; norm3 (rows 0-1) */
 } vdetr_rb_ffn_grads;
 int vdetr_rb_ffn_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream);
+/* the two backward launches that produce an attention's output gradient, leaving its packed form behind as well (see
+ * vdetr_attn_bwd_kv_packed_f32): d->B = 1, d->rows = e->nQ a multiple of 32, g->d_a required */
+int vdetr_rb_ffn_bwd_emit_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, const vdetr_rb_attn_emit* e, vdetr_stream_t stream);
+int vdetr_rb_proj_q_bwd_emit_f32(const vdetr_rb_projq_desc* d, const vdetr_rb_projq_grads* g, const vdetr_rb_attn_emit* e,
+                                 vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * y = dropout(relu(BatchNorm1d(x))) on [B, C, N]: the hidden blocks of GenericMLP (models/helpers.py:74-141,

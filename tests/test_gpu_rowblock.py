@@ -278,6 +278,53 @@ def test_a_position_mlp_left_to_rb_qkv_is_launched_by_a_layer_that_takes_another
         DeferredPosEmbedGrads.pending.clear()
 
 
+@pytest.mark.parametrize("nQ,nK,train", [(64, 256, True), (1024, 512, True), (96, 200, False)])
+def test_key_side_pass_without_its_packing_launch(monkeypatch, nQ, nK, train):
+    """The layer's backward with the operands of both key-side passes left behind by rb_ffn_bwd / rb_proj_q_bwd (+ the step's one prep
+    launch) against the backward whose passes pack their own operands: every gradient; and that the packed path is the one that ran.
+    (delta is summed in another order: fp32 rounding apart.)"""
+    from vdetr_amd import attention as A
+    from vdetr_amd import vdetr_transformer as T
+    monkeypatch.setattr(T, "_ROWBLOCK", True)
+    B = 1
+    layer = _layer(9).train(train)
+    out_norm, next_norm = torch.nn.LayerNorm(256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    g = torch.Generator().manual_seed(nQ)
+    tgt0 = torch.randn((nQ, B, 256), generator=g).to(DEV)
+    mem0 = torch.randn((nK, B, 256), generator=g).to(DEV)
+    pos0 = (0.5 * torch.randn((nQ, B, 256), generator=g)).to(DEV)
+    xyz, verts = _scene(B, nQ, nK, 15)
+    wts = [torch.randn((nQ, B, 256), generator=g).to(DEV) for _ in range(3)]
+    params = list(layer.parameters()) + list(out_norm.parameters()) + list(next_norm.parameters())
+    names = [n for n, _ in layer.named_parameters()] + ["out_norm.weight", "out_norm.bias", "next_norm.weight", "next_norm.bias"]
+    emitted = []
+
+    def run(prepack):
+        monkeypatch.setattr(A, "KV_PREPACK", prepack)
+        A.reset_rng()
+        A._kv_recs.clear()
+        A._kv_by_out.clear()
+        for p in params:
+            p.grad = None
+        tgt, mem, pos = (t.clone().requires_grad_(True) for t in (tgt0, mem0, pos0))
+        layer.post_norms = (out_norm, next_norm)
+        layer.pre_normed = None
+        out, _ = layer(tgt, mem, verts, None, xyz, None, query_pos=pos)
+        o1, o2 = layer.post_normed
+        layer.post_norms = layer.post_normed = None
+        recs = [r for lst in A._kv_recs.values() for r in lst]
+        ((out * wts[0]).sum() + (o1 * wts[1]).sum() + (o2 * wts[2]).sum()).backward()
+        emitted.append([(r.kind, r.prepared, r.emitted is not None) for r in recs])
+        return [tgt.grad, mem.grad, pos.grad] + [p.grad for p in params]
+
+    ref = run(False)
+    got = run(True)
+    assert emitted[0] == [] and len(emitted[1]) == 2 and all(p and e for _, p, e in emitted[1]), emitted
+    all_names = ["d tgt", "d memory", "d query_pos"] + names
+    for n, a, b in zip(all_names, got, ref):
+        _close(a, b, n, rtol=2e-5, frac=2e-6, floor=_floor(n, all_names, ref))
+
+
 def test_a_deferred_merge_that_nobody_takes_is_an_error():
     """fused_attention(defer_combine=True) whose output does not reach rowblock.ffn: the next step (and the next deferred forward)
     refuse to go on instead of letting somebody read an unwritten tensor"""

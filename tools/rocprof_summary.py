@@ -23,19 +23,24 @@ def rows_from_csv(path):
     return out
 
 
+def _is_optimizer(name):
+    """the step boundary: the optimizer's launch (csrc/optim.hip, or torch's multi-tensor AdamW with VDETR_OWN_ADAMW=0)"""
+    return "adamw_clip_kernel" in name or "FusedOptimizerTensorListMetadata" in name
+
+
 def main():
     path = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     warmup = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     rows = rows_from_db(path) if path.endswith(".db") else rows_from_csv(path)
     if warmup:
-        marks = sorted(e for n, _, _, e in rows if "FusedOptimizerTensorListMetadata" in n)
+        marks = sorted(e for n, _, _, e in rows if _is_optimizer(n))
         per_step = len(marks) // (steps + warmup)
         t0 = marks[warmup * per_step - 1]
         rows = [r for r in rows if r[2] > t0]
         print(f"# first {warmup} steps dropped (auto-tuning), {steps} steady-state steps summarised")
     if "--timeline" in sys.argv:  # dispatch sequence of the last traced step, in start order, with gaps
-        marks = sorted(e for n, _, _, e in rows if "FusedOptimizerTensorListMetadata" in n)
+        marks = sorted(e for n, _, _, e in rows if _is_optimizer(n))
         per_step = len(marks) // max(steps, 1)
         t0 = marks[-per_step - 1] if len(marks) > per_step else 0
         seq = sorted((r for r in rows if r[2] > t0), key=lambda r: r[2])

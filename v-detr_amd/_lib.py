@@ -175,6 +175,19 @@ class AttnParts(ctypes.Structure):
                 ("rows", ctypes.c_int64)]
 
 
+class AttnKvPrep(ctypes.Structure):
+    """Mirror of ``vdetr_attn_kv_prep``."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("kind", "B", "H", "nQ", "nK", "v_row_stride")] + [
+        (n, c_void_p) for n in ("q", "v", "vertices", "cos_sin", "workspace", "dk", "dv", "bwd_aux")]
+
+
+class RbAttnEmit(ctypes.Structure):
+    """Mirror of ``vdetr_rb_attn_emit``."""
+
+    _fields_ = [(n, c_void_p) for n in ("workspace", "delta", "out", "bwd_aux")] + [("per_head", ctypes.c_int32), ("nQ", ctypes.c_int32)]
+
+
 class AdamWDesc(ctypes.Structure):
     """Mirror of ``vdetr_adamw_desc``."""
 
@@ -353,6 +366,10 @@ _SIGNATURES = {
     "vdetr_rb_qkv_bwd_f32": (c_int, [ctypes.POINTER(RbQkvDesc), ctypes.POINTER(RbQkvGrads), c_void_p]),
     "vdetr_rb_proj_q_bwd_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), c_void_p]),
     "vdetr_rb_ffn_bwd_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), c_void_p]),
+    "vdetr_rb_ffn_bwd_emit_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), ctypes.POINTER(RbAttnEmit), c_void_p]),
+    "vdetr_rb_proj_q_bwd_emit_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), ctypes.POINTER(RbAttnEmit), c_void_p]),
+    "vdetr_attn_bwd_kv_prep_f32": (c_int, [ctypes.POINTER(AttnKvPrep), c_int, c_void_p]),
+    "vdetr_attn_bwd_kv_packed_f32": (c_int, [ctypes.POINTER(AttnDesc)] + [c_void_p] * 10 + [c_size_t, c_void_p]),
     "vdetr_probe_timestamp": (c_int, [c_void_p, c_void_p]),
     "vdetr_topk_order_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vdetr_anchor_boxes_f32": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 5),

@@ -507,6 +507,8 @@ def begin_step(device):
     _current[key] = snap
     _step_side[key] = False
     _no_pending("begin_step")
+    _kv_recs.pop(key, None)
+    _kv_by_out.clear()
     _zero_pool[key] = None  # a fresh pool of zeros for this step's backward passes (allocated on first use)
     return snap
 
@@ -609,6 +611,81 @@ def _no_pending(where):
                            "(fused_attention(defer_combine=True) must be followed by rowblock.ffn on its output)")
 
 
+# ---- round 6: the key-side pass of the backward without its operand-packing launch ---------------------------------------------------
+# That launch (8-12 us, one per attention backward, on the backward's critical chain) does two things.  What depends on dO — its
+# images, delta, max |dO row|^2 — is now left behind by the row-block kernel that PRODUCES dO (rowblock._Ffn / _ProjQ backward:
+# vdetr_rb_*_bwd_emit_f32); what depends on the forward only — the q images, the zeroed dk / dv, bwd_aux words 1, 4, 5 — is done for all
+# of a step's attention calls by ONE launch when the first of those backward kernels runs (kv_prepare).  A forward call that
+# qualifies leaves a record; the consumer of its output takes the record in ITS forward (kv_record_of) and emits in its backward;
+# the attention's backward then calls the pass alone (vdetr_attn_bwd_kv_packed_f32) — or, when nobody emitted, everything as before.
+KV_PREPACK = os.environ.get("VDETR_KV_PREPACK", "1") != "0"
+_kv_recs = {}    # device key -> this step's records (begin_step clears)
+_kv_by_out = {}  # data_ptr of a call's output -> its record, until the output's consumer has taken it
+
+
+class _KvRec:
+    __slots__ = ("q", "v", "vertices", "cos_sin", "kind", "dims", "want_aux", "ws", "nbytes", "dkv", "delta", "aux", "prepared", "emitted")
+
+
+def _kv_register(out, q, v, table, vertices, cos_sin, kind, B, H, nQ, nK):
+    shared = kind == L.VDETR_ATTN_SHARED_KV
+    if not (KV_PREPACK and FUSED_KV_BWD and B == 1 and H == 4 and nQ % 32 == 0 and q.dtype == torch.float32 and v.dtype == torch.float32
+            and (shared or table is None) and v.stride(1) % 4 == 0 and v.data_ptr() % 16 == 0 and 4 * nQ * nK * 4 < (1 << 31)):
+        return None
+    r = _KvRec()
+    r.q, r.v, r.vertices, r.cos_sin, r.kind, r.dims = q, v, (vertices if table is not None else None), cos_sin, kind, (B, H, nQ, nK)
+    r.want_aux = bool(table is not None and table.requires_grad and DYNAMIC_BWD)
+    r.prepared, r.emitted = False, None
+    r.ws = r.dkv = r.delta = r.aux = None
+    lst = _kv_recs.setdefault(_dev_key(q.device), [])
+    if len(lst) >= 64:  # (steps that never call begin_step: forget what is stale)
+        del lst[:]
+        _kv_by_out.clear()
+    lst.append(r)
+    _kv_by_out[out.data_ptr()] = r
+    return r
+
+
+def kv_record_of(out):
+    """the record of the attention call that produced `out`, for the module that consumes `out` (taken once)"""
+    return _kv_by_out.pop(out.data_ptr(), None) if _kv_by_out else None
+
+
+def kv_prepare(rec):
+    """Called by the first backward kernel of a step that is about to emit: one launch (per 16 calls) leaves the q images, the
+    zeroed dk / dv and the forward-only bwd_aux words of EVERY recorded call of the device."""
+    if rec.prepared:
+        return
+    dev = rec.q.device
+    lib = L.lib()
+    todo = [r for r in _kv_recs.get(_dev_key(dev), []) if not r.prepared]
+    if rec not in todo:
+        todo.append(rec)
+    for i in range(0, len(todo), 16):
+        chunk = todo[i:i + 16]
+        items = (L.AttnKvPrep * len(chunk))()
+        for it, r in zip(items, chunk):
+            B, H, nQ, nK = r.dims
+            shared = r.kind == L.VDETR_ATTN_SHARED_KV
+            dd = L.AttnDesc()
+            dd.kind, dd.B, dd.H, dd.nQ, dd.nK = r.kind, B, H, nQ, nK
+            r.nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(dd))
+            r.ws = L.workspace(r.nbytes, dev)
+            assert r.ws.data_ptr() % 256 == 0
+            r.dkv = torch.empty((2, B, nK, 64 if shared else H * 64), dtype=torch.float32, device=dev)
+            r.delta = torch.empty((B, nQ, H) if shared else (B, H, nQ), dtype=torch.float32, device=dev)
+            r.aux = _take_zeros(r.q, (8,), torch.int32) if r.want_aux else None
+            it.kind, it.B, it.H, it.nQ, it.nK, it.v_row_stride = r.kind, B, H, nQ, nK, r.v.stride(1)
+            it.q, it.v = r.q.data_ptr(), r.v.data_ptr()
+            it.vertices = r.vertices.data_ptr() if (r.vertices is not None and r.aux is not None) else None
+            it.cos_sin = r.cos_sin.data_ptr() if (r.cos_sin is not None and it.vertices) else None
+            it.workspace, it.dk, it.dv = r.ws.data_ptr(), r.dkv[0].data_ptr(), r.dkv[1].data_ptr()
+            it.bwd_aux = r.aux.data_ptr() if r.aux is not None else None
+        L.check(lib.vdetr_attn_bwd_kv_prep_f32(items, len(chunk), L.stream_ptr()), "attn_bwd_kv_prep")
+        for r in chunk:
+            r.prepared = True
+
+
 class _FusedAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, table, vertices, xyz, cos_sin, mask, kind, H, scale, rpe, dropout_p, rng_state,
@@ -678,6 +755,7 @@ class _FusedAttention(Function):
         if need_grad:
             ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
             ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
+            ctx.kv_rec = None if (bf16 or mask is not None) else _kv_register(out, q, v, table, vertices, cos_sin, kind, B, H, nQ, nK)
             ctx.table_async = bool(table_async)
             ctx.boxes = bool(boxes)
             if table_async and table is not None and table.requires_grad and _async_wanted(q.shape[0], q.shape[1], k.shape[1]):
@@ -726,11 +804,21 @@ class _FusedAttention(Function):
             # the query self-attention's pass (256 one-per-CU workgroups at the model's size) next to a live table kernel: one
             # workgroup per key tile
             d.kv_halves = 1 if (_side_keep and (KV_ONE_WG >= 2 or (KV_ONE_WG == 1 and not shared))) else 2
-            nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
-            ws = L.workspace(nbytes, q.device)
-            L.check(lib.vdetr_attn_bwd_kv_delta_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(out), L.ptr(scores),
-                                                    L.ptr(lse), L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws),
-                                                    nbytes, L.stream_ptr()), "attn_bwd_kv")
+            rec = getattr(ctx, "kv_rec", None)
+            if (rec is not None and rec.prepared and rec.emitted == dout.data_ptr() and (rec.aux is not None) == bool(want_table and DYNAMIC_BWD)
+                    and in_dtype == torch.float32):
+                # the producer of dout left its images and delta behind, the step's prep launch everything else: the pass alone
+                delta, dkv, aux = rec.delta, rec.dkv, rec.aux
+                d.bwd_aux = aux.data_ptr() if aux is not None else None
+                L.check(lib.vdetr_attn_bwd_kv_packed_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(scores), L.ptr(lse),
+                                                         L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(rec.ws), rec.nbytes,
+                                                         L.stream_ptr()), "attn_bwd_kv_packed")
+            else:
+                nbytes = lib.vdetr_attn_bwd_kv_workspace_bytes(ctypes.byref(d))
+                ws = L.workspace(nbytes, q.device)
+                L.check(lib.vdetr_attn_bwd_kv_delta_f32(ctypes.byref(d), L.ptr(q), L.ptr(v), L.ptr(dout), L.ptr(out), L.ptr(scores),
+                                                        L.ptr(lse), L.ptr(delta), L.ptr(ds), L.ptr(dkv[0]), L.ptr(dkv[1]), L.ptr(ws),
+                                                        nbytes, L.stream_ptr()), "attn_bwd_kv")
             from .runtime import ts_mark
             ts_mark("main: key-side pass done" if shared else "main: self-attention key-side pass done")
             dtable = fork = None

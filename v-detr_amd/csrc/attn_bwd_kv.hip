@@ -15,7 +15,7 @@
 // error of a product <= 2^-16, far below the 1e-3 parity tolerance and summed over thousands of terms of mixed sign.
 // Determinism: the 16 row slots of a key tile (2 workgroups x 8 waves) are reduced by a fixed tree in LDS, and the two
 // workgroups add their sums onto a zeroed output — two commutative float adds, the same bits in either order.
-#include "attn_common.h"
+#include "kv_pack.h"
 
 #include <stdlib.h>
 
@@ -25,13 +25,10 @@ namespace vdetr {
 
 int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op);
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // waves per workgroup: 8 (2 per SIMD) when the kernel has the chip to itself; 4 (1 per SIMD, <= 256 registers) fit NEXT to
 // the table-gradient kernel's 4 x 64 registers per SIMD when that runs on a side stream (attention.py)
-constexpr int kKvOperandUnits = 2 * kWave;      // one packed operand: (hi, lo) x 64 lanes, 16 B each
-constexpr int kKvTileUnits = 3 * 4 * kKvOperandUnits;
 
 struct KvParams {
   AttnParams A;
@@ -84,17 +81,6 @@ __device__ __forceinline__ KvProblem kv_problem(const KvParams& K, int prob) {
   return p;
 }
 
-// row (inside a 32 x 32 tile) of accumulator register v in lane group g = lane >> 5
-__device__ __forceinline__ constexpr int kv_row(int v, int g) { return (v & 3) + 8 * (v >> 2) + 4 * g; }
-
-__device__ __forceinline__ void kv_split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)x[e];
-    hi[e] = h;
-    lo[e] = (__bf16)(x[e] - (float)h);
-  }
-}
 
 __device__ __forceinline__ f32x16 kv_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -392,6 +378,102 @@ __global__ __launch_bounds__(WAVES * kWave) void attn_bwd_kv_kernel(KvParams K) 
   }
 }
 
+// ---- everything the key-side passes of a step need that does NOT depend on dO, for up to 16 attention calls in ONE launch -------------
+// (round 6) The operand-packing launch in front of every key-side pass sat on the backward's critical chain: 16 launches of 8-12 us
+// per step.  Its dO half (images of dO, delta, max |dO row|^2) is now left behind by the row-block kernel that produces dO
+// (kv_pack.h: kv_emit_rows16); the rest — the q images, the zeroed dK / dV, max |V row|^2 and the box test of the RPE vertices
+// (bwd_aux words 1, 4, 5) — depends on the forward only and is done here for all layers at once, at the head of the backward.
+constexpr int kPrepMax = 16;
+struct PrepItem {
+  const float* q; const float* v; const float* vertices; const float* cos_sin;
+  uint4* pack; float* dk; float* dv; unsigned* aux;
+  int B, H, nQ, nK, v_stride, perhead;
+};
+struct PrepBatch { PrepItem it[kPrepMax]; };
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_prep_kernel(PrepBatch Bt) {
+  const PrepItem& I = Bt.it[blockIdx.y];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nvb = I.aux ? (int)(((long)I.B * I.nK + 4 * kDeltaKeys - 1) / (4 * kDeltaKeys)) : 0;
+  const int nqb = (I.aux && I.vertices) ? (int)(((long)I.B * I.nQ + 3) / 4) : 0;
+  int blk = blockIdx.x;
+  if (blk < nvb) {  // max |V row|^2 -> aux[1] (attn_delta_body's second half)
+    __shared__ float wmax[4];
+    float n2max = 0.f;
+    const int key0 = (blk * 4 + wv) * kDeltaKeys;
+#pragma unroll 4
+    for (int i = 0; i < kDeltaKeys; ++i) {
+      const int key = key0 + i;
+      const float x = key < I.B * I.nK ? I.v[(size_t)key * I.v_stride + lane] : 0.f;
+      n2max = fmaxf(n2max, wave_allsum_f32(x * x));
+    }
+    if (lane == 0) wmax[wv] = n2max;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(I.aux + 1, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+    return;
+  }
+  blk -= nvb;
+  if (blk < nqb) {  // aux[4] += 1 per query whose 8 RPE vertices are not a box, aux[5] = 1 (attn_delta_body's test, word for word)
+    const int row = blk * 4 + wv;
+    if (row >= I.B * I.nQ) return;
+    if (row == 0 && lane == 0) I.aux[5] = 1u;
+    const float* vp = I.vertices + (size_t)row * 24;
+    const int i = lane & 7;
+    bool ok;
+    if (!I.cos_sin) {
+      ok = vp[i * 3] == vp[rpe_box_xi(i) ? 6 : 0] && vp[i * 3 + 1] == vp[rpe_box_yi(i) ? 4 : 1] && vp[i * 3 + 2] == vp[rpe_box_zi(i) ? 14 : 2];
+    } else {
+      float ex = vp[i * 3] - vp[0], ey = vp[i * 3 + 1] - vp[1];
+      const float ez = vp[i * 3 + 2] - vp[2];
+      rpe_rotate(ex, ey, I.cos_sin[(size_t)row * 2], I.cos_sin[(size_t)row * 2 + 1]);
+      const float EX = readlane_f32(ex, 3), EY = readlane_f32(ey, 1), EZ = readlane_f32(ez, 4);
+      const float tol = 1e-5f * (1.f + fabsf(vp[0]) + fabsf(vp[1]) + fabsf(vp[2]));
+      ok = fabsf(ex - (rpe_box_xi(i) ? EX : 0.f)) <= tol && fabsf(ey - (rpe_box_yi(i) ? EY : 0.f)) <= tol &&
+           fabsf(ez - (rpe_box_zi(i) ? EZ : 0.f)) <= tol;
+    }
+    if (!__all(ok) && lane == 0) atomicAdd(I.aux + 4, 1u);
+    return;
+  }
+  blk -= nqb;
+  const int nwork = (int)gridDim.x - nvb - nqb;
+  if (nwork <= 0) return;
+  // ---- the q images (kind 2) and the zeroed outputs ----
+  const int C = I.H * kDh;
+  const int R = I.perhead ? I.nQ : I.H * I.nQ, NT = (R + 31) / 32, nprob = I.perhead ? I.B * I.H : I.B;
+  const long gid = (long)blk * 256 + threadIdx.x, stride = (long)nwork * 256;
+  const long nunits = (long)nprob * NT * 4 * kWave;
+  for (long u = gid; u < nunits; u += stride) {
+    const int ln = (int)(u & 63), sub = (int)((u >> 6) & 3);
+    const long bt = u >> 8;
+    const int prob = (int)(bt / NT), tile = (int)(bt - (long)prob * NT), r0 = tile * 32;
+    const int l31 = ln & 31, g = ln >> 5, d = 32 * (sub >> 1) + l31, t = sub & 1;
+    const float* src;
+    int rstride;
+    if (I.perhead) {
+      const int b = prob / I.H, hh = prob - b * I.H;
+      src = I.q + (size_t)b * I.nQ * C + hh * kDh;
+      rstride = C;
+    } else {
+      src = I.q + (size_t)prob * R * kDh;
+      rstride = kDh;
+    }
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = r0 + kv_row(8 * t + e, g);
+      x[e] = row < R ? src[(size_t)row * rstride + d] : 0.f;
+    }
+    kv_store_unit(I.pack, bt, 2, sub, ln, x);
+  }
+  const long nz = (long)I.B * I.nK * (I.perhead ? I.H : 1) * kDh / 4;
+  f32x4* zk = reinterpret_cast<f32x4*>(I.dk);
+  f32x4* zv = reinterpret_cast<f32x4*>(I.dv);
+  for (long i = gid; i < nz; i += stride) {
+    zk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    zv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 }  // namespace vdetr
 
 using namespace vdetr;
@@ -409,10 +491,12 @@ extern "C" size_t vdetr_attn_bwd_kv_workspace_bytes(const vdetr_attn_desc* d) {
 }
 
 template <bool PERHEAD, int WAVES, int HALVES = 2>
-static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, const DeltaArgs& D, int ndelta, hipStream_t st) {
+static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, const DeltaArgs& D, int ndelta, bool packed, hipStream_t st) {
   const unsigned pack_blocks = (unsigned)((pack_work + 255) / 256 < 2048 ? (pack_work + 255) / 256 : 2048);
-  hipLaunchKernelGGL(attn_bwd_kv_pack_kernel<PERHEAD>, dim3(pack_blocks + (unsigned)ndelta), dim3(256), 0, st, K, D, ndelta);
-  if (int e = check_launch("attn_bwd_kv_pack")) return e;
+  if (!packed) {  // (packed: the images, delta and the zeroed outputs are there already — vdetr_attn_bwd_kv_packed_f32)
+    hipLaunchKernelGGL(attn_bwd_kv_pack_kernel<PERHEAD>, dim3(pack_blocks + (unsigned)ndelta), dim3(256), 0, st, K, D, ndelta);
+    if (int e = check_launch("attn_bwd_kv_pack")) return e;
+  }
   const size_t strips = (size_t)WAVES * 8 * kWave * sizeof(uint4), tree = (size_t)(WAVES / 2) * 64 * kWave * sizeof(float);
   const size_t fin = (size_t)2 * 32 * (kDh + 1) * sizeof(float);
   const size_t lds = strips > tree ? (strips > fin ? strips : fin) : (tree > fin ? tree : fin);
@@ -423,7 +507,7 @@ static int kv_launch(const KvParams& K, int nkt, int nprob, long pack_work, cons
 
 static int kv_run(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* out,
                   const float* scores, const float* lse, float* delta, float* ds_out, float* dk, float* dv, void* workspace,
-                  size_t workspace_bytes, vdetr_stream_t stream) {
+                  size_t workspace_bytes, vdetr_stream_t stream, bool packed = false) {
   KvParams K;
   if (int e = attn_fill_params(d, &K.A, "attn_bwd_kv")) return e;
   VDETR_REQUIRE(kv_supported(d), "attn_bwd_kv: built for shared K/V with 4 heads and for per-head K/V (kind %d, H %d)", d->kind, d->H);
@@ -461,11 +545,11 @@ static int kv_run(const vdetr_attn_desc* d, const float* q, const float* v, cons
     ndelta = D.qblocks + D.vblocks;
   }
   if (d->kind == VDETR_ATTN_PER_HEAD) {
-    if (one) return kv_launch<true, 8, 1>(K, nkt, (int)nprob, work, D, ndelta, st);
-    return four ? kv_launch<true, 4>(K, nkt, (int)nprob, work, D, ndelta, st) : kv_launch<true, 8>(K, nkt, (int)nprob, work, D, ndelta, st);
+    if (one) return kv_launch<true, 8, 1>(K, nkt, (int)nprob, work, D, ndelta, packed, st);
+    return four ? kv_launch<true, 4>(K, nkt, (int)nprob, work, D, ndelta, packed, st) : kv_launch<true, 8>(K, nkt, (int)nprob, work, D, ndelta, packed, st);
   }
-  if (one) return kv_launch<false, 8, 1>(K, nkt, (int)nprob, work, D, ndelta, st);
-  return four ? kv_launch<false, 4>(K, nkt, (int)nprob, work, D, ndelta, st) : kv_launch<false, 8>(K, nkt, (int)nprob, work, D, ndelta, st);
+  if (one) return kv_launch<false, 8, 1>(K, nkt, (int)nprob, work, D, ndelta, packed, st);
+  return four ? kv_launch<false, 4>(K, nkt, (int)nprob, work, D, ndelta, packed, st) : kv_launch<false, 8>(K, nkt, (int)nprob, work, D, ndelta, packed, st);
 }
 
 extern "C" int vdetr_attn_bwd_kv_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout,
@@ -479,4 +563,43 @@ extern "C" int vdetr_attn_bwd_kv_delta_f32(const vdetr_attn_desc* d, const float
                                            float* dk, float* dv, void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
   VDETR_REQUIRE(out, "attn_bwd_kv_delta: null pointer (out)");
   return kv_run(d, q, v, dout, out, scores, lse, delta, ds_out, dk, dv, workspace, workspace_bytes, stream);
+}
+
+// The key-side pass on operands that are ALREADY packed: `workspace` holds the images (dO's from vdetr_rb_ffn_bwd_emit_f32 /
+// vdetr_rb_proj_q_bwd_emit_f32, q's from vdetr_attn_bwd_kv_prep_f32), `delta` is read, dk / dv are zero, bwd_aux is filled.
+extern "C" int vdetr_attn_bwd_kv_packed_f32(const vdetr_attn_desc* d, const float* q, const float* v, const float* dout, const float* scores,
+                                            const float* lse, const float* delta, float* ds_out, float* dk, float* dv, void* workspace,
+                                            size_t workspace_bytes, vdetr_stream_t stream) {
+  VDETR_REQUIRE(workspace && (((uintptr_t)workspace) & 255) == 0, "attn_bwd_kv_packed: the workspace (the operand images) must be 256-B aligned");
+  return kv_run(d, q, v, dout, nullptr, scores, lse, const_cast<float*>(delta), ds_out, dk, dv, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int vdetr_attn_bwd_kv_prep_f32(const vdetr_attn_kv_prep* items, int n, vdetr_stream_t stream) {
+  VDETR_REQUIRE(items && n >= 1 && n <= kPrepMax, "attn_bwd_kv_prep: %d items (1..%d)", n, kPrepMax);
+  PrepBatch Bt;
+  long blocks = 1;
+  for (int i = 0; i < n; ++i) {
+    const vdetr_attn_kv_prep& s = items[i];
+    VDETR_REQUIRE(s.q && s.v && s.workspace && s.dk && s.dv, "attn_bwd_kv_prep: null pointer in item %d", i);
+    VDETR_REQUIRE(s.kind == VDETR_ATTN_SHARED_KV || s.kind == VDETR_ATTN_PER_HEAD, "attn_bwd_kv_prep: kind %d", s.kind);
+    VDETR_REQUIRE(s.B > 0 && s.nQ > 0 && s.nK > 0 && s.H == 4, "attn_bwd_kv_prep: item %d: B=%d nQ=%d nK=%d H=%d (4 heads)", i, s.B, s.nQ, s.nK, s.H);
+    VDETR_REQUIRE((((uintptr_t)s.workspace) & 255) == 0 && (((uintptr_t)s.dk | (uintptr_t)s.dv) & 15) == 0, "attn_bwd_kv_prep: item %d: alignment", i);
+    VDETR_REQUIRE(s.kind == VDETR_ATTN_SHARED_KV || !s.bwd_aux, "attn_bwd_kv_prep: bwd_aux needs the shared-KV kind");
+    PrepItem& I = Bt.it[i];
+    I.q = s.q; I.v = s.v; I.vertices = s.vertices; I.cos_sin = s.vertices ? s.cos_sin : nullptr;
+    I.pack = reinterpret_cast<uint4*>(s.workspace); I.dk = s.dk; I.dv = s.dv; I.aux = s.bwd_aux;
+    I.B = s.B; I.H = s.H; I.nQ = s.nQ; I.nK = s.nK;
+    I.perhead = s.kind == VDETR_ATTN_PER_HEAD ? 1 : 0;
+    I.v_stride = s.v_row_stride ? s.v_row_stride : (I.perhead ? s.H * 64 : 64);
+    const long nvb = s.bwd_aux ? ((long)s.B * s.nK + 4 * kDeltaKeys - 1) / (4 * kDeltaKeys) : 0;
+    const long nqb = (s.bwd_aux && s.vertices) ? ((long)s.B * s.nQ + 3) / 4 : 0;
+    const long R = I.perhead ? s.nQ : (long)s.H * s.nQ, NT = (R + 31) / 32, nprob = I.perhead ? (long)s.B * s.H : s.B;
+    const long units = nprob * NT * 4 * kWave, zero4 = (long)s.B * s.nK * (I.perhead ? s.H : 1) * kDh / 4;
+    long work = ((units > zero4 ? units : zero4) + 255) / 256;
+    work = work < 1 ? 1 : (work > 512 ? 512 : work);
+    blocks = blocks > nvb + nqb + work ? blocks : nvb + nqb + work;
+  }
+  for (int i = n; i < kPrepMax; ++i) Bt.it[i] = Bt.it[0];
+  hipLaunchKernelGGL(attn_bwd_kv_prep_kernel, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)stream, Bt);
+  return check_launch("attn_bwd_kv_prep");
 }

@@ -26,6 +26,7 @@
 // it, with the same dropout streams: the autograd side (v-detr_amd/rowblock.py) reuses vdetr_add_ln_bwd_f32 /
 // vdetr_relu_dropout_bwd_f32 and the parked weight gradients unchanged.
 #include "rowblock.h"
+#include "kv_pack.h"
 
 namespace vdetr {
 
@@ -339,7 +340,9 @@ __device__ __forceinline__ void rb_ln_bwd(const f32x4 (&yv)[4], const f32x4 (&go
 
 
 // ---- rb_ffn_bwd_kernel ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_desc A, vdetr_rb_ffn_grads G) {
+// EMIT: the packed form of d a for the key-side pass of the attention that produced a (kv_pack.h)
+template <bool EMIT>
+__global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_desc A, vdetr_rb_ffn_grads G, KvEmit E) {
   __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
   __shared__ float red[128];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -439,10 +442,18 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_des
     for (int r = 0; r < 4; ++r)
       if (live[r]) rb_st4(G.d_a, rb_bmajor(rowc[r], A.B, A.rows / A.B), colq, rb_row(acc, r));
   }
+  if constexpr (EMIT) {
+    __syncthreads();  // every wave has read its operand out of the tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = rb_row(acc, r);
+    __syncthreads();
+    kv_emit_rows16(E, xs, kRbStride, row0, tid, red);
+  }
 }
 
 // ---- rb_proj_q_bwd_kernel ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRbThreads) void rb_proj_q_bwd_kernel(vdetr_rb_projq_desc A, vdetr_rb_projq_grads G) {
+template <bool EMIT>
+__global__ __launch_bounds__(kRbThreads) void rb_proj_q_bwd_kernel(vdetr_rb_projq_desc A, vdetr_rb_projq_grads G, KvEmit E) {
   __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
   __shared__ float red[128];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -504,6 +515,13 @@ __global__ __launch_bounds__(kRbThreads) void rb_proj_q_bwd_kernel(vdetr_rb_proj
     for (int r = 0; r < 4; ++r)
       if (live[r]) rb_st4(G.d_a, rb_bmajor(rowc[r], A.B, A.rows / A.B), colq, rb_row(acc, r));
   }
+  if constexpr (EMIT) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(xs + (4 * g + r) * kRbStride + colq) = rb_row(acc, r);
+    __syncthreads();
+    kv_emit_rows16(E, xs, kRbStride, row0, tid, red);
+  }
 }
 
 // ---- rb_qkv_bwd_kernel: d (t + pos) = dq Wq + dk Wk;  d t = d (t + pos) + dv Wv ------------------------------------------------------
@@ -556,6 +574,17 @@ extern "C" int vdetr_rb_transpose_f32(const float* const* src, float* dst, int n
   VDETR_REQUIRE(RB_ALIGNED(dst), "rb_transpose: dst must be 16-B aligned");
   hipLaunchKernelGGL(rb_transpose_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, src, dst);
   return check_launch("rb_transpose");
+}
+
+// e != nullptr: the emitting form (vdetr_rb_ffn_bwd_emit_f32 / vdetr_rb_proj_q_bwd_emit_f32)
+static int rb_emit_args(const vdetr_rb_attn_emit* e, int rows, int B, const float* d_a, KvEmit* E, const char* op) {
+  VDETR_REQUIRE(e->workspace && e->delta && e->out && d_a, "%s: null pointer (workspace, delta, out, d_a)", op);
+  VDETR_REQUIRE(B == 1 && e->nQ == rows && rows % 32 == 0, "%s: one scene, nQ = rows = %d a multiple of 32 (B %d, nQ %d)", op, rows, B, e->nQ);
+  VDETR_REQUIRE((((uintptr_t)e->workspace) & 255) == 0 && RB_ALIGNED(e->out), "%s: workspace 256-B, out 16-B aligned", op);
+  E->pack = reinterpret_cast<uint4*>(e->workspace);
+  E->delta = e->delta; E->out = e->out; E->aux = e->bwd_aux;
+  E->per_head = e->per_head ? 1 : 0; E->nQ = e->nQ;
+  return VDETR_OK;
 }
 
 extern "C" int vdetr_rb_qkv_f32(const vdetr_rb_qkv_desc* d, vdetr_stream_t stream) {
@@ -638,7 +667,7 @@ extern "C" int vdetr_rb_qkv_bwd_f32(const vdetr_rb_qkv_desc* d, const vdetr_rb_q
   return check_launch("rb_qkv_bwd");
 }
 
-extern "C" int vdetr_rb_proj_q_bwd_f32(const vdetr_rb_projq_desc* d, const vdetr_rb_projq_grads* g, vdetr_stream_t stream) {
+static int rb_proj_q_bwd_run(const vdetr_rb_projq_desc* d, const vdetr_rb_projq_grads* g, const vdetr_rb_attn_emit* e, vdetr_stream_t stream) {
   VDETR_REQUIRE(d != nullptr && g != nullptr, "rb_proj_q_bwd: null descriptor");
   if (int e = rb_common(d->rows, d->B, "rb_proj_q_bwd")) return e;
   VDETR_REQUIRE(d->proj.w && d->q.w && d->norm2.gamma && d->y && d->mean_y && d->rstd_y && g->d_tgt && g->d_proj && g->part_n2 &&
@@ -646,11 +675,26 @@ extern "C" int vdetr_rb_proj_q_bwd_f32(const vdetr_rb_projq_desc* d, const vdetr
   VDETR_REQUIRE(RB_ALIGNED(d->proj.w) && RB_ALIGNED(d->q.w) && RB_ALIGNED(d->norm2.gamma) && RB_ALIGNED(d->y) && RB_ALIGNED(g->d_y) &&
                 RB_ALIGNED(g->d_qout) && RB_ALIGNED(g->d_tgt) && RB_ALIGNED(g->d_a) && RB_ALIGNED(g->d_t2) && RB_ALIGNED(g->dq_rows) &&
                 RB_ALIGNED(g->d_proj) && RB_ALIGNED(g->part_n2), "rb_proj_q_bwd: operands must be 16-B aligned");
-  hipLaunchKernelGGL(rb_proj_q_bwd_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g);
+  if (e) {
+    KvEmit E;
+    if (int err = rb_emit_args(e, d->rows, d->B, g->d_a, &E, "rb_proj_q_bwd_emit")) return err;
+    hipLaunchKernelGGL(rb_proj_q_bwd_kernel<true>, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g, E);
+  } else {
+    hipLaunchKernelGGL(rb_proj_q_bwd_kernel<false>, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g, KvEmit{});
+  }
   return check_launch("rb_proj_q_bwd");
 }
 
-extern "C" int vdetr_rb_ffn_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream) {
+extern "C" int vdetr_rb_proj_q_bwd_f32(const vdetr_rb_projq_desc* d, const vdetr_rb_projq_grads* g, vdetr_stream_t stream) {
+  return rb_proj_q_bwd_run(d, g, nullptr, stream);
+}
+extern "C" int vdetr_rb_proj_q_bwd_emit_f32(const vdetr_rb_projq_desc* d, const vdetr_rb_projq_grads* g, const vdetr_rb_attn_emit* e,
+                                            vdetr_stream_t stream) {
+  VDETR_REQUIRE(e != nullptr, "rb_proj_q_bwd_emit: null descriptor");
+  return rb_proj_q_bwd_run(d, g, e, stream);
+}
+
+static int rb_ffn_bwd_run(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, const vdetr_rb_attn_emit* e, vdetr_stream_t stream) {
   VDETR_REQUIRE(d != nullptr && g != nullptr, "rb_ffn_bwd: null descriptor");
   if (int e = rb_common(d->rows, d->B, "rb_ffn_bwd")) return e;
   VDETR_REQUIRE(d->proj.w && d->lin1.w && d->lin2.w && d->norm3.gamma && d->post1.gamma && d->y && d->mean_y && d->rstd_y && d->h && d->z &&
@@ -661,6 +705,21 @@ extern "C" int vdetr_rb_ffn_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_f
                 RB_ALIGNED(d->post2.gamma) && RB_ALIGNED(d->y) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) && RB_ALIGNED(g->d_z) && RB_ALIGNED(g->d_o1) &&
                 RB_ALIGNED(g->d_o2) && RB_ALIGNED(g->d_tgt) && RB_ALIGNED(g->d_a) && RB_ALIGNED(g->d_lin2) && RB_ALIGNED(g->d_lin1) &&
                 RB_ALIGNED(g->d_proj) && RB_ALIGNED(g->part_post) && RB_ALIGNED(g->part_n3), "rb_ffn_bwd: operands must be 16-B aligned");
-  hipLaunchKernelGGL(rb_ffn_bwd_kernel, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g);
+  if (e) {
+    KvEmit E;
+    if (int err = rb_emit_args(e, d->rows, d->B, g->d_a, &E, "rb_ffn_bwd_emit")) return err;
+    hipLaunchKernelGGL(rb_ffn_bwd_kernel<true>, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g, E);
+  } else {
+    hipLaunchKernelGGL(rb_ffn_bwd_kernel<false>, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g, KvEmit{});
+  }
   return check_launch("rb_ffn_bwd");
+}
+
+extern "C" int vdetr_rb_ffn_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream) {
+  return rb_ffn_bwd_run(d, g, nullptr, stream);
+}
+extern "C" int vdetr_rb_ffn_bwd_emit_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, const vdetr_rb_attn_emit* e,
+                                         vdetr_stream_t stream) {
+  VDETR_REQUIRE(e != nullptr, "rb_ffn_bwd_emit: null descriptor");
+  return rb_ffn_bwd_run(d, g, e, stream);
 }

@@ -152,6 +152,19 @@ def _check(*ts):
             raise RuntimeError("rowblock operands must be contiguous and 16-B aligned")
 
 
+def _emit_for(rec, a, d_a, rows, B, per_head):
+    """the vdetr_rb_attn_emit of a backward launch that produces d_a = the output gradient of the attention call `rec` (whose forward
+    output is `a`), or None where the call does not qualify (attention.py: the key-side pass without its packing launch)"""
+    if rec is None or d_a is None or B != 1 or rows % 32 or rec.dims[2] != rows or (rec.kind == L.VDETR_ATTN_PER_HEAD) != bool(per_head):
+        return None
+    A.kv_prepare(rec)
+    e = L.RbAttnEmit()
+    e.workspace, e.delta, e.out = rec.ws.data_ptr(), rec.delta.data_ptr(), a.data_ptr()
+    e.bwd_aux = rec.aux.data_ptr() if rec.aux is not None else None
+    e.per_head, e.nQ = int(bool(per_head)), rows
+    return e
+
+
 class _Qkv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, pos, wq, wk, wv, bq, bk, bv, B, wt):
@@ -251,6 +264,7 @@ class _ProjQ(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, tgt, pos, wo, bo, wq, bq, g2, b2, eps, p, salt, rng, B, wot, wqt):
         _check(a, tgt, pos, wo, bo, wq, bq, g2, b2, wot, wqt)
+        ctx.kv_rec = A.kv_record_of(a)  # (the self-attention call that produced a: its backward's operands are emitted here)
         rows = tgt.numel() // C
         dev = tgt.device
         y = torch.empty_like(tgt)
@@ -306,7 +320,12 @@ class _ProjQ(torch.autograd.Function):
             g.d_a = d_a.data_ptr() if d_a is not None else None
             g.d_t2 = d_t2.data_ptr() if d_t2 is not None else None
             g.dq_rows = dq_rows.data_ptr() if dq_rows is not None else None
-            L.check(L.lib().vdetr_rb_proj_q_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_proj_q_bwd")
+            emit = _emit_for(getattr(ctx, "kv_rec", None), a, d_a, rows, B, True)
+            if emit is not None:
+                L.check(L.lib().vdetr_rb_proj_q_bwd_emit_f32(ctypes.byref(d), ctypes.byref(g), ctypes.byref(emit), L.stream_ptr()), "rb_proj_q_bwd_emit")
+                ctx.kv_rec.emitted = d_a.data_ptr()
+            else:
+                L.check(L.lib().vdetr_rb_proj_q_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_proj_q_bwd")
             gwq = gbq = None
             if d_qout is not None:
                 gwq, gbq = _park_or_grad(wq, bq, dq_rows if dq_rows is not None else d_qout.view(rows, C), xq.reshape(-1, C), need[5], need[6])
@@ -338,6 +357,7 @@ class _Ffn(torch.autograd.Function):
     def forward(ctx, a, tgt, wp, bp, w1, b1, w2, b2, g3, be3, gp1, bep1, gp2, bep2, eps3, epsp, p2, salt2, pa, salta, p3, salt3,
                 rng, B, wpt, w1t, w2t):
         _check(a, tgt, wp, bp, w1, b1, w2, b2, g3, be3, gp1, bep1, gp2, bep2, wpt, w1t, w2t)
+        ctx.kv_rec = A.kv_record_of(a)  # (the cross-attention call that produced a)
         rows = tgt.numel() // C
         dev = tgt.device
         new = lambda: torch.empty_like(tgt)
@@ -417,7 +437,12 @@ class _Ffn(torch.autograd.Function):
             g.d_tgt, g.d_lin2, g.d_lin1, g.d_proj = d_tgt.data_ptr(), d_lin2.data_ptr(), d_lin1.data_ptr(), d_proj.data_ptr()
             g.d_a = d_a.data_ptr() if d_a is not None else None
             g.part_post, g.part_n3 = parts[0].data_ptr(), parts[1].data_ptr()
-            L.check(L.lib().vdetr_rb_ffn_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_ffn_bwd")
+            emit = _emit_for(getattr(ctx, "kv_rec", None), a, d_a, rows, B, False)
+            if emit is not None:
+                L.check(L.lib().vdetr_rb_ffn_bwd_emit_f32(ctypes.byref(d), ctypes.byref(g), ctypes.byref(emit), L.stream_ptr()), "rb_ffn_bwd_emit")
+                ctx.kv_rec.emitted = d_a.data_ptr()
+            else:
+                L.check(L.lib().vdetr_rb_ffn_bwd_f32(ctypes.byref(d), ctypes.byref(g), L.stream_ptr()), "rb_ffn_bwd")
             gw2, gb2 = _park_or_grad(w2, b2, d_lin2, h.view(rows, C), need[6], need[7])
             gw1, gb1 = _park_or_grad(w1, b1, d_lin1, t2.view(rows, C), need[4], need[5])
             gwp, gbp = _park_or_grad(wp, bp, d_proj, _seq_rows(a, B), need[2], need[3])
