@@ -675,7 +675,7 @@ int vdetr_sumsq_blocks(long n);
 int vdetr_sumsq_f32(const float* g, long n, float* partial, int npartial, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
- * Z-order permutation of a scene's key points, one launch (one workgroup per scene).  Replaces the tensor expression the
+ * Z-order permutation of a scene's key points, one launch (ranks by counting, n / 64 workgroups per scene).  Replaces the tensor expression the
  * decoder would otherwise spend ~50 launches on in front of the cross attention (v-detr_amd/pc_util.py:morton_argsort; the
  * reference attends in FPS order, models/vdetr_transformer.py:400-436 — attention does not depend on the key order).
  *   xyz [B,n,3] fp32 -> codes [B,n] int32 (30-bit Morton code of the point in the scene's bounding box; may be NULL)
@@ -685,7 +685,7 @@ int vdetr_morton_sort_max(void);
 int vdetr_morton_order_f32(const float* xyz, int B, int n, int* codes, long long* order, vdetr_stream_t stream);
 /* order [B, nq] int64 = indices of the nq largest of values [B, n] per row, largest first, equal values by ascending index — what
  * torch.sort(descending=True, stable=True) returns (one of the orders torch.topk may return, models/vdetr_transformer.py:364-366:
- * the decoder's proposals); one workgroup per row, n <= vdetr_morton_sort_max(). */
+ * the decoder's proposals); n / 64 workgroups per row, n <= vdetr_morton_sort_max() = 16384. */
 int vdetr_topk_order_f32(const float* values, int B, int n, int nq, long long* order, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------

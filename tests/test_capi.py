@@ -62,7 +62,7 @@ def test_round2_entry_points_reject_bad_arguments():
     assert b"sp_pair_plan" in lib.vdetr_last_error()
     assert lib.vdetr_sp_wgrad_reduce_f32(None, None, 27, 6, None, None) == 1      # elems not a multiple of 4
     assert b"sp_wgrad_reduce" in lib.vdetr_last_error()
-    assert lib.vdetr_morton_sort_max() == 8192
+    assert lib.vdetr_morton_sort_max() == 16384
     assert lib.vdetr_morton_order_f32(None, 1, 16, None, None, None) == 1
     assert b"morton_order" in lib.vdetr_last_error()
     assert lib.vdetr_sp_pairs_gemm_f32(None, None, None, None, 5, 24, 64, 0, None, None) == 1

@@ -497,10 +497,10 @@ def test_rotated_boxes_in_world_coordinates_keep_the_general_table_kernel():
         assert float((g - res[1][n]).abs().max()) <= 1e-3 * float(res[1][n].abs().max()) + 1e-12, n
 
 
-@pytest.mark.parametrize("B,N", [(1, 4096), (3, 1000), (2, 1), (1, 8192), (2, 9000), (1, 77)])
+@pytest.mark.parametrize("B,N", [(1, 4096), (3, 1000), (2, 1), (1, 8192), (2, 9000), (1, 77), (1, 16384), (2, 20000)])
 def test_morton_order_equals_the_tensor_expression(B, N):
-    """csrc/morton.hip (one launch) against pc_util.morton_codes evaluated on the CPU: same codes bit for bit, the order is the
-    stable sort of the codes; N > 8192 goes through the codes-only launch + a library sort."""
+    """csrc/morton.hip (one launch: ranks by counting on N / 64 workgroups) against pc_util.morton_codes evaluated on the CPU: same
+    codes bit for bit, the order is the stable sort of the codes; N > 16384 goes through the codes-only launch + a library sort."""
     from vdetr_amd import pc_util
     from vdetr_amd import _lib as L
     g = torch.Generator().manual_seed(B * 10007 + N)
@@ -518,9 +518,9 @@ def test_morton_order_equals_the_tensor_expression(B, N):
     assert torch.equal(codes.cpu().long(), ref_codes)
 
 
-@pytest.mark.parametrize("B,N,nq", [(1, 4096, 1024), (3, 1000, 64), (2, 1, 1), (1, 8192, 8192), (2, 77, 50), (1, 512, 512)])
+@pytest.mark.parametrize("B,N,nq", [(1, 4096, 1024), (3, 1000, 64), (2, 1, 1), (1, 8192, 8192), (2, 77, 50), (1, 512, 512), (2, 12000, 5000)])
 def test_proposal_order_launch_equals_the_stable_sort(B, N, nq):
-    """vdetr_topk_order_f32 (one workgroup per scene, keys in registers: csrc/wgsort.h) == torch.sort(descending, stable)[:nq] —
+    """vdetr_topk_order_f32 (ranks by counting, N / 64 workgroups per scene) == torch.sort(descending, stable)[:nq] —
     the decoder's proposal order (vdetr_transformer._proposal_order) — on values with many exact ties, negative values and zeros."""
     import vdetr_amd.vdetr_transformer as T
     g = torch.Generator().manual_seed(N + nq)
