@@ -277,7 +277,7 @@ class GlobalShareCrossAttention(nn.Module):
                               attn_mask=attn_mask, dropout_p=p, rng_state=rng, salt=self._salt,
                               table_grad_async=cache is not None, vertices_are_boxes=self.vertices_are_boxes, **({"operand_bf16": True} if rounded else {}),
                               **({"kv_img": cache[3]} if (cache is not None and len(cache) > 3 and cache[3] is not None) else {}),
-                              defer_combine=defer_combine and not self.return_attn)
+                              **({"defer_combine": True} if (defer_combine and not self.return_attn) else {}))
         attn = None
         if self.return_attn:
             attn = A.attention_probabilities(q32.float(), k32.float(), num_heads=self.num_heads, scale=self.scale, shared_kv=True,
