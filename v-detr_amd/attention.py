@@ -91,9 +91,10 @@ ASYNC_MIN_PAIRS = 1 << 21
 ASYNC_TABLE_GRID = int(os.environ.get("VDETR_BWD_ASYNC_GRID", "190"))
 _ASYNC_KV4 = os.environ.get("VDETR_BWD_ASYNC_KV_WAVES", "8") == "4"
 # vdetr_attn_desc.kv_halves = 1 (one workgroup per key tile) while a table kernel is live — 1: the per-head pass only; 2: the
-# shared-K/V pass as well; 0 (default): never.  With the side grid at 192 the per-head form won 0.03 ms (7.36 -> 7.33; the
+# shared-K/V pass as well; 0: never.  With the side grid at 192 the per-head form won 0.03 ms (7.36 -> 7.33; the
 # shared-K/V form lost: 7.41); at 190 the default shape is as fast or faster (7.01 / 7.03-7.05 / 7.18 for 0 / 1 / 2).
-KV_ONE_WG = int(os.environ.get("VDETR_BWD_KV_ONE_WG", "0"))
+# (round 6, on the final step: 0 / 1 / 2 = 6.41-6.42 / 6.39 / 6.58-6.59 ms: the per-head form is the default now)
+KV_ONE_WG = int(os.environ.get("VDETR_BWD_KV_ONE_WG", "1"))
 
 
 _step_side = {}  # device key -> this step's forward ran a cross-attention whose table gradient will go to the side stream
