@@ -287,13 +287,48 @@ __global__ __launch_bounds__(kHdThreads) void heads_l2_kernel(HdArgs A, int merg
 
 // ---- between the launches, for long sequences only: the P tile partials of every channel folded into entry 0 of the table -------
 // (every consumer workgroup merging P partials itself is P^2 work: fine at 32 tiles (1024 tokens), 335 MB of L2 reads at 128)
+// Eight lanes per channel: each folds an eighth of the tiles (Chan's update, tile after tile), the eight partial (n, mean, M2) are
+// combined pairwise by three lane exchanges, lower lane = left operand: a fixed tree, the same bits in every run.  (One thread per
+// channel walking all 128 tiles was a 14 us chain of dependent divisions on 5 workgroups, twice in front of the first stage.)
+constexpr int kHdMergeLanes = 8;
 __global__ __launch_bounds__(kHdThreads) void heads_merge_kernel(float* part, int P, int GC) {
-  const int ch = blockIdx.x * kHdThreads + threadIdx.x;
-  if (ch >= GC) return;
-  float mean, m2;
-  hd_merge(part, P, GC, ch, (float)kHdTok, mean, m2);
-  part[2 * (size_t)ch] = mean;       // (entry 0 is read by this thread only, and before it is written)
-  part[2 * (size_t)ch + 1] = m2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int t = blockIdx.x * kHdThreads + threadIdx.x;
+  const int ch = min(t / kHdMergeLanes, GC - 1), sub = t % kHdMergeLanes;  // (lanes past the end fold channel GC - 1 again, and do not store)
+  const int per = (P + kHdMergeLanes - 1) / kHdMergeLanes, i0 = sub * per, i1 = min(P, i0 + per);
+  const float cnt = (float)kHdTok;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  const f32x2* p = reinterpret_cast<const f32x2*>(part) + ch;
+  for (int i = i0; i < i1; i += 4) {
+    f32x2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = i + j < i1 ? p[(size_t)(i + j) * GC] : f32x2{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i + j < i1) {
+        const float nn = n + cnt, d = v[j][0] - mean;
+        mean += d * (cnt / nn);
+        m2 += v[j][1] + d * d * (n * cnt / nn);
+        n = nn;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < kHdMergeLanes; m <<= 1) {
+    const float no = __shfl_xor(n, m, 64), mo = __shfl_xor(mean, m, 64), qo = __shfl_xor(m2, m, 64);
+    const bool left = (sub & m) == 0;  // this lane's state is the left operand of the pair
+    const float na = left ? n : no, ma = left ? mean : mo, qa = left ? m2 : qo;
+    const float nb = left ? no : n, mb = left ? mo : mean, qb = left ? qo : m2;
+    const float nn = na + nb, d = mb - ma;
+    mean = nn > 0.f ? ma + d * (nb / nn) : 0.f;
+    m2 = nn > 0.f ? qa + qb + d * d * (na * nb / nn) : 0.f;
+    n = nn;
+  }
+  __syncthreads();  // every lane of the workgroup has read entry 0 of its channels (sub 0 reads tile 0) before anybody overwrites it
+  if (sub == 0 && t / kHdMergeLanes < GC) {
+    part[2 * (size_t)ch] = mean;
+    part[2 * (size_t)ch + 1] = m2;
+  }
 }
 
 // ---- launch 3 -----------------------------------------------------------------------------------------------------------------
@@ -519,9 +554,9 @@ extern "C" int vdetr_heads_fwd_f32(const vdetr_heads_desc* d, vdetr_stream_t str
   const int merged = tiles > kHdMergeAbove ? 1 : 0;
   float* part = reinterpret_cast<float*>(d->workspace);
   hipLaunchKernelGGL(heads_l1_kernel, dim3(tiles, d->G), dim3(kHdThreads), 0, st, *d);
-  if (merged) hipLaunchKernelGGL(heads_merge_kernel, dim3(ceil_div(GC, kHdThreads)), dim3(kHdThreads), 0, st, part, tiles, GC);
+  if (merged) hipLaunchKernelGGL(heads_merge_kernel, dim3(ceil_div(GC * kHdMergeLanes, kHdThreads)), dim3(kHdThreads), 0, st, part, tiles, GC);
   hipLaunchKernelGGL(heads_l2_kernel, dim3(tiles, d->G), dim3(kHdThreads), 0, st, *d, merged);
-  if (merged) hipLaunchKernelGGL(heads_merge_kernel, dim3(ceil_div(GC, kHdThreads)), dim3(kHdThreads), 0, st, part + (size_t)tiles * GC * 2, tiles, GC);
+  if (merged) hipLaunchKernelGGL(heads_merge_kernel, dim3(ceil_div(GC * kHdMergeLanes, kHdThreads)), dim3(kHdThreads), 0, st, part + (size_t)tiles * GC * 2, tiles, GC);
   hipLaunchKernelGGL(heads_l3_kernel, dim3(d->B * d->N / kHdTok3, d->G), dim3(kHdThreads), 0, st, *d, merged);
   return check_launch("heads_fwd");
 }
