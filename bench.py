@@ -142,13 +142,15 @@ def loss_fn(out):
 
 
 def fps_fork_layer(t1, t_fps, nlayers):
-    """Decoder layer of the forward in front of which the next scene's sampling branch is forked, or -1 (the step's start), from the
-    measured step (t1 ms, sampling forked at the start) and the sampling alone (t_fps ms).  The one-workgroup kernel holds a CU for
-    1.12 t_fps inside the step; it must end 1.2 ms before the step does (the tail of the backward is where the chain's widest
-    launches are), layer k of the forward starts at (0.05 + 0.04 k) t1, and below 0.3 t1 the held CU is not worth a second capture."""
+    """LATEST decoder layer of the forward in front of which the next scene's sampling branch may be forked, or -1 (the step's start),
+    from the measured step (t1 ms, sampling forked at the start) and the sampling alone (t_fps ms).  The one-workgroup kernel holds a
+    CU for 1.12 t_fps inside the step and should end 0.5 ms before the step does; layer k of the forward starts at
+    (0.03 + 0.044 k) t1 (round 6's timeline); below 0.3 t1 the held CU is not worth a second capture.  The caller
+    captures and times this layer AND the two in front of it and keeps what measures fastest: the bound only has to be generous
+    (round 5's 1.2 ms sat exactly on the edge once the step had become 5 % shorter: half the runs fell back to the step's start, 2 % slower)."""
     if nlayers <= 0 or t1 <= 0 or t_fps < 0.3 * t1:
         return -1
-    k = min(int(((t1 - 1.12 * t_fps - 1.2) / t1 - 0.05) / 0.04), nlayers - 1)
+    k = min(int(((t1 - 1.12 * t_fps - 0.5) / t1 - 0.03) / 0.044), nlayers - 1)
     return k if k >= 1 else -1
 
 
@@ -1119,12 +1121,19 @@ def main():
                 captured(t)
                 t.reset_state(snap)
                 return t
-            trk = build(k)
-            tk = over_ranks(replay_ms(trk, reps=12, settle=25))
+            # the latest layer the bound allows and the two in front of it: captured and timed, the fastest measured form kept
+            timed = []
+            for at in [x for x in (k, k - 1, k - 2) if x >= 1]:
+                trk = build(at)
+                timed.append((over_ranks(replay_ms(trk, reps=12, settle=25)), at))
+            tk, best = min(timed)
             if rank == 0:
-                print(f"[bench] sampling {t_fps:.2f} ms alone; captured step {t1:.2f} ms with it forked at the start, {tk:.2f} ms in front "
-                      f"of decoder layer {k}: {'layer ' + str(k) if tk < 0.998 * t1 else 'start'}", file=sys.stderr)
+                print(f"[bench] sampling {t_fps:.2f} ms alone; captured step {t1:.2f} ms with it forked at the start, "
+                      + ", ".join(f"{t:.2f} ms in front of decoder layer {at}" for t, at in timed)
+                      + f": {'layer ' + str(best) if tk < 0.998 * t1 else 'start'}", file=sys.stderr)
             if tk < 0.998 * t1:
+                if best != timed[-1][1]:
+                    trk = build(best)  # (only the last Trainer built has a live graph)
                 trk.reset_state(snap)
                 return trk
             return build(-1)

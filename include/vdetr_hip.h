@@ -637,6 +637,12 @@ typedef struct vdetr_pack_entry {
 /* out[c] = sum_r x[r * row_stride + c]: the bias gradient of nn.Linear / 1x1 Conv1d (the `sum` inside AddmmBackward of
  * every projection in models/vdetr_transformer.py), one launch. */
 int vdetr_colsum_f32(const float* x, float* out, int rows, int cols, long row_stride, vdetr_stream_t stream);
+/* out[i][c] = sum_r x[i * item_stride + r * row_stride + c] for n matrices: one launch, or two for tall matrices with few columns
+ * (partial sums of row ranges into `workspace`, vdetr_colsum_workspace_bytes(n, rows, cols) bytes, then their sum; without a workspace:
+ * one launch, unsplit).  Fixed summation order: bit-reproducible. */
+size_t vdetr_colsum_workspace_bytes(int n, int rows, int cols);
+int vdetr_colsum_batched_f32(const float* x, float* out, int n, int rows, int cols, long row_stride, long item_stride,
+                             void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
 int vdetr_pack_chunk_floats(void);
 int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk, int nblocks,
                    float* dst, vdetr_stream_t stream);

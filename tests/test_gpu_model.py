@@ -260,14 +260,20 @@ def test_adjacent_parameter_aliases_match_cat_and_stack():
     assert flat.grad[off + 12:off + 20].abs().max() == 0  # slab padding stays zero
 
 
-@pytest.mark.parametrize("rows,cols", [(1024, 256), (4096, 64), (1000, 1280), (3, 19)])
+@pytest.mark.parametrize("rows,cols", [(1024, 256), (4096, 64), (1000, 1280), (3, 19), (4096, 1024), (8192, 256), (5000, 130)])
 def test_colsum_and_linear_backward(rows, cols):
-    """vdetr_colsum_f32 and helpers.linear (bias gradient in one launch) vs torch."""
-    from vdetr_amd.helpers import colsum, linear
+    """vdetr_colsum_batched_f32 (tall matrices: the rows split over several workgroups per strip, the last one adds the partial sums in
+    a fixed order) and helpers.linear (bias gradient in one launch) vs torch."""
+    from vdetr_amd.helpers import colsum, colsum_batched, linear
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(rows + cols)
     x = torch.randn(rows, cols, generator=g).to(dev)
-    torch.testing.assert_close(colsum(x), x.sum(0), rtol=1e-5, atol=1e-4)
+    first = colsum(x)
+    torch.testing.assert_close(first, x.double().sum(0).float(), rtol=1e-5, atol=1e-4)
+    for _ in range(3):  # (the ticket counters are left zero: every call does the same, bit for bit)
+        assert torch.equal(colsum(x), first)
+    stack = torch.randn(3, rows, cols + 4, generator=g).to(dev)[:, :, 2:2 + cols]  # item- and row-strided
+    torch.testing.assert_close(colsum_batched(stack), stack.double().sum(1).float(), rtol=1e-5, atol=1e-4)
     wide = torch.randn(rows, cols + 8, generator=g).to(dev)
     torch.testing.assert_close(colsum(wide[:, 3:3 + cols]), wide[:, 3:3 + cols].sum(0), rtol=1e-5, atol=1e-4)
     lin = torch.nn.Linear(cols, 32).to(dev)

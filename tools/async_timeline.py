@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of one captured step from a rocprofv3 kernel trace: every kernel between the starts of the last two steps (morton_order_kernel), in
+"""Timeline of one captured step from a rocprofv3 kernel trace: every kernel between the ends of the last two steps (the optimizer's launch), in
 start order, with its queue, start offset, duration and how much of it ran while a table-gradient kernel was running.
     python tools/async_timeline.py <kernel_trace.csv> [table kernel substring] [--all]"""
 import csv
@@ -10,9 +10,9 @@ pat = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-adam = [r for r in rows if "morton_order_kernel" in r["Kernel_Name"]]  # one per step, at its start
+adam = [r for r in rows if "adamw_clip_kernel" in r["Kernel_Name"] or "FusedOptimizerTensorListMetadata" in r["Kernel_Name"]]  # a step's last launch
 a0, a1 = adam[-2], adam[-1]
-step = [r for r in rows if a0["s"] <= r["s"] < a1["s"] and "fps_rows" not in r["Kernel_Name"]]
+step = [r for r in rows if a0["s"] < r["s"] <= a1["s"] and "fps_rows" not in r["Kernel_Name"]]
 t0 = step[0]["s"]
 tab = [r for r in step if pat in r["Kernel_Name"]]
 print(f"# step of {(a1['s'] - a0['s']) / 1e6:.3f} ms, {len(step)} kernels, {len(tab)} table kernels, sum of kernel time {sum(r['e'] - r['s'] for r in step) / 1e6:.3f} ms")

@@ -323,6 +323,8 @@ _SIGNATURES = {
     "vdetr_bn_act_bwd_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_void_p]),
     "vdetr_bn_act_bwd_batch_f32": (c_int, [ctypes.POINTER(BnActDesc), ctypes.POINTER(BnActGrads), c_int, c_void_p]),
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),
+    "vdetr_colsum_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vdetr_colsum_batched_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_long, ctypes.c_long, c_void_p, c_size_t, c_void_p]),
     "vdetr_nms3d_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vdetr_nms3d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_int, c_void_p,
                         c_void_p, c_size_t, c_void_p]),

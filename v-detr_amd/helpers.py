@@ -13,15 +13,26 @@ import torch
 import torch.nn as nn
 
 
-def colsum(x2d):
-    """sum over the rows of a [rows, cols] fp32 CUDA matrix (row-strided is fine) in one launch (vdetr_colsum_f32)."""
+def colsum_batched(x3d):
+    """sums over the rows of n [rows, cols] fp32 CUDA matrices (x3d [n, rows, cols], rows / items strided is fine) -> [n, cols], one
+    launch — two for tall matrices with few columns (vdetr_colsum_batched_f32; fixed summation order)."""
     import ctypes
     from . import _lib as L
-    assert x2d.dim() == 2 and x2d.stride(1) == 1
-    out = torch.empty(x2d.shape[1], dtype=x2d.dtype, device=x2d.device)
-    L.check(L.lib().vdetr_colsum_f32(L.ptr(x2d), L.ptr(out), x2d.shape[0], x2d.shape[1], ctypes.c_long(x2d.stride(0)),
-                                     L.stream_ptr()), "colsum")
+    assert x3d.dim() == 3 and x3d.stride(2) == 1
+    n, rows, cols = x3d.shape
+    lib = L.lib()
+    need = lib.vdetr_colsum_workspace_bytes(n, rows, cols)
+    ws = torch.empty(need, dtype=torch.uint8, device=x3d.device) if need else None  # (tall, few columns: partial sums of row ranges)
+    out = torch.empty((n, cols), dtype=x3d.dtype, device=x3d.device)
+    L.check(lib.vdetr_colsum_batched_f32(L.ptr(x3d), L.ptr(out), n, rows, cols, ctypes.c_long(x3d.stride(1)), ctypes.c_long(x3d.stride(0)),
+                                         L.ptr(ws), need, L.stream_ptr()), "colsum_batched")
     return out
+
+
+def colsum(x2d):
+    """sum over the rows of a [rows, cols] fp32 CUDA matrix (row-strided is fine)."""
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    return colsum_batched(x2d.unsqueeze(0))[0]
 
 
 class DeferredParamGrads:
@@ -126,7 +137,8 @@ class DeferredParamGrads:
                     G = torch.stack([it[2] for it in group])                       # [n, rows, out]
                     dW = torch.bmm(G.transpose(1, 2), torch.stack([it[3] for it in group])) \
                         if any(it[0] is not None for it in group) else None
-                    dB = G.sum(1) if any(it[1] is not None for it in group) else None
+                    dB = (colsum_batched(G) if G.is_cuda and G.dtype == torch.float32 else G.sum(1)) \
+                        if any(it[1] is not None for it in group) else None
                 for which, R in ((0, dW), (1, dB)):
                     if R is None:
                         continue
