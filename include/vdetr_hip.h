@@ -643,6 +643,9 @@ int vdetr_colsum_f32(const float* x, float* out, int rows, int cols, long row_st
 size_t vdetr_colsum_workspace_bytes(int n, int rows, int cols);
 int vdetr_colsum_batched_f32(const float* x, float* out, int n, int rows, int cols, long row_stride, long item_stride,
                              void* workspace, size_t workspace_bytes, vdetr_stream_t stream);
+/* the same for n separately allocated matrices: `items` is a DEVICE array of n pointers (16-byte aligned; cols, row_stride % 4 == 0) */
+int vdetr_colsum_ptrs_f32(const float* const* items, float* out, int n, int rows, int cols, long row_stride, void* workspace,
+                          size_t workspace_bytes, vdetr_stream_t stream);
 int vdetr_pack_chunk_floats(void);
 int vdetr_pack_f32(const vdetr_pack_entry* entries, const uint32_t* block_entry, const uint32_t* block_chunk, int nblocks,
                    float* dst, vdetr_stream_t stream);

@@ -325,6 +325,7 @@ _SIGNATURES = {
     "vdetr_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_long, c_void_p]),
     "vdetr_colsum_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vdetr_colsum_batched_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_long, ctypes.c_long, c_void_p, c_size_t, c_void_p]),
+    "vdetr_colsum_ptrs_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_long, c_void_p, c_size_t, c_void_p]),
     "vdetr_nms3d_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vdetr_nms3d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_int, c_void_p,
                         c_void_p, c_size_t, c_void_p]),
@@ -442,3 +443,88 @@ def require_int(t, name):
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+# ---- rocBLAS' pointer-array batched GEMM (the library GEMM torch does not expose) ------------------------------------------------------
+# torch.bmm wants ONE strided tensor per operand: the parked weight-gradient operands of a step (64 separately allocated [1024, 256]
+# pairs) went through two torch.stack copies of 64 MB each — 60 us on the backward's tail — before a 71 us GEMM.  rocblas_sgemm_batched
+# takes arrays of device pointers: the same Tensile kernel (bit-identical results), 87 us with no copies
+# (tools/probes/rocblas_batched_probe.py).  Called on torch's own librocblas; survives stream capture (its workspace is allocated by
+# the eager warm-up steps every captured loop runs first).
+_rocblas = {"lib": None, "handles": {}}
+ROCBLAS_OP_N, ROCBLAS_OP_T = 111, 112
+
+
+def rocblas():
+    if _rocblas["lib"] is None:
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librocblas.so")
+        rb = ctypes.CDLL(path if os.path.exists(path) else "librocblas.so")
+        rb.rocblas_create_handle.argtypes = [ctypes.POINTER(c_void_p)]
+        rb.rocblas_set_stream.argtypes = [c_void_p, c_void_p]
+        rb.rocblas_sgemm_batched.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                             c_void_p, c_void_p, c_int, c_int]
+        _rocblas["lib"] = rb
+    return _rocblas["lib"]
+
+
+def sgemm_batched_ptrs(op_a, op_b, m, n, k, a_ptrs, lda, b_ptrs, ldb, c_ptrs, ldc, batch, device, alpha=1.0, beta=0.0):
+    """column-major C_i [m x n] = alpha op(A_i) op(B_i) + beta C_i for `batch` matrices given by DEVICE arrays of pointers (int64
+    tensors or raw addresses), on the current stream of `device`"""
+    rb = rocblas()
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    h = _rocblas["handles"].get(key)
+    if h is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("rocBLAS handle: create it before a stream capture (run one step eagerly first)")
+        h = c_void_p()
+        with torch.cuda.device(key):
+            if rb.rocblas_create_handle(ctypes.byref(h)) != 0:
+                raise RuntimeError("rocblas_create_handle failed")
+        _rocblas["handles"][key] = h
+    if rb.rocblas_set_stream(h, c_void_p(torch.cuda.current_stream(device).cuda_stream)) != 0:
+        raise RuntimeError("rocblas_set_stream failed")
+    al, be = c_float(alpha), c_float(beta)
+    addr = lambda p: c_void_p(p.data_ptr() if torch.is_tensor(p) else int(p))
+    rc = rb.rocblas_sgemm_batched(h, op_a, op_b, m, n, k, ctypes.byref(al), addr(a_ptrs), lda, addr(b_ptrs), ldb, ctypes.byref(be),
+                                  addr(c_ptrs), ldc, batch)
+    if rc != 0:
+        raise RuntimeError(f"rocblas_sgemm_batched failed (status {rc})")
+
+
+# pointer tables for such calls: pinned staging -> device.  Eager: a ring of pinned buffers (the host waits only for the upload that
+# used a buffer three calls ago); under a stream capture the copy is a captured node that re-reads ITS host buffer at every replay, so
+# each captured upload keeps a buffer of its own for good (pre-allocated: no host allocation while capturing).
+_ptr_tables = {}
+
+
+def upload_ptrs(ptrs, device):
+    n = len(ptrs)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    T = _ptr_tables.get(key)
+    if T is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("pointer tables: allocate before a stream capture (run one step eagerly first)")
+        T = _ptr_tables[key] = {"ring": [torch.empty(1024, dtype=torch.int64).pin_memory() for _ in range(4)], "events": [None] * 4, "tick": 0,
+                                "spare": [torch.empty(1024, dtype=torch.int64).pin_memory() for _ in range(48)], "kept": []}
+    if n > 1024:
+        raise RuntimeError(f"pointer table of {n} entries (max 1024)")
+    dev = torch.empty(n, dtype=torch.int64, device=device)
+    if torch.cuda.is_current_stream_capturing():
+        if not T["spare"]:
+            raise RuntimeError("pointer tables: more than 48 captured uploads in this process")
+        host = T["spare"].pop()
+        T["kept"].append(host)
+        host[:n] = torch.tensor(ptrs, dtype=torch.int64)
+        dev.copy_(host[:n], non_blocking=True)
+        return dev
+    slot = T["tick"] % 4
+    T["tick"] += 1
+    if T["events"][slot] is not None:
+        T["events"][slot].synchronize()
+    host = T["ring"][slot]
+    host[:n] = torch.tensor(ptrs, dtype=torch.int64)
+    dev.copy_(host[:n], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    T["events"][slot] = ev
+    return dev

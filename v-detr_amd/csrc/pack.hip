@@ -91,6 +91,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 struct ColsumB {
   const float* x; float* out;
+  const float* const* items;  // or nullptr: item i starts at x + i * item_stride
   int rows, cols, S;
   long row_stride, item_stride;
 };
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(ColsumB A) {
   const f32x4c zero = {0.f, 0.f, 0.f, 0.f};
   f32x4c acc[2] = {zero, zero};
   if (live) {
-    const float* p = A.x + (size_t)item * A.item_stride + c;
+    const float* p = (A.items ? A.items[item] : A.x + (size_t)item * A.item_stride) + c;
     int r = r0 + wv;
     for (; r + 28 < r1; r += 32) {
       f32x4c v[8];
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(1024) void colsum_batched_kernel(ColsumB A) {
   const int c = blockIdx.x * 64 + lane;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < A.cols) {
-    const float* p = A.x + (size_t)item * A.item_stride + c;
+    const float* p = (A.items ? A.items[item] : A.x + (size_t)item * A.item_stride) + c;
     int r = wv;
     for (; r + 48 < A.rows; r += 64) {
       a0 += p[(size_t)r * A.row_stride];
@@ -173,27 +174,39 @@ extern "C" size_t vdetr_colsum_workspace_bytes(int n, int rows, int cols) {
   return S > 1 ? (size_t)n * S * cols * sizeof(float) : 0;
 }
 
-extern "C" int vdetr_colsum_batched_f32(const float* x, float* out, int n, int rows, int cols, long row_stride, long item_stride,
-                                        void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
-  VDETR_REQUIRE(x && out, "colsum_batched: null pointer");
+// items != nullptr: a DEVICE array of n pointers to 16-byte aligned matrices (vdetr_colsum_ptrs_f32)
+static int colsum_run(const float* x, const float* const* items, float* out, int n, int rows, int cols, long row_stride, long item_stride,
+                      void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+  VDETR_REQUIRE((x || items) && out, "colsum_batched: null pointer");
   VDETR_REQUIRE(n > 0 && n <= 65535 && rows > 0 && cols > 0 && row_stride >= cols, "colsum_batched: bad shape n=%d rows=%d cols=%d stride=%ld", n, rows, cols, row_stride);
-  const bool vec = colsum_vec(x, cols, row_stride, item_stride) && (((uintptr_t)out) & 15) == 0;
+  const bool vec = (items ? (cols % 4 == 0 && row_stride % 4 == 0) : colsum_vec(x, cols, row_stride, item_stride)) && (((uintptr_t)out) & 15) == 0;
   const size_t need = vdetr_colsum_workspace_bytes(n, rows, cols);
   const int S = (vec && need && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0) ? colsum_splits(n, rows, cols) : 1;
   ColsumB A;
-  A.x = x; A.rows = rows; A.cols = cols; A.S = S; A.row_stride = row_stride; A.item_stride = item_stride;
+  A.x = x; A.items = items; A.rows = rows; A.cols = cols; A.S = S; A.row_stride = row_stride; A.item_stride = item_stride;
   A.out = S > 1 ? reinterpret_cast<float*>(workspace) : out;
   if (vec) {
     hipLaunchKernelGGL(colsum4_kernel, dim3(ceil_div(cols, 256), S, n), dim3(256), 0, (hipStream_t)stream, A);
     if (S > 1) {  // the [n, S, cols] partial sums -> out
       ColsumB B;
-      B.x = A.out; B.out = out; B.rows = S; B.cols = cols; B.S = 1; B.row_stride = cols; B.item_stride = (long)S * cols;
+      B.x = A.out; B.items = nullptr; B.out = out; B.rows = S; B.cols = cols; B.S = 1; B.row_stride = cols; B.item_stride = (long)S * cols;
       hipLaunchKernelGGL(colsum4_kernel, dim3(ceil_div(cols, 256), 1, n), dim3(256), 0, (hipStream_t)stream, B);
     }
   } else {
     hipLaunchKernelGGL(colsum_batched_kernel, dim3(ceil_div(cols, 64), 1, n), dim3(1024), 0, (hipStream_t)stream, A);
   }
   return check_launch("colsum_batched");
+}
+
+extern "C" int vdetr_colsum_batched_f32(const float* x, float* out, int n, int rows, int cols, long row_stride, long item_stride,
+                                        void* workspace, size_t workspace_bytes, vdetr_stream_t stream) {
+  return colsum_run(x, nullptr, out, n, rows, cols, row_stride, item_stride, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vdetr_colsum_ptrs_f32(const float* const* items, float* out, int n, int rows, int cols, long row_stride, void* workspace,
+                                     size_t workspace_bytes, vdetr_stream_t stream) {
+  VDETR_REQUIRE(cols % 4 == 0 && row_stride % 4 == 0, "colsum_ptrs: cols %d and row_stride %ld must be multiples of 4 (16-byte aligned items)", cols, row_stride);
+  return colsum_run(nullptr, items, out, n, rows, cols, row_stride, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int vdetr_colsum_f32(const float* x, float* out, int rows, int cols, long row_stride, vdetr_stream_t stream) {

@@ -29,6 +29,57 @@ def colsum_batched(x3d):
     return out
 
 
+PTR_BATCH = os.environ.get("VDETR_PTR_BATCH", "1") != "0"
+
+
+def _ptr_batchable(group):
+    """items (w, b, dY [rows, out], X [rows, in]) whose operands rocblas_sgemm_batched / vdetr_colsum_ptrs_f32 can read in place"""
+    if not PTR_BATCH or len(group) > 256 or len(group) < 8:
+        return False  # (few items: the copies are small, and the library's pick for a batch of 2 with K = 4096 measured 90 us slower)
+    g0, x0 = group[0][2], group[0][3]
+    if not (g0.is_cuda and g0.dtype == torch.float32 and x0.dtype == torch.float32 and g0.shape[1] % 4 == 0):
+        return False
+    for it in group:
+        g, x = it[2], it[3]
+        if not (g.stride(1) == 1 and x.stride(1) == 1 and g.stride(0) == g0.stride(0) and x.stride(0) == x0.stride(0)
+                and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 4 == 0):
+            return False
+    return True
+
+
+def _wgrad_ptrs(group, need_w, need_b):
+    """(dW [n, out, in], dB [n, out]) of a group of parked (dY, X) pairs, read where they are"""
+    import ctypes
+    from . import _lib as L
+    n = len(group)
+    g0, x0 = group[0][2], group[0][3]
+    rows, out_f, in_f = g0.shape[0], g0.shape[1], x0.shape[1]
+    dev = g0.device
+    dW = torch.empty((n, out_f, in_f), dtype=torch.float32, device=dev) if need_w else None
+    dB = None
+    ptrs = [it[3].data_ptr() for it in group] + [it[2].data_ptr() for it in group]
+    if need_w:
+        ptrs += [dW.data_ptr() + i * out_f * in_f * 4 for i in range(n)]
+    tab = L.upload_ptrs(ptrs, dev)
+    base = tab.data_ptr()
+    if need_w:
+        # row-major dW [out, in] = dY^T X  ==  column-major [in x out] = X_cm [in x rows] (dY_cm [out x rows])^T
+        L.sgemm_batched_ptrs(L.ROCBLAS_OP_N, L.ROCBLAS_OP_T, in_f, out_f, rows, base, x0.stride(0), base + 8 * n, g0.stride(0),
+                             base + 16 * n, in_f, n, dev)
+    if need_b:
+        lib = L.lib()
+        dB = torch.empty((n, out_f), dtype=torch.float32, device=dev)
+        need = lib.vdetr_colsum_workspace_bytes(n, rows, out_f)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev) if need else None
+        L.check(lib.vdetr_colsum_ptrs_f32(ctypes.c_void_p(base + 8 * n), L.ptr(dB), n, rows, out_f, ctypes.c_long(g0.stride(0)), L.ptr(ws), need,
+                                          L.stream_ptr()), "colsum_ptrs")
+    if dW is not None:
+        dW._ptr_table = tab  # (the launches read the table after this returns: it lives as long as the result)
+    elif dB is not None:
+        dB._ptr_table = tab
+    return dW, dB
+
+
 def colsum(x2d):
     """sum over the rows of a [rows, cols] fp32 CUDA matrix (row-strided is fine)."""
     assert x2d.dim() == 2 and x2d.stride(1) == 1
@@ -134,11 +185,15 @@ class DeferredParamGrads:
                         base = cls._view_of_leaf(it[0]) if cls.direct else None
                         return (0, i, 0) if base is None else (1, id(base), it[0].storage_offset())
                     group = [it for _, it in sorted(enumerate(group), key=order)]
-                    G = torch.stack([it[2] for it in group])                       # [n, rows, out]
-                    dW = torch.bmm(G.transpose(1, 2), torch.stack([it[3] for it in group])) \
-                        if any(it[0] is not None for it in group) else None
-                    dB = (colsum_batched(G) if G.is_cuda and G.dtype == torch.float32 else G.sum(1)) \
-                        if any(it[1] is not None for it in group) else None
+                    need_w, need_b = any(it[0] is not None for it in group), any(it[1] is not None for it in group)
+                    if _ptr_batchable(group):
+                        # the operands where they are: rocBLAS' pointer-array batched GEMM and a column sum over a pointer table —
+                        # the same kernels as below without the two torch.stack copies (64 items: 2 x 64 MB, 60 us of the tail)
+                        dW, dB = _wgrad_ptrs(group, need_w, need_b)
+                    else:
+                        G = torch.stack([it[2] for it in group])                       # [n, rows, out]
+                        dW = torch.bmm(G.transpose(1, 2), torch.stack([it[3] for it in group])) if need_w else None
+                        dB = (colsum_batched(G) if G.is_cuda and G.dtype == torch.float32 else G.sum(1)) if need_b else None
                 for which, R in ((0, dW), (1, dB)):
                     if R is None:
                         continue
