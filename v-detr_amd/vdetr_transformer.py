@@ -581,6 +581,7 @@ class FFNLayer(nn.Module):
 # decoder
 # =====================================================================================================
 _DEFER_HEADS = os.environ.get("VDETR_DEFER_HEADS", "1") != "0"  # A/B switch (read once)
+_STAGE0_WG_SIDE = os.environ.get("VDETR_STAGE0_WG", "inline") == "side"
 _DEFER_STAGE0 = os.environ.get("VDETR_DEFER_STAGE0", "1") != "0"  # the first stage's heads recorded too (round 6; A/B switch)
 # the heads' weight gradients on the side branch (VDETR_HEADS_SIDE): 1 = at once, at the BEGINNING of the backward, where the branch
 # is idle - measured C2 8.376 -> 8.33 ms, but C5 (4 scenes: the GEMMs are 4 x larger and hold the first table kernels up) 26.15 ->
@@ -655,6 +656,7 @@ class _DeferredHeads(torch.autograd.Function):
         #  tail, not behind it)
         on_side = (_HEADS_SIDE and dY.is_cuda and DeferredParamGrads.enabled and DeferredParamGrads.direct
                    and A.side_branch_in_use(dev) and not r0.get("inline_wg", False))
+        late = _HEADS_SIDE_LATE and not r0.get("wg_side_now", False)
 
         def weight_grads(dx2, dx1):
             db3 = dY.sum(dim=(1, 4))                                                               # [S,G,rows]
@@ -677,7 +679,7 @@ class _DeferredHeads(torch.autograd.Function):
         dx1 = torch.empty_like(dh1)
         dbn1 = BNA.backward_from_records([r["bn1"] for r in recs], [dh1[s] for s in range(S)], [dx1[s] for s in range(S)])
         fork = None
-        if on_side and not _HEADS_SIDE_LATE:  # (recorded here, waited for behind the chain's next launch: the chain keeps its queue)
+        if on_side and not late:  # (recorded here, waited for behind the chain's next launch: the chain keeps its queue)
             fork = torch.cuda.Event()
             fork.record(torch.cuda.current_stream(dev))
         if one:  # the transposed product: rows = queries, i.e. the [nQ,B,C] layout the layers want (no permuted view to copy)
@@ -695,7 +697,7 @@ class _DeferredHeads(torch.autograd.Function):
                 return pairs
             for s in range(S):
                 out += [None, dbn1[s][1], dbn1[s][2], None, dbn2[s][1], dbn2[s][2], None, None]
-            if _HEADS_SIDE_LATE:  # at the END of the backward, behind the last table kernel (attention.flush_layer_params_on_side)
+            if late:  # at the END of the backward, behind the last table kernel (attention.flush_layer_params_on_side)
                 A.side_late.append((lambda: pairs_of(*weight_grads(dx2, dx1)), (dY, h2, h1, f, dx2, dx1)))
                 return (None, None, *out)
             side = A._side_stream(dev)
@@ -1091,7 +1093,12 @@ class TransformerDecoder(nn.Module):
                                         enc_box_predictions["size_normalized"]) if (defer and _DEFER_STAGE0) else None
         if recorded is not None:
             box_prediction, rec0 = recorded
-            rec0["inline_wg"] = True
+            # the first stage's node is the LAST the backward reaches: its weight gradients in line (VDETR_STAGE0_WG=side: on the
+            # side branch at once, behind whatever that still has queued)
+            if _STAGE0_WG_SIDE:
+                rec0["wg_side_now"] = True
+            else:
+                rec0["inline_wg"] = True
             self._attach_deferred([rec0], [box_prediction])
         else:
             box_prediction = self.get_proposal_box_predictions_refine(
