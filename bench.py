@@ -958,6 +958,12 @@ def launch_check(a):
 
 
 def main():
+    # a run that is still going after VDETR_BENCH_WATCHDOG seconds (default 900) prints every thread's Python stack to stderr: where a
+    # hung run hangs (round 6 saw two `--config c5` runs out of ~25 sit forever without a line of output)
+    import faulthandler
+    wd = float(os.environ.get("VDETR_BENCH_WATCHDOG", "900"))
+    if wd > 0:
+        faulthandler.dump_traceback_later(wd, repeat=False, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

@@ -37,6 +37,11 @@ def _ptr_batchable(group):
     if not PTR_BATCH or len(group) > 256 or len(group) < 8:
         return False  # (few items: the copies are small, and the library's pick for a batch of 2 with K = 4096 measured 90 us slower)
     g0, x0 = group[0][2], group[0][3]
+    if g0.shape[0] > 1024:
+        # MEASURED: with 4096-row items (BASELINE config 5: four scenes) rocblas_sgemm_batched never returns — the GPU hangs in the
+        # eager warm-up already (tools/probes/job_r6_c5_bisect.sh); the shapes of the one-scene configurations (1024 rows, 64 / 40
+        # items) run in every test and bench of the round.  Longer contractions keep the stacked operands and torch.bmm.
+        return False
     if not (g0.is_cuda and g0.dtype == torch.float32 and x0.dtype == torch.float32 and g0.shape[1] % 4 == 0):
         return False
     for it in group:
