@@ -36,6 +36,8 @@ def _ptr_batchable(group):
     """items (w, b, dY [rows, out], X [rows, in]) whose operands rocblas_sgemm_batched / vdetr_colsum_ptrs_f32 can read in place"""
     if not PTR_BATCH or len(group) > 256 or len(group) < 8:
         return False  # (few items: the copies are small, and the library's pick for a batch of 2 with K = 4096 measured 90 us slower)
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return False  # (data-parallel steps flush in phases: other batch counts than the ones measured; see the note on 4096 rows below)
     g0, x0 = group[0][2], group[0][3]
     if g0.shape[0] > 1024:
         # MEASURED: with 4096-row items (BASELINE config 5: four scenes) rocblas_sgemm_batched never returns — the GPU hangs in the
