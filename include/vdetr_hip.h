@@ -655,6 +655,15 @@ int vdetr_pack_sumsq_f32(const vdetr_pack_entry* entries, const uint32_t* block_
                          float* dst, float* sumsq, vdetr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * The RPE tables of n cpb MLPs (Linear(3, hidden) -> ReLU -> Linear(hidden, 4, bias=False); models/vdetr_transformer.py:725 evaluates
+ * eight of them per cross-attention layer on the T^3 grid) in one launch (csrc/cpb_tables.hip).
+ *   coords [P,3]; w1 [n,hidden,3]; b1 [n,hidden]; w2 [n,4,hidden]  ->  hid_out [n,P,hidden] = relu(coords w1^T + b1) (what the tables'
+ *   backward reads), tables [n,P,4] = hid_out w2^T.  hidden a multiple of 16, <= 256.
+ * ---------------------------------------------------------------------------------------------- */
+int vdetr_cpb_tables_f32(const float* coords, const float* w1, const float* b1, const float* w2, int n, int P, int hidden, int H,
+                         float* hid_out, float* tables, vdetr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Gradient-norm clipping + AdamW on a flat parameter buffer, one launch (csrc/optim.hip).
  * Reference: engine.py:105-107 (clip_grad_norm_ then optimizer.step()), optimizer.py:6-26 (torch.optim.AdamW; amsgrad off).
  *   p -= lr wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)

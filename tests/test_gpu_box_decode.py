@@ -149,3 +149,28 @@ def test_gather_proposals_launch_equals_the_gathers(B, N, nq, camera):
     assert torch.equal(ang, take(pred["angle_continuous"]))
     assert torch.equal(cn, take(pred["center_normalized"])) and torch.equal(sn, take(pred["size_normalized"]))
     assert torch.equal(qref, torch.cat((center, size), -1))
+
+
+@pytest.mark.parametrize("n,hidden,T", [(64, 128, 10), (8, 128, 10), (3, 48, 7), (1, 256, 4)])
+def test_cpb_tables_launch_equals_the_mlps(n, hidden, T):
+    """vdetr_cpb_tables_f32 (the RPE tables of n cpb MLPs in one launch, csrc/cpb_tables.hip) against Linear -> ReLU -> Linear in fp64:
+    the hidden activations (what the tables' backward reads) and the tables"""
+    from vdetr_amd import _lib as L
+    g = torch.Generator().manual_seed(n * 1000 + hidden)
+    lin = torch.linspace(-4.0, 4.0, T)
+    coords = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), dim=-1).reshape(-1, 3).contiguous().to(DEV)
+    w1 = torch.randn((n, hidden, 3), generator=g).to(DEV)
+    b1 = torch.randn((n, hidden), generator=g).to(DEV)
+    w2 = (torch.randn((n, 4, hidden), generator=g) / hidden ** 0.5).to(DEV)
+    P = coords.shape[0]
+    hid = torch.full((n, P, hidden), float("nan"), device=DEV)
+    tab = torch.full((n, P, 4), float("nan"), device=DEV)
+    L.check(L.lib().vdetr_cpb_tables_f32(L.ptr(coords), L.ptr(w1), L.ptr(b1), L.ptr(w2), n, P, hidden, 4, L.ptr(hid), L.ptr(tab), L.stream_ptr()),
+            "cpb_tables")
+    want_h = torch.relu(torch.einsum("pc,nhc->nph", coords.double(), w1.double()) + b1.double()[:, None, :])
+    want_t = torch.einsum("nph,nkh->npk", want_h, w2.double())
+    np.testing.assert_allclose(hid.cpu().numpy(), want_h.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tab.cpu().numpy(), want_t.cpu().numpy(), rtol=1e-5, atol=2e-5 * float(want_t.abs().max()))
+    lib = L.lib()
+    assert lib.vdetr_cpb_tables_f32(L.ptr(coords), L.ptr(w1), L.ptr(b1), L.ptr(w2), n, P, 100, 4, L.ptr(hid), L.ptr(tab), L.stream_ptr()) != 0
+    assert b"hidden" in lib.vdetr_last_error()

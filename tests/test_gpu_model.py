@@ -391,6 +391,10 @@ def test_deferred_weight_gradients_equal_inline_ones(batch, monkeypatch):
     # deferred gradients, and its batch statistics differ from the three-launch form's in the last bits — which this model's ReLU
     # gates amplify past the 2e-4 this comparison of two backward SCHEDULES asserts (measured 2.9e-4 on one parameter)
     monkeypatch.setattr(HD, "FUSED_POS", False)
+    # (likewise the RPE tables: one launch with deferred gradients, csrc/cpb_tables.hip — its own test in test_gpu_box_decode.py —, two
+    #  batched GEMMs without: the same values up to the summation order; measured here with it on: 1.2e-2 on one parameter)
+    import vdetr_amd.vdetr_transformer as T
+    monkeypatch.setattr(T, "_CPB_FUSED", False)
     model = _make_model(nq=64, npre=512, nl=4).to(DEV).train()
     inp = _inputs(3000, 5, DEV, batch)
     model(inp)
@@ -424,13 +428,17 @@ def test_deferred_weight_gradients_equal_inline_ones(batch, monkeypatch):
 
 
 @pytest.mark.parametrize("defer", [True, False])
-def test_side_stream_table_gradient_equals_the_inline_one(defer):
-    """attention.set_async_table_grad("1"): the RPE-table gradient of every decoder layer on a side stream over 192 of the
+def test_side_stream_table_gradient_equals_the_inline_one(defer, monkeypatch):
+    """(The RPE tables themselves by the two batched GEMMs on both sides: the one-launch form, csrc/cpb_tables.hip, exists only where the
+    tables' backward is parked and sums in another order.)
+    attention.set_async_table_grad("1"): the RPE-table gradient of every decoder layer on a side stream over 192 of the
     256 CUs, joined behind the layers' backward (`join_table_grad`) or, with parked weight gradients, behind the flush
     (`DeferredTableGrads`: the cpb MLPs' own backward runs there) — against the in-line launches ("0"): every gradient but
     the cpb MLPs' bit-identical, theirs within the rounding of the histogram's fixed-point scale (it follows the grid)."""
     from vdetr_amd import attention as A
     from vdetr_amd.runtime import defer_weight_grads, flush_weight_grads
+    import vdetr_amd.vdetr_transformer as T
+    monkeypatch.setattr(T, "_CPB_FUSED", False)
     model = _make_model(nq=64, npre=512, nl=4).to(DEV).train()
     inp = _inputs(3000, 5, DEV, 1)
     model(inp)

@@ -338,6 +338,7 @@ _SIGNATURES = {
     "vdetr_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "vdetr_pack_sumsq_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vdetr_adamw_clip_f32": (c_int, [ctypes.POINTER(AdamWDesc), c_void_p]),
+    "vdetr_cpb_tables_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 3),
     "vdetr_sumsq_blocks": (c_int, [ctypes.c_long]),
     "vdetr_sumsq_f32": (c_int, [c_void_p, ctypes.c_long, c_void_p, c_int, c_void_p]),
     "vdetr_gt_prepare_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -757,12 +757,12 @@ class _FusedAttention(Function):
             ctx.save_for_backward(q, k, v, table, vertices, xyz, cos_sin, mask, out, lse, scores, rng)
             ctx.cfg = (kind, H, scale, rpe, dropout_p if use_drop else 0.0, salt)
             ctx.kv_rec = None if (bf16 or mask is not None) else _kv_register(out, q, v, table, vertices, cos_sin, kind, B, H, nQ, nK)
-        if _kv_by_out and getattr(ctx, "kv_rec", None) is None:
-            _kv_by_out.pop(out.data_ptr(), None)  # (a record an earlier call left under this address, never taken: not this output's)
             ctx.table_async = bool(table_async)
             ctx.boxes = bool(boxes)
             if table_async and table is not None and table.requires_grad and _async_wanted(q.shape[0], q.shape[1], k.shape[1]):
                 _step_side[_dev_key(q.device)] = True
+        if _kv_by_out and getattr(ctx, "kv_rec", None) is None:
+            _kv_by_out.pop(out.data_ptr(), None)  # (a record an earlier call left under this address, never taken: not this output's)
         return out
 
     @staticmethod

@@ -210,6 +210,29 @@ class GlobalShareCrossAttention(nn.Module):
         return torch.relu(torch.bmm(c1.unsqueeze(0).expand(n, -1, -1), w1b.transpose(1, 2)))
 
     @staticmethod
+    def _cpb_fused(mod, w1, b1, w2, n):
+        """(relu(coords W1^T + b1) [n, T^3, hid], tables [n, T^3, H]) of n cpb MLPs by vdetr_cpb_tables_f32, or None where the launch
+        does not apply (not on the GPU, other widths); leaves mod._coords1 (the tables' backward reads it) as _cpb_hidden does"""
+        if not (_CPB_FUSED and w1.is_cuda and w1.dtype == torch.float32 and w2.shape[1] == 4 and w1.shape[1] % 16 == 0 and w1.shape[1] <= 256
+                and w1.is_contiguous() and b1.is_contiguous() and w2.is_contiguous()):
+            return None
+        tab = mod.relative_coords_table
+        c1 = mod.__dict__.get("_coords1")
+        if c1 is None or c1.device != tab.device or c1.dtype != tab.dtype:
+            flat = tab.reshape(-1, 3)
+            c1 = mod.__dict__["_coords1"] = torch.cat((flat, torch.ones_like(flat[:, :1])), dim=1)  # [T^3, 4]
+        coords = mod.__dict__.get("_coords3")
+        if coords is None or coords.device != tab.device:
+            coords = mod.__dict__["_coords3"] = tab.reshape(-1, 3).contiguous()
+        P, hidden = coords.shape[0], w1.shape[1]
+        hid = torch.empty((n, P, hidden), dtype=torch.float32, device=w1.device)
+        tables = torch.empty((n, P, 4), dtype=torch.float32, device=w1.device)
+        from . import _lib as L
+        L.check(L.lib().vdetr_cpb_tables_f32(L.ptr(coords), L.ptr(w1), L.ptr(b1), L.ptr(w2), n, P, hidden, 4, L.ptr(hid), L.ptr(tables),
+                                             L.stream_ptr()), "cpb_tables")
+        return hid, tables
+
+    @staticmethod
     def precompute(mods, key):
         """K, V and RPE tables of SEVERAL cross-attention modules that see the same ``key`` [nK,B,C] (the decoder layers
         all attend to the same encoder features): one [C -> n*128] projection GEMM instead of 2n small ones, and the
@@ -238,8 +261,13 @@ class GlobalShareCrossAttention(nn.Module):
         # table kernel ON that stream, next to the flush
         if A.table_grads_parkable(w1) and os.environ.get("VDETR_BWD_ASYNC_MLP", "1") != "0":
             with torch.no_grad():
-                hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
-                tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H)
+                fused = GlobalShareCrossAttention._cpb_fused(mods[0], w1, b1, w2, 8 * n)
+                if fused is not None:  # hidden activations + tables of all 8 n MLPs in one launch (csrc/cpb_tables.hip)
+                    hid, tables = fused
+                    tables = tables.view(n, 8, T, T, T, H)
+                else:
+                    hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
+                    tables = torch.bmm(hid, w2.transpose(1, 2)).view(n, 8, T, T, T, H)
             tables = A.park_table_grads(tables, mlp=(mods[0].__dict__["_coords1"], w1, b1, w2, hid))
         else:
             hid = GlobalShareCrossAttention._cpb_hidden(mods[0], w1, b1, 8 * n)
@@ -581,6 +609,7 @@ class FFNLayer(nn.Module):
 # decoder
 # =====================================================================================================
 _DEFER_HEADS = os.environ.get("VDETR_DEFER_HEADS", "1") != "0"  # A/B switch (read once)
+_CPB_FUSED = os.environ.get("VDETR_CPB_FUSED", "1") != "0"       # the RPE tables' MLPs as one launch (csrc/cpb_tables.hip)
 _STAGE0_WG_SIDE = os.environ.get("VDETR_STAGE0_WG", "inline") == "side"
 _DEFER_STAGE0 = os.environ.get("VDETR_DEFER_STAGE0", "1") != "0"  # the first stage's heads recorded too (round 6; A/B switch)
 # the heads' weight gradients on the side branch (VDETR_HEADS_SIDE): 1 = at once, at the BEGINNING of the backward, where the branch
