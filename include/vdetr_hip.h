@@ -566,6 +566,12 @@ typedef struct vdetr_rb_ffn_grads {
   float *part_post, *part_n3;       /* [ceil(rows/16)][4][256]: post1 / post2; norm3 (rows 0-1) */
 } vdetr_rb_ffn_grads;
 int vdetr_rb_ffn_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream);
+/* The FFN layer in front of the decoder (models/vdetr_transformer.py:585-606, FFNLayer.forward_pre) as one launch forward, one backward:
+ *   t2 = norm3(tgt);  h = drop_act(relu(lin1 t2));  z = t2 + drop3(lin2 h);  o1 = post1(z) [, o2 = post2(z)]
+ * in the descriptor of vdetr_rb_ffn_f32 (a, proj, y, drop2 unused forward; backward: y = the layer's input rows, mean_y / rstd_y the
+ * statistics the forward left; g->d_tgt = the input's gradient, g->d_a / d_proj unused). */
+int vdetr_rb_ffn0_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t stream);
+int vdetr_rb_ffn0_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream);
 /* the two backward launches that produce an attention's output gradient, leaving its packed form behind as well (see
  * vdetr_attn_bwd_kv_packed_f32): d->B = 1, d->rows = e->nQ a multiple of 32, g->d_a required */
 int vdetr_rb_ffn_bwd_emit_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, const vdetr_rb_attn_emit* e, vdetr_stream_t stream);

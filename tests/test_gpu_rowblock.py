@@ -385,3 +385,45 @@ def test_fused_layer_parks_weight_gradients(monkeypatch):
             assert a is None, n
         else:
             _close(a, b, n, floor=_floor(n, all_names, ref))
+
+
+@pytest.mark.parametrize("n,B,train", [(4096, 1, True), (512, 2, True), (100, 3, True), (64, 1, False)])
+def test_first_layer_ffn_as_one_launch_equals_its_composition(monkeypatch, n, B, train):
+    """FFNLayer.forward_pre + the decoder's norm on its output through vdetr_rb_ffn0_f32 / _bwd_f32 (one launch each) against the five /
+    seven launches they replace: output, normed output, the input's and every parameter's gradient (same dropout streams)."""
+    from vdetr_amd import attention as A
+    from vdetr_amd import rowblock as RB
+    from vdetr_amd.vdetr_transformer import FFNLayer
+    from oracle.param_fill import fill_module
+    torch.manual_seed(3)
+    layer = FFNLayer(256, dim_feedforward=256, dropout=0.1)
+    fill_module(layer)
+    layer = layer.to(DEV).train(train)
+    post = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        post.weight.add_(0.2 * torch.randn(256, device=DEV)); post.bias.add_(0.1 * torch.randn(256, device=DEV))
+        layer.norm.weight.add_(0.2 * torch.randn(256, device=DEV)); layer.norm.bias.add_(0.1 * torch.randn(256, device=DEV))
+    g = torch.Generator().manual_seed(n + B)
+    x0 = torch.randn((n, B, 256), generator=g).to(DEV)
+    wts = [torch.randn((n, B, 256), generator=g).to(DEV) for _ in range(2)]
+    params = list(layer.parameters()) + list(post.parameters())
+    names = [k for k, _ in layer.named_parameters()] + ["post.weight", "post.bias"]
+
+    def run(fused):
+        monkeypatch.setattr(RB, "FUSED_FFN0", fused)
+        A.reset_rng()
+        for p in params:
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        layer.post_norm = post
+        out = layer(x)
+        normed = layer.post_normed
+        layer.post_norm = layer.post_normed = None
+        ((out * wts[0]).sum() + (normed * wts[1]).sum()).backward()
+        return [out, normed, x.grad] + [p.grad for p in params]
+
+    ref = run(False)
+    got = run(True)
+    for k, a, b in zip(["out", "norm(out)", "d x"] + names, got, ref):
+        _close(a, b, k)
+    assert torch.equal(run(True)[0], got[0])

@@ -370,6 +370,8 @@ _SIGNATURES = {
     "vdetr_rb_qkv_bwd_f32": (c_int, [ctypes.POINTER(RbQkvDesc), ctypes.POINTER(RbQkvGrads), c_void_p]),
     "vdetr_rb_proj_q_bwd_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), c_void_p]),
     "vdetr_rb_ffn_bwd_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), c_void_p]),
+    "vdetr_rb_ffn0_f32": (c_int, [ctypes.POINTER(RbFfnDesc), c_void_p]),
+    "vdetr_rb_ffn0_bwd_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), c_void_p]),
     "vdetr_rb_ffn_bwd_emit_f32": (c_int, [ctypes.POINTER(RbFfnDesc), ctypes.POINTER(RbFfnGrads), ctypes.POINTER(RbAttnEmit), c_void_p]),
     "vdetr_rb_proj_q_bwd_emit_f32": (c_int, [ctypes.POINTER(RbProjQDesc), ctypes.POINTER(RbProjQGrads), ctypes.POINTER(RbAttnEmit), c_void_p]),
     "vdetr_attn_bwd_kv_prep_f32": (c_int, [ctypes.POINTER(AttnKvPrep), c_int, c_void_p]),

@@ -40,7 +40,10 @@ typedef vdetr_rb_drop RbDropArgs;
 // its first weight steps requested before the epilogue in between runs.
 typedef vdetr_rb_ffn_desc RbFfnArgs;
 
-// PARTS: -1 = the rows of A.a; >= 0: the merge of key-split partials (rb_stage_parts<PARTS>)
+// PARTS: -1 = the rows of A.a; >= 0: the merge of key-split partials (rb_stage_parts<PARTS>);
+// -2 = the FFN layer in front of the decoder (reference :585-606, FFNLayer.forward_pre): no attention branch — t2 = norm3(tgt) is BOTH the
+//      FFN's input and its residual: z = t2 + drop3(lin2(drop(relu(lin1 t2)))), o1 = post1(z); A.a, A.proj, A.y are not used
+//      (the step's first stage ran these 4096 tokens through five launches of 5-12 us forward and seven backward)
 template <int PARTS>
 __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A, RbParts Pp) {
   __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
@@ -57,9 +60,10 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A, RbParts
   f32x4 y[4];  // the residual stream of this lane's rows 4 g + r, columns colq ..
   float mean[4], rstd[4];
   RbRing R;
-  rb_w_begin(A.proj.wt, col0, lane, R);
+  constexpr bool kFfn0 = PARTS == -2;
+  rb_w_begin(kFfn0 ? A.lin1.wt : A.proj.wt, col0, lane, R);
   const bool two = A.post2.gamma != nullptr;
-  const f32x4 bias_p = rb_ldv(A.proj.b, colq), bias_1 = rb_ldv(A.lin1.b, colq), bias_2 = rb_ldv(A.lin2.b, colq);
+  const f32x4 bias_p = rb_ldv(kFfn0 ? nullptr : A.proj.b, colq), bias_1 = rb_ldv(A.lin1.b, colq), bias_2 = rb_ldv(A.lin2.b, colq);
   const f32x4 ga3 = rb_ldv(A.norm3.gamma, colq), be3 = rb_ldv(A.norm3.beta, colq);
   const f32x4 gap = rb_ldv(A.post1.gamma, colq), bep = rb_ldv(A.post1.beta, colq);
   const f32x4 gap2 = rb_ldv(A.post2.gamma, colq), bep2 = rb_ldv(A.post2.beta, colq);
@@ -67,23 +71,28 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A, RbParts
 #pragma unroll
   for (int r = 0; r < 4; ++r) tg[r] = rb_ld4(A.tgt, min(row0 + 4 * g + r, A.rows - 1), colq);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (PARTS < 0) rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
-  else rb_stage_parts<PARTS>(Pp, row0, A.rows, A.B, xs, tid);
-  __syncthreads();
-  rb_load_a(xs, lane, a);
-  rb_zero(acc);
-  rb_w_run(a, A.proj.wt, col0, lane, R, acc);
-  rb_w_begin(A.lin1.wt, col0, lane, R);
+  if constexpr (kFfn0) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
-    f32x4 v = rb_row(acc, r) + bias_p;
-    bool keep[4];
-    rb_keep4_ln(d2, rowc, colq >> 2, keep);
+    for (int r = 0; r < 4; ++r) y[r] = tg[r];
+  } else {
+    if constexpr (PARTS < 0) rb_stage_rows(A.a, row0, A.rows, A.B, true, xs, tid);
+    else rb_stage_parts<PARTS>(Pp, row0, A.rows, A.B, xs, tid);
+    __syncthreads();
+    rb_load_a(xs, lane, a);
+    rb_zero(acc);
+    rb_w_run(a, A.proj.wt, col0, lane, R, acc);
+    rb_w_begin(A.lin1.wt, col0, lane, R);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = tg[r][e] + (keep[e] ? v[e] * d2.scale : 0.f);
-    y[r] = v;
-    if (row < A.rows) rb_st4(A.y, row, colq, v);
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * g + r, rowc = min(row, A.rows - 1);
+      f32x4 v = rb_row(acc, r) + bias_p;
+      bool keep[4];
+      rb_keep4_ln(d2, rowc, colq >> 2, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tg[r][e] + (keep[e] ? v[e] * d2.scale : 0.f);
+      y[r] = v;
+      if (row < A.rows) rb_st4(A.y, row, colq, v);
+    }
   }
   rb_row_stats(y, red, w, lane, A.norm3.eps, mean, rstd);  // (its barriers also fence the reads of xs above)
 #pragma unroll
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_kernel(RbFfnArgs A, RbParts
       rb_st4(A.t2, row, colq, o);
       if (w == 0 && c == 0) { A.mean_y[row] = mean[r]; A.rstd_y[row] = rstd[r]; }
     }
+    if constexpr (kFfn0) y[r] = o;  // (the residual of the FFN is the NORMED input)
   }
   __syncthreads();
   rb_load_a(xs, lane, a);
@@ -341,7 +351,8 @@ __device__ __forceinline__ void rb_ln_bwd(const f32x4 (&yv)[4], const f32x4 (&go
 
 // ---- rb_ffn_bwd_kernel ---------------------------------------------------------------------------------------------------------------
 // EMIT: the packed form of d a for the key-side pass of the attention that produced a (kv_pack.h)
-template <bool EMIT>
+// FFN0: the backward of rb_ffn_kernel<-2> (A.y = the layer's INPUT rows with mean_y / rstd_y their statistics; d_tgt = its gradient)
+template <bool EMIT, bool FFN0 = false>
 __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_desc A, vdetr_rb_ffn_grads G, KvEmit E) {
   __shared__ __attribute__((aligned(16))) float xs[kRbRows * kRbStride];
   __shared__ float red[128];
@@ -410,18 +421,24 @@ __global__ __launch_bounds__(kRbThreads) void rb_ffn_bwd_kernel(vdetr_rb_ffn_des
   rb_load_a(xs, lane, a);
   rb_zero(acc);
   rb_w_run(a, A.lin1.w, col0, lane, R, acc);  // d t2
-  rb_w_begin(A.proj.w, col0, lane, R);
-  // block 2 backward: y = tgt + drop2(proj a); t2 = norm3(y)
+  if constexpr (!FFN0) rb_w_begin(A.proj.w, col0, lane, R);
+  // block 2 backward: y = tgt + drop2(proj a); t2 = norm3(y)   (FFN0: t2 = norm3(x) feeds lin1 AND the residual: d t2 = both)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     mean[r] = mean2[r]; rstd[r] = rstd2[r];
     yv[r] = yv2[r];
-    go[r] = rb_row(acc, r);
+    go[r] = FFN0 ? rb_row(acc, r) + dy[r] : rb_row(acc, r);
     go2[r] = zero;
-    din[r] = dy[r];
+    din[r] = FFN0 ? zero : dy[r];
   }
   rb_ln_bwd(yv, go, go2, false, din, mean, rstd, live, A.norm3.gamma, nullptr, colq, red, G.part_n3 + (size_t)blockIdx.x * 4 * kRbC, w, lane, dy);
   // (rb_ln_bwd's barriers: every wave is past its reads of xs)
+  if constexpr (FFN0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (live[r]) rb_st4(G.d_tgt, rowc[r], colq, dy[r]);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (live[r]) rb_st4(G.d_tgt, rowc[r], colq, dy[r]);
@@ -627,6 +644,44 @@ extern "C" int vdetr_rb_ffn_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t strea
                 "rb_ffn: operands must be 16-B aligned");
   hipLaunchKernelGGL(rb_ffn_kernel<-1>, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, RbParts{});
   return check_launch("rb_ffn");
+}
+
+// the FFN layer in front of the decoder (rb_ffn_kernel<-2>): d->tgt = its input rows, norm3 = its norm, post1 (post2) = the norms applied
+// to its output; d->a, d->proj, d->y, d->drop2 are not used
+static int rb_ffn0_check(const vdetr_rb_ffn_desc* d, const char* op) {
+  VDETR_REQUIRE(d != nullptr, "%s: null descriptor", op);
+  if (int e = rb_common(d->rows, d->B, op)) return e;
+  VDETR_REQUIRE(d->norm3.gamma && d->post1.gamma && d->mean_y && d->rstd_y && d->h && d->z && d->mean_z && d->rstd_z, "%s: null pointer", op);
+  for (const vdetr_rb_drop* dr : {&d->drop_act, &d->drop3})
+    VDETR_REQUIRE(dr->p >= 0.f && dr->p < 1.f, "%s: dropout_p %f outside [0,1)", op, dr->p);
+  return VDETR_OK;
+}
+
+extern "C" int vdetr_rb_ffn0_f32(const vdetr_rb_ffn_desc* d, vdetr_stream_t stream) {
+  if (int e = rb_ffn0_check(d, "rb_ffn0")) return e;
+  VDETR_REQUIRE(d->tgt && d->lin1.wt && d->lin2.wt && d->norm3.beta && d->post1.beta && d->t2 && d->o1,
+                "rb_ffn0: null pointer (lin1.wt / lin2.wt: the W^T images, vdetr_rb_transpose_f32)");
+  VDETR_REQUIRE((d->post2.gamma == nullptr) == (d->post2.beta == nullptr) && (d->post2.gamma == nullptr) == (d->o2 == nullptr),
+                "rb_ffn0: post2.gamma, post2.beta and o2 go together");
+  VDETR_REQUIRE(RB_ALIGNED(d->tgt) && RB_ALIGNED(d->lin1.wt) && RB_ALIGNED(d->lin1.b) && RB_ALIGNED(d->lin2.wt) && RB_ALIGNED(d->lin2.b) &&
+                RB_ALIGNED(d->norm3.gamma) && RB_ALIGNED(d->norm3.beta) && RB_ALIGNED(d->post1.gamma) && RB_ALIGNED(d->post1.beta) &&
+                RB_ALIGNED(d->post2.gamma) && RB_ALIGNED(d->post2.beta) && RB_ALIGNED(d->t2) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) &&
+                RB_ALIGNED(d->o1) && RB_ALIGNED(d->o2), "rb_ffn0: operands must be 16-B aligned");
+  hipLaunchKernelGGL(rb_ffn_kernel<-2>, dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, RbParts{});
+  return check_launch("rb_ffn0");
+}
+
+extern "C" int vdetr_rb_ffn0_bwd_f32(const vdetr_rb_ffn_desc* d, const vdetr_rb_ffn_grads* g, vdetr_stream_t stream) {
+  if (int e = rb_ffn0_check(d, "rb_ffn0_bwd")) return e;
+  VDETR_REQUIRE(g != nullptr && d->y && d->lin1.w && d->lin2.w && g->d_tgt && g->d_lin2 && g->d_lin1 && g->part_post && g->part_n3 &&
+                (g->d_z || g->d_o1 || g->d_o2), "rb_ffn0_bwd: null pointer (d->y = the layer's input rows)");
+  VDETR_REQUIRE(!g->d_o2 || d->post2.gamma, "rb_ffn0_bwd: d_o2 without a second output norm");
+  VDETR_REQUIRE(RB_ALIGNED(d->y) && RB_ALIGNED(d->lin1.w) && RB_ALIGNED(d->lin2.w) && RB_ALIGNED(d->norm3.gamma) && RB_ALIGNED(d->post1.gamma) &&
+                RB_ALIGNED(d->post2.gamma) && RB_ALIGNED(d->h) && RB_ALIGNED(d->z) && RB_ALIGNED(g->d_z) && RB_ALIGNED(g->d_o1) && RB_ALIGNED(g->d_o2) &&
+                RB_ALIGNED(g->d_tgt) && RB_ALIGNED(g->d_lin2) && RB_ALIGNED(g->d_lin1) && RB_ALIGNED(g->part_post) && RB_ALIGNED(g->part_n3),
+                "rb_ffn0_bwd: operands must be 16-B aligned");
+  hipLaunchKernelGGL((rb_ffn_bwd_kernel<false, true>), dim3(ceil_div(d->rows, kRbRows)), dim3(kRbThreads), 0, (hipStream_t)stream, *d, *g, KvEmit{});
+  return check_launch("rb_ffn0_bwd");
 }
 
 extern "C" int vdetr_rb_ffn_parts_f32(const vdetr_rb_ffn_desc* d, const vdetr_attn_parts* parts, float* attn_out, float* attn_lse,

@@ -86,6 +86,9 @@ def decoder_refresh(decoder):
                 ws += [l[0].weight for l in Ls] + [l[4].weight for l in Ls]
         if FUSED_POS:
             ws += [m.position_embedding_head[3].weight for m in decoder.query_pos_projection]
+        fl = getattr(decoder, "first_layer", None)  # (rowblock.ffn0: the FFN layer in front of the decoder reads two images too)
+        if fl is not None and hasattr(fl, "linear1") and hasattr(fl, "linear2"):
+            ws += [fl.linear1.weight, fl.linear2.weight]
     except (AttributeError, IndexError, KeyError):
         return False
     ws = [w for w in ws if _ok_weight(w)]

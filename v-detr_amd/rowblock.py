@@ -152,6 +152,9 @@ def _check(*ts):
             raise RuntimeError("rowblock operands must be contiguous and 16-B aligned")
 
 
+FUSED_FFN0 = os.environ.get("VDETR_FFN0_FUSED", "1") != "0"
+
+
 def _emit_for(rec, a, d_a, rows, B, per_head):
     """the vdetr_rb_attn_emit of a backward launch that produces d_a = the output gradient of the attention call `rec` (whose forward
     output is `a`), or None where the call does not qualify (attention.py: the key-side pass without its packing launch)"""
@@ -472,7 +475,100 @@ class _Ffn(torch.autograd.Function):
         return (d_a, d_tgt.view(shape), gwp, gbp, gw1, gb1, gw2, gb2, dg3, db3, dgp1, dbp1, dgp2, dbp2) + (None,) * 13
 
 
+class _Ffn0(torch.autograd.Function):
+    """FFNLayer.forward_pre (the light layer in front of the decoder, reference :585-606) as one launch forward and one backward
+    (vdetr_rb_ffn0_f32): t2 = norm(x); z = t2 + drop(lin2(drop(relu(lin1 t2)))); o1 = post_norm(z).  Same dropout streams as the
+    composition it replaces (bn_act.relu_dropout / add_ln.add_dropout_layer_norm with the same salts)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, g, be, gp, bep, eps, epsp, pa, salta, p3, salt3, rng, w1t, w2t):
+        _check(x, w1, b1, w2, b2, g, be, gp, bep, w1t, w2t)
+        rows = x.numel() // C
+        dev = x.device
+        new = lambda: torch.empty_like(x)
+        t2, h, z, o1 = new(), new(), new(), new()
+        stats = torch.empty((4, rows), dtype=torch.float32, device=dev)
+        use_rng = rng is not None and (pa > 0 or p3 > 0)
+        d = L.RbFfnDesc()
+        d.rows, d.B = rows, x.shape[1] if x.dim() == 3 else 1
+        d.rng_state = rng.data_ptr() if use_rng else None
+        d.tgt = x.data_ptr()
+        _lin(d.lin1, w1, b1, w1t)
+        _lin(d.lin2, w2, b2, w2t)
+        _drop(d.drop_act, pa, salta)
+        _drop(d.drop3, p3, salt3)
+        _norm(d.norm3, g, be, eps)
+        _norm(d.post1, gp, bep, epsp)
+        d.mean_y, d.rstd_y, d.t2 = stats[0].data_ptr(), stats[1].data_ptr(), t2.data_ptr()
+        d.h = h.data_ptr()
+        d.z, d.mean_z, d.rstd_z, d.o1 = z.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), o1.data_ptr()
+        L.check(L.lib().vdetr_rb_ffn0_f32(ctypes.byref(d), L.stream_ptr()), "rb_ffn0")
+        ctx.cfg = (rows, float(eps), float(epsp), float(pa), float(p3), salt3, d.B, x.shape)
+        ctx.ln = (g, be, None, None)
+        ctx.lnp = (gp, bep, None, None)
+        ctx.save_for_backward(x, t2, h, z, stats, w1, b1, w2, b2, g, gp, rng if use_rng else None)
+        ctx.set_materialize_grads(False)
+        return z, o1
+
+    @staticmethod
+    def backward(ctx, d_z, d_o1):
+        rows, eps, epsp, pa, p3, salt3, B, shape = ctx.cfg
+        x, t2, h, z, stats, w1, b1, w2, b2, g, gp, rng = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if d_z is None and d_o1 is None:
+            return (None,) * 18
+        dev = x.device
+        d_z, d_o1 = _opt(d_z), _opt(d_o1)
+        nblk = (rows + 15) // 16
+        new = lambda: torch.empty((rows, C), dtype=torch.float32, device=dev)
+        d_x, d_lin2, d_lin1 = new(), new(), new()
+        parts = torch.empty((2, nblk, 4, C), dtype=torch.float32, device=dev)
+        d = L.RbFfnDesc()
+        d.rows, d.B = rows, B
+        d.rng_state = rng.data_ptr() if rng is not None else None
+        _lin(d.lin1, w1, None)
+        _lin(d.lin2, w2, None)
+        _drop(d.drop_act, pa, 0)
+        _drop(d.drop3, p3, salt3)
+        _norm(d.norm3, g, g, eps)
+        _norm(d.post1, gp, gp, epsp)
+        d.y, d.mean_y, d.rstd_y = x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
+        d.h, d.z, d.mean_z, d.rstd_z = h.data_ptr(), z.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr()
+        gr = L.RbFfnGrads()
+        gr.d_z = d_z.data_ptr() if d_z is not None else None
+        gr.d_o1 = d_o1.data_ptr() if d_o1 is not None else None
+        gr.d_tgt, gr.d_lin2, gr.d_lin1 = d_x.data_ptr(), d_lin2.data_ptr(), d_lin1.data_ptr()
+        gr.part_post, gr.part_n3 = parts[0].data_ptr(), parts[1].data_ptr()
+        L.check(L.lib().vdetr_rb_ffn0_bwd_f32(ctypes.byref(d), ctypes.byref(gr), L.stream_ptr()), "rb_ffn0_bwd")
+        gw2, gb2 = _park_or_grad(w2, b2, d_lin2, h.view(rows, C), need[3], need[4])
+        gw1, gb1 = _park_or_grad(w1, b1, d_lin1, t2.view(rows, C), need[1], need[2])
+        dgp, dbp, _, _ = _ln_sums(parts[0], nblk, ctx.lnp, False)
+        dg, db, _, _ = _ln_sums(parts[1], nblk, ctx.ln, False)
+        return (d_x.view(shape) if need[0] else None, gw1, gb1, gw2, gb2, dg, db, dgp, dbp) + (None,) * 9
+
+
 # ---- module-level entry points -----------------------------------------------------------------------------------------
+def ffn0_usable(layer, x):
+    """FFNLayer `layer` on x [n, B, 256] through vdetr_rb_ffn0_f32: fp32 on the GPU, 256 -> 256 -> 256 with biases, ReLU, plain LayerNorms
+    (the layer's own and the one the caller applies to its output), gradients on"""
+    return bool(FUSED_FFN0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] == C and layer.normalize_before
+                and layer.linear1.weight.shape == (C, C) and layer.linear2.weight.shape == (C, C) and layer.linear1.bias is not None
+                and layer.linear2.bias is not None and type(layer.activation) is torch.nn.ReLU and _plain_ln(layer.norm)
+                and layer.post_norm is not None and _plain_ln(layer.post_norm) and torch.is_grad_enabled())
+
+
+def ffn0(layer, x, act_salt, aln_salt):
+    """(z, post_norm(z)) of FFNLayer.forward_pre"""
+    pa = layer.dropout.p if layer.dropout.training else 0.0
+    w1, w2 = layer.linear1.weight, layer.linear2.weight
+    base = HD._images([w1, w2], HD._fresh["on"])  # ([2, 256, 256] freshly written, or the first of two adjacent images of this forward's refresh)
+    imgs = (base[0], base[1]) if base.dim() == 3 else (base, HD._current[w2.data_ptr()])
+    n, pn = layer.norm, layer.post_norm
+    return _Ffn0.apply(x.contiguous(), layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, n.weight, n.bias,
+                       pn.weight, pn.bias, n.eps, pn.eps, pa, act_salt, pa, aln_salt, _rng_for(pa, x.device), imgs[0], imgs[1])
+
+
+
 def _plain_ln(m):
     return ALN.supported(m) and m.normalized_shape[0] == C
 

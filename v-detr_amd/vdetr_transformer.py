@@ -590,6 +590,13 @@ class FFNLayer(nn.Module):
         if not ALN.supported(self.norm):
             memory = self.norm(memory)
             return memory + self.dropout(linear(self.dropout(self.activation(linear(memory, self.linear1.weight, self.linear1.bias))), self.linear2.weight, self.linear2.bias))
+        if RB.ffn0_usable(self, memory):  # the whole layer + the caller's output norm as ONE launch (csrc/rowblock.hip: rb_ffn_kernel<-2>)
+            if getattr(self, "_act_salt", None) is None:
+                self._act_salt = BNA.new_salt()
+            if self._aln_salt is None:
+                self._aln_salt = ALN.new_salt()
+            out, self.post_normed = RB.ffn0(self, memory, self._act_salt, self._aln_salt)
+            return out
         memory = ALN.layer_norm(memory, self.norm)
         branch = linear(_act_drop(self, linear(memory, self.linear1.weight, self.linear1.bias)), self.linear2.weight,
                         self.linear2.bias)
@@ -1110,12 +1117,13 @@ class TransformerDecoder(nn.Module):
         fuse_ln = ALN.supported(self.norm) and isinstance(self.first_layer, FFNLayer) and \
             ALN.supported(self.first_layer.norm, self.norm)
         self.first_layer.post_norm = self.norm if fuse_ln else None
+        defer = _DEFER_HEADS and self.mlp_sep and self.return_intermediate and len(self.layers) > 1
+        if defer and self.training and enc_box_features.is_cuda and torch.is_grad_enabled():
+            # the W^T images of every stage's heads, of the position MLPs and of the first layer's FFN: one launch (heads.py)
+            HD.decoder_refresh(self)
         output = self.first_layer(enc_box_features)
         normed = self.first_layer.post_normed if fuse_ln else self.norm(output)
         self.first_layer.post_norm = self.first_layer.post_normed = None
-        defer = _DEFER_HEADS and self.mlp_sep and self.return_intermediate and len(self.layers) > 1
-        if defer and self.training and output.is_cuda and torch.is_grad_enabled():
-            HD.decoder_refresh(self)  # the W^T images of every stage's heads and of the position MLPs: one launch (heads.py)
         # the first stage's heads on all encoder tokens: recorded like the later stages' (the fused launches of csrc/heads.hip where
         # the shapes fit) and differentiated by a _DeferredHeads node of its own — the last thing the backward pass reaches
         recorded = self._stage_recorded(0, point_cloud_dims, normed, enc_box_predictions["center_normalized"],
