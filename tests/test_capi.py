@@ -141,3 +141,39 @@ def test_build_rejects_the_packed_multiply_form_of_design_4_4b():
     assert not b._hi_broadcast(" v[0:1], v[2:3], v[4:5] op_sel:[1,0]")                  # first source: covered by parity tests
     assert not b._hi_broadcast(" v[0:1], v[2:3], v[4:5]")
     assert b.check_code_objects(b.build()) >= 15  # every .hip of the library is a code object, none has the form
+
+
+def test_every_ctypes_mirror_has_the_headers_layout(tmp_path):
+    """include/vdetr_hip.h compiled by gcc: sizeof and the offset of every field of every struct that v-detr_amd/_lib.py mirrors
+    (the class's docstring names it) — a descriptor that drifts from its mirror is a launch reading garbage, on the GPU only."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    from vdetr_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = open(_lib.__file__).read()
+    pairs = re.findall(r'class (\w+)\(ctypes\.Structure\):\n\s+"""Mirror of ``(\w+)``', src)
+    assert len(pairs) >= 28
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vdetr_hip.h"', 'int main(void) {']
+    want = []
+    for cls_name, c_name in pairs:
+        cls = getattr(_lib, cls_name)
+        lines.append(f'  printf("%zu\\n", sizeof({c_name}));')
+        want.append((f"sizeof({c_name})", ctypes.sizeof(cls)))
+        for field in cls._fields_:
+            name = field[0]
+            lines.append(f'  printf("%zu\\n", offsetof({c_name}, {name}));')
+            want.append((f"offsetof({c_name}, {name})", getattr(cls, name).offset))
+    lines += ['  return 0;', '}']
+    c_file = tmp_path / "layout.c"
+    c_file.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([gcc, "-std=c11", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe)], check=True)
+    got = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert len(got) == len(want)
+    bad = [(what, int(g), w) for (what, w), g in zip(want, got) if int(g) != w]
+    assert not bad, bad
