@@ -1468,6 +1468,32 @@ def main():
         finally:
             _A.FWD_KERNEL, _A.FUSED_KV_BWD = keep
 
+    # The secondary measurements must not cost the headline: if they are still running after VDETR_BENCH_LEG_TIMEOUT seconds (a hung
+    # GPU — round 6 met a library GEMM that never returns, DESIGN.md 4.7 — or a CPU oracle on a loaded host), a watchdog thread prints the
+    # line as it stands and leaves.  One rank only: with several, the legs below are the roofline micro-benchmark alone.
+    import threading
+    emitted, emit_lock = [False], threading.Lock()
+
+    def emit():
+        with emit_lock:
+            if not emitted[0]:
+                emitted[0] = True
+                print(json.dumps(result), flush=True)
+
+    legs_done = threading.Event()
+    leg_timeout = float(os.environ.get("VDETR_BENCH_LEG_TIMEOUT", "600"))
+
+    def legs_watchdog():
+        if not legs_done.wait(timeout=leg_timeout):
+            result["secondary_measurements"] = {"error": f"still running after {leg_timeout:.0f} s: the headline measurement is complete, the "
+                                                         "line is printed without what is missing and the process leaves"}
+            print(f"[bench] secondary measurements still running after {leg_timeout:.0f} s: printing the line and leaving", file=sys.stderr)
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+    if rank == 0 and world == 1 and leg_timeout > 0:
+        threading.Thread(target=legs_watchdog, daemon=True).start()
+
     if world > 1 and a.with_backbone_dist and a.config == "c2":
         leg("with_backbone", backbone_leg)  # collective: every rank runs it (own scene each); opt-in, it follows the headline
     if rank == 0:
@@ -1483,8 +1509,9 @@ def main():
             leg("criterion", criterion_leg)  # (times the criterion's CPU oracle as well: after the backbone leg for the same reason)
         if not a.no_cpu_baseline and world == 1:
             leg("cpu_baseline", cpu_leg)
+    legs_done.set()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit()
     # Leave in order: everybody done, the group destroyed.  Only a process whose captured graphs hold RCCL nodes then ends
     # without the interpreter's teardown (their destructors were seen to crash at exit, after the line above); it runs what
     # atexit would have run first (the GEMM-tuning results), and a shutdown that failed is reported through the exit code.
