@@ -80,6 +80,11 @@ int vdetr_gather_points_f32(const float* points, const int32_t* idx, float* out,
  *   grad_out (b,c,m), idx (b,m) -> grad_points (b,c,n) (+=, caller zero-fills) */
 int vdetr_gather_points_grad_f32(const float* grad_out, const int32_t* idx, float* grad_points, int b,
                                  int c, int n, int m, vdetr_stream_t stream);
+/* The same as the reference's binding returns it — grad_points WRITTEN, every element, no zero-fill by the caller (sampling.cpp:53-55
+ * creates the zeros inside the op).  For b*c >= 64 channel rows: one workgroup per row accumulates it in LDS (no global atomics, no
+ * memset); below that a memset node + the launch above. */
+int vdetr_gather_points_grad_set_f32(const float* grad_out, const int32_t* idx, float* grad_points, int b,
+                                     int c, int n, int m, vdetr_stream_t stream);
 
 /* ball_query(new_xyz, xyz, radius, nsample) — ball_query.cpp:11-35, ball_query_gpu.cu:12-57.
  *   new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample) i32 (caller zero-fills; rows with no
@@ -94,6 +99,10 @@ int vdetr_group_points_f32(const float* points, const int32_t* idx, float* out, 
 /* group_points_grad(grad_out, idx, n) — group_points.cpp:40-63, group_points_gpu.cu:46-78. */
 int vdetr_group_points_grad_f32(const float* grad_out, const int32_t* idx, float* grad_points, int b,
                                 int c, int n, int npoints, int nsample, vdetr_stream_t stream);
+/* grad_points WRITTEN (group_points.cpp:50-52 creates the zeros inside the op); as vdetr_gather_points_grad_set_f32, with the padding
+ * of ball_query's rows (repeats of the first hit) summed across the wave before it reaches LDS. */
+int vdetr_group_points_grad_set_f32(const float* grad_out, const int32_t* idx, float* grad_points, int b,
+                                    int c, int n, int npoints, int nsample, vdetr_stream_t stream);
 
 /* three_nn(unknowns, knows) — interpolate.cpp:17-44, interpolate_gpu.cu:12-73.
  *   unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32 (SQUARED), idx (b,n,3) i32.

@@ -157,6 +157,42 @@ def test_gather_group_interpolate_and_grads():
     np.testing.assert_allclose(f.grad.cpu().numpy(), O.three_interpolate_grad(g, iidx, w, n), rtol=1e-5, atol=1e-5)
 
 
+def test_scatter_gradients_through_lds():
+    """gather_points_grad / group_points_grad as the op the reference's binding is (the result written whole: the output buffer
+    starts as NaN here): rows accumulated in LDS (b*c >= 64), one and two ranges per row (n below / above 40,000), pair counts that
+    are no multiple of a wave, ball-query rows padded with their first hit, and the memset + atomics pair below 64 rows."""
+    from vdetr_amd import _lib as L
+    rng = np.random.default_rng(5)
+    for b, c, n, m, npts, ns in [(1, 64, 4000, 333, 70, 9), (2, 40, 45001, 1000, 130, 16), (1, 7, 3000, 257, 33, 5),
+                                 (1, 128, 39642, 4096, 256, 64)]:
+        idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+        idx[:, : m // 4] = idx[:, m // 4: 2 * (m // 4)]  # repeated samples
+        g = rng.normal(size=(b, c, m)).astype(np.float32)
+        out = torch.full((b, c, n), float("nan"), device=DEV)
+        dg, didx = cu(g), cu(idx)
+        L.check(L.lib().vdetr_gather_points_grad_set_f32(L.ptr(dg), L.ptr(didx), L.ptr(out), b, c, n, m, L.stream_ptr()), "t")
+        np.testing.assert_allclose(out.cpu().numpy(), O.gather_points_grad(g, idx, n), rtol=1e-5, atol=1e-5)
+        acc = torch.ones((b, c, n), device=DEV)  # the accumulating entry point keeps its meaning
+        L.check(L.lib().vdetr_gather_points_grad_f32(L.ptr(dg), L.ptr(didx), L.ptr(acc), b, c, n, m, L.stream_ptr()), "t")
+        np.testing.assert_allclose(acc.cpu().numpy(), 1.0 + O.gather_points_grad(g, idx, n), rtol=1e-5, atol=1e-5)
+
+        gidx = rng.integers(0, n, size=(b, npts, ns)).astype(np.int32)
+        hits = rng.integers(1, ns + 1, size=(b, npts))
+        for bi in range(b):
+            for j in range(npts):
+                gidx[bi, j, hits[bi, j]:] = gidx[bi, j, 0]  # what ball_query leaves behind a row's last hit
+        gg = rng.normal(size=(b, c, npts, ns)).astype(np.float32)
+        out = torch.full((b, c, n), float("nan"), device=DEV)
+        dgg, dgidx = cu(gg), cu(gidx)
+        L.check(L.lib().vdetr_group_points_grad_set_f32(L.ptr(dgg), L.ptr(dgidx), L.ptr(out), b, c, n, npts, ns,
+                                                        L.stream_ptr()), "t")
+        np.testing.assert_allclose(out.cpu().numpy(), O.group_points_grad(gg, gidx, n), rtol=1e-5, atol=2e-5)
+    # nothing to scatter: zeros, not whatever the buffer held
+    out = torch.full((1, 64, 100), float("nan"), device=DEV)
+    L.check(L.lib().vdetr_gather_points_grad_set_f32(None, None, L.ptr(out), 1, 64, 100, 0, L.stream_ptr()), "t")
+    assert not out.any()
+
+
 def test_reference_interpolation_test_vector():
     """pointnet2_test.py:15-27 (gradcheck of three_interpolate, atol=rtol=1e-1) on the HIP kernels"""
     from torch.autograd import gradcheck
@@ -192,6 +228,23 @@ def test_three_nn_and_ball_query():
         got = PU.ball_query(radius, ns, cu(xyz), cu(new_xyz)).cpu().numpy()
         assert np.array_equal(ref, got), (radius, ns)
     assert got[0, 5].tolist() == [0, 0, 0]
+
+
+def test_ball_query_tile_edges():
+    """The cloud goes through LDS in tiles of 2048 points shared by the eight queries of a workgroup: clouds shorter than a wave,
+    one point past a tile, two scenes per launch, a query count that leaves waves of the last workgroup without a query, rows that
+    fill up inside the first tile (the workgroup stops early) next to rows that never do."""
+    from vdetr_amd import pointnet2_utils as PU
+    for n, m, b, radius, ns in [(37, 5, 1, 0.3, 4), (2048, 8, 1, 0.2, 16), (2049, 9, 2, 0.2, 64), (6000, 13, 2, 0.08, 32),
+                                (4097, 1, 3, 2.0, 128), (8192, 64, 1, 0.04, 8)]:
+        xyz = np.stack([grid_cloud(3 * n, 11 + s)[:n] for s in range(b)])
+        assert xyz.shape == (b, n, 3)
+        new_xyz = xyz[:, -m:].copy()  # the queries' own points sit at the END of the cloud
+        new_xyz[:, 0] += 50.0         # one query per scene with no neighbour at all
+        ref = O.ball_query(new_xyz, xyz, radius, ns)
+        got = PU.ball_query(radius, ns, cu(xyz), cu(new_xyz)).cpu().numpy()
+        assert np.array_equal(ref, got), (n, m, b, radius, ns)
+        assert not got[:, 0].any()
 
 
 def test_query_and_group_module():

@@ -6,7 +6,8 @@
 // which leaves 255 of 256 CUs idle at batch 1.  Here every op is a flat, coalesced, chip-filling grid:
 // consecutive lanes own consecutive OUTPUT elements (64 x 4 B = one 256-B line per wave store), the
 // index / weight rows are read once per thread and reused across a channel strip, and the scans
-// (ball query, three_nn) are wave-cooperative.  All of them are HBM/L2-bound integer/byte work.
+// (ball query, three_nn) are wave-cooperative.  All of them are HBM/L2-bound integer/byte work.  Round 6: the ball query's
+// cloud goes through LDS tiles shared by eight queries, and the two scattering gradients accumulate a channel row in LDS.
 #include "common.h"
 #include "wave.h"
 
@@ -189,6 +190,107 @@ __global__ __launch_bounds__(kThreads) void group_points_grad_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// The two scattering gradients without global atomics and without the caller's zero-fill (round 6): a channel's row of
+// grad_points (n floats: 158 KB at n = 40k) is accumulated in LDS by ONE workgroup and written once, coalesced.
+//   gather_points_grad, c = 256, n = 40k, m = 4096: 41 MB of zeros written by a memset, then 1 M global atomics (51 us + the memset)
+//   group_points_grad,  c = 128, n = 40k, 2048 x 64: 41 MB memset (b*c*n) + ~9 M global float atomics (126 us)
+// Here workgroup (channel l, range r, batch element) zeroes its `len` floats of LDS, walks ALL ne (index, gradient) pairs of the
+// channel in 64-pair steps — `ds_add_f32` for the pairs whose index falls into its range — and stores the range.  With DEDUP the
+// lanes of a step whose index equals lane 0's (ball_query pads a row with its first hit: most of a 64-sample row) are summed across
+// the wave first and leave as one add: equal addresses inside one LDS atomic instruction serialise.  Any index row is handled
+// correctly (other duplicates meet in the LDS atomics).  The sum's order differs from the atomics' (which had none to speak of).
+// ---------------------------------------------------------------------------------------------
+constexpr int kScThreads = 1024;
+constexpr int kScRange = 40000;  // floats of a row per workgroup (160,000 of the CU's 163,840 bytes)
+template <bool DEDUP>
+__global__ __launch_bounds__(kScThreads) void scatter_rows_lds_kernel(const float* __restrict__ grad_out, const int32_t* __restrict__ idx,
+                                                                      float* __restrict__ grad_points, int c, int n, long ne, int range) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int l = blockIdx.x, bi = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int off = blockIdx.y * range, len = min(range, n - off);
+  float* row = grad_points + ((size_t)bi * c + l) * n + off;
+  // element i of the range lives at lds[sh + i], sh = the row's offset inside its 16-byte line: LDS quads and global quads line up
+  const int sh = (int)(((uintptr_t)row >> 2) & 3);
+  float* acc = lds + sh;
+  for (int e = threadIdx.x; e < ((sh + len + 3) >> 2); e += kScThreads) reinterpret_cast<float4*>(lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const float* g = grad_out + ((size_t)bi * c + l) * ne;
+  const int32_t* ix = idx + (size_t)bi * ne;
+  constexpr int kWaves = kScThreads / kWave;
+  if ((ne & 3) == 0 && (((uintptr_t)grad_out | (uintptr_t)idx) & 15) == 0) {
+    // four consecutive pairs per lane (16-byte loads), two such steps in flight.  The walk is instruction-bound — at c = 128 half the
+    // CUs carry 131k pairs each — so the duplicates are folded where it is cheapest: inside the lane (pairs 1-3 that repeat pair 0's
+    // index join its value), then across the 16 lanes of a DPP row (64 pairs: one ball-query row) for the lanes that start with the
+    // row's first index; what is left goes to LDS pair by pair.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const i32x4* ix4 = reinterpret_cast<const i32x4*>(ix);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    const long nq = ne >> 2;
+    constexpr int kV = 2;
+    for (long q0 = (long)wave * kWave; q0 < nq; q0 += (long)kWaves * kWave * kV) {
+      i32x4 a[kV];
+      f32x4 v[kV];
+#pragma unroll
+      for (int u = 0; u < kV; ++u) {
+        const long q = q0 + (long)u * kWaves * kWave + lane;
+        a[u] = q < nq ? ix4[q] : i32x4{-1, -1, -1, -1};
+        v[u] = q < nq ? g4[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < kV; ++u) {
+        const int a0 = a[u][0];
+        float v0 = v[u][0];
+        if (DEDUP) {
+#pragma unroll
+          for (int t = 1; t < 4; ++t) v0 += a[u][t] == a0 ? v[u][t] : 0.f;
+          const int r0 = __shfl(a0, lane & ~15, 64);
+          const bool same = a0 == r0;
+          const float s = row_allsum_f32(same ? v0 : 0.f);
+          if ((lane & 15) == 0) v0 = s;  // the row's leader carries the row's sum (it is `same` by construction)
+          else if (same) v0 = 0.f, a[u][0] = -1;
+        }
+        if ((unsigned)(a[u][0] - off) < (unsigned)len) unsafeAtomicAdd(acc + (a[u][0] - off), v0);
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+          if ((!DEDUP || a[u][t] != a0) && (unsigned)(a[u][t] - off) < (unsigned)len) unsafeAtomicAdd(acc + (a[u][t] - off), v[u][t]);
+      }
+    }
+  } else {
+    constexpr int kU = 4;  // 64-pair steps in flight per wave
+    for (long e0 = (long)wave * kWave; e0 < ne; e0 += (long)kWaves * kWave * kU) {
+      int a[kU];
+      float v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const long e = e0 + (long)u * kWaves * kWave + lane;
+        a[u] = e < ne ? ix[e] - off : -1;
+        v[u] = e < ne ? g[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool in = (unsigned)a[u] < (unsigned)len;
+        if (DEDUP) {
+          const int a0 = __builtin_amdgcn_readfirstlane(a[u]);
+          const bool same = a[u] == a0;
+          const float s = wave_allsum_f32(same ? v[u] : 0.f);
+          if (lane == 0 && in) unsafeAtomicAdd(acc + a0, s);
+          if (in && !same) unsafeAtomicAdd(acc + a[u], v[u]);
+        } else if (in) {
+          unsafeAtomicAdd(acc + a[u], v[u]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int head = min((4 - sh) & 3, len), quads = (len - head) >> 2;
+  if (threadIdx.x < head) row[threadIdx.x] = acc[threadIdx.x];
+  for (int e = threadIdx.x; e < quads; e += kScThreads)
+    *reinterpret_cast<float4*>(row + head + 4 * e) = *reinterpret_cast<const float4*>(acc + head + 4 * e);
+  for (int e = head + 4 * quads + threadIdx.x; e < len; e += kScThreads) row[e] = acc[e];
+}
+
+// ---------------------------------------------------------------------------------------------
 // three_interpolate: out[b,c,j] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3      (interpolate_gpu.cu:75-104)
 // Contraction order pinned as t = p2*w2; t = fma(p1,w1,t); t = fma(p3,w3,t) (see common.h).
 // ---------------------------------------------------------------------------------------------
@@ -330,39 +432,99 @@ __global__ __launch_bounds__(kThreads) void three_nn_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------------------
 // ball_query: first `nsample` indices (ascending) with d² < r²          (ball_query_gpu.cu:12-47)
-// One WAVE per query: each step tests 64 consecutive points, a 64-bit ballot + prefix popcount
-// compacts the hits in ascending index order, and the scan stops (wave-uniform) as soon as nsample
-// hits are found.  Unfilled slots are set to the first hit afterwards, which is what the reference's
-// "first hit pre-fills the row" produces; rows with no hit are left untouched (zero from the caller).
+// One WAVE per query, eight queries per workgroup, the cloud streamed through LDS in tiles of 2048 points that all eight share
+// (round 6: one wave per query reading the cloud itself moved 12nm bytes through L2 — 983 MB for 2048 queries x 40k points,
+// 135 us; the tile cuts that 8x and the next tile's loads are in flight while this one is scanned).  Each step tests 64
+// consecutive points, a 64-bit ballot + prefix popcount compacts the hits in ascending index order, and a wave stops scanning as
+// soon as it has nsample hits (it keeps loading tiles for the others; the workgroup stops when all eight have); four such steps are issued
+// together (hits past the nsample-th are dropped by position, as the reference's loop exit does).  Unfilled slots are
+// set to the first hit afterwards, which is what the reference's "first hit pre-fills the row" produces; rows with no hit are left
+// untouched (zero from the caller).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void ball_query_kernel(const float* __restrict__ new_xyz,
-                                                              const float* __restrict__ xyz,
-                                                              int32_t* __restrict__ idx, int n, int m,
-                                                              float radius2, int nsample) {
+constexpr int kBqThreads = 512, kBqQueries = kBqThreads / kWave, kBqTile = 4096;
+constexpr int kBqPer = kBqTile * 3 / kBqThreads;  // floats of a tile per thread
+constexpr int kBqUnroll = 4;                      // 64-point steps in flight per wave (two waves per SIMD: the loads need the overlap)
+
+__global__ __launch_bounds__(kBqThreads) void ball_query_kernel(const float* __restrict__ new_xyz,
+                                                                const float* __restrict__ xyz,
+                                                                int32_t* __restrict__ idx, int n, int m,
+                                                                float radius2, int nsample) {
+  __shared__ float tile[(kBqTile + kBqUnroll * kWave) * 3];  // + one step of pad, read ahead and never used
+  __shared__ int full;  // waves whose row is complete
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+  const int j = blockIdx.x * kBqQueries + (threadIdx.x >> 6);
   const int bi = blockIdx.z;
-  if (j >= m) return;  // wave-uniform
-  const float* q = new_xyz + ((size_t)bi * m + j) * 3;
+  const bool live = j < m;  // wave-uniform
+  const float* q = new_xyz + ((size_t)bi * m + (live ? j : 0)) * 3;
   const float qx = q[0], qy = q[1], qz = q[2];
   const float* pts = xyz + (size_t)bi * n * 3;
-  int32_t* row = idx + ((size_t)bi * m + j) * nsample;
-  int cnt = 0, first = -1;
-  for (int k0 = 0; k0 < n && cnt < nsample; k0 += kWave) {
-    const int k = k0 + lane;
-    bool hit = false;
-    if (k < n) {
-      const float d2 = sqdist3(qx - pts[k * 3], qy - pts[k * 3 + 1], qz - pts[k * 3 + 2]);
-      hit = d2 < radius2;
+  int32_t* row = idx + ((size_t)bi * m + (live ? j : 0)) * nsample;
+  const long total = (long)n * 3;
+  int cnt = live ? 0 : nsample, first = -1;
+  bool told = false;
+  if (threadIdx.x == 0) full = 0;
+  float nxt[kBqPer];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < kBqPer; ++u) {
+      const long e = (long)t0 * 3 + u * kBqThreads + threadIdx.x;
+      nxt[u] = e < total ? pts[e] : 3e38f;  // past the cloud's end: a point no radius reaches (d2 = inf), so the scan needs no index test
     }
-    const unsigned long long mask = __ballot(hit);
-    if (mask == 0) continue;
-    if (first < 0) first = k0 + __ffsll((long long)mask) - 1;
-    const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-    if (hit && pos < nsample) row[pos] = k;
-    cnt += __popcll(mask);
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < n; t0 += kBqTile) {
+#pragma unroll
+    for (int u = 0; u < kBqPer; ++u) tile[u * kBqThreads + threadIdx.x] = nxt[u];
+    __syncthreads();
+    if (t0 + kBqTile < n) fetch(t0 + kBqTile);
+    const int tn = min(kBqTile, n - t0);
+    // the tile is a multiple of the step; the next step's points are read from LDS (into the other register set) before this
+    // step's are tested: two waves per SIMD do not cover the read latency by themselves
+    constexpr int kStep = kBqUnroll * kWave;
+    float pa[3][kBqUnroll], pb[3][kBqUnroll];
+    auto read = [&](float (&p)[3][kBqUnroll], int k0) {
+#pragma unroll
+      for (int u = 0; u < kBqUnroll; ++u) {
+        const int k = k0 + u * kWave + lane;
+        p[0][u] = tile[k * 3]; p[1][u] = tile[k * 3 + 1]; p[2][u] = tile[k * 3 + 2];
+      }
+    };
+    auto step = [&](const float (&p)[3][kBqUnroll], float (&q)[3][kBqUnroll], int k0) {
+      float d2[kBqUnroll];
+#pragma unroll
+      for (int u = 0; u < kBqUnroll; ++u) d2[u] = sqdist3(qx - p[0][u], qy - p[1][u], qz - p[2][u]);
+      read(q, k0 + kStep);  // past the tile's end on its last step: the pad (never tested: the loop ends)
+      unsigned long long mask[kBqUnroll], any = 0;
+#pragma unroll
+      for (int u = 0; u < kBqUnroll; ++u) {
+        mask[u] = __ballot(d2[u] < radius2);
+        any |= mask[u];
+      }
+      if (any == 0) return;
+#pragma unroll
+      for (int u = 0; u < kBqUnroll; ++u) {
+        if (mask[u] == 0) continue;
+        const int base = t0 + k0 + u * kWave;
+        if (first < 0) first = base + __ffsll((long long)mask[u]) - 1;
+        const int pos = cnt + __popcll(mask[u] & ((1ull << lane) - 1ull));
+        if (((mask[u] >> lane) & 1ull) && pos < nsample) row[pos] = base + lane;
+        cnt += __popcll(mask[u]);
+      }
+    };
+    if (cnt < nsample) read(pa, 0);
+    for (int k0 = 0; k0 < tn && cnt < nsample; k0 += 2 * kStep) {
+      step(pa, pb, k0);
+      if (k0 + kStep >= tn || cnt >= nsample) break;
+      step(pb, pa, k0 + kStep);
+    }
+    if (cnt >= nsample && !told) {
+      told = true;
+      if (lane == 0) atomicAdd(&full, 1);
+    }
+    __syncthreads();  // the tile may be overwritten; `full` is final for this tile
+    if (full == kBqQueries) break;
   }
-  if (first >= 0)
+  if (live && first >= 0)
     for (int l = min(cnt, nsample) + lane; l < nsample; l += kWave) row[l] = first;
 }
 
@@ -431,6 +593,51 @@ extern "C" int vdetr_group_points_grad_f32(const float* grad_out, const int32_t*
   return check_launch("group_points_grad");
 }
 
+// the LDS form fills the chip when there are channel rows enough; below that the memset + atomics pair is the better one
+static bool scatter_lds_pays(int b, int c) { return (long)b * c >= 64; }
+
+template <bool DEDUP>
+static int scatter_rows_lds(const char* op, const float* grad_out, const int32_t* idx, float* grad_points, int b, int c, int n, long ne,
+                            hipStream_t stream) {
+  const int ranges = ceil_div(n, kScRange);
+  const int range = (ceil_div(n, ranges) + 3) & ~3;  // equal ranges, whole float4s
+  auto kernel = scatter_rows_lds_kernel<DEDUP>;
+  const size_t lds = (size_t)(range + 4) * sizeof(float);  // + the row's offset inside its 16-byte line
+  if (int e = set_lds(kernel, lds, op)) return e;
+  hipLaunchKernelGGL(kernel, dim3(c, ranges, b), dim3(kScThreads), lds, stream, grad_out, idx, grad_points, c, n, ne, range);
+  return check_launch(op);
+}
+
+extern "C" int vdetr_gather_points_grad_set_f32(const float* grad_out, const int32_t* idx, float* grad_points,
+                                                int b, int c, int n, int m, vdetr_stream_t stream) {
+  if (int e = check_bcnm("gather_points_grad_set", b, c, n, m)) return e;
+  if (b == 0 || c == 0 || n == 0) return VDETR_OK;
+  VDETR_REQUIRE(grad_points && (m == 0 || (grad_out && idx)), "gather_points_grad_set: null pointer");
+  if (m > 0 && scatter_lds_pays(b, c))
+    return scatter_rows_lds<false>("gather_points_grad_set", grad_out, idx, grad_points, b, c, n, m, (hipStream_t)stream);
+  if (hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    set_error("gather_points_grad_set: cannot clear grad_points");
+    return VDETR_ERR_LAUNCH;
+  }
+  return vdetr_gather_points_grad_f32(grad_out, idx, grad_points, b, c, n, m, stream);
+}
+
+extern "C" int vdetr_group_points_grad_set_f32(const float* grad_out, const int32_t* idx, float* grad_points,
+                                               int b, int c, int n, int npoints, int nsample, vdetr_stream_t stream) {
+  if (int e = check_bcnm("group_points_grad_set", b, c, n, npoints)) return e;
+  VDETR_REQUIRE(nsample >= 0, "group_points_grad_set: negative nsample");
+  const long ne = (long)npoints * nsample;
+  if (b == 0 || c == 0 || n == 0) return VDETR_OK;
+  VDETR_REQUIRE(grad_points && (ne == 0 || (grad_out && idx)), "group_points_grad_set: null pointer");
+  if (ne > 0 && scatter_lds_pays(b, c))
+    return scatter_rows_lds<true>("group_points_grad_set", grad_out, idx, grad_points, b, c, n, ne, (hipStream_t)stream);
+  if (hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    set_error("group_points_grad_set: cannot clear grad_points");
+    return VDETR_ERR_LAUNCH;
+  }
+  return vdetr_group_points_grad_f32(grad_out, idx, grad_points, b, c, n, npoints, nsample, stream);
+}
+
 extern "C" int vdetr_three_nn_f32(const float* unknown, const float* known, float* dist2, int32_t* idx,
                                   int b, int n, int m, vdetr_stream_t stream) {
   if (int e = check_bcnm("three_nn", b, 0, n, m)) return e;
@@ -479,10 +686,10 @@ extern "C" int vdetr_ball_query_f32(const float* new_xyz, const float* xyz, int3
   VDETR_REQUIRE(nsample >= 0, "ball_query: negative nsample");
   if (b == 0 || m == 0 || nsample == 0 || n == 0) return VDETR_OK;
   VDETR_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");
-  dim3 grid(ceil_div(m, kThreads / kWave), 1, b);
+  dim3 grid(ceil_div(m, kBqQueries), 1, b);
   // radius2 is formed in float like the reference (ball_query_gpu.cu:25)
   const float radius2 = radius * radius;
-  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, new_xyz, xyz, idx, n,
+  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(kBqThreads), 0, (hipStream_t)stream, new_xyz, xyz, idx, n,
                      m, radius2, nsample);
   return check_launch("ball_query");
 }

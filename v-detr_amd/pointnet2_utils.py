@@ -60,9 +60,9 @@ class _Ext:
         self._chk_f(grad_out, "grad_out")
         self._chk_i(idx, "idx")
         b, c, m = grad_out.shape
-        out = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
-        L.check(L.lib().vdetr_gather_points_grad_f32(L.ptr(grad_out), L.ptr(idx), L.ptr(out), b, c, n, m,
-                                                     L.stream_ptr()), "gather_points_grad")
+        out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)  # written whole by the op
+        L.check(L.lib().vdetr_gather_points_grad_set_f32(L.ptr(grad_out), L.ptr(idx), L.ptr(out), b, c, n, m,
+                                                         L.stream_ptr()), "gather_points_grad")
         return out
 
     # std::vector<at::Tensor> three_nn(at::Tensor unknowns, at::Tensor knows)   interpolate.cpp:17
@@ -127,9 +127,9 @@ class _Ext:
         self._chk_f(grad_out, "grad_out")
         self._chk_i(idx, "idx")
         b, c, npoints, nsample = grad_out.shape
-        out = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
-        L.check(L.lib().vdetr_group_points_grad_f32(L.ptr(grad_out), L.ptr(idx), L.ptr(out), b, c, n, npoints, nsample,
-                                                    L.stream_ptr()), "group_points_grad")
+        out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)  # written whole by the op
+        L.check(L.lib().vdetr_group_points_grad_set_f32(L.ptr(grad_out), L.ptr(idx), L.ptr(out), b, c, n, npoints, nsample,
+                                                        L.stream_ptr()), "group_points_grad")
         return out
 
 
