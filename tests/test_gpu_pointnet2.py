@@ -157,6 +157,20 @@ def test_gather_group_interpolate_and_grads():
     np.testing.assert_allclose(f.grad.cpu().numpy(), O.three_interpolate_grad(g, iidx, w, n), rtol=1e-5, atol=1e-5)
 
 
+def test_group_points_row_in_lds():
+    """group_points with the channel row staged in LDS (n <= 40,000, b*c >= 32): 16-byte and scalar index walks, one to eight
+    slices of the index tensor per row, rows at every offset inside a 16-byte line (odd n), and the strided form beyond."""
+    from vdetr_amd import pointnet2_utils as PU
+    rng = np.random.default_rng(6)
+    for b, c, n, npts, ns in [(1, 128, 39642, 256, 64), (2, 16, 4001, 100, 16), (1, 33, 999, 41, 7), (1, 300, 2048, 64, 8),
+                              (1, 40, 45000, 64, 16), (1, 5, 3000, 30, 4)]:
+        pts = rng.normal(size=(b, c, n)).astype(np.float32)
+        gidx = rng.integers(0, n, size=(b, npts, ns)).astype(np.int32)
+        gidx[:, :, ns // 2:] = gidx[:, :, :1]  # padded rows
+        got = PU._ext.group_points(cu(pts), cu(gidx)).cpu().numpy()
+        assert np.array_equal(got, O.group_points(pts, gidx)), (b, c, n, npts, ns)
+
+
 def test_scatter_gradients_through_lds():
     """gather_points_grad / group_points_grad as the op the reference's binding is (the result written whole: the output buffer
     starts as NaN here): rows accumulated in LDS (b*c >= 64), one and two ranges per row (n below / above 40,000), pair counts that

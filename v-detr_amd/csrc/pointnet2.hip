@@ -149,6 +149,43 @@ __global__ __launch_bounds__(kThreads) void group_points_kernel(const float* __r
   }
 }
 
+// The same with the channel row staged in LDS (round 6): the form above reads one 64-byte sector per output element (67 MB of
+// output, 128 x 2048 x 64, out of a 20 MB table: 30.7 us).  Workgroup (channel l, slice s of the index tensor, batch element) reads
+// its row of n <= 40,000 floats once, coalesced, and serves its slice of the (point, sample) pairs out of LDS — four per lane, 16-byte
+// index loads and output stores; equal indices inside a load (ball_query's padding) are a broadcast.  The slices exist to fill the
+// chip when c < 256: each re-reads the row (158 KB, out of L2 after the first).
+constexpr int kGrThreads = 1024;
+constexpr int kGrRow = 40000;  // floats of a row in LDS
+__global__ __launch_bounds__(kGrThreads) void group_points_lds_kernel(const float* __restrict__ points, const int32_t* __restrict__ idx,
+                                                                      float* __restrict__ out, int c, int n, long ne, long per) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int l = blockIdx.x, bi = blockIdx.z;
+  const float* src = points + ((size_t)bi * c + l) * n;
+  const int sh = (int)(((uintptr_t)src >> 2) & 3);  // the row at its offset inside its 16-byte line: global quads == LDS quads
+  float* row = lds + sh;
+  const int head = min((4 - sh) & 3, n), quads = (n - head) >> 2;
+  if (threadIdx.x < head) row[threadIdx.x] = src[threadIdx.x];
+  for (int e = threadIdx.x; e < quads; e += kGrThreads)
+    *reinterpret_cast<float4*>(row + head + 4 * e) = *reinterpret_cast<const float4*>(src + head + 4 * e);
+  for (int e = head + 4 * quads + threadIdx.x; e < n; e += kGrThreads) row[e] = src[e];
+  __syncthreads();
+  const int32_t* ix = idx + (size_t)bi * ne;
+  float* dst = out + ((size_t)bi * c + l) * ne;
+  const long e0 = (long)blockIdx.y * per, e1 = min(ne, e0 + per);  // `per` is a multiple of 4
+  if ((ne & 3) == 0 && (((uintptr_t)idx | (uintptr_t)out) & 15) == 0) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (long q = (e0 >> 2) + threadIdx.x; q < (e1 >> 2); q += kGrThreads) {
+      const i32x4 a = reinterpret_cast<const i32x4*>(ix)[q];
+      f32x4 v;
+      v[0] = row[a[0]]; v[1] = row[a[1]]; v[2] = row[a[2]]; v[3] = row[a[3]];
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst) + q);
+    }
+  } else {
+    for (long e = e0 + threadIdx.x; e < e1; e += kGrThreads) dst[e] = row[ix[e]];
+  }
+}
+
 // group_points_grad: grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k] (group_points_gpu.cu:46-67)
 // One WAVE per (point j, strip of 16 channels); lane k owns sample k of the row, so a channel's 64 gradients are ONE coalesced
 // 256-byte load (round 1's thread-per-row walk read them at a 256-byte lane stride: 67 MB at 0.25 TB/s, 273 us).  Duplicates are
@@ -573,6 +610,15 @@ extern "C" int vdetr_group_points_f32(const float* points, const int32_t* idx, f
   const long ne = (long)npoints * nsample;
   if (b == 0 || c == 0 || ne == 0) return VDETR_OK;
   VDETR_REQUIRE(points && idx && out, "group_points: null pointer");
+  if (n <= kGrRow && ne * 8 >= n && (long)b * c >= 32) {  // the row through LDS (see the kernel): pairs enough to pay for staging it
+    long slices = ceil_div(256, (long)b * c);
+    slices = slices < 1 ? 1 : (slices > 8 ? 8 : slices);
+    const long per = ((ne + slices - 1) / slices + 3) & ~3L;
+    const size_t lds = (size_t)(n + 4) * sizeof(float);
+    if (int e = set_lds(group_points_lds_kernel, lds, "group_points")) return e;
+    hipLaunchKernelGGL(group_points_lds_kernel, dim3(c, ceil_div(ne, per), b), dim3(kGrThreads), lds, (hipStream_t)stream, points, idx, out, c, n, ne, per);
+    return check_launch("group_points");
+  }
   dim3 grid(ceil_div(ne, kThreads), ceil_div(c, kChanStrip), b);
   hipLaunchKernelGGL(group_points_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, points, idx, out, c,
                      n, ne);
