@@ -183,7 +183,10 @@ typedef struct vdetr_attn_desc {
                          matrix instructions; 1 = one workgroup per (query quad, key chunk) (attn_fwd.hip; the round-4 kernel,
                          kept for A/B runs and parity tests); 3 = the persistent kernel with q / k / v each ROUNDED to one bf16
                          part (round to nearest even) on the way into the matrix unit: the bf16 products of BASELINE config 4 on
-                         f32 tensors — scores, softmax, RPE bias, accumulators and every stored tensor stay f32, no cast launches */
+                         f32 tensors — scores, softmax, RPE bias, accumulators and every stored tensor stay f32, no cast launches.
+                         Per-head kind: 1 = the general body in eight-wave workgroups, 4 = the general body in the shape the
+                         library would pick, also where the lean self-attention kernel (attn_fwd_self.hip: no mask, nQ % 16 == 0,
+                         nK % 128 == 0) would be taken — same values either way up to the order of the key sums */
   int32_t bwd_kernel; /* table gradient: 0 = the box kernel where every query's vertices are a box (attn_bwd_box4.hip), the general
                          kernel otherwise — both are launched, the device decides; 1 = the general kernel only (parity tests compare
                          the two); 2 = the box kernel only: the caller vouches for boxes (vertices out of a box decode) and saves the

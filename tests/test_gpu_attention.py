@@ -526,6 +526,30 @@ def test_per_head_attention_at_the_models_size_vs_torch(B, n, p):
         assert_close(got, want.cpu().numpy(), 1e-3, 2e-5 * float(want.abs().max()), name)
 
 
+@pytest.mark.parametrize("B,n,p", [(1, 1024, 0.1), (2, 256, 0.0), (1, 384, 0.3), (4, 1024, 0.1), (3, 128, 0.2)])
+def test_lean_self_attention_kernel_equals_the_general_body(monkeypatch, B, n, p):
+    """attn_fwd_self.hip (no mask, nQ % 16 == 0, nK % 128 == 0: two key tiles per step, hoisted dropout counters) against
+    attn_fwd.hip's body on the same inputs and the same dropout state (vdetr_attn_desc.fwd_kernel = 4): the same keep mask, outputs
+    and gradients equal up to the order of the key sums."""
+    from vdetr_amd import attention as A
+    g = torch.Generator().manual_seed(7 * n + B)
+    base = [torch.randn((B, n, 256), generator=g).to(DEV) for _ in range(3)]
+    wout = torch.randn((B, n, 256), generator=g).to(DEV)
+    res = {}
+    for body in (False, True):
+        monkeypatch.setattr(A, "SELF_FWD_BODY", body)
+        A.reset_rng()
+        rng = A.begin_step(DEV) if p > 0 else None
+        q, k, v = (t_.clone().requires_grad_(True) for t_ in base)
+        out = A.fused_attention(q, k, v, num_heads=4, scale=0.125, shared_kv=False, dropout_p=p, rng_state=rng, salt=3)
+        (out * wout).sum().backward()
+        res[body] = (out.detach(), q.grad, k.grad, v.grad)
+    for name, a, b in zip(("out", "dq", "dk", "dv"), res[False], res[True]):
+        assert_close(a, b.cpu().numpy(), 1e-5, 1e-5 * float(b.abs().max()), name)  # (measured: 3e-6 of the largest entry)
+    if p > 0:  # a dropped probability is an exact zero in both or in neither: the same mask (dv rows see every kept pair)
+        assert float((res[False][0] - res[True][0]).abs().max()) < 1e-4 * float(res[True][0].abs().max())
+
+
 @pytest.mark.parametrize("case", ["cross_attn_small", "cross_attn_rot", "cross_attn_mid"])
 def test_cross_attention_module_vs_reference_vectors(case):
     g = load_golden(case)

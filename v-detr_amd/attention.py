@@ -67,6 +67,7 @@ FUSED_KV_BWD = os.environ.get("VDETR_BWD_FUSED", "1") != "0"
 # matrix time pays 4x: C2 8.34 ms with the library, 8.37-8.41 with the kernel for the self-attention (VDETR_BWD_DQ=1), 8.45-8.48
 # for both (=2).
 _SELF_FWD8 = os.environ.get("VDETR_SELF_FWD8", "0") != "0"  # A/B switch (read once): see _FusedAttention.forward
+SELF_FWD_BODY = os.environ.get("VDETR_SELF_FWD", "") == "body"  # per-head forward: attn_fwd.hip's body instead of attn_fwd_self.hip (A/B; tests flip it)
 _DQ_KERNEL = os.environ.get("VDETR_BWD_DQ", "0") != "0"
 _DQ_KERNEL_SHARED = os.environ.get("VDETR_BWD_DQ", "0") == "2"
 
@@ -719,6 +720,8 @@ class _FusedAttention(Function):
         scores = torch.empty(rows + (nK,), dtype=torch.float32, device=q.device) if need_grad else None
         if kind == L.VDETR_ATTN_PER_HEAD and _SELF_FWD8:
             d.fwd_kernel = 1  # (A/B: the eight-wave workgroups also where the four-wave form would be taken)
+        elif kind == L.VDETR_ATTN_PER_HEAD and SELF_FWD_BODY:
+            d.fwd_kernel = 4  # (A/B, parity tests: the general body also where the lean self-attention kernel would be taken)
         if operand_bf16 and not bf16 and FWD_KERNEL == 0:
             d.fwd_kernel = 3  # f32 tensors, q / k / v rounded to one bf16 part each inside the kernels (vdetr_hip.h)
         if kv_img is not None and not bf16 and FWD_KERNEL == 0:

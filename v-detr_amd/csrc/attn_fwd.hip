@@ -467,6 +467,8 @@ __global__ void mfma_selftest_kernel(const float* a, const float* b, float* cmat
 using namespace vdetr;
 
 namespace vdetr {
+bool attn_fwd_self_eligible(const vdetr_attn_desc* d, int ksplit);  // attn_fwd_self.hip
+int attn_fwd_self_launch(const AttnParams& P, hipStream_t st);
 int attn_fill_params(const vdetr_attn_desc* d, AttnParams* P, const char* op) {
   VDETR_REQUIRE(d != nullptr, "%s: null descriptor", op);
   VDETR_REQUIRE(d->kind == VDETR_ATTN_SHARED_KV || d->kind == VDETR_ATTN_PER_HEAD, "%s: bad kind %d", op, d->kind);
@@ -641,6 +643,8 @@ static int attn_fwd_run(const vdetr_attn_desc* d, const float* q, const float* k
     VDETR_REQUIRE((size_t)d->nK * P.k_stride < (1u << 30) && (size_t)d->nK * P.v_stride < (1u << 30) && (size_t)4 * d->nK < (1u << 30),
                   "attn_fwd: nK=%d too large for the persistent forward's 32-bit tile offsets", d->nK);
     if (int e = attn_fwd_pipe_launch(P, sched, device_cu_count(), kv_img, pipe_split(d), d->kv_img != nullptr, true, st)) return e;
+  } else if (perhead && VDETR_AB("VDETR_FWD_SELF", 1) && attn_fwd_self_eligible(d, ks)) {
+    if (int e = attn_fwd_self_launch(P, st)) return e;  // the lean kernel of the decoder's own case (attn_fwd_self.hip)
   } else if (perhead) {
     dim3 grid((d->nQ + 15) / 16, d->H * ks, d->B);
     const long wgs = (long)grid.x * grid.y * grid.z;

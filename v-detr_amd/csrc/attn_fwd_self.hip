@@ -1,0 +1,272 @@
+// attn_fwd_self.hip — the query self-attention's forward (per-head kind, nn.MultiheadAttention: vdetr_transformer.py:468) at the
+// sizes the decoder runs it, as its own lean kernel (round 6).
+//
+// attn_fwd.hip's body serves every kind (RPE, boxes, masks, ragged sizes, key splits); for the per-head kind its key-tile step had
+// grown to ~800 instructions for 256 scores — index clamps and 64-bit address products per tile, uniform branches on mask / score /
+// dropout switches that cut the scheduling regions, 44 accumulator-register spill moves — and the launch (256 workgroups of four waves,
+// one wave per SIMD) is bound by exactly that: 27 us alone, 34 in the step, the same with eight waves.  This kernel takes the case
+// the model has — no mask, nQ a multiple of 16, nK a multiple of 128, no key split — with the same tiling, the same lane layouts,
+// the same exact-f32 products (v_mfma_f32_16x16x4_f32) and the same dropout counters, so it is interchangeable with the body
+// (fwd_kernel = 4 keeps the body: the parity tests compare the two), and differs in the bookkeeping only:
+//   * pointers advanced by constants (K, V, score rows), no clamps;
+//   * TWO key tiles (32 keys) per step of a wave: one running-max update, one rescale of the accumulators and half the DPP reduction
+//     stages per key; the four rows' DPP stages interleaved (no s_nop between dependent stages);
+//   * the (seed, offset, batch, head group, query) part of the dropout counter hashed once per row, one fmix32 per pair for heads
+//     0 / 1 of a group and two for heads 2 / 3 (the body hashed all four heads' values for every pair);
+//   * DROP / STORE as template parameters.
+#include "attn_common.h"
+#include "wave.h"
+
+namespace vdetr {
+
+constexpr int kSfWaves = 4;
+constexpr int kSfPad = 20;  // floats per row of the P transpose pad (16 + 4: float4 alignment)
+
+// four independent DPP row reductions, stage by stage: three instructions sit between dependent stages, which covers the two
+// wait states a DPP read of a fresh VALU result needs (wave.h's single-value forms carry an s_nop per stage)
+__device__ __forceinline__ void row_allmax4(float& a, float& b, float& c, float& d) {
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void row_allsum4(float& a, float& b, float& c, float& d) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+struct SfTile {
+  f32x4 kb[4];
+};
+
+// (two waves per SIMD = 256 registers: a second workgroup must fit next to the first on a CU — in the training step one CU is held by
+// the next scene's sampling kernel, and 256 workgroups that need a CU each would run a second round for the last one)
+template <bool DROP, bool STORE>
+__global__ __launch_bounds__(kSfWaves * kWave) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_self_kernel(AttnParams P) {
+  __shared__ __attribute__((aligned(16))) float smem[kSfWaves * kWave * 24];  // the waves' P pads first, their merged states last
+  attn_load_rng(P);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 16;
+  const int H = P.H, nQ = P.nQ, nK = P.nK;
+  const int qstride = H * kDh;
+  float* padA = smem + w * (2 * 16 * kSfPad);
+  float* padB = padA + 16 * kSfPad;
+
+  // A operand of QK^T (row = query q0 + c, contraction index d = 16 g + s), scaled
+  float qa[16];
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(P.q + ((size_t)b * nQ + q0 + c) * qstride + head * kDh + 16 * g);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const f32x4 v = src[s4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qa[s4 * 4 + e] = v[e] * P.scale;
+    }
+  }
+  // accumulator register r of lane (g, c): query q0 + 4 g + r, key (tile) + c
+  unsigned xq[4];  // the dropout counter's per-row prefix (attn_common.h: attn_rand4)
+  if (DROP) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      unsigned x = fmix32(((unsigned)(q0 + 4 * g + r) * 0x9E3779B1u + P.off_lo) ^ P.seed_lo);
+      xq[r] = fmix32(x ^ (((unsigned)b * 64u + (unsigned)(head >> 2)) * 0x27D4EB2Fu + P.off_hi) ^ P.seed_hi);
+    }
+  }
+  const bool second = (head & 2) != 0;  // heads 2 / 3 of a group read the counter's second word
+  const int shift = (head & 1) * 16;
+
+  f32x4 o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[4] = {kNegBig, kNegBig, kNegBig, kNegBig}, l[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // wave w: key tiles w, w + 4, w + 8, ...; a step takes two of them (keys +0 and +64)
+  const float* kp = P.k + ((size_t)b * nK + 16 * w + c) * P.k_stride + head * kDh + 16 * g;
+  const float* vp = P.v + ((size_t)b * nK + 16 * w + 4 * g) * P.v_stride + head * kDh + 4 * c;
+  float* sp = STORE ? P.scores + (((size_t)b * H + head) * nQ + q0 + 4 * g) * nK + 16 * w + c : nullptr;
+  const size_t ktile = (size_t)64 * P.k_stride, vtile = (size_t)64 * P.v_stride;
+  auto fetch = [&](const float* kq, SfTile& t) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) t.kb[s4] = reinterpret_cast<const f32x4*>(kq)[s4];
+  };
+  const int steps = nK >> 7;  // 128 keys of the workgroup per step
+  int key = 16 * w + c;
+  // one step: the K tiles (a, bt) are consumed, the next step's go into (na, nb) — two register sets that swap roles (a copy at the
+  // end of the step would wait for the loads it copies).  The step's own V tiles are requested at its start: QK^T and the softmax
+  // cover their latency, and one register set is enough for them.
+  auto step = [&](const SfTile& a, const SfTile& bt, SfTile& na, SfTile& nb, bool more) {
+    f32x4 va[4], vb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      va[s] = *reinterpret_cast<const f32x4*>(vp + (size_t)s * P.v_stride);
+      vb[s] = *reinterpret_cast<const f32x4*>(vp + vtile + (size_t)s * P.v_stride);
+    }
+    kp += 2 * ktile; vp += 2 * vtile;
+    if (more) {
+      fetch(kp, na);
+      fetch(kp + ktile, nb);
+    }
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      sa = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], a.kb[s >> 2][s & 3], sa, 0, 0, 0);
+      sb = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], bt.kb[s >> 2][s & 3], sb, 0, 0, 0);
+    }
+    if (STORE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        __builtin_nontemporal_store(sa[r], sp + (size_t)r * nK);
+        __builtin_nontemporal_store(sb[r], sp + (size_t)r * nK + 64);
+      }
+      sp += 128;
+    }
+    // online softmax over the 32 keys
+    float t0 = fmaxf(sa[0], sb[0]), t1 = fmaxf(sa[1], sb[1]), t2 = fmaxf(sa[2], sb[2]), t3 = fmaxf(sa[3], sb[3]);
+    row_allmax4(t0, t1, t2, t3);
+    const float tm[4] = {t0, t1, t2, t3};
+    float pa_[4], pb_[4], es[4], alpha[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mn = fmaxf(m[r], tm[r]);
+      alpha[r] = __expf(m[r] - mn);
+      pa_[r] = __expf(sa[r] - mn);
+      pb_[r] = __expf(sb[r] - mn);
+      es[r] = pa_[r] + pb_[r];
+      m[r] = mn;
+    }
+    row_allsum4(es[0], es[1], es[2], es[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      l[r] = l[r] * alpha[r] + es[r];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t][r] *= alpha[r];
+    }
+    if (DROP) {
+      const unsigned ka = (unsigned)key * 0x165667B1u, kb2 = (unsigned)(key + 64) * 0x165667B1u;
+      unsigned xa[4], xb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { xa[r] = fmix32(xq[r] ^ ka); xb[r] = fmix32(xq[r] ^ kb2); }
+      if (second) {  // (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xa[r] = fmix32(xa[r] + 0x9E3779B9u); xb[r] = fmix32(xb[r] + 0x9E3779B9u); }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pa_[r] = ((xa[r] >> shift) & 0xFFFFu) >= P.drop_thresh ? pa_[r] * P.drop_scale : 0.f;
+        pb_[r] = ((xb[r] >> shift) & 0xFFFFu) >= P.drop_thresh ? pb_[r] * P.drop_scale : 0.f;
+      }
+    }
+    key += 128;
+    // P: accumulator layout -> A-operand layout (row c, keys 4 g .. 4 g + 3) through the wave's pads
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      padA[(4 * g + r) * kSfPad + c] = pa_[r];
+      padB[(4 * g + r) * kSfPad + c] = pb_[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 qa4 = *reinterpret_cast<const f32x4*>(padA + c * kSfPad + 4 * g);
+    const f32x4 qb4 = *reinterpret_cast<const f32x4*>(padB + c * kSfPad + 4 * g);
+    __builtin_amdgcn_wave_barrier();
+    // O += P V  (V[key 4 g + s][d = 4 c + t])
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa4[s], va[s][t], o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb4[s], vb[s][t], o[t], 0, 0, 0);
+      }
+  };
+  SfTile a0, b0, a1, b1;
+  fetch(kp, a0);
+  fetch(kp + ktile, b0);
+  int it = 0;
+  for (; it + 1 < steps; it += 2) {
+    step(a0, b0, a1, b1, true);
+    step(a1, b1, a0, b0, it + 2 < steps);
+  }
+  if (it < steps) step(a0, b0, a1, b1, false);
+
+  // ---- merge the four wave states (as attn_fwd.hip's body with four waves) -------------------------------------------
+  __syncthreads();
+  float* red = smem;  // [w][lane][24]: 16 o + 4 m + 4 l
+  {
+    float* mine = red + ((size_t)w * kWave + lane) * 24;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[t * 4 + r] = o[t][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mine[16 + r] = m[r]; mine[20 + r] = l[r]; }
+  }
+  __syncthreads();
+  {
+    const int t = w;  // wave w finishes d-tile t = w for the four registers
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float M = kNegBig;
+#pragma unroll
+      for (int ww = 0; ww < kSfWaves; ++ww) M = fmaxf(M, red[((size_t)ww * kWave + lane) * 24 + 16 + r]);
+      float L = 0.f, val = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < kSfWaves; ++ww) {
+        const float* src = red + ((size_t)ww * kWave + lane) * 24;
+        const float f = __expf(src[16 + r] - M);
+        L += src[20 + r] * f;
+        val += src[t * 4 + r] * f;
+      }
+      const int qi = q0 + 4 * g + r;
+      const float inv = L > 0.f ? 1.f / L : 0.f;
+      P.out[((size_t)b * nQ + qi) * qstride + head * kDh + 4 * c + t] = val * inv;
+      if (t == 0 && c == 0) P.lse[((size_t)b * H + head) * nQ + qi] = L > 0.f ? M + __logf(L) : kNegBig;
+    }
+  }
+}
+
+// the case this kernel is written for (attn_fwd.hip asks before it picks its own body)
+bool attn_fwd_self_eligible(const vdetr_attn_desc* d, int ksplit) {
+  return d->kind == VDETR_ATTN_PER_HEAD && !d->table && !d->mask && ksplit == 1 && d->nQ % 16 == 0 && d->nK % 128 == 0 &&
+         d->fwd_kernel != 1 && d->fwd_kernel != 4;
+}
+
+int attn_fwd_self_launch(const AttnParams& P, hipStream_t st) {
+  dim3 grid(P.nQ / 16, P.H, P.B);
+  const bool drop = P.drop_thresh != 0, store = P.scores != nullptr;
+  if (drop && store) hipLaunchKernelGGL((attn_fwd_self_kernel<true, true>), grid, dim3(kSfWaves * kWave), 0, st, P);
+  else if (drop) hipLaunchKernelGGL((attn_fwd_self_kernel<true, false>), grid, dim3(kSfWaves * kWave), 0, st, P);
+  else if (store) hipLaunchKernelGGL((attn_fwd_self_kernel<false, true>), grid, dim3(kSfWaves * kWave), 0, st, P);
+  else hipLaunchKernelGGL((attn_fwd_self_kernel<false, false>), grid, dim3(kSfWaves * kWave), 0, st, P);
+  return VDETR_OK;
+}
+
+}  // namespace vdetr
