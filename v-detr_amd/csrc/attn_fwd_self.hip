@@ -4,7 +4,7 @@
 // attn_fwd.hip's body serves every kind (RPE, boxes, masks, ragged sizes, key splits); for the per-head kind its key-tile step had
 // grown to ~800 instructions for 256 scores — index clamps and 64-bit address products per tile, uniform branches on mask / score /
 // dropout switches that cut the scheduling regions, 44 accumulator-register spill moves — and the launch (256 workgroups of four waves,
-// one wave per SIMD) is bound by exactly that: 27 us alone, 34 in the step, the same with eight waves.  This kernel takes the case
+// one wave per SIMD) is bound by exactly that: 30 us alone (rocprofv3; dropout on, scores stored), 34 in the step, the same with eight waves.  This kernel takes the case
 // the model has — no mask, nQ a multiple of 16, nK a multiple of 128, no key split — with the same tiling, the same lane layouts,
 // the same exact-f32 products (v_mfma_f32_16x16x4_f32) and the same dropout counters, so it is interchangeable with the body
 // (fwd_kernel = 4 keeps the body: the parity tests compare the two), and differs in the bookkeeping only:
@@ -14,6 +14,7 @@
 //   * the (seed, offset, batch, head group, query) part of the dropout counter hashed once per row, one fmix32 per pair for heads
 //     0 / 1 of a group and two for heads 2 / 3 (the body hashed all four heads' values for every pair);
 //   * DROP / STORE as template parameters.
+// 19.6 us alone, 23.7 in the step (profiles/r06_eager_kernel_summary.txt); DESIGN.md 4.1b.
 #include "attn_common.h"
 #include "wave.h"
 
